@@ -1,0 +1,118 @@
+"""ctypes binding of libneumann_gpu.so (include/neumann_gpu.h).
+
+This is the same C ABI the Rust `vector_engine::ffi` module binds; Python only
+plays the role of the host language here because the image has no Rust toolchain.  Loading fails
+loudly when the library has not been built: there is no Python/CPU fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libneumann_gpu.so")
+
+OK = 0
+ERR_NOT_FOUND = -1
+ERR_DIMENSION_MISMATCH = -2
+ERR_EMPTY_VECTOR = -3
+ERR_INVALID_TOP_K = -4
+ERR_STORAGE = -5
+ERR_CONFIGURATION = -6
+ERR_COLLECTION_EXISTS = -7
+ERR_COLLECTION_NOT_FOUND = -8
+ERR_SEARCH_TIMEOUT = -9
+ERR_INVALID_ARGUMENT = -20
+ERR_NO_DEVICE = -21
+ERR_OUT_OF_MEMORY = -22
+ERR_TOP_K_TOO_LARGE = -23
+ERR_CAPACITY = -24
+ERR_BUFFER_TOO_SMALL = -25
+
+MAX_TOP_K = 4096
+MAX_QUERIES = 1024
+
+METRIC_COSINE, METRIC_EUCLIDEAN, METRIC_DOT_PRODUCT = 0, 1, 2
+
+f32p = C.POINTER(C.c_float)
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("flags", C.c_uint32), ("capacity_rows", C.c_uint64),
+                ("row_base", C.c_uint64), ("device", C.c_int32), ("cand_cap", C.c_uint32)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("rows_scanned", C.c_uint64), ("bytes_scanned", C.c_uint64),
+                ("candidates_rescored", C.c_uint32), ("fallback_queries", C.c_uint32),
+                ("scan_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+# name -> (restype, argtypes); one entry per declaration in include/neumann_gpu.h
+SIGNATURES = {
+    "nmn_device_count": (C.c_int32, [i32p]),
+    "nmn_status_str": (C.c_char_p, [C.c_int32]),
+    "nmn_last_error": (C.c_char_p, []),
+    "nmn_version": (C.c_char_p, []),
+    "nmn_index_create": (C.c_int32, [C.POINTER(IndexDesc), C.POINTER(vp)]),
+    "nmn_index_destroy": (C.c_int32, [vp]),
+    "nmn_index_upload": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64]),
+    "nmn_index_upload_device": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, vp]),
+    "nmn_index_set_rows": (C.c_int32, [vp, C.c_uint64]),
+    "nmn_index_rows": (C.c_uint64, [vp]),
+    "nmn_index_dim": (C.c_uint32, [vp]),
+    "nmn_index_row_base": (C.c_uint64, [vp]),
+    "nmn_index_corpus_device": (vp, [vp, u32p]),
+    "nmn_index_norms_device": (vp, [vp]),
+    "nmn_index_search": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp,
+                                     C.POINTER(SearchStats)]),
+    "nmn_index_search_device": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp, vp]),
+    "nmn_index_last_stats": (C.c_int32, [vp, vp, C.POINTER(SearchStats)]),
+    "nmn_index_set_timing": (C.c_int32, [vp, C.c_int32]),
+    "nmn_index_score_rows": (C.c_int32, [vp, vp, C.c_uint32, C.c_int32, vp, C.c_uint32, vp]),
+    "nmn_index_count_exact": (C.c_int32, [vp, vp, C.c_int32, vp, C.c_float, u64p, u64p]),
+    "nmn_merge_topk_host": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "nmn_merge_topk_device": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
+    "nmn_synth_value": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
+    "nmn_synth_fill_host": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "nmn_index_fill_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "nmn_index_set_row": (C.c_int32, [vp, C.c_uint64, vp]),
+}
+
+_lib = None
+
+
+class NeumannGpuError(RuntimeError):
+    """A non-zero nmn_status.  `.status` is the code, the message mirrors VectorError's Display."""
+
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = load().nmn_status_str(status).decode()
+        if detail:
+            msg = f"{msg}: {detail}"
+        super().__init__(msg)
+
+
+def load():
+    """Load the shared library (once).  Raises if it was not built — no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m neumann_amd.build` "
+                "(neumann_amd has no CPU fallback for the SIMILAR TOP-K path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        detail = load().nmn_last_error().decode(errors="replace")
+        raise NeumannGpuError(status, detail)

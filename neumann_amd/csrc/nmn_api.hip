@@ -1,0 +1,721 @@
+// nmn_api.hip — the C ABI of libneumann_gpu.so (declared in include/neumann_gpu.h): shard
+// lifecycle, upload, the SIMILAR TOP-K pipeline, shard merge, synthetic data.  Host code only; every
+// kernel lives in nmn_scan/nmn_select/nmn_exact/nmn_synth.hip.  No CPU compute path exists here:
+// without a HIP device every entry point fails with NMN_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "nmn_internal.h"
+
+using namespace nmn;
+
+namespace nmn {
+float synth_value_host(uint64_t seed, uint64_t row, uint32_t col);
+}
+
+static thread_local std::string g_last_error;
+
+static nmn_status fail_hip(hipError_t e, const char* what) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    g_last_error = buf;
+    (void)hipGetLastError();
+    if (e == hipErrorOutOfMemory) return NMN_ERR_OUT_OF_MEMORY;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+        return NMN_ERR_NO_DEVICE;
+    return NMN_ERR_STORAGE;
+}
+static nmn_status fail_arg(nmn_status code, const char* what) {
+    g_last_error = what;
+    return code;
+}
+
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return fail_hip(_e, #expr);    \
+    } while (0)
+
+// ---- workspace: everything one in-flight search on one stream needs ---------------------------
+struct Workspace {
+    hipStream_t stream = nullptr;
+    uint32_t nq_cap = 0;       // queries per pipeline pass the buffers are sized for
+    uint32_t cand_cap = 0;
+    uint64_t score_stride = 0;
+    uint32_t n_tiles_cap = 0;
+    uint32_t ld = 0;
+    uint32_t* scores = nullptr;
+    uint32_t* tmax = nullptr;
+    float* qpad = nullptr;
+    QInfo* qinfo = nullptr;
+    QState* qstate = nullptr;
+    uint32_t* cand_rows = nullptr;
+    float* cand_scores = nullptr;
+    // staging for the host-buffer API
+    float* h_queries = nullptr;  size_t h_queries_cap = 0;   // device copies of host inputs
+    uint64_t* h_mask = nullptr;  size_t h_mask_cap = 0;
+    uint64_t* h_out_rows = nullptr; float* h_out_scores = nullptr; uint32_t* h_out_counts = nullptr;
+    size_t h_out_rows_cap = 0, h_out_scores_cap = 0, h_cnt_cap = 0;
+    uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
+    float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
+    unsigned long long* h_counts2 = nullptr;
+    // timing + stats of the last search
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    uint32_t last_nq = 0;
+    uint64_t last_rows_scanned = 0;
+    bool last_masked = false;
+};
+
+struct nmn_index {
+    uint32_t dim = 0, ld = 0;
+    uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
+    int device = 0;
+    uint32_t cand_cap = kDefaultCandCap;
+    float* corpus = nullptr;
+    float* norms = nullptr;
+    uint32_t* max_norm_bits = nullptr;
+    hipStream_t host_stream = nullptr;
+    std::mutex mu;       // guards `ws` and the host-buffer API
+    std::unordered_map<hipStream_t, Workspace*> ws;
+    bool timing = false;
+};
+
+static void ws_free(Workspace* w) {
+    if (!w) return;
+    void* ptrs[] = {w->scores, w->tmax, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+                    w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
+                    w->h_counts2};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& e : w->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete w;
+}
+
+template <typename T>
+static hipError_t grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) {
+        hipError_t e = hipFree(*p);
+        *p = nullptr;
+        *cap = 0;
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(need, 1) * sizeof(T));
+    if (e == hipSuccess) *cap = need;
+    return e;
+}
+
+// queries per pipeline pass: bound the score matrix to ~4 GiB
+static uint32_t pass_queries(const nmn_index* idx, uint32_t nq) {
+    const uint64_t per_q = std::max<uint64_t>(idx->cap_pad, 64) * 4ull;
+    uint64_t m = (4ull << 30) / per_q;
+    m = std::max<uint64_t>(1, std::min<uint64_t>(m, 256));
+    return (uint32_t)std::min<uint64_t>(m, nq);
+}
+
+static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32_t k, Workspace** out) {
+    Workspace* w = nullptr;
+    auto it = idx->ws.find(stream);
+    if (it != idx->ws.end()) w = it->second;
+    uint32_t nqc = pass_queries(idx, nq);
+    uint32_t cand_cap = std::max<uint32_t>(std::min<uint32_t>(idx->cand_cap, NMN_MAX_TOP_K), k);
+    if (w && w->nq_cap >= nqc && w->cand_cap >= cand_cap) {
+        *out = w;
+        return NMN_OK;
+    }
+    if (w) {
+        // grow: drain the stream, keep the larger of old/new sizes so alternating callers do not thrash
+        HIP_TRY(hipStreamSynchronize(stream));
+        nqc = std::max(nqc, w->nq_cap);
+        cand_cap = std::max(cand_cap, w->cand_cap);
+        idx->ws.erase(stream);
+        ws_free(w);
+    }
+    w = new (std::nothrow) Workspace();
+    if (!w) return fail_arg(NMN_ERR_OUT_OF_MEMORY, "workspace alloc");
+    w->stream = stream;
+    w->nq_cap = nqc;
+    w->cand_cap = cand_cap;
+    idx->ws[stream] = w;
+    *out = w;
+    return NMN_OK;
+}
+
+static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
+    if (w->scores) return NMN_OK;
+    w->ld = idx->ld;
+    w->score_stride = idx->cap_pad;
+    w->n_tiles_cap = (uint32_t)(idx->cap_pad / kTileRows);
+    const size_t nq = w->nq_cap;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->scores), std::max<size_t>(nq * w->score_stride, 64) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tmax), std::max<size_t>(nq * w->n_tiles_cap, 1) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qpad), nq * w->ld * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo), nq * sizeof(QInfo)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_rows), nq * w->cand_cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->h_counts2), 2 * sizeof(unsigned long long)));
+    for (auto& e : w->ev) HIP_TRY(hipEventCreate(&e));
+    return NMN_OK;
+}
+
+// ---- basic entry points -----------------------------------------------------------------------
+extern "C" nmn_status nmn_device_count(int32_t* n) {
+    if (!n) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "n is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return NMN_OK;
+}
+
+extern "C" const char* nmn_status_str(nmn_status s) {
+    switch (s) {
+        case NMN_OK: return "ok";
+        case NMN_ERR_NOT_FOUND: return "Embedding not found";
+        case NMN_ERR_DIMENSION_MISMATCH: return "Dimension mismatch";
+        case NMN_ERR_EMPTY_VECTOR: return "Empty vector provided";
+        case NMN_ERR_INVALID_TOP_K: return "Invalid top_k value (must be > 0)";
+        case NMN_ERR_STORAGE: return "Storage error";
+        case NMN_ERR_CONFIGURATION: return "Configuration error";
+        case NMN_ERR_COLLECTION_EXISTS: return "Collection already exists";
+        case NMN_ERR_COLLECTION_NOT_FOUND: return "Collection not found";
+        case NMN_ERR_SEARCH_TIMEOUT: return "search timeout";
+        case NMN_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case NMN_ERR_NO_DEVICE: return "no usable HIP device (libneumann_gpu has no CPU fallback)";
+        case NMN_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case NMN_ERR_TOP_K_TOO_LARGE: return "top_k exceeds NMN_MAX_TOP_K";
+        case NMN_ERR_CAPACITY: return "upload exceeds index capacity";
+        case NMN_ERR_BUFFER_TOO_SMALL: return "buffer too small";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* nmn_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* nmn_version(void) { return "0.1.0"; }
+
+extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out) {
+    if (!d || !out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (d->dim == 0) return fail_arg(NMN_ERR_EMPTY_VECTOR, "dim == 0");
+    const uint32_t ld = (d->dim + 3u) & ~3u;
+    if ((uint64_t)ld * 4ull > 160ull * 1024ull)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "dim too large: one query must fit the 160 KiB LDS");
+    if (d->capacity_rows >= 0xFFFFFFC0ull)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "capacity_rows must be < 2^32 - 64 per shard");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail_arg(NMN_ERR_NO_DEVICE, "no HIP device");
+    }
+    int dev = d->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail_arg(NMN_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(dev));
+    nmn_index* idx = new (std::nothrow) nmn_index();
+    if (!idx) return fail_arg(NMN_ERR_OUT_OF_MEMORY, "index alloc");
+    idx->dim = d->dim;
+    idx->ld = ld;
+    idx->cap = d->capacity_rows;
+    idx->cap_pad = std::max<uint64_t>((d->capacity_rows + 63) & ~63ull, 64);
+    idx->row_base = d->row_base;
+    idx->device = dev;
+    idx->cand_cap = d->cand_cap ? d->cand_cap : kDefaultCandCap;
+    auto cleanup = [&](nmn_status st) {
+        if (idx->corpus) (void)hipFree(idx->corpus);
+        if (idx->norms) (void)hipFree(idx->norms);
+        if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
+        if (idx->host_stream) (void)hipStreamDestroy(idx->host_stream);
+        delete idx;
+        return st;
+    };
+    hipError_t e;
+    const size_t corpus_bytes = (size_t)idx->cap_pad * ld * sizeof(float);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&idx->corpus), corpus_bytes)) != hipSuccess)
+        return cleanup(fail_hip(e, "hipMalloc(corpus)"));
+    if ((e = hipMalloc(reinterpret_cast<void**>(&idx->norms), idx->cap_pad * sizeof(float))) != hipSuccess)
+        return cleanup(fail_hip(e, "hipMalloc(norms)"));
+    if ((e = hipMalloc(reinterpret_cast<void**>(&idx->max_norm_bits), 4)) != hipSuccess)
+        return cleanup(fail_hip(e, "hipMalloc(max_norm)"));
+    if ((e = hipStreamCreateWithFlags(&idx->host_stream, hipStreamNonBlocking)) != hipSuccess)
+        return cleanup(fail_hip(e, "hipStreamCreate"));
+    if ((e = hipMemsetAsync(idx->corpus, 0, corpus_bytes, idx->host_stream)) != hipSuccess ||
+        (e = hipMemsetAsync(idx->norms, 0, idx->cap_pad * sizeof(float), idx->host_stream)) != hipSuccess ||
+        (e = hipMemsetAsync(idx->max_norm_bits, 0, 4, idx->host_stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(idx->host_stream)) != hipSuccess)
+        return cleanup(fail_hip(e, "memset"));
+    *out = idx;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
+    if (!idx) return NMN_OK;
+    (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : idx->ws) ws_free(kv.second);
+    idx->ws.clear();
+    if (idx->corpus) (void)hipFree(idx->corpus);
+    if (idx->norms) (void)hipFree(idx->norms);
+    if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
+    if (idx->host_stream) (void)hipStreamDestroy(idx->host_stream);
+    delete idx;
+    return NMN_OK;
+}
+
+extern "C" uint64_t nmn_index_rows(const nmn_index* idx) { return idx ? idx->rows : 0; }
+extern "C" uint32_t nmn_index_dim(const nmn_index* idx) { return idx ? idx->dim : 0; }
+extern "C" uint64_t nmn_index_row_base(const nmn_index* idx) { return idx ? idx->row_base : 0; }
+extern "C" const float* nmn_index_corpus_device(const nmn_index* idx, uint32_t* ld_out) {
+    if (!idx) return nullptr;
+    if (ld_out) *ld_out = idx->ld;
+    return idx->corpus;
+}
+extern "C" const float* nmn_index_norms_device(const nmn_index* idx) { return idx ? idx->norms : nullptr; }
+
+extern "C" nmn_status nmn_index_set_rows(nmn_index* idx, uint64_t rows) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    if (rows > idx->cap) return fail_arg(NMN_ERR_CAPACITY, "rows > capacity");
+    idx->rows = rows;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    idx->timing = enabled != 0;
+    return NMN_OK;
+}
+
+static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_host, uint64_t row0, uint64_t n,
+                                hipStream_t stream) {
+    if (!idx || (!src && n)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (row0 > idx->rows) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "row0 leaves a gap (row0 > rows)");
+    if (row0 + n > idx->cap) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
+    if (n == 0) return NMN_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    float* dst = idx->corpus + row0 * (uint64_t)idx->ld;
+    const hipMemcpyKind kind = src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (idx->ld == idx->dim) {
+        HIP_TRY(hipMemcpyAsync(dst, src, n * (size_t)idx->dim * sizeof(float), kind, stream));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)idx->ld * sizeof(float), src, (size_t)idx->dim * sizeof(float),
+                                 (size_t)idx->dim * sizeof(float), n, kind, stream));
+    }
+    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
+    idx->rows = std::max(idx->rows, row0 + n);
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_upload(nmn_index* idx, const float* rows_host, uint64_t row0, uint64_t n) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    nmn_status st = upload_common(idx, rows_host, true, row0, n, idx->host_stream);
+    if (st != NMN_OK) return st;
+    HIP_TRY(hipStreamSynchronize(idx->host_stream));
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_upload_device(nmn_index* idx, const float* rows_dev, uint64_t row0, uint64_t n,
+                                              void* stream) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    return upload_common(idx, rows_dev, false, row0, n, static_cast<hipStream_t>(stream));
+}
+
+// ---- the search pipeline ------------------------------------------------------------------------
+static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* queries_dev, uint32_t nq, uint32_t k,
+                                 nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
+                                 float* out_scores, uint32_t* out_counts, hipStream_t stream) {
+    nmn_status st = ws_alloc(idx, w);
+    if (st != NMN_OK) return st;
+    const uint64_t n_rows = idx->rows;
+    const uint32_t n_tiles = (uint32_t)((n_rows + kTileRows - 1) / kTileRows);
+    w->timed = idx->timing;
+    w->last_nq = nq;
+    w->last_rows_scanned = n_rows;
+    w->last_masked = mask_dev != nullptr;
+    if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
+    for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
+        const uint32_t nqc = std::min(w->nq_cap, nq - qa);
+        HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
+                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, stream));
+        if (n_rows > 0) {
+            ScanParams sp{};
+            sp.corpus = idx->corpus;
+            sp.norms = idx->norms;
+            sp.qpad = w->qpad;
+            sp.qinfo = w->qinfo;
+            sp.mask = mask_dev;
+            sp.scores = w->scores;
+            sp.tmax = w->tmax;
+            sp.n_rows = n_rows;
+            sp.score_stride = w->score_stride;
+            sp.ld = idx->ld;
+            sp.n_tiles = n_tiles;
+            sp.nq = nqc;
+            // ~16 waves per CU; every wave gets the same number of tiles
+            const uint32_t target_waves = 4096;
+            sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + target_waves - 1) / target_waves);
+            sp.metric = (int)metric;
+            if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));
+            HIP_TRY(launch_scan(sp, stream));
+            if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
+
+            SelectParams sel{};
+            sel.scores = w->scores;
+            sel.tmax = w->tmax;
+            sel.qinfo = w->qinfo;
+            sel.qstate = w->qstate;
+            sel.cand_rows = w->cand_rows;
+            sel.n_rows = n_rows;
+            sel.score_stride = w->score_stride;
+            sel.n_tiles = n_tiles;
+            sel.nq = nqc;
+            sel.k = k;
+            sel.cand_cap = w->cand_cap;
+            // thresholds from tile maxima need at least ~2k tiles to be tight; small shards use all rows
+            sel.use_tiles = (n_tiles >= 2u * k && n_rows > 16384) ? 1 : 0;
+            HIP_TRY(launch_select(sel, stream));
+
+            // exact fallback: both kernels exit immediately unless a query overflowed its candidate list
+            ExactScanParams ex{};
+            ex.corpus = idx->corpus;
+            ex.norms = idx->norms;
+            ex.qpad = w->qpad;
+            ex.qinfo = w->qinfo;
+            ex.qstate = w->qstate;
+            ex.mask = mask_dev;
+            ex.scores = w->scores;
+            ex.n_rows = n_rows;
+            ex.score_stride = w->score_stride;
+            ex.ld = idx->ld;
+            ex.dim = idx->dim;
+            ex.nq = nqc;
+            ex.metric = (int)metric;
+            HIP_TRY(launch_exact_scan(ex, stream));
+            ExactSelectParams es{};
+            es.scores = w->scores;
+            es.qstate = w->qstate;
+            es.cand_rows = w->cand_rows;
+            es.n_rows = n_rows;
+            es.score_stride = w->score_stride;
+            es.nq = nqc;
+            es.k = k;
+            es.cand_cap = w->cand_cap;
+            HIP_TRY(launch_exact_select(es, stream));
+
+            RescoreParams rp{};
+            rp.corpus = idx->corpus;
+            rp.norms = idx->norms;
+            rp.qpad = w->qpad;
+            rp.qinfo = w->qinfo;
+            rp.qstate = w->qstate;
+            rp.cand_rows = w->cand_rows;
+            rp.cand_scores = w->cand_scores;
+            rp.ld = idx->ld;
+            rp.dim = idx->dim;
+            rp.nq = nqc;
+            rp.cand_cap = w->cand_cap;
+            rp.metric = (int)metric;
+            HIP_TRY(launch_rescore(rp, stream));
+        }
+        FinalParams fp{};
+        fp.cand_rows = w->cand_rows;
+        fp.cand_scores = w->cand_scores;
+        fp.qstate = w->qstate;
+        fp.row_base = idx->row_base;
+        fp.nq = nqc;
+        fp.k = k;
+        fp.cand_cap = w->cand_cap;
+        fp.out_rows = out_rows + (size_t)qa * k;
+        fp.out_scores = out_scores + (size_t)qa * k;
+        fp.out_counts = out_counts + qa;
+        HIP_TRY(launch_final(fp, stream));
+    }
+    if (w->timed) HIP_TRY(hipEventRecord(w->ev[3], stream));
+    return NMN_OK;
+}
+
+static nmn_status check_search_args(const nmn_index* idx, const void* queries, uint32_t nq, uint32_t k,
+                                    nmn_metric metric, const void* out_rows, const void* out_scores,
+                                    const void* out_counts) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    if (k == 0) return fail_arg(NMN_ERR_INVALID_TOP_K, "k == 0");
+    if (k > NMN_MAX_TOP_K) return fail_arg(NMN_ERR_TOP_K_TOO_LARGE, "k > NMN_MAX_TOP_K");
+    if (nq == 0 || nq > NMN_MAX_QUERIES) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
+    if (!queries || !out_rows || !out_scores || !out_counts)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null buffer");
+    if ((int)metric < 0 || (int)metric > 2) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "bad metric");
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k,
+                                              nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows_dev,
+                                              float* out_scores_dev, uint32_t* out_counts_dev, void* stream) {
+    nmn_status st = check_search_args(idx, queries_dev, nq, k, metric, out_rows_dev, out_scores_dev, out_counts_dev);
+    if (st != NMN_OK) return st;
+    HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> g(idx->mu);
+    Workspace* w = nullptr;
+    st = ws_get(idx, s, nq, k, &w);
+    if (st != NMN_OK) return st;
+    return search_enqueue(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows_dev, out_scores_dev,
+                          out_counts_dev, s);
+}
+
+static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* stats) {
+    if (!stats) return NMN_OK;
+    memset(stats, 0, sizeof *stats);
+    stats->scan_ms = -1.f;
+    stats->total_ms = -1.f;
+    if (!w || !w->qstate) return NMN_OK;
+    const uint32_t nqc = std::min(w->last_nq, w->nq_cap);
+    std::vector<QState> qs(nqc);
+    if (nqc) HIP_TRY(hipMemcpy(qs.data(), w->qstate, nqc * sizeof(QState), hipMemcpyDeviceToHost));
+    for (auto& q : qs) {
+        stats->candidates_rescored = std::max(stats->candidates_rescored, q.cand_count);
+        stats->fallback_queries += q.overflow ? 1 : 0;
+    }
+    stats->rows_scanned = w->last_rows_scanned;  // upper bound when masked (excluded rows are skipped)
+    stats->bytes_scanned = w->last_rows_scanned * (uint64_t)idx->dim * 4ull;
+    if (w->timed) {
+        float a = 0.f, b = 0.f;
+        if (w->last_rows_scanned && hipEventElapsedTime(&a, w->ev[1], w->ev[2]) == hipSuccess) stats->scan_ms = a;
+        if (hipEventElapsedTime(&b, w->ev[0], w->ev[3]) == hipSuccess) stats->total_ms = b;
+        (void)hipGetLastError();
+    }
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_search_stats* stats) {
+    if (!idx || !stats) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipStreamSynchronize(s));
+    std::lock_guard<std::mutex> g(idx->mu);
+    auto it = idx->ws.find(s);
+    return stats_collect(idx, it == idx->ws.end() ? nullptr : it->second, stats);
+}
+
+extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                       nmn_metric metric, const uint64_t* mask, uint64_t* out_rows,
+                                       float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
+    nmn_status st = check_search_args(idx, queries, nq, k, metric, out_rows, out_scores, out_counts);
+    if (st != NMN_OK) return st;
+    HIP_TRY(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->mu);
+    hipStream_t s = idx->host_stream;
+    Workspace* w = nullptr;
+    st = ws_get(idx, s, nq, k, &w);
+    if (st != NMN_OK) return st;
+    const size_t qn = (size_t)nq * idx->dim, on = (size_t)nq * k;
+    const size_t words = (size_t)((idx->rows + 63) / 64);
+    HIP_TRY(grow(&w->h_queries, &w->h_queries_cap, qn));
+    HIP_TRY(grow(&w->h_out_rows, &w->h_out_rows_cap, on));
+    HIP_TRY(grow(&w->h_out_scores, &w->h_out_scores_cap, on));
+    HIP_TRY(grow(&w->h_out_counts, &w->h_cnt_cap, (size_t)nq));
+    HIP_TRY(hipMemcpyAsync(w->h_queries, queries, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    const uint64_t* mask_dev = nullptr;
+    if (mask && words) {
+        HIP_TRY(grow(&w->h_mask, &w->h_mask_cap, words));
+        HIP_TRY(hipMemcpyAsync(w->h_mask, mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        mask_dev = w->h_mask;
+    }
+    st = search_enqueue(idx, w, w->h_queries, nq, k, metric, mask_dev, w->h_out_rows, w->h_out_scores,
+                        w->h_out_counts, s);
+    if (st != NMN_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out_rows, w->h_out_rows, on * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_scores, w->h_out_scores, on * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_counts, w->h_out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return stats_collect(idx, w, stats);
+}
+
+// ---- exact helpers ------------------------------------------------------------------------------
+extern "C" nmn_status nmn_index_score_rows(nmn_index* idx, const float* queries, uint32_t nq, nmn_metric metric,
+                                           const uint64_t* local_rows, uint32_t n_rows, float* out_scores) {
+    if (!idx || !queries || !local_rows || !out_scores) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (nq == 0 || n_rows == 0) return NMN_OK;
+    if (nq > NMN_MAX_QUERIES) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
+    for (uint32_t i = 0; i < n_rows; i++)
+        if (local_rows[i] >= idx->rows) return fail_arg(NMN_ERR_NOT_FOUND, "row out of range");
+    HIP_TRY(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->mu);
+    hipStream_t s = idx->host_stream;
+    // private small buffers: nq may exceed the per-pass query count of the search workspace
+    float *dq = nullptr, *dqpad = nullptr, *dout = nullptr;
+    QInfo* dqi = nullptr;
+    QState* dqs = nullptr;
+    uint64_t* drows = nullptr;
+    auto done = [&](nmn_status st) {
+        for (void* p : {(void*)dq, (void*)dqpad, (void*)dout, (void*)dqi, (void*)dqs, (void*)drows})
+            if (p) (void)hipFree(p);
+        return st;
+    };
+    hipError_t e;
+#define TRY2(x) if ((e = (x)) != hipSuccess) return done(fail_hip(e, #x))
+    TRY2(hipMalloc(reinterpret_cast<void**>(&dq), (size_t)nq * idx->dim * 4));
+    TRY2(hipMalloc(reinterpret_cast<void**>(&dqpad), (size_t)nq * idx->ld * 4));
+    TRY2(hipMalloc(reinterpret_cast<void**>(&dout), (size_t)nq * n_rows * 4));
+    TRY2(hipMalloc(reinterpret_cast<void**>(&dqi), (size_t)nq * sizeof(QInfo)));
+    TRY2(hipMalloc(reinterpret_cast<void**>(&dqs), (size_t)nq * sizeof(QState)));
+    TRY2(hipMalloc(reinterpret_cast<void**>(&drows), (size_t)n_rows * 8));
+    TRY2(hipMemcpyAsync(dq, queries, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
+    TRY2(hipMemcpyAsync(drows, local_rows, (size_t)n_rows * 8, hipMemcpyHostToDevice, s));
+    TRY2(launch_qprep(dq, nq, idx->dim, idx->ld, (int)metric, idx->max_norm_bits, dqpad, dqi, dqs, s));
+    TRY2(launch_score_rows(idx->corpus, idx->norms, dqpad, dqi, drows, n_rows, nq, idx->ld, idx->dim, (int)metric,
+                           dout, s));
+    TRY2(hipMemcpyAsync(out_scores, dout, (size_t)nq * n_rows * 4, hipMemcpyDeviceToHost, s));
+    TRY2(hipStreamSynchronize(s));
+#undef TRY2
+    return done(NMN_OK);
+}
+
+extern "C" nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, nmn_metric metric,
+                                            const uint64_t* mask, float score, uint64_t* n_greater,
+                                            uint64_t* n_equal) {
+    if (!idx || !query || !n_greater || !n_equal) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->mu);
+    hipStream_t s = idx->host_stream;
+    Workspace* w = nullptr;
+    nmn_status st = ws_get(idx, s, 1, 1, &w);
+    if (st != NMN_OK) return st;
+    st = ws_alloc(idx, w);
+    if (st != NMN_OK) return st;
+    HIP_TRY(grow(&w->h_queries, &w->h_queries_cap, (size_t)idx->dim));
+    HIP_TRY(hipMemcpyAsync(w->h_queries, query, (size_t)idx->dim * 4, hipMemcpyHostToDevice, s));
+    const size_t words = (size_t)((idx->rows + 63) / 64);
+    const uint64_t* mask_dev = nullptr;
+    if (mask && words) {
+        HIP_TRY(grow(&w->h_mask, &w->h_mask_cap, words));
+        HIP_TRY(hipMemcpyAsync(w->h_mask, mask, words * 8, hipMemcpyHostToDevice, s));
+        mask_dev = w->h_mask;
+    }
+    HIP_TRY(launch_qprep(w->h_queries, 1, idx->dim, idx->ld, (int)metric, idx->max_norm_bits, w->qpad, w->qinfo,
+                         w->qstate, s));
+    ExactScanParams ex{};
+    ex.corpus = idx->corpus;
+    ex.norms = idx->norms;
+    ex.qpad = w->qpad;
+    ex.qinfo = w->qinfo;
+    ex.qstate = nullptr;
+    ex.mask = mask_dev;
+    ex.scores = w->scores;
+    ex.n_rows = idx->rows;
+    ex.score_stride = w->score_stride;
+    ex.ld = idx->ld;
+    ex.dim = idx->dim;
+    ex.nq = 1;
+    ex.metric = (int)metric;
+    HIP_TRY(launch_exact_scan(ex, s));
+    HIP_TRY(hipMemsetAsync(w->h_counts2, 0, 16, s));
+    HIP_TRY(launch_count_cmp(w->scores, idx->rows, score, w->h_counts2, s));
+    unsigned long long host2[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host2, w->h_counts2, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *n_greater = host2[0];
+    *n_equal = host2[1];
+    return NMN_OK;
+}
+
+// ---- shard merge --------------------------------------------------------------------------------
+extern "C" nmn_status nmn_merge_topk_host(const uint64_t* rows, const float* scores, const uint32_t* counts,
+                                          uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* out_rows,
+                                          float* out_scores, uint32_t* out_counts) {
+    if (!rows || !scores || !counts || !out_rows || !out_scores || !out_counts)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (k == 0) return fail_arg(NMN_ERR_INVALID_TOP_K, "k == 0");
+    struct Hit {
+        uint32_t key;
+        uint64_t row;
+        float score;
+    };
+    std::vector<Hit> all;
+    all.reserve((size_t)n_lists * k);
+    for (uint32_t q = 0; q < nq; q++) {
+        all.clear();
+        for (uint32_t l = 0; l < n_lists; l++) {
+            const uint32_t c = std::min(counts[(size_t)l * nq + q], k);
+            const size_t base = ((size_t)l * nq + q) * k;
+            for (uint32_t i = 0; i < c; i++) all.push_back({score_to_key(scores[base + i]), rows[base + i], scores[base + i]});
+        }
+        // merge_top_k: sort by score descending (distributed.rs:424-429); ties by ascending row
+        std::sort(all.begin(), all.end(), [](const Hit& a, const Hit& b) {
+            return a.key > b.key || (a.key == b.key && a.row < b.row);
+        });
+        const uint32_t cnt = (uint32_t)std::min<size_t>(all.size(), k);
+        for (uint32_t i = 0; i < k; i++) {
+            out_rows[(size_t)q * k + i] = i < cnt ? all[i].row : UINT64_MAX;
+            out_scores[(size_t)q * k + i] = i < cnt ? all[i].score : -INFINITY;
+        }
+        out_counts[q] = cnt;
+    }
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_merge_topk_device(const uint64_t* rows_dev, const float* scores_dev,
+                                            const uint32_t* counts_dev, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                            uint64_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev,
+                                            void* stream) {
+    if (!rows_dev || !scores_dev || !counts_dev || !out_rows_dev || !out_scores_dev || !out_counts_dev)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (k == 0) return fail_arg(NMN_ERR_INVALID_TOP_K, "k == 0");
+    if (nq == 0 || n_lists == 0) return NMN_OK;
+    HIP_TRY(launch_merge(rows_dev, scores_dev, counts_dev, n_lists, nq, k, out_rows_dev, out_scores_dev,
+                         out_counts_dev, static_cast<hipStream_t>(stream)));
+    return NMN_OK;
+}
+
+// ---- synthetic data -----------------------------------------------------------------------------
+extern "C" float nmn_synth_value(uint64_t seed, uint64_t row, uint32_t col) {
+    return nmn::synth_value_host(seed, row, col);
+}
+
+extern "C" nmn_status nmn_synth_fill_host(float* out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim) {
+    if (!out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint64_t i = 0; i < n; i++)
+        for (uint32_t c = 0; c < dim; c++) out[i * dim + c] = nmn::synth_value_host(seed, row0 + i, c);
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, uint64_t row0, uint64_t n) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    if (row0 > idx->rows) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "row0 leaves a gap (row0 > rows)");
+    if (row0 + n > idx->cap) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
+    if (n == 0) return NMN_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->mu);
+    hipStream_t s = idx->host_stream;
+    HIP_TRY(launch_synth_fill(idx->corpus, idx->ld, idx->dim, seed, idx->row_base + row0, row0, n, s));
+    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    idx->rows = std::max(idx->rows, row0 + n);
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const float* vec_host) {
+    if (!idx || !vec_host) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (row >= idx->rows) return fail_arg(NMN_ERR_NOT_FOUND, "row out of range");
+    HIP_TRY(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->mu);
+    hipStream_t s = idx->host_stream;
+    HIP_TRY(hipMemcpyAsync(idx->corpus + row * (uint64_t)idx->ld, vec_host, (size_t)idx->dim * 4,
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return NMN_OK;
+}

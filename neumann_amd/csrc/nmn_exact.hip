@@ -1,0 +1,223 @@
+// nmn_exact.hip — kernels that restate the reference's f32 arithmetic BIT FOR BIT on the GPU.
+// THIS TRANSLATION UNIT IS BUILT WITH -ffp-contract=off (build.py) and carries a file-scope
+// `#pragma clang fp contract(off)`; tests/test_build.py greps its ISA for v_fma/v_mad: hipcc contracts a*b+c into v_fma by default, and HIP's
+// __fmul_rn/__fadd_rn are plain operators that contraction would fuse.
+//
+// Reference order (tensor_store/src/hnsw.rs:168-229, vector_engine/src/lib.rs:2231-2266):
+//   dot8 / sumsq8 : 8 accumulators, acc[l] = acc[l] + (a[8c+l]*b[8c+l]) for c = 0..d/8-1 (mul and
+//                   add rounded separately), r = ((((((((-0+acc0)+acc1)+...)+acc7), then the scalar
+//                   tail r = r + a[i]*b[i].
+//   euclidean     : strictly sequential s = s + (x-y)*(x-y), sqrt.
+//   cosine        : dot / (|q| * |v|), 0 if either magnitude is 0;  euclid score 1/(1+dist).
+// Work split: 8 consecutive threads own one (query,row) pair, thread l runs accumulator lane l's
+// dependent chain; the 8 partial sums are then added left to right by every thread of the group
+// (shuffles inside the 8-lane group), so no reassociation ever happens.
+#include "nmn_internal.h"
+
+// Belt and braces: even if a build forgets -ffp-contract=off, nothing below may be contracted.
+#pragma clang fp contract(off)
+
+namespace nmn {
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+
+// lane-l chain of dot8 followed by the in-order lane sum and the scalar tail.
+// `l` = threadIdx & 7; all 8 threads of the group return the same value.
+__device__ __forceinline__ float dot8_group(const float* __restrict__ a, const float* __restrict__ b,
+                                            uint32_t dim, uint32_t l) {
+    const uint32_t chunks = dim >> 3;
+    float acc = 0.0f;
+    for (uint32_t c = 0; c < chunks; c++) {
+        const float pr = mul_rn(a[8u * c + l], b[8u * c + l]);
+        acc = add_rn(acc, pr);
+    }
+    float r = -0.0f;
+    const int base = (int)(threadIdx.x & 63u & ~7u);
+#pragma unroll
+    for (int t = 0; t < 8; t++) r = add_rn(r, __shfl(acc, base + t));
+    for (uint32_t i = chunks * 8u; i < dim; i++) r = add_rn(r, mul_rn(a[i], b[i]));
+    return r;
+}
+
+__device__ __forceinline__ float euclid_seq(const float* __restrict__ q, const float* __restrict__ v,
+                                            uint32_t dim) {
+    float s = -0.0f;
+    for (uint32_t i = 0; i < dim; i++) {
+        const float d = sub_rn(q[i], v[i]);
+        s = add_rn(s, mul_rn(d, d));
+    }
+    return __fsqrt_rn(s);
+}
+
+// compute_score (lib.rs:2231-2266) for one (query,row); vmag = stored simd::magnitude(row).
+__device__ __forceinline__ float exact_score(const float* __restrict__ q, const float* __restrict__ v,
+                                             uint32_t dim, float qmag, float vmag, int metric, uint32_t l) {
+    if (metric == NMN_METRIC_EUCLIDEAN) {
+        const float dist = euclid_seq(q, v, dim);  // every thread of the group walks it; loads hit L1
+        return __fdiv_rn(1.0f, add_rn(1.0f, dist));
+    }
+    const float dot = dot8_group(q, v, dim, l);
+    if (metric == NMN_METRIC_DOT_PRODUCT) return dot;
+    if (qmag == 0.0f || vmag == 0.0f) return 0.0f;
+    return __fdiv_rn(dot, mul_rn(qmag, vmag));
+}
+
+// ---- |v| for uploaded rows -------------------------------------------------------------------
+__global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ corpus, uint32_t ld, uint32_t dim,
+                                                    uint64_t row0, uint64_t n, float* __restrict__ norms,
+                                                    uint32_t* __restrict__ max_norm_bits) {
+    const uint32_t l = threadIdx.x & 7u;
+    const uint64_t i = (uint64_t)blockIdx.x * 32u + (threadIdx.x >> 3);
+    const uint64_t row = row0 + (i < n ? i : n - 1);  // keep the whole 8-group converged for the shuffles
+    const float* v = corpus + row * (uint64_t)ld;
+    const float ss = dot8_group(v, v, dim, l);
+    const float mag = __fsqrt_rn(ss);
+    if (i < n && l == 0) {
+        norms[row] = mag;
+        if (mag == mag) atomicMax(max_norm_bits, f2u(mag));  // mag >= 0: bit order == value order
+    }
+}
+
+hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,
+                        uint32_t* max_norm_bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 31) / 32;
+    hipLaunchKernelGGL(norms_kernel, dim3((unsigned)blocks), dim3(256), 0, s, corpus, ld, dim, row0, n, norms,
+                       max_norm_bits);
+    return hipGetLastError();
+}
+
+// ---- query preparation -----------------------------------------------------------------------
+// One block of 64 threads per query: zero-padded copy, |q| in reference order, error margins of the
+// approximate scan, reset of the per-query selection state.
+__global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ queries, uint32_t dim, uint32_t ld,
+                                                   int metric, const uint32_t* __restrict__ max_norm_bits,
+                                                   float* __restrict__ qpad, QInfo* __restrict__ qinfo,
+                                                   QState* __restrict__ qstate) {
+    const uint32_t q = blockIdx.x;
+    const float* src = queries + (size_t)q * dim;
+    float* dst = qpad + (size_t)q * ld;
+    for (uint32_t i = threadIdx.x; i < ld; i += 64) dst[i] = i < dim ? src[i] : 0.0f;
+    const float ss = dot8_group(src, src, dim, threadIdx.x & 7u);
+    if (threadIdx.x == 0) {
+        const float qmag = __fsqrt_rn(ss);
+        const float u = 5.9604645e-08f;  // 2^-24
+        const float dd = (float)dim;
+        QInfo qi;
+        qi.qmag = qmag;
+        qi.pad = 0.f;
+        if (metric == NMN_METRIC_COSINE) {
+            qi.margin_abs = 3.0f * (dd + 10.0f) * u;
+            qi.margin_rel = 0.0f;
+        } else if (metric == NMN_METRIC_DOT_PRODUCT) {
+            const float mx = u2f(*max_norm_bits);
+            qi.margin_abs = 3.0f * (dd + 10.0f) * u * qmag * mx;
+            qi.margin_rel = 8.0f * u;
+        } else {
+            qi.margin_abs = 0.0f;
+            qi.margin_rel = 4.0f * (dd + 8.0f) * u;
+        }
+        qinfo[q] = qi;
+        QState st;
+        st.cand_count = 0;
+        st.overflow = 0;
+        st.n_valid = 0;
+        st.thr_key = 0;
+        qstate[q] = st;
+    }
+}
+
+hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
+                        const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, hipStream_t s) {
+    hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), 0, s, queries, dim, ld, metric, max_norm_bits, qpad,
+                       qinfo, qstate);
+    return hipGetLastError();
+}
+
+// ---- exact rescore of the candidate lists ----------------------------------------------------
+__global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t l = threadIdx.x & 7u;
+    const uint32_t count = min(p.qstate[q].cand_count, p.cand_cap);
+    const uint32_t c = blockIdx.x * 32u + (threadIdx.x >> 3);
+    if (blockIdx.x * 32u >= count) return;  // whole block idle
+    const uint32_t cc = c < count ? c : count - 1;
+    const uint32_t row = p.cand_rows[(size_t)q * p.cand_cap + cc];
+    const float* v = p.corpus + (uint64_t)row * p.ld;
+    const float* qv = p.qpad + (size_t)q * p.ld;
+    const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+    const float sc = exact_score(qv, v, p.dim, p.qinfo[q].qmag, vmag, p.metric, l);
+    if (c < count && l == 0) p.cand_scores[(size_t)q * p.cand_cap + c] = sc;
+}
+
+hipError_t launch_rescore(const RescoreParams& p, hipStream_t s) {
+    dim3 grid((p.cand_cap + 31) / 32, p.nq);
+    hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- exact score of explicit rows ------------------------------------------------------------
+__global__ void __launch_bounds__(256) score_rows_kernel(const float* __restrict__ corpus,
+                                                         const float* __restrict__ norms,
+                                                         const float* __restrict__ qpad,
+                                                         const QInfo* __restrict__ qinfo,
+                                                         const uint64_t* __restrict__ rows, uint32_t n_rows,
+                                                         uint32_t ld, uint32_t dim, int metric,
+                                                         float* __restrict__ out) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t l = threadIdx.x & 7u;
+    const uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3);
+    const uint32_t ii = i < n_rows ? i : n_rows - 1;
+    const uint64_t row = rows[ii];
+    const float* v = corpus + row * (uint64_t)ld;
+    const float vmag = metric == NMN_METRIC_COSINE ? norms[row] : 1.0f;
+    const float sc = exact_score(qpad + (size_t)q * ld, v, dim, qinfo[q].qmag, vmag, metric, l);
+    if (i < n_rows && l == 0) out[(size_t)q * n_rows + i] = sc;
+}
+
+hipError_t launch_score_rows(const float* corpus, const float* norms, const float* qpad, const QInfo* qinfo,
+                             const uint64_t* rows, uint32_t n_rows, uint32_t nq, uint32_t ld, uint32_t dim,
+                             int metric, float* out, hipStream_t s) {
+    if (n_rows == 0 || nq == 0) return hipSuccess;
+    dim3 grid((n_rows + 31) / 32, nq);
+    hipLaunchKernelGGL(score_rows_kernel, grid, dim3(256), 0, s, corpus, norms, qpad, qinfo, rows, n_rows, ld, dim,
+                       metric, out);
+    return hipGetLastError();
+}
+
+// ---- exact scan of every row (fallback path and the count certificate) ------------------------
+// Grid-stride over groups of 32 rows; only queries flagged `overflow` are processed when qstate is
+// given, so on the normal path this launch costs one early-exit wave per block.
+__global__ void __launch_bounds__(256) exact_scan_kernel(ExactScanParams p) {
+    const uint32_t q = blockIdx.y;
+    if (p.qstate && p.qstate[q].overflow == 0) return;
+    const uint32_t l = threadIdx.x & 7u;
+    const float* qv = p.qpad + (size_t)q * p.ld;
+    const float qmag = p.qinfo[q].qmag;
+    const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
+    for (uint64_t base = (uint64_t)blockIdx.x * 32u; base < n_pad; base += (uint64_t)gridDim.x * 32u) {
+        const uint64_t row = base + (threadIdx.x >> 3);
+        bool valid = row < p.n_rows;
+        if (valid && p.mask) valid = ((p.mask[row >> 6] >> (row & 63)) & 1ull) != 0;
+        // the 8-lane group shares `row`, hence `valid`: the branch is uniform per group
+        uint32_t bits = kScoreSentinelBits;
+        if (valid) {
+            const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+            bits = f2u(exact_score(qv, p.corpus + row * (uint64_t)p.ld, p.dim, qmag, vmag, p.metric, l));
+        }
+        if (l == 0 && row < n_pad) p.scores[(uint64_t)q * p.score_stride + row] = bits;
+    }
+}
+
+hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s) {
+    if (p.n_rows == 0) return hipSuccess;
+    uint64_t blocks = (p.n_rows + 31) / 32;
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid((unsigned)blocks, p.nq);
+    hipLaunchKernelGGL(exact_scan_kernel, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace nmn

@@ -1,0 +1,167 @@
+// nmn_internal.h — shared declarations of libneumann_gpu.so (gfx950 only).
+//
+// Pipeline of one SIMILAR TOP-K call:
+//   qprep    pad queries, |q| in reference order, per-query error margins          (nmn_exact.hip)
+//   scan     stream the row-major f32 corpus once: approximate score per row +
+//            per-64-row tile maximum                                                (nmn_scan.hip)
+//   select   per query: 2-pass radix pick of a lower bound on the k-th best score,
+//            collect every row within the rounding margin of it                    (nmn_select.hip)
+//   [exact fallback: only for queries whose candidate list overflowed]             (nmn_exact.hip)
+//   rescore  candidates re-scored bit-exactly in the reference's operation order   (nmn_exact.hip)
+//   final    sort candidates by (exact score desc, row asc), emit top-k            (nmn_select.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/neumann_gpu.h"
+
+namespace nmn {
+
+constexpr uint32_t kTileRows = 64;        // rows per scan tile (one wave, 16 steps of 4 rows)
+constexpr uint32_t kDefaultCandCap = 4096;
+constexpr uint32_t kKeyMasked = 0u;       // row does not take part (mask / beyond n_rows)
+constexpr uint32_t kKeyNaN = 1u;          // NaN score: ranks below -inf
+constexpr uint32_t kScoreSentinelBits = 0xFFFFFFFFu;  // scores[] entry of a non-participating row
+
+// Per-query constants produced by qprep.
+struct QInfo {
+    float qmag;        // simd::magnitude(query), reference order
+    float margin_abs;  // candidates: approx >= tau - margin_abs - |tau|*margin_rel
+    float margin_rel;
+    float pad;
+};
+
+// Per-query selection state shared by select / fallback / rescore / final.
+struct QState {
+    uint32_t cand_count;  // candidates written to cand_rows
+    uint32_t overflow;    // 1 = candidate list overflowed -> exact fallback takes over
+    uint32_t n_valid;     // participating keys seen by select (rows or tiles)
+    uint32_t thr_key;     // collection threshold key (diagnostics)
+};
+
+// ---- score <-> order-preserving u32 key -----------------------------------------------------
+// key order == score order for non-NaN scores; -0.0 and +0.0 map to one key (they compare equal,
+// so ties between them must fall through to the row-id tie-break).
+__host__ __device__ inline uint32_t f2u(float f) {
+    union { float f; uint32_t u; } v; v.f = f; return v.u;
+}
+__host__ __device__ inline float u2f(uint32_t u) {
+    union { float f; uint32_t u; } v; v.u = u; return v.f;
+}
+__host__ __device__ inline uint32_t score_to_key(float s) {
+    if (s != s) return kKeyNaN;
+    uint32_t b = f2u(s);
+    if ((b << 1) == 0u) b = 0u;  // -0.0 -> +0.0
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float key_to_score(uint32_t k) {
+    if (k <= kKeyNaN) return u2f(0x7FC00000u);
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return u2f(b);
+}
+__host__ __device__ inline uint32_t bits_to_key(uint32_t score_bits) {  // scores[] entry -> key
+    return score_bits == kScoreSentinelBits ? kKeyMasked : score_to_key(u2f(score_bits));
+}
+constexpr uint32_t kKeyNegInf = 0x007FFFFFu;  // score_to_key(-inf)
+
+// ---- kernel launchers (each defined in the .hip file named above) ---------------------------
+struct ScanParams {
+    const float* corpus;     // [rows][ld]
+    const float* norms;      // [rows]
+    const float* qpad;       // [nq][ld] zero padded
+    const QInfo* qinfo;      // [nq]
+    const uint64_t* mask;    // nullable, ceil(rows/64) words
+    uint32_t* scores;        // [nq][score_stride] f32 bits (sentinel for non-participating rows)
+    uint32_t* tmax;          // [nq][n_tiles] tile maximum key (0 = empty tile)
+    uint64_t n_rows;
+    uint64_t score_stride;
+    uint32_t ld;             // floats per row, multiple of 4
+    uint32_t n_tiles;
+    uint32_t nq;
+    uint32_t tiles_per_wave;
+    int metric;
+};
+hipError_t launch_scan(const ScanParams& p, hipStream_t s);
+
+struct SelectParams {
+    const uint32_t* scores;  // [nq][score_stride]
+    const uint32_t* tmax;    // [nq][n_tiles]
+    const QInfo* qinfo;
+    QState* qstate;
+    uint32_t* cand_rows;     // [nq][cand_cap]
+    uint64_t n_rows;
+    uint64_t score_stride;
+    uint32_t n_tiles;
+    uint32_t nq;
+    uint32_t k;
+    uint32_t cand_cap;
+    int use_tiles;           // 1: threshold from tile maxima, 0: from all scores
+};
+hipError_t launch_select(const SelectParams& p, hipStream_t s);
+
+struct FinalParams {
+    const uint32_t* cand_rows;   // [nq][cand_cap]
+    const float* cand_scores;    // [nq][cand_cap] exact
+    const QState* qstate;
+    uint64_t row_base;
+    uint32_t nq, k, cand_cap;
+    uint64_t* out_rows;          // [nq][k]
+    float* out_scores;
+    uint32_t* out_counts;
+};
+hipError_t launch_final(const FinalParams& p, hipStream_t s);
+
+hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_t* counts, uint32_t n_lists,
+                        uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                        hipStream_t s);
+
+// exact (reference-order) kernels
+hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,
+                        uint32_t* max_norm_bits, hipStream_t s);
+hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
+                        const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, hipStream_t s);
+struct RescoreParams {
+    const float* corpus;
+    const float* norms;
+    const float* qpad;
+    const QInfo* qinfo;
+    const QState* qstate;
+    const uint32_t* cand_rows;
+    float* cand_scores;
+    uint32_t ld, dim, nq, cand_cap;
+    int metric;
+};
+hipError_t launch_rescore(const RescoreParams& p, hipStream_t s);
+// exact score of explicit (query,row) pairs: out[q][i] = score(q, rows[i])
+hipError_t launch_score_rows(const float* corpus, const float* norms, const float* qpad, const QInfo* qinfo,
+                             const uint64_t* rows, uint32_t n_rows, uint32_t nq, uint32_t ld, uint32_t dim,
+                             int metric, float* out, hipStream_t s);
+struct ExactScanParams {
+    const float* corpus;
+    const float* norms;
+    const float* qpad;
+    const QInfo* qinfo;
+    const QState* qstate;    // nullable; when set only queries with overflow==1 are processed
+    const uint64_t* mask;
+    uint32_t* scores;
+    uint64_t n_rows, score_stride;
+    uint32_t ld, dim, nq;
+    int metric;
+};
+hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s);
+struct ExactSelectParams {
+    const uint32_t* scores;
+    QState* qstate;
+    uint32_t* cand_rows;
+    uint64_t n_rows, score_stride;
+    uint32_t nq, k, cand_cap;
+};
+hipError_t launch_exact_select(const ExactSelectParams& p, hipStream_t s);
+hipError_t launch_count_cmp(const uint32_t* scores, uint64_t n_rows, float score, unsigned long long* out2,
+                            hipStream_t s);
+
+// synthetic data
+hipError_t launch_synth_fill(float* corpus, uint32_t ld, uint32_t dim, uint64_t seed, uint64_t global_row0,
+                             uint64_t local_row0, uint64_t n, hipStream_t s);
+
+}  // namespace nmn

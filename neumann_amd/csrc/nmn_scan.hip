@@ -1,0 +1,231 @@
+// nmn_scan.hip — the HBM-bound kernel of the SIMILAR TOP-K path: one streaming pass over the
+// row-major f32 corpus producing an APPROXIMATE score per row (any summation order, FMA allowed)
+// plus the maximum score key of every 64-row tile.  Exactness is restored later by nmn_exact.hip.
+//
+// Replaces the per-key hot loop of the reference (vector_engine/src/lib.rs:2115-2228: store.get ->
+// extract_vector -> compute_score per key) with one resident-matrix sweep.
+//
+// Mapping (wave64, CDNA4): a wave owns whole 64-row tiles.  Inside a tile it takes 16 steps of 4
+// rows; in a step each 16-lane DPP row of the wave reads ONE corpus row with 16-byte loads (lane j
+// reads float4 columns j, j+16, j+32, ... -> every load instruction covers 4 rows x 256 contiguous
+// bytes = whole 128-B lines), multiplies against the query tile staged in LDS (the 4 DPP rows read
+// the same LDS addresses, i.e. broadcast), and reduces across the 16 lanes with four row_ror DPP
+// adds.  Lane L keeps the dot of tile row (L&15)*4 + (L>>4), so after 16 steps the wave finishes
+// 64 scores at once: one permuted-but-contiguous 256-B norm load, one 256-B score store, one wave
+// max.  Nothing is read twice; algorithmic bytes = rows * dim * 4.
+#include "nmn_internal.h"
+
+namespace nmn {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// all-reduce over a 16-lane DPP row (row_ror 8,4,2,1)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0x128>(v);
+    v += dpp_f<0x124>(v);
+    v += dpp_f<0x122>(v);
+    v += dpp_f<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_u<0x128>(v));
+    v = max(v, dpp_u<0x124>(v));
+    v = max(v, dpp_u<0x122>(v));
+    v = max(v, dpp_u<0x121>(v));
+    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+template <bool NT>
+__device__ __forceinline__ v4f load4(const v4f* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+// METRIC: nmn_metric.  MASKED: predicate bitmap present.  NQ: queries per pass over the corpus.
+// CH: float4 loads per lane per chunk (CH KiB in flight per wave).  FULL: ld4 % (16*CH) == 0, no
+// column predicate.  NT: non-temporal corpus loads.
+template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT>
+__global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][ld]
+    const uint32_t ld = p.ld, ld4 = ld >> 2;
+    const uint32_t q0 = blockIdx.y * NQ;
+    {
+        v4f* qs4 = reinterpret_cast<v4f*>(qs);
+        for (uint32_t i = threadIdx.x; i < NQ * ld4; i += 256) {
+            uint32_t q = i / ld4, c = i - q * ld4;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + q < p.nq) v = reinterpret_cast<const v4f*>(p.qpad + (size_t)(q0 + q) * ld)[c];
+            qs4[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t j = lane & 15u, grp = lane >> 4;
+    const uint32_t t0 = wave * p.tiles_per_wave;
+    if (t0 >= p.n_tiles) return;
+    const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+    const v4f* qs4 = reinterpret_cast<const v4f*>(qs);
+
+    float qmag[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) qmag[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qmag : 0.f;
+
+    for (uint32_t tile = t0; tile < t1; tile++) {
+        const uint64_t r0 = (uint64_t)tile * kTileRows;
+        uint64_t mword = ~0ull;
+        if constexpr (MASKED) mword = p.mask[tile];
+        {
+            const uint64_t left = p.n_rows - r0;
+            if (left < 64) mword &= (1ull << left) - 1ull;
+        }
+        float mydot[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
+
+#pragma unroll 2
+        for (uint32_t s = 0; s < 16; s++) {
+            if constexpr (MASKED) {
+                if (((mword >> (s * 4)) & 0xFull) == 0) continue;  // wave-uniform: 4 rows all excluded
+            }
+            const uint32_t rbit = s * 4 + grp;
+            const bool active = MASKED ? ((mword >> rbit) & 1ull) != 0 : true;
+            const v4f* rowp = reinterpret_cast<const v4f*>(p.corpus + (r0 + rbit) * (uint64_t)ld);
+            float acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc[q] = 0.f;
+
+            for (uint32_t c0 = 0; c0 < ld4; c0 += 16u * CH) {
+                v4f x[CH];
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    const uint32_t col = c0 + (uint32_t)c * 16u + j;
+                    const bool ok = (FULL || col < ld4) && active;
+                    if (ok) x[c] = load4<NT>(rowp + col);
+                    else x[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    uint32_t col = c0 + (uint32_t)c * 16u + j;
+                    if constexpr (!FULL) col = min(col, ld4 - 1u);  // x is zero there; keep the LDS read in range
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const v4f qv = qs4[(uint32_t)q * ld4 + col];
+                        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                            const v4f d = x[c] - qv;
+                            acc[q] = __builtin_fmaf(d.x, d.x, acc[q]);
+                            acc[q] = __builtin_fmaf(d.y, d.y, acc[q]);
+                            acc[q] = __builtin_fmaf(d.z, d.z, acc[q]);
+                            acc[q] = __builtin_fmaf(d.w, d.w, acc[q]);
+                        } else {
+                            acc[q] = __builtin_fmaf(x[c].x, qv.x, acc[q]);
+                            acc[q] = __builtin_fmaf(x[c].y, qv.y, acc[q]);
+                            acc[q] = __builtin_fmaf(x[c].z, qv.z, acc[q]);
+                            acc[q] = __builtin_fmaf(x[c].w, qv.w, acc[q]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const float t = row16_sum(acc[q]);
+                if (j == s) mydot[q] = t;
+            }
+        }
+
+        // lane L finishes tile row (L&15)*4 + (L>>4)
+        const uint32_t mybit = j * 4u + grp;
+        const bool valid = ((mword >> mybit) & 1ull) != 0;
+        const uint64_t myrow = r0 + mybit;
+        float vn = 1.f;
+        if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? p.norms[myrow] : 1.f;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (q0 + q >= p.nq) break;
+            float sc;
+            if constexpr (METRIC == NMN_METRIC_COSINE) {
+                sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : mydot[q] / (qmag[q] * vn);
+            } else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                sc = 1.0f / (1.0f + sqrtf(fmaxf(mydot[q], 0.f)));
+            } else {
+                sc = mydot[q];
+            }
+            const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
+            p.scores[(uint64_t)(q0 + q) * p.score_stride + myrow] = valid ? f2u(sc) : kScoreSentinelBits;
+            const uint32_t m = wave_max_u32(key);
+            if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.n_tiles + tile] = m;
+        }
+    }
+}
+
+template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT>
+static hipError_t launch_one(const ScanParams& p, hipStream_t s) {
+    const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
+    const size_t lds = (size_t)NQ * p.ld * sizeof(float);
+    auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int METRIC, bool MASKED, int NQ>
+static hipError_t launch_layout(const ScanParams& p, hipStream_t s, bool nt) {
+    const uint32_t ld4 = p.ld >> 2;
+    if (ld4 % (16 * 12) == 0) {
+        if (nt && !MASKED) return launch_one<METRIC, MASKED, NQ, 12, true, !MASKED>(p, s);
+        return launch_one<METRIC, MASKED, NQ, 12, true, false>(p, s);
+    }
+    if (ld4 % (16 * 8) == 0) return launch_one<METRIC, MASKED, NQ, 8, true, false>(p, s);
+    if (ld4 % (16 * 2) == 0) return launch_one<METRIC, MASKED, NQ, 2, true, false>(p, s);
+    return launch_one<METRIC, MASKED, NQ, 4, false, false>(p, s);
+}
+
+template <int METRIC, bool MASKED>
+static hipError_t launch_nq(const ScanParams& p, hipStream_t s, bool nt) {
+    if (p.nq >= 3) return launch_layout<METRIC, MASKED, 4>(p, s, nt);
+    if (p.nq == 2) return launch_layout<METRIC, MASKED, 2>(p, s, nt);
+    return launch_layout<METRIC, MASKED, 1>(p, s, nt);
+}
+
+template <int METRIC>
+static hipError_t launch_mask(const ScanParams& p, hipStream_t s, bool nt) {
+    return p.mask ? launch_nq<METRIC, true>(p, s, nt) : launch_nq<METRIC, false>(p, s, nt);
+}
+
+static bool scan_nt_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NMN_SCAN_NT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
+hipError_t launch_scan(const ScanParams& p, hipStream_t s) {
+    const bool nt = scan_nt_enabled();
+    switch (p.metric) {
+        case NMN_METRIC_COSINE: return launch_mask<NMN_METRIC_COSINE>(p, s, nt);
+        case NMN_METRIC_EUCLIDEAN: return launch_mask<NMN_METRIC_EUCLIDEAN>(p, s, nt);
+        default: return launch_mask<NMN_METRIC_DOT_PRODUCT>(p, s, nt);
+    }
+}
+
+}  // namespace nmn

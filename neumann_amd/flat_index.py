@@ -1,0 +1,234 @@
+"""GpuFlatIndex — host-side handle of one row-range shard resident on one MI355X.
+
+Python mirror of the safe Rust wrapper a GPU-enabled `vector_engine` crate would put over the C ABI
+(`GpuFlatIndex::search(&self, q, k, metric, mask) -> Vec<(usize, f32)>`): the
+same shape `HNSWIndex::search` returns into `search_similar`'s cache hook
+(vector_engine/src/lib.rs:1977-2001), i.e. (row, score) pairs that the caller maps back to keys.
+All compute happens in libneumann_gpu.so; this file only marshals buffers.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _capi
+
+
+class DistanceMetric(enum.IntEnum):
+    """vector_engine::DistanceMetric (lib.rs:268-289), same discriminant order."""
+    Cosine = 0
+    Euclidean = 1
+    DotProduct = 2
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class GpuFlatIndex:
+    def __init__(self, dim, capacity_rows, row_base=0, device=-1, cand_cap=0):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        desc = _capi.IndexDesc(dim=int(dim), flags=0, capacity_rows=int(capacity_rows),
+                               row_base=int(row_base), device=int(device), cand_cap=int(cand_cap))
+        _capi.check(self._lib.nmn_index_create(C.byref(desc), C.byref(self._h)))
+        self.dim = int(dim)
+        self.capacity_rows = int(capacity_rows)
+        self.row_base = int(row_base)
+
+    # -- lifecycle --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.nmn_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def rows(self):
+        return int(self._lib.nmn_index_rows(self._h))
+
+    # -- data -------------------------------------------------------------------------------
+    def upload(self, rows, row0=None):
+        """Append (or overwrite from row0) row-major f32 rows held in host memory."""
+        rows = _f32(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise _capi.NeumannGpuError(_capi.ERR_DIMENSION_MISMATCH, f"expected [n,{self.dim}], got {rows.shape}")
+        if row0 is None:
+            row0 = self.rows
+        _capi.check(self._lib.nmn_index_upload(self._h, _ptr(rows), int(row0), rows.shape[0]))
+
+    def upload_device(self, rows_t, row0=None, stream=None):
+        """Same from a CUDA/HIP torch tensor [n, dim] f32 (contiguous); asynchronous."""
+        if row0 is None:
+            row0 = self.rows
+        assert rows_t.is_cuda and rows_t.is_contiguous() and rows_t.shape[1] == self.dim
+        _capi.check(self._lib.nmn_index_upload_device(self._h, C.c_void_p(rows_t.data_ptr()), int(row0),
+                                                      rows_t.shape[0], _stream_ptr(stream)))
+
+    def fill_synthetic(self, seed, n, row0=None):
+        if row0 is None:
+            row0 = self.rows
+        _capi.check(self._lib.nmn_index_fill_synthetic(self._h, int(seed), int(row0), int(n)))
+
+    def set_row(self, row, vec):
+        vec = _f32(vec)
+        assert vec.size == self.dim
+        _capi.check(self._lib.nmn_index_set_row(self._h, int(row), _ptr(vec)))
+
+    def set_rows(self, n):
+        _capi.check(self._lib.nmn_index_set_rows(self._h, int(n)))
+
+    # -- search -----------------------------------------------------------------------------
+    def search(self, queries, k, metric=DistanceMetric.Cosine, mask=None, with_stats=False):
+        """SIMILAR TOP-K with host buffers.  Returns (rows u64 [nq,k], scores f32 [nq,k], counts u32 [nq])."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.size == 0 or q.shape[1] == 0:
+            raise _capi.NeumannGpuError(_capi.ERR_EMPTY_VECTOR)
+        if q.shape[1] != self.dim:
+            raise _capi.NeumannGpuError(_capi.ERR_DIMENSION_MISMATCH, f"expected {self.dim}, got {q.shape[1]}")
+        nq = q.shape[0]
+        k = int(k)
+        out_rows = np.empty((nq, max(k, 1)), dtype=np.uint64)
+        out_scores = np.empty((nq, max(k, 1)), dtype=np.float32)
+        out_counts = np.empty(nq, dtype=np.uint32)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint64)
+            need = (self.rows + 63) // 64
+            if m.size < need:
+                raise _capi.NeumannGpuError(_capi.ERR_BUFFER_TOO_SMALL, f"mask needs {need} words")
+        stats = _capi.SearchStats()
+        _capi.check(self._lib.nmn_index_search(self._h, _ptr(q), nq, k, int(metric),
+                                               None if m is None else _ptr(m), _ptr(out_rows),
+                                               _ptr(out_scores), _ptr(out_counts), C.byref(stats)))
+        if with_stats:
+            return out_rows, out_scores, out_counts, stats
+        return out_rows, out_scores, out_counts
+
+    def search_device(self, queries_t, k, metric=DistanceMetric.Cosine, mask_t=None, out=None, stream=None):
+        """Asynchronous search with torch device tensors.
+
+        queries_t: [nq, dim] f32 cuda.  mask_t: optional int64 cuda tensor holding the u64 bitmap words.
+        Returns (rows int64 [nq,k] — bit pattern of the u64 ids, -1 = unused slot; scores f32 [nq,k];
+        counts int32 [nq]) allocated on the same device unless `out` supplies them.
+        """
+        import torch
+
+        assert queries_t.is_cuda and queries_t.dtype == torch.float32 and queries_t.is_contiguous()
+        if queries_t.dim() == 1:
+            queries_t = queries_t[None, :]
+        nq = queries_t.shape[0]
+        if queries_t.shape[1] != self.dim:
+            raise _capi.NeumannGpuError(_capi.ERR_DIMENSION_MISMATCH, f"expected {self.dim}")
+        if out is None:
+            rows = torch.empty((nq, k), dtype=torch.int64, device=queries_t.device)
+            scores = torch.empty((nq, k), dtype=torch.float32, device=queries_t.device)
+            counts = torch.empty((nq,), dtype=torch.int32, device=queries_t.device)
+        else:
+            rows, scores, counts = out
+        _capi.check(self._lib.nmn_index_search_device(
+            self._h, C.c_void_p(queries_t.data_ptr()), nq, int(k), int(metric),
+            None if mask_t is None else C.c_void_p(mask_t.data_ptr()),
+            C.c_void_p(rows.data_ptr()), C.c_void_p(scores.data_ptr()), C.c_void_p(counts.data_ptr()),
+            _stream_ptr(stream)))
+        return rows, scores, counts
+
+    def set_timing(self, enabled):
+        _capi.check(self._lib.nmn_index_set_timing(self._h, 1 if enabled else 0))
+
+    def last_stats(self, stream=None):
+        st = _capi.SearchStats()
+        _capi.check(self._lib.nmn_index_last_stats(self._h, _stream_ptr(stream), C.byref(st)))
+        return st
+
+    # -- exact helpers ----------------------------------------------------------------------
+    def score_rows(self, queries, local_rows, metric=DistanceMetric.Cosine):
+        """Reference-order scores of explicit rows: f32 [nq, len(local_rows)]."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        r = np.ascontiguousarray(local_rows, dtype=np.uint64)
+        out = np.empty((q.shape[0], r.size), dtype=np.float32)
+        _capi.check(self._lib.nmn_index_score_rows(self._h, _ptr(q), q.shape[0], int(metric), _ptr(r), r.size,
+                                                   _ptr(out)))
+        return out
+
+    def count_exact(self, query, score, metric=DistanceMetric.Cosine, mask=None):
+        """(#rows with exact score > score, #rows with exact score == score) — a full exact pass."""
+        q = _f32(query).reshape(-1)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint64)
+        gt, eq = C.c_uint64(), C.c_uint64()
+        _capi.check(self._lib.nmn_index_count_exact(self._h, _ptr(q), int(metric),
+                                                    None if m is None else _ptr(m), C.c_float(float(score)),
+                                                    C.byref(gt), C.byref(eq)))
+        return gt.value, eq.value
+
+
+def _stream_ptr(stream):
+    """None -> torch's current stream if torch is imported and CUDA is up, else the null stream."""
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except ImportError:
+            pass
+        return C.c_void_p(0)
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+def merge_topk_host(rows, scores, counts, k):
+    """ResultMerger::merge_top_k (query_router/src/distributed.rs:413-433) over [lists][nq][k] host arrays."""
+    lib = _capi.load()
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    scores = _f32(scores)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    n_lists, nq = counts.shape
+    o_r = np.empty((nq, k), dtype=np.uint64)
+    o_s = np.empty((nq, k), dtype=np.float32)
+    o_c = np.empty(nq, dtype=np.uint32)
+    _capi.check(lib.nmn_merge_topk_host(_ptr(rows), _ptr(scores), _ptr(counts), n_lists, nq, int(k), _ptr(o_r),
+                                        _ptr(o_s), _ptr(o_c)))
+    return o_r, o_s, o_c
+
+
+def merge_topk_device(rows_t, scores_t, counts_t, k, stream=None):
+    """Device merge of an all-gathered [lists][nq][k] block (torch tensors: int64, f32, int32)."""
+    import torch
+
+    lib = _capi.load()
+    n_lists, nq = counts_t.shape
+    o_r = torch.empty((nq, k), dtype=torch.int64, device=rows_t.device)
+    o_s = torch.empty((nq, k), dtype=torch.float32, device=rows_t.device)
+    o_c = torch.empty((nq,), dtype=torch.int32, device=rows_t.device)
+    _capi.check(lib.nmn_merge_topk_device(C.c_void_p(rows_t.data_ptr()), C.c_void_p(scores_t.data_ptr()),
+                                          C.c_void_p(counts_t.data_ptr()), n_lists, nq, int(k),
+                                          C.c_void_p(o_r.data_ptr()), C.c_void_p(o_s.data_ptr()),
+                                          C.c_void_p(o_c.data_ptr()), _stream_ptr(stream)))
+    return o_r, o_s, o_c
+
+
+def synth_rows(seed, row0, n, dim):
+    """Host copy of the synthetic generator (bit-identical to the device fill)."""
+    out = np.empty((n, dim), dtype=np.float32)
+    _capi.check(_capi.load().nmn_synth_fill_host(_ptr(out), int(seed), int(row0), int(n), int(dim)))
+    return out

@@ -1,0 +1,377 @@
+/*
+ * nmn_oracle.c — CPU restatement of Neumann's vector_engine SIMILAR TOP-K path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (libneumann_gpu.so, neumann_amd/) may link,
+ * import or call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and only as the checker / the reported CPU baseline.
+ *
+ * What it restates (paths relative to the reference root /root/reference):
+ *   simd::dot_product        tensor_store/src/hnsw.rs:168-193
+ *   simd::sum_of_squares     tensor_store/src/hnsw.rs:198-222
+ *   simd::magnitude          tensor_store/src/hnsw.rs:227-229
+ *   euclidean_distance       vector_engine/src/lib.rs:2249-2253   (scalar, strictly sequential)
+ *   cosine_similarity        vector_engine/src/lib.rs:2257-2266
+ *   compute_score            vector_engine/src/lib.rs:2231-2246
+ *   search_similar*          vector_engine/src/lib.rs:1950-2101   (score all, stable sort desc, truncate)
+ *   search_with_pre_filter   vector_engine/src/lib.rs:3514-3557   (mask = surviving rows)
+ *   merge_top_k              query_router/src/distributed.rs:413-433
+ *
+ * Third-party arithmetic: the reference's lanes are `wide::f32x8` (wide 0.7.33, Cargo.lock:4121;
+ * safe_arch 0.7.4), whose source is NOT under /root/reference.  The ops used (`f32x8::ZERO`,
+ * `From<&[f32]>`, `Mul`, `AddAssign`, `Into<[f32;8]>`; call sites hnsw.rs:172-183,202-212) are
+ * lane-wise IEEE-754 binary32 multiply and add on every backend and `mul_add` is never called, so
+ * the restatement below is fixed by IEEE semantics: 8 strided accumulators, separately rounded
+ * mul and add (build with -ffp-contract=off), lanes summed left to right, scalar tail.
+ * `iter().sum::<f32>()` folds from -0.0 in current Rust (from +0.0 before 1.83); the two differ
+ * only in the sign of an all-zero sum, which no comparison in this path can observe.
+ *
+ * PARITY PINNING: the Rust reference cannot be built here (no cargo/rustc) and its own tests for
+ * this path are tolerance-based known-answer tests, not bit patterns.  This oracle
+ * passes every one of those KATs (tests/test_oracle_kats.py) and agrees bit-for-bit with two
+ * independent restatements (numpy twin oracle/oracle_np.py; exact-rational IEEE simulator in
+ * tests/test_oracle_crosscheck.py), but at the bit level parity is UNPINNED by the reference
+ * itself: "parity unpinned (bit level); pinned at KAT level".
+ *
+ * Ordering rule: score descending; equal scores by ascending row (the reference's tie order is
+ * the nondeterministic HashSet scan order, slab_router.rs:287-305, kept by its stable sort).  NaN
+ * scores (outside the reference's fuzzed input domain) rank last.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_COSINE 0
+#define ORC_EUCLIDEAN 1
+#define ORC_DOT 2
+
+/* ---------------------------------------------------------------- lane arithmetic */
+
+/* hnsw.rs:168-193 */
+float orc_dot8(const float* a, const float* b, uint64_t n) {
+    uint64_t chunks = n / 8, rem = n % 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; /* f32x8::ZERO */
+    for (uint64_t i = 0; i < chunks; i++) {
+        const float* pa = a + i * 8;
+        const float* pb = b + i * 8;
+        for (int l = 0; l < 8; l++) {
+            float p = pa[l] * pb[l]; /* va * vb  (rounded) */
+            acc[l] = acc[l] + p;     /* sum += .. (rounded) */
+        }
+    }
+    float r = -0.0f; /* arr.iter().sum() */
+    for (int l = 0; l < 8; l++) r = r + acc[l];
+    uint64_t start = chunks * 8;
+    for (uint64_t i = 0; i < rem; i++) {
+        float p = a[start + i] * b[start + i];
+        r = r + p;
+    }
+    return r;
+}
+
+/* hnsw.rs:198-222 */
+float orc_sumsq8(const float* v, uint64_t n) {
+    uint64_t chunks = n / 8, rem = n % 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint64_t i = 0; i < chunks; i++) {
+        const float* pv = v + i * 8;
+        for (int l = 0; l < 8; l++) {
+            float p = pv[l] * pv[l];
+            acc[l] = acc[l] + p;
+        }
+    }
+    float r = -0.0f;
+    for (int l = 0; l < 8; l++) r = r + acc[l];
+    uint64_t start = chunks * 8;
+    for (uint64_t i = 0; i < rem; i++) {
+        float p = v[start + i] * v[start + i];
+        r = r + p;
+    }
+    return r;
+}
+
+/* hnsw.rs:227-229 */
+float orc_magnitude(const float* v, uint64_t n) { return sqrtf(orc_sumsq8(v, n)); }
+
+/* lib.rs:2249-2253: a.iter().zip(b).map(|(x,y)| (x-y)*(x-y)).sum::<f32>().sqrt() */
+float orc_euclidean_seq(const float* a, const float* b, uint64_t n) {
+    float s = -0.0f;
+    for (uint64_t i = 0; i < n; i++) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        s = s + p;
+    }
+    return sqrtf(s);
+}
+
+/* lib.rs:2257-2266 */
+float orc_cosine(const float* a, const float* b, uint64_t n, float a_mag) {
+    float dot = orc_dot8(a, b, n);
+    float b_mag = orc_magnitude(b, n);
+    if (a_mag == 0.0f || b_mag == 0.0f) return 0.0f;
+    float den = a_mag * b_mag;
+    return dot / den;
+}
+
+/* lib.rs:2231-2246 */
+float orc_score(const float* q, const float* v, uint64_t n, float q_mag, int metric) {
+    switch (metric) {
+        case ORC_COSINE:
+            return orc_cosine(q, v, n, q_mag);
+        case ORC_DOT:
+            return orc_dot8(q, v, n);
+        default: {
+            float dist = orc_euclidean_seq(q, v, n);
+            float den = 1.0f + dist;
+            return 1.0f / den;
+        }
+    }
+}
+
+/* VectorEngine::compute_similarity (lib.rs ~2268-2290): cosine of two vectors, both magnitudes
+ * computed here. */
+float orc_compute_similarity(const float* a, const float* b, uint64_t n) {
+    return orc_cosine(a, b, n, orc_magnitude(a, n));
+}
+
+/* ---------------------------------------------------------------- scoring all rows */
+
+typedef struct {
+    const float* corpus;
+    const float* q;
+    const uint64_t* mask;
+    float* scores;
+    uint64_t r0, r1;
+    uint32_t d;
+    float qmag;
+    int metric;
+} orc_job;
+
+static int orc_mask_bit(const uint64_t* mask, uint64_t r) {
+    return mask == NULL || ((mask[r >> 6] >> (r & 63)) & 1u);
+}
+
+static void* orc_score_worker(void* p) {
+    orc_job* j = (orc_job*)p;
+    for (uint64_t r = j->r0; r < j->r1; r++) {
+        if (!orc_mask_bit(j->mask, r)) {
+            j->scores[r] = -INFINITY; /* never ranked: excluded below by the mask, not the value */
+            continue;
+        }
+        j->scores[r] = orc_score(j->q, j->corpus + r * (uint64_t)j->d, j->d, j->qmag, j->metric);
+    }
+    return NULL;
+}
+
+/* scores[r] for every row (mask-excluded rows get -inf).  nthreads<=1 runs inline. */
+void orc_scores_all(const float* corpus, uint64_t n, uint32_t d, const float* q, int metric,
+                    const uint64_t* mask, float* scores, int nthreads) {
+    float qmag = orc_magnitude(q, d);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    if ((uint64_t)nthreads > n) nthreads = n ? (int)n : 1;
+    orc_job jobs[256];
+    pthread_t th[256];
+    uint64_t per = (n + nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t r0 = per * t, r1 = r0 + per;
+        if (r0 > n) r0 = n;
+        if (r1 > n) r1 = n;
+        jobs[t] = (orc_job){corpus, q, mask, scores, r0, r1, d, qmag, metric};
+    }
+    if (nthreads == 1) {
+        orc_score_worker(&jobs[0]);
+        return;
+    }
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, orc_score_worker, &jobs[t]);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+
+/* ---------------------------------------------------------------- ranking */
+
+typedef struct {
+    float score;
+    uint64_t row;
+} orc_hit;
+
+/* a ranks before b?  score desc (NaN last), then row asc. */
+static int orc_before(const orc_hit* a, const orc_hit* b) {
+    int an = isnan(a->score), bn = isnan(b->score);
+    if (an != bn) return bn; /* non-NaN first */
+    if (!an) {
+        if (a->score > b->score) return 1;
+        if (a->score < b->score) return 0;
+    }
+    return a->row < b->row;
+}
+
+static int orc_hit_cmp(const void* pa, const void* pb) {
+    const orc_hit* a = (const orc_hit*)pa;
+    const orc_hit* b = (const orc_hit*)pb;
+    if (orc_before(a, b)) return -1;
+    if (orc_before(b, a)) return 1;
+    return 0;
+}
+
+/* top-k of `hits[0..m)` into the first min(k,m) slots (full sort: the reference sorts all N,
+ * lib.rs:2027-2034). */
+static uint32_t orc_rank(orc_hit* hits, uint64_t m, uint32_t k) {
+    qsort(hits, m, sizeof(orc_hit), orc_hit_cmp);
+    return (uint32_t)(m < k ? m : k);
+}
+
+/* search_similar_with_metric restated over a flat row-major corpus.  Returns the result count,
+ * or a negative VectorError-like code: -3 EmptyVector (d==0), -4 InvalidTopK (k==0).
+ * Zero-magnitude query: empty result for COSINE/DOT (lib.rs:1970-1974, 2066-2068), scored for
+ * EUCLIDEAN.  `row_base` is added to the reported row ids. */
+int64_t orc_search(const float* corpus, uint64_t n, uint32_t d, const float* q, uint32_t k, int metric,
+                   const uint64_t* mask, uint64_t row_base, uint64_t* out_rows, float* out_scores,
+                   int nthreads) {
+    if (d == 0) return -3;
+    if (k == 0) return -4;
+    float qmag = orc_magnitude(q, d);
+    if (qmag == 0.0f && metric != ORC_EUCLIDEAN) return 0;
+    float* scores = (float*)malloc((n ? n : 1) * sizeof(float));
+    if (!scores) return -22;
+    orc_scores_all(corpus, n, d, q, metric, mask, scores, nthreads);
+    uint64_t m = 0;
+    for (uint64_t r = 0; r < n; r++) m += orc_mask_bit(mask, r) ? 1 : 0;
+    orc_hit* hits = (orc_hit*)malloc((m ? m : 1) * sizeof(orc_hit));
+    if (!hits) {
+        free(scores);
+        return -22;
+    }
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < n; r++)
+        if (orc_mask_bit(mask, r)) hits[w++] = (orc_hit){scores[r], row_base + r};
+    uint32_t cnt = orc_rank(hits, m, k);
+    for (uint32_t i = 0; i < cnt; i++) {
+        out_rows[i] = hits[i].row;
+        out_scores[i] = hits[i].score;
+    }
+    free(hits);
+    free(scores);
+    return cnt;
+}
+
+/* Same selection but with a bounded heap-free partial pass (per-thread top-k then merge): this is
+ * the form timed as the CPU baseline.  It is OPTIMISTIC for the reference, which also pays a
+ * BTreeMap lookup, two clones per row and a full O(N log N) sort (lib.rs:2121-2138,2027-2034). */
+typedef struct {
+    const float* corpus;
+    const float* q;
+    const uint64_t* mask;
+    orc_hit* best; /* k slots, kept sorted best-first */
+    uint32_t k, cnt;
+    uint64_t r0, r1, row_base;
+    uint32_t d;
+    float qmag;
+    int metric;
+} orc_tk_job;
+
+static void orc_tk_insert(orc_tk_job* j, orc_hit h) {
+    if (j->cnt == j->k && !orc_before(&h, &j->best[j->k - 1])) return;
+    uint32_t pos = j->cnt < j->k ? j->cnt : j->k - 1;
+    while (pos > 0 && orc_before(&h, &j->best[pos - 1])) {
+        j->best[pos] = j->best[pos - 1];
+        pos--;
+    }
+    j->best[pos] = h;
+    if (j->cnt < j->k) j->cnt++;
+}
+
+static void* orc_tk_worker(void* p) {
+    orc_tk_job* j = (orc_tk_job*)p;
+    for (uint64_t r = j->r0; r < j->r1; r++) {
+        if (!orc_mask_bit(j->mask, r)) continue;
+        float s = orc_score(j->q, j->corpus + r * (uint64_t)j->d, j->d, j->qmag, j->metric);
+        orc_hit h = {s, j->row_base + r};
+        orc_tk_insert(j, h);
+    }
+    return NULL;
+}
+
+int64_t orc_search_partial(const float* corpus, uint64_t n, uint32_t d, const float* q, uint32_t k,
+                           int metric, const uint64_t* mask, uint64_t row_base, uint64_t* out_rows,
+                           float* out_scores, int nthreads) {
+    if (d == 0) return -3;
+    if (k == 0) return -4;
+    float qmag = orc_magnitude(q, d);
+    if (qmag == 0.0f && metric != ORC_EUCLIDEAN) return 0;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    orc_tk_job jobs[256];
+    pthread_t th[256];
+    orc_hit* pool = (orc_hit*)malloc((size_t)nthreads * k * sizeof(orc_hit));
+    if (!pool) return -22;
+    uint64_t per = (n + nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t r0 = per * t, r1 = r0 + per;
+        if (r0 > n) r0 = n;
+        if (r1 > n) r1 = n;
+        jobs[t] = (orc_tk_job){corpus, q, mask, pool + (size_t)t * k, k, 0, r0, r1, row_base, d, qmag, metric};
+    }
+    if (nthreads == 1) {
+        orc_tk_worker(&jobs[0]);
+    } else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, orc_tk_worker, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    uint64_t m = 0;
+    orc_hit* all = (orc_hit*)malloc((size_t)nthreads * k * sizeof(orc_hit));
+    for (int t = 0; t < nthreads; t++)
+        for (uint32_t i = 0; i < jobs[t].cnt; i++) all[m++] = jobs[t].best[i];
+    uint32_t cnt = orc_rank(all, m, k);
+    for (uint32_t i = 0; i < cnt; i++) {
+        out_rows[i] = all[i].row;
+        out_scores[i] = all[i].score;
+    }
+    free(all);
+    free(pool);
+    return cnt;
+}
+
+/* merge_top_k (distributed.rs:413-433): lists laid out [list][query][k]; counts [list][query]. */
+void orc_merge_topk(const uint64_t* rows, const float* scores, const uint32_t* counts, uint32_t n_lists,
+                    uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_counts) {
+    orc_hit* all = (orc_hit*)malloc((size_t)n_lists * k * sizeof(orc_hit) + sizeof(orc_hit));
+    for (uint32_t q = 0; q < nq; q++) {
+        uint64_t m = 0;
+        for (uint32_t l = 0; l < n_lists; l++) {
+            uint32_t c = counts[(size_t)l * nq + q];
+            if (c > k) c = k;
+            size_t base = ((size_t)l * nq + q) * k;
+            for (uint32_t i = 0; i < c; i++) all[m++] = (orc_hit){scores[base + i], rows[base + i]};
+        }
+        uint32_t cnt = orc_rank(all, m, k);
+        for (uint32_t i = 0; i < k; i++) {
+            out_rows[(size_t)q * k + i] = i < cnt ? all[i].row : UINT64_MAX;
+            out_scores[(size_t)q * k + i] = i < cnt ? all[i].score : -INFINITY;
+        }
+        out_counts[q] = cnt;
+    }
+    free(all);
+}
+
+/* ---------------------------------------------------------------- synthetic data (twin of the
+ * device generator in neumann_amd/csrc; not part of the reference algorithm) */
+
+static uint64_t orc_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+float orc_synth_value(uint64_t seed, uint64_t row, uint32_t col) {
+    uint64_t h = orc_mix64(orc_mix64(seed ^ (row * 0xD6E8FEB86659FD93ull)) + (uint64_t)col);
+    int32_t s = (int32_t)(h & 0xFFFF) + (int32_t)((h >> 16) & 0xFFFF) + (int32_t)((h >> 32) & 0xFFFF) +
+                (int32_t)(h >> 48) - 131070;
+    return (float)s * 0x1.bb685ep-16f; /* = f32(1/37837): unit variance for a sum of four u16 */
+}
+
+void orc_synth_fill(float* out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim) {
+    for (uint64_t i = 0; i < n; i++)
+        for (uint32_t c = 0; c < dim; c++) out[i * dim + c] = orc_synth_value(seed, row0 + i, c);
+}
