@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""bench.py — SIMILAR TOP-K throughput of the MI355X-native vector_engine hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`): 10M x 768 f32 cosine brute-force TOP-100.  One "step" = one pass
+of the hot path over one batch of `--nq` synthetic queries (default 1: the HBM-bound single-query
+scan the roofline target is quoted on).  The corpus and the queries are resident in HBM before the
+timed region.  With N > 1 the 10M-row corpus is row-range sharded over the N GPUs (one process per
+GPU); every step each rank scans its shard, the per-shard top-k blocks are all-gathered over RCCL
+and merged on-device (strong scaling: total work per query is fixed).  `--scaling weak` instead
+keeps 10M rows PER GPU (config 4: 80M rows on 8 GPUs).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (scan) algorithmic bytes / measured kernel time vs HBM peak
+  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded
+                row sample of the same workload, extrapolated linearly to the full row count
+  parity        the GPU result of the last timed query checked against the oracle / exact certificate
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable by a copy)
+SEED_CORPUS = 0x5EED0003
+SEED_QUERY = 0x5EED0002
+METRICS = {"cosine": 0, "euclidean": 1, "dot": 2}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (strong) / rows per GPU (weak)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--nq", type=int, default=1, help="queries per step")
+    ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, metric, total_rows, device):
+    """Time the CPU oracle on a bounded row sample (and, as the checker, compare the GPU path with it
+    on that same sample); returns the cpu_baseline object."""
+    from oracle import oracle_c as oc
+    from neumann_amd import GpuFlatIndex
+    cores = os.cpu_count() or 1
+    sample_rows = min(100_000, total_rows)
+    A = oc.synth(SEED_CORPUS, 0, sample_rows, args.dim)
+    Q = oc.synth(SEED_QUERY, 0, 4, args.dim)
+    oc.search(A, Q[0], args.k, metric, partial=True, nthreads=cores, native=True)  # warm (page-in, threads)
+    t0 = time.perf_counter()
+    er, es = oc.search(A, Q[1], args.k, metric, partial=True, nthreads=cores, native=True)
+    t1 = time.perf_counter() - t0
+    reps = int(max(2, min(200, args.cpu_seconds / max(t1, 1e-4))))
+    t0 = time.perf_counter()
+    for i in range(reps):
+        oc.search(A, Q[i % 4], args.k, metric, partial=True, nthreads=cores, native=True)
+    dt = (time.perf_counter() - t0) / reps
+    # single-thread figure on a smaller slice, for the record
+    t0 = time.perf_counter()
+    oc.search(A[:20000], Q[0], args.k, metric, partial=True, nthreads=1, native=True)
+    dt1 = (time.perf_counter() - t0) * (sample_rows / 20000.0)
+    # checker: the HIP path on the same sample rows must return the oracle's rows and scores
+    with GpuFlatIndex(args.dim, sample_rows, row_base=0, device=device) as small:
+        small.fill_synthetic(SEED_CORPUS, sample_rows)
+        gr, gs, gc = small.search(Q[1], args.k, metric)
+    sample_ok = bool(gc[0] == er.size and np.array_equal(gr[0, :er.size], er) and np.all(gs[0, :er.size] == es))
+    qps_full = 1.0 / (dt * (total_rows / sample_rows))
+    return {
+        "value": qps_full, "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": f"{reps} queries x {sample_rows} rows x {args.dim} (same generator/seed), "
+                  f"{dt * 1e3:.2f} ms/query on {cores} threads, extrapolated linearly to {total_rows} rows; "
+                  f"1 thread: {dt1 * 1e3:.1f} ms per {sample_rows} rows. Optimistic for the reference "
+                  f"(flat array, per-thread partial top-k; the Rust path also pays a BTreeMap lookup, two clones "
+                  f"per row and a full sort, published 193-367 ns/row)",
+        "gbps": sample_rows * args.dim * 4 / dt / 1e9,
+        "gpu_matches_oracle_on_sample": sample_ok,
+    }
+
+
+def certificate(idx, q_host, metric, rows, scores, counts, world, dev):
+    """Size-independent proof that (rows, scores) is the exact top-k of the whole sharded corpus, using
+    only the product's exact (reference-order) kernels, which tests/ pin bit-for-bit to the oracle:
+      1. every returned score equals the exact score of its row (owner shard recomputes it);
+      2. the list is ordered (score desc, row asc);
+      3. #rows anywhere with exact score > s_k  ==  #returned scores > s_k, and the returned ties at
+         s_k do not exceed the corpus-wide number of rows scoring exactly s_k."""
+    import torch
+    import torch.distributed as dist
+    cnt = int(counts[0])
+    r = rows[0, :cnt].astype(np.uint64)
+    s = scores[0, :cnt]
+    base, n_local = idx.row_base, idx.rows
+    mine = (r >= base) & (r < base + n_local)
+    ok_scores = True
+    if mine.any():
+        ex = idx.score_rows(q_host, (r[mine] - np.uint64(base)), metric)[0]
+        ok_scores = bool(np.all(ex == s[mine]))
+    ordered = bool(np.all((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (r[:-1] < r[1:])))) if cnt > 1 else True
+    sk = float(s[-1]) if cnt else float("inf")
+    gt, eq = idx.count_exact(q_host, sk, metric) if cnt else (0, 0)
+    agg = torch.tensor([gt, eq, 0 if ok_scores else 1], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg)
+    gt, eq, bad = (int(x) for x in agg.tolist())
+    n_gt_ret = int(np.sum(s > np.float32(sk)))
+    n_eq_ret = int(np.sum(s == np.float32(sk)))
+    exact = bad == 0 and ordered and gt == n_gt_ret and n_eq_ret <= eq and (cnt == 0 or n_eq_ret >= 1)
+    return {"exact_topk_certified": bool(exact), "scores_bit_equal_exact_kernel": bad == 0, "ordered": ordered,
+            "rows_above_kth": gt, "rows_equal_kth": eq, "returned": cnt, "recall_at_k": 1.0 if exact else None}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from neumann_amd import GpuFlatIndex
+    from neumann_amd.sharded import ShardedSearcher, shard_range
+
+    metric = METRICS[args.metric]
+    if args.scaling == "weak":
+        total_rows = args.rows * world
+    else:
+        total_rows = args.rows
+    r0, r1 = shard_range(total_rows, world, rank)
+    local_rows = r1 - r0
+
+    idx = GpuFlatIndex(args.dim, local_rows, row_base=r0, device=local_rank)
+    t_fill = time.perf_counter()
+    idx.fill_synthetic(SEED_CORPUS, local_rows)
+    torch.cuda.synchronize()
+    t_fill = time.perf_counter() - t_fill
+
+    n_query_sets = 16
+    q_host = np.stack([_synth(SEED_QUERY, s * args.nq, args.nq, args.dim) for s in range(n_query_sets)])
+    q_dev = torch.from_numpy(q_host).to(dev)  # [sets, nq, dim] resident in HBM
+    searcher = ShardedSearcher(idx, world_size=world, rank=rank, k=args.k, nq=args.nq, device=dev)
+
+    def step(i):
+        return searcher.search_device(q_dev[i % n_query_sets], metric)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.nq * args.steps / elapsed
+    last_out = tuple(t.cpu().numpy().copy() for t in out)  # result of the last timed step
+
+    # ---- dominant-kernel timing (HIP events on the launch stream, recorded inside the library) ----
+    idx.set_timing(True)
+    scan_ms, total_ms = [], []
+    n_meas = min(max(args.steps, 5), 30)
+    for i in range(n_meas):
+        step(i)
+        st = idx.last_stats()
+        if st.scan_ms > 0:
+            scan_ms.append(st.scan_ms)
+            total_ms.append(st.total_ms)
+    idx.set_timing(False)
+    fence()
+    scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
+    passes = (args.nq + 3) // 4 if args.nq >= 3 else 1  # corpus sweeps per step (4 queries per sweep)
+    alg_bytes = local_rows * args.dim * 4 * passes
+    achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
+
+    # ---- parity of the last result ----------------------------------------------------------------
+    parity = None
+    if not args.no_parity:
+        o_rows, o_scores, o_counts = last_out
+        parity = certificate(idx, q_host[(args.steps - 1) % n_query_sets][0], metric,
+                             o_rows.view(np.uint64), o_scores, o_counts, world, dev)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, metric, total_rows, local_rank)
+
+    if rank == 0:
+        line = {
+            "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
+            "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={args.nq}/step",
+                       "rows_total": total_rows, "rows_per_gpu": local_rows, "dim": args.dim, "k": args.k,
+                       "nq": args.nq, "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": None,
+                         "kernel": "nmn::scan_kernel", "avg_kernel_ms": scan_avg,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None},
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "fill_s": t_fill,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _synth(seed, row0, n, dim):
+    from neumann_amd import synth_rows
+    return synth_rows(seed, row0, n, dim)
+
+
+if __name__ == "__main__":
+    main()

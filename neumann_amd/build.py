@@ -21,7 +21,7 @@ ARCH = "gfx950"
 SOURCES = {
     "nmn_scan.hip": [],
     "nmn_select.hip": [],
-    "nmn_exact.hip": ["-ffp-contract=off"],
+    "nmn_exact.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_synth.hip": ["-ffp-contract=off"],
     "nmn_api.hip": [],
     "nmn_engine.cpp": ["-x", "hip"],

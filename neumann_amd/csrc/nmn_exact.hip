@@ -22,6 +22,11 @@ namespace nmn {
 __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
 __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
 __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+// IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt (passed explicitly by build.py).
+// NOT HIP's __fsqrt_rn / __fdiv_rn: without OCML_BASIC_ROUNDED_OPERATIONS __fsqrt_rn is the
+// *native* (approximate) square root.
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }
 
 // lane-l chain of dot8 followed by the in-order lane sum and the scalar tail.
 // `l` = threadIdx & 7; all 8 threads of the group return the same value.
@@ -48,7 +53,7 @@ __device__ __forceinline__ float euclid_seq(const float* __restrict__ q, const f
         const float d = sub_rn(q[i], v[i]);
         s = add_rn(s, mul_rn(d, d));
     }
-    return __fsqrt_rn(s);
+    return sqrt_rn(s);
 }
 
 // compute_score (lib.rs:2231-2266) for one (query,row); vmag = stored simd::magnitude(row).
@@ -56,12 +61,12 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ q, const 
                                              uint32_t dim, float qmag, float vmag, int metric, uint32_t l) {
     if (metric == NMN_METRIC_EUCLIDEAN) {
         const float dist = euclid_seq(q, v, dim);  // every thread of the group walks it; loads hit L1
-        return __fdiv_rn(1.0f, add_rn(1.0f, dist));
+        return div_rn(1.0f, add_rn(1.0f, dist));
     }
     const float dot = dot8_group(q, v, dim, l);
     if (metric == NMN_METRIC_DOT_PRODUCT) return dot;
     if (qmag == 0.0f || vmag == 0.0f) return 0.0f;
-    return __fdiv_rn(dot, mul_rn(qmag, vmag));
+    return div_rn(dot, mul_rn(qmag, vmag));
 }
 
 // ---- |v| for uploaded rows -------------------------------------------------------------------
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ co
     const uint64_t row = row0 + (i < n ? i : n - 1);  // keep the whole 8-group converged for the shuffles
     const float* v = corpus + row * (uint64_t)ld;
     const float ss = dot8_group(v, v, dim, l);
-    const float mag = __fsqrt_rn(ss);
+    const float mag = sqrt_rn(ss);
     if (i < n && l == 0) {
         norms[row] = mag;
         if (mag == mag) atomicMax(max_norm_bits, f2u(mag));  // mag >= 0: bit order == value order
@@ -102,7 +107,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
     for (uint32_t i = threadIdx.x; i < ld; i += 64) dst[i] = i < dim ? src[i] : 0.0f;
     const float ss = dot8_group(src, src, dim, threadIdx.x & 7u);
     if (threadIdx.x == 0) {
-        const float qmag = __fsqrt_rn(ss);
+        const float qmag = sqrt_rn(ss);
         const float u = 5.9604645e-08f;  // 2^-24
         const float dd = (float)dim;
         QInfo qi;
