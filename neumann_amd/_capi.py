@@ -95,10 +95,33 @@ class NeumannGpuError(RuntimeError):
         super().__init__(msg)
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the SONAME libneumann_gpu.so needs).  If ours resolved to /opt/rocm first, a later
+    `import torch` would bring up a second runtime in the same process (torch then sees no GPU, and torch
+    streams / tensors would belong to a different runtime than our kernels).  Loading torch's copy first
+    makes the dynamic loader satisfy our NEEDED entry with it.  Without torch installed this is a no-op
+    and the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library (once).  Raises if it was not built — no fallback."""
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m neumann_amd.build` "

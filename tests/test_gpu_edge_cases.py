@@ -1,0 +1,225 @@
+"""GPU edge cases of the SIMILAR TOP-K path through the C ABI: ties, duplicates, the exact-fallback
+path, n<k, empty shards, k=NMN_MAX_TOP_K, multi-query batches, tile-threshold mode, error codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def check(idx, A, Q, k, metric, mask=None, row_base=0):
+    Q = np.atleast_2d(Q)
+    out = idx.search(Q, k, metric, mask=mask, with_stats=True)
+    rows, scores, counts, stats = out
+    for qi in range(Q.shape[0]):
+        er, es = oc.search(A, Q[qi], k, metric, mask=mask, row_base=row_base)
+        c = er.size
+        assert counts[qi] == c, (qi, counts[qi], c)
+        assert np.array_equal(rows[qi, :c], er), (qi, rows[qi, :c][:8], er[:8])
+        assert np.all(scores[qi, :c] == es)
+        assert np.all(rows[qi, c:] == U64_MAX) and np.all(np.isneginf(scores[qi, c:]))
+    return stats
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_all_rows_identical_ties_by_row(metric):
+    from neumann_amd import GpuFlatIndex
+    n, d = 5000, 24
+    A = np.tile(np.linspace(-1, 1, d, dtype=np.float32), (n, 1))
+    q = np.linspace(1, 2, d, dtype=np.float32)
+    with GpuFlatIndex(d, n) as idx:          # default cand_cap 4096 < 5000 tied rows -> exact fallback
+        idx.upload(A)
+        st = check(idx, A, q, 10, metric)
+        assert st.fallback_queries == 1
+        rows, _, _ = idx.search(q, 10, metric)
+        assert list(rows[0]) == list(range(10))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_forced_fallback_small_cand_cap(metric):
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(11)
+    n, d, k = 3000, 40, 7
+    base = rng.standard_normal((30, d)).astype(np.float32)
+    A = base[rng.integers(0, 30, n)]          # 30 distinct vectors, ~100 exact copies each
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n, cand_cap=8) as idx:
+        idx.upload(A)
+        st = check(idx, A, q, k, metric)
+        assert st.fallback_queries == 1
+        keep = rng.random(n) < 0.4
+        check(idx, A, q, k, metric, mask=oc.mask_from_bool(keep))
+
+
+def test_mixed_fallback_and_normal_queries_in_one_batch():
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(12)
+    n, d, k = 6000, 16, 5
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[1000:5500] = A[1000]                    # 4500 duplicates: a query near them overflows 4096
+    Q = np.stack([A[1000] + 0.0, rng.standard_normal(d).astype(np.float32), -A[1000]])
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        st = check(idx, A, Q, k, 0)
+        assert 1 <= st.fallback_queries <= 2
+
+
+@pytest.mark.parametrize("n,k", [(3, 10), (1, 1), (64, 64), (65, 100), (100, 4096)])
+def test_n_less_than_or_equal_k(n, k):
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(n * 31 + k)
+    A = rng.standard_normal((n, 12)).astype(np.float32)
+    q = rng.standard_normal(12).astype(np.float32)
+    with GpuFlatIndex(12, max(n, 1)) as idx:
+        idx.upload(A)
+        for m in (0, 1, 2):
+            check(idx, A, q, k, m)
+
+
+def test_empty_index_and_empty_mask():
+    from neumann_amd import GpuFlatIndex
+    with GpuFlatIndex(8, 100) as idx:
+        rows, scores, counts = idx.search(np.ones(8, np.float32), 5, 0)
+        assert counts[0] == 0 and np.all(rows == U64_MAX) and np.all(np.isneginf(scores))
+        A = np.random.default_rng(0).standard_normal((100, 8)).astype(np.float32)
+        idx.upload(A)
+        check(idx, A, np.ones(8, np.float32), 5, 0, mask=np.zeros(2, dtype=np.uint64))
+
+
+def test_k_max_and_too_large():
+    from neumann_amd import GpuFlatIndex, NeumannGpuError, _capi
+    rng = np.random.default_rng(77)
+    n, d = 20000, 20
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        check(idx, A, q, 4096, 0)
+        check(idx, A, q, 1000, 1)
+        with pytest.raises(NeumannGpuError) as e:
+            idx.search(q, 4097, 0)
+        assert e.value.status == _capi.ERR_TOP_K_TOO_LARGE
+        with pytest.raises(NeumannGpuError) as e:
+            idx.search(q, 0, 0)
+        assert e.value.status == _capi.ERR_INVALID_TOP_K and "Invalid top_k" in str(e.value)
+
+
+@pytest.mark.parametrize("nq", [2, 3, 4, 5, 9])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_multi_query_batches(nq, metric):
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(nq)
+    n, d, k = 7000, 72, 20
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        check(idx, A, Q, k, metric)
+        check(idx, A, Q, k, metric, mask=oc.mask_from_bool(rng.random(n) < 0.3))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_tile_threshold_mode_large_n(metric):
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 200_000, 32, 10                # n_tiles = 3125 >= 2k and n > 16384 -> tile maxima mode
+    A = oc.synth(5, 0, n, d)
+    Q = oc.synth(6, 0, 2, d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(5, n)
+        check(idx, A, Q, k, metric)
+        rng = np.random.default_rng(1)
+        check(idx, A, Q, k, metric, mask=oc.mask_from_bool(rng.random(n) < 0.1))
+        check(idx, A, Q, k, metric, mask=oc.mask_from_bool(rng.random(n) < 0.0002))  # fewer valid rows than tiles
+
+
+def test_dot_product_with_outlier_norms():
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(3)
+    n, d = 30000, 48
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[::1000] *= 1000.0                       # huge-norm rows inflate the dot margin (max |v|)
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        check(idx, A, q, 50, 2)
+        check(idx, A, q, 50, 0)
+
+
+def test_near_ties_around_rank_k():
+    """Rows whose scores differ by single ulps straddle rank k: only the exact rescore orders them."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(8)
+    n, d, k = 4000, 768, 10
+    A = (rng.standard_normal((n, d)) * 0.01).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    for i in range(40):                       # 40 near-copies of q, perturbed in the last ulps
+        v = q.copy()
+        j = rng.integers(0, d, 5)
+        v[j] = np.nextafter(v[j], np.float32(np.inf if i % 2 else -np.inf))
+        A[rng.integers(0, n)] = v
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for m in (0, 1, 2):
+            check(idx, A, q, k, m)
+
+
+def test_upload_errors_and_append():
+    from neumann_amd import GpuFlatIndex, NeumannGpuError, _capi
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((100, 10)).astype(np.float32)
+    with GpuFlatIndex(10, 100) as idx:
+        idx.upload(A[:60])
+        idx.upload(A[60:])                    # append
+        assert idx.rows == 100
+        check(idx, A, A[3], 5, 0)
+        with pytest.raises(NeumannGpuError) as e:
+            idx.upload(A[:1])                 # capacity exceeded
+        assert e.value.status == _capi.ERR_CAPACITY
+        with pytest.raises(NeumannGpuError) as e:
+            idx.upload(np.zeros((1, 11), np.float32), row0=0)
+        assert e.value.status == _capi.ERR_DIMENSION_MISMATCH
+        B = A.copy()
+        B[10:20] = rng.standard_normal((10, 10)).astype(np.float32)
+        idx.upload(B[10:20], row0=10)         # overwrite in place: norms recomputed
+        check(idx, B, B[15], 5, 0)
+
+
+def test_device_api_equals_host_api():
+    import torch
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(2)
+    n, d, k = 9000, 128, 25
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((3, d)).astype(np.float32)
+    keep = rng.random(n) < 0.5
+    mask = oc.mask_from_bool(keep)
+    with GpuFlatIndex(d, n, row_base=1_000_000_000_000) as idx:
+        idx.upload_device(torch.from_numpy(A).cuda())
+        torch.cuda.synchronize()
+        for mk, mt in ((None, None), (mask, torch.from_numpy(mask.view(np.int64)).cuda())):
+            hr, hs, hc = idx.search(Q, k, 0, mask=mk)
+            dr, ds, dc = idx.search_device(torch.from_numpy(Q).cuda(), k, 0, mask_t=mt)
+            torch.cuda.synchronize()
+            assert np.array_equal(dr.cpu().numpy().view(np.uint64), hr)
+            assert np.array_equal(ds.cpu().numpy(), hs) and np.array_equal(dc.cpu().numpy().view(np.uint32), hc)
+            er, es = oc.search(A, Q[0], k, 0, mask=mk, row_base=1_000_000_000_000)
+            assert np.array_equal(hr[0], er)
+
+
+def test_count_exact_certificate():
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(4)
+    n, d = 12345, 64
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for m in (0, 1, 2):
+            s = oc.scores_all(A, q, m)
+            ref = np.sort(s)[::-1][99]
+            gt, eq = idx.count_exact(q, ref, m)
+            assert gt == int(np.sum(s > ref)) and eq == int(np.sum(s == ref))

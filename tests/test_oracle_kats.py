@@ -1,0 +1,188 @@
+"""The reference's own known-answer tests for the SIMILAR TOP-K path, restated against the CPU oracle
+(C restatement and numpy twin).  Each test cites the reference test it restates
+(vector_engine/src/lib.rs unless noted).  These pin the oracle at the level the reference pins itself:
+tolerance-based KATs — bit-level lane order is pinned by tests/test_oracle_crosscheck.py
+and tests/golden/.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+from oracle import oracle_np as on
+
+COS, EUC, DOT = 0, 1, 2
+F = np.float32
+
+
+def normalize(v):
+    """tests::normalize (lib.rs:4040-4047): sequential f32 sum of squares, sqrt, divide."""
+    v = np.asarray(v, dtype=F)
+    s = F(0)
+    for x in v:
+        s = F(s + x * x)
+    mag = np.sqrt(s)
+    return v if mag == 0 else (v / mag).astype(F)
+
+
+def create_test_vector(dim, seed):
+    """tests::create_test_vector (lib.rs:4029-4038).  Uses f32 sin, hence only top-1/self-match is pinned."""
+    i = np.arange(dim, dtype=np.int64)
+    x = (seed * 31 + i * 17).astype(F)
+    return (np.sin(x * F(0.0001), dtype=F) * ((seed + i).astype(F) * F(0.001))).astype(F)
+
+
+def both(A, q, k, metric):
+    A = np.asarray(A, dtype=F)
+    r1, s1 = oc.search(A, q, k, metric)
+    r2, s2 = on.search(A, q, k, metric)
+    assert np.array_equal(r1, r2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+    return r1, s1
+
+
+def test_search_similar_basic():  # lib.rs:4119-4135
+    A = [[1, 0, 0], [0, 1, 0], [1, 1, 0]]
+    rows, scores = both(A, [1, 0, 0], 3, COS)
+    assert len(rows) == 3 and rows[0] == 0 and abs(scores[0] - 1.0) < 1e-6
+
+
+def test_cosine_identical_orthogonal_opposite():  # lib.rs:4182-4206
+    assert abs(oc.compute_similarity([1, 2, 3], [1, 2, 3]) - 1.0) < 1e-6
+    assert abs(oc.compute_similarity([1, 0], [0, 1])) < 1e-6
+    assert abs(oc.compute_similarity([1, 0], [-1, 0]) + 1.0) < 1e-6
+
+
+def test_cosine_normalized_45deg():  # lib.rs:4208-4216
+    a, b = normalize([1, 0]), normalize([1, 1])
+    assert abs(oc.compute_similarity(a, b) - np.sqrt(F(2)) / 2) < 1e-6
+
+
+def test_cosine_zero_vectors_are_zero_not_nan():  # lib.rs:4226-4239
+    assert oc.compute_similarity([0, 0], [1, 0]) == 0.0
+    s = oc.compute_similarity([0, 0], [0, 0])
+    assert s == 0.0 and not np.isnan(s)
+    # a zero ROW still appears in the results with score 0.0 (cosine_similarity, lib.rs:2261-2263)
+    rows, scores = both([[0, 0], [1, 0]], [1, 0], 5, COS)
+    assert list(rows) == [1, 0] and scores[1] == 0.0
+
+
+def test_store_10000_vectors_search():  # lib.rs:4255-4276
+    dim = 128
+    A = np.stack([create_test_vector(dim, i) for i in range(10000)])
+    rows, scores = both(A, create_test_vector(dim, 5000), 5, COS)
+    assert len(rows) == 5 and rows[0] == 5000 and abs(scores[0] - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("dim,qseed,k", [(768, 50, 3), (1536, 75, 5)])  # lib.rs:4278-4312
+def test_high_dimensional(dim, qseed, k):
+    A = np.stack([create_test_vector(dim, i) for i in range(100)])
+    rows, _ = both(A, create_test_vector(dim, qseed), k, COS)
+    assert len(rows) == k and rows[0] == qseed
+
+
+def test_similarity_scores_mathematically_correct():  # lib.rs:4314-4352
+    A = np.stack([normalize(v) for v in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [-1, 0, 0])])
+    rows, scores = both(A, normalize([1, 0, 0]), 5, COS)
+    got = dict(zip(rows.tolist(), scores.tolist()))
+    assert abs(got[0] - 1.0) < 1e-6 and abs(got[1]) < 1e-6 and abs(got[2]) < 1e-6
+    assert abs(got[3] - np.sqrt(2.0) / 2) < 1e-6 and abs(got[4] + 1.0) < 1e-6
+
+
+def test_zero_query_returns_empty_for_cosine_and_dot():  # lib.rs:4458-4466, 4940-4949
+    A = np.array([[1, 0]], dtype=F)
+    for m in (COS, DOT):
+        rows, _ = oc.search(A, [0, 0], 5, m)
+        assert rows.size == 0
+        assert on.search(A, [0, 0], 5, m)[0].size == 0
+
+
+def test_no_embeddings():  # lib.rs:4468-4473
+    rows, _ = oc.search(np.zeros((0, 2), dtype=F), [1, 0], 5, COS)
+    assert rows.size == 0
+
+
+def test_invalid_arguments():  # lib.rs:4926-4938
+    with pytest.raises(ValueError, match="InvalidTopK"):
+        oc.search(np.ones((1, 1), dtype=F), [1.0], 0, COS)
+    with pytest.raises(ValueError, match="EmptyVector"):
+        oc.search(np.zeros((0, 0), dtype=F), np.zeros(0, dtype=F), 5, COS)
+
+
+def test_search_with_metric_cosine():  # lib.rs:4876-4890
+    rows, scores = both([[1, 0], [0.707, 0.707], [0, 1]], [1, 0], 3, COS)
+    assert len(rows) == 3 and rows[0] == 0 and abs(scores[0] - 1.0) < 0.01
+
+
+def test_search_with_metric_dot_product():  # lib.rs:4892-4906
+    rows, scores = both([[1, 0], [2, 0], [0.5, 0]], [1, 0], 3, DOT)
+    assert rows[0] == 1 and abs(scores[0] - 2.0) < 0.01
+
+
+def test_search_with_metric_euclidean():  # lib.rs:4908-4924
+    rows, scores = both([[1, 0], [2, 0], [10, 0]], [1, 0], 3, EUC)
+    assert list(rows[:2]) == [0, 1] and abs(scores[0] - 1.0) < 0.01 and abs(scores[1] - 0.5) < 0.01
+
+
+def test_zero_query_euclidean_is_scored():  # lib.rs:4951-4970
+    rows, scores = both([[0, 0], [1, 0], [10, 0]], [0, 0], 3, EUC)
+    assert list(rows) == [0, 1, 2] and abs(scores[0] - 1.0) < 0.01 and abs(scores[1] - 0.5) < 0.01
+
+
+def test_euclidean_distance_kats():  # lib.rs:4972-4995
+    assert abs(oc.euclidean_seq([1, 2, 3], [1, 2, 3])) < 1e-6
+    assert abs(oc.euclidean_seq([0, 0], [1, 0]) - 1.0) < 1e-6
+    assert abs(oc.euclidean_seq([0, 0], [3, 4]) - 5.0) < 1e-6
+
+
+def test_parallel_path_returns_k():  # lib.rs:6583-6603 (parallel_threshold: 5)
+    A = np.array([[i, 0, 0] for i in range(10)], dtype=F)
+    rows, _ = oc.search(A, [5, 0, 0], 3, EUC, nthreads=4, partial=True)
+    assert len(rows) == 3
+    assert np.array_equal(rows, oc.search(A, [5, 0, 0], 3, EUC)[0])
+
+
+def test_n_less_than_k_returns_n():  # lib.rs:4137-4150 (search_similar_top_k family)
+    A = np.eye(4, dtype=F)
+    rows, _ = both(A, [1, 1, 0, 0], 10, COS)
+    assert len(rows) == 4
+
+
+def test_merge_top_k():  # query_router/src/distributed.rs:645-680
+    rows = np.array([[[0, 1]], [[2, 99]]], dtype=np.uint64)          # shard0: a,b ; shard1: c
+    scores = np.array([[[0.9, 0.8]], [[0.95, 0.0]]], dtype=F)
+    counts = np.array([[2], [1]], dtype=np.uint32)
+    r, s, c = oc.merge_topk(rows, scores, counts, 2)
+    assert c[0] == 2 and list(r[0]) == [2, 0] and np.allclose(s[0], [0.95, 0.9])
+
+
+def test_example_vector_search_rs():  # examples/vector_search.rs:26-67, queries :80,:96,:112 (TOP 3)
+    docs = np.array([
+        [0.8, 0.7, 0.1, 0.2, 0.1, 0.1, 0.1, 0.1], [0.9, 0.8, 0.2, 0.1, 0.1, 0.1, 0.1, 0.1],
+        [0.85, 0.75, 0.15, 0.15, 0.1, 0.1, 0.1, 0.1], [0.1, 0.1, 0.8, 0.7, 0.2, 0.1, 0.1, 0.1],
+        [0.1, 0.1, 0.75, 0.8, 0.25, 0.1, 0.1, 0.1], [0.1, 0.1, 0.2, 0.2, 0.8, 0.7, 0.1, 0.1],
+        [0.2, 0.1, 0.3, 0.3, 0.3, 0.3, 0.8, 0.7], [0.15, 0.1, 0.25, 0.25, 0.25, 0.25, 0.75, 0.8]], dtype=F)
+    ml, _ = both(docs, [0.85, 0.75, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1], 3, COS)
+    db, _ = both(docs, [0.1, 0.1, 0.8, 0.75, 0.2, 0.1, 0.1, 0.1], 3, COS)
+    sy, _ = both(docs, [0.1, 0.1, 0.2, 0.2, 0.2, 0.2, 0.8, 0.8], 3, COS)
+    assert set(ml.tolist()) == {0, 1, 2}       # the three ML documents
+    assert set(db.tolist()[:2]) == {3, 4}      # both database documents first
+    assert set(sy.tolist()[:2]) == {6, 7}      # both systems documents first
+
+
+def test_ties_rank_by_ascending_row():
+    # the reference's tie order is its HashSet scan order (slab_router.rs:287-305); ours is row-ascending
+    A = np.array([[0, 1], [1, 0], [0, 2], [2, 0], [0, 3]], dtype=F)
+    rows, scores = both(A, [1, 0], 5, COS)
+    assert list(rows) == [1, 3, 0, 2, 4] and list(scores) == [1, 1, 0, 0, 0]
+
+
+def test_mask_is_prefilter_semantics():  # search_with_pre_filter, lib.rs:3514-3557
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((300, 24)).astype(F)
+    q = rng.standard_normal(24).astype(F)
+    keep = rng.random(300) < 0.3
+    rows, scores = oc.search(A, q, 10, COS, mask=oc.mask_from_bool(keep))
+    r2, s2 = on.search(A, q, 10, COS, keep=keep)
+    assert np.array_equal(rows, r2) and np.array_equal(scores, s2)
+    sub_rows, sub_scores = oc.search(A[keep], q, 10, COS)
+    assert np.array_equal(np.flatnonzero(keep)[sub_rows.astype(np.int64)], rows.astype(np.int64))
+    assert np.array_equal(sub_scores, scores)
