@@ -1,0 +1,169 @@
+/*
+ * neumann_engine.h — C ABI of the host-side mirror of Neumann's `VectorEngine` (the part of it that is
+ * on or next to the SIMILAR TOP-K path), implemented in C++ in neumann_amd/csrc/nmn_engine.cpp on top
+ * of include/neumann_gpu.h.
+ *
+ * Why it exists: the reference's drop-in boundary is the public Rust API of crate `vector_engine`
+ *  and this image has no Rust toolchain, so the host side is written in C++ with the
+ * reference's method names, argument meaning and error behaviour, and driven from Python tests that
+ * read like the reference's own (vector_engine/src/lib.rs:4024+).  A Rust maintainer binds
+ * neumann_gpu.h directly; this header is the test/embedding surface of the mirror.
+ *
+ * Every search entry point validates exactly as the reference does (EmptyVector, InvalidTopK,
+ * max_dimension, collection dimension, zero-magnitude query, deadline), then runs on the GPU mirror of
+ * the affected collection.  The mirror is a derived cache with the lifecycle of the reference's
+ * `hnsw_cache` (lib.rs:98,1156,1311-1328): built lazily on first search, dropped by every
+ * store/delete in that collection (lib.rs:1497,1532,1866,1923).
+ *
+ * Status codes are the nmn_status values of neumann_gpu.h; `nmn_engine_last_error()` returns the
+ * reference's `Display` text of the VectorError (e.g. "Dimension mismatch: expected 3, got 2").
+ */
+#ifndef NEUMANN_ENGINE_H
+#define NEUMANN_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "neumann_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmn_engine nmn_engine;
+typedef struct nmn_results nmn_results; /* Vec<SearchResult> */
+typedef struct nmn_filter nmn_filter;   /* FilterCondition (lib.rs:296-324) */
+typedef struct nmn_strlist nmn_strlist; /* Vec<String> */
+
+/* VectorEngineConfig (lib.rs:626-664); 0 / negative = None where the reference has Option. */
+typedef struct nmn_engine_config {
+    uint64_t default_dimension;  /* 0 = None */
+    float sparse_threshold;      /* 0.5 (storage format only; scoring is unaffected) */
+    uint64_t parallel_threshold; /* 5000: kept for API parity, the GPU path has no sequential mode */
+    int32_t default_metric;      /* nmn_metric */
+    uint64_t max_dimension;      /* 0 = None */
+    uint64_t max_keys_per_scan;  /* 0 = None */
+    int64_t search_timeout_ms;   /* <0 = None */
+    int32_t device;              /* GPU ordinal, -1 = current (new knob, additive) */
+    uint32_t cand_cap;           /* 0 = default (new knob, additive) */
+} nmn_engine_config;
+
+/* ScalarValue / FilterValue payload (tensor_store ScalarValue; lib.rs:342-353). */
+#define NMN_VAL_NULL 0
+#define NMN_VAL_BOOL 1
+#define NMN_VAL_INT 2
+#define NMN_VAL_FLOAT 3
+#define NMN_VAL_STRING 4
+typedef struct nmn_value {
+    int32_t kind;
+    int32_t b;
+    int64_t i;
+    double f;
+    const char* s;
+} nmn_value;
+typedef struct nmn_meta_field {
+    const char* name;
+    nmn_value value;
+} nmn_meta_field;
+
+/* FilterStrategy (lib.rs:386-397) / FilteredSearchConfig (lib.rs:399-449). */
+#define NMN_FILTER_AUTO 0
+#define NMN_FILTER_PRE 1
+#define NMN_FILTER_POST 2
+typedef struct nmn_filtered_config {
+    int32_t strategy;
+    float selectivity_threshold; /* 0.1 */
+    uint64_t oversample_factor;  /* 3 */
+} nmn_filtered_config;
+
+void nmn_engine_config_default(nmn_engine_config* c);
+void nmn_filtered_config_default(nmn_filtered_config* c);
+
+/* VectorEngine::new / with_config (lib.rs:1162-1203); config NULL = default. */
+nmn_status nmn_engine_create(const nmn_engine_config* config, nmn_engine** out);
+void nmn_engine_destroy(nmn_engine* e);
+const char* nmn_engine_last_error(void);
+
+/* store_embedding / store_embedding_with_metadata (lib.rs:1840-1868, 3272-3310) */
+nmn_status nmn_engine_store_embedding(nmn_engine* e, const char* key, const float* v, uint64_t dim);
+nmn_status nmn_engine_store_embedding_with_metadata(nmn_engine* e, const char* key, const float* v, uint64_t dim,
+                                                    const nmn_meta_field* meta, uint32_t n_meta);
+/* get_embedding (lib.rs:1895-1908): *dim_out receives the length; copies min(cap, len) floats. */
+nmn_status nmn_engine_get_embedding(nmn_engine* e, const char* key, float* out, uint64_t cap, uint64_t* dim_out);
+nmn_status nmn_engine_delete_embedding(nmn_engine* e, const char* key); /* lib.rs:1915-1925 */
+int32_t nmn_engine_exists(nmn_engine* e, const char* key);              /* lib.rs:1929-1932 */
+uint64_t nmn_engine_count(nmn_engine* e);                               /* lib.rs:1936-1938 */
+nmn_strlist* nmn_engine_list_keys(nmn_engine* e);                       /* lib.rs:2312-2319 */
+nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed);          /* lib.rs:2340-2352 */
+nmn_status nmn_engine_batch_store(nmn_engine* e, const char* const* keys, const float* rows, uint64_t n,
+                                  uint64_t dim); /* batch_store_embeddings (lib.rs:2865-2913), uniform dim */
+
+/* search_similar / search_similar_with_metric (lib.rs:1950-2101) */
+nmn_status nmn_engine_search_similar(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k,
+                                     nmn_results** out);
+nmn_status nmn_engine_search_similar_with_metric(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k,
+                                                 int32_t metric, nmn_results** out);
+/* search_similar_filtered (lib.rs:3429-3477); config NULL = default */
+nmn_status nmn_engine_search_similar_filtered(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k,
+                                              const nmn_filter* filter, const nmn_filtered_config* config,
+                                              nmn_results** out);
+/* compute_similarity (lib.rs:2278-2295) — scored by the exact GPU kernel */
+nmn_status nmn_engine_compute_similarity(nmn_engine* e, const float* a, uint64_t na, const float* b, uint64_t nb,
+                                         float* out);
+
+/* collections (lib.rs:1369-1582) */
+nmn_status nmn_engine_create_collection(nmn_engine* e, const char* name, uint64_t dimension /*0=None*/,
+                                        int32_t metric);
+nmn_status nmn_engine_delete_collection(nmn_engine* e, const char* name);
+int32_t nmn_engine_collection_exists(nmn_engine* e, const char* name);
+uint64_t nmn_engine_collection_count(nmn_engine* e, const char* name);
+nmn_strlist* nmn_engine_list_collections(nmn_engine* e);
+nmn_status nmn_engine_store_in_collection(nmn_engine* e, const char* coll, const char* key, const float* v,
+                                          uint64_t dim, const nmn_meta_field* meta, uint32_t n_meta);
+nmn_status nmn_engine_get_from_collection(nmn_engine* e, const char* coll, const char* key, float* out,
+                                          uint64_t cap, uint64_t* dim_out);
+nmn_status nmn_engine_delete_from_collection(nmn_engine* e, const char* coll, const char* key);
+/* search_in_collection / search_filtered_in_collection (lib.rs:1585-1829) */
+nmn_status nmn_engine_search_in_collection(nmn_engine* e, const char* coll, const float* q, uint64_t dim,
+                                           uint64_t top_k, nmn_results** out);
+nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* coll, const float* q, uint64_t dim,
+                                                    uint64_t top_k, const nmn_filter* filter,
+                                                    const nmn_filtered_config* config, nmn_results** out);
+
+/* results */
+uint64_t nmn_results_len(const nmn_results* r);
+const char* nmn_results_key(const nmn_results* r, uint64_t i);
+float nmn_results_score(const nmn_results* r, uint64_t i);
+void nmn_results_free(nmn_results* r);
+uint64_t nmn_strlist_len(const nmn_strlist* l);
+const char* nmn_strlist_get(const nmn_strlist* l, uint64_t i);
+void nmn_strlist_free(nmn_strlist* l);
+
+/* FilterCondition builders (lib.rs:296-340); ops for nmn_filter_cmp */
+#define NMN_OP_EQ 0
+#define NMN_OP_NE 1
+#define NMN_OP_LT 2
+#define NMN_OP_LE 3
+#define NMN_OP_GT 4
+#define NMN_OP_GE 5
+nmn_filter* nmn_filter_cmp(int32_t op, const char* field, const nmn_value* value);
+nmn_filter* nmn_filter_and(nmn_filter* a, nmn_filter* b); /* takes ownership of a and b */
+nmn_filter* nmn_filter_or(nmn_filter* a, nmn_filter* b);
+nmn_filter* nmn_filter_true(void);
+nmn_filter* nmn_filter_exists(const char* field);
+nmn_filter* nmn_filter_contains(const char* field, const char* substr);
+nmn_filter* nmn_filter_starts_with(const char* field, const char* prefix);
+nmn_filter* nmn_filter_in(const char* field, const nmn_value* values, uint32_t n);
+void nmn_filter_free(nmn_filter* f);
+/* count_matching / estimate_filter_selectivity (lib.rs:3698-3722) */
+uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f);
+
+/* Mirror bookkeeping (for the cache-protocol tests, lib.rs:9686-9944): number of GPU mirror builds
+ * so far and whether a mirror is currently cached for `coll` (NULL = default collection). */
+uint64_t nmn_engine_mirror_builds(nmn_engine* e);
+int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUMANN_ENGINE_H */

@@ -24,9 +24,9 @@ SOURCES = {
     "nmn_exact.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_synth.hip": ["-ffp-contract=off"],
     "nmn_api.hip": [],
-    "nmn_engine.cpp": ["-x", "hip"],
+    "nmn_engine.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["nmn_internal.h", "nmn_engine.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
+HEADERS = ["nmn_internal.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
            os.path.join("..", "..", "include", "neumann_engine.h")]
 
 

@@ -1,0 +1,921 @@
+// nmn_engine.cpp — host-side mirror of Neumann's `VectorEngine` for the SIMILAR TOP-K path
+// (C ABI: include/neumann_engine.h).  C++ because the reference is compiled code and the image has no
+// Rust toolchain; names, argument meaning, validation order and error texts follow
+// vector_engine/src/lib.rs (cited per function).  ALL scoring happens on the GPU through
+// include/neumann_gpu.h; this file holds the key/value bookkeeping the reference keeps in
+// `TensorStore`, the validation rules, the metadata predicate evaluator and the GPU-mirror cache.
+//
+// Built with -ffp-contract=off: the zero-magnitude-query rule needs `simd::magnitude(query)` in
+// reference order on the host (validation, not the hot path).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/neumann_engine.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+nmn_status fail(nmn_status code, std::string msg) {
+    g_err = std::move(msg);
+    return code;
+}
+// Display texts of VectorError (lib.rs:151-183)
+nmn_status err_not_found(const std::string& key) { return fail(NMN_ERR_NOT_FOUND, "Embedding not found: " + key); }
+nmn_status err_dim(uint64_t expected, uint64_t got) {
+    return fail(NMN_ERR_DIMENSION_MISMATCH,
+                "Dimension mismatch: expected " + std::to_string(expected) + ", got " + std::to_string(got));
+}
+nmn_status err_empty() { return fail(NMN_ERR_EMPTY_VECTOR, "Empty vector provided"); }
+nmn_status err_topk() { return fail(NMN_ERR_INVALID_TOP_K, "Invalid top_k value (must be > 0)"); }
+nmn_status err_timeout(const char* op, int64_t ms) {
+    return fail(NMN_ERR_SEARCH_TIMEOUT, std::string("search timeout: ") + op + " exceeded " + std::to_string(ms) + "ms");
+}
+nmn_status err_gpu(nmn_status st) {
+    // StorageError(String) carries the shim's message (lib.rs:185-189: From<TensorStoreError>)
+    const char* detail = nmn_last_error();
+    return fail(st, std::string("Storage error: ") + nmn_status_str(st) + (detail && *detail ? std::string(": ") + detail : ""));
+}
+
+// ---- ScalarValue / FilterValue -------------------------------------------------------------------
+struct Value {
+    int kind = NMN_VAL_NULL;
+    bool b = false;
+    int64_t i = 0;
+    double f = 0.0;
+    std::string s;
+    static Value from(const nmn_value& v) {
+        Value o;
+        o.kind = v.kind;
+        o.b = v.b != 0;
+        o.i = v.i;
+        o.f = v.f;
+        if (v.kind == NMN_VAL_STRING && v.s) o.s = v.s;
+        return o;
+    }
+};
+
+// compare_tensor_value_to_filter (lib.rs:3648-3670): ordering if the types are compatible.
+// returns false when incomparable; *ord = -1/0/+1 otherwise.
+bool compare_values(const Value& stored, const Value& flt, int* ord) {
+    auto cmp3 = [](auto a, auto b) { return a < b ? -1 : (a > b ? 1 : 0); };
+    if (stored.kind == NMN_VAL_INT && flt.kind == NMN_VAL_INT) { *ord = cmp3(stored.i, flt.i); return true; }
+    if (stored.kind == NMN_VAL_FLOAT && flt.kind == NMN_VAL_FLOAT) {
+        if (std::isnan(stored.f) || std::isnan(flt.f)) return false;  // partial_cmp -> None
+        *ord = cmp3(stored.f, flt.f); return true;
+    }
+    if (stored.kind == NMN_VAL_FLOAT && flt.kind == NMN_VAL_INT) {
+        if (std::isnan(stored.f)) return false;
+        *ord = cmp3(stored.f, (double)flt.i); return true;
+    }
+    if (stored.kind == NMN_VAL_INT && flt.kind == NMN_VAL_FLOAT) {
+        if (std::isnan(flt.f)) return false;
+        *ord = cmp3((double)stored.i, flt.f); return true;
+    }
+    if (stored.kind == NMN_VAL_STRING && flt.kind == NMN_VAL_STRING) { *ord = cmp3(stored.s.compare(flt.s), 0); return true; }
+    if (stored.kind == NMN_VAL_BOOL && flt.kind == NMN_VAL_BOOL) { *ord = cmp3((int)stored.b, (int)flt.b); return true; }
+    if (stored.kind == NMN_VAL_NULL && flt.kind == NMN_VAL_NULL) { *ord = 0; return true; }
+    return false;
+}
+
+}  // namespace
+
+// FilterCondition (lib.rs:296-324)
+struct nmn_filter {
+    enum Kind { Cmp, And, Or, True, Exists, Contains, StartsWith, In } kind = True;
+    int op = NMN_OP_EQ;
+    std::string field, text;
+    Value value;
+    std::vector<Value> values;
+    std::unique_ptr<nmn_filter> a, b;
+};
+
+struct nmn_results {
+    std::vector<std::string> keys;
+    std::vector<float> scores;
+};
+struct nmn_strlist {
+    std::vector<std::string> items;
+};
+
+namespace {
+
+using Meta = std::map<std::string, Value>;
+
+// evaluate_filter (lib.rs:3592-3630)
+bool evaluate_filter(const Meta& meta, const nmn_filter& f) {
+    switch (f.kind) {
+        case nmn_filter::True: return true;
+        case nmn_filter::And: return evaluate_filter(meta, *f.a) && evaluate_filter(meta, *f.b);
+        case nmn_filter::Or: return evaluate_filter(meta, *f.a) || evaluate_filter(meta, *f.b);
+        case nmn_filter::Exists: return meta.count(f.field) != 0;
+        case nmn_filter::Cmp: {
+            auto it = meta.find(f.field);
+            if (it == meta.end()) return false;
+            int ord = 0;
+            if (!compare_values(it->second, f.value, &ord)) return false;
+            switch (f.op) {
+                case NMN_OP_EQ: return ord == 0;
+                case NMN_OP_NE: return ord != 0;
+                case NMN_OP_LT: return ord < 0;
+                case NMN_OP_LE: return ord <= 0;
+                case NMN_OP_GT: return ord > 0;
+                default: return ord >= 0;
+            }
+        }
+        case nmn_filter::Contains: {
+            auto it = meta.find(f.field);
+            return it != meta.end() && it->second.kind == NMN_VAL_STRING && it->second.s.find(f.text) != std::string::npos;
+        }
+        case nmn_filter::StartsWith: {
+            auto it = meta.find(f.field);
+            return it != meta.end() && it->second.kind == NMN_VAL_STRING && it->second.s.compare(0, f.text.size(), f.text) == 0;
+        }
+        case nmn_filter::In: {
+            auto it = meta.find(f.field);
+            if (it == meta.end()) return false;
+            for (const auto& v : f.values) {
+                int ord = 0;
+                if (compare_values(it->second, v, &ord) && ord == 0) return true;
+            }
+            return false;
+        }
+    }
+    return false;
+}
+
+// simd::sum_of_squares in reference order (hnsw.rs:198-222) — host-side, validation only.
+float sumsq8_host(const float* v, uint64_t n) {
+    const uint64_t chunks = n / 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint64_t c = 0; c < chunks; c++)
+        for (int l = 0; l < 8; l++) {
+            const float p = v[8 * c + l] * v[8 * c + l];
+            acc[l] = acc[l] + p;
+        }
+    float r = -0.0f;
+    for (int l = 0; l < 8; l++) r = r + acc[l];
+    for (uint64_t i = chunks * 8; i < n; i++) {
+        const float p = v[i] * v[i];
+        r = r + p;
+    }
+    return r;
+}
+bool zero_magnitude(const float* q, uint64_t n) { return std::sqrt(sumsq8_host(q, n)) == 0.0f; }
+
+struct Entry {
+    std::string key;
+    std::vector<float> vec;
+    Meta meta;
+    bool live = false;
+};
+
+// GPU mirror of the rows of one collection that have one dimension: the `hnsw_cache` slot of the
+// reference (lib.rs:98,1311-1328) with a flat GPU index instead of an HNSW graph.
+struct Mirror {
+    nmn_index* idx = nullptr;
+    std::vector<uint32_t> row_to_slot;
+    ~Mirror() {
+        if (idx) nmn_index_destroy(idx);
+    }
+};
+
+struct Collection {
+    std::vector<Entry> slots;
+    std::unordered_map<std::string, uint32_t> by_key;
+    std::vector<uint32_t> free_slots;
+    uint64_t live = 0;
+    std::unordered_map<uint64_t, std::unique_ptr<Mirror>> mirrors;  // by dimension
+    void invalidate() { mirrors.clear(); }
+};
+
+struct CollectionConfig {
+    uint64_t dimension = 0;  // 0 = None
+    int32_t metric = NMN_METRIC_COSINE;
+};
+
+struct Deadline {  // lib.rs:216-249
+    bool has = false;
+    std::chrono::steady_clock::time_point at;
+    int64_t ms = 0;
+    explicit Deadline(int64_t timeout_ms) {
+        if (timeout_ms >= 0) {
+            has = true;
+            ms = timeout_ms;
+            at = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+        }
+    }
+    bool expired() const { return has && std::chrono::steady_clock::now() >= at; }
+};
+
+}  // namespace
+
+struct nmn_engine {
+    nmn_engine_config cfg;
+    std::mutex mu;  // `&self` from many threads is safe; operations are serialised
+    Collection dflt;
+    std::map<std::string, Collection> colls;          // storage of named collections
+    std::map<std::string, CollectionConfig> configs;  // `collections` map (configured ones only)
+    uint64_t mirror_builds = 0;
+    std::unordered_map<uint64_t, std::unique_ptr<Mirror>> scratch;  // compute_similarity, by dim
+
+    Collection* storage(const char* coll, bool create) {
+        if (!coll) return &dflt;
+        auto it = colls.find(coll);
+        if (it != colls.end()) return &it->second;
+        if (!create) return nullptr;
+        return &colls[coll];
+    }
+};
+
+namespace {
+
+nmn_status store_into(nmn_engine* e, Collection* c, const char* key, const float* v, uint64_t dim,
+                      const nmn_meta_field* meta, uint32_t n_meta) {
+    Entry ent;
+    ent.key = key;
+    ent.vec.assign(v, v + dim);
+    for (uint32_t i = 0; i < n_meta; i++)
+        if (meta[i].name) ent.meta[meta[i].name] = Value::from(meta[i].value);
+    ent.live = true;
+    auto it = c->by_key.find(ent.key);
+    if (it != c->by_key.end()) {
+        c->slots[it->second] = std::move(ent);  // put() overwrites the whole TensorData
+    } else {
+        uint32_t slot;
+        if (!c->free_slots.empty()) {
+            slot = c->free_slots.back();
+            c->free_slots.pop_back();
+            c->slots[slot] = std::move(ent);
+        } else {
+            slot = (uint32_t)c->slots.size();
+            c->slots.push_back(std::move(ent));
+        }
+        c->by_key[c->slots[slot].key] = slot;
+        c->live++;
+    }
+    c->invalidate();  // invalidate_hnsw_cache(collection) (lib.rs:1497,1866)
+    (void)e;
+    return NMN_OK;
+}
+
+nmn_status delete_from(Collection* c, const std::string& key, const std::string& shown) {
+    auto it = c->by_key.find(key);
+    if (it == c->by_key.end()) return err_not_found(shown);
+    Entry& ent = c->slots[it->second];
+    ent = Entry();
+    c->free_slots.push_back(it->second);
+    c->by_key.erase(it);
+    c->live--;
+    c->invalidate();  // lib.rs:1532,1923
+    return NMN_OK;
+}
+
+// Lazily (re)build the GPU mirror of the rows of `c` with dimension `dim`.
+nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) {
+    auto it = c->mirrors.find(dim);
+    if (it != c->mirrors.end()) {
+        *out = it->second.get();
+        return NMN_OK;
+    }
+    auto m = std::make_unique<Mirror>();
+    uint64_t n = 0;
+    for (const auto& ent : c->slots)
+        if (ent.live && ent.vec.size() == dim) n++;  // `if stored_vec.len() != query.len() { return None }`
+    if (n > 0) {
+        nmn_index_desc d{};
+        d.dim = (uint32_t)dim;
+        d.capacity_rows = n;
+        d.row_base = 0;
+        d.device = e->cfg.device;
+        d.cand_cap = e->cfg.cand_cap;
+        nmn_status st = nmn_index_create(&d, &m->idx);
+        if (st != NMN_OK) return err_gpu(st);
+        m->row_to_slot.reserve(n);
+        // stage in chunks so the host copy stays small next to the store itself
+        const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (dim * sizeof(float)));
+        std::vector<float> buf;
+        buf.reserve((size_t)std::min(chunk, n) * dim);
+        uint64_t row0 = 0;
+        auto flush = [&]() -> nmn_status {
+            if (buf.empty()) return NMN_OK;
+            const uint64_t cnt = buf.size() / dim;
+            nmn_status s2 = nmn_index_upload(m->idx, buf.data(), row0, cnt);
+            row0 += cnt;
+            buf.clear();
+            return s2;
+        };
+        for (uint32_t s = 0; s < c->slots.size(); s++) {
+            const Entry& ent = c->slots[s];
+            if (!ent.live || ent.vec.size() != dim) continue;
+            buf.insert(buf.end(), ent.vec.begin(), ent.vec.end());
+            m->row_to_slot.push_back(s);
+            if (buf.size() >= chunk * dim) {
+                st = flush();
+                if (st != NMN_OK) return err_gpu(st);
+            }
+        }
+        st = flush();
+        if (st != NMN_OK) return err_gpu(st);
+    }
+    e->mirror_builds++;
+    *out = m.get();
+    c->mirrors[dim] = std::move(m);
+    return NMN_OK;
+}
+
+// Run the GPU search over a mirror and map rows back to keys.
+nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, int32_t metric,
+                    const std::vector<uint64_t>* mask, nmn_results* res) {
+    if (!m->idx) return NMN_OK;  // no rows of this dimension
+    const uint64_t rows = nmn_index_rows(m->idx);
+    uint64_t k = std::min<uint64_t>(top_k, rows);
+    if (k == 0) return NMN_OK;
+    if (k > NMN_MAX_TOP_K)
+        return fail(NMN_ERR_TOP_K_TOO_LARGE, "top_k exceeds NMN_MAX_TOP_K (4096) on a collection larger than that");
+    std::vector<uint64_t> out_rows(k);
+    std::vector<float> out_scores(k);
+    uint32_t count = 0;
+    nmn_status st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, mask ? mask->data() : nullptr,
+                                     out_rows.data(), out_scores.data(), &count, nullptr);
+    if (st != NMN_OK) return err_gpu(st);
+    for (uint32_t i = 0; i < count; i++) {
+        res->keys.push_back(c->slots[m->row_to_slot[out_rows[i]]].key);
+        res->scores.push_back(out_scores[i]);
+    }
+    return NMN_OK;
+}
+
+// shared body of search_similar / search_similar_with_metric / search_in_collection
+nmn_status search_common(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
+                         const char* op, const Deadline& dl, const std::vector<uint64_t>* mask_rows_of_mirror,
+                         Mirror* prebuilt, nmn_results* res) {
+    Mirror* m = prebuilt;
+    if (!m) {
+        nmn_status st = get_mirror(e, c, dim, &m);  // "let keys = self.store.scan(prefix)" stage
+        if (st != NMN_OK) return st;
+    }
+    if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2005-2010
+    nmn_status st = gpu_topk(c, m, q, top_k, metric, mask_rows_of_mirror, res);
+    if (st != NMN_OK) return st;
+    if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2019-2024
+    return NMN_OK;
+}
+
+nmn_status validate_query(const nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, bool check_max_dim) {
+    if (!q || dim == 0) return err_empty();          // query.is_empty() first (lib.rs:1953)
+    if (top_k == 0) return err_topk();               // then top_k (lib.rs:1956)
+    if (check_max_dim && e->cfg.max_dimension && dim > e->cfg.max_dimension)
+        return err_dim(e->cfg.max_dimension, dim);   // lib.rs:1960-1967
+    return NMN_OK;
+}
+
+nmn_results* new_results() { return new (std::nothrow) nmn_results(); }
+
+// Pre-filter strategy (lib.rs:3514-3557 / 1776-1796): predicate on the host metadata -> row bitmap of
+// the mirror -> masked GPU scan.  Exact.
+nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k,
+                             const nmn_filter& f, const char* op, const Deadline& dl, nmn_results* res) {
+    Mirror* m = nullptr;
+    nmn_status st = get_mirror(e, c, dim, &m);
+    if (st != NMN_OK) return st;
+    if (!m->idx) return NMN_OK;
+    const uint64_t rows = m->row_to_slot.size();
+    std::vector<uint64_t> mask((rows + 63) / 64, 0ull);
+    uint64_t matching = 0;
+    for (uint64_t r = 0; r < rows; r++)
+        if (evaluate_filter(c->slots[m->row_to_slot[r]].meta, f)) {
+            mask[r >> 6] |= 1ull << (r & 63);
+            matching++;
+        }
+    if (matching == 0) return NMN_OK;
+    return search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &mask, m, res);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+void nmn_engine_config_default(nmn_engine_config* c) {  // lib.rs:648-664
+    if (!c) return;
+    c->default_dimension = 0;
+    c->sparse_threshold = 0.5f;
+    c->parallel_threshold = 5000;
+    c->default_metric = NMN_METRIC_COSINE;
+    c->max_dimension = 0;
+    c->max_keys_per_scan = 0;
+    c->search_timeout_ms = -1;
+    c->device = -1;
+    c->cand_cap = 0;
+}
+
+void nmn_filtered_config_default(nmn_filtered_config* c) {  // lib.rs:412-420
+    if (!c) return;
+    c->strategy = NMN_FILTER_AUTO;
+    c->selectivity_threshold = 0.1f;
+    c->oversample_factor = 3;
+}
+
+const char* nmn_engine_last_error(void) { return g_err.c_str(); }
+
+nmn_status nmn_engine_create(const nmn_engine_config* config, nmn_engine** out) {
+    if (!out) return fail(NMN_ERR_INVALID_ARGUMENT, "out is null");
+    nmn_engine* e = new (std::nothrow) nmn_engine();
+    if (!e) return fail(NMN_ERR_OUT_OF_MEMORY, "engine alloc");
+    if (config) e->cfg = *config;
+    else nmn_engine_config_default(&e->cfg);
+    // VectorEngineConfig::validate (lib.rs:710-740)
+    if (!(e->cfg.sparse_threshold >= 0.0f && e->cfg.sparse_threshold <= 1.0f)) {
+        delete e;
+        return fail(NMN_ERR_CONFIGURATION, "Configuration error: sparse_threshold must be between 0.0 and 1.0");
+    }
+    if (e->cfg.parallel_threshold == 0) {
+        delete e;
+        return fail(NMN_ERR_CONFIGURATION, "Configuration error: parallel_threshold must be greater than 0");
+    }
+    *out = e;
+    return NMN_OK;
+}
+
+void nmn_engine_destroy(nmn_engine* e) { delete e; }
+
+nmn_status nmn_engine_store_embedding_with_metadata(nmn_engine* e, const char* key, const float* v, uint64_t dim,
+                                                    const nmn_meta_field* meta, uint32_t n_meta) {
+    if (!e || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v || dim == 0) return err_empty();  // lib.rs:1841-1843
+    if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);
+    std::lock_guard<std::mutex> g(e->mu);
+    return store_into(e, &e->dflt, key, v, dim, meta, n_meta);
+}
+
+nmn_status nmn_engine_store_embedding(nmn_engine* e, const char* key, const float* v, uint64_t dim) {
+    return nmn_engine_store_embedding_with_metadata(e, key, v, dim, nullptr, 0);
+}
+
+nmn_status nmn_engine_batch_store(nmn_engine* e, const char* const* keys, const float* rows, uint64_t n,
+                                  uint64_t dim) {
+    if (!e || !keys || (!rows && n)) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (n && dim == 0) return err_empty();
+    if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);
+    std::lock_guard<std::mutex> g(e->mu);
+    for (uint64_t i = 0; i < n; i++) {
+        if (!keys[i]) return fail(NMN_ERR_INVALID_ARGUMENT, "null key");
+        store_into(e, &e->dflt, keys[i], rows + i * dim, dim, nullptr, 0);
+    }
+    return NMN_OK;
+}
+
+static nmn_status get_from(Collection* c, const std::string& key, const std::string& shown, float* out, uint64_t cap,
+                           uint64_t* dim_out) {
+    if (!c) return err_not_found(shown);
+    auto it = c->by_key.find(key);
+    if (it == c->by_key.end()) return err_not_found(shown);
+    const Entry& ent = c->slots[it->second];
+    if (dim_out) *dim_out = ent.vec.size();
+    if (out) memcpy(out, ent.vec.data(), std::min<uint64_t>(cap, ent.vec.size()) * sizeof(float));
+    return NMN_OK;
+}
+
+nmn_status nmn_engine_get_embedding(nmn_engine* e, const char* key, float* out, uint64_t cap, uint64_t* dim_out) {
+    if (!e || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    return get_from(&e->dflt, key, key, out, cap, dim_out);
+}
+
+nmn_status nmn_engine_delete_embedding(nmn_engine* e, const char* key) {
+    if (!e || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    return delete_from(&e->dflt, key, key);
+}
+
+int32_t nmn_engine_exists(nmn_engine* e, const char* key) {
+    if (!e || !key) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->dflt.by_key.count(key) ? 1 : 0;
+}
+
+uint64_t nmn_engine_count(nmn_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->dflt.live;
+}
+
+nmn_strlist* nmn_engine_list_keys(nmn_engine* e) {
+    nmn_strlist* l = new (std::nothrow) nmn_strlist();
+    if (!e || !l) return l;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (const auto& ent : e->dflt.slots)
+        if (ent.live) l->items.push_back(ent.key);
+    return l;
+}
+
+nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed) {
+    if (!e) return fail(NMN_ERR_INVALID_ARGUMENT, "null engine");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (removed) *removed = e->dflt.live;
+    e->dflt = Collection();
+    return NMN_OK;
+}
+
+// ---- searches ------------------------------------------------------------------------------------
+nmn_status nmn_engine_search_similar_with_metric(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k,
+                                                 int32_t metric, nmn_results** out) {
+    if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    nmn_status st = validate_query(e, q, dim, top_k, /*check_max_dim=*/false);  // lib.rs:2056-2061
+    if (st != NMN_OK) return st;
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    // zero-magnitude queries: empty for cosine/dot, scored for euclidean (lib.rs:2063-2068)
+    if (!(zero_magnitude(q, dim) && metric != NMN_METRIC_EUCLIDEAN)) {
+        std::lock_guard<std::mutex> g(e->mu);
+        st = search_common(e, &e->dflt, q, dim, top_k, metric, "search_similar_with_metric", dl, nullptr, nullptr, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+nmn_status nmn_engine_search_similar(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, nmn_results** out) {
+    if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    nmn_status st = validate_query(e, q, dim, top_k, /*check_max_dim=*/true);  // lib.rs:1953-1967
+    if (st != NMN_OK) return st;
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    if (!zero_magnitude(q, dim)) {  // lib.rs:1970-1974
+        std::lock_guard<std::mutex> g(e->mu);
+        st = search_common(e, &e->dflt, q, dim, top_k, NMN_METRIC_COSINE, "search_similar", dl, nullptr, nullptr, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+static int choose_strategy(Collection* c, const nmn_filter& f, const nmn_filtered_config& cfg) {
+    // choose_filter_strategy (lib.rs:3480-3511): True -> post; sample the first 100 keys
+    if (f.kind == nmn_filter::True) return NMN_FILTER_POST;
+    uint64_t sample = 0, matches = 0;
+    for (const auto& ent : c->slots) {
+        if (!ent.live) continue;
+        if (sample == 100) break;
+        sample++;
+        if (evaluate_filter(ent.meta, f)) matches++;
+    }
+    if (sample == 0) return NMN_FILTER_POST;
+    const float sel = (float)matches / (float)sample;
+    return sel < cfg.selectivity_threshold ? NMN_FILTER_PRE : NMN_FILTER_POST;
+}
+
+static nmn_status post_filter(Collection* c, const nmn_filter& f, nmn_results* cand, uint64_t top_k, bool truncate,
+                              nmn_results* res) {
+    for (size_t i = 0; i < cand->keys.size(); i++) {
+        auto it = c->by_key.find(cand->keys[i]);
+        if (it == c->by_key.end()) continue;
+        if (!evaluate_filter(c->slots[it->second].meta, f)) continue;
+        if (truncate && res->keys.size() >= top_k) break;  // `.take(top_k)`
+        res->keys.push_back(cand->keys[i]);
+        res->scores.push_back(cand->scores[i]);
+    }
+    return NMN_OK;
+}
+
+nmn_status nmn_engine_search_similar_filtered(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k,
+                                              const nmn_filter* filter, const nmn_filtered_config* config,
+                                              nmn_results** out) {
+    if (!e || !out || !filter) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    nmn_status st = validate_query(e, q, dim, top_k, true);  // lib.rs:3438-3453
+    if (st != NMN_OK) return st;
+    nmn_filtered_config cfg;
+    if (config) cfg = *config;
+    else nmn_filtered_config_default(&cfg);
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    std::lock_guard<std::mutex> g(e->mu);
+    int strategy = cfg.strategy == NMN_FILTER_AUTO ? choose_strategy(&e->dflt, *filter, cfg) : cfg.strategy;
+    if (dl.expired()) {
+        delete res;
+        return err_timeout("search_similar_filtered", dl.ms);
+    }
+    if (strategy == NMN_FILTER_POST) {
+        // search_with_post_filter (lib.rs:3560-3579): search_similar(k * oversample) then filter, take k
+        uint64_t over = top_k * cfg.oversample_factor;
+        if (cfg.oversample_factor && over / cfg.oversample_factor != top_k) over = UINT64_MAX;  // saturating_mul
+        over = std::max(over, top_k);
+        nmn_results cand;
+        if (!zero_magnitude(q, dim)) {
+            st = search_common(e, &e->dflt, q, dim, over, NMN_METRIC_COSINE, "search_similar", dl, nullptr, nullptr, &cand);
+            if (st != NMN_OK) {
+                delete res;
+                return st;
+            }
+        }
+        post_filter(&e->dflt, *filter, &cand, top_k, true, res);
+    } else if (!zero_magnitude(q, dim)) {  // search_with_pre_filter (lib.rs:3520-3523)
+        st = pre_filter_search(e, &e->dflt, q, dim, top_k, *filter, "search_similar_filtered", dl, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+nmn_status nmn_engine_compute_similarity(nmn_engine* e, const float* a, uint64_t na, const float* b, uint64_t nb,
+                                         float* out) {
+    if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!a || !b || na == 0 || nb == 0) return err_empty();  // lib.rs:2279-2281
+    if (na != nb) return err_dim(na, nb);                    // lib.rs:2282-2287
+    std::lock_guard<std::mutex> g(e->mu);
+    auto& slot = e->scratch[na];
+    if (!slot) {
+        slot = std::make_unique<Mirror>();
+        nmn_index_desc d{};
+        d.dim = (uint32_t)na;
+        d.capacity_rows = 1;
+        d.device = e->cfg.device;
+        nmn_status st = nmn_index_create(&d, &slot->idx);
+        if (st != NMN_OK) {
+            e->scratch.erase(na);
+            return err_gpu(st);
+        }
+    }
+    nmn_status st = nmn_index_upload(slot->idx, b, 0, 1);
+    if (st != NMN_OK) return err_gpu(st);
+    const uint64_t row = 0;
+    // a_magnitude == 0 -> 0.0 (lib.rs:2289-2292) is what the exact kernel returns for |q| == 0
+    st = nmn_index_score_rows(slot->idx, a, 1, NMN_METRIC_COSINE, &row, 1, out);
+    return st == NMN_OK ? NMN_OK : err_gpu(st);
+}
+
+// ---- collections ---------------------------------------------------------------------------------
+nmn_status nmn_engine_create_collection(nmn_engine* e, const char* name, uint64_t dimension, int32_t metric) {
+    if (!e || !name) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->configs.count(name)) return fail(NMN_ERR_COLLECTION_EXISTS, std::string("Collection already exists: ") + name);
+    e->configs[name] = CollectionConfig{dimension, metric};
+    return NMN_OK;
+}
+
+nmn_status nmn_engine_delete_collection(nmn_engine* e, const char* name) {
+    if (!e || !name) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->configs.count(name)) return fail(NMN_ERR_COLLECTION_NOT_FOUND, std::string("Collection not found: ") + name);
+    e->configs.erase(name);
+    e->colls.erase(name);  // "Delete all embeddings in the collection"
+    return NMN_OK;
+}
+
+int32_t nmn_engine_collection_exists(nmn_engine* e, const char* name) {
+    if (!e || !name) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->configs.count(name) ? 1 : 0;
+}
+
+uint64_t nmn_engine_collection_count(nmn_engine* e, const char* name) {
+    if (!e || !name) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    Collection* c = e->storage(name, false);
+    return c ? c->live : 0;
+}
+
+nmn_strlist* nmn_engine_list_collections(nmn_engine* e) {
+    nmn_strlist* l = new (std::nothrow) nmn_strlist();
+    if (!e || !l) return l;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (const auto& kv : e->configs) l->items.push_back(kv.first);
+    return l;
+}
+
+nmn_status nmn_engine_store_in_collection(nmn_engine* e, const char* coll, const char* key, const float* v,
+                                          uint64_t dim, const nmn_meta_field* meta, uint32_t n_meta) {
+    if (!e || !coll || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v || dim == 0) return err_empty();  // lib.rs:1454-1456
+    std::lock_guard<std::mutex> g(e->mu);
+    auto cit = e->configs.find(coll);
+    if (cit != e->configs.end() && cit->second.dimension && dim != cit->second.dimension)
+        return err_dim(cit->second.dimension, dim);  // lib.rs:1459-1469
+    if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);
+    return store_into(e, e->storage(coll, true), key, v, dim, meta, n_meta);
+}
+
+nmn_status nmn_engine_get_from_collection(nmn_engine* e, const char* coll, const char* key, float* out,
+                                          uint64_t cap, uint64_t* dim_out) {
+    if (!e || !coll || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    return get_from(e->storage(coll, false), key, std::string(coll) + ":" + key, out, cap, dim_out);
+}
+
+nmn_status nmn_engine_delete_from_collection(nmn_engine* e, const char* coll, const char* key) {
+    if (!e || !coll || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    Collection* c = e->storage(coll, false);
+    const std::string shown = std::string(coll) + ":" + key;
+    if (!c) return err_not_found(shown);
+    return delete_from(c, key, shown);
+}
+
+nmn_status nmn_engine_search_in_collection(nmn_engine* e, const char* coll, const float* q, uint64_t dim,
+                                           uint64_t top_k, nmn_results** out) {
+    if (!e || !out || !coll) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    nmn_status st = validate_query(e, q, dim, top_k, false);  // lib.rs:1593-1598
+    if (st != NMN_OK) return st;
+    std::lock_guard<std::mutex> g(e->mu);
+    int32_t metric = NMN_METRIC_COSINE;
+    auto cit = e->configs.find(coll);
+    if (cit != e->configs.end()) {
+        if (cit->second.dimension && dim != cit->second.dimension) return err_dim(cit->second.dimension, dim);
+        metric = cit->second.metric;  // lib.rs:1614-1616
+    }
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    Collection* c = e->storage(coll, false);
+    if (c && !(zero_magnitude(q, dim) && metric == NMN_METRIC_COSINE)) {  // lib.rs:1617-1620
+        st = search_common(e, c, q, dim, top_k, metric, "search_in_collection", dl, nullptr, nullptr, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* coll, const float* q, uint64_t dim,
+                                                    uint64_t top_k, const nmn_filter* filter,
+                                                    const nmn_filtered_config* config, nmn_results** out) {
+    if (!e || !out || !coll || !filter) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    nmn_status st = validate_query(e, q, dim, top_k, false);  // lib.rs:1708-1713
+    if (st != NMN_OK) return st;
+    nmn_filtered_config cfg;
+    if (config) cfg = *config;
+    else nmn_filtered_config_default(&cfg);
+    std::lock_guard<std::mutex> g(e->mu);
+    auto cit = e->configs.find(coll);
+    int32_t coll_metric = NMN_METRIC_COSINE;
+    if (cit != e->configs.end()) {
+        if (cit->second.dimension && dim != cit->second.dimension) return err_dim(cit->second.dimension, dim);
+        coll_metric = cit->second.metric;
+    }
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    Collection* c = e->storage(coll, false);
+    if (!c || zero_magnitude(q, dim)) {  // lib.rs:1729-1733
+        *out = res;
+        return NMN_OK;
+    }
+    int strategy = cfg.strategy;
+    if (strategy == NMN_FILTER_AUTO) {  // lib.rs:1737-1764 (no special case for True here)
+        uint64_t sample = 0, matches = 0;
+        for (const auto& ent : c->slots) {
+            if (!ent.live) continue;
+            if (sample == 100) break;
+            sample++;
+            if (evaluate_filter(ent.meta, *filter)) matches++;
+        }
+        strategy = (sample == 0 || !((float)matches / (float)sample < cfg.selectivity_threshold)) ? NMN_FILTER_POST
+                                                                                                  : NMN_FILTER_PRE;
+    }
+    if (dl.expired()) {
+        delete res;
+        return err_timeout("search_filtered_in_collection", dl.ms);
+    }
+    if (strategy == NMN_FILTER_POST) {
+        // lib.rs:1797-1813: search_in_collection(k*oversample) with the COLLECTION's metric, filter, then the
+        // common sort + truncate(k)
+        uint64_t over = top_k * cfg.oversample_factor;
+        if (cfg.oversample_factor && over / cfg.oversample_factor != top_k) over = UINT64_MAX;
+        over = std::max(over, top_k);
+        nmn_results cand;
+        st = search_common(e, c, q, dim, over, coll_metric, "search_in_collection", dl, nullptr, nullptr, &cand);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+        post_filter(c, *filter, &cand, top_k, false, res);
+        if (res->keys.size() > top_k) {  // results.truncate(top_k) — candidates are already sorted
+            res->keys.resize(top_k);
+            res->scores.resize(top_k);
+        }
+    } else {
+        st = pre_filter_search(e, c, q, dim, top_k, *filter, "search_filtered_in_collection", dl, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+    }
+    if (dl.expired()) {
+        delete res;
+        return err_timeout("search_filtered_in_collection", dl.ms);
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+// ---- results / lists / filters -------------------------------------------------------------------
+uint64_t nmn_results_len(const nmn_results* r) { return r ? r->keys.size() : 0; }
+const char* nmn_results_key(const nmn_results* r, uint64_t i) { return (r && i < r->keys.size()) ? r->keys[i].c_str() : nullptr; }
+float nmn_results_score(const nmn_results* r, uint64_t i) { return (r && i < r->scores.size()) ? r->scores[i] : NAN; }
+void nmn_results_free(nmn_results* r) { delete r; }
+uint64_t nmn_strlist_len(const nmn_strlist* l) { return l ? l->items.size() : 0; }
+const char* nmn_strlist_get(const nmn_strlist* l, uint64_t i) { return (l && i < l->items.size()) ? l->items[i].c_str() : nullptr; }
+void nmn_strlist_free(nmn_strlist* l) { delete l; }
+
+nmn_filter* nmn_filter_cmp(int32_t op, const char* field, const nmn_value* value) {
+    if (!field || !value || op < NMN_OP_EQ || op > NMN_OP_GE) return nullptr;
+    nmn_filter* f = new (std::nothrow) nmn_filter();
+    if (!f) return nullptr;
+    f->kind = nmn_filter::Cmp;
+    f->op = op;
+    f->field = field;
+    f->value = Value::from(*value);
+    return f;
+}
+static nmn_filter* binary(nmn_filter::Kind k, nmn_filter* a, nmn_filter* b) {
+    if (!a || !b) {
+        delete a;
+        delete b;
+        return nullptr;
+    }
+    nmn_filter* f = new (std::nothrow) nmn_filter();
+    if (!f) return nullptr;
+    f->kind = k;
+    f->a.reset(a);
+    f->b.reset(b);
+    return f;
+}
+nmn_filter* nmn_filter_and(nmn_filter* a, nmn_filter* b) { return binary(nmn_filter::And, a, b); }
+nmn_filter* nmn_filter_or(nmn_filter* a, nmn_filter* b) { return binary(nmn_filter::Or, a, b); }
+nmn_filter* nmn_filter_true(void) { return new (std::nothrow) nmn_filter(); }
+static nmn_filter* text_filter(nmn_filter::Kind k, const char* field, const char* text) {
+    if (!field) return nullptr;
+    nmn_filter* f = new (std::nothrow) nmn_filter();
+    if (!f) return nullptr;
+    f->kind = k;
+    f->field = field;
+    if (text) f->text = text;
+    return f;
+}
+nmn_filter* nmn_filter_exists(const char* field) { return text_filter(nmn_filter::Exists, field, nullptr); }
+nmn_filter* nmn_filter_contains(const char* field, const char* s) { return text_filter(nmn_filter::Contains, field, s); }
+nmn_filter* nmn_filter_starts_with(const char* field, const char* s) { return text_filter(nmn_filter::StartsWith, field, s); }
+nmn_filter* nmn_filter_in(const char* field, const nmn_value* values, uint32_t n) {
+    if (!field || (!values && n)) return nullptr;
+    nmn_filter* f = new (std::nothrow) nmn_filter();
+    if (!f) return nullptr;
+    f->kind = nmn_filter::In;
+    f->field = field;
+    for (uint32_t i = 0; i < n; i++) f->values.push_back(Value::from(values[i]));
+    return f;
+}
+void nmn_filter_free(nmn_filter* f) { delete f; }
+
+uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f) {
+    if (!e || !f) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    uint64_t n = 0;
+    for (const auto& ent : e->dflt.slots)
+        if (ent.live && evaluate_filter(ent.meta, *f)) n++;
+    return n;
+}
+
+uint64_t nmn_engine_mirror_builds(nmn_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->mirror_builds;
+}
+
+int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    Collection* c = e->storage(coll, false);
+    return (c && !c->mirrors.empty()) ? 1 : 0;
+}
+
+}  // extern "C"

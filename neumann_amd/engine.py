@@ -1,0 +1,471 @@
+"""Python face of the host-side `VectorEngine` mirror (include/neumann_engine.h).
+
+Method names, argument order, error types and messages follow the reference's public Rust API
+(vector_engine/src/lib.rs) so that the parity tests read like the reference's own tests:
+
+    engine = VectorEngine()
+    engine.store_embedding("a", [1.0, 0.0, 0.0])
+    results = engine.search_similar([1.0, 0.0, 0.0], 3)     # -> [SearchResult(key, score), ...]
+
+All logic lives in the C++ library; every search runs on the GPU (no CPU fallback).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from .flat_index import DistanceMetric
+
+vp = C.c_void_p
+
+
+class _EngineConfig(C.Structure):
+    _fields_ = [("default_dimension", C.c_uint64), ("sparse_threshold", C.c_float),
+                ("parallel_threshold", C.c_uint64), ("default_metric", C.c_int32),
+                ("max_dimension", C.c_uint64), ("max_keys_per_scan", C.c_uint64),
+                ("search_timeout_ms", C.c_int64), ("device", C.c_int32), ("cand_cap", C.c_uint32)]
+
+
+class _Value(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("b", C.c_int32), ("i", C.c_int64), ("f", C.c_double), ("s", C.c_char_p)]
+
+
+class _MetaField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("value", _Value)]
+
+
+class _FilteredConfig(C.Structure):
+    _fields_ = [("strategy", C.c_int32), ("selectivity_threshold", C.c_float), ("oversample_factor", C.c_uint64)]
+
+
+ENGINE_SIGNATURES = {
+    "nmn_engine_config_default": (None, [C.POINTER(_EngineConfig)]),
+    "nmn_filtered_config_default": (None, [C.POINTER(_FilteredConfig)]),
+    "nmn_engine_create": (C.c_int32, [C.POINTER(_EngineConfig), C.POINTER(vp)]),
+    "nmn_engine_destroy": (None, [vp]),
+    "nmn_engine_last_error": (C.c_char_p, []),
+    "nmn_engine_store_embedding": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64]),
+    "nmn_engine_store_embedding_with_metadata": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64,
+                                                             C.POINTER(_MetaField), C.c_uint32]),
+    "nmn_engine_get_embedding": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "nmn_engine_delete_embedding": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_exists": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_count": (C.c_uint64, [vp]),
+    "nmn_engine_list_keys": (vp, [vp]),
+    "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
+    "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
+    "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_search_similar_with_metric": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(vp)]),
+    "nmn_engine_search_similar_filtered": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, vp,
+                                                       C.POINTER(_FilteredConfig), C.POINTER(vp)]),
+    "nmn_engine_compute_similarity": (C.c_int32, [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_float)]),
+    "nmn_engine_create_collection": (C.c_int32, [vp, C.c_char_p, C.c_uint64, C.c_int32]),
+    "nmn_engine_delete_collection": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_collection_exists": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_collection_count": (C.c_uint64, [vp, C.c_char_p]),
+    "nmn_engine_list_collections": (vp, [vp]),
+    "nmn_engine_store_in_collection": (C.c_int32, [vp, C.c_char_p, C.c_char_p, vp, C.c_uint64,
+                                                   C.POINTER(_MetaField), C.c_uint32]),
+    "nmn_engine_get_from_collection": (C.c_int32, [vp, C.c_char_p, C.c_char_p, vp, C.c_uint64,
+                                                   C.POINTER(C.c_uint64)]),
+    "nmn_engine_delete_from_collection": (C.c_int32, [vp, C.c_char_p, C.c_char_p]),
+    "nmn_engine_search_in_collection": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_search_filtered_in_collection": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64, C.c_uint64, vp,
+                                                             C.POINTER(_FilteredConfig), C.POINTER(vp)]),
+    "nmn_results_len": (C.c_uint64, [vp]),
+    "nmn_results_key": (C.c_char_p, [vp, C.c_uint64]),
+    "nmn_results_score": (C.c_float, [vp, C.c_uint64]),
+    "nmn_results_free": (None, [vp]),
+    "nmn_strlist_len": (C.c_uint64, [vp]),
+    "nmn_strlist_get": (C.c_char_p, [vp, C.c_uint64]),
+    "nmn_strlist_free": (None, [vp]),
+    "nmn_filter_cmp": (vp, [C.c_int32, C.c_char_p, C.POINTER(_Value)]),
+    "nmn_filter_and": (vp, [vp, vp]),
+    "nmn_filter_or": (vp, [vp, vp]),
+    "nmn_filter_true": (vp, []),
+    "nmn_filter_exists": (vp, [C.c_char_p]),
+    "nmn_filter_contains": (vp, [C.c_char_p, C.c_char_p]),
+    "nmn_filter_starts_with": (vp, [C.c_char_p, C.c_char_p]),
+    "nmn_filter_in": (vp, [C.c_char_p, C.POINTER(_Value), C.c_uint32]),
+    "nmn_filter_free": (None, [vp]),
+    "nmn_engine_count_matching": (C.c_uint64, [vp, vp]),
+    "nmn_engine_mirror_builds": (C.c_uint64, [vp]),
+    "nmn_engine_mirror_cached": (C.c_int32, [vp, C.c_char_p]),
+}
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = _capi.load()
+    if not _bound:
+        for name, (res, args) in ENGINE_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bound = True
+    return lib
+
+
+class VectorError(Exception):
+    """vector_engine::VectorError (lib.rs:101-149).  `.kind` is the variant name, str() the Display text."""
+    KINDS = {
+        _capi.ERR_NOT_FOUND: "NotFound", _capi.ERR_DIMENSION_MISMATCH: "DimensionMismatch",
+        _capi.ERR_EMPTY_VECTOR: "EmptyVector", _capi.ERR_INVALID_TOP_K: "InvalidTopK",
+        _capi.ERR_STORAGE: "StorageError", _capi.ERR_CONFIGURATION: "ConfigurationError",
+        _capi.ERR_COLLECTION_EXISTS: "CollectionExists", _capi.ERR_COLLECTION_NOT_FOUND: "CollectionNotFound",
+        _capi.ERR_SEARCH_TIMEOUT: "SearchTimeout",
+    }
+
+    def __init__(self, status, message):
+        self.status = status
+        self.kind = self.KINDS.get(status, "StorageError")
+        super().__init__(message)
+
+
+def _check(status):
+    if status != _capi.OK:
+        raise VectorError(status, _lib().nmn_engine_last_error().decode(errors="replace"))
+
+
+@dataclass
+class SearchResult:
+    """vector_engine::SearchResult (lib.rs:252-266)."""
+    key: str
+    score: float
+
+
+@dataclass
+class VectorEngineConfig:
+    """vector_engine::VectorEngineConfig (lib.rs:626-664); None = the reference's Option::None."""
+    default_dimension: int = None
+    sparse_threshold: float = 0.5
+    parallel_threshold: int = 5000
+    default_metric: DistanceMetric = DistanceMetric.Cosine
+    max_dimension: int = None
+    max_keys_per_scan: int = None
+    search_timeout: float = None  # seconds
+    device: int = -1
+    cand_cap: int = 0
+
+
+@dataclass
+class VectorCollectionConfig:
+    """vector_engine::VectorCollectionConfig (lib.rs:455-499)."""
+    dimension: int = None
+    distance_metric: DistanceMetric = DistanceMetric.Cosine
+
+    def with_dimension(self, dim):
+        return VectorCollectionConfig(dim, self.distance_metric)
+
+    def with_metric(self, metric):
+        return VectorCollectionConfig(self.dimension, metric)
+
+
+class FilterStrategy:
+    Auto, PreFilter, PostFilter = 0, 1, 2
+
+
+@dataclass
+class FilteredSearchConfig:
+    """vector_engine::FilteredSearchConfig (lib.rs:399-449)."""
+    strategy: int = FilterStrategy.Auto
+    selectivity_threshold: float = 0.1
+    oversample_factor: int = 3
+
+    @staticmethod
+    def pre_filter():
+        return FilteredSearchConfig(FilterStrategy.PreFilter)
+
+    @staticmethod
+    def post_filter():
+        return FilteredSearchConfig(FilterStrategy.PostFilter)
+
+
+def _value(v):
+    out = _Value()
+    if v is None:
+        out.kind = 0
+    elif isinstance(v, bool):
+        out.kind, out.b = 1, int(v)
+    elif isinstance(v, (int, np.integer)):
+        out.kind, out.i = 2, int(v)
+    elif isinstance(v, (float, np.floating)):
+        out.kind, out.f = 3, float(v)
+    elif isinstance(v, str):
+        out.kind, out.s = 4, v.encode()
+    else:
+        raise TypeError(f"unsupported metadata/filter value {v!r}")
+    return out
+
+
+class FilterCondition:
+    """vector_engine::FilterCondition (lib.rs:296-340), built from the same constructors."""
+
+    def __init__(self, build):
+        self._build = build  # () -> owned nmn_filter*
+
+    @staticmethod
+    def _cmp(op, field, value):
+        def build():
+            v = _value(value)
+            return _lib().nmn_filter_cmp(op, field.encode(), C.byref(v))
+        return FilterCondition(build)
+
+    Eq = staticmethod(lambda f, v: FilterCondition._cmp(0, f, v))
+    Ne = staticmethod(lambda f, v: FilterCondition._cmp(1, f, v))
+    Lt = staticmethod(lambda f, v: FilterCondition._cmp(2, f, v))
+    Le = staticmethod(lambda f, v: FilterCondition._cmp(3, f, v))
+    Gt = staticmethod(lambda f, v: FilterCondition._cmp(4, f, v))
+    Ge = staticmethod(lambda f, v: FilterCondition._cmp(5, f, v))
+    TRUE = None  # set below
+
+    @staticmethod
+    def Exists(field):
+        return FilterCondition(lambda: _lib().nmn_filter_exists(field.encode()))
+
+    @staticmethod
+    def Contains(field, s):
+        return FilterCondition(lambda: _lib().nmn_filter_contains(field.encode(), s.encode()))
+
+    @staticmethod
+    def StartsWith(field, s):
+        return FilterCondition(lambda: _lib().nmn_filter_starts_with(field.encode(), s.encode()))
+
+    @staticmethod
+    def In(field, values):
+        def build():
+            arr = (_Value * max(len(values), 1))(*[_value(v) for v in values])
+            return _lib().nmn_filter_in(field.encode(), arr, len(values))
+        return FilterCondition(build)
+
+    def and_(self, other):
+        return FilterCondition(lambda: _lib().nmn_filter_and(self._build(), other._build()))
+
+    def or_(self, other):
+        return FilterCondition(lambda: _lib().nmn_filter_or(self._build(), other._build()))
+
+
+FilterCondition.TRUE = FilterCondition(lambda: _lib().nmn_filter_true())
+
+
+class _OwnedFilter:
+    def __init__(self, cond):
+        self.h = cond._build()
+        if not self.h:
+            raise ValueError("invalid filter")
+
+    def __enter__(self):
+        return self.h
+
+    def __exit__(self, *exc):
+        _lib().nmn_filter_free(self.h)
+
+
+def _vec(v):
+    a = np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+    return a, C.c_void_p(a.ctypes.data), a.size
+
+
+def _meta_array(metadata):
+    if not metadata:
+        return None, 0, None
+    keep = []
+    arr = (_MetaField * len(metadata))()
+    for i, (k, v) in enumerate(metadata.items()):
+        kb = k.encode()
+        keep.append(kb)
+        arr[i].name = kb
+        arr[i].value = _value(v)
+    return arr, len(metadata), keep
+
+
+class VectorEngine:
+    """Host-side mirror of vector_engine::VectorEngine for the SIMILAR TOP-K path."""
+
+    def __init__(self, config=None):
+        lib = _lib()
+        cfg = _EngineConfig()
+        lib.nmn_engine_config_default(C.byref(cfg))
+        if config is not None:
+            cfg.default_dimension = config.default_dimension or 0
+            cfg.sparse_threshold = config.sparse_threshold
+            cfg.parallel_threshold = config.parallel_threshold
+            cfg.default_metric = int(config.default_metric)
+            cfg.max_dimension = config.max_dimension or 0
+            cfg.max_keys_per_scan = config.max_keys_per_scan or 0
+            cfg.search_timeout_ms = -1 if config.search_timeout is None else int(config.search_timeout * 1000)
+            cfg.device = config.device
+            cfg.cand_cap = config.cand_cap
+        self._h = vp()
+        _check(lib.nmn_engine_create(C.byref(cfg), C.byref(self._h)))
+
+    @classmethod
+    def with_config(cls, config):
+        return cls(config)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().nmn_engine_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- results helpers ------------------------------------------------------------------------
+    @staticmethod
+    def _take_results(h):
+        lib = _lib()
+        try:
+            n = lib.nmn_results_len(h)
+            return [SearchResult(lib.nmn_results_key(h, i).decode(), float(np.float32(lib.nmn_results_score(h, i))))
+                    for i in range(n)]
+        finally:
+            lib.nmn_results_free(h)
+
+    @staticmethod
+    def _take_list(h):
+        lib = _lib()
+        try:
+            return [lib.nmn_strlist_get(h, i).decode() for i in range(lib.nmn_strlist_len(h))]
+        finally:
+            lib.nmn_strlist_free(h)
+
+    # -- default collection ---------------------------------------------------------------------
+    def store_embedding(self, key, vector):
+        a, p, n = _vec(vector)
+        _check(_lib().nmn_engine_store_embedding(self._h, key.encode(), p, n))
+
+    def store_embedding_with_metadata(self, key, vector, metadata):
+        a, p, n = _vec(vector)
+        arr, m, keep = _meta_array(metadata)
+        _check(_lib().nmn_engine_store_embedding_with_metadata(self._h, key.encode(), p, n, arr, m))
+
+    def batch_store_embeddings(self, keys, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        ks = (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+        _check(_lib().nmn_engine_batch_store(self._h, ks, C.c_void_p(rows.ctypes.data), rows.shape[0], rows.shape[1]))
+
+    def get_embedding(self, key):
+        dim = C.c_uint64()
+        _check(_lib().nmn_engine_get_embedding(self._h, key.encode(), None, 0, C.byref(dim)))
+        out = np.empty(dim.value, dtype=np.float32)
+        _check(_lib().nmn_engine_get_embedding(self._h, key.encode(), C.c_void_p(out.ctypes.data), out.size, C.byref(dim)))
+        return out
+
+    def delete_embedding(self, key):
+        _check(_lib().nmn_engine_delete_embedding(self._h, key.encode()))
+
+    def exists(self, key):
+        return bool(_lib().nmn_engine_exists(self._h, key.encode()))
+
+    def count(self):
+        return int(_lib().nmn_engine_count(self._h))
+
+    def list_keys(self):
+        return self._take_list(_lib().nmn_engine_list_keys(self._h))
+
+    def clear(self):
+        n = C.c_uint64()
+        _check(_lib().nmn_engine_clear(self._h, C.byref(n)))
+        return n.value
+
+    def search_similar(self, query, top_k):
+        a, p, n = _vec(query)
+        h = vp()
+        _check(_lib().nmn_engine_search_similar(self._h, p, n, int(top_k), C.byref(h)))
+        return self._take_results(h)
+
+    def search_similar_with_metric(self, query, top_k, metric):
+        a, p, n = _vec(query)
+        h = vp()
+        _check(_lib().nmn_engine_search_similar_with_metric(self._h, p, n, int(top_k), int(metric), C.byref(h)))
+        return self._take_results(h)
+
+    def search_similar_filtered(self, query, top_k, filter, config=None):
+        a, p, n = _vec(query)
+        h = vp()
+        cfg = None
+        if config is not None:
+            cfg = _FilteredConfig(config.strategy, config.selectivity_threshold, config.oversample_factor)
+        with _OwnedFilter(filter) as f:
+            _check(_lib().nmn_engine_search_similar_filtered(self._h, p, n, int(top_k), f,
+                                                             None if cfg is None else C.byref(cfg), C.byref(h)))
+        return self._take_results(h)
+
+    def compute_similarity(self, a, b):
+        a1, pa, na = _vec(a)
+        b1, pb, nb = _vec(b)
+        out = C.c_float()
+        _check(_lib().nmn_engine_compute_similarity(self._h, pa, na, pb, nb, C.byref(out)))
+        return float(np.float32(out.value))
+
+    def count_matching(self, filter):
+        with _OwnedFilter(filter) as f:
+            return int(_lib().nmn_engine_count_matching(self._h, f))
+
+    # -- collections ----------------------------------------------------------------------------
+    def create_collection(self, name, config=None):
+        config = config or VectorCollectionConfig()
+        _check(_lib().nmn_engine_create_collection(self._h, name.encode(), config.dimension or 0,
+                                                   int(config.distance_metric)))
+
+    def delete_collection(self, name):
+        _check(_lib().nmn_engine_delete_collection(self._h, name.encode()))
+
+    def collection_exists(self, name):
+        return bool(_lib().nmn_engine_collection_exists(self._h, name.encode()))
+
+    def collection_count(self, name):
+        return int(_lib().nmn_engine_collection_count(self._h, name.encode()))
+
+    def list_collections(self):
+        return self._take_list(_lib().nmn_engine_list_collections(self._h))
+
+    def store_in_collection(self, collection, key, vector):
+        self.store_in_collection_with_metadata(collection, key, vector, None)
+
+    def store_in_collection_with_metadata(self, collection, key, vector, metadata):
+        a, p, n = _vec(vector)
+        arr, m, keep = _meta_array(metadata)
+        _check(_lib().nmn_engine_store_in_collection(self._h, collection.encode(), key.encode(), p, n, arr, m))
+
+    def get_from_collection(self, collection, key):
+        dim = C.c_uint64()
+        _check(_lib().nmn_engine_get_from_collection(self._h, collection.encode(), key.encode(), None, 0, C.byref(dim)))
+        out = np.empty(dim.value, dtype=np.float32)
+        _check(_lib().nmn_engine_get_from_collection(self._h, collection.encode(), key.encode(),
+                                                     C.c_void_p(out.ctypes.data), out.size, C.byref(dim)))
+        return out
+
+    def delete_from_collection(self, collection, key):
+        _check(_lib().nmn_engine_delete_from_collection(self._h, collection.encode(), key.encode()))
+
+    def search_in_collection(self, collection, query, top_k):
+        a, p, n = _vec(query)
+        h = vp()
+        _check(_lib().nmn_engine_search_in_collection(self._h, collection.encode(), p, n, int(top_k), C.byref(h)))
+        return self._take_results(h)
+
+    def search_filtered_in_collection(self, collection, query, top_k, filter, config=None):
+        a, p, n = _vec(query)
+        h = vp()
+        cfg = None
+        if config is not None:
+            cfg = _FilteredConfig(config.strategy, config.selectivity_threshold, config.oversample_factor)
+        with _OwnedFilter(filter) as f:
+            _check(_lib().nmn_engine_search_filtered_in_collection(
+                self._h, collection.encode(), p, n, int(top_k), f, None if cfg is None else C.byref(cfg), C.byref(h)))
+        return self._take_results(h)
+
+    # -- mirror bookkeeping (cache protocol tests) ------------------------------------------------
+    def mirror_builds(self):
+        return int(_lib().nmn_engine_mirror_builds(self._h))
+
+    def mirror_cached(self, collection=None):
+        return bool(_lib().nmn_engine_mirror_cached(self._h, None if collection is None else collection.encode()))

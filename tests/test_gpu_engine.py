@@ -1,0 +1,449 @@
+"""The reference's own VectorEngine tests for the SIMILAR path, restated against the host-side mirror
+(neumann_amd.engine.VectorEngine -> C++ nmn_engine -> libneumann_gpu C ABI -> HIP kernels).
+Each test cites the reference test it follows (vector_engine/src/lib.rs)."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture
+def E():
+    from neumann_amd import engine
+    return engine
+
+
+def normalize(v):  # tests::normalize (lib.rs:4040-4047)
+    v = np.asarray(v, dtype=F)
+    s = F(0)
+    for x in v:
+        s = F(s + x * x)
+    mag = np.sqrt(s)
+    return v if mag == 0 else (v / mag).astype(F)
+
+
+def create_test_vector(dim, seed):  # tests::create_test_vector (lib.rs:4029-4038)
+    i = np.arange(dim, dtype=np.int64)
+    x = (seed * 31 + i * 17).astype(F)
+    return (np.sin(x * F(0.0001), dtype=F) * ((seed + i).astype(F) * F(0.001))).astype(F)
+
+
+# ---- basic CRUD + search (lib.rs:4049-4180) ---------------------------------------------------------
+def test_store_and_retrieve_embedding(E):  # lib.rs:4049-4059
+    engine = E.VectorEngine()
+    engine.store_embedding("test", [1.0, 2.0, 3.0])
+    assert np.array_equal(engine.get_embedding("test"), np.array([1, 2, 3], F))
+
+
+def test_store_overwrites_existing(E):  # lib.rs:4061-4070
+    engine = E.VectorEngine()
+    engine.store_embedding("key", [1.0, 2.0])
+    engine.store_embedding("key", [3.0, 4.0])
+    assert np.array_equal(engine.get_embedding("key"), np.array([3, 4], F))
+    assert engine.count() == 1
+
+
+def test_delete_embedding_and_errors(E):  # lib.rs:4072-4100
+    engine = E.VectorEngine()
+    engine.store_embedding("key", [1.0, 2.0])
+    engine.delete_embedding("key")
+    assert not engine.exists("key")
+    with pytest.raises(E.VectorError) as e:
+        engine.delete_embedding("missing")
+    assert e.value.kind == "NotFound" and str(e.value) == "Embedding not found: missing"
+    with pytest.raises(E.VectorError) as e:
+        engine.get_embedding("missing")
+    assert e.value.kind == "NotFound"
+    with pytest.raises(E.VectorError) as e:
+        engine.store_embedding("empty", [])
+    assert e.value.kind == "EmptyVector" and str(e.value) == "Empty vector provided"
+
+
+def test_search_similar_basic(E):  # lib.rs:4119-4135
+    engine = E.VectorEngine()
+    engine.store_embedding("a", [1.0, 0.0, 0.0])
+    engine.store_embedding("b", [0.0, 1.0, 0.0])
+    engine.store_embedding("c", [1.0, 1.0, 0.0])
+    results = engine.search_similar([1.0, 0.0, 0.0], 3)
+    assert len(results) == 3
+    assert results[0].key == "a" and abs(results[0].score - 1.0) < 1e-6
+
+
+def test_search_similar_top_k_and_errors(E):  # lib.rs:4137-4180
+    engine = E.VectorEngine()
+    for i in range(10):
+        engine.store_embedding(f"v{i}", [float(i), 1.0])
+    assert len(engine.search_similar([1.0, 1.0], 3)) == 3
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar([1.0, 1.0], 0)
+    assert e.value.kind == "InvalidTopK" and "Invalid top_k" in str(e.value)
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar([], 5)
+    assert e.value.kind == "EmptyVector"
+
+
+def test_compute_similarity_kats(E):  # lib.rs:4182-4239
+    engine = E.VectorEngine()
+    assert abs(engine.compute_similarity([1, 2, 3], [1, 2, 3]) - 1.0) < 1e-6
+    assert abs(engine.compute_similarity([1, 0], [0, 1])) < 1e-6
+    assert abs(engine.compute_similarity([1, 0], [-1, 0]) + 1.0) < 1e-6
+    a, b = normalize([1, 0]), normalize([1, 1])
+    assert abs(engine.compute_similarity(a, b) - np.sqrt(F(2)) / 2) < 1e-6
+    with pytest.raises(E.VectorError) as e:
+        engine.compute_similarity([1, 2], [1, 2, 3])
+    assert e.value.kind == "DimensionMismatch" and str(e.value) == "Dimension mismatch: expected 2, got 3"
+    assert engine.compute_similarity([0, 0], [1, 0]) == 0.0
+    s = engine.compute_similarity([0, 0], [0, 0])
+    assert s == 0.0 and not np.isnan(s)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(333).astype(F), rng.standard_normal(333).astype(F)
+    assert engine.compute_similarity(x, y) == float(oc.compute_similarity(x, y))  # bit-exact vs the oracle
+
+
+def test_search_skips_dimension_mismatch(E):  # lib.rs:4241-4253
+    engine = E.VectorEngine()
+    engine.store_embedding("2d", [1.0, 0.0])
+    engine.store_embedding("3d", [1.0, 0.0, 0.0])
+    results = engine.search_similar([1.0, 0.0], 10)
+    assert len(results) == 1 and results[0].key == "2d"
+
+
+def test_store_10000_vectors_search(E):  # lib.rs:4255-4276
+    engine = E.VectorEngine()
+    dim = 128
+    engine.batch_store_embeddings([f"v{i}" for i in range(10000)],
+                                  np.stack([create_test_vector(dim, i) for i in range(10000)]))
+    assert engine.count() == 10000
+    results = engine.search_similar(create_test_vector(dim, 5000), 5)
+    assert len(results) == 5
+    assert results[0].key == "v5000" and abs(results[0].score - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("dim,qseed,k", [(768, 50, 3), (1536, 75, 5), (4096, 10, 3)])  # lib.rs:4278-4312, 6021
+def test_high_dimensional(E, dim, qseed, k):
+    engine = E.VectorEngine()
+    for i in range(100):
+        engine.store_embedding(f"v{i}", create_test_vector(dim, i))
+    results = engine.search_similar(create_test_vector(dim, qseed), k)
+    assert len(results) == k and results[0].key == f"v{qseed}"
+
+
+def test_similarity_scores_mathematically_correct(E):  # lib.rs:4314-4352
+    engine = E.VectorEngine()
+    engine.store_embedding("unit_x", normalize([1, 0, 0]))
+    engine.store_embedding("unit_y", normalize([0, 1, 0]))
+    engine.store_embedding("unit_z", normalize([0, 0, 1]))
+    engine.store_embedding("diag_xy", normalize([1, 1, 0]))
+    engine.store_embedding("neg_x", normalize([-1, 0, 0]))
+    results = engine.search_similar(normalize([1, 0, 0]), 5)
+    assert len(results) == 5
+    for r in results:
+        if r.key == "unit_x":
+            assert abs(r.score - 1.0) < 1e-6
+        elif r.key in ("unit_y", "unit_z"):
+            assert abs(r.score) < 1e-6
+        elif r.key == "diag_xy":
+            assert abs(r.score - np.sqrt(2.0) / 2) < 1e-6
+        elif r.key == "neg_x":
+            assert abs(r.score + 1.0) < 1e-6
+        else:
+            raise AssertionError(r.key)
+
+
+def test_zero_query_and_empty_engine(E):  # lib.rs:4458-4473
+    engine = E.VectorEngine()
+    assert engine.search_similar([1.0, 0.0], 5) == []
+    engine.store_embedding("a", [1.0, 0.0])
+    assert engine.search_similar([0.0, 0.0], 5) == []
+
+
+def test_search_with_metric(E):  # lib.rs:4876-4970
+    M = E.DistanceMetric
+    engine = E.VectorEngine()
+    engine.store_embedding("a", [1.0, 0.0])
+    engine.store_embedding("b", [0.707, 0.707])
+    engine.store_embedding("c", [0.0, 1.0])
+    r = engine.search_similar_with_metric([1.0, 0.0], 3, M.Cosine)
+    assert len(r) == 3 and r[0].key == "a" and abs(r[0].score - 1.0) < 0.01
+
+    engine = E.VectorEngine()
+    engine.store_embedding("a", [1.0, 0.0])
+    engine.store_embedding("b", [2.0, 0.0])
+    engine.store_embedding("c", [0.5, 0.0])
+    r = engine.search_similar_with_metric([1.0, 0.0], 3, M.DotProduct)
+    assert r[0].key == "b" and abs(r[0].score - 2.0) < 0.01
+
+    engine = E.VectorEngine()
+    engine.store_embedding("a", [1.0, 0.0])
+    engine.store_embedding("b", [2.0, 0.0])
+    engine.store_embedding("c", [10.0, 0.0])
+    r = engine.search_similar_with_metric([1.0, 0.0], 3, M.Euclidean)
+    assert [x.key for x in r[:2]] == ["a", "b"] and abs(r[0].score - 1.0) < 0.01 and abs(r[1].score - 0.5) < 0.01
+
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar_with_metric([], 5, M.Cosine)
+    assert e.value.kind == "EmptyVector"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar_with_metric([1.0], 0, M.Cosine)
+    assert e.value.kind == "InvalidTopK"
+    assert engine.search_similar_with_metric([0.0, 0.0], 5, M.Cosine) == []
+
+    engine = E.VectorEngine()  # zero query is valid for Euclidean (lib.rs:4951-4970)
+    engine.store_embedding("origin", [0.0, 0.0])
+    engine.store_embedding("unit", [1.0, 0.0])
+    engine.store_embedding("far", [10.0, 0.0])
+    r = engine.search_similar_with_metric([0.0, 0.0], 3, M.Euclidean)
+    assert [x.key for x in r] == ["origin", "unit", "far"]
+    assert abs(r[0].score - 1.0) < 0.01 and abs(r[1].score - 0.5) < 0.01
+
+
+def test_engine_matches_oracle_on_random_corpus(E):
+    rng = np.random.default_rng(21)
+    n, d, k = 6000, 96, 40
+    A = rng.standard_normal((n, d)).astype(F)
+    A[rng.integers(0, n, 600)] *= 0.0  # zero rows (stored sparse by the reference; scored 0.0)
+    sp = rng.integers(0, n, 800)
+    A[sp, : d // 2 + 8] = 0.0          # >= 50 % zeros -> TensorValue::Sparse in the reference: exact either way
+    q = rng.standard_normal(d).astype(F)
+    engine = E.VectorEngine()
+    engine.batch_store_embeddings([f"k{i}" for i in range(n)], A)
+    for metric in E.DistanceMetric:
+        res = engine.search_similar_with_metric(q, k, metric)
+        er, es = oc.search(A, q, k, int(metric))
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+        assert np.all(np.array([r.score for r in res], F) == es)
+
+
+# ---- max_dimension / timeout (lib.rs:1960-1967, 2005-2024) --------------------------------------------
+def test_max_dimension_and_timeout(E):
+    engine = E.VectorEngine(E.VectorEngineConfig(max_dimension=4))
+    with pytest.raises(E.VectorError) as e:
+        engine.store_embedding("big", [1.0] * 5)
+    assert e.value.kind == "DimensionMismatch" and str(e.value) == "Dimension mismatch: expected 4, got 5"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar([1.0] * 5, 3)
+    assert e.value.kind == "DimensionMismatch"
+
+    engine = E.VectorEngine(E.VectorEngineConfig(search_timeout=0.0))  # expires immediately
+    engine.store_embedding("a", [1.0, 0.0])
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar([1.0, 0.0], 1)
+    assert e.value.kind == "SearchTimeout" and str(e.value) == "search timeout: search_similar exceeded 0ms"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar_with_metric([1.0, 0.0], 1, E.DistanceMetric.Euclidean)
+    assert "search_similar_with_metric" in str(e.value)
+    engine = E.VectorEngine(E.VectorEngineConfig(search_timeout=30.0))
+    engine.store_embedding("a", [1.0, 0.0])
+    assert engine.search_similar([1.0, 0.0], 1)[0].key == "a"
+    with pytest.raises(E.VectorError) as e:
+        E.VectorEngine(E.VectorEngineConfig(sparse_threshold=1.5))  # lib.rs:5174
+    assert e.value.kind == "ConfigurationError"
+
+
+# ---- mirror cache protocol (the hnsw_cache lifecycle, lib.rs:9686-9944) ------------------------------
+def test_mirror_built_lazily_and_invalidated_on_writes(E):
+    engine = E.VectorEngine()
+    for i in range(50):
+        engine.store_embedding(f"v{i}", [float(i + 1), 1.0, 0.5])
+    assert not engine.mirror_cached() and engine.mirror_builds() == 0
+    engine.search_similar([1.0, 1.0, 1.0], 3)
+    assert engine.mirror_cached() and engine.mirror_builds() == 1
+    engine.search_similar([2.0, 1.0, 1.0], 3)
+    engine.search_similar_with_metric([2.0, 1.0, 1.0], 3, E.DistanceMetric.Euclidean)
+    assert engine.mirror_builds() == 1                       # reused across searches and metrics
+    engine.store_embedding("new", [100.0, 1.0, 0.5])         # cache_invalidated_on_store
+    assert not engine.mirror_cached()
+    assert engine.search_similar([100.0, 1.0, 0.5], 1)[0].key == "new"
+    assert engine.mirror_builds() == 2
+    engine.delete_embedding("new")                           # cache_invalidated_on_delete
+    assert not engine.mirror_cached()
+    assert engine.search_similar([100.0, 1.0, 0.5], 1)[0].key != "new"
+    engine.store_in_collection("other", "x", [1.0, 2.0, 3.0])  # another collection leaves the default mirror alone
+    assert engine.mirror_cached() and not engine.mirror_cached("other")
+
+
+# ---- collections (lib.rs:7723-7960) ---------------------------------------------------------------------
+def test_collections(E):
+    engine = E.VectorEngine()
+    engine.create_collection("test", E.VectorCollectionConfig())
+    assert engine.collection_exists("test")
+    with pytest.raises(E.VectorError) as e:
+        engine.create_collection("test", E.VectorCollectionConfig())
+    assert e.value.kind == "CollectionExists" and str(e.value) == "Collection already exists: test"
+    with pytest.raises(E.VectorError) as e:
+        engine.delete_collection("nope")
+    assert e.value.kind == "CollectionNotFound"
+    engine.store_in_collection("test", "k", [1.0, 2.0])
+    assert engine.collection_count("test") == 1
+    engine.delete_collection("test")
+    assert not engine.collection_exists("test") and engine.collection_count("test") == 0
+
+    engine.store_in_collection("auto", "k", [1.0, 2.0])      # store_in_collection_without_prior_create
+    assert np.array_equal(engine.get_from_collection("auto", "k"), np.array([1, 2], F))
+    with pytest.raises(E.VectorError) as e:
+        engine.get_from_collection("auto", "missing")
+    assert str(e.value) == "Embedding not found: auto:missing"
+
+    engine.create_collection("fixed", E.VectorCollectionConfig().with_dimension(3))
+    engine.store_in_collection("fixed", "ok", [1.0, 2.0, 3.0])
+    with pytest.raises(E.VectorError) as e:
+        engine.store_in_collection("fixed", "bad", [1.0, 2.0])
+    assert str(e.value) == "Dimension mismatch: expected 3, got 2"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_in_collection("fixed", [1.0, 2.0], 5)   # search_in_collection_dimension_constraint
+    assert str(e.value) == "Dimension mismatch: expected 3, got 2"
+
+
+def test_search_in_collection(E):  # lib.rs:7900-7930
+    engine = E.VectorEngine()
+    engine.store_in_collection("products", "p1", [1.0, 0.0, 0.0])
+    engine.store_in_collection("products", "p2", [0.0, 1.0, 0.0])
+    engine.store_in_collection("products", "p3", [0.0, 0.0, 1.0])
+    engine.store_embedding("p1", [0.0, 0.0, 1.0])             # default collection is a separate key space
+    r = engine.search_in_collection("products", [1.0, 0.0, 0.0], 2)
+    assert len(r) == 2 and r[0].key == "p1" and abs(r[0].score - 1.0) < 1e-6
+    assert engine.search_in_collection("empty", [1.0, 2.0], 5) == []
+    # per-collection metric (lib.rs:1614-1616)
+    engine.create_collection("l2", E.VectorCollectionConfig().with_metric(E.DistanceMetric.Euclidean))
+    engine.store_in_collection("l2", "near", [1.0, 0.0])
+    engine.store_in_collection("l2", "far", [10.0, 0.0])
+    r = engine.search_in_collection("l2", [0.0, 0.0], 2)      # zero query is fine for a non-cosine collection
+    assert [x.key for x in r] == ["near", "far"] and abs(r[0].score - 0.5) < 1e-6
+    engine.create_collection("dot", E.VectorCollectionConfig().with_metric(E.DistanceMetric.DotProduct))
+    engine.store_in_collection("dot", "small", [1.0, 0.0])
+    engine.store_in_collection("dot", "big", [3.0, 0.0])
+    assert engine.search_in_collection("dot", [1.0, 0.0], 1)[0].key == "big"
+
+
+# ---- filtered search (lib.rs:6968-7722) ----------------------------------------------------------------
+def setup_filtered_search_engine(E):  # lib.rs:6968-7001
+    engine = E.VectorEngine()
+    for i, (cat, price) in enumerate(zip(["electronics", "clothing", "food"], [100, 50, 25])):
+        engine.store_embedding_with_metadata(f"item{i}", [float(i + 1), 1.0, 1.0],
+                                             {"category": cat, "price": price, "active": i % 2 == 0})
+    return engine
+
+
+def test_search_filtered_operators(E):  # lib.rs:7004-7135, 7277-7335
+    FC = E.FilterCondition
+    engine = setup_filtered_search_engine(E)
+    q = [1.0, 1.0, 1.0]
+    r = engine.search_similar_filtered(q, 10, FC.Eq("category", "electronics"))
+    assert len(r) == 1 and r[0].key == "item0"
+    r = engine.search_similar_filtered([1.0, 0.0, 0.0], 10, FC.Eq("price", 50))
+    assert len(r) == 1 and r[0].key == "item1"
+    assert len(engine.search_similar_filtered(q, 10, FC.Gt("price", 30))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.Lt("price", 60))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.Le("price", 50))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.Ge("price", 50))) == 2
+    r = engine.search_similar_filtered(q, 10, FC.Gt("price", 30).and_(FC.Lt("price", 80)))
+    assert len(r) == 1 and r[0].key == "item1"
+    assert len(engine.search_similar_filtered(q, 10, FC.Eq("category", "electronics").or_(FC.Eq("category", "food")))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.TRUE)) == 3
+    assert len(engine.search_similar_filtered(q, 10, FC.In("category", ["electronics", "food"]))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.Ne("category", "electronics"))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.Eq("active", True))) == 2
+    assert len(engine.search_similar_filtered(q, 10, FC.Eq("active", False))) == 1
+    assert engine.search_similar_filtered(q, 10, FC.Eq("category", "nonexistent")) == []
+    assert engine.search_similar_filtered(q, 10, FC.Eq("missing_field", 1)) == []
+    assert len(engine.search_similar_filtered(q, 10, FC.Exists("price"))) == 3
+    assert len(engine.search_similar_filtered(q, 10, FC.Contains("category", "oth"))) == 1
+    assert len(engine.search_similar_filtered(q, 10, FC.StartsWith("category", "f"))) == 1
+    assert engine.search_similar_filtered(q, 10, FC.Contains("price", "5")) == []      # non-string field
+    assert len(engine.search_similar_filtered(q, 10, FC.Ge("price", 50.0))) == 2         # int vs float filter
+    assert engine.search_similar_filtered(q, 10, FC.Eq("price", "50")) == []             # incompatible types
+    assert engine.count_matching(FC.Gt("price", 30)) == 2
+
+
+def test_search_filtered_strategies_and_errors(E):  # lib.rs:7337-7400, 7701-7722
+    FC, FS = E.FilterCondition, E.FilteredSearchConfig
+    engine = setup_filtered_search_engine(E)
+    q = [1.0, 1.0, 1.0]
+    f = FC.Eq("category", "electronics")
+    assert len(engine.search_similar_filtered(q, 10, f, FS.pre_filter())) == 1
+    assert len(engine.search_similar_filtered(q, 10, f, FS.post_filter())) == 1
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar_filtered([], 10, f)
+    assert e.value.kind == "EmptyVector"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_similar_filtered(q, 0, f)
+    assert e.value.kind == "InvalidTopK"
+    assert engine.search_similar_filtered([0.0, 0.0, 0.0], 10, f, FS.pre_filter()) == []
+    # respects top_k
+    engine = E.VectorEngine()
+    for i in range(20):
+        engine.store_embedding_with_metadata(f"i{i}", [float(i + 1), 1.0], {"g": "a"})
+    assert len(engine.search_similar_filtered([1.0, 1.0], 5, FC.Eq("g", "a"))) == 5
+
+
+def test_prefilter_is_exact_against_oracle(E):
+    """search_with_pre_filter semantics (lib.rs:3514-3557) on a corpus where the filter is selective."""
+    rng = np.random.default_rng(33)
+    n, d, k = 5000, 64, 25
+    A = rng.standard_normal((n, d)).astype(F)
+    bucket = rng.integers(0, 10, n)
+    engine = E.VectorEngine()
+    for i in range(n):
+        engine.store_embedding_with_metadata(f"k{i}", A[i], {"bucket": int(bucket[i]), "name": f"n{i % 7}"})
+    q = rng.standard_normal(d).astype(F)
+    FC = E.FilterCondition
+    for cond, keep in ((FC.Eq("bucket", 3), bucket == 3),
+                       (FC.Lt("bucket", 2).or_(FC.Eq("name", "n0")), (bucket < 2) | (np.arange(n) % 7 == 0))):
+        res = engine.search_similar_filtered(q, k, cond, E.FilteredSearchConfig.pre_filter())
+        er, es = oc.search(A, q, k, 0, mask=oc.mask_from_bool(keep))
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+        assert np.all(np.array([r.score for r in res], F) == es)
+    # post-filter: oversample x3 then filter (approximate by design, lib.rs:3560-3579)
+    res = engine.search_similar_filtered(q, k, FC.Eq("bucket", 3), E.FilteredSearchConfig.post_filter())
+    er, es = oc.search(A, q, 3 * k, 0)
+    exp = [f"k{i}" for i in er if bucket[int(i)] == 3][:k]
+    assert [r.key for r in res] == exp
+
+
+def test_search_filtered_in_collection(E):  # lib.rs:7935-8000
+    engine = E.VectorEngine()
+    engine.store_in_collection_with_metadata("test", "item1", [1.0, 0.0], {"category": "A"})
+    engine.store_in_collection_with_metadata("test", "item2", [0.9, 0.1], {"category": "B"})
+    engine.store_in_collection_with_metadata("test", "item3", [0.8, 0.2], {"category": "A"})
+    FC = E.FilterCondition
+    for cfg in (None, E.FilteredSearchConfig.pre_filter(), E.FilteredSearchConfig.post_filter()):
+        r = engine.search_filtered_in_collection("test", [1.0, 0.0], 10, FC.Eq("category", "A"), cfg)
+        assert [x.key for x in r] == ["item1", "item3"]
+    assert engine.search_filtered_in_collection("test", [0.0, 0.0], 10, FC.TRUE) == []
+
+
+# ---- concurrency contract (lib.rs:5615-5711) -------------------------------------------------------------
+def test_concurrent_search_and_store(E):
+    engine = E.VectorEngine()
+    for i in range(200):
+        engine.store_embedding(f"v{i}", create_test_vector(16, i))
+    errors = []
+
+    def searcher(t):
+        try:
+            for j in range(5):
+                r = engine.search_similar(create_test_vector(16, (t * 7 + j) % 200), 5)
+                assert len(r) == 5
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    def writer(t):
+        try:
+            for j in range(5):
+                engine.store_embedding(f"w{t}_{j}", create_test_vector(16, 1000 + t * 10 + j))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=searcher, args=(t,)) for t in range(20)]
+    threads += [threading.Thread(target=writer, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert engine.count() == 220
