@@ -54,6 +54,8 @@ struct Workspace {
     uint32_t ld = 0;
     uint32_t* scores = nullptr;
     uint32_t* tmax = nullptr;
+    uint32_t* wmax = nullptr;
+    uint64_t tmax_stride = 0;
     float* qpad = nullptr;
     QInfo* qinfo = nullptr;
     QState* qstate = nullptr;
@@ -91,7 +93,7 @@ struct nmn_index {
 
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->scores, w->tmax, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
                     w->h_counts2};
     for (void* p : ptrs)
@@ -158,7 +160,9 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     w->n_tiles_cap = (uint32_t)(idx->cap_pad / kTileRows);
     const size_t nq = w->nq_cap;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->scores), std::max<size_t>(nq * w->score_stride, 64) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tmax), std::max<size_t>(nq * w->n_tiles_cap, 1) * 4));
+    w->tmax_stride = ((uint64_t)w->n_tiles_cap + 3) & ~3ull;  // rows of tmax stay 16-B aligned (uint4 sweeps)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tmax), std::max<size_t>(nq * w->tmax_stride, 4) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->wmax), nq * kMaxScanWaves * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qpad), nq * w->ld * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo), nq * sizeof(QInfo)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
@@ -360,14 +364,16 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.mask = mask_dev;
             sp.scores = w->scores;
             sp.tmax = w->tmax;
+            sp.wmax = w->wmax;
+            sp.tmax_stride = w->tmax_stride;
+            sp.wmax_stride = kMaxScanWaves;
             sp.n_rows = n_rows;
             sp.score_stride = w->score_stride;
             sp.ld = idx->ld;
             sp.n_tiles = n_tiles;
             sp.nq = nqc;
             // ~16 waves per CU; every wave gets the same number of tiles
-            const uint32_t target_waves = 4096;
-            sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + target_waves - 1) / target_waves);
+            sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + kMaxScanWaves - 1) / kMaxScanWaves);
             sp.metric = (int)metric;
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));
             HIP_TRY(launch_scan(sp, stream));
@@ -376,6 +382,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             SelectParams sel{};
             sel.scores = w->scores;
             sel.tmax = w->tmax;
+            sel.wmax = w->wmax;
+            sel.tmax_stride = w->tmax_stride;
+            sel.wmax_stride = kMaxScanWaves;
+            sel.tiles_per_wave = sp.tiles_per_wave;
+            sel.n_waves = (n_tiles + sp.tiles_per_wave - 1) / sp.tiles_per_wave;
             sel.qinfo = w->qinfo;
             sel.qstate = w->qstate;
             sel.cand_rows = w->cand_rows;
@@ -385,36 +396,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.nq = nqc;
             sel.k = k;
             sel.cand_cap = w->cand_cap;
-            // thresholds from tile maxima need at least ~2k tiles to be tight; small shards use all rows
-            sel.use_tiles = (n_tiles >= 2u * k && n_rows > 16384) ? 1 : 0;
             HIP_TRY(launch_select(sel, stream));
-
-            // exact fallback: both kernels exit immediately unless a query overflowed its candidate list
-            ExactScanParams ex{};
-            ex.corpus = idx->corpus;
-            ex.norms = idx->norms;
-            ex.qpad = w->qpad;
-            ex.qinfo = w->qinfo;
-            ex.qstate = w->qstate;
-            ex.mask = mask_dev;
-            ex.scores = w->scores;
-            ex.n_rows = n_rows;
-            ex.score_stride = w->score_stride;
-            ex.ld = idx->ld;
-            ex.dim = idx->dim;
-            ex.nq = nqc;
-            ex.metric = (int)metric;
-            HIP_TRY(launch_exact_scan(ex, stream));
-            ExactSelectParams es{};
-            es.scores = w->scores;
-            es.qstate = w->qstate;
-            es.cand_rows = w->cand_rows;
-            es.n_rows = n_rows;
-            es.score_stride = w->score_stride;
-            es.nq = nqc;
-            es.k = k;
-            es.cand_cap = w->cand_cap;
-            HIP_TRY(launch_exact_select(es, stream));
 
             RescoreParams rp{};
             rp.corpus = idx->corpus;
@@ -424,6 +406,10 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             rp.qstate = w->qstate;
             rp.cand_rows = w->cand_rows;
             rp.cand_scores = w->cand_scores;
+            rp.mask = mask_dev;       // fallback duty of the same launch
+            rp.scores = w->scores;
+            rp.n_rows = n_rows;
+            rp.score_stride = w->score_stride;
             rp.ld = idx->ld;
             rp.dim = idx->dim;
             rp.nq = nqc;
@@ -435,6 +421,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.cand_rows = w->cand_rows;
         fp.cand_scores = w->cand_scores;
         fp.qstate = w->qstate;
+        fp.scores = w->scores;
+        fp.score_stride = w->score_stride;
+        fp.n_rows = n_rows;
         fp.row_base = idx->row_base;
         fp.nq = nqc;
         fp.k = k;

@@ -29,14 +29,29 @@ __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 __device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }
 
 // lane-l chain of dot8 followed by the in-order lane sum and the scalar tail.
-// `l` = threadIdx & 7; all 8 threads of the group return the same value.
+// `l` = threadIdx & 7; all 8 threads of the group return the same value.  Loads are issued PF chunks
+// ahead of the dependent mul/add chain (the chain order is untouched; only the memory latency of the
+// 8 x (d/8) strided reads is overlapped).
+template <int PF>
 __device__ __forceinline__ float dot8_group(const float* __restrict__ a, const float* __restrict__ b,
                                             uint32_t dim, uint32_t l) {
     const uint32_t chunks = dim >> 3;
     float acc = 0.0f;
-    for (uint32_t c = 0; c < chunks; c++) {
-        const float pr = mul_rn(a[8u * c + l], b[8u * c + l]);
-        acc = add_rn(acc, pr);
+    for (uint32_t c0 = 0; c0 < chunks; c0 += PF) {
+        float av[PF], bv[PF];
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const uint32_t c = c0 + (uint32_t)i;
+            av[i] = c < chunks ? a[8u * c + l] : 0.0f;
+            bv[i] = c < chunks ? b[8u * c + l] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            if (c0 + (uint32_t)i < chunks) {
+                const float pr = mul_rn(av[i], bv[i]);
+                acc = add_rn(acc, pr);
+            }
+        }
     }
     float r = -0.0f;
     const int base = (int)(threadIdx.x & 63u & ~7u);
@@ -46,12 +61,34 @@ __device__ __forceinline__ float dot8_group(const float* __restrict__ a, const f
     return r;
 }
 
+// lib.rs:2249-2253: one strictly sequential sum.  The 8 threads of a group split the LOADS and the
+// (x-y)^2 products (thread l owns elements i with i % 8 == l); the sum itself is then accumulated in
+// element order by pulling each product from its owner with a shuffle, so the order of the additions is
+// exactly 0,1,2,...,d-1.
+template <int PF>
 __device__ __forceinline__ float euclid_seq(const float* __restrict__ q, const float* __restrict__ v,
-                                            uint32_t dim) {
+                                            uint32_t dim, uint32_t l) {
     float s = -0.0f;
-    for (uint32_t i = 0; i < dim; i++) {
-        const float d = sub_rn(q[i], v[i]);
-        s = add_rn(s, mul_rn(d, d));
+    const int base = (int)(threadIdx.x & 63u & ~7u);
+    const uint32_t chunks = (dim + 7u) >> 3;
+    for (uint32_t c0 = 0; c0 < chunks; c0 += PF) {
+        float pr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const uint32_t e = 8u * (c0 + (uint32_t)i) + l;
+            const float x = e < dim ? q[e] : 0.0f;
+            const float y = e < dim ? v[e] : 0.0f;
+            const float d = sub_rn(x, y);
+            pr[i] = mul_rn(d, d);
+        }
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const float pt = __shfl(pr[i], base + t);
+                if (8u * (c0 + (uint32_t)i) + (uint32_t)t < dim) s = add_rn(s, pt);
+            }
+        }
     }
     return sqrt_rn(s);
 }
@@ -60,10 +97,10 @@ __device__ __forceinline__ float euclid_seq(const float* __restrict__ q, const f
 __device__ __forceinline__ float exact_score(const float* __restrict__ q, const float* __restrict__ v,
                                              uint32_t dim, float qmag, float vmag, int metric, uint32_t l) {
     if (metric == NMN_METRIC_EUCLIDEAN) {
-        const float dist = euclid_seq(q, v, dim);  // every thread of the group walks it; loads hit L1
+        const float dist = euclid_seq<16>(q, v, dim, l);
         return div_rn(1.0f, add_rn(1.0f, dist));
     }
-    const float dot = dot8_group(q, v, dim, l);
+    const float dot = dot8_group<32>(q, v, dim, l);
     if (metric == NMN_METRIC_DOT_PRODUCT) return dot;
     if (qmag == 0.0f || vmag == 0.0f) return 0.0f;
     return div_rn(dot, mul_rn(qmag, vmag));
@@ -77,7 +114,7 @@ __global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ co
     const uint64_t i = (uint64_t)blockIdx.x * 32u + (threadIdx.x >> 3);
     const uint64_t row = row0 + (i < n ? i : n - 1);  // keep the whole 8-group converged for the shuffles
     const float* v = corpus + row * (uint64_t)ld;
-    const float ss = dot8_group(v, v, dim, l);
+    const float ss = dot8_group<32>(v, v, dim, l);
     const float mag = sqrt_rn(ss);
     if (i < n && l == 0) {
         norms[row] = mag;
@@ -105,7 +142,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
     const float* src = queries + (size_t)q * dim;
     float* dst = qpad + (size_t)q * ld;
     for (uint32_t i = threadIdx.x; i < ld; i += 64) dst[i] = i < dim ? src[i] : 0.0f;
-    const float ss = dot8_group(src, src, dim, threadIdx.x & 7u);
+    const float ss = dot8_group<32>(src, src, dim, threadIdx.x & 7u);
     if (threadIdx.x == 0) {
         const float qmag = sqrt_rn(ss);
         const float u = 5.9604645e-08f;  // 2^-24
@@ -141,24 +178,46 @@ hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_
     return hipGetLastError();
 }
 
-// ---- exact rescore of the candidate lists ----------------------------------------------------
+// ---- exact rescore of the candidate lists -----------------------------------------------------
+// Normal duty: re-score the <= cand_cap candidates of each query (32 per workgroup).
+// Fallback duty (query flagged `overflow` by select_kernel): the same launch instead computes the exact
+// score of EVERY row into scores[] (grid-stride, 32 rows per workgroup step); final_kernel then selects
+// from those.  Folding the fallback into this launch keeps the normal pipeline free of extra launches
+// and of any host round trip.
 __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
     const uint32_t q = blockIdx.y;
     const uint32_t l = threadIdx.x & 7u;
-    const uint32_t count = min(p.qstate[q].cand_count, p.cand_cap);
-    const uint32_t c = blockIdx.x * 32u + (threadIdx.x >> 3);
-    if (blockIdx.x * 32u >= count) return;  // whole block idle
-    const uint32_t cc = c < count ? c : count - 1;
-    const uint32_t row = p.cand_rows[(size_t)q * p.cand_cap + cc];
-    const float* v = p.corpus + (uint64_t)row * p.ld;
     const float* qv = p.qpad + (size_t)q * p.ld;
-    const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
-    const float sc = exact_score(qv, v, p.dim, p.qinfo[q].qmag, vmag, p.metric, l);
-    if (c < count && l == 0) p.cand_scores[(size_t)q * p.cand_cap + c] = sc;
+    const float qmag = p.qinfo[q].qmag;
+    if (p.qstate[q].overflow) {
+        const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
+        for (uint64_t base = (uint64_t)blockIdx.x * 32u; base < n_pad; base += (uint64_t)gridDim.x * 32u) {
+            const uint64_t row = base + (threadIdx.x >> 3);
+            bool valid = row < p.n_rows;
+            if (valid && p.mask) valid = ((p.mask[row >> 6] >> (row & 63)) & 1ull) != 0;
+            uint32_t bits = kScoreSentinelBits;
+            if (valid) {  // uniform per 8-lane group
+                const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+                bits = f2u(exact_score(qv, p.corpus + row * (uint64_t)p.ld, p.dim, qmag, vmag, p.metric, l));
+            }
+            if (l == 0 && row < n_pad) p.scores[(uint64_t)q * p.score_stride + row] = bits;
+        }
+        return;
+    }
+    const uint32_t count = min(p.qstate[q].cand_count, p.cand_cap);
+    for (uint32_t c0 = blockIdx.x * 32u; c0 < count; c0 += gridDim.x * 32u) {
+        const uint32_t c = c0 + (threadIdx.x >> 3);
+        const uint32_t cc = c < count ? c : count - 1;  // keep every 8-lane group converged
+        const uint32_t row = p.cand_rows[(size_t)q * p.cand_cap + cc];
+        const float* v = p.corpus + (uint64_t)row * p.ld;
+        const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+        const float sc = exact_score(qv, v, p.dim, qmag, vmag, p.metric, l);
+        if (c < count && l == 0) p.cand_scores[(size_t)q * p.cand_cap + c] = sc;
+    }
 }
 
 hipError_t launch_rescore(const RescoreParams& p, hipStream_t s) {
-    dim3 grid((p.cand_cap + 31) / 32, p.nq);
+    dim3 grid(128, p.nq);  // 4096 candidates = one step; the fallback duty grid-strides over all rows
     hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -19,6 +19,7 @@ namespace nmn {
 
 constexpr uint32_t kTileRows = 64;        // rows per scan tile (one wave, 16 steps of 4 rows)
 constexpr uint32_t kDefaultCandCap = 4096;
+constexpr uint32_t kMaxScanWaves = 4096;   // scan waves per query sweep (= entries of the wave-max level)
 constexpr uint32_t kKeyMasked = 0u;       // row does not take part (mask / beyond n_rows)
 constexpr uint32_t kKeyNaN = 1u;          // NaN score: ranks below -inf
 constexpr uint32_t kScoreSentinelBits = 0xFFFFFFFFu;  // scores[] entry of a non-participating row
@@ -72,7 +73,10 @@ struct ScanParams {
     const QInfo* qinfo;      // [nq]
     const uint64_t* mask;    // nullable, ceil(rows/64) words
     uint32_t* scores;        // [nq][score_stride] f32 bits (sentinel for non-participating rows)
-    uint32_t* tmax;          // [nq][n_tiles] tile maximum key (0 = empty tile)
+    uint32_t* tmax;          // [nq][tmax_stride] tile maximum key (0 = empty tile)
+    uint32_t* wmax;          // [nq][wmax_stride] maximum key over the tiles of each scan wave
+    uint64_t tmax_stride;
+    uint64_t wmax_stride;
     uint64_t n_rows;
     uint64_t score_stride;
     uint32_t ld;             // floats per row, multiple of 4
@@ -85,7 +89,12 @@ hipError_t launch_scan(const ScanParams& p, hipStream_t s);
 
 struct SelectParams {
     const uint32_t* scores;  // [nq][score_stride]
-    const uint32_t* tmax;    // [nq][n_tiles]
+    const uint32_t* tmax;    // [nq][tmax_stride]
+    const uint32_t* wmax;    // [nq][wmax_stride]
+    uint64_t tmax_stride;
+    uint64_t wmax_stride;
+    uint32_t n_waves;        // scan waves that own tiles (<= kMaxScanWaves)
+    uint32_t tiles_per_wave;
     const QInfo* qinfo;
     QState* qstate;
     uint32_t* cand_rows;     // [nq][cand_cap]
@@ -95,14 +104,16 @@ struct SelectParams {
     uint32_t nq;
     uint32_t k;
     uint32_t cand_cap;
-    int use_tiles;           // 1: threshold from tile maxima, 0: from all scores
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 
 struct FinalParams {
     const uint32_t* cand_rows;   // [nq][cand_cap]
     const float* cand_scores;    // [nq][cand_cap] exact
-    const QState* qstate;
+    QState* qstate;
+    const uint32_t* scores;      // [nq][score_stride]: EXACT scores of every row for overflowed queries
+    uint64_t score_stride;
+    uint64_t n_rows;
     uint64_t row_base;
     uint32_t nq, k, cand_cap;
     uint64_t* out_rows;          // [nq][k]
@@ -128,6 +139,10 @@ struct RescoreParams {
     const QState* qstate;
     const uint32_t* cand_rows;
     float* cand_scores;
+    // exact-fallback duty (queries with qstate.overflow): exact score of EVERY row -> scores
+    const uint64_t* mask;
+    uint32_t* scores;
+    uint64_t n_rows, score_stride;
     uint32_t ld, dim, nq, cand_cap;
     int metric;
 };
@@ -149,14 +164,6 @@ struct ExactScanParams {
     int metric;
 };
 hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s);
-struct ExactSelectParams {
-    const uint32_t* scores;
-    QState* qstate;
-    uint32_t* cand_rows;
-    uint64_t n_rows, score_stride;
-    uint32_t nq, k, cand_cap;
-};
-hipError_t launch_exact_select(const ExactSelectParams& p, hipStream_t s);
 hipError_t launch_count_cmp(const uint32_t* scores, uint64_t n_rows, float score, unsigned long long* out2,
                             hipStream_t s);
 

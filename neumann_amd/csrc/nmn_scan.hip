@@ -84,6 +84,10 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) qmag[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qmag : 0.f;
 
+    uint32_t wmax[NQ];  // maximum key over every tile of this wave (third level of the max hierarchy)
+#pragma unroll
+    for (int q = 0; q < NQ; q++) wmax[q] = kKeyMasked;
+
     for (uint32_t tile = t0; tile < t1; tile++) {
         const uint64_t r0 = (uint64_t)tile * kTileRows;
         uint64_t mword = ~0ull;
@@ -166,8 +170,14 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
             const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
             p.scores[(uint64_t)(q0 + q) * p.score_stride + myrow] = valid ? f2u(sc) : kScoreSentinelBits;
             const uint32_t m = wave_max_u32(key);
-            if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.n_tiles + tile] = m;
+            if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tile] = m;
+            wmax[q] = max(wmax[q], m);
         }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            if (q0 + q < p.nq) p.wmax[(size_t)(q0 + q) * p.wmax_stride + wave] = wmax[q];
     }
 }
 

@@ -17,37 +17,42 @@ struct PickResult {
     uint32_t above;  // keys in bins strictly above it
 };
 
-// hist[0..nbins) filled; find the bin containing the kk-th largest key (1 <= kk <= total).
-// Executed by wave 0; result broadcast through `out` (LDS).
+// hist[0..nbins) filled (nbins = 1024 or 2048); find the bin containing the kk-th largest key
+// (1 <= kk <= total).  Block-wide: every thread owns nbins/1024 adjacent bins, suffix sums by wave
+// shuffles + one LDS hop across the 16 waves; exactly one thread sees the crossing and publishes it.
+// Callers __syncthreads() before reading *out.
 __device__ void pick_bin(const uint32_t* hist, int nbins, uint32_t kk, PickResult* out) {
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const int per = nbins / 64;
-        uint32_t s = 0;
-        for (int b = 0; b < per; b++) s += hist[lane * per + b];
-        // inclusive suffix sum over lanes: S_i = sum_{j>=i} s_j
-        uint32_t S = s;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_down(S, off);
-            if (lane + off < 64) S += t;
-        }
-        const unsigned long long m = __ballot(S >= kk);
-        const int star = 63 - __builtin_clzll(m);  // m != 0 because S_0 = total >= kk
-        if (lane == star) {
-            uint32_t above = S - s;
-            int b = per - 1;
-            for (; b > 0; b--) {
-                const uint32_t h = hist[lane * per + b];
-                if (above + h >= kk) break;
-                above += h;
-            }
-            out->bin = (uint32_t)(lane * per + b);
+    __shared__ uint32_t wtot[kSelThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int per = nbins / kSelThreads;  // 1 or 2
+    const uint32_t h0 = hist[tid * per];
+    const uint32_t h1 = per == 2 ? hist[tid * per + 1] : 0u;
+    const uint32_t s = h0 + h1;
+    uint32_t S = s;  // inclusive suffix sum inside the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_down(S, off);
+        if (lane + off < 64) S += t;
+    }
+    if (lane == 0) wtot[wave] = S;
+    __syncthreads();
+    uint32_t above_waves = 0;
+    for (uint32_t w = wave + 1; w < kSelThreads / 64; w++) above_waves += wtot[w];
+    const uint32_t Sfx = S + above_waves;  // keys in bins >= first bin of this thread
+    const uint32_t above = Sfx - s;        // keys in bins above this thread's bins
+    if (Sfx >= kk && above < kk) {
+        if (per == 2 && above + h1 >= kk) {
+            out->bin = tid * per + 1;
             out->above = above;
+        } else {
+            out->bin = tid * per;
+            out->above = above + h1;
         }
     }
+    __syncthreads();
 }
 
-// wave-aggregated append: returns the slot of this lane's element (or UINT32_MAX if !pred)
+// wave-aggregated append: returns the slot of this lane's element (or UINT32_MAX if !pred).
+// Must be called from wave-uniform control flow.
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
     const unsigned long long m = __ballot(pred);
     if (m == 0) return 0xFFFFFFFFu;
@@ -60,108 +65,211 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
     return pred ? base + ofs : 0xFFFFFFFFu;
 }
 
+// collection threshold key from the radix lower bound T and the query's error margins
+__device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
+    uint32_t Tc = kKeyNaN;
+    if (T > kKeyNegInf) {
+        const float tau = key_to_score(T);
+        const float thr = tau - qi.margin_abs - fabsf(tau) * qi.margin_rel;
+        if (thr == thr) {
+            Tc = score_to_key(thr);
+            if (Tc > T) Tc = T;
+            if (Tc < kKeyNaN) Tc = kKeyNaN;
+        }
+    }
+    return Tc;
+}
+
+constexpr uint32_t kListCap = 4096;  // LDS work lists (waves, tiles); both bounded by kMaxScanWaves / cand_cap
+
+// Two 11-bit radix digits over n gathered keys (key_at(e) == 0: does not take part): returns T, the
+// lower edge of the 2^10-ulp bin that holds the kk-th largest key.  Requires kk <= #valid keys.
+// Loads are issued V at a time per thread so a single workgroup still keeps ~8K loads in flight.
+template <typename KeyAt>
+__device__ uint32_t radix2(KeyAt key_at, uint32_t n, uint32_t kk, uint32_t* hist, PickResult* pick) {
+    const uint32_t tid = threadIdx.x;
+    constexpr int V = 8;
+    uint32_t b1 = 0, above1 = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
+        __syncthreads();
+        for (uint32_t e0 = tid; e0 < n; e0 += kSelThreads * V) {
+            uint32_t kv[V];
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                kv[u] = e < n ? key_at(e) : kKeyMasked;
+            }
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t key = kv[u];
+                if (key == kKeyMasked) continue;
+                if (pass == 0) atomicAdd(&hist[key >> 21], 1u);
+                else if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 2047u], 1u);
+            }
+        }
+        __syncthreads();
+        pick_bin(hist, kBins, pass == 0 ? kk : kk - above1, pick);
+        if (pass == 0) {
+            b1 = pick->bin;
+            above1 = pick->above;
+        }
+        __syncthreads();
+    }
+    return (b1 << 21) | (pick->bin << 10);
+}
+
+// count of valid (non-zero) gathered keys
+template <typename KeyAt>
+__device__ uint32_t count_valid(KeyAt key_at, uint32_t n, uint32_t* s_word) {
+    const uint32_t tid = threadIdx.x;
+    constexpr int V = 8;
+    if (tid == 0) *s_word = 0;
+    __syncthreads();
+    uint32_t loc = 0;
+    for (uint32_t e0 = tid; e0 < n; e0 += kSelThreads * V) {
+        uint32_t kv[V];
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+            const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+            kv[u] = e < n ? key_at(e) : kKeyMasked;
+        }
+#pragma unroll
+        for (int u = 0; u < V; u++) loc += kv[u] != kKeyMasked;
+    }
+    if (loc) atomicAdd(s_word, loc);
+    __syncthreads();
+    return *s_word;
+}
+
 // ---- main-path selection: one workgroup per query ---------------------------------------------
-// keys = tile maxima (use_tiles) or every row's score key.  Two 11-bit radix passes give T, the
-// lower edge of the 2^10-ulp bin holding the k-th largest key: at least k keys are >= T, hence at
-// least k rows score >= score(T).  Every row with approx >= score(T) - margin is a candidate; the
-// exact top-k is among them.
+// The scan left a three-level maximum hierarchy: scores[row] -> tmax[64-row tile] -> wmax[scan wave =
+// `tiles_per_wave` consecutive tiles] (<= 4096 entries, kept in LDS here).  A lower bound T on the
+// k-th best approximate score is the k-th largest key of ONE level: at least k groups of that level
+// hold a row >= T.  The coarsest level with comfortably more valid groups than k is used (>= 8k waves,
+// else >= 2k tiles, else rows), which also keeps sparse / clustered predicate masks on a fast path.
+// Collection then walks down the hierarchy: waves with wmax >= Tc -> their tiles with tmax >= Tc ->
+// their rows with key >= Tc, Tc = key(score(T) - margin).  Typical traffic at 10M rows,
+// k = 100: 16 KB of wmax + ~100 waves x 39 tile maxima + ~103 tiles x 256 B of scores.
 __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     __shared__ uint32_t hist[kBins];
+    __shared__ uint32_t wk[kMaxScanWaves];
+    __shared__ uint32_t la[kListCap];  // waves (valid, then passing)
+    __shared__ uint32_t lb[kListCap];  // tiles (valid at row level, then passing)
     __shared__ PickResult pick;
-    __shared__ uint32_t s_total, s_count;
+    __shared__ uint32_t s_w[4];
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t* scores = p.scores + (uint64_t)q * p.score_stride;
-    const uint32_t* tmax = p.tmax + (uint64_t)q * p.n_tiles;
-    const uint64_t n_pad = (uint64_t)p.n_tiles * kTileRows;
-    const uint64_t n_keys = p.use_tiles ? p.n_tiles : n_pad;
-    auto getkey = [&](uint64_t i) -> uint32_t { return p.use_tiles ? tmax[i] : bits_to_key(scores[i]); };
+    const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
+    const uint32_t* wmax = p.wmax + (uint64_t)q * p.wmax_stride;
+    const uint32_t W = p.n_waves, tpw = p.tiles_per_wave, n_tiles = p.n_tiles;
+    const QInfo qi = p.qinfo[q];
+    uint32_t* out = p.cand_rows + (size_t)q * p.cand_cap;
+    const uint32_t k = p.k;
 
-    for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-    if (tid == 0) { s_total = 0; s_count = 0; }
+    for (uint32_t i = tid; i < kMaxScanWaves; i += kSelThreads) wk[i] = i < W ? wmax[i] : kKeyMasked;
     __syncthreads();
-    // pass 1: bits 31..21
-    uint32_t local_valid = 0;
-    for (uint64_t i = tid; i < n_keys; i += kSelThreads) {
-        const uint32_t key = getkey(i);
-        if (key == kKeyMasked) continue;
-        local_valid++;
-        atomicAdd(&hist[key >> 21], 1u);
-    }
-    atomicAdd(&s_total, local_valid);
-    __syncthreads();
-    const uint32_t total = s_total;
-    if (total == 0) {
-        if (tid == 0) {
-            p.qstate[q].cand_count = 0;
-            p.qstate[q].n_valid = 0;
-        }
+    const uint32_t vw = count_valid([&](uint32_t e) { return wk[e]; }, W, &s_w[0]);
+    if (vw == 0) {
+        if (tid == 0) { p.qstate[q].cand_count = 0; p.qstate[q].n_valid = 0; }
         return;
     }
-    uint32_t Tc = kKeyNaN;  // collect everything that takes part
-    if (total > p.k) {
-        pick_bin(hist, kBins, p.k, &pick);
+
+    uint32_t Tc = kKeyNaN;  // default: every participating row is a candidate
+    if (vw >= 8u * k) {
+        Tc = margin_key(radix2([&](uint32_t e) { return wk[e]; }, W, k, hist, &pick), qi);
+    } else {
+        // too few waves hold valid rows (small shard, large k, or a clustered mask): go one level down
+        if (tid == 0) s_w[1] = 0;
         __syncthreads();
-        const uint32_t b1 = pick.bin, above1 = pick.above;
+        for (uint32_t i = tid; i < W; i += kSelThreads)
+            if (wk[i] != kKeyMasked) la[atomicAdd(&s_w[1], 1u)] = i;  // vw <= W <= kListCap
         __syncthreads();
-        for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-        __syncthreads();
-        // pass 2: bits 20..10 inside bin b1
-        for (uint64_t i = tid; i < n_keys; i += kSelThreads) {
-            const uint32_t key = getkey(i);
-            if (key != kKeyMasked && (key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 2047u], 1u);
+        const uint32_t slots = vw * tpw;
+        auto tile_key = [&](uint32_t e) -> uint32_t {
+            const uint32_t t = la[e / tpw] * tpw + e % tpw;
+            return t < n_tiles ? tmax[t] : kKeyMasked;
+        };
+        const uint32_t vt = count_valid(tile_key, slots, &s_w[2]);
+        if (vt >= 2u * k || vt > kListCap) {
+            Tc = margin_key(radix2(tile_key, slots, k, hist, &pick), qi);
+        } else {
+            // row level over the (few) valid tiles
+            if (tid == 0) s_w[1] = 0;
+            __syncthreads();
+            for (uint32_t e = tid; e < slots; e += kSelThreads) {
+                const uint32_t t = la[e / tpw] * tpw + e % tpw;
+                if (t < n_tiles && tmax[t] != kKeyMasked) lb[atomicAdd(&s_w[1], 1u)] = t;  // vt <= kListCap
+            }
+            __syncthreads();
+            auto row_key = [&](uint32_t e) -> uint32_t {
+                return bits_to_key(scores[(uint64_t)lb[e >> 6] * kTileRows + (e & 63u)]);
+            };
+            const uint32_t vr = count_valid(row_key, vt * kTileRows, &s_w[2]);
+            if (vr > k) Tc = margin_key(radix2(row_key, vt * kTileRows, k, hist, &pick), qi);
         }
-        __syncthreads();
-        pick_bin(hist, kBins, p.k - above1, &pick);
-        __syncthreads();
-        const uint32_t T = (b1 << 21) | (pick.bin << 10);
-        if (T > kKeyNegInf) {
-            const float tau = key_to_score(T);
-            const QInfo qi = p.qinfo[q];
-            const float thr = tau - qi.margin_abs - fabsf(tau) * qi.margin_rel;
-            if (thr == thr) {
-                Tc = score_to_key(thr);
-                if (Tc > T) Tc = T;
-                if (Tc < kKeyNaN) Tc = kKeyNaN;
+    }
+
+    // ---- collection: waves -> tiles -> rows --------------------------------------------------
+    if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < W; i += kSelThreads)
+        if (wk[i] != kKeyMasked && wk[i] >= Tc) la[atomicAdd(&s_w[0], 1u)] = i;
+    __syncthreads();
+    const uint32_t nA = s_w[0];
+    constexpr int V = 8;
+    {
+        const uint32_t slots = nA * tpw;
+        for (uint32_t e0 = tid; e0 < slots; e0 += kSelThreads * V) {
+            uint32_t tk[V], tt[V];
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                tt[u] = e < slots ? la[e / tpw] * tpw + e % tpw : 0xFFFFFFFFu;
+                tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
+            }
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                if (tk[u] != kKeyMasked && tk[u] >= Tc) {
+                    const uint32_t pos = atomicAdd(&s_w[1], 1u);
+                    if (pos < kListCap) lb[pos] = tt[u];
+                }
             }
         }
     }
-    // pass 3: collect rows with key >= Tc
-    uint32_t* out = p.cand_rows + (size_t)q * p.cand_cap;
-    if (p.use_tiles) {
-        const uint32_t wave = tid >> 6, lane = tid & 63u;
-        const uint32_t nw = kSelThreads / 64;
-        for (uint64_t tb = (uint64_t)wave * 64u; tb < p.n_tiles; tb += (uint64_t)nw * 64u) {
-            const uint64_t t = tb + lane;
-            const uint32_t tk = t < p.n_tiles ? tmax[t] : 0u;
-            unsigned long long m = __ballot(tk != kKeyMasked && tk >= Tc);
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1ull;
-                const uint64_t row = (tb + (uint64_t)b) * kTileRows + lane;
-                const uint32_t key = bits_to_key(scores[row]);
-                const bool pred = key != kKeyMasked && key >= Tc;
-                const uint32_t pos = wave_append(pred, &s_count);
-                if (pred && pos < p.cand_cap) out[pos] = (uint32_t)row;
+    __syncthreads();
+    const uint32_t nB_raw = s_w[1];
+    const uint32_t nB = min(nB_raw, kListCap);
+    {
+        const uint32_t tot = nB * kTileRows;
+        for (uint32_t e0 = tid; e0 < tot; e0 += kSelThreads * V) {
+            uint32_t kb[V];
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                kb[u] = e < tot ? scores[(uint64_t)lb[e >> 6] * kTileRows + (e & 63u)] : kScoreSentinelBits;
             }
-        }
-    } else {
-        const uint64_t n_round = (n_pad + kSelThreads - 1) / kSelThreads * kSelThreads;
-        for (uint64_t i = tid; i < n_round; i += kSelThreads) {
-            const uint32_t key = i < n_pad ? bits_to_key(scores[i]) : kKeyMasked;
-            const bool pred = key != kKeyMasked && key >= Tc;
-            const uint32_t pos = wave_append(pred, &s_count);
-            if (pred && pos < p.cand_cap) out[pos] = (uint32_t)i;
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                const uint32_t key = bits_to_key(kb[u]);
+                if (e < tot && key != kKeyMasked && key >= Tc) {
+                    const uint32_t pos = atomicAdd(&s_w[2], 1u);
+                    if (pos < p.cand_cap) out[pos] = lb[e >> 6] * kTileRows + (e & 63u);
+                }
+            }
         }
     }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t c = s_count;
+        const uint32_t c = s_w[2];
+        const bool over = c > p.cand_cap || nB_raw > kListCap;  // > 4096 passing tiles means > 4096 candidates
         QState st;
-        st.n_valid = total;
+        st.n_valid = vw;
         st.thr_key = Tc;
-        st.overflow = c > p.cand_cap ? 1u : 0u;
-        st.cand_count = c > p.cand_cap ? 0u : c;
+        st.overflow = over ? 1u : 0u;
+        st.cand_count = over ? 0u : c;
         p.qstate[q] = st;
     }
 }
@@ -171,125 +279,89 @@ hipError_t launch_select(const SelectParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---- exact-fallback selection -----------------------------------------------------------------
-// scores[] now holds EXACT scores (exact_scan_kernel).  Three radix passes find the exact key of the
-// k-th best row; rows strictly above it are taken in any order, rows tied with it in ascending row
-// order until k rows are chosen — exactly the (score desc, row asc) prefix, whatever the number of
-// ties.  One workgroup per flagged query (slow by design: this path only runs when more than
-// cand_cap rows sit within the rounding margin of the k-th score, e.g. masses of duplicates).
-__global__ void __launch_bounds__(kSelThreads) exact_select_kernel(ExactSelectParams p) {
-    __shared__ uint32_t hist[kBins];
-    __shared__ PickResult pick;
-    __shared__ uint32_t s_total, s_count, s_wsum[kSelThreads / 64], s_run;
-    const uint32_t q = blockIdx.x;
-    if (p.qstate[q].overflow == 0) return;
+// ---- exact-fallback selection (device function of final_kernel) ----------------------------------
+// For a query whose candidate list overflowed, rescore_kernel has replaced scores[] by the EXACT score
+// of every row.  Composite keys (score key << 32 | ~row) are unique, so the k-th largest composite is
+// well defined and {composite >= it} is exactly the (score desc, row asc) top-k whatever the number of
+// ties: a 64-bit radix select, 11+11+10 bits of score key, then (only if the ties at the k-th score
+// straddle it) 11+11+10 bits of ~row.  One workgroup walks all rows up to six times: slow by design,
+// this path only runs when more than cand_cap rows sit within the rounding margin of the k-th score.
+__device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint64_t n_rows, uint32_t k,
+                                      unsigned long long* list, uint32_t* hist, PickResult* pick,
+                                      uint32_t* s_misc /* >= 2 words */) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t* scores = p.scores + (uint64_t)q * p.score_stride;
-    const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
-
-    for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-    if (tid == 0) { s_total = 0; s_count = 0; s_run = 0; }
-    __syncthreads();
-    uint32_t local_valid = 0;
-    for (uint64_t i = tid; i < n_pad; i += kSelThreads) {
-        const uint32_t key = bits_to_key(scores[i]);
-        if (key == kKeyMasked) continue;
-        local_valid++;
-        atomicAdd(&hist[key >> 21], 1u);
-    }
-    atomicAdd(&s_total, local_valid);
-    __syncthreads();
-    const uint32_t total = s_total;
-    const uint32_t kk = min(p.k, total);
-    uint32_t* out = p.cand_rows + (size_t)q * p.cand_cap;
-    if (kk == 0) {
-        if (tid == 0) p.qstate[q].cand_count = 0;
-        return;
-    }
-    pick_bin(hist, kBins, kk, &pick);
-    __syncthreads();
-    const uint32_t b1 = pick.bin, above1 = pick.above;
-    __syncthreads();
-    for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-    __syncthreads();
-    for (uint64_t i = tid; i < n_pad; i += kSelThreads) {
-        const uint32_t key = bits_to_key(scores[i]);
-        if (key != kKeyMasked && (key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 2047u], 1u);
-    }
-    __syncthreads();
-    pick_bin(hist, kBins, kk - above1, &pick);
-    __syncthreads();
-    const uint32_t b2 = pick.bin, above2 = above1 + pick.above;
-    __syncthreads();
-    for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-    __syncthreads();
-    const uint32_t hi = (b1 << 11) | b2;
-    for (uint64_t i = tid; i < n_pad; i += kSelThreads) {
-        const uint32_t key = bits_to_key(scores[i]);
-        if (key != kKeyMasked && (key >> 10) == hi) atomicAdd(&hist[key & 1023u], 1u);
-    }
-    __syncthreads();
-    pick_bin(hist, 1024, kk - above2, &pick);
-    __syncthreads();
-    const uint32_t Tk = (hi << 10) | pick.bin;
-    const uint32_t above = above2 + pick.above;  // rows strictly better than the k-th
-    const uint32_t need = kk - above;            // tied rows to take, lowest row ids first
-    // (a) strictly better rows, any order
-    const uint64_t n_round = (n_pad + kSelThreads - 1) / kSelThreads * kSelThreads;
-    for (uint64_t i = tid; i < n_round; i += kSelThreads) {
+    const uint64_t n_pad = (n_rows + 63) & ~63ull;
+    auto comp = [&](uint64_t i) -> unsigned long long {
         const uint32_t key = i < n_pad ? bits_to_key(scores[i]) : kKeyMasked;
-        const bool pred = key != kKeyMasked && key > Tk;
-        const uint32_t pos = wave_append(pred, &s_count);
-        if (pred && pos < p.cand_cap) out[pos] = (uint32_t)i;
-    }
+        return key == kKeyMasked ? 0ull : (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i));
+    };
+    // digit layout over the 64-bit composite, most significant first
+    const int shifts[6] = {53, 42, 32, 21, 10, 0};
+    const int widths[6] = {11, 11, 10, 11, 11, 10};
+    if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
     __syncthreads();
-    // (b) ties in ascending row order
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    for (uint64_t base = 0; base < n_round; base += kSelThreads) {
-        const uint64_t i = base + tid;
-        const uint32_t key = i < n_pad ? bits_to_key(scores[i]) : kKeyMasked;
-        const bool tie = key == Tk;
-        const unsigned long long m = __ballot(tie);
-        if (lane == 0) s_wsum[wave] = (uint32_t)__builtin_popcountll(m);
+    uint32_t loc = 0;
+    for (uint64_t i = tid; i < n_pad; i += kSelThreads) loc += comp(i) != 0ull;
+    atomicAdd(&s_misc[0], loc);
+    __syncthreads();
+    const uint32_t total = s_misc[0];
+    uint32_t kk = min(k, total);
+    if (kk == 0) return 0;
+    unsigned long long prefix = 0ull;  // digits fixed so far (high bits)
+    uint32_t need = kk;                // rank of the wanted composite among those matching the prefix
+    for (int d = 0; d < 6; d++) {
+        const int nb = 1 << widths[d];
+        for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
         __syncthreads();
-        uint32_t before = s_run;
-        for (uint32_t w = 0; w < wave; w++) before += s_wsum[w];
-        const uint32_t idx = before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (tie && idx < need) out[above + idx] = (uint32_t)i;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = s_run;
-            for (uint32_t w = 0; w < kSelThreads / 64; w++) t += s_wsum[w];
-            s_run = t;
+        const int hi_shift = shifts[d] + widths[d];
+        for (uint64_t i = tid; i < n_pad; i += kSelThreads) {
+            const unsigned long long c = comp(i);
+            if (c == 0ull) continue;
+            if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) continue;
+            atomicAdd(&hist[(uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1)], 1u);
         }
         __syncthreads();
-        if (s_run >= need) break;
+        pick_bin(hist, nb, need, pick);
+        __syncthreads();
+        prefix |= (unsigned long long)pick->bin << shifts[d];
+        need -= pick->above;
+        __syncthreads();
     }
-    if (tid == 0) p.qstate[q].cand_count = kk;
-}
-
-hipError_t launch_exact_select(const ExactSelectParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(exact_select_kernel, dim3(p.nq), dim3(kSelThreads), 0, s, p);
-    return hipGetLastError();
+    // prefix is now the kk-th largest composite; collect everything >= it (exactly kk entries)
+    const uint64_t n_round = (n_pad + kSelThreads - 1) / kSelThreads * kSelThreads;
+    for (uint64_t i = tid; i < n_round; i += kSelThreads) {
+        const unsigned long long c = comp(i);
+        const bool pred = c != 0ull && c >= prefix;
+        const uint32_t pos = wave_append(pred, &s_misc[1]);
+        if (pred && pos < NMN_MAX_TOP_K) list[pos] = c;
+    }
+    __syncthreads();
+    return min(s_misc[1], (uint32_t)NMN_MAX_TOP_K);
 }
 
 // ---- final sort: candidates by (exact score desc, row asc) -> top-k ---------------------------
 __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     __shared__ unsigned long long list[NMN_MAX_TOP_K];
+    __shared__ uint32_t hist[kBins];
+    __shared__ PickResult pick;
+    __shared__ uint32_t s_misc[2];
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = min(p.qstate[q].cand_count, min(p.cand_cap, (uint32_t)NMN_MAX_TOP_K));
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t i = tid; i < np2; i += kSelThreads) {
-        unsigned long long v = 0ull;
-        if (i < n) {
+    uint32_t n;
+    if (p.qstate[q].overflow) {
+        n = exact_select_into(p.scores + (uint64_t)q * p.score_stride, p.n_rows, p.k, list, hist, &pick, s_misc);
+        if (tid == 0) p.qstate[q].cand_count = n;
+    } else {
+        n = min(p.qstate[q].cand_count, min(p.cand_cap, (uint32_t)NMN_MAX_TOP_K));
+        for (uint32_t i = tid; i < n; i += kSelThreads) {
             const uint32_t row = p.cand_rows[(size_t)q * p.cand_cap + i];
             const uint32_t key = score_to_key(p.cand_scores[(size_t)q * p.cand_cap + i]);
-            v = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+            list[i] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - row);
         }
-        list[i] = v;
     }
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + tid; i < np2; i += kSelThreads) list[i] = 0ull;
     __syncthreads();
     // bitonic sort, descending
     for (uint32_t size = 2; size <= np2; size <<= 1) {
