@@ -202,7 +202,10 @@ def main():
     idx.set_timing(False)
     fence()
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
-    passes = (args.nq + 3) // 4 if args.nq >= 3 else 1  # corpus sweeps per step (4 queries per sweep)
+    # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 5 queries, cosine/dot, dim % 128 == 0,
+    # dim <= 768), else 4 (VALU) — mirrors search_enqueue() in neumann_amd/csrc/nmn_api.hip
+    mfma = args.nq >= 5 and args.metric in ("cosine", "dot") and args.dim % 128 == 0 and args.dim <= 768
+    passes = (args.nq + 63) // 64 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     alg_bytes = local_rows * args.dim * 4 * passes
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
 
@@ -228,7 +231,7 @@ def main():
                        "nq": args.nq, "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": None,
-                         "kernel": "nmn::scan_kernel", "avg_kernel_ms": scan_avg,
+                         "kernel": "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel", "avg_kernel_ms": scan_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None},
             "cpu_baseline": cpu,

@@ -20,6 +20,7 @@ ARCH = "gfx950"
 
 SOURCES = {
     "nmn_scan.hip": [],
+    "nmn_scan_mfma.hip": [],
     "nmn_select.hip": [],
     "nmn_exact.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_synth.hip": ["-ffp-contract=off"],

@@ -353,8 +353,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
+        // >= 5 queries in a pass: one corpus sweep per 64 queries on the matrix cores, else 4 per sweep on VALU
+        const bool use_mfma = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
+                              getenv("NMN_NO_MFMA") == nullptr;
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
-                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, stream));
+                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : 0, stream));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
@@ -374,9 +377,10 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.nq = nqc;
             // ~16 waves per CU; every wave gets the same number of tiles
             sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + kMaxScanWaves - 1) / kMaxScanWaves);
+            if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + 255) / 256);  // per workgroup, 1 per CU
             sp.metric = (int)metric;
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));
-            HIP_TRY(launch_scan(sp, stream));
+            HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : launch_scan(sp, stream));
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
 
             SelectParams sel{};
@@ -564,7 +568,7 @@ extern "C" nmn_status nmn_index_score_rows(nmn_index* idx, const float* queries,
     TRY2(hipMalloc(reinterpret_cast<void**>(&drows), (size_t)n_rows * 8));
     TRY2(hipMemcpyAsync(dq, queries, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
     TRY2(hipMemcpyAsync(drows, local_rows, (size_t)n_rows * 8, hipMemcpyHostToDevice, s));
-    TRY2(launch_qprep(dq, nq, idx->dim, idx->ld, (int)metric, idx->max_norm_bits, dqpad, dqi, dqs, s));
+    TRY2(launch_qprep(dq, nq, idx->dim, idx->ld, (int)metric, idx->max_norm_bits, dqpad, dqi, dqs, 0, s));
     TRY2(launch_score_rows(idx->corpus, idx->norms, dqpad, dqi, drows, n_rows, nq, idx->ld, idx->dim, (int)metric,
                            dout, s));
     TRY2(hipMemcpyAsync(out_scores, dout, (size_t)nq * n_rows * 4, hipMemcpyDeviceToHost, s));
@@ -595,7 +599,7 @@ extern "C" nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, 
         mask_dev = w->h_mask;
     }
     HIP_TRY(launch_qprep(w->h_queries, 1, idx->dim, idx->ld, (int)metric, idx->max_norm_bits, w->qpad, w->qinfo,
-                         w->qstate, s));
+                         w->qstate, 0, s));
     ExactScanParams ex{};
     ex.corpus = idx->corpus;
     ex.norms = idx->norms;

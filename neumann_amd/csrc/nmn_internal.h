@@ -86,6 +86,9 @@ struct ScanParams {
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
+// batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
+bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
+hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
 
 struct SelectParams {
     const uint32_t* scores;  // [nq][score_stride]
@@ -130,7 +133,8 @@ hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_
 hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,
                         uint32_t* max_norm_bits, hipStream_t s);
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
-                        const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, hipStream_t s);
+                        const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
+                        hipStream_t s);
 struct RescoreParams {
     const float* corpus;
     const float* norms;

@@ -1,0 +1,371 @@
+// nmn_scan_mfma.hip — batched-query scan (5..64 queries per corpus sweep) on the CDNA4 matrix cores.
+//
+// With nq queries the scan is a [rows x dim] x [dim x nq] product.  At nq = 64 the f32 VALU / f32-MFMA
+// rate (157 TFLOP/s) would bound it at 6.25 ms per 10M x 768 sweep, above the 3.84 ms HBM floor
+// (SURVEY.md §7 hard part b), so the APPROXIMATE pass runs on bf16 MFMA with every f32 operand split
+// in registers into hi + lo bf16 (x = hi + lo + O(2^-16 x)) and three products hi*hi + hi*lo + lo*hi:
+// relative error <= 2^-15 * sum|q_i v_i| — the same class as f32 summation error; it only widens the
+// candidate margin (qprep adds 2^-14), the exact rescore (nmn_exact.hip) restores bit parity.  HBM bytes
+// are unchanged: the corpus is still read once, as f32.
+//
+// Structure (one workgroup = 4 waves = 64 queries x 64-row tiles, persistent over a tile range):
+//   * queries are STATIONARY in registers: wave w owns queries 16w..16w+15 as MFMA B-fragments
+//     (v_mfma_f32_16x16x32_bf16; hi and lo; 8 VGPRs per 32-wide k-step -> 192 VGPRs at dim 768);
+//   * the corpus STREAMS through LDS: [64 rows][128 floats] stages (32 KiB) filled by
+//     global_load_lds_dwordx4 (LDS-DMA: full 512-B row segments, no VGPRs), double buffered;
+//     every wave reads each stage as A-fragments (ds_read_b128), splits hi/lo and issues 3 MFMAs per
+//     16-row block and k-step;
+//   * the LDS image is XOR-swizzled through the DMA SOURCE address (chunk ^= row & 15) so that the
+//     16 rows of a ds_read_b128 service group fall on 16 different bank slots;
+//   * the k index inside a k-step is permuted (lane group g takes floats 4g..4g+3 and 16+4g..16+4g+3)
+//     so each ds_read_b128 / query load is one contiguous 16 B — any permutation is legal as long as A
+//     and B use the same one;
+//   * epilogue per tile: scores (float4 per lane), per-(query,tile) maxima, per-(query,block) maxima —
+//     the same three-level hierarchy select_kernel consumes after the VALU scan.
+// Cosine and dot product only: the Euclidean score needs |x-q|^2, whose expansion cancels
+// catastrophically for near neighbours; Euclidean batches use the VALU kernel (4 queries per sweep).
+#include "nmn_internal.h"
+
+namespace nmn {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaQ = 64;       // queries per sweep
+constexpr int kStageK = 128;     // floats of every row per LDS stage
+constexpr int kStageBytes = kTileRows * kStageK * 4;  // 32 KiB
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+
+// two f32 -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 (compiler-visible, so the
+// scheduler can interleave it with MFMAs; an inline-asm version is opaque to it)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+
+// x[0..7] (f32) -> hi (8 bf16, RNE) and lo = bf16(x - hi): x = hi + lo + O(2^-16 |x|)
+__device__ __forceinline__ void split8(const f4& a, const f4& b, s8& hi, s8& lo) {
+    u4 h, l;
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t pk = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
+        const float h0 = __uint_as_float(pk << 16);
+        const float h1 = __uint_as_float(pk & 0xFFFF0000u);
+        h[i] = pk;
+        l[i] = cvt_pk_bf16(x[2 * i] - h0, x[2 * i + 1] - h1);
+    }
+    hi = __builtin_bit_cast(s8, h);
+    lo = __builtin_bit_cast(s8, l);
+}
+
+constexpr int kRing = 4;         // LDS stages in the DMA ring (3 in flight while one is consumed: ~96 KiB per CU)
+
+// issue the LDS-DMA of one stage into LDS buffer `buf`.  `stage_base` = corpus + (tile*64*ld + kc*128)
+// (wave-uniform); `loff[pp]` = this lane's byte offset for piece pp, computed once per kernel.
+// wave w moves pieces 8w..8w+7; piece p = rows 2p,2p+1 (2 x 512 B); lane i -> row 2p+(i>>5), LDS chunk
+// i&31, global chunk (i&31) ^ (row&15)  (the swizzle lives on the source side: the LDS side of an
+// LDS-DMA is always wave-base + lane*16).
+template <int AUX>
+__device__ __forceinline__ void stage_dma(const float* stage_base, const uint32_t (&loff)[8], float* buf,
+                                          uint32_t wave) {
+#pragma unroll
+    for (int pp = 0; pp < 8; pp++) {
+        const char* src = reinterpret_cast<const char*>(stage_base) + loff[pp];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + (wave * 8u + (uint32_t)pp) * 256u),
+                                         16, 0, AUX);  // AUX = 2: non-temporal
+    }
+}
+
+// |v| of the 64 rows of a tile, also by LDS-DMA (one dword per lane): the streaming loop then contains
+// no ordinary VGPR-destination load, so nothing makes the compiler drain the DMA queue with vmcnt(0).
+__device__ __forceinline__ void norms_dma(const float* __restrict__ norms, uint64_t tile, float* nbuf, uint32_t lane) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(norms + tile * kTileRows + lane),
+                                     (__attribute__((address_space(3))) void*)nbuf, 4, 0, 0);
+}
+
+// wait until at most `stages_after` younger stages (8 DMA ops each) are still in flight.  vmcnt retires
+// in issue order on gfx9-class parts, so this guarantees the oldest stage has landed; the few extra
+// ops some waves carry (norm DMA, epilogue stores) only make the wait slightly conservative.
+__device__ __forceinline__ void wait_stage(uint32_t stages_after) {
+    if (stages_after >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (stages_after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (stages_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Workgroup = 4 waves, one per SIMD (the kernel needs ~300 of the 512 registers a lone wave may use).
+// Wave w owns k-step w (32 of the 128 floats) of EVERY stage, for all 64 rows and all 64 queries: every
+// corpus element is therefore read from LDS and split into hi/lo bf16 exactly once per workgroup (an
+// earlier layout with the queries spread over the waves converted each element four times and was
+// VALU-bound at 12 VALU per MFMA).  Its 64 queries x 32 k stationary B-fragments cost KC*32 VGPRs
+// (192 at dim 768), the 4 row-blocks x 4 query-groups of accumulators 64.  The four K-quarter partial
+// sums of a tile meet once per tile through LDS; wave w then finishes query group w.
+template <int KC, int METRIC, bool MASKED, int AUX>
+__global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | exchange | norms
+    float* xch = lds + kRing * (kStageBytes / 4);                // [4 src waves][64 lanes][4 rb] f4, reused per round
+    float* nrm = xch + 4 * 64 * 16;                              // [2 tiles][64] row magnitudes
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g = lane >> 4, n = lane & 15u;
+    const uint32_t ld = p.ld;
+    const uint32_t q0 = blockIdx.y * kMfmaQ;
+
+    // ---- stationary operand: 64 queries x this wave's k-step of every stage --------------------
+    s8 bhi[KC][4], blo[KC][4];
+#pragma unroll
+    for (int qg = 0; qg < 4; qg++) {
+        const uint32_t qq = q0 + (uint32_t)qg * 16u + n;
+        const bool ok = qq < p.nq;
+        const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            const uint32_t k0 = (uint32_t)kc * kStageK + wave * 32u;
+            f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                a = *reinterpret_cast<const f4*>(qv + k0 + g * 4u);
+                b = *reinterpret_cast<const f4*>(qv + k0 + 16u + g * 4u);
+            }
+            split8(a, b, bhi[kc][qg], blo[kc][qg]);
+        }
+    }
+    const uint32_t qn = q0 + wave * 16u + n;  // the query this lane FINISHES (C column of group `wave`)
+    const bool q_ok = qn < p.nq;
+    const float qmag = q_ok ? p.qinfo[qn].qmag : 0.f;
+
+    const uint32_t t0 = blockIdx.x * p.tiles_per_wave;  // tiles per WORKGROUP on this path
+    if (t0 >= p.n_tiles) return;
+    const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+    const uint32_t n_stage = (t1 - t0) * KC;
+
+    uint32_t loff[8];  // per-lane source byte offsets of the 8 DMA pieces this wave moves per stage
+#pragma unroll
+    for (int pp = 0; pp < 8; pp++) {
+        const uint32_t r = 2u * (wave * 8u + (uint32_t)pp) + (lane >> 5);
+        loff[pp] = (r * ld + (((lane & 31u) ^ (r & 15u)) * 4u)) * 4u;
+    }
+    auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const float* {
+        return p.corpus + (uint64_t)tile_ * kTileRows * ld + kc_ * kStageK;
+    };
+
+    // prologue: stages 0..kRing-2 in flight (stage s lives in ring slot s % kRing)
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < kRing - 1; s0++) {
+        if (s0 < n_stage) {
+            if (METRIC == NMN_METRIC_COSINE && wave == 0 && s0 % KC == 0)
+                norms_dma(p.norms, t0 + s0 / KC, nrm + ((s0 / KC) & 1u) * 64u, lane);
+            stage_dma<AUX>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
+        }
+    }
+
+    // LDS offsets of this lane's two 16-B reads per row block (swizzled chunk ^ (row & 15), row & 15 == n)
+    const uint32_t off0 = n * kStageK + (((wave * 8u + g) ^ n) * 4u);
+    const uint32_t off1 = n * kStageK + (((wave * 8u + 4u + g) ^ n) * 4u);
+
+    uint32_t wmax = kKeyMasked;
+    uint32_t sidx = 0;  // running stage index of this workgroup
+    for (uint32_t tile = t0; tile < t1; tile++) {
+        f4 acc[4][4];  // [row block][query group]
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int qg = 0; qg < 4; qg++) acc[rb][qg] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++, sidx++) {
+            const float* buf = lds + (sidx % kRing) * (kStageBytes / 4);
+            // RAW: stage sidx has landed once every wave saw its own pieces retire (counted vmcnt: the
+            // younger stages stay in flight) and all waves met at the barrier.  WAR: a wave reaches this
+            // barrier only after consuming (lgkmcnt) its reads of stage sidx-1, whose ring slot is the
+            // one the DMA issued right below (stage sidx+kRing-1) overwrites.
+            wait_stage(min(n_stage - 1u - sidx, (uint32_t)(kRing - 2)));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const uint32_t ns = sidx + (kRing - 1);
+                if (ns < n_stage) {
+                    const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
+                    if (METRIC == NMN_METRIC_COSINE && wave == 0 && nkc == 0)
+                        norms_dma(p.norms, nt, nrm + ((nt - t0) & 1u) * 64u, lane);
+                    stage_dma<AUX>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
+                }
+            }
+            // software pipeline over the 4 row blocks: the LDS reads + hi/lo split of block rb+1 are
+            // issued between the 12 MFMAs of block rb (one wave per SIMD: nothing else hides them)
+            s8 ahi, alo;
+            {
+                const f4 xa = *reinterpret_cast<const f4*>(buf + off0);
+                const f4 xb = *reinterpret_cast<const f4*>(buf + off1);
+                split8(xa, xb, ahi, alo);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                f4 xa = {0.f, 0.f, 0.f, 0.f}, xb = {0.f, 0.f, 0.f, 0.f};
+                if (rb < 3) {
+                    xa = *reinterpret_cast<const f4*>(buf + (rb + 1) * 16 * kStageK + off0);
+                    xb = *reinterpret_cast<const f4*>(buf + (rb + 1) * 16 * kStageK + off1);
+                }
+#pragma unroll
+                for (int qg = 0; qg < 2; qg++) {
+                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
+                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[kc][qg], acc[rb][qg], 0, 0, 0);
+                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
+                }
+                s8 nhi = ahi, nlo = alo;
+                if (rb < 3) split8(xa, xb, nhi, nlo);
+#pragma unroll
+                for (int qg = 2; qg < 4; qg++) {
+                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
+                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[kc][qg], acc[rb][qg], 0, 0, 0);
+                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
+                }
+                if (rb < 3) {
+                    // 12 MFMAs with the 2 LDS reads up front and ~24 VALU of the next split spread between them
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+#pragma unroll
+                    for (int i = 0; i < 12; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
+                    }
+                }
+                ahi = nhi;
+                alo = nlo;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // ---- the four K-quarters meet.  Three rounds through one 16 KiB exchange area (the LDS is
+        // better spent on a deeper DMA ring): in round j wave w publishes its partial of query group
+        // (w+1+j) % 4 and collects, from wave (w-1-j) % 4, that wave's partial of group w.
+        f4 fin[4];
+#define NMN_XCH_PUT(W, J)                                                                          \
+    _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                               \
+        *reinterpret_cast<f4*>(xch + (((W) * 64u + lane) * 4u + (uint32_t)rb) * 4u) = acc[rb][((W) + 1 + (J)) & 3];
+#define NMN_XCH_ROUND(J)                                                                           \
+    switch (wave) {                                                                                \
+        case 0: NMN_XCH_PUT(0, J) break;                                                           \
+        case 1: NMN_XCH_PUT(1, J) break;                                                           \
+        case 2: NMN_XCH_PUT(2, J) break;                                                           \
+        default: NMN_XCH_PUT(3, J) break;                                                          \
+    }                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+    __builtin_amdgcn_s_barrier();                                                                  \
+    asm volatile("" ::: "memory");                                                                 \
+    {                                                                                              \
+        const uint32_t src = (wave + 3u - (uint32_t)(J)) & 3u;                                     \
+        _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                           \
+            fin[rb] += *reinterpret_cast<const f4*>(xch + ((src * 64u + lane) * 4u + (uint32_t)rb) * 4u); \
+    }                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+    __builtin_amdgcn_s_barrier();                                                                  \
+    asm volatile("" ::: "memory");
+        switch (wave) {
+            case 0:
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][0];
+                break;
+            case 1:
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][1];
+                break;
+            case 2:
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][2];
+                break;
+            default:
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][3];
+                break;
+        }
+        NMN_XCH_ROUND(0)
+        NMN_XCH_ROUND(1)
+        NMN_XCH_ROUND(2)
+#undef NMN_XCH_ROUND
+#undef NMN_XCH_PUT
+        {
+            // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
+            const uint64_t r0 = (uint64_t)tile * kTileRows;
+            uint64_t mword = ~0ull;
+            if constexpr (MASKED) mword = p.mask[tile];
+            const uint64_t left = p.n_rows - r0;
+            if (left < 64) mword &= (1ull << left) - 1ull;
+            uint32_t tkey = kKeyMasked;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
+                f4 vn = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (METRIC == NMN_METRIC_COSINE)
+                    vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) & 1u) * 64u + rr);
+                u4 bits;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
+                    float sc = fin[rb][e];
+                    if constexpr (METRIC == NMN_METRIC_COSINE)
+                        sc = (vn[e] == 0.f || qmag == 0.f) ? 0.f : sc / (qmag * vn[e]);
+                    bits[e] = valid ? f2u(sc) : kScoreSentinelBits;
+                    if (valid) tkey = max(tkey, score_to_key(sc));
+                }
+                if (q_ok) *reinterpret_cast<u4*>(p.scores + (uint64_t)qn * p.score_stride + r0 + rr) = bits;
+            }
+            // tile maximum of query n: combine the four lane groups
+            tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 16));
+            tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 32));
+            if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + tile] = tkey;
+            wmax = max(wmax, tkey);
+        }
+    }
+    if (q_ok && g == 0) p.wmax[(size_t)qn * p.wmax_stride + blockIdx.x] = wmax;
+}
+
+template <int KC, int METRIC, bool MASKED, int AUX>
+static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
+    const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    dim3 grid(blocks, (p.nq + kMfmaQ - 1) / kMfmaQ);
+    const size_t lds = kRing * kStageBytes + 4 * 64 * 16 * 4 + 2 * 64 * 4;
+    auto kern = scan_mfma_kernel<KC, METRIC, MASKED, AUX>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int KC, int METRIC>
+static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
+    // non-temporal LDS-DMA (the corpus is read once per sweep); NMN_MFMA_NT=0 restores the default policy
+    static const bool nt = !(getenv("NMN_MFMA_NT") && getenv("NMN_MFMA_NT")[0] == '0');
+    if (p.mask) return nt ? launch_one_mfma<KC, METRIC, true, 2>(p, s) : launch_one_mfma<KC, METRIC, true, 0>(p, s);
+    return nt ? launch_one_mfma<KC, METRIC, false, 2>(p, s) : launch_one_mfma<KC, METRIC, false, 0>(p, s);
+}
+
+template <int METRIC>
+static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
+    switch (p.ld / kStageK) {
+        case 1: return launch_kc<1, METRIC>(p, s);
+        case 2: return launch_kc<2, METRIC>(p, s);
+        case 3: return launch_kc<3, METRIC>(p, s);
+        case 4: return launch_kc<4, METRIC>(p, s);
+        case 5: return launch_kc<5, METRIC>(p, s);
+        case 6: return launch_kc<6, METRIC>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Can the MFMA sweep serve this shape?  (cosine / dot, row length a multiple of 128 floats up to 768
+// so that the 16 stationary queries of a wave fit its VGPRs.)
+bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
+    return (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT) && ld == dim && ld % kStageK == 0 &&
+           ld / kStageK >= 1 && ld / kStageK <= 6;
+}
+
+// p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
+hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
+    return p.metric == NMN_METRIC_COSINE ? launch_metric<NMN_METRIC_COSINE>(p, s)
+                                         : launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+}
+
+}  // namespace nmn

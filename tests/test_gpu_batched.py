@@ -1,0 +1,80 @@
+"""Batched queries (config 3): the MFMA sweep (>= 5 queries, cosine/dot, dim % 128 == 0) and the VALU
+multi-sweep path must both return exactly the oracle's rows and scores for every query."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def check_batch(idx, A, Q, k, metric, mask=None):
+    rows, scores, counts, st = idx.search(Q, k, metric, mask=mask, with_stats=True)
+    for qi in range(Q.shape[0]):
+        er, es = oc.search(A, Q[qi], k, metric, mask=mask)
+        c = er.size
+        assert counts[qi] == c, (qi, counts[qi], c)
+        assert np.array_equal(rows[qi, :c], er), (qi, rows[qi, :8], er[:8])
+        assert np.all(scores[qi, :c] == es), qi
+        assert np.all(rows[qi, c:] == U64_MAX)
+    return st
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 768, 64, 100), (20000, 768, 5, 10), (9000, 128, 16, 20),
+                                      (30000, 256, 70, 50), (4000, 384, 33, 7), (70000, 512, 64, 100),
+                                      (100, 640, 8, 200)])
+def test_mfma_batch_matches_oracle(metric, n, d, nq, k):
+    from neumann_amd import GpuFlatIndex
+    A = oc.synth(1000 + n + d, 0, n, d)
+    Q = oc.synth(2000 + nq, 0, nq, d)
+    Q[nq // 2] = A[n // 3]                       # one query equal to a stored row
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(1000 + n + d, n)
+        st = check_batch(idx, A, Q, k, metric)
+        assert st.fallback_queries == 0
+        rng = np.random.default_rng(n)
+        check_batch(idx, A, Q, k, metric, mask=oc.mask_from_bool(rng.random(n) < 0.3))
+
+
+def test_mfma_batch_with_planted_near_ties_and_duplicates():
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 12000, 768, 16, 20
+    A = (rng.standard_normal((n, d)) * 0.05).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    for qi in range(4):                          # near-copies of 4 queries, last-ulp perturbations
+        for j in range(30):
+            v = Q[qi].copy()
+            pos = rng.integers(0, d, 4)
+            v[pos] = np.nextafter(v[pos], np.float32(np.inf if j % 2 else -np.inf))
+            A[rng.integers(0, n)] = v
+    A[5000:5010] = A[4999]                       # exact duplicates
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for metric in (0, 2):
+            check_batch(idx, A, Q, k, metric)
+
+
+def test_euclidean_batches_use_valu_sweeps():
+    from neumann_amd import GpuFlatIndex
+    n, d, nq, k = 15000, 256, 11, 30
+    A = oc.synth(77, 0, n, d)
+    Q = oc.synth(78, 0, nq, d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(77, n)
+        check_batch(idx, A, Q, k, 1)
+
+
+def test_batch_matches_single_query_calls():
+    """A batch is exactly the concatenation of single-query searches (rows, scores, counts)."""
+    from neumann_amd import GpuFlatIndex
+    n, d, nq, k = 50000, 768, 64, 100
+    Q = oc.synth(91, 0, nq, d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(90, n)
+        br, bs, bc = idx.search(Q, k, 0)
+        for qi in range(0, nq, 7):
+            r, s, c = idx.search(Q[qi], k, 0)
+            assert np.array_equal(br[qi], r[0]) and np.array_equal(bs[qi], s[0]) and bc[qi] == c[0]
