@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--nq", type=int, default=1, help="queries per step")
     ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--mask", type=float, default=1.0,
+                    help="selectivity of a synthetic WHERE-predicate bitmap (config 5); 1.0 = no mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     ap.add_argument("--no-parity", action="store_true")
@@ -92,7 +94,7 @@ def cpu_baseline(args, metric, total_rows, device):
     }
 
 
-def certificate(idx, q_host, metric, rows, scores, counts, world, dev):
+def certificate(idx, q_host, metric, rows, scores, counts, world, dev, mask_host=None):
     """Size-independent proof that (rows, scores) is the exact top-k of the whole sharded corpus, using
     only the product's exact (reference-order) kernels, which tests/ pin bit-for-bit to the oracle:
       1. every returned score equals the exact score of its row (owner shard recomputes it);
@@ -112,7 +114,7 @@ def certificate(idx, q_host, metric, rows, scores, counts, world, dev):
         ok_scores = bool(np.all(ex == s[mine]))
     ordered = bool(np.all((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (r[:-1] < r[1:])))) if cnt > 1 else True
     sk = float(s[-1]) if cnt else float("inf")
-    gt, eq = idx.count_exact(q_host, sk, metric) if cnt else (0, 0)
+    gt, eq = idx.count_exact(q_host, sk, metric, mask=mask_host) if cnt else (0, 0)
     agg = torch.tensor([gt, eq, 0 if ok_scores else 1], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(agg)
@@ -164,9 +166,20 @@ def main():
     q_host = np.stack([_synth(SEED_QUERY, s * args.nq, args.nq, args.dim) for s in range(n_query_sets)])
     q_dev = torch.from_numpy(q_host).to(dev)  # [sets, nq, dim] resident in HBM
     searcher = ShardedSearcher(idx, world_size=world, rank=rank, k=args.k, nq=args.nq, device=dev)
+    mask_host = mask_dev = None
+    kept_rows = local_rows
+    if args.mask < 1.0:
+        # relational_engine-style selection bitmap (bit i of word i/64, LSB first), resident in HBM
+        keep = np.random.default_rng(0x5EED0005 + rank).random(local_rows) < args.mask
+        kept_rows = int(keep.sum())
+        words = (local_rows + 63) // 64
+        padded = np.zeros(words * 64, dtype=bool)
+        padded[:local_rows] = keep
+        mask_host = np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words)
+        mask_dev = torch.from_numpy(mask_host.view(np.int64)).to(dev)
 
     def step(i):
-        return searcher.search_device(q_dev[i % n_query_sets], metric)
+        return searcher.search_device(q_dev[i % n_query_sets], metric, mask_t=mask_dev)
 
     def fence():
         if world > 1:
@@ -206,7 +219,7 @@ def main():
     # dim <= 768), else 4 (VALU) — mirrors search_enqueue() in neumann_amd/csrc/nmn_api.hip
     mfma = args.nq >= 5 and args.metric in ("cosine", "dot") and args.dim % 128 == 0 and args.dim <= 768
     passes = (args.nq + 63) // 64 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
-    alg_bytes = local_rows * args.dim * 4 * passes
+    alg_bytes = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
 
     # ---- parity of the last result ----------------------------------------------------------------
@@ -214,7 +227,7 @@ def main():
     if not args.no_parity:
         o_rows, o_scores, o_counts = last_out
         parity = certificate(idx, q_host[(args.steps - 1) % n_query_sets][0], metric,
-                             o_rows.view(np.uint64), o_scores, o_counts, world, dev)
+                             o_rows.view(np.uint64), o_scores, o_counts, world, dev, mask_host)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -226,7 +239,8 @@ def main():
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={args.nq}/step",
+            "config": {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={args.nq}/step"
+                                   + (f", WHERE mask selectivity {args.mask}" if args.mask < 1.0 else ""),
                        "rows_total": total_rows, "rows_per_gpu": local_rows, "dim": args.dim, "k": args.k,
                        "nq": args.nq, "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -144,18 +144,29 @@ __device__ uint32_t count_valid(KeyAt key_at, uint32_t n, uint32_t* s_word) {
 
 // ---- main-path selection: one workgroup per query ---------------------------------------------
 // The scan left a three-level maximum hierarchy: scores[row] -> tmax[64-row tile] -> wmax[scan wave =
-// `tiles_per_wave` consecutive tiles] (<= 4096 entries, kept in LDS here).  A lower bound T on the
-// k-th best approximate score is the k-th largest key of ONE level: at least k groups of that level
-// hold a row >= T.  The coarsest level with comfortably more valid groups than k is used (>= 8k waves,
-// else >= 2k tiles, else rows), which also keeps sparse / clustered predicate masks on a fast path.
-// Collection then walks down the hierarchy: waves with wmax >= Tc -> their tiles with tmax >= Tc ->
-// their rows with key >= Tc, Tc = key(score(T) - margin).  Typical traffic at 10M rows,
-// k = 100: 16 KB of wmax + ~100 waves x 39 tile maxima + ~103 tiles x 256 B of scores.
+// `tiles_per_wave` consecutive tiles] (<= 4096 entries, kept in LDS here).  The k-th largest key of ANY
+// level is a lower bound on the k-th best approximate score (k groups of that level each hold a row at
+// least that good), and everything below a valid bound can be dropped before looking one level down.
+// Top-down refinement, all lists compacted in LDS:
+//   Tw = k-th largest wave maximum                  (LDS only)
+//   LT = tiles >= Tw-margin inside waves >= Tw-margin, T2 = k-th largest of LT   (reads those waves' tmax)
+//   LR = rows  >= T2-margin inside tiles >= T2-margin, T3 = k-th largest of LR   (reads those tiles' scores)
+//   candidates = LR entries >= T3-margin  — i.e. k rows plus those within the rounding margin.
+// Expected list sizes are k(1+small) at every level, whatever the shard size; global reads at 10M rows,
+// k = 100: 16 KB wmax + ~100 x 39 tile maxima + ~105 x 256 B of scores.  If a compact list overflows
+// (more than 8192 groups within the margin: heavy ties, or fewer valid waves than k with many valid
+// tiles) the generic three-level code below takes over.
+constexpr uint32_t kCompCap = 8192;
+constexpr size_t kSelectLds = 2 * kCompCap * 8 + kMaxScanWaves * 4 + kBins * 4;  // 152 KiB
+
 __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
-    __shared__ uint32_t hist[kBins];
-    __shared__ uint32_t wk[kMaxScanWaves];
-    __shared__ uint32_t la[kListCap];  // waves (valid, then passing)
-    __shared__ uint32_t lb[kListCap];  // tiles (valid at row level, then passing)
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sel_lds[];
+    unsigned long long* LT = sel_lds;                              // (key << 32 | tile)
+    unsigned long long* LR = sel_lds + kCompCap;                   // (key << 32 | row)
+    uint32_t* wk = reinterpret_cast<uint32_t*>(sel_lds + 2 * kCompCap);
+    uint32_t* hist = wk + kMaxScanWaves;
+    uint32_t* la = reinterpret_cast<uint32_t*>(LR);                // passing waves (dead before LR is filled)
+    uint32_t* lb = la + kListCap;                                  // generic path: tile list
     __shared__ PickResult pick;
     __shared__ uint32_t s_w[4];
     const uint32_t q = blockIdx.x;
@@ -167,6 +178,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const QInfo qi = p.qinfo[q];
     uint32_t* out = p.cand_rows + (size_t)q * p.cand_cap;
     const uint32_t k = p.k;
+    constexpr int V = 8;
 
     for (uint32_t i = tid; i < kMaxScanWaves; i += kSelThreads) wk[i] = i < W ? wmax[i] : kKeyMasked;
     __syncthreads();
@@ -175,52 +187,126 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         if (tid == 0) { p.qstate[q].cand_count = 0; p.qstate[q].n_valid = 0; }
         return;
     }
+    // ---- level W ---------------------------------------------------------------------------
+    uint32_t Tw = kKeyNaN;
+    if (vw >= k) Tw = radix2([&](uint32_t e) { return wk[e]; }, W, k, hist, &pick);
+    const uint32_t Twm = margin_key(Tw, qi);
+    if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < W; i += kSelThreads)
+        if (wk[i] != kKeyMasked && wk[i] >= Twm) la[atomicAdd(&s_w[0], 1u)] = i;  // <= W <= kListCap
+    __syncthreads();
+    const uint32_t nA = s_w[0];
+    // ---- level T: compact (key,tile) of tiles >= Twm in passing waves -------------------------
+    {
+        const uint32_t slots = nA * tpw;
+        for (uint32_t e0 = tid; e0 < slots; e0 += kSelThreads * V) {
+            uint32_t tk[V], tt[V];
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                tt[u] = e < slots ? la[e / tpw] * tpw + e % tpw : 0xFFFFFFFFu;
+                tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
+            }
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                if (tk[u] != kKeyMasked && tk[u] >= Twm) {
+                    const uint32_t pos = atomicAdd(&s_w[1], 1u);
+                    if (pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t ct = s_w[1];
+    uint32_t Tc = Twm;
+    bool done = false;
+    if (ct <= kCompCap) {
+        uint32_t T2 = Tw;
+        if (ct > k) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);
+        const uint32_t T2m = margin_key(T2, qi);
+        Tc = T2m;
+        // ---- level R: compact (key,row) of rows >= T2m in tiles >= T2m (la is dead: LR may be written)
+        __syncthreads();
+        const uint32_t tot = ct * kTileRows;
+        for (uint32_t e0 = tid; e0 < tot; e0 += kSelThreads * V) {
+            uint32_t kb[V], rr[V];
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                kb[u] = kScoreSentinelBits;
+                rr[u] = 0;
+                if (e < tot) {
+                    const unsigned long long ent = LT[e >> 6];
+                    if ((uint32_t)(ent >> 32) >= T2m) {
+                        rr[u] = (uint32_t)(ent & 0xFFFFFFFFull) * kTileRows + (e & 63u);
+                        kb[u] = scores[rr[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t key = bits_to_key(kb[u]);
+                if (key != kKeyMasked && key >= T2m) {
+                    const uint32_t pos = atomicAdd(&s_w[2], 1u);
+                    if (pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | rr[u];
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t cr = s_w[2];
+        if (cr <= kCompCap) {
+            uint32_t T3 = T2;
+            if (cr > k) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
+            Tc = margin_key(T3, qi);  // >= T2m: every row that can matter is in LR
+            for (uint32_t e = tid; e < cr; e += kSelThreads) {
+                const unsigned long long ent = LR[e];
+                if ((uint32_t)(ent >> 32) >= Tc) {
+                    const uint32_t pos = atomicAdd(&s_w[3], 1u);
+                    if (pos < p.cand_cap) out[pos] = (uint32_t)(ent & 0xFFFFFFFFull);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t c = s_w[3];
+                QState st;
+                st.n_valid = vw;
+                st.thr_key = Tc;
+                st.overflow = c > p.cand_cap ? 1u : 0u;
+                st.cand_count = c > p.cand_cap ? 0u : c;
+                p.qstate[q] = st;
+            }
+            done = true;
+        }
+    }
+    if (done) return;
 
-    uint32_t Tc = kKeyNaN;  // default: every participating row is a candidate
-    if (vw >= 8u * k) {
-        Tc = margin_key(radix2([&](uint32_t e) { return wk[e]; }, W, k, hist, &pick), qi);
-    } else {
-        // too few waves hold valid rows (small shard, large k, or a clustered mask): go one level down
+    // ---- generic path (a compact list overflowed) ------------------------------------------------
+    __syncthreads();
+    if (ct > kCompCap) {
+        // tile-level bound from the un-compacted tile keys of every valid wave
         if (tid == 0) s_w[1] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < W; i += kSelThreads)
-            if (wk[i] != kKeyMasked) la[atomicAdd(&s_w[1], 1u)] = i;  // vw <= W <= kListCap
+            if (wk[i] != kKeyMasked && wk[i] >= Twm) la[atomicAdd(&s_w[1], 1u)] = i;
         __syncthreads();
-        const uint32_t slots = vw * tpw;
+        const uint32_t slots = s_w[1] * tpw;
         auto tile_key = [&](uint32_t e) -> uint32_t {
             const uint32_t t = la[e / tpw] * tpw + e % tpw;
-            return t < n_tiles ? tmax[t] : kKeyMasked;
+            const uint32_t key = t < n_tiles ? tmax[t] : kKeyMasked;
+            return key >= Twm ? key : kKeyMasked;
         };
         const uint32_t vt = count_valid(tile_key, slots, &s_w[2]);
-        if (vt >= 2u * k || vt > kListCap) {
-            Tc = margin_key(radix2(tile_key, slots, k, hist, &pick), qi);
-        } else {
-            // row level over the (few) valid tiles
-            if (tid == 0) s_w[1] = 0;
-            __syncthreads();
-            for (uint32_t e = tid; e < slots; e += kSelThreads) {
-                const uint32_t t = la[e / tpw] * tpw + e % tpw;
-                if (t < n_tiles && tmax[t] != kKeyMasked) lb[atomicAdd(&s_w[1], 1u)] = t;  // vt <= kListCap
-            }
-            __syncthreads();
-            auto row_key = [&](uint32_t e) -> uint32_t {
-                return bits_to_key(scores[(uint64_t)lb[e >> 6] * kTileRows + (e & 63u)]);
-            };
-            const uint32_t vr = count_valid(row_key, vt * kTileRows, &s_w[2]);
-            if (vr > k) Tc = margin_key(radix2(row_key, vt * kTileRows, k, hist, &pick), qi);
-        }
+        if (vt > k) Tc = margin_key(radix2(tile_key, slots, k, hist, &pick), qi);
     }
-
-    // ---- collection: waves -> tiles -> rows --------------------------------------------------
+    // collection: waves -> tiles -> rows, all >= Tc
     if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; }
     __syncthreads();
     for (uint32_t i = tid; i < W; i += kSelThreads)
         if (wk[i] != kKeyMasked && wk[i] >= Tc) la[atomicAdd(&s_w[0], 1u)] = i;
     __syncthreads();
-    const uint32_t nA = s_w[0];
-    constexpr int V = 8;
     {
-        const uint32_t slots = nA * tpw;
+        const uint32_t slots = s_w[0] * tpw;
         for (uint32_t e0 = tid; e0 < slots; e0 += kSelThreads * V) {
             uint32_t tk[V], tt[V];
 #pragma unroll
@@ -275,7 +361,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 }
 
 hipError_t launch_select(const SelectParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(select_kernel, dim3(p.nq), dim3(kSelThreads), 0, s, p);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelectLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(select_kernel, dim3(p.nq), dim3(kSelThreads), kSelectLds, s, p);
     return hipGetLastError();
 }
 
