@@ -178,6 +178,14 @@ nmn_status nmn_merge_topk_device(const uint64_t* rows_dev, const float* scores_d
                                  uint64_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev,
                                  void* stream);
 
+/* Same merge over an all-gather of PACKED per-rank blocks: rank l's rows / scores / counts start at
+ * (char*)rows_dev + l*list_stride_bytes etc., so one collective can move all three fields.  With
+ * list_stride_bytes == 0 the layout is the contiguous one of nmn_merge_topk_device. */
+nmn_status nmn_merge_topk_device_strided(const uint64_t* rows_dev, const float* scores_dev,
+                                         const uint32_t* counts_dev, uint64_t list_stride_bytes, uint32_t n_lists,
+                                         uint32_t nq, uint32_t k, uint64_t* out_rows_dev, float* out_scores_dev,
+                                         uint32_t* out_counts_dev, void* stream);
+
 /* ---- synthetic data (bench / tests) ------------------------------------------------------- */
 
 /* value(seed,row,col): a counter-based generator that is bit-identical on host and device

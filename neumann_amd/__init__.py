@@ -5,7 +5,7 @@ host-side mirror of the reference's `VectorEngine` interface for this path, and 
 sharding layer (one process per GPU, RCCL all-gather of per-shard top-k).
 """
 from ._capi import NeumannGpuError, load as load_library  # noqa: F401
-from .flat_index import (DistanceMetric, GpuFlatIndex, merge_topk_device, merge_topk_host,  # noqa: F401
-                         synth_rows)
+from .flat_index import (DistanceMetric, GpuFlatIndex, merge_topk_device, merge_topk_device_packed,  # noqa: F401
+                         merge_topk_host, packed_layout, synth_rows)
 
 __version__ = "0.1.0"

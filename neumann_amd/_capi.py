@@ -75,6 +75,8 @@ SIGNATURES = {
     "nmn_index_count_exact": (C.c_int32, [vp, vp, C.c_int32, vp, C.c_float, u64p, u64p]),
     "nmn_merge_topk_host": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "nmn_merge_topk_device": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
+    "nmn_merge_topk_device_strided": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  vp, vp, vp, vp]),
     "nmn_synth_value": (C.c_float, [C.c_uint64, C.c_uint64, C.c_uint32]),
     "nmn_synth_fill_host": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "nmn_index_fill_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),

@@ -668,8 +668,22 @@ extern "C" nmn_status nmn_merge_topk_device(const uint64_t* rows_dev, const floa
         return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (k == 0) return fail_arg(NMN_ERR_INVALID_TOP_K, "k == 0");
     if (nq == 0 || n_lists == 0) return NMN_OK;
-    HIP_TRY(launch_merge(rows_dev, scores_dev, counts_dev, n_lists, nq, k, out_rows_dev, out_scores_dev,
+    HIP_TRY(launch_merge(rows_dev, scores_dev, counts_dev, 0, n_lists, nq, k, out_rows_dev, out_scores_dev,
                          out_counts_dev, static_cast<hipStream_t>(stream)));
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_merge_topk_device_strided(const uint64_t* rows_dev, const float* scores_dev,
+                                                    const uint32_t* counts_dev, uint64_t list_stride_bytes,
+                                                    uint32_t n_lists, uint32_t nq, uint32_t k,
+                                                    uint64_t* out_rows_dev, float* out_scores_dev,
+                                                    uint32_t* out_counts_dev, void* stream) {
+    if (!rows_dev || !scores_dev || !counts_dev || !out_rows_dev || !out_scores_dev || !out_counts_dev)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (k == 0) return fail_arg(NMN_ERR_INVALID_TOP_K, "k == 0");
+    if (nq == 0 || n_lists == 0) return NMN_OK;
+    HIP_TRY(launch_merge(rows_dev, scores_dev, counts_dev, list_stride_bytes, n_lists, nq, k, out_rows_dev,
+                         out_scores_dev, out_counts_dev, static_cast<hipStream_t>(stream)));
     return NMN_OK;
 }
 

@@ -125,9 +125,10 @@ struct FinalParams {
 };
 hipError_t launch_final(const FinalParams& p, hipStream_t s);
 
-hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_t* counts, uint32_t n_lists,
-                        uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
-                        hipStream_t s);
+// list l of each field starts `list_stride_bytes` * l bytes after list 0 (0 = contiguous [list][nq][k])
+hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_t* counts, uint64_t list_stride_bytes,
+                        uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores,
+                        uint32_t* out_counts, hipStream_t s);
 
 // exact (reference-order) kernels
 hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,

@@ -496,33 +496,41 @@ __device__ __forceinline__ bool hit_before(uint32_t ka, uint64_t ra, uint32_t kb
     return ka > kb || (ka == kb && ra < rb);
 }
 
-__global__ void __launch_bounds__(256) merge_kernel(const uint64_t* __restrict__ rows,
-                                                    const float* __restrict__ scores,
-                                                    const uint32_t* __restrict__ counts, uint32_t n_lists,
-                                                    uint32_t nq, uint32_t k, uint64_t* __restrict__ out_rows,
-                                                    float* __restrict__ out_scores,
+struct MergeView {
+    const char* rows;
+    const char* scores;
+    const char* counts;
+    uint64_t stride_r, stride_s, stride_c;  // bytes between consecutive lists
+    __device__ const uint64_t* R(uint32_t l) const { return reinterpret_cast<const uint64_t*>(rows + l * stride_r); }
+    __device__ const float* S(uint32_t l) const { return reinterpret_cast<const float*>(scores + l * stride_s); }
+    __device__ const uint32_t* C(uint32_t l) const { return reinterpret_cast<const uint32_t*>(counts + l * stride_c); }
+};
+
+__global__ void __launch_bounds__(256) merge_kernel(MergeView v, uint32_t n_lists, uint32_t nq, uint32_t k,
+                                                    uint64_t* __restrict__ out_rows, float* __restrict__ out_scores,
                                                     uint32_t* __restrict__ out_counts) {
     const uint32_t q = blockIdx.x;
     uint32_t total = 0;
-    for (uint32_t l = 0; l < n_lists; l++) total += min(counts[(size_t)l * nq + q], k);
+    for (uint32_t l = 0; l < n_lists; l++) total += min(v.C(l)[q], k);
     const uint32_t cnt = min(total, k);
     for (uint32_t e = threadIdx.x; e < n_lists * k; e += blockDim.x) {
         const uint32_t l = e / k, i = e - l * k;
-        const uint32_t cl = min(counts[(size_t)l * nq + q], k);
+        const uint32_t cl = min(v.C(l)[q], k);
         if (i >= cl) continue;
-        const size_t base = ((size_t)l * nq + q) * k;
-        const float sc = scores[base + i];
+        const size_t base = (size_t)q * k;
+        const float sc = v.S(l)[base + i];
         const uint32_t key = score_to_key(sc);
-        const uint64_t row = rows[base + i];
+        const uint64_t row = v.R(l)[base + i];
         uint32_t rank = i;
         for (uint32_t m = 0; m < n_lists; m++) {
             if (m == l) continue;
-            const uint32_t cm = min(counts[(size_t)m * nq + q], k);
-            const size_t bm = ((size_t)m * nq + q) * k;
+            const uint32_t cm = min(v.C(m)[q], k);
+            const uint64_t* rm = v.R(m) + base;
+            const float* sm = v.S(m) + base;
             uint32_t lo = 0, hi = cm;  // first index in list m that does NOT precede e
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (hit_before(score_to_key(scores[bm + mid]), rows[bm + mid], key, row)) lo = mid + 1;
+                if (hit_before(score_to_key(sm[mid]), rm[mid], key, row)) lo = mid + 1;
                 else hi = mid;
             }
             rank += lo;
@@ -539,11 +547,17 @@ __global__ void __launch_bounds__(256) merge_kernel(const uint64_t* __restrict__
     if (threadIdx.x == 0) out_counts[q] = cnt;
 }
 
-hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_t* counts, uint32_t n_lists,
-                        uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(256), 0, s, rows, scores, counts, n_lists, nq, k, out_rows,
-                       out_scores, out_counts);
+hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_t* counts, uint64_t list_stride_bytes,
+                        uint32_t n_lists, uint32_t nq, uint32_t k, uint64_t* out_rows, float* out_scores,
+                        uint32_t* out_counts, hipStream_t s) {
+    MergeView v;
+    v.rows = reinterpret_cast<const char*>(rows);
+    v.scores = reinterpret_cast<const char*>(scores);
+    v.counts = reinterpret_cast<const char*>(counts);
+    v.stride_r = list_stride_bytes ? list_stride_bytes : (uint64_t)nq * k * 8;
+    v.stride_s = list_stride_bytes ? list_stride_bytes : (uint64_t)nq * k * 4;
+    v.stride_c = list_stride_bytes ? list_stride_bytes : (uint64_t)nq * 4;
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(256), 0, s, v, n_lists, nq, k, out_rows, out_scores, out_counts);
     return hipGetLastError();
 }
 

@@ -227,6 +227,33 @@ def merge_topk_device(rows_t, scores_t, counts_t, k, stream=None):
     return o_r, o_s, o_c
 
 
+def packed_layout(nq, k):
+    """Byte layout of one rank's packed result block: (size, offset of scores, offset of counts)."""
+    off_s = nq * k * 8
+    off_c = off_s + nq * k * 4
+    return (off_c + nq * 4 + 15) // 16 * 16, off_s, off_c
+
+
+def merge_topk_device_packed(gathered_t, n_lists, nq, k, out=None, stream=None):
+    """Device merge of `n_lists` PACKED blocks ([rows i64 | scores f32 | counts i32], see packed_layout)
+    laid end to end in the uint8 tensor `gathered_t` — the output of ONE all-gather."""
+    import torch
+
+    lib = _capi.load()
+    size, off_s, off_c = packed_layout(nq, k)
+    assert gathered_t.dtype == torch.uint8 and gathered_t.numel() >= n_lists * size
+    if out is None:
+        out = (torch.empty((nq, k), dtype=torch.int64, device=gathered_t.device),
+               torch.empty((nq, k), dtype=torch.float32, device=gathered_t.device),
+               torch.empty((nq,), dtype=torch.int32, device=gathered_t.device))
+    g = gathered_t.data_ptr()
+    _capi.check(lib.nmn_merge_topk_device_strided(
+        C.c_void_p(g), C.c_void_p(g + off_s), C.c_void_p(g + off_c), size, int(n_lists), int(nq), int(k),
+        C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()),
+        _stream_ptr(stream)))
+    return out
+
+
 def synth_rows(seed, row0, n, dim):
     """Host copy of the synthetic generator (bit-identical to the device fill)."""
     out = np.empty((n, dim), dtype=np.float32)

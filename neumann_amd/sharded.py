@@ -43,19 +43,23 @@ class ShardedSearcher:
 
     # ---- GPU path ------------------------------------------------------------------------------
     def _alloc(self):
+        """One packed block per rank: [rows nq*k i64 | scores nq*k f32 | counts nq i32], padded to 16 B, so
+        that ONE all-gather moves all three fields (the step is latency-bound: nq*k*12 B per rank)."""
         import torch
         dev, nq, k, w = self.device, self.nq, self.k, self.world_size
+        size, off_s, off_c = flat_index.packed_layout(nq, k)
+        block = torch.empty(size, dtype=torch.uint8, device=dev)
         self._bufs = {
-            "rows": torch.empty((nq, k), dtype=torch.int64, device=dev),
-            "scores": torch.empty((nq, k), dtype=torch.float32, device=dev),
-            "counts": torch.empty((nq,), dtype=torch.int32, device=dev),
+            "block": block, "size": size, "off_s": off_s, "off_c": off_c,
+            "rows": block[:off_s].view(torch.int64).view(nq, k),
+            "scores": block[off_s:off_c].view(torch.float32).view(nq, k),
+            "counts": block[off_c:off_c + nq * 4].view(torch.int32),
         }
         if w > 1:
-            self._bufs.update({
-                "g_rows": torch.empty((w, nq, k), dtype=torch.int64, device=dev),
-                "g_scores": torch.empty((w, nq, k), dtype=torch.float32, device=dev),
-                "g_counts": torch.empty((w, nq), dtype=torch.int32, device=dev),
-            })
+            self._bufs["gathered"] = torch.empty(w * size, dtype=torch.uint8, device=dev)
+            self._bufs["out"] = (torch.empty((nq, k), dtype=torch.int64, device=dev),
+                                 torch.empty((nq, k), dtype=torch.float32, device=dev),
+                                 torch.empty((nq,), dtype=torch.int32, device=dev))
 
     def search_device(self, queries_t, metric, mask_t=None):
         """queries_t [nq, dim] f32 on this rank's GPU (replicated on every rank).  Everything is
@@ -69,10 +73,8 @@ class ShardedSearcher:
         if self.world_size == 1:
             return b["rows"], b["scores"], b["counts"]
         import torch.distributed as dist
-        dist.all_gather_into_tensor(b["g_rows"], b["rows"], group=self.group)
-        dist.all_gather_into_tensor(b["g_scores"], b["scores"], group=self.group)
-        dist.all_gather_into_tensor(b["g_counts"], b["counts"], group=self.group)
-        return flat_index.merge_topk_device(b["g_rows"], b["g_scores"], b["g_counts"], self.k)
+        dist.all_gather_into_tensor(b["gathered"], b["block"], group=self.group)
+        return flat_index.merge_topk_device_packed(b["gathered"], self.world_size, self.nq, self.k, out=b["out"])
 
     # ---- host path (gloo tests, router-side merge) -----------------------------------------------
     def search_host(self, queries, metric, mask=None):

@@ -64,7 +64,8 @@ def test_synth_fixture(name, device_fill):
 def test_sharded_indexes_merge_to_unsharded():
     """8 row-range shards on one GPU, device merge kernel == unsharded golden (distributed.rs:413-433)."""
     import torch
-    from neumann_amd import GpuFlatIndex, merge_topk_device, merge_topk_host, synth_rows
+    from neumann_amd import (GpuFlatIndex, merge_topk_device, merge_topk_device_packed, merge_topk_host,
+                             packed_layout, synth_rows)
     g = G.load("synth_4096x768_top100.npz")
     A = G.rebuild_corpus(g, synth_rows)
     k, S = 100, 8
@@ -86,7 +87,18 @@ def test_sharded_indexes_merge_to_unsharded():
                                            torch.from_numpy(Sc).cuda(),
                                            torch.from_numpy(C.view(np.int32)).cuda(), k)
             torch.cuda.synchronize()
-            for rr, ss, cc in ((hr, hs, hc), (dr.cpu().numpy().view(np.uint64), ds.cpu().numpy(), dc.cpu().numpy())):
+            # the same S blocks packed end to end as ONE all-gather would deliver them (sharded.py)
+            size, off_s, off_c = packed_layout(1, k)
+            packed = np.zeros(S * size, dtype=np.uint8)
+            for sh in range(S):
+                blk = packed[sh * size:(sh + 1) * size]
+                blk[:off_s] = R[sh].view(np.uint8).reshape(-1)
+                blk[off_s:off_c] = Sc[sh].view(np.uint8).reshape(-1)
+                blk[off_c:off_c + 4] = C[sh].view(np.uint8).reshape(-1)
+            pr, ps, pc = merge_topk_device_packed(torch.from_numpy(packed).cuda(), S, 1, k)
+            torch.cuda.synchronize()
+            for rr, ss, cc in ((hr, hs, hc), (dr.cpu().numpy().view(np.uint64), ds.cpu().numpy(), dc.cpu().numpy()),
+                               (pr.cpu().numpy().view(np.uint64), ps.cpu().numpy(), pc.cpu().numpy())):
                 assert cc[0] == k
                 assert np.array_equal(rr[0], g[f"rows_m{m}_q0_all"])
                 assert np.all(ss[0] == g[f"scores_m{m}_q0_all"])
