@@ -376,7 +376,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.n_tiles = n_tiles;
             sp.nq = nqc;
             // ~16 waves per CU; every wave gets the same number of tiles
-            sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + kMaxScanWaves - 1) / kMaxScanWaves);
+            static const uint32_t wave_target = [] {  // tuning knob: NMN_SCAN_WAVES in [256, kMaxScanWaves]
+                const char* e = getenv("NMN_SCAN_WAVES");
+                long v = e ? atol(e) : (long)kMaxScanWaves;
+                return (uint32_t)std::min<long>(std::max<long>(v, 256), (long)kMaxScanWaves);
+            }();
+            sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + wave_target - 1) / wave_target);
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + 255) / 256);  // per workgroup, 1 per CU
             sp.metric = (int)metric;
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));

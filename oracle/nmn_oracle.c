@@ -375,3 +375,32 @@ void orc_synth_fill(float* out, uint64_t seed, uint64_t row0, uint64_t n, uint32
     for (uint64_t i = 0; i < n; i++)
         for (uint32_t c = 0; c < dim; c++) out[i * dim + c] = orc_synth_value(seed, row0 + i, c);
 }
+
+typedef struct {
+    float* out;
+    uint64_t seed, row0, r0, r1;
+    uint32_t dim;
+} orc_fill_job;
+
+static void* orc_fill_worker(void* p) {
+    orc_fill_job* j = (orc_fill_job*)p;
+    orc_synth_fill(j->out + j->r0 * j->dim, j->seed, j->row0 + j->r0, j->r1 - j->r0, j->dim);
+    return NULL;
+}
+
+/* multi-threaded fill (the bench's CPU-baseline sample is 1M x 768 = 3 GB) */
+void orc_synth_fill_mt(float* out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    orc_fill_job jobs[256];
+    pthread_t th[256];
+    uint64_t per = (n + nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t r0 = per * t, r1 = r0 + per;
+        if (r0 > n) r0 = n;
+        if (r1 > n) r1 = n;
+        jobs[t] = (orc_fill_job){out, seed, row0, r0, r1, dim};
+    }
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, orc_fill_worker, &jobs[t]);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}

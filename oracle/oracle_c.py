@@ -48,6 +48,8 @@ def _bind(lib):
     lib.orc_synth_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
     lib.orc_synth_fill.restype = None
     lib.orc_synth_fill.argtypes = [_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+    lib.orc_synth_fill_mt.restype = None
+    lib.orc_synth_fill_mt.argtypes = [_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]
     return lib
 
 
@@ -140,9 +142,12 @@ def merge_topk(rows, scores, counts, k):
     return o_r, o_s, o_c
 
 
-def synth(seed, row0, n, dim):
+def synth(seed, row0, n, dim, nthreads=1):
     out = np.empty((n, dim), dtype=np.float32)
-    lib().orc_synth_fill(_p(out, _f32p), seed, row0, n, dim)
+    if nthreads > 1:
+        lib(native=True).orc_synth_fill_mt(_p(out, _f32p), seed, row0, n, dim, nthreads)
+    else:
+        lib().orc_synth_fill(_p(out, _f32p), seed, row0, n, dim)
     return out
 
 
