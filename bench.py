@@ -98,6 +98,20 @@ def cpu_baseline(args, metric, total_rows, device):
     }
 
 
+def pmc_traffic(rows_per_gpu, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if this
+    exact workload was profiled; bench.py cannot collect PMC counters itself (they need a rocprofv3 wrapper)."""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for e in ent:
+        if (e["rows_per_gpu"], e["dim"], e["metric"], e["nq"], e["mask"]) == (rows_per_gpu, args.dim, args.metric,
+                                                                              args.nq, args.mask):
+            return e["hbm_bytes_per_launch"], e["source"]
+    return None, None
+
+
 def certificate(idx, q_host, metric, rows, scores, counts, world, dev, mask_host=None):
     """Size-independent proof that (rows, scores) is the exact top-k of the whole sharded corpus, using
     only the product's exact (reference-order) kernels, which tests/ pin bit-for-bit to the oracle:
@@ -241,6 +255,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, metric, total_rows, local_rank)
 
+    traffic, traffic_src = pmc_traffic(local_rows, args)
     if rank == 0:
         line = {
             "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
@@ -253,7 +268,8 @@ def main():
                        "nq": args.nq, "streams": n_streams,
                        "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel", "avg_kernel_ms": scan_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None},

@@ -178,13 +178,23 @@ struct Entry {
     std::vector<float> vec;
     Meta meta;
     bool live = false;
+    int64_t mrow = -1;  // row of this entry in the GPU mirror of its dimension (-1: not mirrored yet)
 };
 
 // GPU mirror of the rows of one collection that have one dimension: the `hnsw_cache` slot of the
 // reference (lib.rs:98,1311-1328) with a flat GPU index instead of an HNSW graph.
+//
+// Maintenance: the reference drops its cache on every store/delete
+// (lib.rs:1497,1532,1866,1923) because an HNSW graph cannot be patched cheaply; a flat matrix can.
+// New keys are APPENDED into spare capacity (one 3 KB H2D copy + one norm), overwrites rewrite their
+// row in place, deletes clear the row's bit in a `live` bitmap that every search passes as (part of)
+// the predicate mask.  The mirror is rebuilt only when the spare capacity is exhausted or more than a
+// quarter of its rows are dead.  Searches always see exactly the store's current contents.
 struct Mirror {
     nmn_index* idx = nullptr;
     std::vector<uint32_t> row_to_slot;
+    std::vector<uint64_t> live;  // bit r of word r/64: row r takes part
+    uint64_t cap = 0, n_dead = 0;
     ~Mirror() {
         if (idx) nmn_index_destroy(idx);
     }
@@ -196,7 +206,7 @@ struct Collection {
     std::vector<uint32_t> free_slots;
     uint64_t live = 0;
     std::unordered_map<uint64_t, std::unique_ptr<Mirror>> mirrors;  // by dimension
-    void invalidate() { mirrors.clear(); }
+    void invalidate() { mirrors.clear(); }  // full drop (delete_collection / clear)
 };
 
 struct CollectionConfig {
@@ -240,6 +250,40 @@ struct nmn_engine {
 
 namespace {
 
+Mirror* mirror_of(Collection* c, uint64_t dim) {
+    auto it = c->mirrors.find(dim);
+    if (it == c->mirrors.end()) return nullptr;
+    if (!it->second->idx) {  // built when no row of this dimension existed: nothing to patch, rebuild lazily
+        c->mirrors.erase(it);
+        return nullptr;
+    }
+    return it->second.get();
+}
+
+// mark a mirrored row dead; rebuild later once a quarter of the mirror is dead
+void mirror_tombstone(Collection* c, uint64_t dim, int64_t row) {
+    Mirror* m = mirror_of(c, dim);
+    if (!m || row < 0) return;
+    m->live[(uint64_t)row >> 6] &= ~(1ull << ((uint64_t)row & 63));
+    m->n_dead++;
+    if (m->n_dead * 4 > m->row_to_slot.size()) c->mirrors.erase(dim);
+}
+
+// append one vector to the mirror of its dimension; returns its row, or -1 (mirror absent / dropped)
+int64_t mirror_append(Collection* c, uint64_t dim, const float* v, uint32_t slot) {
+    Mirror* m = mirror_of(c, dim);
+    if (!m) return -1;
+    const uint64_t row = m->row_to_slot.size();
+    if (row >= m->cap || nmn_index_upload(m->idx, v, row, 1) != NMN_OK) {
+        c->mirrors.erase(dim);  // out of spare capacity (or a device error): rebuild on the next search
+        return -1;
+    }
+    m->row_to_slot.push_back(slot);
+    if ((row >> 6) >= m->live.size()) m->live.push_back(0ull);
+    m->live[row >> 6] |= 1ull << (row & 63);
+    return (int64_t)row;
+}
+
 nmn_status store_into(nmn_engine* e, Collection* c, const char* key, const float* v, uint64_t dim,
                       const nmn_meta_field* meta, uint32_t n_meta) {
     Entry ent;
@@ -250,21 +294,32 @@ nmn_status store_into(nmn_engine* e, Collection* c, const char* key, const float
     ent.live = true;
     auto it = c->by_key.find(ent.key);
     if (it != c->by_key.end()) {
-        c->slots[it->second] = std::move(ent);  // put() overwrites the whole TensorData
+        // put() overwrites the whole TensorData (vector and metadata)
+        Entry& old = c->slots[it->second];
+        const uint64_t old_dim = old.vec.size();
+        Mirror* m = old.mrow >= 0 ? mirror_of(c, old_dim) : nullptr;
+        if (m && old_dim == dim) {
+            if (nmn_index_set_row(m->idx, (uint64_t)old.mrow, v) == NMN_OK) ent.mrow = old.mrow;
+            else c->mirrors.erase(old_dim);
+        } else {
+            if (m) mirror_tombstone(c, old_dim, old.mrow);
+            ent.mrow = mirror_append(c, dim, v, it->second);
+        }
+        old = std::move(ent);
     } else {
         uint32_t slot;
         if (!c->free_slots.empty()) {
             slot = c->free_slots.back();
             c->free_slots.pop_back();
-            c->slots[slot] = std::move(ent);
         } else {
             slot = (uint32_t)c->slots.size();
-            c->slots.push_back(std::move(ent));
+            c->slots.emplace_back();
         }
+        ent.mrow = mirror_append(c, dim, v, slot);
+        c->slots[slot] = std::move(ent);
         c->by_key[c->slots[slot].key] = slot;
         c->live++;
     }
-    c->invalidate();  // invalidate_hnsw_cache(collection) (lib.rs:1497,1866)
     (void)e;
     return NMN_OK;
 }
@@ -273,11 +328,11 @@ nmn_status delete_from(Collection* c, const std::string& key, const std::string&
     auto it = c->by_key.find(key);
     if (it == c->by_key.end()) return err_not_found(shown);
     Entry& ent = c->slots[it->second];
+    mirror_tombstone(c, ent.vec.size(), ent.mrow);
     ent = Entry();
     c->free_slots.push_back(it->second);
     c->by_key.erase(it);
     c->live--;
-    c->invalidate();  // lib.rs:1532,1923
     return NMN_OK;
 }
 
@@ -295,7 +350,8 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
     if (n > 0) {
         nmn_index_desc d{};
         d.dim = (uint32_t)dim;
-        d.capacity_rows = n;
+        m->cap = n + std::max<uint64_t>(n / 2, 1024);  // spare rows for appended keys
+        d.capacity_rows = m->cap;
         d.row_base = 0;
         d.device = e->cfg.device;
         d.cand_cap = e->cfg.cand_cap;
@@ -316,9 +372,10 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
             return s2;
         };
         for (uint32_t s = 0; s < c->slots.size(); s++) {
-            const Entry& ent = c->slots[s];
+            Entry& ent = c->slots[s];
             if (!ent.live || ent.vec.size() != dim) continue;
             buf.insert(buf.end(), ent.vec.begin(), ent.vec.end());
+            ent.mrow = (int64_t)m->row_to_slot.size();
             m->row_to_slot.push_back(s);
             if (buf.size() >= chunk * dim) {
                 st = flush();
@@ -327,6 +384,8 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
         }
         st = flush();
         if (st != NMN_OK) return err_gpu(st);
+        m->live.assign((n + 63) / 64, ~0ull);
+        if (n & 63) m->live.back() = (1ull << (n & 63)) - 1ull;
     }
     e->mirror_builds++;
     *out = m.get();
@@ -339,14 +398,16 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
                     const std::vector<uint64_t>* mask, nmn_results* res) {
     if (!m->idx) return NMN_OK;  // no rows of this dimension
     const uint64_t rows = nmn_index_rows(m->idx);
-    uint64_t k = std::min<uint64_t>(top_k, rows);
+    uint64_t k = std::min<uint64_t>(top_k, rows - std::min<uint64_t>(m->n_dead, rows));
     if (k == 0) return NMN_OK;
     if (k > NMN_MAX_TOP_K)
         return fail(NMN_ERR_TOP_K_TOO_LARGE, "top_k exceeds NMN_MAX_TOP_K (4096) on a collection larger than that");
     std::vector<uint64_t> out_rows(k);
     std::vector<float> out_scores(k);
     uint32_t count = 0;
-    nmn_status st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, mask ? mask->data() : nullptr,
+    // deleted rows stay in the matrix until the next rebuild: the live bitmap keeps them out of every scan
+    const uint64_t* mask_ptr = mask ? mask->data() : (m->n_dead ? m->live.data() : nullptr);
+    nmn_status st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, mask_ptr,
                                      out_rows.data(), out_scores.data(), &count, nullptr);
     if (st != NMN_OK) return err_gpu(st);
     for (uint32_t i = 0; i < count; i++) {
@@ -394,7 +455,7 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
     std::vector<uint64_t> mask((rows + 63) / 64, 0ull);
     uint64_t matching = 0;
     for (uint64_t r = 0; r < rows; r++)
-        if (evaluate_filter(c->slots[m->row_to_slot[r]].meta, f)) {
+        if (((m->live[r >> 6] >> (r & 63)) & 1ull) && evaluate_filter(c->slots[m->row_to_slot[r]].meta, f)) {
             mask[r >> 6] |= 1ull << (r & 63);
             matching++;
         }

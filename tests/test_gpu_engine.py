@@ -246,7 +246,10 @@ def test_max_dimension_and_timeout(E):
 
 
 # ---- mirror cache protocol (the hnsw_cache lifecycle, lib.rs:9686-9944) ------------------------------
-def test_mirror_built_lazily_and_invalidated_on_writes(E):
+def test_mirror_built_lazily_and_patched_on_writes(E):
+    """The reference invalidates its cache on every store/delete (cache_invalidated_on_store / _on_delete);
+    the flat GPU mirror is patched in place instead — what must hold is what those tests
+    protect: a search after a write sees exactly the store's current contents."""
     engine = E.VectorEngine()
     for i in range(50):
         engine.store_embedding(f"v{i}", [float(i + 1), 1.0, 0.5])
@@ -256,15 +259,74 @@ def test_mirror_built_lazily_and_invalidated_on_writes(E):
     engine.search_similar([2.0, 1.0, 1.0], 3)
     engine.search_similar_with_metric([2.0, 1.0, 1.0], 3, E.DistanceMetric.Euclidean)
     assert engine.mirror_builds() == 1                       # reused across searches and metrics
-    engine.store_embedding("new", [100.0, 1.0, 0.5])         # cache_invalidated_on_store
-    assert not engine.mirror_cached()
+    engine.store_embedding("new", [100.0, 1.0, 0.5])         # appended into spare capacity
     assert engine.search_similar([100.0, 1.0, 0.5], 1)[0].key == "new"
-    assert engine.mirror_builds() == 2
-    engine.delete_embedding("new")                           # cache_invalidated_on_delete
-    assert not engine.mirror_cached()
-    assert engine.search_similar([100.0, 1.0, 0.5], 1)[0].key != "new"
-    engine.store_in_collection("other", "x", [1.0, 2.0, 3.0])  # another collection leaves the default mirror alone
+    engine.store_embedding("v3", [-5.0, 2.0, 9.0])           # overwritten in place
+    r = engine.search_similar([-5.0, 2.0, 9.0], 1)[0]
+    assert r.key == "v3" and abs(r.score - 1.0) < 1e-6
+    engine.delete_embedding("new")                           # tombstoned
+    assert all(x.key != "new" for x in engine.search_similar([100.0, 1.0, 0.5], 51))
+    assert len(engine.search_similar([100.0, 1.0, 0.5], 100)) == 50
+    assert engine.mirror_builds() == 1                       # none of the above rebuilt the mirror
+    engine.store_in_collection("other", "x", [1.0, 2.0, 3.0])  # another collection has its own mirror
     assert engine.mirror_cached() and not engine.mirror_cached("other")
+
+
+def test_incremental_mirror_matches_oracle_under_churn(E):
+    """Random interleaving of inserts, overwrites (same and different dimension), deletes and searches;
+    after every batch the engine must equal the oracle run over its current contents."""
+    rng = np.random.default_rng(99)
+    d = 48
+    engine = E.VectorEngine()
+    truth = {}
+    for i in range(1500):
+        v = rng.standard_normal(d).astype(F)
+        engine.store_embedding(f"k{i}", v)
+        truth[f"k{i}"] = v
+    nxt = 1500
+    for batch in range(12):
+        for _ in range(120):
+            op = rng.integers(0, 4)
+            if op == 0 or not truth:
+                v = rng.standard_normal(d).astype(F)
+                engine.store_embedding(f"k{nxt}", v)
+                truth[f"k{nxt}"] = v
+                nxt += 1
+            elif op == 1:
+                key = list(truth)[rng.integers(0, len(truth))]
+                v = rng.standard_normal(d).astype(F)
+                engine.store_embedding(key, v)
+                truth[key] = v
+            elif op == 2:
+                key = list(truth)[rng.integers(0, len(truth))]
+                engine.delete_embedding(key)
+                del truth[key]
+            else:  # overwrite with another dimension: leaves this dimension's mirror
+                key = list(truth)[rng.integers(0, len(truth))]
+                engine.store_embedding(key, rng.standard_normal(d + 8).astype(F))
+                del truth[key]
+        keys = sorted(truth)                      # oracle over the current d-dimensional contents
+        A = np.stack([truth[k] for k in keys])
+        q = rng.standard_normal(d).astype(F)
+        for metric in E.DistanceMetric:
+            res = engine.search_similar_with_metric(q, 25, metric)
+            s = oc.scores_all(A, q, int(metric))
+            got = {r.key: np.float32(r.score) for r in res}
+            assert len(res) == 25 and set(got) <= set(keys)
+            exp_scores = np.sort(s)[::-1][:25]
+            assert np.array_equal(np.array([r.score for r in res], F), exp_scores)
+            for r in res:                          # each returned score is that key's exact score
+                assert np.float32(r.score) == s[keys.index(r.key)]
+    assert engine.mirror_builds() <= 4            # churn is absorbed by patching, not by rebuilding every time
+    # mass delete: more than a quarter dead -> one rebuild, still exact
+    for key in list(truth)[: len(truth) // 2]:
+        engine.delete_embedding(key)
+        del truth[key]
+    keys = sorted(truth)
+    A = np.stack([truth[k] for k in keys])
+    q = rng.standard_normal(d).astype(F)
+    res = engine.search_similar(q, 10)
+    assert np.array_equal(np.array([r.score for r in res], F), np.sort(oc.scores_all(A, q, 0))[::-1][:10])
 
 
 # ---- collections (lib.rs:7723-7960) ---------------------------------------------------------------------
