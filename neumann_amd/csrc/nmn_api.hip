@@ -55,6 +55,9 @@ struct Workspace {
     uint32_t* scores = nullptr;
     uint32_t* tmax = nullptr;
     uint32_t* wmax = nullptr;
+    uint32_t* tsample = nullptr;   // [nq][n_sample_cap] tile maxima of the sampling pass (batched sweep)
+    uint32_t* skip_key = nullptr;  // [nq] score-write threshold of the batched sweep
+    uint64_t n_sample_cap = 0;
     uint64_t tmax_stride = 0;
     float* qpad = nullptr;
     QInfo* qinfo = nullptr;
@@ -83,6 +86,9 @@ struct nmn_index {
     int device = 0;
     uint32_t cand_cap = kDefaultCandCap;
     float* corpus = nullptr;
+    float* split = nullptr;      // split-bf16 mirror for the batched (MFMA) sweep; allocated on first use
+    uint64_t split_rows = 0;     // rows [0, split_rows) of `split` are current
+    bool split_failed = false;   // allocation failed once: stay on the VALU sweeps
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;
     hipStream_t host_stream = nullptr;
@@ -93,7 +99,7 @@ struct nmn_index {
 
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
                     w->h_counts2};
     for (void* p : ptrs)
@@ -116,6 +122,8 @@ static hipError_t grow(T** p, size_t* cap, size_t need) {
     if (e == hipSuccess) *cap = need;
     return e;
 }
+
+constexpr uint32_t kSampleStep = 32;  // sampling pass of the batched sweep: every 32nd tile (3 % of the corpus)
 
 // queries per pipeline pass: bound the score matrix to ~4 GiB
 static uint32_t pass_queries(const nmn_index* idx, uint32_t nq) {
@@ -163,6 +171,9 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     w->tmax_stride = ((uint64_t)w->n_tiles_cap + 3) & ~3ull;  // rows of tmax stay 16-B aligned (uint4 sweeps)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tmax), std::max<size_t>(nq * w->tmax_stride, 4) * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->wmax), nq * kMaxScanWaves * 4));
+    w->n_sample_cap = (w->n_tiles_cap + kSampleStep - 1) / kSampleStep + 4;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tsample), nq * w->n_sample_cap * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->skip_key), nq * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qpad), nq * w->ld * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo), nq * sizeof(QInfo)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
@@ -272,6 +283,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     for (auto& kv : idx->ws) ws_free(kv.second);
     idx->ws.clear();
     if (idx->corpus) (void)hipFree(idx->corpus);
+    if (idx->split) (void)hipFree(idx->split);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
     if (idx->host_stream) (void)hipStreamDestroy(idx->host_stream);
@@ -319,6 +331,7 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
     idx->rows = std::max(idx->rows, row0 + n);
+    idx->split_rows = std::min(idx->split_rows, row0);  // the mirror is re-derived from row0 on, lazily
     return NMN_OK;
 }
 
@@ -354,13 +367,36 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
         // >= 5 queries in a pass: one corpus sweep per 64 queries on the matrix cores, else 4 per sweep on VALU
-        const bool use_mfma = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
-                              getenv("NMN_NO_MFMA") == nullptr;
+        bool use_mfma = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
+                        !idx->split_failed && getenv("NMN_NO_MFMA") == nullptr;
+        if (use_mfma) {
+            // bring the split-bf16 mirror up to date (allocation + conversion of new rows happen once)
+            if (!idx->split) {
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->split), (size_t)idx->cap_pad * idx->ld * sizeof(float));
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    idx->split = nullptr;
+                    idx->split_failed = true;  // not enough HBM for the mirror: VALU sweeps (4 queries each) instead
+                    use_mfma = false;
+                } else {
+                    idx->split_rows = 0;
+                    HIP_TRY(hipMemsetAsync(idx->split, 0, (size_t)idx->cap_pad * idx->ld * sizeof(float), stream));
+                }
+            }
+            if (use_mfma && idx->split_rows < n_rows) {
+                HIP_TRY(launch_split_rows(idx->corpus, idx->split, idx->ld, idx->split_rows, n_rows - idx->split_rows, stream));
+                // rare (first batched search, or rows uploaded since): wait here so that searches enqueued on
+                // OTHER streams afterwards may rely on the mirror without cross-stream events
+                HIP_TRY(hipStreamSynchronize(stream));
+                idx->split_rows = n_rows;
+            }
+        }
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : 0, stream));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
+            sp.corpus_split = idx->split;
             sp.norms = idx->norms;
             sp.qpad = w->qpad;
             sp.qinfo = w->qinfo;
@@ -371,7 +407,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.tmax_stride = w->tmax_stride;
             sp.wmax_stride = kMaxScanWaves;
             sp.n_rows = n_rows;
-            sp.score_stride = w->score_stride;
+            sp.nql = nqc;
             sp.ld = idx->ld;
             sp.n_tiles = n_tiles;
             sp.nq = nqc;
@@ -384,7 +420,25 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + wave_target - 1) / wave_target);
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + 255) / 256);  // per workgroup, 1 per CU
             sp.metric = (int)metric;
+            sp.tile_step = 1;
+            sp.skip_key = nullptr;
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));
+            // Batched sweep on a large shard: a sampling pass over every 32nd tile (tile maxima only) bounds
+            // the k-th best score of each query from below, so the main sweep writes scores only for the few
+            // tiles that can still hold a candidate.
+            const uint32_t n_sample = (n_tiles + kSampleStep - 1) / kSampleStep;
+            const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && getenv("NMN_NO_SAMPLE") == nullptr;
+            if (sample) {
+                ScanParams ss = sp;
+                ss.tile_step = kSampleStep;
+                ss.n_tiles = n_sample;
+                ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
+                ss.tmax = w->tsample;
+                ss.tmax_stride = w->n_sample_cap;
+                HIP_TRY(launch_scan_mfma(ss, stream));
+                HIP_TRY(launch_sample_bound(w->tsample, w->n_sample_cap, n_sample, w->qinfo, nqc, k, w->skip_key, stream));
+                sp.skip_key = w->skip_key;
+            }
             HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : launch_scan(sp, stream));
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
 
@@ -400,11 +454,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.qstate = w->qstate;
             sel.cand_rows = w->cand_rows;
             sel.n_rows = n_rows;
-            sel.score_stride = w->score_stride;
+            sel.nql = nqc;
             sel.n_tiles = n_tiles;
             sel.nq = nqc;
             sel.k = k;
             sel.cand_cap = w->cand_cap;
+            sel.skip_key = sp.skip_key;
             HIP_TRY(launch_select(sel, stream));
 
             RescoreParams rp{};
@@ -418,7 +473,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             rp.mask = mask_dev;       // fallback duty of the same launch
             rp.scores = w->scores;
             rp.n_rows = n_rows;
-            rp.score_stride = w->score_stride;
+            rp.nql = nqc;
             rp.ld = idx->ld;
             rp.dim = idx->dim;
             rp.nq = nqc;
@@ -431,7 +486,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.cand_scores = w->cand_scores;
         fp.qstate = w->qstate;
         fp.scores = w->scores;
-        fp.score_stride = w->score_stride;
+        fp.nql = nqc;
         fp.n_rows = n_rows;
         fp.row_base = idx->row_base;
         fp.nq = nqc;
@@ -614,7 +669,7 @@ extern "C" nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, 
     ex.mask = mask_dev;
     ex.scores = w->scores;
     ex.n_rows = idx->rows;
-    ex.score_stride = w->score_stride;
+    ex.nql = 1;
     ex.ld = idx->ld;
     ex.dim = idx->dim;
     ex.nq = 1;
@@ -716,6 +771,7 @@ extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, ui
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, s));
     HIP_TRY(hipStreamSynchronize(s));
     idx->rows = std::max(idx->rows, row0 + n);
+    idx->split_rows = std::min(idx->split_rows, row0);
     return NMN_OK;
 }
 
@@ -728,6 +784,7 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
     HIP_TRY(hipMemcpyAsync(idx->corpus + row * (uint64_t)idx->ld, vec_host, (size_t)idx->dim * 4,
                            hipMemcpyHostToDevice, s));
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
+    if (idx->split && row < idx->split_rows) HIP_TRY(launch_split_rows(idx->corpus, idx->split, idx->ld, row, 1, s));
     HIP_TRY(hipStreamSynchronize(s));
     return NMN_OK;
 }

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
                 const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
                 bits = f2u(exact_score(qv, p.corpus + row * (uint64_t)p.ld, p.dim, qmag, vmag, p.metric, l));
             }
-            if (l == 0 && row < n_pad) p.scores[(uint64_t)q * p.score_stride + row] = bits;
+            if (l == 0 && row < n_pad) p.scores[score_at(row, q, p.nql)] = bits;
         }
         return;
     }
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) exact_scan_kernel(ExactScanParams p) {
             const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
             bits = f2u(exact_score(qv, p.corpus + row * (uint64_t)p.ld, p.dim, qmag, vmag, p.metric, l));
         }
-        if (l == 0 && row < n_pad) p.scores[(uint64_t)q * p.score_stride + row] = bits;
+        if (l == 0 && row < n_pad) p.scores[score_at(row, q, p.nql)] = bits;
     }
 }
 

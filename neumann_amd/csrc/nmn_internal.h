@@ -65,20 +65,32 @@ __host__ __device__ inline uint32_t bits_to_key(uint32_t score_bits) {  // score
 }
 constexpr uint32_t kKeyNegInf = 0x007FFFFFu;  // score_to_key(-inf)
 
+// ---- layout of the approximate-score matrix -------------------------------------------------
+// scores[tile][query-in-pass][64 rows]: tile-major, so a batched sweep writes ONE contiguous block per
+// tile (64 queries x 256 B = 16 KiB) instead of 64 scattered 256-B pieces (that cost 1.5 ms of a 6.3 ms
+// nq=64 sweep); with one query per pass it degenerates to plain row order.
+__host__ __device__ inline uint64_t score_at(uint64_t row, uint32_t q, uint32_t nql) {
+    return ((row >> 6) * nql + q) * 64ull + (row & 63ull);
+}
+
 // ---- kernel launchers (each defined in the .hip file named above) ---------------------------
 struct ScanParams {
     const float* corpus;     // [rows][ld]
+    const float* corpus_split;  // split-bf16 mirror of corpus (MFMA sweep only), same shape and stride
     const float* norms;      // [rows]
     const float* qpad;       // [nq][ld] zero padded
     const QInfo* qinfo;      // [nq]
     const uint64_t* mask;    // nullable, ceil(rows/64) words
-    uint32_t* scores;        // [nq][score_stride] f32 bits (sentinel for non-participating rows)
+    uint32_t* scores;        // score_at(row, q, nql): f32 bits (sentinel for non-participating rows)
     uint32_t* tmax;          // [nq][tmax_stride] tile maximum key (0 = empty tile)
     uint32_t* wmax;          // [nq][wmax_stride] maximum key over the tiles of each scan wave
     uint64_t tmax_stride;
     uint64_t wmax_stride;
     uint64_t n_rows;
-    uint64_t score_stride;
+    uint32_t nql;            // queries interleaved per tile in `scores` (= queries of this pass)
+    // MFMA sweep only: sampling and score-write suppression (nmn_scan_mfma.hip)
+    uint32_t tile_step;      // 1: every tile; S: sample pass over tiles 0,S,2S,.. (tile maxima only -> tmax[q][i])
+    const uint32_t* skip_key;  // nullable [nq]: scores of a tile are written only if its maximum key >= skip_key[q]
     uint32_t ld;             // floats per row, multiple of 4
     uint32_t n_tiles;
     uint32_t nq;
@@ -89,9 +101,11 @@ hipError_t launch_scan(const ScanParams& p, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
+// (re)build rows [row0,row0+n) of the split-bf16 mirror from the f32 corpus
+hipError_t launch_split_rows(const float* corpus, float* split, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s);
 
 struct SelectParams {
-    const uint32_t* scores;  // [nq][score_stride]
+    const uint32_t* scores;  // score_at(row, q, nql)
     const uint32_t* tmax;    // [nq][tmax_stride]
     const uint32_t* wmax;    // [nq][wmax_stride]
     uint64_t tmax_stride;
@@ -102,20 +116,24 @@ struct SelectParams {
     QState* qstate;
     uint32_t* cand_rows;     // [nq][cand_cap]
     uint64_t n_rows;
-    uint64_t score_stride;
+    uint32_t nql;
     uint32_t n_tiles;
     uint32_t nq;
     uint32_t k;
     uint32_t cand_cap;
+    const uint32_t* skip_key;  // nullable [nq]: scores of tiles whose maximum is below it were never written
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
+// per query: skip_key[q] = margin_key(k-th largest of the sampled tile maxima) (kKeyNaN if fewer than k are valid)
+hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uint32_t n_sample, const QInfo* qinfo,
+                               uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s);
 
 struct FinalParams {
     const uint32_t* cand_rows;   // [nq][cand_cap]
     const float* cand_scores;    // [nq][cand_cap] exact
     QState* qstate;
-    const uint32_t* scores;      // [nq][score_stride]: EXACT scores of every row for overflowed queries
-    uint64_t score_stride;
+    const uint32_t* scores;      // score_at(row, q, nql): EXACT scores of every row for overflowed queries
+    uint32_t nql;
     uint64_t n_rows;
     uint64_t row_base;
     uint32_t nq, k, cand_cap;
@@ -147,7 +165,8 @@ struct RescoreParams {
     // exact-fallback duty (queries with qstate.overflow): exact score of EVERY row -> scores
     const uint64_t* mask;
     uint32_t* scores;
-    uint64_t n_rows, score_stride;
+    uint64_t n_rows;
+    uint32_t nql;
     uint32_t ld, dim, nq, cand_cap;
     int metric;
 };
@@ -164,7 +183,8 @@ struct ExactScanParams {
     const QState* qstate;    // nullable; when set only queries with overflow==1 are processed
     const uint64_t* mask;
     uint32_t* scores;
-    uint64_t n_rows, score_stride;
+    uint64_t n_rows;
+    uint32_t nql;
     uint32_t ld, dim, nq;
     int metric;
 };

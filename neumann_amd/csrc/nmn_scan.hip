@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
                 sc = mydot[q];
             }
             const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
-            p.scores[(uint64_t)(q0 + q) * p.score_stride + myrow] = valid ? f2u(sc) : kScoreSentinelBits;
+            p.scores[score_at(myrow, q0 + q, p.nql)] = valid ? f2u(sc) : kScoreSentinelBits;
             const uint32_t m = wave_max_u32(key);
             if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tile] = m;
             wmax[q] = max(wmax[q], m);

@@ -3,10 +3,17 @@
 // With nq queries the scan is a [rows x dim] x [dim x nq] product.  At nq = 64 the f32 VALU / f32-MFMA
 // rate (157 TFLOP/s) would bound it at 6.25 ms per 10M x 768 sweep, above the 3.84 ms HBM floor
 // (SURVEY.md §7 hard part b), so the APPROXIMATE pass runs on bf16 MFMA with every f32 operand split
-// in registers into hi + lo bf16 (x = hi + lo + O(2^-16 x)) and three products hi*hi + hi*lo + lo*hi:
-// relative error <= 2^-15 * sum|q_i v_i| — the same class as f32 summation error; it only widens the
-// candidate margin (qprep adds 2^-14), the exact rescore (nmn_exact.hip) restores bit parity.  HBM bytes
-// are unchanged: the corpus is still read once, as f32.
+// into hi + lo bf16 (x = hi + lo + O(2^-16 x)) and three products hi*hi + hi*lo + lo*hi: relative error
+// <= 2^-15 * sum|q_i v_i| — the same class as f32 summation error; it only widens the candidate margin
+// (qprep adds 2^-14), the exact rescore (nmn_exact.hip) restores bit parity.
+//
+// The corpus side of the split is NOT done in the sweep: the shard keeps a split-bf16 MIRROR of the
+// corpus in HBM (split_rows_kernel below; built lazily on the first batched search, 288 GB per GPU
+// makes the second copy affordable) with the SAME 4 bytes per element and the same row stride: each
+// 32-float k-step of a row (128 B) becomes [32 bf16 hi | 32 bf16 lo].  A sweep therefore moves exactly
+// the algorithmic rows*dim*4 bytes, and its inner loop is ds_read_b128 -> MFMA with no conversion VALU
+// (converting in-register made the sweep VALU/issue-bound at 12 VALU per MFMA: 6.3 ms instead of the
+// ~4.6 ms the HBM stream allows).  The f32 corpus stays the source of truth for the exact kernels.
 //
 // Structure (one workgroup = 4 waves = 64 queries x 64-row tiles, persistent over a tile range):
 //   * queries are STATIONARY in registers: wave w owns queries 16w..16w+15 as MFMA B-fragments
@@ -109,7 +116,8 @@ template <int KC, int METRIC, bool MASKED, int AUX>
 __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | exchange | norms
     float* xch = lds + kRing * (kStageBytes / 4);                // [4 src waves][64 lanes][4 rb] f4, reused per round
-    float* nrm = xch + 4 * 64 * 16;                              // [2 tiles][64] row magnitudes
+    float* nrm = xch + 4 * 64 * 16;                              // [kRing tiles][64] row magnitudes (with one-stage
+                                                                 // tiles, dim 128, kRing tiles are in flight at once)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
@@ -125,11 +133,11 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
-            const uint32_t k0 = (uint32_t)kc * kStageK + wave * 32u;
+            const uint32_t k0 = (uint32_t)kc * kStageK + wave * 32u + g * 8u;  // lane group g: k0..k0+7
             f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                a = *reinterpret_cast<const f4*>(qv + k0 + g * 4u);
-                b = *reinterpret_cast<const f4*>(qv + k0 + 16u + g * 4u);
+                a = *reinterpret_cast<const f4*>(qv + k0);
+                b = *reinterpret_cast<const f4*>(qv + k0 + 4u);
             }
             split8(a, b, bhi[kc][qg], blo[kc][qg]);
         }
@@ -137,7 +145,10 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t qn = q0 + wave * 16u + n;  // the query this lane FINISHES (C column of group `wave`)
     const bool q_ok = qn < p.nq;
     const float qmag = q_ok ? p.qinfo[qn].qmag : 0.f;
+    const uint32_t skip = (q_ok && p.skip_key) ? p.skip_key[qn] : kKeyNaN;  // kKeyNaN: write every tile
 
+    const uint32_t tstep = p.tile_step;                  // 1, or S on the sampling pass (tile index i -> tile i*S)
+    const bool sampling = tstep > 1;
     const uint32_t t0 = blockIdx.x * p.tiles_per_wave;  // tiles per WORKGROUP on this path
     if (t0 >= p.n_tiles) return;
     const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         loff[pp] = (r * ld + (((lane & 31u) ^ (r & 15u)) * 4u)) * 4u;
     }
     auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const float* {
-        return p.corpus + (uint64_t)tile_ * kTileRows * ld + kc_ * kStageK;
+        return p.corpus_split + (uint64_t)tile_ * tstep * kTileRows * ld + kc_ * kStageK;
     };
 
     // prologue: stages 0..kRing-2 in flight (stage s lives in ring slot s % kRing)
@@ -158,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     for (uint32_t s0 = 0; s0 < kRing - 1; s0++) {
         if (s0 < n_stage) {
             if (METRIC == NMN_METRIC_COSINE && wave == 0 && s0 % KC == 0)
-                norms_dma(p.norms, t0 + s0 / KC, nrm + ((s0 / KC) & 1u) * 64u, lane);
+                norms_dma(p.norms, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kRing) * 64u, lane);
             stage_dma<AUX>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         }
     }
@@ -190,50 +201,23 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 if (ns < n_stage) {
                     const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
                     if (METRIC == NMN_METRIC_COSINE && wave == 0 && nkc == 0)
-                        norms_dma(p.norms, nt, nrm + ((nt - t0) & 1u) * 64u, lane);
+                        norms_dma(p.norms, (uint64_t)nt * tstep, nrm + ((nt - t0) % kRing) * 64u, lane);
                     stage_dma<AUX>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
                 }
             }
-            // software pipeline over the 4 row blocks: the LDS reads + hi/lo split of block rb+1 are
-            // issued between the 12 MFMAs of block rb (one wave per SIMD: nothing else hides them)
-            s8 ahi, alo;
-            {
-                const f4 xa = *reinterpret_cast<const f4*>(buf + off0);
-                const f4 xb = *reinterpret_cast<const f4*>(buf + off1);
-                split8(xa, xb, ahi, alo);
-            }
+            if (p.metric & 0x100) continue;  // tuning probe (NMN_MFMA_DEBUG=1): stream only, no LDS reads / MFMAs
+            // A fragments straight from the split-bf16 stage: chunk g of this wave's k-step holds 8 hi
+            // values, chunk 4+g the matching 8 lo values (both one ds_read_b128)
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
-                f4 xa = {0.f, 0.f, 0.f, 0.f}, xb = {0.f, 0.f, 0.f, 0.f};
-                if (rb < 3) {
-                    xa = *reinterpret_cast<const f4*>(buf + (rb + 1) * 16 * kStageK + off0);
-                    xb = *reinterpret_cast<const f4*>(buf + (rb + 1) * 16 * kStageK + off1);
-                }
+                const s8 ahi = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kStageK + off0));
+                const s8 alo = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kStageK + off1));
 #pragma unroll
-                for (int qg = 0; qg < 2; qg++) {
+                for (int qg = 0; qg < 4; qg++) {
                     acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
                     acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[kc][qg], acc[rb][qg], 0, 0, 0);
                     acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
                 }
-                s8 nhi = ahi, nlo = alo;
-                if (rb < 3) split8(xa, xb, nhi, nlo);
-#pragma unroll
-                for (int qg = 2; qg < 4; qg++) {
-                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
-                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[kc][qg], acc[rb][qg], 0, 0, 0);
-                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
-                }
-                if (rb < 3) {
-                    // 12 MFMAs with the 2 LDS reads up front and ~24 VALU of the next split spread between them
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
-#pragma unroll
-                    for (int i = 0; i < 12; i++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
-                    }
-                }
-                ahi = nhi;
-                alo = nlo;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -287,37 +271,46 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #undef NMN_XCH_PUT
         {
             // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
-            const uint64_t r0 = (uint64_t)tile * kTileRows;
+            const uint64_t rtile = (uint64_t)tile * tstep;  // real tile index (sampling pass: every tstep-th)
+            const uint64_t r0 = rtile * kTileRows;
             uint64_t mword = ~0ull;
-            if constexpr (MASKED) mword = p.mask[tile];
+            if constexpr (MASKED) mword = p.mask[rtile];
             const uint64_t left = p.n_rows - r0;
             if (left < 64) mword &= (1ull << left) - 1ull;
             uint32_t tkey = kKeyMasked;
+            u4 bits[4];
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
                 const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
                 f4 vn = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (METRIC == NMN_METRIC_COSINE)
-                    vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) & 1u) * 64u + rr);
-                u4 bits;
+                    vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + rr);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
                     float sc = fin[rb][e];
                     if constexpr (METRIC == NMN_METRIC_COSINE)
                         sc = (vn[e] == 0.f || qmag == 0.f) ? 0.f : sc / (qmag * vn[e]);
-                    bits[e] = valid ? f2u(sc) : kScoreSentinelBits;
+                    bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
                     if (valid) tkey = max(tkey, score_to_key(sc));
                 }
-                if (q_ok) *reinterpret_cast<u4*>(p.scores + (uint64_t)qn * p.score_stride + r0 + rr) = bits;
             }
             // tile maximum of query n: combine the four lane groups
             tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 16));
             tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 32));
             if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + tile] = tkey;
             wmax = max(wmax, tkey);
+            // Scores are only worth their HBM write when the tile can still hold a candidate: with a
+            // per-query bound from the sampling pass ~2 % of the tiles qualify (64 queries x 10M rows would
+            // otherwise write 2.56 GB per sweep, measured at +1.45 ms on a 5.3 ms sweep).
+            if (q_ok && !sampling && !(p.metric & 0x200) && tkey != kKeyMasked && tkey >= skip) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+                    *reinterpret_cast<u4*>(p.scores + score_at(r0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = bits[rb];
+            }
         }
     }
+    if (sampling) return;  // the sampling pass leaves only tmax
     if (q_ok && g == 0) p.wmax[(size_t)qn * p.wmax_stride + blockIdx.x] = wmax;
 }
 
@@ -325,7 +318,7 @@ template <int KC, int METRIC, bool MASKED, int AUX>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid(blocks, (p.nq + kMfmaQ - 1) / kMfmaQ);
-    const size_t lds = kRing * kStageBytes + 4 * 64 * 16 * 4 + 2 * 64 * 4;
+    const size_t lds = kRing * kStageBytes + 4 * 64 * 16 * 4 + kRing * 64 * 4;
     auto kern = scan_mfma_kernel<KC, METRIC, MASKED, AUX>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -355,6 +348,35 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
     }
 }
 
+// ---- the split-bf16 mirror ----------------------------------------------------------------------
+// One thread per 8 consecutive floats: thread t of a k-step (t = 0..3) turns floats 8t..8t+7 into 16 B of
+// hi (written to chunk t of the 128-B k-step) and 16 B of lo (chunk 4+t).
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ corpus, float* __restrict__ split,
+                                                         uint32_t ld, uint64_t row0, uint64_t n) {
+    const uint32_t per_row = ld >> 3;  // 8-float groups per row (ld % 32 == 0 on this path)
+    const uint64_t total = n * per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = row0 + i / per_row;
+        const uint32_t grp = (uint32_t)(i % per_row);
+        const uint32_t ks = grp >> 2, t = grp & 3u;
+        const float* src = corpus + r * ld + ks * 32u + t * 8u;
+        const f4 a = *reinterpret_cast<const f4*>(src);
+        const f4 b = *reinterpret_cast<const f4*>(src + 4);
+        s8 hi, lo;
+        split8(a, b, hi, lo);
+        float* dst = split + r * ld + ks * 32u;
+        *reinterpret_cast<u4*>(dst + t * 4u) = __builtin_bit_cast(u4, hi);
+        *reinterpret_cast<u4*>(dst + 16u + t * 4u) = __builtin_bit_cast(u4, lo);
+    }
+}
+
+hipError_t launch_split_rows(const float* corpus, float* split, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(split_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, split, ld, row0, n);
+    return hipGetLastError();
+}
+
 // Can the MFMA sweep serve this shape?  (cosine / dot, row length a multiple of 128 floats up to 768
 // so that the 16 stationary queries of a wave fit its VGPRs.)
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
@@ -363,9 +385,13 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
 }
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
-hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
-    return p.metric == NMN_METRIC_COSINE ? launch_metric<NMN_METRIC_COSINE>(p, s)
-                                         : launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+hipError_t launch_scan_mfma(const ScanParams& p0, hipStream_t s) {
+    ScanParams p = p0;
+    static const int dbg = getenv("NMN_MFMA_DEBUG") ? atoi(getenv("NMN_MFMA_DEBUG")) : 0;  // tuning probes
+    const bool cosine = p.metric == NMN_METRIC_COSINE;
+    if (dbg & 1) p.metric |= 0x100;  // stream only
+    if (dbg & 2) p.metric |= 0x200;  // no score stores
+    return cosine ? launch_metric<NMN_METRIC_COSINE>(p, s) : launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
 }
 
 }  // namespace nmn

@@ -156,6 +156,33 @@ __device__ uint32_t count_valid(KeyAt key_at, uint32_t n, uint32_t* s_word) {
 // k = 100: 16 KB wmax + ~100 x 39 tile maxima + ~105 x 256 B of scores.  If a compact list overflows
 // (more than 8192 groups within the margin: heavy ties, or fewer valid waves than k with many valid
 // tiles) the generic three-level code below takes over.
+// ---- sampling bound of the batched sweep -------------------------------------------------------
+// tmax_sample[q][i] = maximum key of sampled tile i (every S-th tile).  If k sampled tiles reach T, k rows
+// of the corpus reach T, so no row scoring below T - margin can be in the top-k: the main sweep only
+// writes the scores of tiles whose maximum reaches skip_key[q] = key(score(T) - margin).
+__global__ void __launch_bounds__(kSelThreads) sample_bound_kernel(const uint32_t* __restrict__ tmax_sample,
+                                                                   uint64_t stride, uint32_t n_sample,
+                                                                   const QInfo* __restrict__ qinfo, uint32_t k,
+                                                                   uint32_t* __restrict__ skip_key) {
+    __shared__ uint32_t hist[kBins];
+    __shared__ PickResult pick;
+    __shared__ uint32_t s_cnt;
+    const uint32_t q = blockIdx.x;
+    const uint32_t* keys = tmax_sample + (uint64_t)q * stride;
+    auto key_at = [&](uint32_t e) { return keys[e]; };
+    const uint32_t valid = count_valid(key_at, n_sample, &s_cnt);
+    uint32_t skip = kKeyNaN;
+    if (valid >= k) skip = margin_key(radix2(key_at, n_sample, k, hist, &pick), qinfo[q]);
+    if (threadIdx.x == 0) skip_key[q] = skip;
+}
+
+hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uint32_t n_sample, const QInfo* qinfo,
+                               uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s) {
+    hipLaunchKernelGGL(sample_bound_kernel, dim3(nq), dim3(kSelThreads), 0, s, tmax_sample, stride, n_sample, qinfo, k,
+                       skip_key);
+    return hipGetLastError();
+}
+
 constexpr uint32_t kCompCap = 8192;
 constexpr size_t kSelectLds = 2 * kCompCap * 8 + kMaxScanWaves * 4 + kBins * 4;  // 152 KiB
 
@@ -171,7 +198,8 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     __shared__ uint32_t s_w[4];
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    const uint32_t* scores = p.scores + (uint64_t)q * p.score_stride;
+    const uint32_t nql = p.nql;
+    auto score_bits = [&](uint64_t row) -> uint32_t { return p.scores[score_at(row, q, nql)]; };
     const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
     const uint32_t* wmax = p.wmax + (uint64_t)q * p.wmax_stride;
     const uint32_t W = p.n_waves, tpw = p.tiles_per_wave, n_tiles = p.n_tiles;
@@ -190,7 +218,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     // ---- level W ---------------------------------------------------------------------------
     uint32_t Tw = kKeyNaN;
     if (vw >= k) Tw = radix2([&](uint32_t e) { return wk[e]; }, W, k, hist, &pick);
-    const uint32_t Twm = margin_key(Tw, qi);
+    // scores of tiles whose maximum is below `skip` were never written by the batched sweep: no threshold that
+    // gates a read of scores[] may fall below it (rows below it cannot be in the top-k anyway)
+    const uint32_t skip = p.skip_key ? p.skip_key[q] : kKeyNaN;
+    const uint32_t Twm = max(margin_key(Tw, qi), skip);
     if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
     __syncthreads();
     for (uint32_t i = tid; i < W; i += kSelThreads)
@@ -224,7 +255,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     if (ct <= kCompCap) {
         uint32_t T2 = Tw;
         if (ct > k) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);
-        const uint32_t T2m = margin_key(T2, qi);
+        const uint32_t T2m = max(margin_key(T2, qi), skip);
         Tc = T2m;
         // ---- level R: compact (key,row) of rows >= T2m in tiles >= T2m (la is dead: LR may be written)
         __syncthreads();
@@ -240,7 +271,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                     const unsigned long long ent = LT[e >> 6];
                     if ((uint32_t)(ent >> 32) >= T2m) {
                         rr[u] = (uint32_t)(ent & 0xFFFFFFFFull) * kTileRows + (e & 63u);
-                        kb[u] = scores[rr[u]];
+                        kb[u] = score_bits(rr[u]);
                     }
                 }
             }
@@ -258,7 +289,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         if (cr <= kCompCap) {
             uint32_t T3 = T2;
             if (cr > k) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
-            Tc = margin_key(T3, qi);  // >= T2m: every row that can matter is in LR
+            Tc = max(margin_key(T3, qi), skip);  // >= T2m: every row that can matter is in LR
             for (uint32_t e = tid; e < cr; e += kSelThreads) {
                 const unsigned long long ent = LR[e];
                 if ((uint32_t)(ent >> 32) >= Tc) {
@@ -297,7 +328,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             return key >= Twm ? key : kKeyMasked;
         };
         const uint32_t vt = count_valid(tile_key, slots, &s_w[2]);
-        if (vt > k) Tc = margin_key(radix2(tile_key, slots, k, hist, &pick), qi);
+        if (vt > k) Tc = max(margin_key(radix2(tile_key, slots, k, hist, &pick), qi), skip);
     }
     // collection: waves -> tiles -> rows, all >= Tc
     if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; }
@@ -334,7 +365,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 #pragma unroll
             for (int u = 0; u < V; u++) {
                 const uint32_t e = e0 + (uint32_t)u * kSelThreads;
-                kb[u] = e < tot ? scores[(uint64_t)lb[e >> 6] * kTileRows + (e & 63u)] : kScoreSentinelBits;
+                kb[u] = e < tot ? score_bits((uint64_t)lb[e >> 6] * kTileRows + (e & 63u)) : kScoreSentinelBits;
             }
 #pragma unroll
             for (int u = 0; u < V; u++) {
@@ -375,13 +406,14 @@ hipError_t launch_select(const SelectParams& p, hipStream_t s) {
 // ties: a 64-bit radix select, 11+11+10 bits of score key, then (only if the ties at the k-th score
 // straddle it) 11+11+10 bits of ~row.  One workgroup walks all rows up to six times: slow by design,
 // this path only runs when more than cand_cap rows sit within the rounding margin of the k-th score.
-__device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint64_t n_rows, uint32_t k,
+__device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint32_t q, uint32_t nql, uint64_t n_rows,
+                                      uint32_t k,
                                       unsigned long long* list, uint32_t* hist, PickResult* pick,
                                       uint32_t* s_misc /* >= 2 words */) {
     const uint32_t tid = threadIdx.x;
     const uint64_t n_pad = (n_rows + 63) & ~63ull;
     auto comp = [&](uint64_t i) -> unsigned long long {
-        const uint32_t key = i < n_pad ? bits_to_key(scores[i]) : kKeyMasked;
+        const uint32_t key = i < n_pad ? bits_to_key(scores[score_at(i, q, nql)]) : kKeyMasked;
         return key == kKeyMasked ? 0ull : (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i));
     };
     // digit layout over the 64-bit composite, most significant first
@@ -438,7 +470,7 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     const uint32_t tid = threadIdx.x;
     uint32_t n;
     if (p.qstate[q].overflow) {
-        n = exact_select_into(p.scores + (uint64_t)q * p.score_stride, p.n_rows, p.k, list, hist, &pick, s_misc);
+        n = exact_select_into(p.scores, q, p.nql, p.n_rows, p.k, list, hist, &pick, s_misc);
         if (tid == 0) p.qstate[q].cand_count = n;
     } else {
         n = min(p.qstate[q].cand_count, min(p.cand_cap, (uint32_t)NMN_MAX_TOP_K));

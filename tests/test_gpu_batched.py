@@ -78,3 +78,27 @@ def test_batch_matches_single_query_calls():
         for qi in range(0, nq, 7):
             r, s, c = idx.search(Q[qi], k, 0)
             assert np.array_equal(br[qi], r[0]) and np.array_equal(bs[qi], s[0]) and bc[qi] == c[0]
+
+
+def test_mfma_sampling_pass_large_shard():
+    """Shards with >= 32768 tiles run the sampling pre-pass and suppress the score writes of hopeless tiles;
+    results must not change (oracle on the full 2.2M x 128 corpus), with and without a mask."""
+    from neumann_amd import GpuFlatIndex
+    n, d, nq, k = 2_200_000, 128, 12, 25
+    A = oc.synth(4242, 0, n, d, nthreads=8)
+    Q = oc.synth(4243, 0, nq, d)
+    Q[3] = A[1_234_567]
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(4242, n)
+        for metric in (0, 2):
+            rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
+            assert st.fallback_queries == 0
+            for qi in range(nq):
+                er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
+                assert counts[qi] == k and np.array_equal(rows[qi], er) and np.all(scores[qi] == es), (metric, qi)
+        keep = np.random.default_rng(1).random(n) < 0.2
+        mask = oc.mask_from_bool(keep)
+        rows, scores, counts = idx.search(Q[:6], k, 0, mask=mask)
+        for qi in range(6):
+            er, es = oc.search(A, Q[qi], k, 0, mask=mask, nthreads=8, partial=True, native=True)
+            assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es)
