@@ -161,6 +161,10 @@ uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f);
 /* Mirror bookkeeping (for the cache-protocol tests, lib.rs:9686-9944): number of GPU mirror builds
  * so far and whether a mirror is currently cached for `coll` (NULL = default collection). */
 uint64_t nmn_engine_mirror_builds(nmn_engine* e);
+/* Pre-filter predicates evaluated by the GPU predicate kernel over the metadata columns, and how many
+ * times a column set was (re)built from the store (instrumentation of SURVEY.md §8f-2). */
+uint64_t nmn_engine_device_filter_evals(nmn_engine* e);
+uint64_t nmn_engine_column_builds(nmn_engine* e);
 int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll);
 
 #ifdef __cplusplus

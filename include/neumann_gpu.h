@@ -186,6 +186,95 @@ nmn_status nmn_merge_topk_device_strided(const uint64_t* rows_dev, const float* 
                                          uint32_t nq, uint32_t k, uint64_t* out_rows_dev, float* out_scores_dev,
                                          uint32_t* out_counts_dev, void* stream);
 
+/* ---- columnar metadata + WHERE-predicate programs ----------------------- */
+
+/* Filtered SIMILAR in the reference evaluates the predicate per key on the host: one `store.get`
+ * (BTreeMap lookup + TensorData clone) and one `evaluate_filter` walk per stored row
+ * (vector_engine/src/lib.rs:3526-3530, 3582-3630).  Here the metadata fields of the mirrored rows
+ * live as typed COLUMNS in HBM, aligned with the rows of an nmn_index, and the predicate is a
+ * postfix program one kernel evaluates for every row, writing the selection bitmap the masked scan
+ * consumes (same layout as relational_engine's bitmaps: bit i of word i/64, LSB first).
+ *
+ * A cell is (kind u8, payload u64).  Strings are dictionary-encoded per column by the caller; every
+ * string predicate reaches the device as a bitset over dictionary ids (NMN_PRED_STRSET), so the
+ * string comparison itself runs once per DISTINCT value on the host, never per row. */
+typedef struct nmn_columns nmn_columns;
+
+#define NMN_CELL_ABSENT 0u /* the row has no such field (TensorData::get -> None)        */
+#define NMN_CELL_NULL 1u   /* ScalarValue::Null                                            */
+#define NMN_CELL_BOOL 2u   /* ScalarValue::Bool,   payload 0/1                             */
+#define NMN_CELL_INT 3u    /* ScalarValue::Int,    payload = the i64's bits                */
+#define NMN_CELL_FLOAT 4u  /* ScalarValue::Float,  payload = the f64's bits                */
+#define NMN_CELL_STRING 5u /* ScalarValue::String, payload = dictionary id in this column  */
+
+/* Program opcodes: postfix over a 64-deep boolean stack; the program must leave exactly one value. */
+#define NMN_PRED_TRUE 0u   /* push true                       (FilterCondition::True)                   */
+#define NMN_PRED_FALSE 1u  /* push false                      (a field no row has)                      */
+#define NMN_PRED_AND 2u    /* pop b, pop a, push a && b       (FilterCondition::And)                    */
+#define NMN_PRED_OR 3u     /* pop b, pop a, push a || b       (FilterCondition::Or)                     */
+#define NMN_PRED_EXISTS 4u /* push kind != ABSENT             (Exists, lib.rs:3602)                     */
+#define NMN_PRED_CMP 5u    /* push cmp(cell, value)           (Eq/Ne/Lt/Le/Gt/Ge, lib.rs:3603-3620; the
+                              typed comparison of compare_tensor_value_to_filter, lib.rs:3648-3670:
+                              Int/Int, Float/Float, Float/Int, Int/Float (int side widened `as f64`),
+                              Bool/Bool, Null/Null; anything else, or a NaN operand, is false) */
+#define NMN_PRED_IN 6u     /* push any_j cell == value_j      (In, lib.rs:3627-3629); values are the
+                              (kind,payload) pairs consts[a .. a+2*b) */
+#define NMN_PRED_STRSET 7u /* push kind == STRING && bit payload of the bitset consts[a ..] (b = number
+                              of ids covered)              (string Eq/Ne/Lt/Le/Gt/Ge, Contains,
+                              StartsWith, string members of In; lib.rs:3621-3626, 3673-3692) */
+
+/* cmp field of NMN_PRED_CMP, FilterCondition order (lib.rs:296-309). */
+#define NMN_CMP_EQ 0u
+#define NMN_CMP_NE 1u
+#define NMN_CMP_LT 2u
+#define NMN_CMP_LE 3u
+#define NMN_CMP_GT 4u
+#define NMN_CMP_GE 5u
+
+typedef struct nmn_pred_op {
+    uint32_t op;     /* NMN_PRED_*                                            */
+    uint32_t cmp;    /* NMN_CMP_* (CMP only)                                  */
+    uint32_t vkind;  /* NMN_CELL_* kind of the filter value (CMP only)        */
+    uint32_t column; /* column id (EXISTS, CMP, IN, STRSET)                   */
+    uint64_t a;      /* CMP: value payload; IN / STRSET: offset into consts   */
+    uint64_t b;      /* IN: number of values; STRSET: number of ids covered   */
+} nmn_pred_op;
+
+/* A column set for `capacity_rows` rows on `device` (-1 = current).  All cells start ABSENT and the
+ * row-validity bitmap starts all-zero. */
+nmn_status nmn_columns_create(int32_t device, uint64_t capacity_rows, nmn_columns** out);
+nmn_status nmn_columns_destroy(nmn_columns* cols);
+/* Add one column (every cell ABSENT); its id is returned in *column_out. */
+nmn_status nmn_columns_add(nmn_columns* cols, uint32_t* column_out);
+uint32_t nmn_columns_count(const nmn_columns* cols);
+/* Write cells [row0, row0+n) of one column from HOST arrays. */
+nmn_status nmn_columns_write(nmn_columns* cols, uint32_t column, uint64_t row0, uint64_t n,
+                             const uint8_t* kinds, const uint64_t* payloads);
+/* Make every column's cell of `row` ABSENT (a key overwritten in place drops its old metadata:
+ * `put` replaces the whole TensorData, tensor_store/src/lib.rs:927-938, vector_engine/src/lib.rs:3291-3307). */
+nmn_status nmn_columns_clear_row(nmn_columns* cols, uint64_t row);
+/* Write words [word0, word0+n) of the row-validity bitmap (rows that exist and are not deleted); every
+ * evaluation is ANDed with it. */
+nmn_status nmn_columns_write_valid(nmn_columns* cols, uint64_t word0, uint64_t n_words, const uint64_t* words);
+/* Evaluate the program over rows [0, n_rows): the resulting bitmap stays in device memory
+ * (nmn_columns_mask_device), *count_out = number of selected rows.  `prog` and `consts` are HOST
+ * arrays.  Synchronous.  Replaces the `list_keys().filter(evaluate_filter_for_key)` stage of
+ * search_with_pre_filter (lib.rs:3526-3530) and of search_filtered_in_collection (lib.rs:1776-1784). */
+nmn_status nmn_columns_eval(nmn_columns* cols, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
+                            uint64_t n_consts, uint64_t n_rows, uint64_t* count_out);
+/* Device bitmap of the last evaluation, ceil(capacity_rows/64) words. */
+const uint64_t* nmn_columns_mask_device(const nmn_columns* cols);
+/* Device row-validity bitmap (a ready-made mask of the live rows). */
+const uint64_t* nmn_columns_valid_device(const nmn_columns* cols);
+/* Copy words of the last evaluation's bitmap to the host (tests). */
+nmn_status nmn_columns_read_mask(nmn_columns* cols, uint64_t* out_words, uint64_t n_words);
+
+/* nmn_index_search with the selection bitmap already in DEVICE memory (e.g. nmn_columns_mask_device);
+ * queries and outputs are HOST buffers as in nmn_index_search.  Synchronous. */
+nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
+                                  float* out_scores, uint32_t* out_counts, nmn_search_stats* stats);
+
 /* ---- synthetic data (bench / tests) ------------------------------------------------------- */
 
 /* value(seed,row,col): a counter-based generator that is bit-identical on host and device

@@ -50,6 +50,16 @@ class SearchStats(C.Structure):
                 ("scan_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+class PredOp(C.Structure):
+    """nmn_pred_op: one step of a WHERE-predicate program (include/neumann_gpu.h, NMN_PRED_*)."""
+    _fields_ = [("op", C.c_uint32), ("cmp", C.c_uint32), ("vkind", C.c_uint32), ("column", C.c_uint32),
+                ("a", C.c_uint64), ("b", C.c_uint64)]
+
+
+CELL_ABSENT, CELL_NULL, CELL_BOOL, CELL_INT, CELL_FLOAT, CELL_STRING = range(6)
+PRED_TRUE, PRED_FALSE, PRED_AND, PRED_OR, PRED_EXISTS, PRED_CMP, PRED_IN, PRED_STRSET = range(8)
+CMP_EQ, CMP_NE, CMP_LT, CMP_LE, CMP_GT, CMP_GE = range(6)
+
 # name -> (restype, argtypes); one entry per declaration in include/neumann_gpu.h
 SIGNATURES = {
     "nmn_device_count": (C.c_int32, [i32p]),
@@ -81,6 +91,19 @@ SIGNATURES = {
     "nmn_synth_fill_host": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "nmn_index_fill_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),
     "nmn_index_set_row": (C.c_int32, [vp, C.c_uint64, vp]),
+    "nmn_columns_create": (C.c_int32, [C.c_int32, C.c_uint64, C.POINTER(vp)]),
+    "nmn_columns_destroy": (C.c_int32, [vp]),
+    "nmn_columns_add": (C.c_int32, [vp, u32p]),
+    "nmn_columns_count": (C.c_uint32, [vp]),
+    "nmn_columns_write": (C.c_int32, [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]),
+    "nmn_columns_clear_row": (C.c_int32, [vp, C.c_uint64]),
+    "nmn_columns_write_valid": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
+    "nmn_columns_eval": (C.c_int32, [vp, C.POINTER(PredOp), C.c_uint32, vp, C.c_uint64, C.c_uint64, u64p]),
+    "nmn_columns_mask_device": (vp, [vp]),
+    "nmn_columns_valid_device": (vp, [vp]),
+    "nmn_columns_read_mask": (C.c_int32, [vp, vp, C.c_uint64]),
+    "nmn_index_search_dmask": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp,
+                                           C.POINTER(SearchStats)]),
 }
 
 _lib = None

@@ -38,6 +38,11 @@ static nmn_status fail_arg(nmn_status code, const char* what) {
     return code;
 }
 
+namespace nmn {
+nmn_status set_error(nmn_status code, const char* what) { return fail_arg(code, what); }
+nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, what); }
+}  // namespace nmn
+
 #define HIP_TRY(expr)                                        \
     do {                                                     \
         hipError_t _e = (expr);                              \
@@ -563,9 +568,9 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
     return stats_collect(idx, it == idx->ws.end() ? nullptr : it->second, stats);
 }
 
-extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
-                                       nmn_metric metric, const uint64_t* mask, uint64_t* out_rows,
-                                       float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
+static nmn_status search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                                const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
+                                uint32_t* out_counts, nmn_search_stats* stats) {
     nmn_status st = check_search_args(idx, queries, nq, k, metric, out_rows, out_scores, out_counts);
     if (st != NMN_OK) return st;
     HIP_TRY(hipSetDevice(idx->device));
@@ -582,7 +587,9 @@ extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uin
     HIP_TRY(grow(&w->h_out_counts, &w->h_cnt_cap, (size_t)nq));
     HIP_TRY(hipMemcpyAsync(w->h_queries, queries, qn * sizeof(float), hipMemcpyHostToDevice, s));
     const uint64_t* mask_dev = nullptr;
-    if (mask && words) {
+    if (mask && words && mask_on_device) {
+        mask_dev = mask;
+    } else if (mask && words) {
         HIP_TRY(grow(&w->h_mask, &w->h_mask_cap, words));
         HIP_TRY(hipMemcpyAsync(w->h_mask, mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         mask_dev = w->h_mask;
@@ -595,6 +602,18 @@ extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uin
     HIP_TRY(hipMemcpyAsync(out_counts, w->h_out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return stats_collect(idx, w, stats);
+}
+
+extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                       nmn_metric metric, const uint64_t* mask, uint64_t* out_rows,
+                                       float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
+    return search_hostio(idx, queries, nq, k, metric, mask, false, out_rows, out_scores, out_counts, stats);
+}
+
+extern "C" nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                             nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
+                                             float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
+    return search_hostio(idx, queries, nq, k, metric, mask_dev, true, out_rows, out_scores, out_counts, stats);
 }
 
 // ---- exact helpers ------------------------------------------------------------------------------

@@ -1,0 +1,383 @@
+// nmn_columns.hip — columnar metadata in HBM and the WHERE-predicate kernel.
+//
+// The reference evaluates a FilterCondition per stored key on the host: `store.get` (BTreeMap
+// lookup + clone of the whole TensorData) then a recursive `evaluate_filter`
+// (vector_engine/src/lib.rs:3582-3630) with the typed comparison of
+// `compare_tensor_value_to_filter` (lib.rs:3648-3670).  Here each metadata field is one column of
+// (kind u8, payload u64) cells aligned with the rows of the mirrored index, the condition is a
+// postfix program, and ONE kernel evaluates it for every row: a wavefront owns 64 consecutive rows,
+// each lane walks the (wave-uniform) program over its row's cells, and `__ballot` turns the 64
+// verdicts into one word of the selection bitmap that the masked scan consumes unchanged.
+//
+// HBM-bound integer/byte work: per leaf the kernel reads 1 B (kind) [+ 8 B payload] per row, fully
+// coalesced (64 B / 512 B per wave per column); the bitmap write is 1 bit per row.
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "nmn_internal.h"
+
+using namespace nmn;
+
+namespace {
+
+struct DevOp {  // one program step as the kernel reads it (column ids already resolved to pointers)
+    uint32_t op, cmp, vkind, pad;
+    const uint8_t* kinds;
+    const uint64_t* payload;
+    uint64_t a, b;
+};
+
+// compare_tensor_value_to_filter (lib.rs:3648-3670) followed by the operator's test of the
+// ordering (lib.rs:3603-3620).  `ordering.is_some_and(cmp)`: an incomparable pair is false for
+// every operator, Ne included.
+__device__ __forceinline__ bool cmp_cell(uint32_t ck, uint64_t cp, uint32_t vk, uint64_t vp, uint32_t cmp) {
+    int ord;
+    if (ck == NMN_CELL_INT && vk == NMN_CELL_INT) {  // a.cmp(b)
+        const long long a = (long long)cp, b = (long long)vp;
+        ord = a < b ? -1 : (a > b ? 1 : 0);
+    } else if ((ck == NMN_CELL_FLOAT || ck == NMN_CELL_INT) && (vk == NMN_CELL_FLOAT || vk == NMN_CELL_INT)) {
+        // Float/Float, Float/Int (`*b as f64`), Int/Float (`*a as f64`): partial_cmp on f64
+        const double a = ck == NMN_CELL_FLOAT ? __longlong_as_double((long long)cp) : (double)(long long)cp;
+        const double b = vk == NMN_CELL_FLOAT ? __longlong_as_double((long long)vp) : (double)(long long)vp;
+        if (a != a || b != b) return false;  // partial_cmp -> None
+        ord = a < b ? -1 : (a > b ? 1 : 0);
+    } else if (ck == NMN_CELL_BOOL && vk == NMN_CELL_BOOL) {
+        const int a = (int)(cp & 1ull), b = (int)(vp & 1ull);
+        ord = a - b;
+    } else if (ck == NMN_CELL_NULL && vk == NMN_CELL_NULL) {
+        ord = 0;
+    } else {
+        return false;  // incompatible types (strings arrive as NMN_PRED_STRSET, never here)
+    }
+    switch (cmp) {
+        case NMN_CMP_EQ: return ord == 0;
+        case NMN_CMP_NE: return ord != 0;
+        case NMN_CMP_LT: return ord < 0;
+        case NMN_CMP_LE: return ord <= 0;
+        case NMN_CMP_GT: return ord > 0;
+        default: return ord >= 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void pred_eval_kernel(const DevOp* __restrict__ ops, uint32_t n_ops,
+                                                        const uint64_t* __restrict__ consts,
+                                                        const uint64_t* __restrict__ valid, uint64_t n_rows,
+                                                        uint64_t* __restrict__ mask,
+                                                        unsigned long long* __restrict__ count) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_words = (n_rows + 63) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long selected = 0;
+    for (uint64_t w = wave; w < n_words; w += n_waves) {
+        const uint64_t row = (w << 6) + lane;
+        const bool in_range = row < n_rows;
+        uint64_t stack = 0;  // bit i = stack slot i; the program is validated on the host (depth <= 64)
+        uint32_t sp = 0;
+        for (uint32_t i = 0; i < n_ops; i++) {
+            const DevOp o = ops[i];  // wave-uniform: scalar loads
+            bool r = false;
+            switch (o.op) {
+                case NMN_PRED_TRUE: r = true; break;
+                case NMN_PRED_FALSE: r = false; break;
+                case NMN_PRED_AND:
+                case NMN_PRED_OR: {
+                    const bool y = (stack >> (sp - 1)) & 1ull, x = (stack >> (sp - 2)) & 1ull;
+                    sp -= 2;
+                    r = o.op == NMN_PRED_AND ? (x && y) : (x || y);
+                    break;
+                }
+                case NMN_PRED_EXISTS: r = in_range && o.kinds[row] != NMN_CELL_ABSENT; break;
+                case NMN_PRED_CMP:
+                    if (in_range) {
+                        const uint32_t ck = o.kinds[row];
+                        if (ck != NMN_CELL_ABSENT) r = cmp_cell(ck, o.payload[row], o.vkind, o.a, o.cmp);
+                    }
+                    break;
+                case NMN_PRED_IN:
+                    if (in_range) {
+                        const uint32_t ck = o.kinds[row];
+                        if (ck != NMN_CELL_ABSENT) {
+                            const uint64_t cp = o.payload[row];
+                            for (uint64_t j = 0; j < o.b; j++)
+                                r = r || cmp_cell(ck, cp, (uint32_t)consts[o.a + 2 * j], consts[o.a + 2 * j + 1], NMN_CMP_EQ);
+                        }
+                    }
+                    break;
+                case NMN_PRED_STRSET:
+                    if (in_range && o.kinds[row] == NMN_CELL_STRING) {
+                        const uint64_t id = o.payload[row];
+                        if (id < o.b) r = (consts[o.a + (id >> 6)] >> (id & 63ull)) & 1ull;
+                    }
+                    break;
+                default: break;
+            }
+            stack = (stack & ~(1ull << sp)) | ((uint64_t)r << sp);
+            sp++;
+        }
+        const bool verdict = in_range && (stack & 1ull);
+        const uint64_t word = __ballot(verdict) & valid[w];
+        if (lane == 0) {
+            mask[w] = word;
+            selected += (unsigned long long)__popcll(word);
+        }
+    }
+    if (lane == 0 && selected) atomicAdd(count, selected);
+}
+
+__global__ void clear_row_kernel(uint8_t* const* kinds, uint32_t n_cols, uint64_t row) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cols) kinds[c][row] = NMN_CELL_ABSENT;
+}
+
+struct Column {
+    uint8_t* kinds = nullptr;
+    uint64_t* payload = nullptr;
+};
+
+}  // namespace
+
+struct nmn_columns {
+    int device = 0;
+    uint64_t cap = 0, words = 0;
+    std::vector<Column> cols;
+    uint64_t* valid = nullptr;
+    uint64_t* mask = nullptr;
+    unsigned long long* count = nullptr;
+    uint8_t* prog = nullptr;  // device staging: [DevOp x n_ops | consts]
+    size_t prog_cap = 0;
+    uint8_t** kinds_tab = nullptr;  // device table of the columns' kind arrays (clear_row)
+    size_t kinds_tab_cap = 0;
+    bool kinds_tab_dirty = true;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+};
+
+#define COL_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return nmn::set_error_hip(_e, #expr); \
+    } while (0)
+
+extern "C" nmn_status nmn_columns_create(int32_t device, uint64_t capacity_rows, nmn_columns** out) {
+    if (!out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    if (capacity_rows == 0) return set_error(NMN_ERR_INVALID_ARGUMENT, "capacity_rows == 0");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        (void)hipGetLastError();
+        return set_error(NMN_ERR_NO_DEVICE, "no HIP device");
+    }
+    int dev = device;
+    if (dev < 0) COL_TRY(hipGetDevice(&dev));
+    if (dev >= n_dev) return set_error(NMN_ERR_NO_DEVICE, "device ordinal out of range");
+    COL_TRY(hipSetDevice(dev));
+    nmn_columns* c = new (std::nothrow) nmn_columns();
+    if (!c) return set_error(NMN_ERR_OUT_OF_MEMORY, "host alloc");
+    c->device = dev;
+    c->cap = capacity_rows;
+    c->words = (capacity_rows + 63) / 64;
+    auto bail = [&](hipError_t e, const char* what) {
+        nmn_status st = set_error_hip(e, what);
+        nmn_columns_destroy(c);
+        return st;
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->valid), c->words * 8)) != hipSuccess) return bail(e, "hipMalloc(valid)");
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->mask), c->words * 8)) != hipSuccess) return bail(e, "hipMalloc(mask)");
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->count), 8)) != hipSuccess) return bail(e, "hipMalloc(count)");
+    if ((e = hipMemsetAsync(c->valid, 0, c->words * 8, c->stream)) != hipSuccess) return bail(e, "hipMemset(valid)");
+    if ((e = hipMemsetAsync(c->mask, 0, c->words * 8, c->stream)) != hipSuccess) return bail(e, "hipMemset(mask)");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    *out = c;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_destroy(nmn_columns* c) {
+    if (!c) return NMN_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& col : c->cols) {
+        if (col.kinds) (void)hipFree(col.kinds);
+        if (col.payload) (void)hipFree(col.payload);
+    }
+    for (void* p : {(void*)c->valid, (void*)c->mask, (void*)c->count, (void*)c->prog, (void*)c->kinds_tab})
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_add(nmn_columns* c, uint32_t* column_out) {
+    if (!c || !column_out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    COL_TRY(hipSetDevice(c->device));
+    Column col;
+    COL_TRY(hipMalloc(reinterpret_cast<void**>(&col.kinds), c->cap));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&col.payload), c->cap * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(col.kinds, 0, c->cap, c->stream);  // all cells ABSENT
+    if (e == hipSuccess) e = hipMemsetAsync(col.payload, 0, c->cap * 8, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(col.kinds);
+        if (col.payload) (void)hipFree(col.payload);
+        return set_error_hip(e, "nmn_columns_add");
+    }
+    *column_out = (uint32_t)c->cols.size();
+    c->cols.push_back(col);
+    c->kinds_tab_dirty = true;
+    return NMN_OK;
+}
+
+extern "C" uint32_t nmn_columns_count(const nmn_columns* c) { return c ? (uint32_t)c->cols.size() : 0; }
+
+extern "C" nmn_status nmn_columns_write(nmn_columns* c, uint32_t column, uint64_t row0, uint64_t n,
+                                        const uint8_t* kinds, const uint64_t* payloads) {
+    if (!c || (n && (!kinds || !payloads))) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (column >= c->cols.size()) return set_error(NMN_ERR_INVALID_ARGUMENT, "no such column");
+    if (row0 > c->cap || n > c->cap - row0) return set_error(NMN_ERR_CAPACITY, "cells beyond capacity_rows");
+    if (n == 0) return NMN_OK;
+    for (uint64_t i = 0; i < n; i++)
+        if (kinds[i] > NMN_CELL_STRING) return set_error(NMN_ERR_INVALID_ARGUMENT, "bad cell kind");
+    COL_TRY(hipSetDevice(c->device));
+    COL_TRY(hipMemcpyAsync(c->cols[column].kinds + row0, kinds, n, hipMemcpyHostToDevice, c->stream));
+    COL_TRY(hipMemcpyAsync(c->cols[column].payload + row0, payloads, n * 8, hipMemcpyHostToDevice, c->stream));
+    COL_TRY(hipStreamSynchronize(c->stream));
+    return NMN_OK;
+}
+
+static nmn_status sync_kinds_tab(nmn_columns* c) {
+    if (!c->kinds_tab_dirty) return NMN_OK;
+    const size_t n = c->cols.size();
+    if (n > c->kinds_tab_cap) {
+        if (c->kinds_tab) COL_TRY(hipFree(c->kinds_tab));
+        c->kinds_tab = nullptr;
+        c->kinds_tab_cap = 0;
+        COL_TRY(hipMalloc(reinterpret_cast<void**>(&c->kinds_tab), (n + 16) * sizeof(uint8_t*)));
+        c->kinds_tab_cap = n + 16;
+    }
+    std::vector<uint8_t*> tab(n);
+    for (size_t i = 0; i < n; i++) tab[i] = c->cols[i].kinds;
+    if (n) COL_TRY(hipMemcpyAsync(c->kinds_tab, tab.data(), n * sizeof(uint8_t*), hipMemcpyHostToDevice, c->stream));
+    COL_TRY(hipStreamSynchronize(c->stream));  // `tab` is a stack temporary
+    c->kinds_tab_dirty = false;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_clear_row(nmn_columns* c, uint64_t row) {
+    if (!c) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (row >= c->cap) return set_error(NMN_ERR_CAPACITY, "row beyond capacity_rows");
+    if (c->cols.empty()) return NMN_OK;
+    COL_TRY(hipSetDevice(c->device));
+    nmn_status st = sync_kinds_tab(c);
+    if (st != NMN_OK) return st;
+    const uint32_t n = (uint32_t)c->cols.size();
+    hipLaunchKernelGGL(clear_row_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->kinds_tab, n, row);
+    COL_TRY(hipGetLastError());
+    COL_TRY(hipStreamSynchronize(c->stream));
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_write_valid(nmn_columns* c, uint64_t word0, uint64_t n_words, const uint64_t* words) {
+    if (!c || (n_words && !words)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (word0 > c->words || n_words > c->words - word0) return set_error(NMN_ERR_CAPACITY, "words beyond capacity");
+    if (n_words == 0) return NMN_OK;
+    COL_TRY(hipSetDevice(c->device));
+    COL_TRY(hipMemcpyAsync(c->valid + word0, words, n_words * 8, hipMemcpyHostToDevice, c->stream));
+    COL_TRY(hipStreamSynchronize(c->stream));
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_eval(nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
+                                       uint64_t n_consts, uint64_t n_rows, uint64_t* count_out) {
+    if (!c || !prog || n_ops == 0 || !count_out || (n_consts && !consts))
+        return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_rows > c->cap) return set_error(NMN_ERR_CAPACITY, "n_rows beyond capacity_rows");
+    // validate the program on the host: column ids, constant ranges, stack discipline
+    std::vector<DevOp> dops(n_ops);
+    int64_t depth = 0;
+    for (uint32_t i = 0; i < n_ops; i++) {
+        const nmn_pred_op& o = prog[i];
+        DevOp d{};
+        d.op = o.op;
+        d.cmp = o.cmp;
+        d.vkind = o.vkind;
+        d.a = o.a;
+        d.b = o.b;
+        const bool leaf_col = o.op == NMN_PRED_EXISTS || o.op == NMN_PRED_CMP || o.op == NMN_PRED_IN || o.op == NMN_PRED_STRSET;
+        if (leaf_col) {
+            if (o.column >= c->cols.size()) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: no such column");
+            d.kinds = c->cols[o.column].kinds;
+            d.payload = c->cols[o.column].payload;
+        }
+        switch (o.op) {
+            case NMN_PRED_TRUE: case NMN_PRED_FALSE: case NMN_PRED_EXISTS: depth++; break;
+            case NMN_PRED_CMP:
+                if (o.cmp > NMN_CMP_GE || o.vkind > NMN_CELL_STRING) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: bad CMP");
+                depth++;
+                break;
+            case NMN_PRED_IN:
+                if (o.a > n_consts || o.b > (n_consts - o.a) / 2) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: IN list out of range");
+                depth++;
+                break;
+            case NMN_PRED_STRSET:
+                if (o.a > n_consts || (o.b + 63) / 64 > n_consts - o.a) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: bitset out of range");
+                depth++;
+                break;
+            case NMN_PRED_AND: case NMN_PRED_OR:
+                if (depth < 2) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: stack underflow");
+                depth--;
+                break;
+            default: return set_error(NMN_ERR_INVALID_ARGUMENT, "program: unknown opcode");
+        }
+        if (depth > 64) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: stack deeper than 64");
+        dops[i] = d;
+    }
+    if (depth != 1) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: must leave exactly one value");
+    *count_out = 0;
+    if (n_rows == 0) return NMN_OK;
+    COL_TRY(hipSetDevice(c->device));
+    const size_t ops_bytes = (size_t)n_ops * sizeof(DevOp), need = ops_bytes + (size_t)n_consts * 8 + 8;
+    if (need > c->prog_cap) {
+        if (c->prog) COL_TRY(hipFree(c->prog));
+        c->prog = nullptr;
+        c->prog_cap = 0;
+        COL_TRY(hipMalloc(reinterpret_cast<void**>(&c->prog), need * 2));
+        c->prog_cap = need * 2;
+    }
+    hipStream_t s = c->stream;
+    COL_TRY(hipMemcpyAsync(c->prog, dops.data(), ops_bytes, hipMemcpyHostToDevice, s));
+    if (n_consts) COL_TRY(hipMemcpyAsync(c->prog + ops_bytes, consts, (size_t)n_consts * 8, hipMemcpyHostToDevice, s));
+    COL_TRY(hipMemsetAsync(c->count, 0, 8, s));
+    const uint64_t n_words = (n_rows + 63) / 64;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 256ull * 16ull);
+    hipLaunchKernelGGL(pred_eval_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const DevOp*>(c->prog), n_ops,
+                       reinterpret_cast<const uint64_t*>(c->prog + ops_bytes), c->valid, n_rows, c->mask, c->count);
+    COL_TRY(hipGetLastError());
+    unsigned long long cnt = 0;
+    COL_TRY(hipMemcpyAsync(&cnt, c->count, 8, hipMemcpyDeviceToHost, s));
+    COL_TRY(hipStreamSynchronize(s));  // also keeps `dops` alive until the H2D copy has been consumed
+    *count_out = cnt;
+    return NMN_OK;
+}
+
+extern "C" const uint64_t* nmn_columns_mask_device(const nmn_columns* c) { return c ? c->mask : nullptr; }
+extern "C" const uint64_t* nmn_columns_valid_device(const nmn_columns* c) { return c ? c->valid : nullptr; }
+
+extern "C" nmn_status nmn_columns_read_mask(nmn_columns* c, uint64_t* out_words, uint64_t n_words) {
+    if (!c || (n_words && !out_words)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_words > c->words) return set_error(NMN_ERR_CAPACITY, "words beyond capacity");
+    if (n_words == 0) return NMN_OK;
+    COL_TRY(hipSetDevice(c->device));
+    COL_TRY(hipMemcpyAsync(out_words, c->mask, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+    COL_TRY(hipStreamSynchronize(c->stream));
+    return NMN_OK;
+}

@@ -190,12 +190,33 @@ struct Entry {
 // row in place, deletes clear the row's bit in a `live` bitmap that every search passes as (part of)
 // the predicate mask.  The mirror is rebuilt only when the spare capacity is exhausted or more than a
 // quarter of its rows are dead.  Searches always see exactly the store's current contents.
+//
+// Metadata: on the first pre-filtered search the metadata fields of the mirrored rows
+// are laid out as typed columns in HBM (`cols`, one (kind, payload) cell per row and field; strings
+// dictionary-encoded per field) and kept current by the same append / overwrite / tombstone hooks, so
+// the predicate of every later filtered search is one kernel over the columns instead of a
+// `store.get` + `evaluate_filter` per key (lib.rs:3526-3530).
+struct FieldColumn {
+    uint32_t id = 0;                                  // column id inside `cols`
+    std::unordered_map<std::string, uint32_t> dict;   // string value -> dictionary id
+    std::vector<std::string> strings;                 // dictionary id -> string value
+};
+
 struct Mirror {
     nmn_index* idx = nullptr;
     std::vector<uint32_t> row_to_slot;
     std::vector<uint64_t> live;  // bit r of word r/64: row r takes part
     uint64_t cap = 0, n_dead = 0;
+    int32_t device = -1;
+    nmn_columns* cols = nullptr;  // null until a filtered search needs it (or after a device error)
+    std::unordered_map<std::string, FieldColumn> fields;
+    void drop_columns() {
+        if (cols) nmn_columns_destroy(cols);
+        cols = nullptr;
+        fields.clear();
+    }
     ~Mirror() {
+        drop_columns();
         if (idx) nmn_index_destroy(idx);
     }
 };
@@ -237,6 +258,8 @@ struct nmn_engine {
     std::map<std::string, Collection> colls;          // storage of named collections
     std::map<std::string, CollectionConfig> configs;  // `collections` map (configured ones only)
     uint64_t mirror_builds = 0;
+    uint64_t column_builds = 0;    // metadata column sets built from the store
+    uint64_t device_filters = 0;   // predicates evaluated by the GPU kernel
     std::unordered_map<uint64_t, std::unique_ptr<Mirror>> scratch;  // compute_similarity, by dim
 
     Collection* storage(const char* coll, bool create) {
@@ -260,6 +283,92 @@ Mirror* mirror_of(Collection* c, uint64_t dim) {
     return it->second.get();
 }
 
+// ---- metadata columns of a mirror -------------------------------------------------------------------
+// ScalarValue -> (kind, payload) cell; strings get (or take) an id in the field's dictionary
+void encode_cell(FieldColumn& fc, const Value& v, uint8_t* kind, uint64_t* payload) {
+    *payload = 0;
+    switch (v.kind) {
+        case NMN_VAL_BOOL: *kind = NMN_CELL_BOOL; *payload = v.b ? 1 : 0; break;
+        case NMN_VAL_INT: *kind = NMN_CELL_INT; memcpy(payload, &v.i, 8); break;
+        case NMN_VAL_FLOAT: *kind = NMN_CELL_FLOAT; memcpy(payload, &v.f, 8); break;
+        case NMN_VAL_STRING: {
+            *kind = NMN_CELL_STRING;
+            auto it = fc.dict.find(v.s);
+            if (it == fc.dict.end()) {
+                it = fc.dict.emplace(v.s, (uint32_t)fc.strings.size()).first;
+                fc.strings.push_back(v.s);
+            }
+            *payload = it->second;
+            break;
+        }
+        default: *kind = NMN_CELL_NULL; break;
+    }
+}
+
+// keep the device copy of one word of the live bitmap current (no-op without columns)
+void columns_sync_valid(Mirror* m, uint64_t word) {
+    if (!m->cols) return;
+    if (nmn_columns_write_valid(m->cols, word, 1, &m->live[word]) != NMN_OK) m->drop_columns();
+}
+
+// write the metadata cells of one (new or overwritten) row; `overwrite` first drops the old cells
+void columns_write_row(Mirror* m, uint64_t row, const Meta& meta, bool overwrite) {
+    if (!m->cols) return;
+    if (overwrite && nmn_columns_clear_row(m->cols, row) != NMN_OK) return m->drop_columns();
+    for (const auto& kv : meta) {
+        auto it = m->fields.find(kv.first);
+        if (it == m->fields.end()) {
+            FieldColumn fc;
+            if (nmn_columns_add(m->cols, &fc.id) != NMN_OK) return m->drop_columns();
+            it = m->fields.emplace(kv.first, std::move(fc)).first;
+        }
+        uint8_t kind;
+        uint64_t payload;
+        encode_cell(it->second, kv.second, &kind, &payload);
+        if (nmn_columns_write(m->cols, it->second.id, row, 1, &kind, &payload) != NMN_OK) return m->drop_columns();
+    }
+}
+
+// build the column set of a mirror from the store (first filtered search, or after drop_columns)
+nmn_status columns_build(nmn_engine* e, Collection* c, Mirror* m) {
+    if (m->cols) return NMN_OK;
+    nmn_status st = nmn_columns_create(m->device, m->cap, &m->cols);
+    if (st != NMN_OK) return err_gpu(st);
+    const uint64_t n = m->row_to_slot.size();
+    struct Staging {
+        std::vector<uint8_t> kinds;
+        std::vector<uint64_t> payload;
+    };
+    std::unordered_map<std::string, Staging> staging;
+    for (uint64_t r = 0; r < n; r++) {
+        if (!((m->live[r >> 6] >> (r & 63)) & 1ull)) continue;  // a dead row's slot may belong to another key now
+        for (const auto& kv : c->slots[m->row_to_slot[r]].meta) {
+            Staging& sg = staging[kv.first];
+            if (sg.kinds.empty()) {
+                sg.kinds.assign(n, NMN_CELL_ABSENT);
+                sg.payload.assign(n, 0ull);
+            }
+            encode_cell(m->fields[kv.first], kv.second, &sg.kinds[r], &sg.payload[r]);
+        }
+    }
+    for (auto& kv : staging) {
+        FieldColumn& fc = m->fields[kv.first];
+        st = nmn_columns_add(m->cols, &fc.id);
+        if (st == NMN_OK) st = nmn_columns_write(m->cols, fc.id, 0, n, kv.second.kinds.data(), kv.second.payload.data());
+        if (st != NMN_OK) {
+            m->drop_columns();
+            return err_gpu(st);
+        }
+    }
+    st = nmn_columns_write_valid(m->cols, 0, m->live.size(), m->live.data());
+    if (st != NMN_OK) {
+        m->drop_columns();
+        return err_gpu(st);
+    }
+    e->column_builds++;
+    return NMN_OK;
+}
+
 // mark a mirrored row dead; rebuild later once a quarter of the mirror is dead
 void mirror_tombstone(Collection* c, uint64_t dim, int64_t row) {
     Mirror* m = mirror_of(c, dim);
@@ -267,10 +376,11 @@ void mirror_tombstone(Collection* c, uint64_t dim, int64_t row) {
     m->live[(uint64_t)row >> 6] &= ~(1ull << ((uint64_t)row & 63));
     m->n_dead++;
     if (m->n_dead * 4 > m->row_to_slot.size()) c->mirrors.erase(dim);
+    else columns_sync_valid(m, (uint64_t)row >> 6);
 }
 
 // append one vector to the mirror of its dimension; returns its row, or -1 (mirror absent / dropped)
-int64_t mirror_append(Collection* c, uint64_t dim, const float* v, uint32_t slot) {
+int64_t mirror_append(Collection* c, uint64_t dim, const float* v, uint32_t slot, const Meta& meta) {
     Mirror* m = mirror_of(c, dim);
     if (!m) return -1;
     const uint64_t row = m->row_to_slot.size();
@@ -281,6 +391,8 @@ int64_t mirror_append(Collection* c, uint64_t dim, const float* v, uint32_t slot
     m->row_to_slot.push_back(slot);
     if ((row >> 6) >= m->live.size()) m->live.push_back(0ull);
     m->live[row >> 6] |= 1ull << (row & 63);
+    columns_write_row(m, row, meta, false);  // a fresh row's cells are still ABSENT
+    columns_sync_valid(m, row >> 6);
     return (int64_t)row;
 }
 
@@ -299,11 +411,15 @@ nmn_status store_into(nmn_engine* e, Collection* c, const char* key, const float
         const uint64_t old_dim = old.vec.size();
         Mirror* m = old.mrow >= 0 ? mirror_of(c, old_dim) : nullptr;
         if (m && old_dim == dim) {
-            if (nmn_index_set_row(m->idx, (uint64_t)old.mrow, v) == NMN_OK) ent.mrow = old.mrow;
-            else c->mirrors.erase(old_dim);
+            if (nmn_index_set_row(m->idx, (uint64_t)old.mrow, v) == NMN_OK) {
+                ent.mrow = old.mrow;
+                columns_write_row(m, (uint64_t)old.mrow, ent.meta, true);
+            } else {
+                c->mirrors.erase(old_dim);
+            }
         } else {
             if (m) mirror_tombstone(c, old_dim, old.mrow);
-            ent.mrow = mirror_append(c, dim, v, it->second);
+            ent.mrow = mirror_append(c, dim, v, it->second, ent.meta);
         }
         old = std::move(ent);
     } else {
@@ -315,7 +431,7 @@ nmn_status store_into(nmn_engine* e, Collection* c, const char* key, const float
             slot = (uint32_t)c->slots.size();
             c->slots.emplace_back();
         }
-        ent.mrow = mirror_append(c, dim, v, slot);
+        ent.mrow = mirror_append(c, dim, v, slot, ent.meta);
         c->slots[slot] = std::move(ent);
         c->by_key[c->slots[slot].key] = slot;
         c->live++;
@@ -344,6 +460,7 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
         return NMN_OK;
     }
     auto m = std::make_unique<Mirror>();
+    m->device = e->cfg.device;
     uint64_t n = 0;
     for (const auto& ent : c->slots)
         if (ent.live && ent.vec.size() == dim) n++;  // `if stored_vec.len() != query.len() { return None }`
@@ -394,21 +511,34 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
 }
 
 // Run the GPU search over a mirror and map rows back to keys.
+// `selected` (optional): a device bitmap of the rows that take part and how many bits it has set — the
+// output of the predicate kernel, already ANDed with the live bitmap.
+struct DeviceSelection {
+    const uint64_t* mask_dev;
+    uint64_t count;
+};
+
 nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, int32_t metric,
-                    const std::vector<uint64_t>* mask, nmn_results* res) {
+                    const DeviceSelection* selected, nmn_results* res) {
     if (!m->idx) return NMN_OK;  // no rows of this dimension
     const uint64_t rows = nmn_index_rows(m->idx);
-    uint64_t k = std::min<uint64_t>(top_k, rows - std::min<uint64_t>(m->n_dead, rows));
+    const uint64_t taking_part = selected ? selected->count : rows - std::min<uint64_t>(m->n_dead, rows);
+    uint64_t k = std::min<uint64_t>(top_k, taking_part);
     if (k == 0) return NMN_OK;
     if (k > NMN_MAX_TOP_K)
         return fail(NMN_ERR_TOP_K_TOO_LARGE, "top_k exceeds NMN_MAX_TOP_K (4096) on a collection larger than that");
     std::vector<uint64_t> out_rows(k);
     std::vector<float> out_scores(k);
     uint32_t count = 0;
-    // deleted rows stay in the matrix until the next rebuild: the live bitmap keeps them out of every scan
-    const uint64_t* mask_ptr = mask ? mask->data() : (m->n_dead ? m->live.data() : nullptr);
-    nmn_status st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, mask_ptr,
-                                     out_rows.data(), out_scores.data(), &count, nullptr);
+    nmn_status st;
+    if (selected) {
+        st = nmn_index_search_dmask(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, selected->mask_dev,
+                                    out_rows.data(), out_scores.data(), &count, nullptr);
+    } else {
+        // deleted rows stay in the matrix until the next rebuild: the live bitmap keeps them out of every scan
+        st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, m->n_dead ? m->live.data() : nullptr,
+                              out_rows.data(), out_scores.data(), &count, nullptr);
+    }
     if (st != NMN_OK) return err_gpu(st);
     for (uint32_t i = 0; i < count; i++) {
         res->keys.push_back(c->slots[m->row_to_slot[out_rows[i]]].key);
@@ -419,7 +549,7 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
 
 // shared body of search_similar / search_similar_with_metric / search_in_collection
 nmn_status search_common(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
-                         const char* op, const Deadline& dl, const std::vector<uint64_t>* mask_rows_of_mirror,
+                         const char* op, const Deadline& dl, const DeviceSelection* selected,
                          Mirror* prebuilt, nmn_results* res) {
     Mirror* m = prebuilt;
     if (!m) {
@@ -427,7 +557,7 @@ nmn_status search_common(nmn_engine* e, Collection* c, const float* q, uint64_t 
         if (st != NMN_OK) return st;
     }
     if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2005-2010
-    nmn_status st = gpu_topk(c, m, q, top_k, metric, mask_rows_of_mirror, res);
+    nmn_status st = gpu_topk(c, m, q, top_k, metric, selected, res);
     if (st != NMN_OK) return st;
     if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2019-2024
     return NMN_OK;
@@ -443,24 +573,161 @@ nmn_status validate_query(const nmn_engine* e, const float* q, uint64_t dim, uin
 
 nmn_results* new_results() { return new (std::nothrow) nmn_results(); }
 
-// Pre-filter strategy (lib.rs:3514-3557 / 1776-1796): predicate on the host metadata -> row bitmap of
-// the mirror -> masked GPU scan.  Exact.
+// ---- FilterCondition -> predicate program (include/neumann_gpu.h, NMN_PRED_*) ------------------------
+struct Program {
+    std::vector<nmn_pred_op> ops;
+    std::vector<uint64_t> consts;
+};
+struct Code {
+    std::vector<nmn_pred_op> ops;
+    uint32_t need = 1;  // stack slots the fragment uses
+};
+
+nmn_pred_op make_op(uint32_t op, uint32_t column = 0, uint32_t cmp = 0, uint32_t vkind = 0, uint64_t a = 0, uint64_t b = 0) {
+    nmn_pred_op o;
+    o.op = op;
+    o.cmp = cmp;
+    o.vkind = vkind;
+    o.column = column;
+    o.a = a;
+    o.b = b;
+    return o;
+}
+
+// the (kind, payload) a FilterValue compares as; strings never get here
+bool filter_value_cell(const Value& v, uint32_t* kind, uint64_t* payload) {
+    *payload = 0;
+    switch (v.kind) {
+        case NMN_VAL_NULL: *kind = NMN_CELL_NULL; return true;
+        case NMN_VAL_BOOL: *kind = NMN_CELL_BOOL; *payload = v.b ? 1 : 0; return true;
+        case NMN_VAL_INT: *kind = NMN_CELL_INT; memcpy(payload, &v.i, 8); return true;
+        case NMN_VAL_FLOAT: *kind = NMN_CELL_FLOAT; memcpy(payload, &v.f, 8); return true;
+        default: return false;
+    }
+}
+
+// bitset over the dictionary ids of one string column: bit i = test(strings[i])
+template <typename Test>
+nmn_pred_op string_set(const FieldColumn& fc, Program& p, Test test) {
+    const uint64_t n = fc.strings.size(), off = p.consts.size();
+    p.consts.resize(off + (n + 63) / 64, 0ull);
+    for (uint64_t i = 0; i < n; i++)
+        if (test(fc.strings[i])) p.consts[off + (i >> 6)] |= 1ull << (i & 63);
+    return make_op(NMN_PRED_STRSET, fc.id, 0, 0, off, n);
+}
+
+// Postfix code of a condition.  And/Or are pure here, so the deeper operand is emitted first
+// (Sethi-Ullman order): the stack need grows with log2 of the leaf count, not with the nesting depth.
+Code compile_filter(const nmn_filter& f, const Mirror& m, Program& p) {
+    Code c;
+    auto field = [&](const std::string& name) -> const FieldColumn* {
+        auto it = m.fields.find(name);
+        return it == m.fields.end() ? nullptr : &it->second;
+    };
+    switch (f.kind) {
+        case nmn_filter::True: c.ops.push_back(make_op(NMN_PRED_TRUE)); return c;
+        case nmn_filter::And:
+        case nmn_filter::Or: {
+            Code a = compile_filter(*f.a, m, p), b = compile_filter(*f.b, m, p);
+            if (a.need < b.need) std::swap(a, b);
+            c.ops = std::move(a.ops);
+            c.ops.insert(c.ops.end(), b.ops.begin(), b.ops.end());
+            c.ops.push_back(make_op(f.kind == nmn_filter::And ? NMN_PRED_AND : NMN_PRED_OR));
+            c.need = std::max(a.need, b.need + 1);
+            return c;
+        }
+        default: break;
+    }
+    const FieldColumn* fc = field(f.field);
+    if (!fc) {  // no mirrored row has the field: `tensor.get(..)` is None for every row
+        c.ops.push_back(make_op(NMN_PRED_FALSE));
+        return c;
+    }
+    switch (f.kind) {
+        case nmn_filter::Exists: c.ops.push_back(make_op(NMN_PRED_EXISTS, fc->id)); break;
+        case nmn_filter::Contains:
+            c.ops.push_back(string_set(*fc, p, [&](const std::string& s) { return s.find(f.text) != std::string::npos; }));
+            break;
+        case nmn_filter::StartsWith:
+            c.ops.push_back(string_set(*fc, p, [&](const std::string& s) { return s.compare(0, f.text.size(), f.text) == 0; }));
+            break;
+        case nmn_filter::Cmp:
+            if (f.value.kind == NMN_VAL_STRING) {
+                const int op = f.op;
+                c.ops.push_back(string_set(*fc, p, [&](const std::string& s) {
+                    const int ord = s.compare(f.value.s);
+                    switch (op) {
+                        case NMN_OP_EQ: return ord == 0;
+                        case NMN_OP_NE: return ord != 0;
+                        case NMN_OP_LT: return ord < 0;
+                        case NMN_OP_LE: return ord <= 0;
+                        case NMN_OP_GT: return ord > 0;
+                        default: return ord >= 0;
+                    }
+                }));
+            } else {
+                uint32_t vk;
+                uint64_t vp;
+                if (filter_value_cell(f.value, &vk, &vp)) c.ops.push_back(make_op(NMN_PRED_CMP, fc->id, (uint32_t)f.op, vk, vp));
+                else c.ops.push_back(make_op(NMN_PRED_FALSE));
+            }
+            break;
+        case nmn_filter::In: {
+            // scalar members -> one IN list; string members -> one bitset; In = any member equal
+            const uint64_t off = p.consts.size();
+            uint64_t n_scalar = 0;
+            bool any_string = false;
+            for (const auto& v : f.values) {
+                uint32_t vk;
+                uint64_t vp;
+                if (v.kind == NMN_VAL_STRING) any_string = true;
+                else if (filter_value_cell(v, &vk, &vp)) {
+                    p.consts.push_back(vk);
+                    p.consts.push_back(vp);
+                    n_scalar++;
+                }
+            }
+            if (n_scalar) c.ops.push_back(make_op(NMN_PRED_IN, fc->id, 0, 0, off, n_scalar));
+            if (any_string) {
+                c.ops.push_back(string_set(*fc, p, [&](const std::string& s) {
+                    for (const auto& v : f.values)
+                        if (v.kind == NMN_VAL_STRING && v.s == s) return true;
+                    return false;
+                }));
+                if (n_scalar) {
+                    c.ops.push_back(make_op(NMN_PRED_OR));
+                    c.need = 2;
+                }
+            }
+            if (c.ops.empty()) c.ops.push_back(make_op(NMN_PRED_FALSE));  // `values.iter().any(..)` of nothing
+            break;
+        }
+        default: c.ops.push_back(make_op(NMN_PRED_FALSE)); break;
+    }
+    return c;
+}
+
+// Pre-filter strategy (lib.rs:3514-3557 / 1776-1796): the predicate runs on the GPU over the mirror's
+// metadata columns and leaves the selection bitmap in HBM; the masked scan reads it in place.  Exact.
 nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k,
                              const nmn_filter& f, const char* op, const Deadline& dl, nmn_results* res) {
     Mirror* m = nullptr;
     nmn_status st = get_mirror(e, c, dim, &m);
     if (st != NMN_OK) return st;
     if (!m->idx) return NMN_OK;
-    const uint64_t rows = m->row_to_slot.size();
-    std::vector<uint64_t> mask((rows + 63) / 64, 0ull);
-    uint64_t matching = 0;
-    for (uint64_t r = 0; r < rows; r++)
-        if (((m->live[r >> 6] >> (r & 63)) & 1ull) && evaluate_filter(c->slots[m->row_to_slot[r]].meta, f)) {
-            mask[r >> 6] |= 1ull << (r & 63);
-            matching++;
-        }
-    if (matching == 0) return NMN_OK;
-    return search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &mask, m, res);
+    st = columns_build(e, c, m);
+    if (st != NMN_OK) return st;
+    Program p;
+    Code code = compile_filter(f, *m, p);
+    p.ops = std::move(code.ops);
+    DeviceSelection sel{nullptr, 0};
+    st = nmn_columns_eval(m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(),
+                          m->row_to_slot.size(), &sel.count);
+    if (st != NMN_OK) return err_gpu(st);
+    e->device_filters++;
+    if (sel.count == 0) return NMN_OK;  // `if matching_keys.is_empty() { return Vec::new() }`
+    sel.mask_dev = nmn_columns_mask_device(m->cols);
+    return search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &sel, m, res);
 }
 
 }  // namespace
@@ -964,6 +1231,18 @@ uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f) {
     for (const auto& ent : e->dflt.slots)
         if (ent.live && evaluate_filter(ent.meta, *f)) n++;
     return n;
+}
+
+uint64_t nmn_engine_device_filter_evals(nmn_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->device_filters;
+}
+
+uint64_t nmn_engine_column_builds(nmn_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->column_builds;
 }
 
 uint64_t nmn_engine_mirror_builds(nmn_engine* e) {

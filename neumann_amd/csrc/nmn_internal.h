@@ -196,4 +196,9 @@ hipError_t launch_count_cmp(const uint32_t* scores, uint64_t n_rows, float score
 hipError_t launch_synth_fill(float* corpus, uint32_t ld, uint32_t dim, uint64_t seed, uint64_t global_row0,
                              uint64_t local_row0, uint64_t n, hipStream_t s);
 
+// error reporting shared by the translation units that export C ABI entry points (nmn_api.hip owns
+// the thread-local message behind nmn_last_error)
+nmn_status set_error(nmn_status code, const char* what);
+nmn_status set_error_hip(hipError_t e, const char* what);
+
 }  // namespace nmn

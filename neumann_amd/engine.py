@@ -91,6 +91,8 @@ ENGINE_SIGNATURES = {
     "nmn_filter_free": (None, [vp]),
     "nmn_engine_count_matching": (C.c_uint64, [vp, vp]),
     "nmn_engine_mirror_builds": (C.c_uint64, [vp]),
+    "nmn_engine_device_filter_evals": (C.c_uint64, [vp]),
+    "nmn_engine_column_builds": (C.c_uint64, [vp]),
     "nmn_engine_mirror_cached": (C.c_int32, [vp, C.c_char_p]),
 }
 
@@ -466,6 +468,14 @@ class VectorEngine:
     # -- mirror bookkeeping (cache protocol tests) ------------------------------------------------
     def mirror_builds(self):
         return int(_lib().nmn_engine_mirror_builds(self._h))
+
+    def device_filter_evals(self):
+        """Pre-filter predicates evaluated by the GPU predicate kernel so far."""
+        return int(_lib().nmn_engine_device_filter_evals(self._h))
+
+    def column_builds(self):
+        """Times a metadata column set was (re)built from the store."""
+        return int(_lib().nmn_engine_column_builds(self._h))
 
     def mirror_cached(self, collection=None):
         return bool(_lib().nmn_engine_mirror_cached(self._h, None if collection is None else collection.encode()))

@@ -122,6 +122,19 @@ class GpuFlatIndex:
             return out_rows, out_scores, out_counts, stats
         return out_rows, out_scores, out_counts
 
+    def search_dmask(self, queries, k, metric, mask_device_ptr):
+        """`search` with the selection bitmap already in device memory (e.g. GpuColumns.mask_device)."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, k = q.shape[0], int(k)
+        out_rows = np.empty((nq, max(k, 1)), dtype=np.uint64)
+        out_scores = np.empty((nq, max(k, 1)), dtype=np.float32)
+        out_counts = np.empty(nq, dtype=np.uint32)
+        _capi.check(self._lib.nmn_index_search_dmask(self._h, _ptr(q), nq, k, int(metric), mask_device_ptr,
+                                                     _ptr(out_rows), _ptr(out_scores), _ptr(out_counts), None))
+        return out_rows, out_scores, out_counts
+
     def search_device(self, queries_t, k, metric=DistanceMetric.Cosine, mask_t=None, out=None, stream=None):
         """Asynchronous search with torch device tensors.
 

@@ -30,8 +30,10 @@ def shard_range(total_rows, world_size, rank):
 class ShardedSearcher:
     """Per-rank driver: local shard search -> all-gather -> merge.  World size 1 skips the collective."""
 
-    def __init__(self, index, world_size=1, rank=0, k=10, nq=1, device=None, group=None, local_search=None):
+    def __init__(self, index, world_size=1, rank=0, k=10, nq=1, device=None, group=None, local_search=None,
+                 always_gather=False):
         self.index = index
+        self.always_gather = bool(always_gather)  # run the all-gather + merge even with one rank (1-GPU RCCL test)
         self.world_size = int(world_size)
         self.rank = int(rank)
         self.k = int(k)
@@ -55,7 +57,7 @@ class ShardedSearcher:
             "scores": block[off_s:off_c].view(torch.float32).view(nq, k),
             "counts": block[off_c:off_c + nq * 4].view(torch.int32),
         }
-        if w > 1:
+        if w > 1 or self.always_gather:
             self._bufs["gathered"] = torch.empty(w * size, dtype=torch.uint8, device=dev)
             self._bufs["out"] = (torch.empty((nq, k), dtype=torch.int64, device=dev),
                                  torch.empty((nq, k), dtype=torch.float32, device=dev),
@@ -70,7 +72,7 @@ class ShardedSearcher:
         b = self._bufs
         self.index.search_device(queries_t, self.k, metric, mask_t=mask_t,
                                  out=(b["rows"], b["scores"], b["counts"]))
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.always_gather:
             return b["rows"], b["scores"], b["counts"]
         import torch.distributed as dist
         dist.all_gather_into_tensor(b["gathered"], b["block"], group=self.group)

@@ -30,3 +30,44 @@ def test_sharded_searcher_world1_matches_oracle():
         hr, hs, hc = ss.search_host(Q, 0)
         er, es = oc.search(A, Q[0], k, 0)
         assert np.array_equal(hr[0], er) and np.all(hs[0] == es)
+
+
+def test_rccl_gather_and_device_merge_single_rank():
+    """The N>1 device path end to end on one GPU: an RCCL ("nccl") process group of one rank, the packed
+    all-gather on the search stream and the device merge — the exact calls every rank makes at N>1."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from neumann_amd import GpuFlatIndex
+    from neumann_amd.sharded import ShardedSearcher
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n, d, k, nq = 50000, 256, 100, 5
+        A = oc.synth(21, 1000, n, d)  # shard rows are generated from their GLOBAL ids
+        Q = oc.synth(22, 0, nq, d)
+        with GpuFlatIndex(d, n, row_base=1000) as idx:
+            idx.fill_synthetic(21, n)
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            ss = [ShardedSearcher(idx, world_size=1, rank=0, k=k, nq=nq, device=dev, always_gather=True) for _ in streams]
+            qd = torch.from_numpy(Q).to(dev)
+            outs = []
+            for i in range(6):  # pipelined over two streams like bench.py
+                with torch.cuda.stream(streams[i % 2]):
+                    outs.append(ss[i % 2].search_device(qd, i % 3))
+            dist.barrier()
+            torch.cuda.synchronize()
+            for i in (4, 5):  # the last result of each stream is still in its buffers
+                rows, scores, counts = (t.cpu().numpy() for t in outs[i])
+                for qi in range(nq):
+                    er, es = oc.search(A, Q[qi], k, i % 3, row_base=1000)
+                    assert counts[qi] == k
+                    assert np.array_equal(rows[qi].view(np.uint64), er) and np.all(scores[qi] == es)
+    finally:
+        if created:
+            dist.destroy_process_group()
