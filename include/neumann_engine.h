@@ -155,6 +155,17 @@ nmn_filter* nmn_filter_contains(const char* field, const char* substr);
 nmn_filter* nmn_filter_starts_with(const char* field, const char* prefix);
 nmn_filter* nmn_filter_in(const char* field, const nmn_value* values, uint32_t n);
 void nmn_filter_free(nmn_filter* f);
+/* ---- unified entity mode (lib.rs:3060-3237): vectors in the `_embedding` field of entity keys ---- */
+nmn_status nmn_engine_set_entity_embedding(nmn_engine* e, const char* entity_key, const float* v, uint64_t dim);
+nmn_status nmn_engine_get_entity_embedding(nmn_engine* e, const char* entity_key, float* out, uint64_t cap,
+                                           uint64_t* dim_out);
+int32_t nmn_engine_entity_has_embedding(nmn_engine* e, const char* entity_key);
+nmn_status nmn_engine_remove_entity_embedding(nmn_engine* e, const char* entity_key);
+nmn_strlist* nmn_engine_scan_entities_with_embeddings(nmn_engine* e);
+uint64_t nmn_engine_count_entities_with_embeddings(nmn_engine* e);
+/* search_entities (lib.rs:3155-3219): cosine TOP-K over every entity that has an embedding */
+nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, nmn_results** out);
+
 /* count_matching / estimate_filter_selectivity (lib.rs:3698-3722) */
 uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f);
 

@@ -255,6 +255,7 @@ struct nmn_engine {
     nmn_engine_config cfg;
     std::mutex mu;  // `&self` from many threads is safe; operations are serialised
     Collection dflt;
+    Collection entities;                              // unified entity mode: keys whose TensorData has `_embedding`
     std::map<std::string, Collection> colls;          // storage of named collections
     std::map<std::string, CollectionConfig> configs;  // `collections` map (configured ones only)
     uint64_t mirror_builds = 0;
@@ -890,6 +891,73 @@ nmn_status nmn_engine_search_similar(nmn_engine* e, const float* q, uint64_t dim
     if (!zero_magnitude(q, dim)) {  // lib.rs:1970-1974
         std::lock_guard<std::mutex> g(e->mu);
         st = search_common(e, &e->dflt, q, dim, top_k, NMN_METRIC_COSINE, "search_similar", dl, nullptr, nullptr, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+// ---- unified entity mode (lib.rs:3060-3237) --------------------------------------------------------
+// Entity keys ("user:1") carry their vector in the `_embedding` field of the entity's TensorData
+// (fields::EMBEDDING, tensor_store/src/lib.rs:183).  On this path only that field matters, so the
+// entities are one more key space with its own GPU mirror; `search_entities` is the same cosine scan
+// over it (lib.rs:3155-3219: rows without `_embedding` or of another dimension are skipped).
+nmn_status nmn_engine_set_entity_embedding(nmn_engine* e, const char* entity_key, const float* v, uint64_t dim) {
+    if (!e || !entity_key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v || dim == 0) return err_empty();  // lib.rs:3073-3075
+    if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);  // 3077-3084
+    std::lock_guard<std::mutex> g(e->mu);
+    return store_into(e, &e->entities, entity_key, v, dim, nullptr, 0);
+}
+
+nmn_status nmn_engine_get_entity_embedding(nmn_engine* e, const char* entity_key, float* out, uint64_t cap,
+                                           uint64_t* dim_out) {
+    if (!e || !entity_key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    return get_from(&e->entities, entity_key, entity_key, out, cap, dim_out);  // NotFound(entity_key), lib.rs:3110-3119
+}
+
+int32_t nmn_engine_entity_has_embedding(nmn_engine* e, const char* entity_key) {  // lib.rs:3123-3128
+    if (!e || !entity_key) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->entities.by_key.count(entity_key) ? 1 : 0;
+}
+
+nmn_status nmn_engine_remove_entity_embedding(nmn_engine* e, const char* entity_key) {  // lib.rs:3135-3147
+    if (!e || !entity_key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    return delete_from(&e->entities, entity_key, entity_key);
+}
+
+nmn_strlist* nmn_engine_scan_entities_with_embeddings(nmn_engine* e) {  // lib.rs:3224-3232
+    nmn_strlist* l = new (std::nothrow) nmn_strlist();
+    if (!e || !l) return l;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (const auto& ent : e->entities.slots)
+        if (ent.live) l->items.push_back(ent.key);
+    return l;
+}
+
+uint64_t nmn_engine_count_entities_with_embeddings(nmn_engine* e) {  // lib.rs:3235-3237
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    return e->entities.live;
+}
+
+nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, nmn_results** out) {
+    if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    nmn_status st = validate_query(e, q, dim, top_k, /*check_max_dim=*/true);  // lib.rs:3158-3173
+    if (st != NMN_OK) return st;
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    if (!zero_magnitude(q, dim)) {  // lib.rs:3175-3178
+        std::lock_guard<std::mutex> g(e->mu);
+        st = search_common(e, &e->entities, q, dim, top_k, NMN_METRIC_COSINE, "search_entities", dl, nullptr, nullptr, res);
         if (st != NMN_OK) {
             delete res;
             return st;

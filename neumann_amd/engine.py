@@ -56,6 +56,13 @@ ENGINE_SIGNATURES = {
     "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
     "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_set_entity_embedding": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64]),
+    "nmn_engine_get_entity_embedding": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "nmn_engine_entity_has_embedding": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_remove_entity_embedding": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_scan_entities_with_embeddings": (vp, [vp]),
+    "nmn_engine_count_entities_with_embeddings": (C.c_uint64, [vp]),
+    "nmn_engine_search_entities": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "nmn_engine_search_similar_with_metric": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(vp)]),
     "nmn_engine_search_similar_filtered": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, vp,
                                                        C.POINTER(_FilteredConfig), C.POINTER(vp)]),
@@ -381,6 +388,37 @@ class VectorEngine:
         a, p, n = _vec(query)
         h = vp()
         _check(_lib().nmn_engine_search_similar(self._h, p, n, int(top_k), C.byref(h)))
+        return self._take_results(h)
+
+    # ---- unified entity mode (lib.rs:3060-3237) ----
+    def set_entity_embedding(self, entity_key, vector):
+        a, p, n = _vec(vector)
+        _check(_lib().nmn_engine_set_entity_embedding(self._h, entity_key.encode(), p, n))
+
+    def get_entity_embedding(self, entity_key):
+        dim = C.c_uint64()
+        _check(_lib().nmn_engine_get_entity_embedding(self._h, entity_key.encode(), None, 0, C.byref(dim)))
+        out = np.empty(dim.value, dtype=np.float32)
+        _check(_lib().nmn_engine_get_entity_embedding(self._h, entity_key.encode(), C.c_void_p(out.ctypes.data),
+                                                      out.size, C.byref(dim)))
+        return out
+
+    def entity_has_embedding(self, entity_key):
+        return bool(_lib().nmn_engine_entity_has_embedding(self._h, entity_key.encode()))
+
+    def remove_entity_embedding(self, entity_key):
+        _check(_lib().nmn_engine_remove_entity_embedding(self._h, entity_key.encode()))
+
+    def scan_entities_with_embeddings(self):
+        return self._take_list(_lib().nmn_engine_scan_entities_with_embeddings(self._h))
+
+    def count_entities_with_embeddings(self):
+        return int(_lib().nmn_engine_count_entities_with_embeddings(self._h))
+
+    def search_entities(self, query, top_k):
+        a, p, n = _vec(query)
+        h = vp()
+        _check(_lib().nmn_engine_search_entities(self._h, p, n, int(top_k), C.byref(h)))
         return self._take_results(h)
 
     def search_similar_with_metric(self, query, top_k, metric):

@@ -479,6 +479,80 @@ def test_search_filtered_in_collection(E):  # lib.rs:7935-8000
     assert engine.search_filtered_in_collection("test", [0.0, 0.0], 10, FC.TRUE) == []
 
 
+# ---- unified entity mode (lib.rs:4692-4867) -----------------------------------------------------------------
+def test_entity_embedding_crud(E):  # lib.rs:4692-4770, 4815-4840
+    engine = E.VectorEngine()
+    assert not engine.entity_has_embedding("user:1")
+    assert engine.count_entities_with_embeddings() == 0
+    engine.set_entity_embedding("user:1", [1.0, 2.0, 3.0])
+    assert np.array_equal(engine.get_entity_embedding("user:1"), np.array([1.0, 2.0, 3.0], F))
+    assert engine.entity_has_embedding("user:1")
+    engine.set_entity_embedding("user:2", [3.0, 4.0])
+    assert sorted(engine.scan_entities_with_embeddings()) == ["user:1", "user:2"]
+    assert engine.count_entities_with_embeddings() == 2
+    engine.remove_entity_embedding("user:1")
+    assert not engine.entity_has_embedding("user:1")
+    for call in (lambda: engine.remove_entity_embedding("user:999"), lambda: engine.get_entity_embedding("user:999")):
+        with pytest.raises(E.VectorError) as e:
+            call()
+        assert e.value.kind == "NotFound"
+    with pytest.raises(E.VectorError) as e:
+        engine.set_entity_embedding("user:1", [])
+    assert e.value.kind == "EmptyVector"
+    # entity keys and embedding keys are separate key spaces (`user:1` vs `emb:user:1`)
+    engine.store_embedding("user:2", [9.0, 9.0])
+    assert np.array_equal(engine.get_entity_embedding("user:2"), np.array([3.0, 4.0], F))
+    assert engine.count() == 1 and engine.count_entities_with_embeddings() == 1
+
+
+def test_search_entities(E):  # lib.rs:4772-4790, 4842-4864, 6372-6390
+    engine = E.VectorEngine()
+    engine.set_entity_embedding("user:1", [1.0, 0.0, 0.0])
+    engine.set_entity_embedding("user:2", [0.0, 1.0, 0.0])
+    engine.set_entity_embedding("user:3", [1.0, 1.0, 0.0])
+    engine.store_embedding("doc", [1.0, 0.0, 0.0])          # not an entity: never returned
+    engine.set_entity_embedding("other_dim", [1.0, 0.0])    # dimension mismatch: skipped
+    r = engine.search_entities([1.0, 0.0, 0.0], 3)
+    assert len(r) == 3 and r[0].key == "user:1" and abs(r[0].score - 1.0) < 1e-6
+    assert [x.key for x in r] == ["user:1", "user:3", "user:2"]
+    with pytest.raises(E.VectorError) as e:
+        engine.search_entities([], 5)
+    assert e.value.kind == "EmptyVector"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_entities([1.0], 0)
+    assert e.value.kind == "InvalidTopK"
+    assert engine.search_entities([0.0, 0.0, 0.0], 5) == []
+    limited = E.VectorEngine(E.VectorEngineConfig(max_dimension=2))
+    with pytest.raises(E.VectorError) as e:
+        limited.search_entities([1.0, 0.0, 0.0], 1)
+    assert e.value.kind == "DimensionMismatch"
+    with pytest.raises(E.VectorError) as e:
+        limited.set_entity_embedding("u", [1.0, 0.0, 0.0])
+    assert e.value.kind == "DimensionMismatch"
+
+
+def test_search_entities_matches_oracle(E):
+    rng = np.random.default_rng(61)
+    n, d, k = 4000, 96, 30
+    A = rng.standard_normal((n, d)).astype(F)
+    engine = E.VectorEngine()
+    for i in range(n):
+        engine.set_entity_embedding(f"k{i}", A[i])
+    live = np.ones(n, bool)
+    for i in rng.choice(n, 300, replace=False):
+        engine.remove_entity_embedding(f"k{int(i)}")
+        live[int(i)] = False
+    for i in rng.choice(np.flatnonzero(live), 200, replace=False):
+        A[int(i)] = rng.standard_normal(d).astype(F)
+        engine.set_entity_embedding(f"k{int(i)}", A[int(i)])
+    for t in range(3):
+        q = rng.standard_normal(d).astype(F)
+        res = engine.search_entities(q, k)
+        er, es = oc.search(A, q, k, 0, mask=oc.mask_from_bool(live))
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+        assert np.all(np.array([r.score for r in res], F) == es)
+
+
 # ---- concurrency contract (lib.rs:5615-5711) -------------------------------------------------------------
 def test_concurrent_search_and_store(E):
     engine = E.VectorEngine()
