@@ -43,11 +43,13 @@ typedef int32_t nmn_status;
 #define NMN_ERR_INVALID_ARGUMENT (-20)
 #define NMN_ERR_NO_DEVICE (-21)
 #define NMN_ERR_OUT_OF_MEMORY (-22)
-#define NMN_ERR_TOP_K_TOO_LARGE (-23)     /* k > NMN_MAX_TOP_K */
+#define NMN_ERR_TOP_K_TOO_LARGE (-23)     /* reserved (k > NMN_MAX_TOP_K is served by the large-k path) */
 #define NMN_ERR_CAPACITY (-24)            /* upload beyond capacity_rows */
 #define NMN_ERR_BUFFER_TOO_SMALL (-25)
 
-/* Largest k one search call accepts (single-workgroup final sort in LDS). */
+/* Largest k the candidate pipeline serves (single-workgroup final sort in LDS).  Larger k is legal — the
+ * reference sorts everything and truncates (lib.rs:2026-2034) — and takes the large-k path: exact score
+ * of every row, full device sort, first k (neumann_amd/csrc/nmn_sortk.hip). */
 #define NMN_MAX_TOP_K 4096u
 /* Largest number of queries one search call accepts. */
 #define NMN_MAX_QUERIES 1024u
@@ -125,7 +127,7 @@ const float* nmn_index_norms_device(const nmn_index* idx);
  * `search_in_collection` scoring + full sort + truncate (vector_engine/src/lib.rs:1950-2101,
  * 1585-1689) and, with `mask`, the survivor scan of `search_with_pre_filter` (lib.rs:3514-3557).
  *
- *   queries  nq x dim f32, HOST.          k  1..NMN_MAX_TOP_K
+ *   queries  nq x dim f32, HOST.          k  >= 1 (k > NMN_MAX_TOP_K: large-k path, one full sort per query)
  *   mask     nullable HOST bitmap, ceil(rows/64) u64 words, bit i of word i/64 (LSB first) = row i
  *            takes part (layout of relational_engine's selection bitmaps, simd.rs:6-311).
  *   out_rows   nq x k  global row ids (row_base + local row), best first; unused slots = UINT64_MAX

@@ -77,6 +77,7 @@ struct Workspace {
     uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
     float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
     unsigned long long* h_counts2 = nullptr;
+    uint64_t* lk_keys = nullptr; size_t lk_keys_cap = 0;  // composite keys of the large-k path (k > NMN_MAX_TOP_K)
     // timing + stats of the last search
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
@@ -106,7 +107,7 @@ static void ws_free(Workspace* w) {
     if (!w) return;
     void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
-                    w->h_counts2};
+                    w->h_counts2, w->lk_keys};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : w->ev)
@@ -143,7 +144,8 @@ static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32
     auto it = idx->ws.find(stream);
     if (it != idx->ws.end()) w = it->second;
     uint32_t nqc = pass_queries(idx, nq);
-    uint32_t cand_cap = std::max<uint32_t>(std::min<uint32_t>(idx->cand_cap, NMN_MAX_TOP_K), k);
+    // k beyond NMN_MAX_TOP_K takes the large-k path, which needs no candidate lists
+    uint32_t cand_cap = std::max<uint32_t>(std::min<uint32_t>(idx->cand_cap, NMN_MAX_TOP_K), std::min<uint32_t>(k, NMN_MAX_TOP_K));
     if (w && w->nq_cap >= nqc && w->cand_cap >= cand_cap) {
         *out = w;
         return NMN_OK;
@@ -217,7 +219,7 @@ extern "C" const char* nmn_status_str(nmn_status s) {
         case NMN_ERR_INVALID_ARGUMENT: return "invalid argument";
         case NMN_ERR_NO_DEVICE: return "no usable HIP device (libneumann_gpu has no CPU fallback)";
         case NMN_ERR_OUT_OF_MEMORY: return "out of device memory";
-        case NMN_ERR_TOP_K_TOO_LARGE: return "top_k exceeds NMN_MAX_TOP_K";
+        case NMN_ERR_TOP_K_TOO_LARGE: return "top_k too large";
         case NMN_ERR_CAPACITY: return "upload exceeds index capacity";
         case NMN_ERR_BUFFER_TOO_SMALL: return "buffer too small";
         default: return "unknown status";
@@ -357,11 +359,61 @@ extern "C" nmn_status nmn_index_upload_device(nmn_index* idx, const float* rows_
 }
 
 // ---- the search pipeline ------------------------------------------------------------------------
+// k > NMN_MAX_TOP_K: exact score of every row, full descending sort of the composite keys, first k
+// (nmn_sortk.hip).  One query at a time; the reference does the same amount of work for every k.
+static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* queries_dev, uint32_t nq, uint32_t k,
+                                 nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows, float* out_scores,
+                                 uint32_t* out_counts, hipStream_t stream) {
+    const uint64_t n_rows = idx->rows;
+    const uint64_t n_sort = largek_sort_len(n_rows);
+    if (n_sort > w->lk_keys_cap) HIP_TRY(hipStreamSynchronize(stream));  // the old buffer may still be in use
+    HIP_TRY(grow(&w->lk_keys, &w->lk_keys_cap, (size_t)n_sort));
+    w->timed = idx->timing;
+    w->last_nq = nq;
+    w->last_rows_scanned = n_rows;
+    w->last_masked = mask_dev != nullptr;
+    if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
+    for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
+        const uint32_t nqc = std::min(w->nq_cap, nq - qa);
+        HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric, idx->max_norm_bits,
+                             w->qpad, w->qinfo, w->qstate, 0, stream));
+        for (uint32_t q = 0; q < nqc; q++) {
+            const bool first = qa == 0 && q == 0;
+            if (w->timed && first) HIP_TRY(hipEventRecord(w->ev[1], stream));
+            if (n_rows > 0) {
+                ExactScanParams ep{};
+                ep.corpus = idx->corpus;
+                ep.norms = idx->norms;
+                ep.qpad = w->qpad + (size_t)q * idx->ld;
+                ep.qinfo = w->qinfo + q;
+                ep.qstate = nullptr;
+                ep.mask = mask_dev;
+                ep.scores = w->scores;  // plain row order: score_at(row, 0, 1) == row
+                ep.n_rows = n_rows;
+                ep.nql = 1;
+                ep.ld = idx->ld;
+                ep.dim = idx->dim;
+                ep.nq = 1;
+                ep.metric = (int)metric;
+                HIP_TRY(launch_exact_scan(ep, stream));
+            }
+            if (w->timed && first) HIP_TRY(hipEventRecord(w->ev[2], stream));
+            const size_t o = (size_t)(qa + q);
+            HIP_TRY(launch_largek(w->scores, n_rows, w->lk_keys, k, idx->row_base, out_rows + o * k, out_scores + o * k,
+                                  out_counts + o, stream));
+        }
+    }
+    if (w->timed) HIP_TRY(hipEventRecord(w->ev[3], stream));
+    return NMN_OK;
+}
+
 static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* queries_dev, uint32_t nq, uint32_t k,
                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                  float* out_scores, uint32_t* out_counts, hipStream_t stream) {
     nmn_status st = ws_alloc(idx, w);
     if (st != NMN_OK) return st;
+    if (k > NMN_MAX_TOP_K)
+        return search_large_k(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows, out_scores, out_counts, stream);
     const uint64_t n_rows = idx->rows;
     const uint32_t n_tiles = (uint32_t)((n_rows + kTileRows - 1) / kTileRows);
     w->timed = idx->timing;
@@ -511,7 +563,6 @@ static nmn_status check_search_args(const nmn_index* idx, const void* queries, u
                                     const void* out_counts) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     if (k == 0) return fail_arg(NMN_ERR_INVALID_TOP_K, "k == 0");
-    if (k > NMN_MAX_TOP_K) return fail_arg(NMN_ERR_TOP_K_TOO_LARGE, "k > NMN_MAX_TOP_K");
     if (nq == 0 || nq > NMN_MAX_QUERIES) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
     if (!queries || !out_rows || !out_scores || !out_counts)
         return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null buffer");

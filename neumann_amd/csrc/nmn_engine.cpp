@@ -526,8 +526,6 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
     const uint64_t taking_part = selected ? selected->count : rows - std::min<uint64_t>(m->n_dead, rows);
     uint64_t k = std::min<uint64_t>(top_k, taking_part);
     if (k == 0) return NMN_OK;
-    if (k > NMN_MAX_TOP_K)
-        return fail(NMN_ERR_TOP_K_TOO_LARGE, "top_k exceeds NMN_MAX_TOP_K (4096) on a collection larger than that");
     std::vector<uint64_t> out_rows(k);
     std::vector<float> out_scores(k);
     uint32_t count = 0;

@@ -192,6 +192,12 @@ hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s);
 hipError_t launch_count_cmp(const uint32_t* scores, uint64_t n_rows, float score, unsigned long long* out2,
                             hipStream_t s);
 
+// large-k path (nmn_sortk.hip): keys[] holds largek_sort_len(n_rows) u64 (next power of two >= max(n_rows, 4096));
+// score_bits[] are exact scores in plain row order (kScoreSentinelBits = row does not take part)
+uint64_t largek_sort_len(uint64_t n_rows);
+hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* keys, uint32_t k, uint64_t row_base,
+                         uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s);
+
 // synthetic data
 hipError_t launch_synth_fill(float* corpus, uint32_t ld, uint32_t dim, uint64_t seed, uint64_t global_row0,
                              uint64_t local_row0, uint64_t n, hipStream_t s);

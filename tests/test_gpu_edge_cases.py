@@ -100,9 +100,7 @@ def test_k_max_and_too_large():
         idx.upload(A)
         check(idx, A, q, 4096, 0)
         check(idx, A, q, 1000, 1)
-        with pytest.raises(NeumannGpuError) as e:
-            idx.search(q, 4097, 0)
-        assert e.value.status == _capi.ERR_TOP_K_TOO_LARGE
+        check(idx, A, q, 4097, 0)   # beyond the candidate pipeline: the large-k path (full sort), same answer
         with pytest.raises(NeumannGpuError) as e:
             idx.search(q, 0, 0)
         assert e.value.status == _capi.ERR_INVALID_TOP_K and "Invalid top_k" in str(e.value)
@@ -223,3 +221,63 @@ def test_count_exact_certificate():
             ref = np.sort(s)[::-1][99]
             gt, eq = idx.count_exact(q, ref, m)
             assert gt == int(np.sum(s > ref)) and eq == int(np.sum(s == ref))
+
+
+# ---- large-k path (k > NMN_MAX_TOP_K): exact scan of every row + full device sort (nmn_sortk.hip) -----------
+@pytest.mark.parametrize("n,d", [(5000, 24), (4096, 8), (20011, 40), (70000, 16)])
+def test_large_k_matches_oracle(n, d):
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(n + d)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[10] = A[3]                    # exact duplicates: ties resolve by ascending row id
+    A[n // 2] = A[3]
+    A[7] = 0.0                      # zero vector: cosine 0.0, still returned
+    q = rng.standard_normal(d).astype(np.float32)
+    keep = rng.random(n) < 0.6
+    mask = oc.mask_from_bool(keep)
+    with GpuFlatIndex(d, n + 50, row_base=10**9) as idx:   # spare capacity, global ids
+        idx.upload(A)
+        for metric in (0, 1, 2):
+            for k in (4097, n - 1, n, n + 1000):
+                rows, scores, counts = idx.search(q, k, metric)
+                er, es = oc.search(A, q, k, metric, row_base=10**9)
+                assert counts[0] == min(k, n) == er.size
+                assert np.array_equal(rows[0, :er.size], er) and np.all(scores[0, :er.size] == es)
+                assert np.all(rows[0, er.size:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isneginf(scores[0, er.size:]))
+            rows, scores, counts = idx.search(q, n, metric, mask=mask)
+            er, es = oc.search(A, q, n, metric, mask=mask, row_base=10**9)
+            assert counts[0] == int(keep.sum()) == er.size
+            assert np.array_equal(rows[0, :er.size], er) and np.all(scores[0, :er.size] == es)
+
+
+def test_large_k_multi_query_and_special_values():
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(404)
+    n, d, k = 9000, 12, 6000
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[5, 0] = np.inf                # inf / nan scores rank as in the candidate pipeline: NaN below -inf
+    A[6, 1] = np.nan
+    A[8] = -A[9]
+    Q = rng.standard_normal((3, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for metric in (0, 1, 2):
+            rows, scores, counts = idx.search(Q, k, metric)
+            small_rows, small_scores, _ = idx.search(Q, 4096, metric)      # candidate pipeline on the same data
+            for qi in range(3):
+                assert counts[qi] == k
+                assert np.array_equal(rows[qi, :4096], small_rows[qi])
+                assert np.array_equal(scores[qi, :4096], small_scores[qi], equal_nan=True)
+                er, es = oc.search(A, Q[qi], k, metric)
+                ok = ~np.isnan(es)
+                assert np.array_equal(rows[qi][ok], er[ok]) and np.all(scores[qi][ok] == es[ok])
+
+
+def test_large_k_on_empty_and_tiny_shards():
+    from neumann_amd import GpuFlatIndex
+    with GpuFlatIndex(4, 100) as idx:
+        rows, scores, counts = idx.search(np.ones(4, np.float32), 5000, 0)
+        assert counts[0] == 0 and np.all(rows == np.uint64(0xFFFFFFFFFFFFFFFF))
+        idx.upload(np.eye(4, dtype=np.float32))
+        rows, scores, counts = idx.search(np.array([1, 0.5, 0, 0], np.float32), 5000, 0)
+        assert counts[0] == 4 and rows[0, :4].tolist() == [0, 1, 2, 3]

@@ -479,6 +479,32 @@ def test_search_filtered_in_collection(E):  # lib.rs:7935-8000
     assert engine.search_filtered_in_collection("test", [0.0, 0.0], 10, FC.TRUE) == []
 
 
+def test_top_k_beyond_4096_returns_the_full_ranking(E):
+    """The reference sorts every score and truncates (lib.rs:2026-2034): any top_k is legal."""
+    rng = np.random.default_rng(8)
+    n, d = 6000, 16
+    A = rng.standard_normal((n, d)).astype(F)
+    engine = E.VectorEngine()
+    engine.batch_store_embeddings([f"k{i}" for i in range(n)], A)
+    q = rng.standard_normal(d).astype(F)
+    for top_k in (5000, n, 10 * n):
+        res = engine.search_similar(q, top_k)
+        er, es = oc.search(A, q, top_k, 0)
+        assert len(res) == min(top_k, n)
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+        assert np.all(np.array([r.score for r in res], F) == es)
+    res = engine.search_similar_with_metric(q, n, E.DistanceMetric.Euclidean)
+    er, es = oc.search(A, q, n, 1)
+    assert [r.key for r in res] == [f"k{i}" for i in er]
+    # post-filter oversampling asks the scan for 3 * top_k (lib.rs:3567-3568)
+    eng2 = E.VectorEngine()
+    for i in range(n):
+        eng2.store_embedding_with_metadata(f"k{i}", A[i], {"even": i % 2 == 0})
+    res = eng2.search_similar_filtered(q, 1500, E.FilterCondition.Eq("even", True), E.FilteredSearchConfig.post_filter())
+    er, _ = oc.search(A, q, 4500, 0)
+    assert [r.key for r in res] == [f"k{i}" for i in er if i % 2 == 0][:1500]
+
+
 # ---- unified entity mode (lib.rs:4692-4867) -----------------------------------------------------------------
 def test_entity_embedding_crud(E):  # lib.rs:4692-4770, 4815-4840
     engine = E.VectorEngine()
