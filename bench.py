@@ -293,8 +293,10 @@ def main():
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
     # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 5 queries, cosine/dot, dim % 128 == 0,
     # dim <= 768), else 4 (VALU) — mirrors search_enqueue() in neumann_amd/csrc/nmn_api.hip
-    mfma = args.nq >= 5 and args.metric in ("cosine", "dot") and args.dim % 128 == 0 and args.dim <= 768
+    mfma = args.nq >= 5 and args.metric in ("cosine", "dot") and args.dim % 128 == 0 and args.dim <= 768 and args.k <= 4096
     passes = (args.nq + 63) // 64 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
+    if args.k > 4096:
+        passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
     alg_bytes = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
 
@@ -328,7 +330,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel", "avg_kernel_ms": scan_avg,
+                         "kernel": ("nmn::exact_scan_kernel" if args.k > 4096 else
+                                    "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel"), "avg_kernel_ms": scan_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None},
             "cpu_baseline": cpu,
