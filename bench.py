@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--always-gather", action="store_true",
+                    help="run the RCCL all-gather + device merge even with one rank (measures what the N>1 step adds "
+                         "on a 1-GPU box; the group has one member)")
     ap.add_argument("--batched", type=int, default=64,
                     help="also measure config 3 (this many queries per step on the MFMA sweep) after the main "
                          "measurement and report it under \"batched\" (single-GPU runs only; 0 = skip)")
@@ -212,7 +215,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.always_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -239,7 +244,8 @@ def main():
     q_dev = torch.from_numpy(q_host).to(dev)  # [sets, nq, dim] resident in HBM
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    searchers = [ShardedSearcher(idx, world_size=world, rank=rank, k=args.k, nq=args.nq, device=dev)
+    searchers = [ShardedSearcher(idx, world_size=world, rank=rank, k=args.k, nq=args.nq, device=dev,
+                                 always_gather=args.always_gather)
                  for _ in range(n_streams)]  # one set of result buffers (and one library workspace) per stream
     mask_host = mask_dev = None
     kept_rows = local_rows
@@ -340,7 +346,7 @@ def main():
             "fill_s": t_fill,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.always_gather:
         dist.destroy_process_group()
 
 
