@@ -277,6 +277,32 @@ nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t
                                   nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                   float* out_scores, uint32_t* out_counts, nmn_search_stats* stats);
 
+/* ---- IVF-Flat probe ------------------------------------------------------ */
+
+/* `tensor_store::ivf::IVFIndex` with `IVFStorage::Flat` (tensor_store/src/ivf.rs:160-406), searched on the
+ * GPU.  Training (k-means, ivf.rs:222-233) stays with the caller: the index is created from trained
+ * centroids.  Vectors live in id (insertion) order; ids are the row numbers `add` assigns (ivf.rs:287-289). */
+typedef struct nmn_ivf nmn_ivf;
+/* desc: dim, capacity_rows (vectors that can be added), device; centroids: HOST, n_clusters x dim. */
+nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters, nmn_ivf** out);
+nmn_status nmn_ivf_destroy(nmn_ivf* ivf);
+/* IVFIndex::add for n vectors (HOST, n x dim): each goes to the list of its nearest centroid
+ * (squared Euclidean, first minimum: find_nearest_centroid, ivf.rs:490-497) and gets the next id.
+ * clusters_out (nullable, HOST [n]) receives the chosen clusters. */
+nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t n, uint32_t* clusters_out);
+uint64_t nmn_ivf_len(const nmn_ivf* ivf);       /* IVFIndex::len, ivf.rs:409-415 */
+uint32_t nmn_ivf_clusters(const nmn_ivf* ivf);
+nmn_status nmn_ivf_cluster_sizes(nmn_ivf* ivf, uint64_t* out_sizes /* [n_clusters] */); /* ivf.rs:448-454 */
+/* IVFIndex::search_with_nprobe (ivf.rs:325-406): the nprobe nearest centroids (squared distance,
+ * ascending, ties by index), every vector of their lists scored by Euclidean distance
+ * `squared_euclidean(q, v).sqrt()`, ascending; equal distances in probe order of the cluster, then id.
+ *   queries HOST nq x dim;  out_ids nq x k (unused = UINT64_MAX);  out_distances nq x k (unused = +inf);
+ *   out_counts nq = min(k, vectors in the probed lists).  Synchronous. */
+nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_t nq, uint32_t k, uint32_t nprobe,
+                          uint64_t* out_ids, float* out_distances, uint32_t* out_counts, nmn_search_stats* stats);
+/* The flat index holding the vectors (exhaustive search over the same rows, stats, ...). */
+nmn_index* nmn_ivf_vectors(nmn_ivf* ivf);
+
 /* ---- synthetic data (bench / tests) ------------------------------------------------------- */
 
 /* value(seed,row,col): a counter-based generator that is bit-identical on host and device

@@ -102,6 +102,14 @@ SIGNATURES = {
     "nmn_columns_mask_device": (vp, [vp]),
     "nmn_columns_valid_device": (vp, [vp]),
     "nmn_columns_read_mask": (C.c_int32, [vp, vp, C.c_uint64]),
+    "nmn_ivf_create": (C.c_int32, [C.POINTER(IndexDesc), vp, C.c_uint32, C.POINTER(vp)]),
+    "nmn_ivf_destroy": (C.c_int32, [vp]),
+    "nmn_ivf_add": (C.c_int32, [vp, vp, C.c_uint64, vp]),
+    "nmn_ivf_len": (C.c_uint64, [vp]),
+    "nmn_ivf_clusters": (C.c_uint32, [vp]),
+    "nmn_ivf_cluster_sizes": (C.c_int32, [vp, vp]),
+    "nmn_ivf_search": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(SearchStats)]),
+    "nmn_ivf_vectors": (vp, [vp]),
     "nmn_index_search_dmask": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp,
                                            C.POINTER(SearchStats)]),
 }

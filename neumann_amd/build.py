@@ -26,10 +26,11 @@ SOURCES = {
     "nmn_synth.hip": ["-ffp-contract=off"],
     "nmn_sortk.hip": [],
     "nmn_columns.hip": [],
+    "nmn_ivf.hip": [],
     "nmn_api.hip": [],
     "nmn_engine.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["nmn_internal.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
+HEADERS = ["nmn_internal.h", "nmn_index.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
            os.path.join("..", "..", "include", "neumann_engine.h")]
 
 

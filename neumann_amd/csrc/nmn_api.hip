@@ -13,7 +13,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "nmn_internal.h"
+#include "nmn_index.h"
 
 using namespace nmn;
 
@@ -48,60 +48,6 @@ nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, wh
         hipError_t _e = (expr);                              \
         if (_e != hipSuccess) return fail_hip(_e, #expr);    \
     } while (0)
-
-// ---- workspace: everything one in-flight search on one stream needs ---------------------------
-struct Workspace {
-    hipStream_t stream = nullptr;
-    uint32_t nq_cap = 0;       // queries per pipeline pass the buffers are sized for
-    uint32_t cand_cap = 0;
-    uint64_t score_stride = 0;
-    uint32_t n_tiles_cap = 0;
-    uint32_t ld = 0;
-    uint32_t* scores = nullptr;
-    uint32_t* tmax = nullptr;
-    uint32_t* wmax = nullptr;
-    uint32_t* tsample = nullptr;   // [nq][n_sample_cap] tile maxima of the sampling pass (batched sweep)
-    uint32_t* skip_key = nullptr;  // [nq] score-write threshold of the batched sweep
-    uint64_t n_sample_cap = 0;
-    uint64_t tmax_stride = 0;
-    float* qpad = nullptr;
-    QInfo* qinfo = nullptr;
-    QState* qstate = nullptr;
-    uint32_t* cand_rows = nullptr;
-    float* cand_scores = nullptr;
-    // staging for the host-buffer API
-    float* h_queries = nullptr;  size_t h_queries_cap = 0;   // device copies of host inputs
-    uint64_t* h_mask = nullptr;  size_t h_mask_cap = 0;
-    uint64_t* h_out_rows = nullptr; float* h_out_scores = nullptr; uint32_t* h_out_counts = nullptr;
-    size_t h_out_rows_cap = 0, h_out_scores_cap = 0, h_cnt_cap = 0;
-    uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
-    float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
-    unsigned long long* h_counts2 = nullptr;
-    uint64_t* lk_keys = nullptr; size_t lk_keys_cap = 0;  // composite keys of the large-k path (k > NMN_MAX_TOP_K)
-    // timing + stats of the last search
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool timed = false;
-    uint32_t last_nq = 0;
-    uint64_t last_rows_scanned = 0;
-    bool last_masked = false;
-};
-
-struct nmn_index {
-    uint32_t dim = 0, ld = 0;
-    uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
-    int device = 0;
-    uint32_t cand_cap = kDefaultCandCap;
-    float* corpus = nullptr;
-    float* split = nullptr;      // split-bf16 mirror for the batched (MFMA) sweep; allocated on first use
-    uint64_t split_rows = 0;     // rows [0, split_rows) of `split` are current
-    bool split_failed = false;   // allocation failed once: stay on the VALU sweeps
-    float* norms = nullptr;
-    uint32_t* max_norm_bits = nullptr;
-    hipStream_t host_stream = nullptr;
-    std::mutex mu;       // guards `ws` and the host-buffer API
-    std::unordered_map<hipStream_t, Workspace*> ws;
-    bool timing = false;
-};
 
 static void ws_free(Workspace* w) {
     if (!w) return;
@@ -619,10 +565,11 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
     return stats_collect(idx, it == idx->ws.end() ? nullptr : it->second, stats);
 }
 
-static nmn_status search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
-                                const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
-                                uint32_t* out_counts, nmn_search_stats* stats) {
-    nmn_status st = check_search_args(idx, queries, nq, k, metric, out_rows, out_scores, out_counts);
+nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
+                                    const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
+                                    uint32_t* out_counts, nmn_search_stats* stats) {
+    nmn_status st = check_search_args(idx, queries, nq, k, metric == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : (nmn_metric)metric,
+                                      out_rows, out_scores, out_counts);
     if (st != NMN_OK) return st;
     HIP_TRY(hipSetDevice(idx->device));
     std::lock_guard<std::mutex> g(idx->mu);
@@ -645,7 +592,7 @@ static nmn_status search_hostio(nmn_index* idx, const float* queries, uint32_t n
         HIP_TRY(hipMemcpyAsync(w->h_mask, mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         mask_dev = w->h_mask;
     }
-    st = search_enqueue(idx, w, w->h_queries, nq, k, metric, mask_dev, w->h_out_rows, w->h_out_scores,
+    st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)metric, mask_dev, w->h_out_rows, w->h_out_scores,
                         w->h_out_counts, s);
     if (st != NMN_OK) return st;
     HIP_TRY(hipMemcpyAsync(out_rows, w->h_out_rows, on * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -658,13 +605,13 @@ static nmn_status search_hostio(nmn_index* idx, const float* queries, uint32_t n
 extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
                                        nmn_metric metric, const uint64_t* mask, uint64_t* out_rows,
                                        float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
-    return search_hostio(idx, queries, nq, k, metric, mask, false, out_rows, out_scores, out_counts, stats);
+    return index_search_hostio(idx, queries, nq, k, (int)metric, mask, false, out_rows, out_scores, out_counts, stats);
 }
 
 extern "C" nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
                                              nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                              float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
-    return search_hostio(idx, queries, nq, k, metric, mask_dev, true, out_rows, out_scores, out_counts, stats);
+    return index_search_hostio(idx, queries, nq, k, (int)metric, mask_dev, true, out_rows, out_scores, out_counts, stats);
 }
 
 // ---- exact helpers ------------------------------------------------------------------------------

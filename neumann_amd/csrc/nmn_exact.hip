@@ -66,8 +66,8 @@ __device__ __forceinline__ float dot8_group(const float* __restrict__ a, const f
 // element order by pulling each product from its owner with a shuffle, so the order of the additions is
 // exactly 0,1,2,...,d-1.
 template <int PF>
-__device__ __forceinline__ float euclid_seq(const float* __restrict__ q, const float* __restrict__ v,
-                                            uint32_t dim, uint32_t l) {
+__device__ __forceinline__ float euclid_sumsq_seq(const float* __restrict__ q, const float* __restrict__ v,
+                                                  uint32_t dim, uint32_t l) {
     float s = -0.0f;
     const int base = (int)(threadIdx.x & 63u & ~7u);
     const uint32_t chunks = (dim + 7u) >> 3;
@@ -90,14 +90,21 @@ __device__ __forceinline__ float euclid_seq(const float* __restrict__ q, const f
             }
         }
     }
-    return sqrt_rn(s);
+    return s;
 }
 
 // compute_score (lib.rs:2231-2266) for one (query,row); vmag = stored simd::magnitude(row).
+// The two internal metrics serve the IVF probe (tensor_store/src/ivf.rs:500-508 `squared_euclidean` is the same
+// sequential sum as euclidean_distance's): kMetricNegL2Sq ranks centroids by squared distance (ivf.rs:331-337),
+// kMetricNegL2 ranks list members by `squared_euclidean(..).sqrt()` (ivf.rs:365-369); negated so that
+// "nearest first" is the descending order every later stage works in (negation is exact).
 __device__ __forceinline__ float exact_score(const float* __restrict__ q, const float* __restrict__ v,
                                              uint32_t dim, float qmag, float vmag, int metric, uint32_t l) {
-    if (metric == NMN_METRIC_EUCLIDEAN) {
-        const float dist = euclid_seq<16>(q, v, dim, l);
+    if (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2 || metric == kMetricNegL2Sq) {
+        const float ss = euclid_sumsq_seq<16>(q, v, dim, l);
+        if (metric == kMetricNegL2Sq) return -ss;
+        const float dist = sqrt_rn(ss);
+        if (metric == kMetricNegL2) return -dist;
         return div_rn(1.0f, add_rn(1.0f, dist));
     }
     const float dot = dot8_group<32>(q, v, dim, l);

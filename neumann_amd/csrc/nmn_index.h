@@ -1,0 +1,74 @@
+// nmn_index.h — the shard object behind the opaque `nmn_index` handle and the entry points other
+// translation units of libneumann_gpu.so use (nmn_ivf.hip).  Internal: never installed.
+#pragma once
+#include <mutex>
+#include <unordered_map>
+
+#include "nmn_internal.h"
+
+using nmn::QInfo;
+using nmn::QState;
+using nmn::kDefaultCandCap;
+
+// ---- workspace: everything one in-flight search on one stream needs ---------------------------
+struct Workspace {
+    hipStream_t stream = nullptr;
+    uint32_t nq_cap = 0;       // queries per pipeline pass the buffers are sized for
+    uint32_t cand_cap = 0;
+    uint64_t score_stride = 0;
+    uint32_t n_tiles_cap = 0;
+    uint32_t ld = 0;
+    uint32_t* scores = nullptr;
+    uint32_t* tmax = nullptr;
+    uint32_t* wmax = nullptr;
+    uint32_t* tsample = nullptr;   // [nq][n_sample_cap] tile maxima of the sampling pass (batched sweep)
+    uint32_t* skip_key = nullptr;  // [nq] score-write threshold of the batched sweep
+    uint64_t n_sample_cap = 0;
+    uint64_t tmax_stride = 0;
+    float* qpad = nullptr;
+    QInfo* qinfo = nullptr;
+    QState* qstate = nullptr;
+    uint32_t* cand_rows = nullptr;
+    float* cand_scores = nullptr;
+    // staging for the host-buffer API
+    float* h_queries = nullptr;  size_t h_queries_cap = 0;   // device copies of host inputs
+    uint64_t* h_mask = nullptr;  size_t h_mask_cap = 0;
+    uint64_t* h_out_rows = nullptr; float* h_out_scores = nullptr; uint32_t* h_out_counts = nullptr;
+    size_t h_out_rows_cap = 0, h_out_scores_cap = 0, h_cnt_cap = 0;
+    uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
+    float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
+    unsigned long long* h_counts2 = nullptr;
+    uint64_t* lk_keys = nullptr; size_t lk_keys_cap = 0;  // composite keys of the large-k path (k > NMN_MAX_TOP_K)
+    // timing + stats of the last search
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    uint32_t last_nq = 0;
+    uint64_t last_rows_scanned = 0;
+    bool last_masked = false;
+};
+
+struct nmn_index {
+    uint32_t dim = 0, ld = 0;
+    uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
+    int device = 0;
+    uint32_t cand_cap = kDefaultCandCap;
+    float* corpus = nullptr;
+    float* split = nullptr;      // split-bf16 mirror for the batched (MFMA) sweep; allocated on first use
+    uint64_t split_rows = 0;     // rows [0, split_rows) of `split` are current
+    bool split_failed = false;   // allocation failed once: stay on the VALU sweeps
+    float* norms = nullptr;
+    uint32_t* max_norm_bits = nullptr;
+    hipStream_t host_stream = nullptr;
+    std::mutex mu;       // guards `ws` and the host-buffer API
+    std::unordered_map<hipStream_t, Workspace*> ws;
+    bool timing = false;
+};
+
+namespace nmn {
+
+// nmn_index_search / nmn_index_search_dmask with the internal metrics allowed (host queries and outputs)
+nmn_status index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
+                               const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
+                               uint32_t* out_counts, nmn_search_stats* stats);
+
+}  // namespace nmn

@@ -17,6 +17,10 @@
 
 namespace nmn {
 
+// internal metrics (beyond nmn_metric): both rank "nearest first" as a descending score
+constexpr int kMetricNegL2 = 3;    // score = -sqrt(sum (q_i - v_i)^2), sequential sum (IVF list scan, ivf.rs:365-369)
+constexpr int kMetricNegL2Sq = 4;  // score = -(sum (q_i - v_i)^2); exact kernels only (centroid ranking, ivf.rs:331-337)
+
 constexpr uint32_t kTileRows = 64;        // rows per scan tile (one wave, 16 steps of 4 rows)
 constexpr uint32_t kDefaultCandCap = 4096;
 constexpr uint32_t kMaxScanWaves = 4096;   // scan waves per query sweep (= entries of the wave-max level)

@@ -1,0 +1,331 @@
+// nmn_ivf.hip — IVF-Flat probe on the GPU: `IVFIndex::{add, search_with_nprobe}` of
+// tensor_store/src/ivf.rs:276-406 for `IVFStorage::Flat`, on top of the flat-scan kernels.
+//
+// Layout: the vectors stay in ID (insertion) order in one nmn_index — row == the id `add` returns
+// (ivf.rs:288) — plus `assign[row]`, the cluster of each row.  An inverted list is therefore a set of
+// rows, not a contiguous range: a probe marks the nprobe nearest clusters, one kernel turns
+// `assign` into the selection bitmap (1 bit per row), and the masked scan reads only the selected
+// rows (3 KB contiguous each at d = 768).  `add` is an append, never a list reshuffle.
+//
+// Exactness: every distance the reference computes here is `squared_euclidean` (ivf.rs:500-508), the
+// same strictly sequential f32 sum as the flat Euclidean metric, so the exact kernels restate it
+// bit for bit: centroids are ranked by the squared distance, ascending, ties by centroid index
+// (stable sort of an enumerate, ivf.rs:331-337); list members by `sqrt` of it, ascending; equal
+// distances keep candidate order = probe order of the cluster, then list (= id) order (stable sort,
+// ivf.rs:402).  `add` picks the first nearest centroid (`min_by`, ivf.rs:490-497).
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "nmn_index.h"
+
+using namespace nmn;
+
+namespace {
+
+constexpr uint32_t kNoRank = 0xFFFFFFFFu;
+constexpr uint32_t kAssignChunk = 4096;  // rows assigned per exact sweep over the centroids
+
+// first centroid whose squared distance is minimal, with `min_by`'s fold semantics on NaN
+// (core::iter::Iterator::min_by keeps the earlier element unless the later compares strictly Less):
+// scores are -d^2 in tile-major layout score_at(c, q, nql); one wave per new row.
+__global__ __launch_bounds__(256) void ivf_assign_kernel(const uint32_t* __restrict__ scores, uint32_t n_clusters,
+                                                         uint32_t nql, uint32_t nq, uint32_t* __restrict__ assign_out) {
+    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (q >= nq) return;
+    const float first = u2f(scores[score_at(0, q, nql)]);
+    float best = -__builtin_inff();
+    uint32_t best_c = kNoRank;
+    for (uint32_t c = lane; c < n_clusters; c += 64) {
+        const float s = u2f(scores[score_at(c, q, nql)]);
+        if (s > best || (s == best && c < best_c)) {  // NaN never wins; ties go to the lower index
+            best = s;
+            best_c = c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off);
+        const uint32_t oc = __shfl_down(best_c, off);
+        if (ob > best || (ob == best && oc < best_c)) {
+            best = ob;
+            best_c = oc;
+        }
+    }
+    if (lane == 0) {
+        uint32_t c = best_c;
+        if (first != first || c == kNoRank) c = 0;  // a NaN first element is never displaced; all-NaN keeps 0
+        // -inf everywhere except NaNs: `best_c` may still be kNoRank only when every score is NaN or -inf;
+        // with -inf scores the fold keeps the first element as well
+        assign_out[q] = c;
+    }
+}
+
+__global__ void ivf_probe_rank_kernel(const uint64_t* __restrict__ probe_rows, const uint32_t* __restrict__ probe_count,
+                                      uint32_t* __restrict__ probe_rank) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *probe_count) probe_rank[probe_rows[i]] = i;
+}
+
+__global__ __launch_bounds__(256) void ivf_mask_kernel(const uint32_t* __restrict__ assign,
+                                                       const uint32_t* __restrict__ probe_rank, uint64_t n_rows,
+                                                       uint64_t* __restrict__ mask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_words = (n_rows + 63) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t w = wave; w < n_words; w += n_waves) {
+        const uint64_t row = (w << 6) + lane;
+        const bool in = row < n_rows && probe_rank[assign[row]] != kNoRank;
+        const uint64_t word = __ballot(in);
+        if (lane == 0) mask[w] = word;
+    }
+}
+
+}  // namespace
+
+struct nmn_ivf {
+    nmn_index* vectors = nullptr;
+    nmn_index* centroids = nullptr;
+    uint32_t n_clusters = 0, dim = 0;
+    int device = 0;
+    uint64_t cap = 0;
+    uint32_t* assign = nullptr;          // device [cap]
+    std::vector<uint32_t> assign_host;   // same, for cluster_sizes and the tie order of equal distances
+    hipStream_t stream = nullptr;
+    uint32_t* cscores = nullptr;         // exact -d^2 of a chunk of queries vs every centroid (tile-major)
+    size_t cscores_cap = 0;
+    uint64_t* ckeys = nullptr;           // sort buffer of the centroid ranking
+    uint64_t* probe_rows = nullptr;      // [n_clusters] clusters in probe order
+    float* probe_scores = nullptr;
+    uint32_t* probe_count = nullptr;
+    uint32_t* probe_rank = nullptr;      // [n_clusters] probe rank or kNoRank
+    uint64_t* mask = nullptr;            // [ceil(cap/64)]
+    float* qraw = nullptr;               // one query, dim floats
+    float* qpad = nullptr;               // padded to ld
+    QInfo* qinfo = nullptr;              // [kAssignChunk] (qmag is unused by the L2 metrics)
+    QState* qstate = nullptr;
+    uint32_t* assign_tmp = nullptr;      // [kAssignChunk]
+    uint32_t assign_chunk = kAssignChunk;
+    std::mutex mu;
+};
+
+#define IVF_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return set_error_hip(_e, #expr); \
+    } while (0)
+
+extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
+    if (!ivf) return NMN_OK;
+    (void)hipSetDevice(ivf->device);
+    if (ivf->stream) (void)hipStreamSynchronize(ivf->stream);
+    for (void* p : {(void*)ivf->assign, (void*)ivf->cscores, (void*)ivf->ckeys, (void*)ivf->probe_rows,
+                    (void*)ivf->probe_scores, (void*)ivf->probe_count, (void*)ivf->probe_rank, (void*)ivf->mask,
+                    (void*)ivf->qraw, (void*)ivf->qpad, (void*)ivf->qinfo, (void*)ivf->qstate, (void*)ivf->assign_tmp})
+        if (p) (void)hipFree(p);
+    if (ivf->stream) (void)hipStreamDestroy(ivf->stream);
+    if (ivf->vectors) nmn_index_destroy(ivf->vectors);
+    if (ivf->centroids) nmn_index_destroy(ivf->centroids);
+    delete ivf;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters,
+                                     nmn_ivf** out) {
+    if (!desc || !centroids || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (n_clusters == 0) return set_error(NMN_ERR_INVALID_ARGUMENT, "an IVF index needs at least one centroid");
+    nmn_ivf* ivf = new (std::nothrow) nmn_ivf();
+    if (!ivf) return set_error(NMN_ERR_OUT_OF_MEMORY, "host alloc");
+    auto bail = [&](nmn_status st) {
+        nmn_ivf_destroy(ivf);
+        return st;
+    };
+    nmn_status st = nmn_index_create(desc, &ivf->vectors);
+    if (st != NMN_OK) return bail(st);
+    nmn_index_desc cd = *desc;
+    cd.capacity_rows = n_clusters;
+    cd.row_base = 0;
+    cd.device = ivf->vectors->device;
+    st = nmn_index_create(&cd, &ivf->centroids);
+    if (st != NMN_OK) return bail(st);
+    st = nmn_index_upload(ivf->centroids, centroids, 0, n_clusters);
+    if (st != NMN_OK) return bail(st);
+    ivf->n_clusters = n_clusters;
+    ivf->dim = desc->dim;
+    ivf->device = ivf->vectors->device;
+    ivf->cap = ivf->vectors->cap;
+    const uint32_t ld = ivf->vectors->ld;
+    const size_t c_pad = ivf->centroids->cap_pad;
+    hipError_t e = hipSetDevice(ivf->device);
+    auto alloc = [&](void** p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 64));
+    };
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ivf->stream, hipStreamNonBlocking);
+    alloc(reinterpret_cast<void**>(&ivf->assign), std::max<uint64_t>(ivf->cap, 1) * 4);
+    // rows assigned per sweep: bound the score matrix to 64 MiB whatever the number of clusters
+    ivf->assign_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kAssignChunk, (16ull << 20) / c_pad));
+    ivf->cscores_cap = c_pad * ivf->assign_chunk;
+    alloc(reinterpret_cast<void**>(&ivf->cscores), ivf->cscores_cap * 4);
+    alloc(reinterpret_cast<void**>(&ivf->ckeys), largek_sort_len(n_clusters) * 8);
+    alloc(reinterpret_cast<void**>(&ivf->probe_rows), (size_t)n_clusters * 8);
+    alloc(reinterpret_cast<void**>(&ivf->probe_scores), (size_t)n_clusters * 4);
+    alloc(reinterpret_cast<void**>(&ivf->probe_count), 4);
+    alloc(reinterpret_cast<void**>(&ivf->probe_rank), (size_t)n_clusters * 4);
+    alloc(reinterpret_cast<void**>(&ivf->mask), ((ivf->cap + 63) / 64 + 1) * 8);
+    alloc(reinterpret_cast<void**>(&ivf->qraw), (size_t)desc->dim * 4);
+    alloc(reinterpret_cast<void**>(&ivf->qpad), (size_t)ld * 4);
+    alloc(reinterpret_cast<void**>(&ivf->qinfo), sizeof(QInfo) * kAssignChunk);
+    alloc(reinterpret_cast<void**>(&ivf->qstate), sizeof(QState) * kAssignChunk);
+    alloc(reinterpret_cast<void**>(&ivf->assign_tmp), 4 * kAssignChunk);
+    if (e == hipSuccess) e = hipMemsetAsync(ivf->qinfo, 0, sizeof(QInfo) * kAssignChunk, ivf->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ivf->stream);
+    if (e != hipSuccess) return bail(set_error_hip(e, "nmn_ivf_create"));
+    *out = ivf;
+    return NMN_OK;
+}
+
+extern "C" uint64_t nmn_ivf_len(const nmn_ivf* ivf) { return ivf ? ivf->vectors->rows : 0; }
+extern "C" uint32_t nmn_ivf_clusters(const nmn_ivf* ivf) { return ivf ? ivf->n_clusters : 0; }
+extern "C" nmn_index* nmn_ivf_vectors(nmn_ivf* ivf) { return ivf ? ivf->vectors : nullptr; }
+
+extern "C" nmn_status nmn_ivf_cluster_sizes(nmn_ivf* ivf, uint64_t* out_sizes) {
+    if (!ivf || !out_sizes) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ivf->mu);
+    std::fill(out_sizes, out_sizes + ivf->n_clusters, 0ull);
+    for (uint32_t c : ivf->assign_host) out_sizes[c]++;
+    return NMN_OK;
+}
+
+// exact -d^2 of `nq` queries (already padded to ld in device memory) against every centroid -> cscores
+static nmn_status centroid_scores(nmn_ivf* ivf, const float* qpad_dev, uint32_t nq) {
+    ExactScanParams ep{};
+    ep.corpus = ivf->centroids->corpus;
+    ep.norms = ivf->centroids->norms;
+    ep.qpad = qpad_dev;
+    ep.qinfo = ivf->qinfo;
+    ep.qstate = nullptr;
+    ep.mask = nullptr;
+    ep.scores = ivf->cscores;
+    ep.n_rows = ivf->n_clusters;
+    ep.nql = nq;
+    ep.ld = ivf->centroids->ld;
+    ep.dim = ivf->dim;
+    ep.nq = nq;
+    ep.metric = kMetricNegL2Sq;
+    IVF_TRY(launch_exact_scan(ep, ivf->stream));
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t n, uint32_t* clusters_out) {
+    if (!ivf || (n && !rows_host)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return NMN_OK;
+    std::lock_guard<std::mutex> g(ivf->mu);
+    const uint64_t row0 = ivf->vectors->rows;
+    nmn_status st = nmn_index_upload(ivf->vectors, rows_host, row0, n);  // ids = insertion order (ivf.rs:287-289)
+    if (st != NMN_OK) return st;
+    IVF_TRY(hipSetDevice(ivf->device));
+    IVF_TRY(hipStreamSynchronize(ivf->vectors->host_stream));  // rows are in place before another stream reads them
+    const uint32_t ld = ivf->vectors->ld;
+    ivf->assign_host.resize(row0 + n);
+    for (uint64_t off = 0; off < n; off += ivf->assign_chunk) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(ivf->assign_chunk, n - off);
+        // the new rows are laid out exactly like padded queries: score them against the centroids in place
+        st = centroid_scores(ivf, ivf->vectors->corpus + (row0 + off) * (uint64_t)ld, cnt);
+        if (st != NMN_OK) return st;
+        hipLaunchKernelGGL(ivf_assign_kernel, dim3((cnt * 64 + 255) / 256), dim3(256), 0, ivf->stream, ivf->cscores,
+                           ivf->n_clusters, cnt, cnt, ivf->assign + row0 + off);
+        IVF_TRY(hipGetLastError());
+        IVF_TRY(hipMemcpyAsync(ivf->assign_host.data() + row0 + off, ivf->assign + row0 + off, (size_t)cnt * 4,
+                               hipMemcpyDeviceToHost, ivf->stream));
+    }
+    IVF_TRY(hipStreamSynchronize(ivf->stream));
+    if (clusters_out) memcpy(clusters_out, ivf->assign_host.data() + row0, n * 4);
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_t nq, uint32_t k, uint32_t nprobe,
+                                     uint64_t* out_ids, float* out_distances, uint32_t* out_counts,
+                                     nmn_search_stats* stats) {
+    if (!ivf || !queries || !out_ids || !out_distances || !out_counts)
+        return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (k == 0) return set_error(NMN_ERR_INVALID_TOP_K, "k == 0");
+    if (nq == 0) return NMN_OK;
+    std::lock_guard<std::mutex> g(ivf->mu);
+    IVF_TRY(hipSetDevice(ivf->device));
+    const uint64_t n_rows = ivf->vectors->rows;
+    const uint32_t np = std::min<uint32_t>(nprobe, ivf->n_clusters);  // ivf.rs:339
+    hipStream_t s = ivf->stream;
+    std::vector<uint64_t> probe_host(np);
+    std::vector<uint32_t> rank_host;
+    std::vector<uint64_t> tmp_ids;
+    std::vector<float> tmp_dist;
+    for (uint32_t q = 0; q < nq; q++) {
+        uint64_t* o_ids = out_ids + (size_t)q * k;
+        float* o_dist = out_distances + (size_t)q * k;
+        std::fill(o_ids, o_ids + k, UINT64_MAX);
+        std::fill(o_dist, o_dist + k, __builtin_inff());
+        out_counts[q] = 0;
+        if (n_rows == 0 || np == 0) continue;
+        // 1. rank the centroids by squared distance (ascending; ties by index) and keep the first nprobe
+        IVF_TRY(hipMemcpyAsync(ivf->qraw, queries + (size_t)q * ivf->dim, (size_t)ivf->dim * 4, hipMemcpyHostToDevice, s));
+        IVF_TRY(launch_qprep(ivf->qraw, 1, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits,
+                             ivf->qpad, ivf->qinfo, ivf->qstate, 0, s));
+        nmn_status st = centroid_scores(ivf, ivf->qpad, 1);
+        if (st != NMN_OK) return st;
+        IVF_TRY(launch_largek(ivf->cscores, ivf->n_clusters, ivf->ckeys, np, 0, ivf->probe_rows, ivf->probe_scores,
+                              ivf->probe_count, s));
+        // 2. clusters -> probe rank -> selection bitmap over the rows
+        IVF_TRY(hipMemsetAsync(ivf->probe_rank, 0xFF, (size_t)ivf->n_clusters * 4, s));
+        hipLaunchKernelGGL(ivf_probe_rank_kernel, dim3((np + 255) / 256), dim3(256), 0, s, ivf->probe_rows,
+                           ivf->probe_count, ivf->probe_rank);
+        const uint64_t n_words = (n_rows + 63) / 64;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
+        hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, ivf->probe_rank, n_rows, ivf->mask);
+        IVF_TRY(hipGetLastError());
+        IVF_TRY(hipMemcpyAsync(probe_host.data(), ivf->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost, s));
+        IVF_TRY(hipStreamSynchronize(s));
+        // 3. masked scan ranking by distance (negated so that nearest = largest).  One result more than asked
+        //    for: the scan breaks equal distances by id, the reference by candidate order, so a run of equal
+        //    distances that straddles the cut must be seen whole before it is reordered and cut.
+        uint64_t kk = std::min<uint64_t>((uint64_t)k + 1, std::max<uint64_t>(n_rows, 1));
+        uint32_t cnt = 0;
+        for (;;) {
+            tmp_ids.resize(kk);
+            tmp_dist.resize(kk);
+            st = index_search_hostio(ivf->vectors, queries + (size_t)q * ivf->dim, 1, (uint32_t)kk, kMetricNegL2, ivf->mask,
+                                     true, tmp_ids.data(), tmp_dist.data(), &cnt, q + 1 == nq ? stats : nullptr);
+            if (st != NMN_OK) return st;
+            const bool cut_inside_run = cnt > k && tmp_dist[k] == tmp_dist[k - 1];
+            if (!cut_inside_run || cnt < kk || kk >= n_rows) break;  // run seen whole, or nothing more to fetch
+            kk = std::min<uint64_t>(kk * 2, n_rows);
+        }
+        for (uint32_t i = 0; i < cnt; i++) tmp_dist[i] = -tmp_dist[i];
+        // 4. equal distances keep candidate order: probe order of the cluster, then id (stable sort, ivf.rs:402)
+        bool any_tie = false;
+        for (uint32_t i = 1; i < cnt && !any_tie; i++) any_tie = tmp_dist[i] == tmp_dist[i - 1];
+        if (any_tie) {
+            rank_host.assign(ivf->n_clusters, kNoRank);
+            for (uint32_t i = 0; i < np; i++) rank_host[probe_host[i]] = i;
+            const uint64_t base = ivf->vectors->row_base;
+            for (uint32_t a = 0; a < cnt;) {
+                uint32_t b = a + 1;
+                while (b < cnt && tmp_dist[b] == tmp_dist[a]) b++;
+                if (b - a > 1)
+                    std::sort(tmp_ids.begin() + a, tmp_ids.begin() + b, [&](uint64_t x, uint64_t y) {
+                        const uint32_t rx = rank_host[ivf->assign_host[x - base]], ry = rank_host[ivf->assign_host[y - base]];
+                        return rx != ry ? rx < ry : x < y;
+                    });
+                a = b;
+            }
+        }
+        const uint32_t keep = std::min<uint32_t>(cnt, k);
+        std::copy(tmp_ids.begin(), tmp_ids.begin() + keep, o_ids);
+        std::copy(tmp_dist.begin(), tmp_dist.begin() + keep, o_dist);
+        out_counts[q] = keep;
+    }
+    return NMN_OK;
+}

@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
             if constexpr (METRIC == NMN_METRIC_COSINE) {
                 sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : mydot[q] / (qmag[q] * vn);
             } else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
-                sc = 1.0f / (1.0f + sqrtf(fmaxf(mydot[q], 0.f)));
+                const float dist = sqrtf(fmaxf(mydot[q], 0.f));
+                sc = p.metric == kMetricNegL2 ? -dist : 1.0f / (1.0f + dist);  // IVF probe ranks by distance
             } else {
                 sc = mydot[q];
             }
@@ -233,7 +234,8 @@ hipError_t launch_scan(const ScanParams& p, hipStream_t s) {
     const bool nt = scan_nt_enabled();
     switch (p.metric) {
         case NMN_METRIC_COSINE: return launch_mask<NMN_METRIC_COSINE>(p, s, nt);
-        case NMN_METRIC_EUCLIDEAN: return launch_mask<NMN_METRIC_EUCLIDEAN>(p, s, nt);
+        case NMN_METRIC_EUCLIDEAN:
+        case kMetricNegL2: return launch_mask<NMN_METRIC_EUCLIDEAN>(p, s, nt);  // same sweep, epilogue picks -d over 1/(1+d)
         default: return launch_mask<NMN_METRIC_DOT_PRODUCT>(p, s, nt);
     }
 }

@@ -1,0 +1,77 @@
+"""IVF-Flat probe on the GPU — host wrapper of `nmn_ivf_*` (include/neumann_gpu.h).
+
+Mirrors `tensor_store::ivf::IVFIndex` with `IVFStorage::Flat` (tensor_store/src/ivf.rs:160-406) for
+the parts on the SIMILAR path: `add` (nearest-centroid assignment) and `search` / `search_with_nprobe`.
+Training is the caller's (the engine ports the reference's k-means, neumann_amd/csrc/nmn_engine.cpp);
+the index is created from trained centroids."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class GpuIvfFlat:
+    def __init__(self, centroids, capacity_rows, nprobe=None, device=-1):
+        self._lib = _capi.load()
+        c = np.ascontiguousarray(centroids, dtype=np.float32)
+        assert c.ndim == 2 and c.shape[0] >= 1
+        self.n_clusters, self.dim = int(c.shape[0]), int(c.shape[1])
+        # default_nprobe (ivf.rs:46-56): ceil(sqrt(num_clusters)) computed in f32
+        self.nprobe = int(np.ceil(np.sqrt(np.float32(self.n_clusters)))) if nprobe is None else int(nprobe)
+        desc = _capi.IndexDesc(dim=self.dim, flags=0, capacity_rows=int(capacity_rows), row_base=0, device=int(device),
+                               cand_cap=0)
+        h = C.c_void_p()
+        _capi.check(self._lib.nmn_ivf_create(C.byref(desc), C.c_void_p(c.ctypes.data), self.n_clusters, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.nmn_ivf_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.nmn_ivf_len(self._h))
+
+    def add(self, rows):
+        """IVFIndex::add for each row; returns the clusters chosen (ids are len-before .. len-after - 1)."""
+        r = np.ascontiguousarray(rows, dtype=np.float32)
+        if r.ndim == 1:
+            r = r[None, :]
+        assert r.shape[1] == self.dim
+        out = np.empty(r.shape[0], dtype=np.uint32)
+        _capi.check(self._lib.nmn_ivf_add(self._h, C.c_void_p(r.ctypes.data), r.shape[0], C.c_void_p(out.ctypes.data)))
+        return out
+
+    def cluster_sizes(self):
+        out = np.zeros(self.n_clusters, dtype=np.uint64)
+        _capi.check(self._lib.nmn_ivf_cluster_sizes(self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def search(self, queries, k, nprobe=None):
+        """-> (ids u64 [nq,k], distances f32 [nq,k], counts u32 [nq]); IVFIndex::search_with_nprobe."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        assert q.shape[1] == self.dim
+        nq, k = q.shape[0], int(k)
+        ids = np.empty((nq, max(k, 1)), dtype=np.uint64)
+        dist = np.empty((nq, max(k, 1)), dtype=np.float32)
+        counts = np.empty(nq, dtype=np.uint32)
+        _capi.check(self._lib.nmn_ivf_search(self._h, C.c_void_p(q.ctypes.data), nq, k,
+                                             self.nprobe if nprobe is None else int(nprobe),
+                                             C.c_void_p(ids.ctypes.data), C.c_void_p(dist.ctypes.data),
+                                             C.c_void_p(counts.ctypes.data), None))
+        return ids, dist, counts

@@ -1,0 +1,118 @@
+"""IVF-Flat probe on the GPU against oracle/ivf_oracle.py, the restatement of
+tensor_store/src/ivf.rs: identical cluster assignments, identical ids in identical order, bit-equal
+distances; plus the reference's own IVF property tests (ivf.rs:656-770) on the GPU index."""
+import numpy as np
+import pytest
+
+from oracle import ivf_oracle as io
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def create_test_vectors(n, dim):  # ivf.rs:569-577
+    return np.array([[((i * 7 + j * 13) % 100) / 100.0 for j in range(dim)] for i in range(n)], dtype=F)
+
+
+FAST = dict(max_iterations=2, convergence_threshold=1.0, seed=42, init_method="random")  # ivf.rs:589-596
+
+
+def build_pair(vectors, num_clusters, nprobe=None, kmeans=None, train=None):
+    """Oracle index trained on `train` (default: the vectors) and a GPU index created from ITS centroids."""
+    from neumann_amd.ivf import GpuIvfFlat
+    orc = io.IVFFlat(num_clusters, nprobe=nprobe, kmeans=io.KMeansConfig(**(kmeans or FAST)))
+    orc.train(vectors if train is None else train)
+    gpu = GpuIvfFlat(orc.centroids, capacity_rows=len(vectors) + 64, nprobe=orc.nprobe)
+    return orc, gpu
+
+
+def check_same(orc, gpu, q, k, nprobe=None):
+    ids, dist, counts = gpu.search(q, k, nprobe)
+    eids, ed = orc.search(q, k, nprobe)
+    assert counts[0] == len(eids)
+    assert ids[0, :len(eids)].tolist() == eids
+    assert np.array_equal(dist[0, :len(eids)], ed)
+    assert np.all(ids[0, len(eids):] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isposinf(dist[0, len(eids):]))
+
+
+def test_reference_property_tests():  # ivf.rs:656-770
+    V = create_test_vectors(20, 16)
+    orc, gpu = build_pair(V, 4, nprobe=2)
+    with gpu:
+        clusters = gpu.add(V)
+        for v in V:
+            orc.add(v)
+        assert len(gpu) == 20 and int(gpu.cluster_sizes().sum()) == 20           # ivf_add_assigns_correct_cluster
+        assert clusters.tolist() == orc.assign and gpu.cluster_sizes().tolist() == orc.cluster_sizes()
+        ids, dist, counts = gpu.search(V[0], 5)                                     # ivf_search_basic
+        assert 0 < counts[0] <= 5 and np.all(np.diff(dist[0, :counts[0]]) >= 0)
+        assert ids[0, 0] == 0 and dist[0, 0] == 0.0
+        check_same(orc, gpu, V[0], 5)
+    V = create_test_vectors(40, 16)                                                 # ivf_search_nprobe_effect
+    orc, gpu = build_pair(V, 8)
+    with gpu:
+        gpu.add(V)
+        for v in V:
+            orc.add(v)
+        r1 = gpu.search(V[0], 5, 1)
+        r8 = gpu.search(V[0], 5, 8)
+        assert r8[1][0, 0] <= r1[1][0, 0] + 0.001 and gpu.search(V[0], 5, 4)[2][0] > 0
+        for nprobe in (1, 2, 4, 8, 100):
+            check_same(orc, gpu, V[3], 5, nprobe)
+
+
+@pytest.mark.parametrize("n,d,c,nprobe", [(3000, 32, 16, None), (5000, 96, 50, 7), (2000, 17, 9, 3)])
+def test_ivf_matches_oracle_on_random_data(n, d, c, nprobe):
+    rng = np.random.default_rng(n + d)
+    V = rng.standard_normal((n, d)).astype(F)
+    V[11] = V[5]                      # duplicates: same list, id order
+    V[n - 1] = V[5]
+    orc, gpu = build_pair(V, c, nprobe=nprobe, kmeans=dict(max_iterations=5, convergence_threshold=1e-4, seed=7,
+                                                           init_method="kmeans++"), train=V[:600])
+    with gpu:
+        # added in several calls: ids keep counting, assignments do not depend on the batching
+        got = np.concatenate([gpu.add(V[:1000]), gpu.add(V[1000:1001]), gpu.add(V[1001:])])
+        for v in V:
+            orc.add(v)
+        assert got.tolist() == orc.assign
+        assert gpu.cluster_sizes().tolist() == orc.cluster_sizes()
+        Q = rng.standard_normal((4, d)).astype(F)
+        for q in list(Q) + [V[5], V[123]]:
+            for k in (1, 10, 200):
+                check_same(orc, gpu, q, k)
+            check_same(orc, gpu, q, 50, nprobe=1)
+            check_same(orc, gpu, q, 5000, nprobe=c)       # every list probed, k beyond the candidate pipeline
+        # multi-query call = the single-query calls
+        ids, dist, counts = gpu.search(Q, 10)
+        for i in range(4):
+            eids, ed = orc.search(Q[i], 10)
+            assert ids[i].tolist() == eids and np.array_equal(dist[i], ed)
+
+
+def test_ivf_equal_distances_keep_probe_order():
+    """Vectors at exactly the same distance in DIFFERENT lists come back in probe order of their lists
+    (stable sort of the candidate list, ivf.rs:402), not in id order."""
+    from neumann_amd.ivf import GpuIvfFlat
+    cents = np.array([[10.0, 0.0], [-10.0, 0.0], [0.0, 10.0]], dtype=F)
+    orc = io.IVFFlat(3, nprobe=3)
+    orc.centroids = cents
+    orc.lists = [[], [], []]
+    V = np.array([[-9.0, 0.0],    # id 0, list 1, distance 9 from the query
+                  [9.0, 0.0],     # id 1, list 0, distance 9
+                  [0.0, 9.0],     # id 2, list 2, distance 9
+                  [9.0, 0.0],     # id 3, list 0, distance 9 (duplicate of id 1)
+                  [5.0, 0.0]], dtype=F)
+    q = np.array([0.0, 0.0], dtype=F) + np.array([1e-3, 0.0], dtype=F) * 0  # origin
+    q = np.array([0.5, 0.0], dtype=F)   # nearest centroid order: 0 (9.5^2), 2, 1
+    V[0] = [-8.0, 0.0]                  # distance 8.5
+    V[1] = [9.0, 0.0]                   # distance 8.5
+    V[2] = [0.5, 8.5]                   # distance 8.5
+    V[3] = [9.0, 0.0]                   # distance 8.5
+    with GpuIvfFlat(cents, capacity_rows=16, nprobe=3) as gpu:
+        gpu.add(V)
+        for v in V:
+            orc.add(v)
+        eids, ed = orc.search(q, 5)
+        assert eids == [4, 1, 3, 2, 0]          # list 0 first (ids 1, 3), then list 2, then list 1
+        check_same(orc, gpu, q, 5)
+        check_same(orc, gpu, q, 3)
