@@ -155,6 +155,32 @@ nmn_filter* nmn_filter_contains(const char* field, const char* substr);
 nmn_filter* nmn_filter_starts_with(const char* field, const char* prefix);
 nmn_filter* nmn_filter_in(const char* field, const nmn_value* values, uint32_t n);
 void nmn_filter_free(nmn_filter* f);
+/* ---- IVF-Flat (lib.rs:2641-2812; tensor_store/src/ivf.rs) ---------------------------------------- */
+#define NMN_KMEANS_INIT_RANDOM 0   /* KMeansInit::Random          (delta_vector.rs:781-800) */
+#define NMN_KMEANS_INIT_PLUSPLUS 1 /* KMeansInit::KMeansPlusPlus  (delta_vector.rs:805-853) */
+typedef struct nmn_ivf_options {   /* IVFBuildOptions / IVFConfig (Flat storage) + KMeansConfig */
+    uint64_t num_clusters;         /* 100 */
+    uint64_t nprobe;               /* 0 = default_nprobe(num_clusters) = ceil(sqrt(num_clusters)) */
+    uint64_t max_iterations;       /* 100 */
+    float convergence_threshold;   /* 1e-4 */
+    uint64_t seed;                 /* 42 */
+    int32_t init_method;           /* NMN_KMEANS_INIT_PLUSPLUS */
+} nmn_ivf_options;
+typedef struct nmn_engine_ivf nmn_engine_ivf; /* (IVFIndex, Vec<String> key_mapping) */
+void nmn_ivf_options_default(nmn_ivf_options* o);
+/* build_ivf_index (lib.rs:2641-2694): k-means on the host in the reference's operation order, lists on the GPU */
+nmn_status nmn_engine_build_ivf_index(nmn_engine* e, const nmn_ivf_options* options, nmn_engine_ivf** out);
+void nmn_engine_ivf_free(nmn_engine_ivf* ivf);
+uint64_t nmn_engine_ivf_len(const nmn_engine_ivf* ivf);
+uint32_t nmn_engine_ivf_clusters(const nmn_engine_ivf* ivf);
+uint64_t nmn_engine_ivf_nprobe(const nmn_engine_ivf* ivf);
+const char* nmn_engine_ivf_key(const nmn_engine_ivf* ivf, uint64_t id);
+nmn_status nmn_engine_ivf_centroids(const nmn_engine_ivf* ivf, float* out, uint64_t cap_floats);
+nmn_status nmn_engine_ivf_cluster_sizes(nmn_engine_ivf* ivf, uint64_t* out);
+/* search_with_ivf (nprobe = 0) / search_with_ivf_nprobe (lib.rs:2708-2812): score = 1 / (1 + distance) */
+nmn_status nmn_engine_search_with_ivf(nmn_engine* e, nmn_engine_ivf* ivf, const float* q, uint64_t dim, uint64_t top_k,
+                                      uint64_t nprobe, nmn_results** out);
+
 /* ---- unified entity mode (lib.rs:3060-3237): vectors in the `_embedding` field of entity keys ---- */
 nmn_status nmn_engine_set_entity_embedding(nmn_engine* e, const char* entity_key, const float* v, uint64_t dim);
 nmn_status nmn_engine_get_entity_embedding(nmn_engine* e, const char* entity_key, float* out, uint64_t cap,

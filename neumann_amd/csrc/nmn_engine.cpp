@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -106,6 +107,17 @@ struct nmn_results {
 };
 struct nmn_strlist {
     std::vector<std::string> items;
+};
+// (IVFIndex, Vec<String>) as build_ivf_index returns it (lib.rs:2641-2694): the GPU index + id -> key mapping
+struct nmn_engine_ivf {
+    nmn_ivf* index = nullptr;           // null = untrained (built from an empty store)
+    std::vector<std::string> keys;      // key_mapping: id -> key
+    std::vector<float> centroids;
+    uint32_t n_clusters = 0;
+    uint64_t dim = 0, nprobe = 0;
+    ~nmn_engine_ivf() {
+        if (index) nmn_ivf_destroy(index);
+    }
 };
 
 namespace {
@@ -283,6 +295,130 @@ Mirror* mirror_of(Collection* c, uint64_t dim) {
     }
     return it->second.get();
 }
+
+// ---- IVF-Flat index built from the store (lib.rs:2641-2694) ------------------------------------------
+// KMeans::fit (tensor_store/src/delta_vector.rs:737-777) restated on the host in the reference's own
+// operation order — training is not on the SIMILAR path and its result (the centroids) must be the
+// reference's bit for bit, or every list assignment downstream differs.  This file is compiled with
+// -ffp-contract=off.
+namespace kmeans {
+
+inline uint64_t lcg(uint64_t s) { return s * 6364136223846793005ull + 1ull; }  // wrapping_mul + wrapping_add
+
+// euclidean_distance_sq (delta_vector.rs:896-901): strictly sequential f32 sum, `.sum()` folds from -0.0
+float dist_sq(const float* a, const float* b, uint64_t dim) {
+    float s = -0.0f;
+    for (uint64_t i = 0; i < dim; i++) {
+        const float d = a[i] - b[i];
+        const float p = d * d;
+        s = s + p;
+    }
+    return s;
+}
+
+// nearest_centroid (856-863): min_by keeps the earlier element unless the later one is strictly less
+uint32_t nearest(const float* v, const std::vector<float>& cents, uint32_t k, uint64_t dim) {
+    uint32_t best = 0;
+    float best_d = dist_sq(v, cents.data(), dim);
+    for (uint32_t c = 1; c < k; c++) {
+        const float d = dist_sq(v, cents.data() + (size_t)c * dim, dim);
+        if (d < best_d) {
+            best = c;
+            best_d = d;
+        }
+    }
+    return best;
+}
+
+std::vector<float> init_random(const float* rows, uint64_t n, uint64_t dim, uint32_t k, uint64_t seed) {  // 781-800
+    std::vector<uint64_t> idx(n);
+    for (uint64_t i = 0; i < n; i++) idx[i] = i;
+    uint64_t state = seed;
+    for (uint64_t i = n - 1; i >= 1; i--) {
+        state = lcg(state);
+        std::swap(idx[i], idx[state % (i + 1)]);
+    }
+    std::vector<float> c((size_t)k * dim);
+    for (uint32_t j = 0; j < k; j++) memcpy(c.data() + (size_t)j * dim, rows + idx[j] * dim, dim * sizeof(float));
+    return c;
+}
+
+std::vector<float> init_plusplus(const float* rows, uint64_t n, uint64_t dim, uint32_t k, uint64_t seed) {  // 805-853
+    std::vector<float> c;
+    c.reserve((size_t)k * dim);
+    uint64_t state = lcg(seed);
+    const float* first = rows + (state % n) * dim;
+    c.insert(c.end(), first, first + dim);
+    std::vector<float> dist(n, std::numeric_limits<float>::max());
+    for (uint32_t j = 1; j < k; j++) {
+        const float* last = c.data() + (size_t)(j - 1) * dim;
+        for (uint64_t i = 0; i < n; i++) dist[i] = std::fmin(dist[i], dist_sq(rows + i * dim, last, dim));  // f32::min
+        float total = -0.0f;
+        for (uint64_t i = 0; i < n; i++) total = total + dist[i];
+        state = lcg(state);
+        uint64_t pick;
+        if (total == 0.0f) {
+            pick = state % n;
+        } else {
+            const float frac = (float)state / (float)UINT64_MAX;  // `rng_state as f32 / u64::MAX as f32`
+            const float threshold = frac * total;
+            float cumulative = 0.0f;
+            pick = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                cumulative = cumulative + dist[i];
+                if (cumulative >= threshold) {
+                    pick = i;
+                    break;
+                }
+            }
+        }
+        const float* src = rows + pick * dim;
+        c.insert(c.end(), src, src + dim);
+    }
+    return c;
+}
+
+// KMeans::fit; rows is n x dim row-major.  Returns k' = min(k, n) centroids.
+std::vector<float> fit(const float* rows, uint64_t n, uint64_t dim, uint64_t k_in, const nmn_ivf_options& o,
+                       uint32_t* k_out) {
+    *k_out = 0;
+    if (n == 0 || k_in == 0) return {};
+    const uint32_t k = (uint32_t)std::min<uint64_t>(k_in, n);
+    *k_out = k;
+    std::vector<float> cents = o.init_method == NMN_KMEANS_INIT_RANDOM ? init_random(rows, n, dim, k, o.seed)
+                                                                       : init_plusplus(rows, n, dim, k, o.seed);
+    std::vector<uint32_t> assign(n, 0);
+    std::vector<float> sums((size_t)k * dim);
+    std::vector<uint64_t> counts(k);
+    for (uint64_t it = 0; it < o.max_iterations; it++) {
+        for (uint64_t i = 0; i < n; i++) assign[i] = nearest(rows + i * dim, cents, k, dim);
+        // update_centroids (867-893): sequential f32 sums in vector order, then sum / count as f32
+        std::fill(sums.begin(), sums.end(), 0.0f);
+        std::fill(counts.begin(), counts.end(), 0ull);
+        for (uint64_t i = 0; i < n; i++) {
+            float* sm = sums.data() + (size_t)assign[i] * dim;
+            const float* v = rows + i * dim;
+            counts[assign[i]]++;
+            for (uint64_t j = 0; j < dim; j++) sm[j] = sm[j] + v[j];
+        }
+        for (uint32_t c = 0; c < k; c++) {
+            float* sm = sums.data() + (size_t)c * dim;
+            if (counts[c] == 0) std::fill(sm, sm + dim, 0.0f);
+            else {
+                const float cnt = (float)counts[c];
+                for (uint64_t j = 0; j < dim; j++) sm[j] = sm[j] / cnt;
+            }
+        }
+        float movement = 0.0f;  // fold(0.0f32, f32::max)
+        for (uint32_t c = 0; c < k; c++)
+            movement = std::fmax(movement, std::sqrt(dist_sq(cents.data() + (size_t)c * dim, sums.data() + (size_t)c * dim, dim)));
+        cents.swap(sums);
+        if (movement < o.convergence_threshold) break;
+    }
+    return cents;
+}
+
+}  // namespace kmeans
 
 // ---- metadata columns of a mirror -------------------------------------------------------------------
 // ScalarValue -> (kind, payload) cell; strings get (or take) an id in the field's dictionary
@@ -892,6 +1028,123 @@ nmn_status nmn_engine_search_similar(nmn_engine* e, const float* q, uint64_t dim
         if (st != NMN_OK) {
             delete res;
             return st;
+        }
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+// ---- IVF (lib.rs:2641-2812) --------------------------------------------------------------------------
+void nmn_ivf_options_default(nmn_ivf_options* o) {  // IVFConfig::default + KMeansConfig::default
+    if (!o) return;
+    o->num_clusters = 100;
+    o->nprobe = 0;  // default_nprobe(num_clusters) = ceil(sqrt(num_clusters)), ivf.rs:46-56
+    o->max_iterations = 100;
+    o->convergence_threshold = 1e-4f;
+    o->seed = 42;
+    o->init_method = NMN_KMEANS_INIT_PLUSPLUS;
+}
+
+nmn_status nmn_engine_build_ivf_index(nmn_engine* e, const nmn_ivf_options* options, nmn_engine_ivf** out) {
+    if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    nmn_ivf_options o;
+    if (options) o = *options;
+    else nmn_ivf_options_default(&o);
+    auto res = std::unique_ptr<nmn_engine_ivf>(new (std::nothrow) nmn_engine_ivf());
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "ivf alloc");
+    res->nprobe = o.nprobe ? o.nprobe : (uint64_t)std::ceil(std::sqrt((float)o.num_clusters));
+    std::lock_guard<std::mutex> g(e->mu);
+    // `let keys = self.list_keys()` then every vector in that order; one dimension only (lib.rs:2653-2668)
+    std::vector<float> rows;
+    uint64_t dim = 0;
+    for (const auto& ent : e->dflt.slots) {
+        if (!ent.live) continue;
+        if (dim == 0) dim = ent.vec.size();
+        else if (ent.vec.size() != dim) return err_dim(dim, ent.vec.size());
+        res->keys.push_back(ent.key);
+        rows.insert(rows.end(), ent.vec.begin(), ent.vec.end());
+    }
+    const uint64_t n = res->keys.size();
+    if (n == 0) {  // `return Ok((IVFIndex::new(options.config), Vec::new()))`: untrained, searches find nothing
+        *out = res.release();
+        return NMN_OK;
+    }
+    if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);  // lib.rs:2671-2680
+    res->dim = dim;
+    res->centroids = kmeans::fit(rows.data(), n, dim, o.num_clusters, o, &res->n_clusters);  // index.train
+    if (res->n_clusters == 0) {
+        *out = res.release();
+        return NMN_OK;
+    }
+    nmn_index_desc d{};
+    d.dim = (uint32_t)dim;
+    d.capacity_rows = n;
+    d.device = e->cfg.device;
+    d.cand_cap = e->cfg.cand_cap;
+    nmn_status st = nmn_ivf_create(&d, res->centroids.data(), res->n_clusters, &res->index);
+    if (st != NMN_OK) return err_gpu(st);
+    st = nmn_ivf_add(res->index, rows.data(), n, nullptr);  // `for vector in &vectors { index.add(vector) }`
+    if (st != NMN_OK) return err_gpu(st);
+    *out = res.release();
+    return NMN_OK;
+}
+
+void nmn_engine_ivf_free(nmn_engine_ivf* ivf) { delete ivf; }
+uint64_t nmn_engine_ivf_len(const nmn_engine_ivf* ivf) { return (ivf && ivf->index) ? nmn_ivf_len(ivf->index) : 0; }
+uint32_t nmn_engine_ivf_clusters(const nmn_engine_ivf* ivf) { return ivf ? ivf->n_clusters : 0; }
+uint64_t nmn_engine_ivf_nprobe(const nmn_engine_ivf* ivf) { return ivf ? ivf->nprobe : 0; }
+const char* nmn_engine_ivf_key(const nmn_engine_ivf* ivf, uint64_t id) {
+    return (ivf && id < ivf->keys.size()) ? ivf->keys[id].c_str() : nullptr;
+}
+nmn_status nmn_engine_ivf_centroids(const nmn_engine_ivf* ivf, float* out, uint64_t cap_floats) {
+    if (!ivf || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (cap_floats < ivf->centroids.size()) return fail(NMN_ERR_BUFFER_TOO_SMALL, "centroid buffer too small");
+    memcpy(out, ivf->centroids.data(), ivf->centroids.size() * sizeof(float));
+    return NMN_OK;
+}
+nmn_status nmn_engine_ivf_cluster_sizes(nmn_engine_ivf* ivf, uint64_t* out) {
+    if (!ivf || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ivf->index) return NMN_OK;
+    nmn_status st = nmn_ivf_cluster_sizes(ivf->index, out);
+    return st == NMN_OK ? NMN_OK : err_gpu(st);
+}
+
+// search_with_ivf / search_with_ivf_nprobe (lib.rs:2708-2812); nprobe == 0 = the index's own
+nmn_status nmn_engine_search_with_ivf(nmn_engine* e, nmn_engine_ivf* ivf, const float* q, uint64_t dim, uint64_t top_k,
+                                      uint64_t nprobe, nmn_results** out) {
+    if (!e || !ivf || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const Deadline dl(e->cfg.search_timeout_ms);
+    if (!q || dim == 0) return err_empty();  // lib.rs:2717-2719
+    if (top_k == 0) return err_topk();       // lib.rs:2720-2722
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    if (ivf->index) {  // untrained index: `return Vec::new()` (ivf.rs:326-328)
+        if (dim != ivf->dim) {
+            delete res;
+            return err_dim(ivf->dim, dim);  // the reference zips and silently truncates; refused here
+        }
+        const uint64_t len = nmn_ivf_len(ivf->index);
+        const uint32_t k = (uint32_t)std::min<uint64_t>(top_k, std::max<uint64_t>(len, 1));
+        std::vector<uint64_t> ids(k);
+        std::vector<float> dist(k);
+        uint32_t count = 0;
+        nmn_status st = nmn_ivf_search(ivf->index, q, 1, k, (uint32_t)std::min<uint64_t>(nprobe ? nprobe : ivf->nprobe, UINT32_MAX),
+                                       ids.data(), dist.data(), &count, nullptr);
+        if (st != NMN_OK) {
+            delete res;
+            return err_gpu(st);
+        }
+        if (dl.expired()) {  // lib.rs:2726-2731
+            delete res;
+            return err_timeout(nprobe ? "search_with_ivf_nprobe" : "search_with_ivf", dl.ms);
+        }
+        for (uint32_t i = 0; i < count; i++) {
+            if (ids[i] >= ivf->keys.size()) continue;  // `key_mapping.get(vector_id)` -> filter_map
+            res->keys.push_back(ivf->keys[ids[i]]);
+            const float denom = 1.0f + dist[i];
+            res->scores.push_back(1.0f / denom);  // "IVF returns distances, convert to similarity"
         }
     }
     *out = res;

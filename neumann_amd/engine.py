@@ -56,6 +56,16 @@ ENGINE_SIGNATURES = {
     "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
     "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_ivf_options_default": (None, [vp]),
+    "nmn_engine_build_ivf_index": (C.c_int32, [vp, vp, C.POINTER(vp)]),
+    "nmn_engine_ivf_free": (None, [vp]),
+    "nmn_engine_ivf_len": (C.c_uint64, [vp]),
+    "nmn_engine_ivf_clusters": (C.c_uint32, [vp]),
+    "nmn_engine_ivf_nprobe": (C.c_uint64, [vp]),
+    "nmn_engine_ivf_key": (C.c_char_p, [vp, C.c_uint64]),
+    "nmn_engine_ivf_centroids": (C.c_int32, [vp, vp, C.c_uint64]),
+    "nmn_engine_ivf_cluster_sizes": (C.c_int32, [vp, vp]),
+    "nmn_engine_search_with_ivf": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "nmn_engine_set_entity_embedding": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64]),
     "nmn_engine_get_entity_embedding": (C.c_int32, [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "nmn_engine_entity_has_embedding": (C.c_int32, [vp, C.c_char_p]),
@@ -208,6 +218,73 @@ def _value(v):
     else:
         raise TypeError(f"unsupported metadata/filter value {v!r}")
     return out
+
+
+class _IvfOptions(C.Structure):
+    _fields_ = [("num_clusters", C.c_uint64), ("nprobe", C.c_uint64), ("max_iterations", C.c_uint64),
+                ("convergence_threshold", C.c_float), ("seed", C.c_uint64), ("init_method", C.c_int32)]
+
+
+@dataclass
+class IVFBuildOptions:
+    """vector_engine::IVFBuildOptions with IVFConfig::flat + KMeansConfig (lib.rs:941-1000, ivf.rs:61-147,
+    delta_vector.rs:691-711).  nprobe None = default_nprobe(num_clusters)."""
+    num_clusters: int = 100
+    nprobe: int = None
+    max_iterations: int = 100
+    convergence_threshold: float = 1e-4
+    seed: int = 42
+    init_method: str = "kmeans++"   # or "random"
+
+    @staticmethod
+    def flat(num_clusters):
+        return IVFBuildOptions(num_clusters=num_clusters)
+
+
+class IVFIndex:
+    """The (IVFIndex, key_mapping) pair build_ivf_index returns; vectors and lists live on the GPU."""
+
+    def __init__(self, handle):
+        self._h = handle
+        n = int(_lib().nmn_engine_ivf_len(handle))
+        self.keys = [_lib().nmn_engine_ivf_key(handle, i).decode() for i in range(n)]
+
+    def __len__(self):
+        return int(_lib().nmn_engine_ivf_len(self._h))
+
+    @property
+    def num_clusters(self):
+        return int(_lib().nmn_engine_ivf_clusters(self._h))
+
+    @property
+    def nprobe(self):
+        return int(_lib().nmn_engine_ivf_nprobe(self._h))
+
+    def is_trained(self):
+        return self.num_clusters > 0
+
+    def centroids(self, dim):
+        out = np.empty((self.num_clusters, dim), dtype=np.float32)
+        if out.size:
+            _check(_lib().nmn_engine_ivf_centroids(self._h, C.c_void_p(out.ctypes.data), out.size))
+        return out
+
+    def cluster_sizes(self):
+        out = np.zeros(self.num_clusters, dtype=np.uint64)
+        if out.size:
+            _check(_lib().nmn_engine_ivf_cluster_sizes(self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib().nmn_engine_ivf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FilterCondition:
@@ -389,6 +466,37 @@ class VectorEngine:
         h = vp()
         _check(_lib().nmn_engine_search_similar(self._h, p, n, int(top_k), C.byref(h)))
         return self._take_results(h)
+
+    # ---- IVF (lib.rs:2641-2812) ----
+    def build_ivf_index(self, options=None):
+        """-> (IVFIndex, key_mapping) like the reference; k-means as the reference runs it, lists on the GPU."""
+        o = options or IVFBuildOptions()
+        co = _IvfOptions(num_clusters=o.num_clusters, nprobe=o.nprobe or 0, max_iterations=o.max_iterations,
+                         convergence_threshold=o.convergence_threshold, seed=o.seed,
+                         init_method=0 if o.init_method == "random" else 1)
+        h = vp()
+        _check(_lib().nmn_engine_build_ivf_index(self._h, C.byref(co), C.byref(h)))
+        index = IVFIndex(h)
+        return index, index.keys
+
+    def build_ivf_index_default(self):
+        return self.build_ivf_index(IVFBuildOptions())
+
+    def search_with_ivf(self, index, key_mapping, query, top_k, _nprobe=0):
+        a, p, n = _vec(query)
+        h = vp()
+        _check(_lib().nmn_engine_search_with_ivf(self._h, index._h, p, n, int(top_k), int(_nprobe), C.byref(h)))
+        res = self._take_results(h)
+        if key_mapping is not index.keys and list(key_mapping) != index.keys:
+            # `key_mapping.get(vector_id)` (lib.rs:2735-2743) with a caller-supplied mapping
+            ids = {k: i for i, k in enumerate(index.keys)}
+            res = [SearchResult(key_mapping[ids[r.key]], r.score) for r in res if ids[r.key] < len(key_mapping)]
+        return res
+
+    def search_with_ivf_nprobe(self, index, key_mapping, query, top_k, nprobe):
+        if nprobe <= 0:
+            return []  # `nprobe.min(len)` = 0 clusters probed (ivf.rs:339-343)
+        return self.search_with_ivf(index, key_mapping, query, top_k, _nprobe=nprobe)
 
     # ---- unified entity mode (lib.rs:3060-3237) ----
     def set_entity_embedding(self, entity_key, vector):

@@ -116,3 +116,61 @@ def test_ivf_equal_distances_keep_probe_order():
         assert eids == [4, 1, 3, 2, 0]          # list 0 first (ids 1, 3), then list 2, then list 1
         check_same(orc, gpu, q, 5)
         check_same(orc, gpu, q, 3)
+
+
+# ---- engine level: build_ivf_index / search_with_ivf (vector_engine/src/lib.rs:2641-2812) ------------------
+@pytest.fixture
+def E():
+    from neumann_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("init", ["random", "kmeans++"])
+def test_engine_build_ivf_index_matches_oracle(E, init):
+    rng = np.random.default_rng(17)
+    n, d, c = 1500, 24, 12
+    V = rng.standard_normal((n, d)).astype(F)
+    engine = E.VectorEngine()
+    engine.batch_store_embeddings([f"k{i}" for i in range(n)], V)
+    opts = E.IVFBuildOptions(num_clusters=c, nprobe=4, max_iterations=6, convergence_threshold=1e-4, seed=99,
+                             init_method=init)
+    index, keys = engine.build_ivf_index(opts)
+    assert index.is_trained() and len(index) == n and index.num_clusters == c and index.nprobe == 4
+    order = [int(k[1:]) for k in keys]                      # the engine's list_keys() order feeds the training
+    orc = io.IVFFlat(c, nprobe=4, kmeans=io.KMeansConfig(6, 1e-4, 99, init))
+    orc.train(V[order])
+    for i in order:
+        orc.add(V[i])
+    assert np.array_equal(index.centroids(d), orc.centroids)          # k-means restated bit for bit
+    assert index.cluster_sizes().tolist() == orc.cluster_sizes()
+    for t in range(5):
+        q = rng.standard_normal(d).astype(F)
+        for nprobe in (None, 1, c):
+            res = (engine.search_with_ivf(index, keys, q, 10) if nprobe is None
+                   else engine.search_with_ivf_nprobe(index, keys, q, 10, nprobe))
+            eids, ed = orc.search(q, 10, nprobe)
+            assert [r.key for r in res] == [keys[i] for i in eids]
+            assert np.array_equal(np.array([r.score for r in res], F), np.array([io.ivf_score(x) for x in ed], F))
+
+
+def test_engine_ivf_edge_cases(E):  # lib.rs:2643-2647, 2717-2722; ivf.rs:326-328
+    engine = E.VectorEngine()
+    index, keys = engine.build_ivf_index_default()
+    assert keys == [] and not index.is_trained()
+    assert engine.search_with_ivf(index, keys, [1.0, 0.0], 5) == []
+    for i in range(30):
+        engine.store_embedding(f"k{i}", [float(i), 1.0, 0.5])
+    index, keys = engine.build_ivf_index(E.IVFBuildOptions.flat(100))   # more clusters than vectors: min(k, n)
+    assert index.num_clusters == 30 and len(index) == 30 and index.nprobe == 10
+    res = engine.search_with_ivf_nprobe(index, keys, [3.0, 1.0, 0.5], 3, 30)
+    assert res[0].key == "k3" and res[0].score == 1.0
+    with pytest.raises(E.VectorError) as e:
+        engine.search_with_ivf(index, keys, [], 5)
+    assert e.value.kind == "EmptyVector"
+    with pytest.raises(E.VectorError) as e:
+        engine.search_with_ivf(index, keys, [1.0, 2.0, 3.0], 0)
+    assert e.value.kind == "InvalidTopK"
+    engine.store_embedding("odd", [1.0, 2.0])
+    with pytest.raises(E.VectorError) as e:
+        engine.build_ivf_index_default()
+    assert e.value.kind == "DimensionMismatch"
