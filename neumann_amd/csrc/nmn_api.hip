@@ -519,7 +519,17 @@ static nmn_status check_search_args(const nmn_index* idx, const void* queries, u
 extern "C" nmn_status nmn_index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k,
                                               nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows_dev,
                                               float* out_scores_dev, uint32_t* out_counts_dev, void* stream) {
-    nmn_status st = check_search_args(idx, queries_dev, nq, k, metric, out_rows_dev, out_scores_dev, out_counts_dev);
+    if ((int)metric < 0 || (int)metric > 2) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "bad metric");
+    return index_search_device(idx, queries_dev, nq, k, (int)metric, mask_dev, out_rows_dev, out_scores_dev,
+                               out_counts_dev, static_cast<hipStream_t>(stream));
+}
+
+nmn_status nmn::index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric_i,
+                                    const uint64_t* mask_dev, uint64_t* out_rows_dev, float* out_scores_dev,
+                                    uint32_t* out_counts_dev, hipStream_t stream) {
+    const nmn_metric metric = (nmn_metric)metric_i;
+    nmn_status st = check_search_args(idx, queries_dev, nq, k, metric_i == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : metric,
+                                      out_rows_dev, out_scores_dev, out_counts_dev);
     if (st != NMN_OK) return st;
     HIP_TRY(hipSetDevice(idx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);

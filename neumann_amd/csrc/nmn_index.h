@@ -71,4 +71,9 @@ nmn_status index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq
                                const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
                                uint32_t* out_counts, nmn_search_stats* stats);
 
+// nmn_index_search_device with the internal metrics allowed (everything in device memory, asynchronous)
+nmn_status index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric,
+                               const uint64_t* mask_dev, uint64_t* out_rows_dev, float* out_scores_dev,
+                               uint32_t* out_counts_dev, hipStream_t stream);
+
 }  // namespace nmn

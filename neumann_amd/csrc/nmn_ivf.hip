@@ -109,6 +109,8 @@ struct nmn_ivf {
     QState* qstate = nullptr;
     uint32_t* assign_tmp = nullptr;      // [kAssignChunk]
     uint32_t assign_chunk = kAssignChunk;
+    uint64_t* res_rows = nullptr; size_t res_rows_cap = 0;   // device results of the list scan
+    float* res_scores = nullptr; size_t res_scores_cap = 0;
     std::mutex mu;
 };
 
@@ -124,7 +126,8 @@ extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
     if (ivf->stream) (void)hipStreamSynchronize(ivf->stream);
     for (void* p : {(void*)ivf->assign, (void*)ivf->cscores, (void*)ivf->ckeys, (void*)ivf->probe_rows,
                     (void*)ivf->probe_scores, (void*)ivf->probe_count, (void*)ivf->probe_rank, (void*)ivf->mask,
-                    (void*)ivf->qraw, (void*)ivf->qpad, (void*)ivf->qinfo, (void*)ivf->qstate, (void*)ivf->assign_tmp})
+                    (void*)ivf->qraw, (void*)ivf->qpad, (void*)ivf->qinfo, (void*)ivf->qstate, (void*)ivf->assign_tmp,
+                    (void*)ivf->res_rows, (void*)ivf->res_scores})
         if (p) (void)hipFree(p);
     if (ivf->stream) (void)hipStreamDestroy(ivf->stream);
     if (ivf->vectors) nmn_index_destroy(ivf->vectors);
@@ -173,7 +176,7 @@ extern "C" nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* ce
     alloc(reinterpret_cast<void**>(&ivf->ckeys), largek_sort_len(n_clusters) * 8);
     alloc(reinterpret_cast<void**>(&ivf->probe_rows), (size_t)n_clusters * 8);
     alloc(reinterpret_cast<void**>(&ivf->probe_scores), (size_t)n_clusters * 4);
-    alloc(reinterpret_cast<void**>(&ivf->probe_count), 4);
+    alloc(reinterpret_cast<void**>(&ivf->probe_count), 8);  // [0] clusters probed, [1] results of the list scan
     alloc(reinterpret_cast<void**>(&ivf->probe_rank), (size_t)n_clusters * 4);
     alloc(reinterpret_cast<void**>(&ivf->mask), ((ivf->cap + 63) / 64 + 1) * 8);
     alloc(reinterpret_cast<void**>(&ivf->qraw), (size_t)desc->dim * 4);
@@ -247,6 +250,17 @@ extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t
     return NMN_OK;
 }
 
+template <typename T>
+static hipError_t grow_dev(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(need, 1) * sizeof(T));
+    if (e == hipSuccess) *cap = need;
+    return e;
+}
+
 extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_t nq, uint32_t k, uint32_t nprobe,
                                      uint64_t* out_ids, float* out_distances, uint32_t* out_counts,
                                      nmn_search_stats* stats) {
@@ -270,6 +284,7 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
         std::fill(o_dist, o_dist + k, __builtin_inff());
         out_counts[q] = 0;
         if (n_rows == 0 || np == 0) continue;
+        // Everything below is enqueued on ONE stream; the host waits once per attempt.
         // 1. rank the centroids by squared distance (ascending; ties by index) and keep the first nprobe
         IVF_TRY(hipMemcpyAsync(ivf->qraw, queries + (size_t)q * ivf->dim, (size_t)ivf->dim * 4, hipMemcpyHostToDevice, s));
         IVF_TRY(launch_qprep(ivf->qraw, 1, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits,
@@ -286,28 +301,37 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
         hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, ivf->probe_rank, n_rows, ivf->mask);
         IVF_TRY(hipGetLastError());
-        IVF_TRY(hipMemcpyAsync(probe_host.data(), ivf->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost, s));
-        IVF_TRY(hipStreamSynchronize(s));
         // 3. masked scan ranking by distance (negated so that nearest = largest).  One result more than asked
         //    for: the scan breaks equal distances by id, the reference by candidate order, so a run of equal
         //    distances that straddles the cut must be seen whole before it is reordered and cut.
         uint64_t kk = std::min<uint64_t>((uint64_t)k + 1, std::max<uint64_t>(n_rows, 1));
         uint32_t cnt = 0;
         for (;;) {
+            IVF_TRY(grow_dev(&ivf->res_rows, &ivf->res_rows_cap, (size_t)kk));
+            IVF_TRY(grow_dev(&ivf->res_scores, &ivf->res_scores_cap, (size_t)kk));
             tmp_ids.resize(kk);
             tmp_dist.resize(kk);
-            st = index_search_hostio(ivf->vectors, queries + (size_t)q * ivf->dim, 1, (uint32_t)kk, kMetricNegL2, ivf->mask,
-                                     true, tmp_ids.data(), tmp_dist.data(), &cnt, q + 1 == nq ? stats : nullptr);
+            st = index_search_device(ivf->vectors, ivf->qraw, 1, (uint32_t)kk, kMetricNegL2, ivf->mask, ivf->res_rows,
+                                     ivf->res_scores, ivf->probe_count + 1, s);
             if (st != NMN_OK) return st;
+            IVF_TRY(hipMemcpyAsync(tmp_ids.data(), ivf->res_rows, (size_t)kk * 8, hipMemcpyDeviceToHost, s));
+            IVF_TRY(hipMemcpyAsync(tmp_dist.data(), ivf->res_scores, (size_t)kk * 4, hipMemcpyDeviceToHost, s));
+            IVF_TRY(hipMemcpyAsync(&cnt, ivf->probe_count + 1, 4, hipMemcpyDeviceToHost, s));
+            IVF_TRY(hipStreamSynchronize(s));
             const bool cut_inside_run = cnt > k && tmp_dist[k] == tmp_dist[k - 1];
             if (!cut_inside_run || cnt < kk || kk >= n_rows) break;  // run seen whole, or nothing more to fetch
             kk = std::min<uint64_t>(kk * 2, n_rows);
+        }
+        if (stats && q + 1 == nq) {
+            st = nmn_index_last_stats(ivf->vectors, s, stats);
+            if (st != NMN_OK) return st;
         }
         for (uint32_t i = 0; i < cnt; i++) tmp_dist[i] = -tmp_dist[i];
         // 4. equal distances keep candidate order: probe order of the cluster, then id (stable sort, ivf.rs:402)
         bool any_tie = false;
         for (uint32_t i = 1; i < cnt && !any_tie; i++) any_tie = tmp_dist[i] == tmp_dist[i - 1];
         if (any_tie) {
+            IVF_TRY(hipMemcpy(probe_host.data(), ivf->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost));
             rank_host.assign(ivf->n_clusters, kNoRank);
             for (uint32_t i = 0; i < np; i++) rank_host[probe_host[i]] = i;
             const uint64_t base = ivf->vectors->row_base;
