@@ -155,6 +155,17 @@ nmn_filter* nmn_filter_contains(const char* field, const char* substr);
 nmn_filter* nmn_filter_starts_with(const char* field, const char* prefix);
 nmn_filter* nmn_filter_in(const char* field, const nmn_value* values, uint32_t n);
 void nmn_filter_free(nmn_filter* f);
+/* ---- tensor_blob artifact similarity (tensor_blob/src/lib.rs:520-625) ----------------------------- */
+/* set_embedding (529-556) for the artifact record `_blob:meta:{artifact_id}`; filename = its `_filename`. */
+nmn_status nmn_engine_blob_set_embedding(nmn_engine* e, const char* artifact_id, const char* filename, const float* v,
+                                         uint64_t dim);
+nmn_status nmn_engine_blob_remove(nmn_engine* e, const char* artifact_id);
+/* search_by_embedding (591-625): SimilarArtifact{id = key, filename = aux, similarity = score}, f64 sparse cosine */
+nmn_status nmn_engine_blob_search_by_embedding(nmn_engine* e, const float* q, uint64_t dim, uint64_t k, nmn_results** out);
+/* similar (563-583) */
+nmn_status nmn_engine_blob_similar(nmn_engine* e, const char* artifact_id, uint64_t k, nmn_results** out);
+const char* nmn_results_aux(const nmn_results* r, uint64_t i);
+
 /* ---- IVF-Flat (lib.rs:2641-2812; tensor_store/src/ivf.rs) ---------------------------------------- */
 #define NMN_KMEANS_INIT_RANDOM 0   /* KMeansInit::Random          (delta_vector.rs:781-800) */
 #define NMN_KMEANS_INIT_PLUSPLUS 1 /* KMeansInit::KMeansPlusPlus  (delta_vector.rs:805-853) */

@@ -58,7 +58,11 @@ typedef int32_t nmn_status;
 typedef enum nmn_metric {
     NMN_METRIC_COSINE = 0,
     NMN_METRIC_EUCLIDEAN = 1,
-    NMN_METRIC_DOT_PRODUCT = 2
+    NMN_METRIC_DOT_PRODUCT = 2,
+    /* Not a vector_engine metric: tensor_blob's artifact similarity (tensor_blob/src/lib.rs:591-625), i.e.
+     * SparseVector::from_dense(a).cosine_similarity(&SparseVector::from_dense(b)) — f64 dot and magnitudes over
+     * the non-zero positions, NaN/Inf -> 0, clamped to [-1, 1], rounded once to f32 (sparse_vector.rs:583-599). */
+    NMN_METRIC_SPARSE_COSINE_F64 = 3
 } nmn_metric;
 
 typedef struct nmn_index nmn_index; /* opaque: one row-range shard resident on one GPU */

@@ -51,7 +51,7 @@ nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, wh
 
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
                     w->h_counts2, w->lk_keys};
     for (void* p : ptrs)
@@ -127,6 +127,7 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     w->n_sample_cap = (w->n_tiles_cap + kSampleStep - 1) / kSampleStep + 4;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tsample), nq * w->n_sample_cap * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->skip_key), nq * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->k_extra), 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qpad), nq * w->ld * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo), nq * sizeof(QInfo)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
@@ -463,6 +464,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.k = k;
             sel.cand_cap = w->cand_cap;
             sel.skip_key = sp.skip_key;
+            sel.k_extra = nullptr;
+            if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
+                HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
+                sel.k_extra = w->k_extra;
+            }
             HIP_TRY(launch_select(sel, stream));
 
             RescoreParams rp{};
@@ -512,14 +518,14 @@ static nmn_status check_search_args(const nmn_index* idx, const void* queries, u
     if (nq == 0 || nq > NMN_MAX_QUERIES) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
     if (!queries || !out_rows || !out_scores || !out_counts)
         return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null buffer");
-    if ((int)metric < 0 || (int)metric > 2) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "bad metric");
+    if ((int)metric < 0 || (int)metric > 3) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "bad metric");
     return NMN_OK;
 }
 
 extern "C" nmn_status nmn_index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k,
                                               nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows_dev,
                                               float* out_scores_dev, uint32_t* out_counts_dev, void* stream) {
-    if ((int)metric < 0 || (int)metric > 2) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "bad metric");
+    if ((int)metric < 0 || (int)metric > 3) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "bad metric");
     return index_search_device(idx, queries_dev, nq, k, (int)metric, mask_dev, out_rows_dev, out_scores_dev,
                                out_counts_dev, static_cast<hipStream_t>(stream));
 }

@@ -104,6 +104,7 @@ struct nmn_filter {
 struct nmn_results {
     std::vector<std::string> keys;
     std::vector<float> scores;
+    std::vector<std::string> aux;  // SimilarArtifact::filename for the artifact searches, otherwise empty
 };
 struct nmn_strlist {
     std::vector<std::string> items;
@@ -268,6 +269,7 @@ struct nmn_engine {
     std::mutex mu;  // `&self` from many threads is safe; operations are serialised
     Collection dflt;
     Collection entities;                              // unified entity mode: keys whose TensorData has `_embedding`
+    Collection artifacts;                             // tensor_blob: `_blob:meta:{id}` records that carry `_embedding`
     std::map<std::string, Collection> colls;          // storage of named collections
     std::map<std::string, CollectionConfig> configs;  // `collections` map (configured ones only)
     uint64_t mirror_builds = 0;
@@ -1034,6 +1036,93 @@ nmn_status nmn_engine_search_similar(nmn_engine* e, const float* q, uint64_t dim
     return NMN_OK;
 }
 
+// ---- tensor_blob artifact similarity (tensor_blob/src/lib.rs:520-625) -----------------------------------
+// The blob store keeps an optional `_embedding` (+ `_id`, `_filename`) in each artifact's `_blob:meta:{id}`
+// record; `search_by_embedding` scans those records, keeps the ones of the query's dimension and ranks them by
+// the f64 sparse cosine (NMN_METRIC_SPARSE_COSINE_F64).  Here the embeddings of the artifacts are one more
+// mirrored key space; the artifact bytes, chunks, tags and links are the blob store's business, not this path's.
+nmn_status nmn_engine_blob_set_embedding(nmn_engine* e, const char* artifact_id, const char* filename, const float* v,
+                                         uint64_t dim) {
+    if (!e || !artifact_id) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!v || dim == 0) return err_empty();
+    nmn_meta_field mf{};
+    mf.name = "_filename";
+    mf.value.kind = NMN_VAL_STRING;
+    mf.value.s = filename ? filename : "";
+    std::lock_guard<std::mutex> g(e->mu);
+    return store_into(e, &e->artifacts, artifact_id, v, dim, &mf, 1);
+}
+
+nmn_status nmn_engine_blob_remove(nmn_engine* e, const char* artifact_id) {  // BlobStore::delete drops the record
+    if (!e || !artifact_id) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    return delete_from(&e->artifacts, artifact_id, artifact_id);
+}
+
+static void fill_filenames(Collection* c, nmn_results* res) {
+    res->aux.clear();
+    for (const auto& key : res->keys) {
+        auto it = c->by_key.find(key);
+        std::string fn;
+        if (it != c->by_key.end()) {
+            auto m = c->slots[it->second].meta.find("_filename");
+            if (m != c->slots[it->second].meta.end()) fn = m->second.s;  // get_string(..).unwrap_or_default()
+        }
+        res->aux.push_back(std::move(fn));
+    }
+}
+
+// search_by_embedding (lib.rs:591-625): no validation in the reference — an empty query or k == 0 simply finds nothing
+nmn_status nmn_engine_blob_search_by_embedding(nmn_engine* e, const float* q, uint64_t dim, uint64_t k, nmn_results** out) {
+    if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    nmn_results* res = new_results();
+    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    if (q && dim && k) {
+        const Deadline dl(-1);
+        std::lock_guard<std::mutex> g(e->mu);
+        nmn_status st = search_common(e, &e->artifacts, q, dim, k, NMN_METRIC_SPARSE_COSINE_F64, "search_by_embedding", dl,
+                                      nullptr, nullptr, res);
+        if (st != NMN_OK) {
+            delete res;
+            return st;
+        }
+        fill_filenames(&e->artifacts, res);
+    }
+    *out = res;
+    return NMN_OK;
+}
+
+// similar (lib.rs:563-583): search k + 1 with the artifact's own embedding, drop the artifact itself, take k
+nmn_status nmn_engine_blob_similar(nmn_engine* e, const char* artifact_id, uint64_t k, nmn_results** out) {
+    if (!e || !artifact_id || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    std::vector<float> emb;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        auto it = e->artifacts.by_key.find(artifact_id);
+        if (it == e->artifacts.by_key.end()) return err_not_found(artifact_id);  // BlobError::NotFound
+        emb = e->artifacts.slots[it->second].vec;
+    }
+    nmn_results* all = nullptr;
+    nmn_status st = nmn_engine_blob_search_by_embedding(e, emb.data(), emb.size(), k + 1, &all);
+    if (st != NMN_OK) return st;
+    nmn_results* res = new_results();
+    if (!res) {
+        delete all;
+        return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    }
+    for (size_t i = 0; i < all->keys.size() && res->keys.size() < k; i++) {
+        if (all->keys[i] == artifact_id) continue;
+        res->keys.push_back(all->keys[i]);
+        res->scores.push_back(all->scores[i]);
+        res->aux.push_back(all->aux[i]);
+    }
+    delete all;
+    *out = res;
+    return NMN_OK;
+}
+
 // ---- IVF (lib.rs:2641-2812) --------------------------------------------------------------------------
 void nmn_ivf_options_default(nmn_ivf_options* o) {  // IVFConfig::default + KMeansConfig::default
     if (!o) return;
@@ -1489,6 +1578,7 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
 uint64_t nmn_results_len(const nmn_results* r) { return r ? r->keys.size() : 0; }
 const char* nmn_results_key(const nmn_results* r, uint64_t i) { return (r && i < r->keys.size()) ? r->keys[i].c_str() : nullptr; }
 float nmn_results_score(const nmn_results* r, uint64_t i) { return (r && i < r->scores.size()) ? r->scores[i] : NAN; }
+const char* nmn_results_aux(const nmn_results* r, uint64_t i) { return (r && i < r->aux.size()) ? r->aux[i].c_str() : nullptr; }
 void nmn_results_free(nmn_results* r) { delete r; }
 uint64_t nmn_strlist_len(const nmn_strlist* l) { return l ? l->items.size() : 0; }
 const char* nmn_strlist_get(const nmn_strlist* l, uint64_t i) { return (l && i < l->items.size()) ? l->items[i].c_str() : nullptr; }

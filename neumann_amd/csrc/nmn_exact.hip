@@ -93,6 +93,50 @@ __device__ __forceinline__ float euclid_sumsq_seq(const float* __restrict__ q, c
     return s;
 }
 
+// tensor_blob's artifact similarity (tensor_blob/src/lib.rs:601-603): both vectors go through
+// SparseVector::from_dense (keeps every value != 0.0, NaN included; sparse_vector.rs:221-229) and
+// SparseVector::cosine_similarity (583-599): dot_f64 = sequential f64 sum of f64(a_i)*f64(b_i) over the positions
+// where BOTH are stored (419-443), magnitude_f64 = sqrt of the sequential f64 sum of squares of the stored values
+// (553-559), result = dot / (mag_a * mag_b) with 0.0 for a zero magnitude or a NaN/Inf result, clamped to
+// [-1, 1] and rounded once to f32.  Products of two f32 are exact in f64, and a skipped position contributes
+// exactly what adding +0.0 does (the running sums start at 0.0 and can never become -0.0), so the 8 threads of
+// the group form the products and every thread then adds them in index order.
+template <int PF>
+__device__ __forceinline__ float sparse_cos64(const float* __restrict__ q, const float* __restrict__ v, uint32_t dim,
+                                              uint32_t l) {
+    double dot = 0.0, sa = 0.0, sb = 0.0;
+    const int base = (int)(threadIdx.x & 63u & ~7u);
+    const uint32_t chunks = (dim + 7u) >> 3;
+    for (uint32_t c0 = 0; c0 < chunks; c0 += PF) {
+        double pd[PF], pa[PF], pb[PF];
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const uint32_t e = 8u * (c0 + (uint32_t)i) + l;
+            const float x = e < dim ? q[e] : 0.0f;
+            const float y = e < dim ? v[e] : 0.0f;
+            const bool sx = x != 0.0f, sy = y != 0.0f;  // stored in the sparse form (true for NaN)
+            pd[i] = (sx && sy) ? (double)x * (double)y : 0.0;
+            pa[i] = sx ? (double)x * (double)x : 0.0;
+            pb[i] = sy ? (double)y * (double)y : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                dot = dot + __shfl(pd[i], base + t);
+                sa = sa + __shfl(pa[i], base + t);
+                sb = sb + __shfl(pb[i], base + t);
+            }
+        }
+    }
+    const double mag_a = __builtin_sqrt(sa), mag_b = __builtin_sqrt(sb);
+    if (mag_a == 0.0 || mag_b == 0.0) return 0.0f;
+    const double r = dot / (mag_a * mag_b);
+    if (r != r || __builtin_isinf(r)) return 0.0f;
+    const double c = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    return (float)c;
+}
+
 // compute_score (lib.rs:2231-2266) for one (query,row); vmag = stored simd::magnitude(row).
 // The two internal metrics serve the IVF probe (tensor_store/src/ivf.rs:500-508 `squared_euclidean` is the same
 // sequential sum as euclidean_distance's): kMetricNegL2Sq ranks centroids by squared distance (ivf.rs:331-337),
@@ -107,6 +151,7 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ q, const 
         if (metric == kMetricNegL2) return -dist;
         return div_rn(1.0f, add_rn(1.0f, dist));
     }
+    if (metric == NMN_METRIC_SPARSE_COSINE_F64) return sparse_cos64<8>(q, v, dim, l);
     const float dot = dot8_group<32>(q, v, dim, l);
     if (metric == NMN_METRIC_DOT_PRODUCT) return dot;
     if (qmag == 0.0f || vmag == 0.0f) return 0.0f;
@@ -159,7 +204,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         qi.pad = 0.f;
         // split-bf16 MFMA sweep: each product carries an extra 2^-15 relative error (nmn_scan_mfma.hip)
         const float split = mfma_pass ? 6.1035156e-05f /* 2^-14 */ : 0.0f;
-        if (metric == NMN_METRIC_COSINE) {
+        if (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_SPARSE_COSINE_F64) {
             qi.margin_abs = 3.0f * (dd + 10.0f) * u + split;
             qi.margin_rel = 0.0f;
         } else if (metric == NMN_METRIC_DOT_PRODUCT) {

@@ -23,6 +23,7 @@ struct Workspace {
     uint32_t* wmax = nullptr;
     uint32_t* tsample = nullptr;   // [nq][n_sample_cap] tile maxima of the sampling pass (batched sweep)
     uint32_t* skip_key = nullptr;  // [nq] score-write threshold of the batched sweep
+    uint32_t* k_extra = nullptr;   // [1] rows forced into the candidates (f64 artifact similarity)
     uint64_t n_sample_cap = 0;
     uint64_t tmax_stride = 0;
     float* qpad = nullptr;

@@ -18,8 +18,8 @@
 namespace nmn {
 
 // internal metrics (beyond nmn_metric): both rank "nearest first" as a descending score
-constexpr int kMetricNegL2 = 3;    // score = -sqrt(sum (q_i - v_i)^2), sequential sum (IVF list scan, ivf.rs:365-369)
-constexpr int kMetricNegL2Sq = 4;  // score = -(sum (q_i - v_i)^2); exact kernels only (centroid ranking, ivf.rs:331-337)
+constexpr int kMetricNegL2 = 16;    // score = -sqrt(sum (q_i - v_i)^2), sequential sum (IVF list scan, ivf.rs:365-369)
+constexpr int kMetricNegL2Sq = 17;  // score = -(sum (q_i - v_i)^2); exact kernels only (centroid ranking, ivf.rs:331-337)
 
 constexpr uint32_t kTileRows = 64;        // rows per scan tile (one wave, 16 steps of 4 rows)
 constexpr uint32_t kDefaultCandCap = 4096;
@@ -126,8 +126,10 @@ struct SelectParams {
     uint32_t k;
     uint32_t cand_cap;
     const uint32_t* skip_key;  // nullable [nq]: scores of tiles whose maximum is below it were never written
+    const uint32_t* k_extra;   // nullable: added to k for the threshold rank (rows forced to +inf, f64 similarity)
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
+hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);
 // per query: skip_key[q] = margin_key(k-th largest of the sampled tile maxima) (kKeyNaN if fewer than k are valid)
 hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uint32_t n_sample, const QInfo* qinfo,
                                uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s);

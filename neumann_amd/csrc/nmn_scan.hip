@@ -155,13 +155,21 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
         const bool valid = ((mword >> mybit) & 1ull) != 0;
         const uint64_t myrow = r0 + mybit;
         float vn = 1.f;
-        if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? p.norms[myrow] : 1.f;
+        if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? p.norms[myrow] : 1.f;  // f32 |v|: fine as an approximation of the f64 one too
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             if (q0 + q >= p.nq) break;
             float sc;
             if constexpr (METRIC == NMN_METRIC_COSINE) {
                 sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : mydot[q] / (qmag[q] * vn);
+                // f64 artifact similarity: the reference computes in f64, so magnitudes whose SQUARES leave the f32
+                // range (overflow to inf, underflow to 0), a NaN anywhere, or a zero magnitude say nothing about the
+                // f64 result: such rows are forced into the candidates and the exact f64 rescore decides.
+                if (p.metric == NMN_METRIC_SPARSE_COSINE_F64) {
+                    const bool trust = vn >= 1e-15f && vn <= 1e18f && qmag[q] >= 1e-15f && qmag[q] <= 1e18f &&
+                                       __builtin_fabsf(mydot[q]) <= 3.0e38f;
+                    if (!trust) sc = __builtin_inff();
+                }
             } else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
                 const float dist = sqrtf(fmaxf(mydot[q], 0.f));
                 sc = p.metric == kMetricNegL2 ? -dist : 1.0f / (1.0f + dist);  // IVF probe ranks by distance
@@ -233,7 +241,8 @@ static bool scan_nt_enabled() {
 hipError_t launch_scan(const ScanParams& p, hipStream_t s) {
     const bool nt = scan_nt_enabled();
     switch (p.metric) {
-        case NMN_METRIC_COSINE: return launch_mask<NMN_METRIC_COSINE>(p, s, nt);
+        case NMN_METRIC_COSINE:
+        case NMN_METRIC_SPARSE_COSINE_F64: return launch_mask<NMN_METRIC_COSINE>(p, s, nt);  // same sweep
         case NMN_METRIC_EUCLIDEAN:
         case kMetricNegL2: return launch_mask<NMN_METRIC_EUCLIDEAN>(p, s, nt);  // same sweep, epilogue picks -d over 1/(1+d)
         default: return launch_mask<NMN_METRIC_DOT_PRODUCT>(p, s, nt);

@@ -5,6 +5,8 @@
 // (vector_engine/src/lib.rs:2027-2034, 2093-2100) and `ResultMerger::merge_top_k`
 // (query_router/src/distributed.rs:413-433).  Order everywhere: score descending, ties by ascending
 // row id; NaN scores last.
+#include <algorithm>
+
 #include "nmn_internal.h"
 
 namespace nmn {
@@ -205,7 +207,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t W = p.n_waves, tpw = p.tiles_per_wave, n_tiles = p.n_tiles;
     const QInfo qi = p.qinfo[q];
     uint32_t* out = p.cand_rows + (size_t)q * p.cand_cap;
-    const uint32_t k = p.k;
+    // rank of the threshold: k, plus (f64 artifact similarity only) the rows whose approximate score is forced to
+    // +inf because f32 cannot vouch for them — they occupy the top ranks without being real contenders
+    const uint32_t k = p.k + (p.k_extra ? *p.k_extra : 0u);
     constexpr int V = 8;
 
     for (uint32_t i = tid; i < kMaxScanWaves; i += kSelThreads) wk[i] = i < W ? wmax[i] : kKeyMasked;
@@ -612,6 +616,31 @@ __global__ void __launch_bounds__(256) count_cmp_kernel(const uint32_t* __restri
         if (gt) atomicAdd(&out2[0], gt);
         if (eq) atomicAdd(&out2[1], eq);
     }
+}
+
+// rows whose stored f32 magnitude is outside the range in which the approximate cosine can be trusted for the
+// f64 artifact similarity (same test as scan_kernel's epilogue); masked-out rows may be counted too — a larger
+// rank only lowers the threshold
+__global__ __launch_bounds__(256) void count_untrusted_kernel(const float* __restrict__ norms, uint64_t n_rows,
+                                                              uint32_t* __restrict__ out) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (uint64_t)gridDim.x * 256) {
+        const float vn = norms[i];
+        c += (vn >= 1e-15f && vn <= 1e18f) ? 0u : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    __shared__ uint32_t ws[4];
+    if ((threadIdx.x & 63u) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && (ws[0] + ws[1] + ws[2] + ws[3])) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, 4, s);
+    if (e != hipSuccess || n_rows == 0) return e;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_rows + 255) / 256, 1024);
+    hipLaunchKernelGGL(count_untrusted_kernel, dim3(blocks), dim3(256), 0, s, norms, n_rows, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_count_cmp(const uint32_t* scores, uint64_t n_rows, float score, unsigned long long* out2,

@@ -56,6 +56,11 @@ ENGINE_SIGNATURES = {
     "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
     "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_blob_set_embedding": (C.c_int32, [vp, C.c_char_p, C.c_char_p, vp, C.c_uint64]),
+    "nmn_engine_blob_remove": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_blob_search_by_embedding": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_blob_similar": (C.c_int32, [vp, C.c_char_p, C.c_uint64, C.POINTER(vp)]),
+    "nmn_results_aux": (C.c_char_p, [vp, C.c_uint64]),
     "nmn_ivf_options_default": (None, [vp]),
     "nmn_engine_build_ivf_index": (C.c_int32, [vp, vp, C.POINTER(vp)]),
     "nmn_engine_ivf_free": (None, [vp]),
@@ -154,6 +159,14 @@ class SearchResult:
     """vector_engine::SearchResult (lib.rs:252-266)."""
     key: str
     score: float
+
+
+@dataclass
+class SimilarArtifact:
+    """tensor_blob::SimilarArtifact (tensor_blob/src/metadata.rs:155-162)."""
+    id: str
+    filename: str
+    similarity: float
 
 
 @dataclass
@@ -466,6 +479,35 @@ class VectorEngine:
         h = vp()
         _check(_lib().nmn_engine_search_similar(self._h, p, n, int(top_k), C.byref(h)))
         return self._take_results(h)
+
+    # ---- tensor_blob artifact similarity (tensor_blob/src/lib.rs:520-625) ----
+    def blob_set_embedding(self, artifact_id, filename, embedding):
+        a, p, n = _vec(embedding)
+        _check(_lib().nmn_engine_blob_set_embedding(self._h, artifact_id.encode(), filename.encode(), p, n))
+
+    def blob_remove(self, artifact_id):
+        _check(_lib().nmn_engine_blob_remove(self._h, artifact_id.encode()))
+
+    @staticmethod
+    def _take_artifacts(h):
+        lib = _lib()
+        try:
+            n = lib.nmn_results_len(h)
+            return [SimilarArtifact(lib.nmn_results_key(h, i).decode(), lib.nmn_results_aux(h, i).decode(),
+                                    float(np.float32(lib.nmn_results_score(h, i)))) for i in range(n)]
+        finally:
+            lib.nmn_results_free(h)
+
+    def blob_search_by_embedding(self, embedding, k):
+        a, p, n = _vec(embedding)
+        h = vp()
+        _check(_lib().nmn_engine_blob_search_by_embedding(self._h, p if n else None, n, int(k), C.byref(h)))
+        return self._take_artifacts(h)
+
+    def blob_similar(self, artifact_id, k):
+        h = vp()
+        _check(_lib().nmn_engine_blob_similar(self._h, artifact_id.encode(), int(k), C.byref(h)))
+        return self._take_artifacts(h)
 
     # ---- IVF (lib.rs:2641-2812) ----
     def build_ivf_index(self, options=None):

@@ -45,6 +45,7 @@
 #define ORC_COSINE 0
 #define ORC_EUCLIDEAN 1
 #define ORC_DOT 2
+#define ORC_SPARSE_COS64 3 /* tensor_blob artifact similarity: f64 sparse cosine (not a vector_engine metric) */
 
 /* ---------------------------------------------------------------- lane arithmetic */
 
@@ -114,9 +115,32 @@ float orc_cosine(const float* a, const float* b, uint64_t n, float a_mag) {
     return dot / den;
 }
 
+/* tensor_blob/src/lib.rs:601-603: SparseVector::from_dense(a).cosine_similarity(&SparseVector::from_dense(b)).
+ * from_dense keeps every value != 0.0 (sparse_vector.rs:221-229; NaN != 0.0 is true); dot_f64 walks the two
+ * position lists and adds f64(a)*f64(b) where both are stored (419-443); magnitude_f64 is the sqrt of the
+ * sequential f64 sum of squares of the stored values (553-559); cosine_similarity (583-599) returns 0.0 for a
+ * zero magnitude or a NaN/Inf quotient, else clamp(-1, 1) as f32. */
+float orc_sparse_cos64(const float* a, const float* b, uint64_t n) {
+    double dot = 0.0, sa = -0.0, sb = -0.0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (a[i] != 0.0f && b[i] != 0.0f) dot += (double)a[i] * (double)b[i];
+        if (a[i] != 0.0f) sa += (double)a[i] * (double)a[i];
+        if (b[i] != 0.0f) sb += (double)b[i] * (double)b[i];
+    }
+    double mag_a = sqrt(sa), mag_b = sqrt(sb);
+    if (mag_a == 0.0 || mag_b == 0.0) return 0.0f;
+    double r = dot / (mag_a * mag_b);
+    if (isnan(r) || isinf(r)) return 0.0f;
+    if (r < -1.0) r = -1.0;
+    if (r > 1.0) r = 1.0;
+    return (float)r;
+}
+
 /* lib.rs:2231-2246 */
 float orc_score(const float* q, const float* v, uint64_t n, float q_mag, int metric) {
     switch (metric) {
+        case ORC_SPARSE_COS64:
+            return orc_sparse_cos64(q, v, n);
         case ORC_COSINE:
             return orc_cosine(q, v, n, q_mag);
         case ORC_DOT:
@@ -231,7 +255,7 @@ int64_t orc_search(const float* corpus, uint64_t n, uint32_t d, const float* q, 
     if (d == 0) return -3;
     if (k == 0) return -4;
     float qmag = orc_magnitude(q, d);
-    if (qmag == 0.0f && metric != ORC_EUCLIDEAN) return 0;
+    if (qmag == 0.0f && (metric == ORC_COSINE || metric == ORC_DOT)) return 0;
     float* scores = (float*)malloc((n ? n : 1) * sizeof(float));
     if (!scores) return -22;
     orc_scores_all(corpus, n, d, q, metric, mask, scores, nthreads);
@@ -298,7 +322,7 @@ int64_t orc_search_partial(const float* corpus, uint64_t n, uint32_t d, const fl
     if (d == 0) return -3;
     if (k == 0) return -4;
     float qmag = orc_magnitude(q, d);
-    if (qmag == 0.0f && metric != ORC_EUCLIDEAN) return 0;
+    if (qmag == 0.0f && (metric == ORC_COSINE || metric == ORC_DOT)) return 0;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     orc_tk_job jobs[256];

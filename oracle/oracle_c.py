@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-COSINE, EUCLIDEAN, DOT = 0, 1, 2
+COSINE, EUCLIDEAN, DOT, SPARSE_COS64 = 0, 1, 2, 3
 
 _f32p = C.POINTER(C.c_float)
 _u64p = C.POINTER(C.c_uint64)
@@ -33,6 +33,8 @@ def _bind(lib):
     lib.orc_cosine.argtypes = [_f32p, _f32p, C.c_uint64, C.c_float]
     lib.orc_score.restype = C.c_float
     lib.orc_score.argtypes = [_f32p, _f32p, C.c_uint64, C.c_float, C.c_int]
+    lib.orc_sparse_cos64.restype = C.c_float
+    lib.orc_sparse_cos64.argtypes = [_f32p, _f32p, C.c_uint64]
     lib.orc_compute_similarity.restype = C.c_float
     lib.orc_compute_similarity.argtypes = [_f32p, _f32p, C.c_uint64]
     lib.orc_scores_all.restype = None
@@ -91,6 +93,12 @@ def magnitude(v):
 def euclidean_seq(a, b):
     a, b = _f32(a), _f32(b)
     return np.float32(lib().orc_euclidean_seq(_p(a, _f32p), _p(b, _f32p), a.size))
+
+
+def sparse_cos64(a, b):
+    """tensor_blob artifact similarity: SparseVector::cosine_similarity of the two from_dense'd vectors."""
+    a, b = _f32(a), _f32(b)
+    return np.float32(lib().orc_sparse_cos64(_p(a, _f32p), _p(b, _f32p), a.size))
 
 
 def compute_similarity(a, b):

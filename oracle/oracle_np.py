@@ -8,7 +8,7 @@ generate the committed fixtures under tests/golden/ (tests/golden/make_golden.py
 """
 import numpy as np
 
-COSINE, EUCLIDEAN, DOT = 0, 1, 2
+COSINE, EUCLIDEAN, DOT, SPARSE_COS64 = 0, 1, 2, 3
 F = np.float32
 
 
@@ -69,10 +69,36 @@ def euclid_rows(A, q):
     return np.sqrt(s)
 
 
+def sparse_cos64_rows(A, q):
+    """tensor_blob artifact similarity for every row (tensor_blob/src/lib.rs:601-603; sparse_vector.rs:419-443,
+    553-559, 583-599): sequential f64 sums over the positions both vectors store (value != 0.0)."""
+    A = np.asarray(A, dtype=F)
+    q = np.asarray(q, dtype=F)
+    n = A.shape[0]
+    dot = np.zeros(n, np.float64)
+    sa = np.float64(0.0)
+    sb = np.zeros(n, np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for i in range(A.shape[1]):
+            x, y = np.float64(q[i]), A[:, i].astype(np.float64)
+            sx, sy = q[i] != 0, A[:, i] != 0
+            if sx:
+                sa = sa + x * x
+                dot = dot + np.where(sy, x * y, 0.0)
+            sb = sb + np.where(sy, y * y, 0.0)
+        mag_a, mag_b = np.sqrt(sa), np.sqrt(sb)
+        r = dot / (mag_a * mag_b)
+    out = np.where(np.isnan(r) | np.isinf(r), 0.0, np.clip(r, -1.0, 1.0))
+    out[(mag_b == 0) | (mag_a == 0)] = 0.0
+    return out.astype(F)
+
+
 def scores(A, q, metric):
     """compute_score for every row (lib.rs:2231-2266)."""
     A = np.asarray(A, dtype=F)
     q = np.asarray(q, dtype=F)
+    if metric == SPARSE_COS64:
+        return sparse_cos64_rows(A, q)
     if metric == DOT:
         return _lanes_dot(A, q)
     if metric == EUCLIDEAN:
@@ -95,7 +121,7 @@ def search(A, q, k, metric=COSINE, keep=None, row_base=0):
         raise ValueError("EmptyVector")
     if k == 0:
         raise ValueError("InvalidTopK")
-    if magnitude(q) == 0 and metric != EUCLIDEAN:
+    if magnitude(q) == 0 and metric in (COSINE, DOT):
         return np.zeros(0, np.uint64), np.zeros(0, F)
     s = scores(A, q, metric) if A.shape[0] else np.zeros(0, F)
     rows = np.arange(A.shape[0], dtype=np.uint64)

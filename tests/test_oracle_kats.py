@@ -186,3 +186,28 @@ def test_mask_is_prefilter_semantics():  # search_with_pre_filter, lib.rs:3514-3
     sub_rows, sub_scores = oc.search(A[keep], q, 10, COS)
     assert np.array_equal(np.flatnonzero(keep)[sub_rows.astype(np.int64)], rows.astype(np.int64))
     assert np.array_equal(sub_scores, scores)
+
+
+# ---- tensor_blob artifact similarity: SparseVector::cosine_similarity in f64 (sparse_vector.rs:1320-1375) ----
+def test_sparse_cos64_kats():
+    f = oc.sparse_cos64
+    assert abs(f([1.0, 2.0, 3.0], [1.0, 2.0, 3.0]) - 1.0) < 1e-6          # cosine_similarity_identical
+    assert abs(f([1.0, 0.0], [0.0, 1.0])) < 1e-6                          # cosine_similarity_orthogonal
+    assert f([1.0, 2.0, 3.0], [0.0, 0.0, 0.0]) == 0.0                     # zero_vector_returns_zero
+    assert f([0.0, 0.0, 0.0], [0.0, 0.0, 0.0]) == 0.0                     # both_zero_returns_zero
+    r = f([1.0, 2.0, 3.0], [1.0, 2.0, 3.0])                               # clamps_to_valid_range
+    assert -1.0 <= r <= 1.0 and abs(r - 1.0) < 1e-6
+    assert abs(f([1.0, 0.0, 0.0], [-1.0, 0.0, 0.0]) + 1.0) < 1e-6         # opposite_returns_negative_one
+    # sanitisation (sparse_vector.rs:593-598): NaN/Inf quotients become 0.0; f64 keeps huge f32 values finite
+    assert f([np.nan, 1.0], [0.0, 1.0]) == 0.0 and f([np.inf, 1.0], [1.0, 1.0]) == 0.0
+    assert f([3e38, 3e38], [3e38, 3e38]) == 1.0
+    # a NaN opposite a zero is never multiplied (the position is not stored on the other side) ...
+    assert f([1.0, 2.0], [np.nan, 0.0]) == 0.0      # ... but it still poisons its own magnitude
+    # C restatement == numpy twin on random sparse data, bit for bit
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((200, 37)).astype(np.float32) * (rng.random((200, 37)) < 0.4)
+    q = (rng.standard_normal(37) * (rng.random(37) < 0.6)).astype(np.float32)
+    a = np.array([f(q, row) for row in A], np.float32)
+    assert np.array_equal(a, onp.sparse_cos64_rows(A, q))
+    assert np.array_equal(a, oc.scores_all(A, q, oc.SPARSE_COS64))
