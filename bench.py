@@ -190,7 +190,8 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
             c = certificate(idx, qh[qi], metric, rows.view(np.uint64)[qi:qi + 1], scores[qi:qi + 1], counts[qi:qi + 1],
                             1, dev)
             ok = ok and c["exact_topk_certified"]
-    sweeps = (nq + 63) // 64
+    per_sweep = 64 if args.dim // 128 <= 6 else 32
+    sweeps = (nq + per_sweep - 1) // per_sweep
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
     gbps = idx.rows * args.dim * 4 * sweeps / (sweep * 1e-3) / 1e9
     return {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
@@ -297,10 +298,13 @@ def main():
     idx.set_timing(False)
     fence()
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
-    # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 5 queries, cosine/dot, dim % 128 == 0,
-    # dim <= 768), else 4 (VALU) — mirrors search_enqueue() in neumann_amd/csrc/nmn_api.hip
-    mfma = args.nq >= 5 and args.metric in ("cosine", "dot") and args.dim % 128 == 0 and args.dim <= 768 and args.k <= 4096
-    passes = (args.nq + 63) // 64 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
+    # corpus sweeps per step: 64 (dim <= 768) or 32 (1024/1280/1536) queries per sweep on the MFMA path (>= 5
+    # queries, cosine/dot), else 4 (VALU) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
+    kc = args.dim // 128
+    mfma = (args.nq >= 5 and args.metric in ("cosine", "dot") and args.dim % 128 == 0 and (kc <= 6 or kc in (8, 10, 12))
+            and args.k <= 4096)
+    per_sweep = 64 if kc <= 6 else 32  # stationary queries of the MFMA sweep (scan_mfma_queries_per_sweep)
+    passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
     alg_bytes = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read

@@ -104,6 +104,7 @@ struct ScanParams {
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
+uint32_t scan_mfma_queries_per_sweep(uint32_t ld);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
 // (re)build rows [row0,row0+n) of the split-bf16 mirror from the f32 corpus
 hipError_t launch_split_rows(const float* corpus, float* split, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s);

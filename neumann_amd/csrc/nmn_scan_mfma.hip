@@ -29,6 +29,8 @@
 //     and B use the same one;
 //   * epilogue per tile: scores (float4 per lane), per-(query,tile) maxima, per-(query,block) maxima —
 //     the same three-level hierarchy select_kernel consumes after the VALU scan.
+// Rows longer than 768 floats (up to 1536) keep HALF the queries stationary (QG = 2 groups of 16: the
+// B-fragments still cost 192 VGPRs) and sweep the corpus once per 32 queries.
 // Cosine and dot product only: the Euclidean score needs |x-q|^2, whose expansion cancels
 // catastrophically for near neighbours; Euclidean batches use the VALU kernel (4 queries per sweep).
 #include "nmn_internal.h"
@@ -39,7 +41,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef short s8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaQ = 64;       // queries per sweep
+constexpr int kMfmaQ = 64;       // queries per sweep when 4 query groups fit the registers (dim <= 768)
 constexpr int kStageK = 128;     // floats of every row per LDS stage
 constexpr int kStageBytes = kTileRows * kStageK * 4;  // 32 KiB
 
@@ -112,7 +114,8 @@ __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
 // VALU-bound at 12 VALU per MFMA).  Its 64 queries x 32 k stationary B-fragments cost KC*32 VGPRs
 // (192 at dim 768), the 4 row-blocks x 4 query-groups of accumulators 64.  The four K-quarter partial
 // sums of a tile meet once per tile through LDS; wave w then finishes query group w.
-template <int KC, int METRIC, bool MASKED, int AUX>
+// QG = query groups of 16 kept stationary (4: 64 queries per sweep, 2: 32).  Waves 0..QG-1 finish one group each.
+template <int KC, int QG, int METRIC, bool MASKED, int AUX>
 __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | exchange | norms
     float* xch = lds + kRing * (kStageBytes / 4);                // [4 src waves][64 lanes][4 rb] f4, reused per round
@@ -122,12 +125,12 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
     const uint32_t ld = p.ld;
-    const uint32_t q0 = blockIdx.y * kMfmaQ;
+    const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
 
-    // ---- stationary operand: 64 queries x this wave's k-step of every stage --------------------
-    s8 bhi[KC][4], blo[KC][4];
+    // ---- stationary operand: QG*16 queries x this wave's k-step of every stage -----------------
+    s8 bhi[KC][QG], blo[KC][QG];
 #pragma unroll
-    for (int qg = 0; qg < 4; qg++) {
+    for (int qg = 0; qg < QG; qg++) {
         const uint32_t qq = q0 + (uint32_t)qg * 16u + n;
         const bool ok = qq < p.nq;
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         }
     }
     const uint32_t qn = q0 + wave * 16u + n;  // the query this lane FINISHES (C column of group `wave`)
-    const bool q_ok = qn < p.nq;
+    const bool q_ok = wave < (uint32_t)QG && qn < p.nq;
     const float qmag = q_ok ? p.qinfo[qn].qmag : 0.f;
     const uint32_t skip = (q_ok && p.skip_key) ? p.skip_key[qn] : kKeyNaN;  // kKeyNaN: write every tile
 
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     uint32_t wmax = kKeyMasked;
     uint32_t sidx = 0;  // running stage index of this workgroup
     for (uint32_t tile = t0; tile < t1; tile++) {
-        f4 acc[4][4];  // [row block][query group]
+        f4 acc[4][4];  // [row block][query group]; groups >= QG stay zero and are never published
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
@@ -205,7 +208,6 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                     stage_dma<AUX>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
                 }
             }
-            if (p.metric & 0x100) continue;  // tuning probe (NMN_MFMA_DEBUG=1): stream only, no LDS reads / MFMAs
             // A fragments straight from the split-bf16 stage: chunk g of this wave's k-step holds 8 hi
             // values, chunk 4+g the matching 8 lo values (both one ds_read_b128)
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 const s8 ahi = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kStageK + off0));
                 const s8 alo = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kStageK + off1));
 #pragma unroll
-                for (int qg = 0; qg < 4; qg++) {
+                for (int qg = 0; qg < QG; qg++) {
                     acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
                     acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[kc][qg], acc[rb][qg], 0, 0, 0);
                     acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
@@ -226,8 +228,10 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         // (w+1+j) % 4 and collects, from wave (w-1-j) % 4, that wave's partial of group w.
         f4 fin[4];
 #define NMN_XCH_PUT(W, J)                                                                          \
-    _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                               \
-        *reinterpret_cast<f4*>(xch + (((W) * 64u + lane) * 4u + (uint32_t)rb) * 4u) = acc[rb][((W) + 1 + (J)) & 3];
+    if ((((W) + 1 + (J)) & 3) < QG) {                                                              \
+        _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                           \
+            *reinterpret_cast<f4*>(xch + (((W) * 64u + lane) * 4u + (uint32_t)rb) * 4u) = acc[rb][((W) + 1 + (J)) & 3]; \
+    }
 #define NMN_XCH_ROUND(J)                                                                           \
     switch (wave) {                                                                                \
         case 0: NMN_XCH_PUT(0, J) break;                                                           \
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
     __builtin_amdgcn_s_barrier();                                                                  \
     asm volatile("" ::: "memory");                                                                 \
-    {                                                                                              \
+    if (wave < (uint32_t)QG) {                                                                     \
         const uint32_t src = (wave + 3u - (uint32_t)(J)) & 3u;                                     \
         _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                           \
             fin[rb] += *reinterpret_cast<const f4*>(xch + ((src * 64u + lane) * 4u + (uint32_t)rb) * 4u); \
@@ -303,7 +307,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             // Scores are only worth their HBM write when the tile can still hold a candidate: with a
             // per-query bound from the sampling pass ~2 % of the tiles qualify (64 queries x 10M rows would
             // otherwise write 2.56 GB per sweep, measured at +1.45 ms on a 5.3 ms sweep).
-            if (q_ok && !sampling && !(p.metric & 0x200) && tkey != kKeyMasked && tkey >= skip) {
+            if (q_ok && !sampling && tkey != kKeyMasked && tkey >= skip) {
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++)
                     *reinterpret_cast<u4*>(p.scores + score_at(r0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = bits[rb];
@@ -314,12 +318,12 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     if (q_ok && g == 0) p.wmax[(size_t)qn * p.wmax_stride + blockIdx.x] = wmax;
 }
 
-template <int KC, int METRIC, bool MASKED, int AUX>
+template <int KC, int QG, int METRIC, bool MASKED>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
-    dim3 grid(blocks, (p.nq + kMfmaQ - 1) / kMfmaQ);
+    dim3 grid(blocks, (p.nq + QG * 16 - 1) / (QG * 16));
     const size_t lds = kRing * kStageBytes + 4 * 64 * 16 * 4 + kRing * 64 * 4;
-    auto kern = scan_mfma_kernel<KC, METRIC, MASKED, AUX>;
+    auto kern = scan_mfma_kernel<KC, QG, METRIC, MASKED, 2>;  // AUX = 2: non-temporal LDS-DMA (the corpus is read once)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -327,23 +331,23 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int KC, int METRIC>
+template <int KC, int QG, int METRIC>
 static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
-    // non-temporal LDS-DMA (the corpus is read once per sweep); NMN_MFMA_NT=0 restores the default policy
-    static const bool nt = !(getenv("NMN_MFMA_NT") && getenv("NMN_MFMA_NT")[0] == '0');
-    if (p.mask) return nt ? launch_one_mfma<KC, METRIC, true, 2>(p, s) : launch_one_mfma<KC, METRIC, true, 0>(p, s);
-    return nt ? launch_one_mfma<KC, METRIC, false, 2>(p, s) : launch_one_mfma<KC, METRIC, false, 0>(p, s);
+    return p.mask ? launch_one_mfma<KC, QG, METRIC, true>(p, s) : launch_one_mfma<KC, QG, METRIC, false>(p, s);
 }
 
 template <int METRIC>
 static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
     switch (p.ld / kStageK) {
-        case 1: return launch_kc<1, METRIC>(p, s);
-        case 2: return launch_kc<2, METRIC>(p, s);
-        case 3: return launch_kc<3, METRIC>(p, s);
-        case 4: return launch_kc<4, METRIC>(p, s);
-        case 5: return launch_kc<5, METRIC>(p, s);
-        case 6: return launch_kc<6, METRIC>(p, s);
+        case 1: return launch_kc<1, 4, METRIC>(p, s);
+        case 2: return launch_kc<2, 4, METRIC>(p, s);
+        case 3: return launch_kc<3, 4, METRIC>(p, s);
+        case 4: return launch_kc<4, 4, METRIC>(p, s);
+        case 5: return launch_kc<5, 4, METRIC>(p, s);
+        case 6: return launch_kc<6, 4, METRIC>(p, s);
+        case 8: return launch_kc<8, 2, METRIC>(p, s);    // 1024
+        case 10: return launch_kc<10, 2, METRIC>(p, s);  // 1280
+        case 12: return launch_kc<12, 2, METRIC>(p, s);  // 1536
         default: return hipErrorInvalidValue;
     }
 }
@@ -377,21 +381,21 @@ hipError_t launch_split_rows(const float* corpus, float* split, uint32_t ld, uin
     return hipGetLastError();
 }
 
-// Can the MFMA sweep serve this shape?  (cosine / dot, row length a multiple of 128 floats up to 768
-// so that the 16 stationary queries of a wave fit its VGPRs.)
+// Can the MFMA sweep serve this shape?  Cosine / dot, row length a multiple of 128 floats: up to 768 with 64
+// stationary queries per sweep, 1024 / 1280 / 1536 with 32 (the stationary B-fragments must fit 192 VGPRs).
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
-    return (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT) && ld == dim && ld % kStageK == 0 &&
-           ld / kStageK >= 1 && ld / kStageK <= 6;
+    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT) || ld != dim || ld % kStageK != 0) return false;
+    const uint32_t kc = ld / kStageK;
+    return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12;
 }
 
+// queries one corpus sweep of the MFMA kernel serves at this row length
+uint32_t scan_mfma_queries_per_sweep(uint32_t ld) { return ld / kStageK <= 6 ? 64u : 32u; }
+
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
-hipError_t launch_scan_mfma(const ScanParams& p0, hipStream_t s) {
-    ScanParams p = p0;
-    static const int dbg = getenv("NMN_MFMA_DEBUG") ? atoi(getenv("NMN_MFMA_DEBUG")) : 0;  // tuning probes
-    const bool cosine = p.metric == NMN_METRIC_COSINE;
-    if (dbg & 1) p.metric |= 0x100;  // stream only
-    if (dbg & 2) p.metric |= 0x200;  // no score stores
-    return cosine ? launch_metric<NMN_METRIC_COSINE>(p, s) : launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
+    return p.metric == NMN_METRIC_COSINE ? launch_metric<NMN_METRIC_COSINE>(p, s)
+                                         : launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
 }
 
 }  // namespace nmn
