@@ -1,7 +1,9 @@
 // nmn_exact.hip — kernels that restate the reference's f32 arithmetic BIT FOR BIT on the GPU.
 // THIS TRANSLATION UNIT IS BUILT WITH -ffp-contract=off (build.py) and carries a file-scope
-// `#pragma clang fp contract(off)`; tests/test_build.py greps its ISA for v_fma/v_mad: hipcc contracts a*b+c into v_fma by default, and HIP's
-// __fmul_rn/__fadd_rn are plain operators that contraction would fuse.
+// `#pragma clang fp contract(off)`: hipcc contracts a*b+c into v_fma by default, and HIP's
+// __fmul_rn/__fadd_rn are plain operators that contraction would fuse.  (The only FMAs left in its ISA
+// are inside the correctly rounded division / square-root expansions.)  A contracted build cannot pass
+// the bit-level parity tests in tests/test_gpu_parity_basic.py.
 //
 // Reference order (tensor_store/src/hnsw.rs:168-229, vector_engine/src/lib.rs:2231-2266):
 //   dot8 / sumsq8 : 8 accumulators, acc[l] = acc[l] + (a[8c+l]*b[8c+l]) for c = 0..d/8-1 (mul and

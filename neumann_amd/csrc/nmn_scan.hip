@@ -53,6 +53,51 @@ __device__ __forceinline__ v4f load4(const v4f* p) {
     else return *p;
 }
 
+// dot (or squared-difference sum) of ONE corpus row against NQ staged queries, this lane's share:
+// lane j of a 16-lane DPP row takes float4 columns j, j+16, ...; the caller reduces across the row.
+template <int METRIC, int NQ, int CH, bool FULL, bool NT>
+__device__ __forceinline__ void row_partial(const v4f* __restrict__ rowp, bool active, uint32_t j, uint32_t ld4,
+                                            const v4f* __restrict__ qs4, float (&acc)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = 0.f;
+    for (uint32_t c0 = 0; c0 < ld4; c0 += 16u * CH) {
+        v4f x[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t col = c0 + (uint32_t)c * 16u + j;
+            const bool ok = (FULL || col < ld4) && active;
+            if (ok) x[c] = load4<NT>(rowp + col);
+            else x[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            uint32_t col = c0 + (uint32_t)c * 16u + j;
+            if constexpr (!FULL) col = min(col, ld4 - 1u);  // x is zero there; keep the LDS read in range
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const v4f qv = qs4[(uint32_t)q * ld4 + col];
+                if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                    const v4f d = x[c] - qv;
+                    acc[q] = __builtin_fmaf(d.x, d.x, acc[q]);
+                    acc[q] = __builtin_fmaf(d.y, d.y, acc[q]);
+                    acc[q] = __builtin_fmaf(d.z, d.z, acc[q]);
+                    acc[q] = __builtin_fmaf(d.w, d.w, acc[q]);
+                } else {
+                    acc[q] = __builtin_fmaf(x[c].x, qv.x, acc[q]);
+                    acc[q] = __builtin_fmaf(x[c].y, qv.y, acc[q]);
+                    acc[q] = __builtin_fmaf(x[c].z, qv.z, acc[q]);
+                    acc[q] = __builtin_fmaf(x[c].w, qv.w, acc[q]);
+                }
+            }
+        }
+    }
+}
+
+// Sparse predicate bitmaps (a selective WHERE, an IVF probe): a tile with at most this many participating rows
+// is processed in COMPACTED steps — the 4 DPP rows of the wave always read 4 participating corpus rows — instead
+// of 16 fixed steps in which most 16-lane groups would idle and the wave would keep a quarter of its loads in flight.
+constexpr uint32_t kCompactMaxRows = 40;
+
 // METRIC: nmn_metric.  MASKED: predicate bitmap present.  NQ: queries per pass over the corpus.
 // CH: float4 loads per lane per chunk (CH KiB in flight per wave).  FULL: ld4 % (16*CH) == 0, no
 // column predicate.  NT: non-temporal corpus loads.
@@ -100,53 +145,55 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
 
-#pragma unroll 2
-        for (uint32_t s = 0; s < 16; s++) {
-            if constexpr (MASKED) {
-                if (((mword >> (s * 4)) & 0xFull) == 0) continue;  // wave-uniform: 4 rows all excluded
-            }
-            const uint32_t rbit = s * 4 + grp;
-            const bool active = MASKED ? ((mword >> rbit) & 1ull) != 0 : true;
-            const v4f* rowp = reinterpret_cast<const v4f*>(p.corpus + (r0 + rbit) * (uint64_t)ld);
-            float acc[NQ];
+        bool compacted = false;
+        if constexpr (MASKED) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(mword);
+            if (cnt <= kCompactMaxRows) {  // wave-uniform
+                compacted = true;
+                float* stg = qs + (size_t)NQ * ld + (threadIdx.x >> 6) * (NQ * 64);  // this wave's [NQ][64] staging
+                const bool myset = ((mword >> lane) & 1ull) != 0;
+                const uint32_t myrank = (uint32_t)__builtin_popcountll(mword & ((1ull << lane) - 1ull));
+                for (uint32_t s0 = 0; s0 < cnt; s0 += 4) {
+                    uint32_t pos = 0;  // bit of the participating row of rank s0 + grp
 #pragma unroll
-            for (int q = 0; q < NQ; q++) acc[q] = 0.f;
-
-            for (uint32_t c0 = 0; c0 < ld4; c0 += 16u * CH) {
-                v4f x[CH];
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    const uint32_t col = c0 + (uint32_t)c * 16u + j;
-                    const bool ok = (FULL || col < ld4) && active;
-                    if (ok) x[c] = load4<NT>(rowp + col);
-                    else x[c] = (v4f){0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    uint32_t col = c0 + (uint32_t)c * 16u + j;
-                    if constexpr (!FULL) col = min(col, ld4 - 1u);  // x is zero there; keep the LDS read in range
+                    for (uint32_t g2 = 0; g2 < 4; g2++) {
+                        const uint64_t b = __ballot(myset && myrank == s0 + g2);
+                        if (grp == g2) pos = b ? (uint32_t)__builtin_ctzll(b) : 0u;
+                    }
+                    const bool active = s0 + grp < cnt;
+                    const v4f* rowp = reinterpret_cast<const v4f*>(p.corpus + (r0 + pos) * (uint64_t)ld);
+                    float acc[NQ];
+                    row_partial<METRIC, NQ, CH, FULL, NT>(rowp, active, j, ld4, qs4, acc);
 #pragma unroll
                     for (int q = 0; q < NQ; q++) {
-                        const v4f qv = qs4[(uint32_t)q * ld4 + col];
-                        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
-                            const v4f d = x[c] - qv;
-                            acc[q] = __builtin_fmaf(d.x, d.x, acc[q]);
-                            acc[q] = __builtin_fmaf(d.y, d.y, acc[q]);
-                            acc[q] = __builtin_fmaf(d.z, d.z, acc[q]);
-                            acc[q] = __builtin_fmaf(d.w, d.w, acc[q]);
-                        } else {
-                            acc[q] = __builtin_fmaf(x[c].x, qv.x, acc[q]);
-                            acc[q] = __builtin_fmaf(x[c].y, qv.y, acc[q]);
-                            acc[q] = __builtin_fmaf(x[c].z, qv.z, acc[q]);
-                            acc[q] = __builtin_fmaf(x[c].w, qv.w, acc[q]);
-                        }
+                        const float t = row16_sum(acc[q]);
+                        if (j == 0 && active) stg[q * 64 + (int)pos] = t;
                     }
                 }
-            }
+                // hand every result to the lane that finishes its row (lane L <- tile row (L&15)*4 + (L>>4))
+                const uint32_t bit = j * 4u + grp;
+                if ((mword >> bit) & 1ull) {
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const float t = row16_sum(acc[q]);
-                if (j == s) mydot[q] = t;
+                    for (int q = 0; q < NQ; q++) mydot[q] = stg[q * 64 + (int)bit];
+                }
+            }
+        }
+        if (!compacted) {
+#pragma unroll 2
+            for (uint32_t s = 0; s < 16; s++) {
+                if constexpr (MASKED) {
+                    if (((mword >> (s * 4)) & 0xFull) == 0) continue;  // wave-uniform: 4 rows all excluded
+                }
+                const uint32_t rbit = s * 4 + grp;
+                const bool active = MASKED ? ((mword >> rbit) & 1ull) != 0 : true;
+                const v4f* rowp = reinterpret_cast<const v4f*>(p.corpus + (r0 + rbit) * (uint64_t)ld);
+                float acc[NQ];
+                row_partial<METRIC, NQ, CH, FULL, NT>(rowp, active, j, ld4, qs4, acc);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const float t = row16_sum(acc[q]);
+                    if (j == s) mydot[q] = t;
+                }
             }
         }
 
@@ -194,7 +241,8 @@ template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT>
 static hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
-    const size_t lds = (size_t)NQ * p.ld * sizeof(float);
+    // queries, plus (masked kernels) one [NQ][64] staging array per wave for the compacted tiles
+    const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) : 0);
     auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
