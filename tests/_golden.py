@@ -29,3 +29,37 @@ def rebuild_corpus(g, synth_fn):
     if g["planted_idx"].size:
         A[g["planted_idx"]] = g["planted"]
     return A
+
+
+# ---- fixtures of the widened rows (tests/golden/make_golden_next.py) ---------------------------------------
+def _dec(v):
+    tag = v[0]
+    if tag == "null":
+        return None
+    if tag == "bool":
+        return bool(v[1])
+    if tag == "int":
+        return int(v[1])
+    if tag == "float":
+        return float.fromhex(v[1])
+    return v[1]
+
+
+def _dec_cond(c):
+    op = c[0]
+    if op in ("and", "or"):
+        return (op, _dec_cond(c[1]), _dec_cond(c[2]))
+    if op == "in":
+        return (op, c[1], [_dec(v) for v in c[2]])
+    if op in ("eq", "ne", "lt", "le", "gt", "ge"):
+        return (op, c[1], _dec(c[2]))
+    return tuple(c)
+
+
+def load_filters():
+    """-> (rows: list of metadata dicts, cases: list of (condition tuple, selected row indices))."""
+    import json
+    with open(os.path.join(GOLDEN, "filters_mixed.json")) as fh:
+        doc = json.load(fh)
+    rows = [{k: _dec(v) for k, v in r.items()} for r in doc["rows"]]
+    return rows, [(_dec_cond(c["cond"]), c["selected"]) for c in doc["cases"]]

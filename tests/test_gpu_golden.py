@@ -105,3 +105,62 @@ def test_sharded_indexes_merge_to_unsharded():
     finally:
         for idx in shards:
             idx.close()
+
+
+# ---- widened rows against their committed fixtures (tests/golden/make_golden_next.py) ------------------------
+def test_filters_golden_through_the_predicate_kernel():
+    from neumann_amd import engine as E
+    from tests.test_gpu_filter import to_fc
+    rows, cases = G.load_filters()
+    n, d = len(rows), 8
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    eng = E.VectorEngine()
+    for i, meta in enumerate(rows):
+        eng.store_embedding_with_metadata(f"k{i}", A[i], meta)
+    q = rng.standard_normal(d).astype(np.float32)
+    for cond, selected in cases:
+        res = eng.search_similar_filtered(q, n, to_fc(E, cond), E.FilteredSearchConfig.pre_filter())
+        assert sorted(int(r.key[1:]) for r in res) == selected, cond       # top_k = n: exactly the selected rows
+    assert eng.device_filter_evals() == len(cases)
+
+
+def test_ivf_golden_on_the_gpu():
+    from neumann_amd.ivf import GpuIvfFlat
+    g = G.load("ivf_flat_small.npz")
+    V, Q = g["V"], g["Q"]
+    for tag in ("rnd", "pp"):
+        with GpuIvfFlat(g[f"centroids_{tag}"], capacity_rows=len(V), nprobe=3) as ivf:
+            assert np.array_equal(ivf.add(V), g[f"assign_{tag}"])
+            for qi in range(6):
+                for nprobe in (1, 3, 10):
+                    ids, dist, counts = ivf.search(Q[qi], 15, nprobe)
+                    exp = g[f"ids_{tag}_q{qi}_p{nprobe}"]
+                    assert counts[0] == exp.size and np.array_equal(ids[0, :exp.size], exp)
+                    assert np.array_equal(dist[0, :exp.size], g[f"dist_{tag}_q{qi}_p{nprobe}"])
+
+
+def test_sparse_cos64_golden_on_the_gpu():
+    from neumann_amd import GpuFlatIndex
+    g = G.load("sparse_cos64_small.npz")
+    A, Q = g["A"], g["Q"]
+    with GpuFlatIndex(A.shape[1], A.shape[0]) as idx:
+        idx.upload(A)
+        rows, scores, counts = idx.search(Q, 20, 3)
+        for qi in range(5):
+            assert counts[qi] == 20 and np.array_equal(rows[qi], g[f"rows_q{qi}"])
+            assert np.array_equal(scores[qi], g[f"scores_q{qi}"])
+
+
+def test_engine_kmeans_matches_golden_centroids():
+    """The C++ k-means port (nmn_engine.cpp) reproduces the committed centroids bit for bit."""
+    from neumann_amd import engine as E
+    g = G.load("ivf_flat_small.npz")
+    V = g["V"]
+    eng = E.VectorEngine()
+    eng.batch_store_embeddings([f"k{i:04d}" for i in range(len(V))], V)
+    for init, tag in (("random", "rnd"), ("kmeans++", "pp")):
+        index, keys = eng.build_ivf_index(E.IVFBuildOptions(num_clusters=10, nprobe=3, max_iterations=8,
+                                                            convergence_threshold=1e-4, seed=4242, init_method=init))
+        assert keys == [f"k{i:04d}" for i in range(len(V))]       # list_keys() order = insertion order here
+        assert np.array_equal(index.centroids(V.shape[1]), g[f"centroids_{tag}"])
