@@ -1,0 +1,87 @@
+// Pure HBM read-bandwidth probe for MI355X: what a streaming kernel can reach with no compute at all.
+//   hipcc --offload-arch=gfx950 -O3 -o read_bw read_bw.hip && ./read_bw [GiB]
+// Variants: loads in flight per lane (U x 16 B), non-temporal or default policy, waves per CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void read_kernel(const v4f* __restrict__ src, size_t n4, float* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        v4f x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += x[u];
+    }
+    for (; i < n4; i += stride) acc += src[i];
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;  // never true: keeps the loads alive
+}
+
+// each wave reads CONTIGUOUS 3 KiB rows the way the scan does (16 lanes per row, 4 rows per step)
+template <int CH, bool NT>
+__global__ __launch_bounds__(256) void read_rows_kernel(const v4f* __restrict__ src, size_t n_rows, uint32_t ld4,
+                                                        float* __restrict__ sink) {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, grp = lane >> 4;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t rows_per_wave = (n_rows + n_waves - 1) / n_waves;
+    const size_t r0 = wave * rows_per_wave, r1 = r0 + rows_per_wave < n_rows ? r0 + rows_per_wave : n_rows;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t r = r0 + grp; r < r1; r += 4) {
+        const v4f* rowp = src + r * ld4;
+        for (uint32_t c0 = 0; c0 < ld4; c0 += 16u * CH) {
+            v4f x[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) x[c] = NT ? __builtin_nontemporal_load(rowp + c0 + c * 16 + j) : rowp[c0 + c * 16 + j];
+#pragma unroll
+            for (int c = 0; c < CH; c++) acc += x[c];
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <typename L>
+static float time_ms(L launch, int reps) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; i++) launch();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const double gib = argc > 1 ? atof(argv[1]) : 28.6;
+    const size_t bytes = (size_t)(gib * (1ull << 30)) / 3072 * 3072;
+    void* buf; float* sink;
+    CK(hipMalloc(&buf, bytes)); CK(hipMalloc((void**)&sink, 4));
+    CK(hipMemset(buf, 1, bytes));
+    const size_t n4 = bytes / 16;
+    const v4f* src = (const v4f*)buf;
+    printf("buffer %.2f GB\n", bytes / 1e9);
+    for (int waves_per_cu : {8, 16, 32}) {
+        const int blocks = 256 * waves_per_cu / 4;
+#define RUN(U, NT) { float ms = time_ms([&] { hipLaunchKernelGGL((read_kernel<U, NT>), dim3(blocks), dim3(256), 0, 0, src, n4, sink); }, 5); \
+                     printf("grid-stride  waves/CU %2d  U %2d  %s : %7.3f ms  %6.0f GB/s\n", waves_per_cu, U, NT ? "nt " : "def", ms, bytes / ms / 1e6); }
+        RUN(4, false) RUN(4, true) RUN(8, true) RUN(12, true) RUN(16, true)
+    }
+    const size_t n_rows = bytes / 3072;
+    for (int waves_per_cu : {8, 16, 32}) {
+        const int blocks = 256 * waves_per_cu / 4;
+#define RUNR(CH, NT) { float ms = time_ms([&] { hipLaunchKernelGGL((read_rows_kernel<CH, NT>), dim3(blocks), dim3(256), 0, 0, src, n_rows, 192u, sink); }, 5); \
+                       printf("row-major    waves/CU %2d  CH %2d  %s : %7.3f ms  %6.0f GB/s\n", waves_per_cu, CH, NT ? "nt " : "def", ms, bytes / ms / 1e6); }
+        RUNR(12, true) RUNR(12, false) RUNR(6, true)
+    }
+    return 0;
+}
