@@ -422,7 +422,14 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 return (uint32_t)std::min<long>(std::max<long>(v, 256), (long)kMaxScanWaves);
             }();
             sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + wave_target - 1) / wave_target);
-            if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + 255) / 256);  // per workgroup, 1 per CU
+            // workgroups of the MFMA sweep: 4 per CU in sequence (one resident at a time) evens out the CUs' finish
+            // times; measured 256 -> 1024: -2 % sweep time, 2048: worse (ring ramp-up per workgroup).  Knob: NMN_MFMA_WGS
+            static const uint32_t mfma_wgs = [] {
+                const char* e = getenv("NMN_MFMA_WGS");
+                long v = e ? atol(e) : 1024;
+                return (uint32_t)std::min<long>(std::max<long>(v, 64), (long)kMaxScanWaves);
+            }();
+            if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
             sp.metric = (int)metric;
             sp.tile_step = 1;
             sp.skip_key = nullptr;
