@@ -47,6 +47,45 @@ __global__ __launch_bounds__(256) void read_rows_kernel(const v4f* __restrict__ 
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
 }
 
+
+// the access pattern of an MFMA sweep that loads A-fragments straight into registers: workgroup = 4 waves,
+// wave w owns the 128-byte k-step w of every 512-byte stage of a row; lane (n = lane & 15, g = lane >> 4) reads
+// 16 B at row n of a 16-row block, offset g*16 (hi half) and 64 + g*16 (lo half): 16 rows x 64 B per instruction.
+template <int DEPTH, bool NT>
+__global__ __launch_bounds__(256) void frag_read_kernel(const v4f* __restrict__ src, uint32_t n_tiles,
+                                                        uint32_t tiles_per_wg, float* __restrict__ sink) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6, n = lane & 15u, g = lane >> 4;
+    const uint32_t t0 = blockIdx.x * tiles_per_wg, t1 = t0 + tiles_per_wg < n_tiles ? t0 + tiles_per_wg : n_tiles;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    // one "stage" = (tile, kc): 4 row blocks x (hi, lo) = 8 loads per lane
+    const uint32_t n_stage = (t1 > t0 ? t1 - t0 : 0) * 6;
+    auto addr = [&](uint32_t s, uint32_t rb, uint32_t half) -> const v4f* {
+        const uint32_t tile = t0 + s / 6, kc = s % 6;
+        return src + ((size_t)(tile * 64u + rb * 16u + n) * 3072u + kc * 512u + w * 128u + half * 64u + g * 16u) / 16u;
+    };
+    v4f buf[DEPTH][8];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if ((uint32_t)d < n_stage)
+#pragma unroll
+            for (int i = 0; i < 8; i++) buf[d][i] = NT ? __builtin_nontemporal_load(addr(d, i >> 1, i & 1)) : *addr(d, i >> 1, i & 1);
+    for (uint32_t s0 = 0; s0 < n_stage; s0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const uint32_t s = s0 + d;
+            if (s < n_stage) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc += buf[d][i];
+                const uint32_t ns = s + DEPTH;
+                if (ns < n_stage)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) buf[d][i] = NT ? __builtin_nontemporal_load(addr(ns, i >> 1, i & 1)) : *addr(ns, i >> 1, i & 1);
+            }
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <typename L>
@@ -82,6 +121,13 @@ int main(int argc, char** argv) {
 #define RUNR(CH, NT) { float ms = time_ms([&] { hipLaunchKernelGGL((read_rows_kernel<CH, NT>), dim3(blocks), dim3(256), 0, 0, src, n_rows, 192u, sink); }, 5); \
                        printf("row-major    waves/CU %2d  CH %2d  %s : %7.3f ms  %6.0f GB/s\n", waves_per_cu, CH, NT ? "nt " : "def", ms, bytes / ms / 1e6); }
         RUNR(12, true) RUNR(12, false) RUNR(6, true)
+    }
+    const uint32_t n_tiles = (uint32_t)(n_rows / 64);
+    for (int wgs : {256, 512, 1024, 2048}) {
+        const uint32_t tpw = (n_tiles + wgs - 1) / wgs;
+#define RUNF(D, NT) { float ms = time_ms([&] { hipLaunchKernelGGL((frag_read_kernel<D, NT>), dim3(wgs), dim3(256), 0, 0, src, n_tiles, tpw, sink); }, 5); \
+                      printf("fragment     wgs %4d  depth %d  %s : %7.3f ms  %6.0f GB/s\n", wgs, D, NT ? "nt " : "def", ms, (double)n_tiles * 64 * 3072 / ms / 1e6); }
+        RUNF(3, true) RUNF(6, true) RUNF(6, false) RUNF(12, true)
     }
     return 0;
 }
