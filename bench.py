@@ -310,6 +310,9 @@ def main():
     alg_bytes = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
 
+    # ---- read ceiling of this device: the scan's access pattern with the arithmetic removed (rank 0 reports) ----
+    read_ceiling = idx.read_probe(3) if local_rows else None
+
     # ---- parity of the last result ----------------------------------------------------------------
     parity = None
     if not args.no_parity:
@@ -343,7 +346,10 @@ def main():
                          "kernel": ("nmn::exact_scan_kernel" if args.k > 4096 else
                                     "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel"), "avg_kernel_ms": scan_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None},
+                         "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None,
+                         # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
+                         "measured_read_ceiling": read_ceiling,
+                         "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None},
             "cpu_baseline": cpu,
             "parity": parity,
             "batched": batched,

@@ -169,6 +169,10 @@ nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, nmn_metric 
                                  const uint64_t* mask, float score, uint64_t* n_greater,
                                  uint64_t* n_equal);
 
+/* Measurement aid: a pure read sweep over the shard (the scan's access pattern without arithmetic), best of
+ * `reps` runs, in GB/s.  What a read-only kernel can reach on this device; bench.py reports the scan against it. */
+nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double* gbps_out);
+
 /* ---- shard merge (multi-GPU) -------------------------------------------------------------- */
 
 /* Merge `n_lists` per-shard top-k lists (each nq x k, padded as nmn_index_search pads) into one:

@@ -637,6 +637,39 @@ extern "C" nmn_status nmn_index_search_dmask(nmn_index* idx, const float* querie
     return index_search_hostio(idx, queries, nq, k, (int)metric, mask_dev, true, out_rows, out_scores, out_counts, stats);
 }
 
+// Pure read sweep over the shard's rows (no arithmetic): the bandwidth a read-only kernel reaches on this device
+// with the scan's own access pattern.  *gbps_out = rows * ld * 4 bytes / best-of-`reps` kernel time.
+extern "C" nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double* gbps_out) {
+    if (!idx || !gbps_out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *gbps_out = 0.0;
+    if (idx->rows == 0) return NMN_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->mu);
+    hipStream_t s = idx->host_stream;
+    float* sink = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sink), 4));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    float best = 0.f;
+    if (e == hipSuccess) e = launch_read_probe(idx->corpus, idx->rows, idx->ld, sink, s);  // warm-up
+    for (uint32_t i = 0; i < std::max(reps, 1u) && e == hipSuccess; i++) {
+        e = hipEventRecord(a, s);
+        if (e == hipSuccess) e = launch_read_probe(idx->corpus, idx->rows, idx->ld, sink, s);
+        if (e == hipSuccess) e = hipEventRecord(b, s);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e == hipSuccess && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail_hip(e, "nmn_index_read_probe");
+    if (best > 0.f) *gbps_out = (double)idx->rows * idx->ld * 4.0 / (best * 1e-3) / 1e9;
+    return NMN_OK;
+}
+
 // ---- exact helpers ------------------------------------------------------------------------------
 extern "C" nmn_status nmn_index_score_rows(nmn_index* idx, const float* queries, uint32_t nq, nmn_metric metric,
                                            const uint64_t* local_rows, uint32_t n_rows, float* out_scores) {

@@ -102,6 +102,7 @@ struct ScanParams {
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
+hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 uint32_t scan_mfma_queries_per_sweep(uint32_t ld);

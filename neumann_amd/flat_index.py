@@ -183,6 +183,12 @@ class GpuFlatIndex:
                                                    _ptr(out)))
         return out
 
+    def read_probe(self, reps=3):
+        """GB/s of a pure read sweep over this shard (the scan's access pattern without arithmetic)."""
+        out = C.c_double()
+        _capi.check(self._lib.nmn_index_read_probe(self._h, int(reps), C.byref(out)))
+        return float(out.value)
+
     def count_exact(self, query, score, metric=DistanceMetric.Cosine, mask=None):
         """(#rows with exact score > score, #rows with exact score == score) — a full exact pass."""
         q = _f32(query).reshape(-1)
