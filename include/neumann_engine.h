@@ -155,6 +155,32 @@ nmn_filter* nmn_filter_contains(const char* field, const char* substr);
 nmn_filter* nmn_filter_starts_with(const char* field, const char* prefix);
 nmn_filter* nmn_filter_in(const char* field, const nmn_value* values, uint32_t n);
 void nmn_filter_free(nmn_filter* f);
+/* ---- metadata CRUD (lib.rs:3311-3385) and the remaining helpers of the filtered / paginated surface ---- */
+typedef struct nmn_metalist nmn_metalist;  /* HashMap<String, TensorValue> */
+nmn_metalist* nmn_engine_get_metadata(nmn_engine* e, const char* key, nmn_status* status);      /* 3312-3327 */
+uint64_t nmn_metalist_len(const nmn_metalist* l);
+const char* nmn_metalist_name(const nmn_metalist* l, uint64_t i);
+nmn_status nmn_metalist_value(const nmn_metalist* l, uint64_t i, nmn_value* out);
+void nmn_metalist_free(nmn_metalist* l);
+nmn_status nmn_engine_update_metadata(nmn_engine* e, const char* key, const nmn_meta_field* meta, uint32_t n_meta); /* 3329-3351 */
+nmn_status nmn_engine_remove_metadata_field(nmn_engine* e, const char* key, const char* field);                    /* 3353-3364 */
+int32_t nmn_engine_has_metadata_field(nmn_engine* e, const char* key, const char* field);                          /* 3366-3372 */
+nmn_status nmn_engine_get_metadata_field(nmn_engine* e, const char* key, const char* field, nmn_value* out,
+                                         int32_t* present);                                                         /* 3374-3383 */
+nmn_status nmn_engine_estimate_filter_selectivity(nmn_engine* e, const nmn_filter* f, float* out);                  /* 3695-3711 */
+nmn_strlist* nmn_engine_list_keys_matching(nmn_engine* e, const nmn_filter* f);                                     /* 3720-3725 */
+nmn_status nmn_engine_batch_delete(nmn_engine* e, const char* const* keys, uint64_t n, uint64_t* deleted);         /* 2924-2940 */
+uint64_t nmn_engine_dimension(nmn_engine* e);                                            /* 2298-2308; 0 = None */
+int32_t nmn_engine_exists_in_collection(nmn_engine* e, const char* coll, const char* key);                          /* 1537-1540 */
+nmn_strlist* nmn_engine_list_collection_keys(nmn_engine* e, const char* coll);                                      /* 1543-1550 */
+/* Pagination{skip, limit (-1 = None), count_total} -> PagedResult{items, total_count (-1 = None), has_more} (lib.rs:1052-1112) */
+nmn_status nmn_engine_search_similar_paginated(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, uint64_t skip,
+                                               int64_t limit, int32_t count_total, nmn_results** out, int64_t* total_count,
+                                               int32_t* has_more);                                                  /* 2988-3019 */
+nmn_status nmn_engine_search_entities_paginated(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, uint64_t skip,
+                                                int64_t limit, int32_t count_total, nmn_results** out, int64_t* total_count,
+                                                int32_t* has_more);                                                 /* 3027-3058 */
+
 /* ---- tensor_blob artifact similarity (tensor_blob/src/lib.rs:520-625) ----------------------------- */
 /* set_embedding (529-556) for the artifact record `_blob:meta:{artifact_id}`; filename = its `_filename`. */
 nmn_status nmn_engine_blob_set_embedding(nmn_engine* e, const char* artifact_id, const char* filename, const float* v,

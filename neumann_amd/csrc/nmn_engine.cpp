@@ -109,6 +109,10 @@ struct nmn_results {
 struct nmn_strlist {
     std::vector<std::string> items;
 };
+struct nmn_metalist {  // HashMap<String, TensorValue> of get_metadata (lib.rs:3312-3327)
+    std::vector<std::string> names;
+    std::vector<Value> values;
+};
 // (IVFIndex, Vec<String>) as build_ivf_index returns it (lib.rs:2641-2694): the GPU index + id -> key mapping
 struct nmn_engine_ivf {
     nmn_ivf* index = nullptr;           // null = untrained (built from an empty store)
@@ -1034,6 +1038,227 @@ nmn_status nmn_engine_search_similar(nmn_engine* e, const float* q, uint64_t dim
     }
     *out = res;
     return NMN_OK;
+}
+
+// ---- metadata CRUD of stored embeddings (lib.rs:3311-3385): filtered searches see the change at once ----
+static void value_out(const Value& v, nmn_value* out) {
+    out->kind = v.kind;
+    out->b = v.b ? 1 : 0;
+    out->i = v.i;
+    out->f = v.f;
+    out->s = v.kind == NMN_VAL_STRING ? v.s.c_str() : nullptr;
+}
+
+nmn_metalist* nmn_engine_get_metadata(nmn_engine* e, const char* key, nmn_status* status) {  // lib.rs:3312-3327
+    nmn_status dummy;
+    if (!status) status = &dummy;
+    if (!e || !key) {
+        *status = fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> g(e->mu);
+    auto it = e->dflt.by_key.find(key);
+    if (it == e->dflt.by_key.end()) {
+        *status = err_not_found(key);
+        return nullptr;
+    }
+    nmn_metalist* l = new (std::nothrow) nmn_metalist();
+    if (!l) {
+        *status = fail(NMN_ERR_OUT_OF_MEMORY, "metadata list alloc");
+        return nullptr;
+    }
+    for (const auto& kv : e->dflt.slots[it->second].meta) {
+        l->names.push_back(kv.first);
+        l->values.push_back(kv.second);
+    }
+    *status = NMN_OK;
+    return l;
+}
+uint64_t nmn_metalist_len(const nmn_metalist* l) { return l ? l->names.size() : 0; }
+const char* nmn_metalist_name(const nmn_metalist* l, uint64_t i) { return (l && i < l->names.size()) ? l->names[i].c_str() : nullptr; }
+nmn_status nmn_metalist_value(const nmn_metalist* l, uint64_t i, nmn_value* out) {
+    if (!l || !out || i >= l->values.size()) return fail(NMN_ERR_INVALID_ARGUMENT, "bad metadata index");
+    value_out(l->values[i], out);  // out->s points into the list: valid until nmn_metalist_free
+    return NMN_OK;
+}
+void nmn_metalist_free(nmn_metalist* l) { delete l; }
+
+// update_metadata (lib.rs:3329-3351): set the given fields, keep the others and the vector
+nmn_status nmn_engine_update_metadata(nmn_engine* e, const char* key, const nmn_meta_field* meta, uint32_t n_meta) {
+    if (!e || !key || (n_meta && !meta)) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    auto it = e->dflt.by_key.find(key);
+    if (it == e->dflt.by_key.end()) return err_not_found(key);
+    Entry& ent = e->dflt.slots[it->second];
+    Meta changed;
+    for (uint32_t i = 0; i < n_meta; i++)
+        if (meta[i].name) {
+            ent.meta[meta[i].name] = Value::from(meta[i].value);
+            changed[meta[i].name] = ent.meta[meta[i].name];
+        }
+    Mirror* m = ent.mrow >= 0 ? mirror_of(&e->dflt, ent.vec.size()) : nullptr;
+    if (m) columns_write_row(m, (uint64_t)ent.mrow, changed, /*overwrite=*/false);  // only the touched cells
+    return NMN_OK;
+}
+
+// remove_metadata_field (lib.rs:3353-3364): NotFound only for a missing key; a missing field is not an error
+nmn_status nmn_engine_remove_metadata_field(nmn_engine* e, const char* key, const char* field) {
+    if (!e || !key || !field) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    auto it = e->dflt.by_key.find(key);
+    if (it == e->dflt.by_key.end()) return err_not_found(key);
+    Entry& ent = e->dflt.slots[it->second];
+    if (ent.meta.erase(field) == 0) return NMN_OK;
+    Mirror* m = ent.mrow >= 0 ? mirror_of(&e->dflt, ent.vec.size()) : nullptr;
+    if (m && m->cols) {
+        auto fc = m->fields.find(field);
+        if (fc != m->fields.end()) {
+            const uint8_t kind = NMN_CELL_ABSENT;
+            const uint64_t payload = 0;
+            if (nmn_columns_write(m->cols, fc->second.id, (uint64_t)ent.mrow, 1, &kind, &payload) != NMN_OK) m->drop_columns();
+        }
+    }
+    return NMN_OK;
+}
+
+int32_t nmn_engine_has_metadata_field(nmn_engine* e, const char* key, const char* field) {  // lib.rs:3366-3372
+    if (!e || !key || !field) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    auto it = e->dflt.by_key.find(key);
+    return (it != e->dflt.by_key.end() && e->dflt.slots[it->second].meta.count(field)) ? 1 : 0;
+}
+
+// get_metadata_field (lib.rs:3374-3383): Ok(None) for a missing field -> *present = 0.  out->s (strings) points to
+// thread-local storage that stays valid until this thread's next call of this function.
+nmn_status nmn_engine_get_metadata_field(nmn_engine* e, const char* key, const char* field, nmn_value* out,
+                                         int32_t* present) {
+    if (!e || !key || !field || !out || !present) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    static thread_local Value hold;
+    *present = 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    auto it = e->dflt.by_key.find(key);
+    if (it == e->dflt.by_key.end()) return err_not_found(key);
+    const Meta& meta = e->dflt.slots[it->second].meta;
+    auto f = meta.find(field);
+    if (f == meta.end()) return NMN_OK;
+    hold = f->second;
+    value_out(hold, out);
+    *present = 1;
+    return NMN_OK;
+}
+
+// estimate_filter_selectivity (lib.rs:3695-3711): the first min(100, count) keys
+nmn_status nmn_engine_estimate_filter_selectivity(nmn_engine* e, const nmn_filter* f, float* out) {
+    if (!e || !f || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    uint64_t sample = 0, matches = 0;
+    for (const auto& ent : e->dflt.slots) {
+        if (!ent.live) continue;
+        if (sample == 100) break;
+        sample++;
+        if (evaluate_filter(ent.meta, *f)) matches++;
+    }
+    *out = sample ? (float)matches / (float)sample : 0.0f;
+    return NMN_OK;
+}
+
+nmn_strlist* nmn_engine_list_keys_matching(nmn_engine* e, const nmn_filter* f) {  // lib.rs:3720-3725
+    nmn_strlist* l = new (std::nothrow) nmn_strlist();
+    if (!e || !f || !l) return l;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (const auto& ent : e->dflt.slots)
+        if (ent.live && evaluate_filter(ent.meta, *f)) l->items.push_back(ent.key);
+    return l;
+}
+
+// batch_delete_embeddings (lib.rs:2924-2940): missing keys are skipped, the number deleted is returned
+nmn_status nmn_engine_batch_delete(nmn_engine* e, const char* const* keys, uint64_t n, uint64_t* deleted) {
+    if (!e || (n && !keys)) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(e->mu);
+    uint64_t cnt = 0;
+    for (uint64_t i = 0; i < n; i++)
+        if (keys[i] && e->dflt.by_key.count(keys[i]) && delete_from(&e->dflt, keys[i], keys[i]) == NMN_OK) cnt++;
+    if (deleted) *deleted = cnt;
+    return NMN_OK;
+}
+
+uint64_t nmn_engine_dimension(nmn_engine* e) {  // lib.rs:2298-2308: the first stored vector's length; 0 = None
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (const auto& ent : e->dflt.slots)
+        if (ent.live) return ent.vec.size();
+    return 0;
+}
+
+int32_t nmn_engine_exists_in_collection(nmn_engine* e, const char* coll, const char* key) {  // lib.rs:1537-1540
+    if (!e || !coll || !key) return 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    Collection* c = e->storage(coll, false);
+    return (c && c->by_key.count(key)) ? 1 : 0;
+}
+
+nmn_strlist* nmn_engine_list_collection_keys(nmn_engine* e, const char* coll) {  // lib.rs:1543-1550
+    nmn_strlist* l = new (std::nothrow) nmn_strlist();
+    if (!e || !coll || !l) return l;
+    std::lock_guard<std::mutex> g(e->mu);
+    Collection* c = e->storage(coll, false);
+    if (c)
+        for (const auto& ent : c->slots)
+            if (ent.live) l->items.push_back(ent.key);
+    return l;
+}
+
+// search_similar_paginated / search_entities_paginated (lib.rs:2988-3058): search min(skip + limit.unwrap_or(top_k),
+// top_k) results, then skip / take; total_count (when asked for) is the number of results FOUND, not of rows stored.
+static nmn_status paginate(nmn_status st, nmn_results* all, uint64_t skip, int64_t limit, int32_t count_total,
+                           nmn_results** out, int64_t* total_count, int32_t* has_more) {
+    if (st != NMN_OK) return st;
+    const uint64_t found = all->keys.size();
+    if (total_count) *total_count = count_total ? (int64_t)found : -1;
+    nmn_results* res = new_results();
+    if (!res) {
+        delete all;
+        return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+    }
+    for (uint64_t i = skip; i < found && (limit < 0 || res->keys.size() < (uint64_t)limit); i++) {
+        res->keys.push_back(all->keys[i]);
+        res->scores.push_back(all->scores[i]);
+    }
+    if (has_more) {
+        uint64_t reach = skip + res->keys.size();
+        if (reach < skip) reach = UINT64_MAX;  // saturating_add
+        *has_more = (limit >= 0 && count_total && reach < found) ? 1 : 0;
+    }
+    delete all;
+    *out = res;
+    return NMN_OK;
+}
+
+static uint64_t total_needed(uint64_t top_k, uint64_t skip, int64_t limit) {
+    const uint64_t want = limit >= 0 ? (uint64_t)limit : top_k;
+    uint64_t need = skip + want;
+    if (need < skip) need = UINT64_MAX;  // saturating_add
+    return std::min(need, top_k);
+}
+
+nmn_status nmn_engine_search_similar_paginated(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, uint64_t skip,
+                                               int64_t limit, int32_t count_total, nmn_results** out, int64_t* total_count,
+                                               int32_t* has_more) {
+    if (!out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    nmn_results* all = nullptr;
+    nmn_status st = nmn_engine_search_similar(e, q, dim, total_needed(top_k, skip, limit), &all);
+    return paginate(st, all, skip, limit, count_total, out, total_count, has_more);
+}
+
+nmn_status nmn_engine_search_entities_paginated(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, uint64_t skip,
+                                                int64_t limit, int32_t count_total, nmn_results** out, int64_t* total_count,
+                                                int32_t* has_more) {
+    if (!out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    nmn_results* all = nullptr;
+    nmn_status st = nmn_engine_search_entities(e, q, dim, total_needed(top_k, skip, limit), &all);
+    return paginate(st, all, skip, limit, count_total, out, total_count, has_more);
 }
 
 // ---- tensor_blob artifact similarity (tensor_blob/src/lib.rs:520-625) -----------------------------------

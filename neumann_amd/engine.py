@@ -56,6 +56,25 @@ ENGINE_SIGNATURES = {
     "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
     "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_get_metadata": (vp, [vp, C.c_char_p, C.POINTER(C.c_int32)]),
+    "nmn_metalist_len": (C.c_uint64, [vp]),
+    "nmn_metalist_name": (C.c_char_p, [vp, C.c_uint64]),
+    "nmn_metalist_value": (C.c_int32, [vp, C.c_uint64, C.POINTER(_Value)]),
+    "nmn_metalist_free": (None, [vp]),
+    "nmn_engine_update_metadata": (C.c_int32, [vp, C.c_char_p, C.POINTER(_MetaField), C.c_uint32]),
+    "nmn_engine_remove_metadata_field": (C.c_int32, [vp, C.c_char_p, C.c_char_p]),
+    "nmn_engine_has_metadata_field": (C.c_int32, [vp, C.c_char_p, C.c_char_p]),
+    "nmn_engine_get_metadata_field": (C.c_int32, [vp, C.c_char_p, C.c_char_p, C.POINTER(_Value), C.POINTER(C.c_int32)]),
+    "nmn_engine_estimate_filter_selectivity": (C.c_int32, [vp, vp, C.POINTER(C.c_float)]),
+    "nmn_engine_list_keys_matching": (vp, [vp, vp]),
+    "nmn_engine_batch_delete": (C.c_int32, [vp, C.POINTER(C.c_char_p), C.c_uint64, C.POINTER(C.c_uint64)]),
+    "nmn_engine_dimension": (C.c_uint64, [vp]),
+    "nmn_engine_exists_in_collection": (C.c_int32, [vp, C.c_char_p, C.c_char_p]),
+    "nmn_engine_list_collection_keys": (vp, [vp, C.c_char_p]),
+    "nmn_engine_search_similar_paginated": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
+                                                        C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "nmn_engine_search_entities_paginated": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
+                                                         C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "nmn_engine_blob_set_embedding": (C.c_int32, [vp, C.c_char_p, C.c_char_p, vp, C.c_uint64]),
     "nmn_engine_blob_remove": (C.c_int32, [vp, C.c_char_p]),
     "nmn_engine_blob_search_by_embedding": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
@@ -159,6 +178,29 @@ class SearchResult:
     """vector_engine::SearchResult (lib.rs:252-266)."""
     key: str
     score: float
+
+
+@dataclass
+class Pagination:
+    """vector_engine::Pagination (lib.rs:1052-1085); limit None = no limit."""
+    skip: int = 0
+    limit: int = None
+    count_total: bool = False
+
+    def with_total(self):
+        return Pagination(self.skip, self.limit, True)
+
+
+@dataclass
+class PagedResult:
+    """vector_engine::PagedResult (lib.rs:1087-1112)."""
+    items: list
+    total_count: int
+    has_more: bool
+
+
+def _py_value(v):
+    return {0: None, 1: bool(v.b), 2: int(v.i), 3: float(v.f)}.get(v.kind, v.s.decode() if v.s is not None else "")
 
 
 @dataclass
@@ -594,6 +636,75 @@ class VectorEngine:
         out = C.c_float()
         _check(_lib().nmn_engine_compute_similarity(self._h, pa, na, pb, nb, C.byref(out)))
         return float(np.float32(out.value))
+
+    # ---- metadata CRUD (lib.rs:3311-3385) ----
+    def get_metadata(self, key):
+        st = C.c_int32()
+        h = _lib().nmn_engine_get_metadata(self._h, key.encode(), C.byref(st))
+        _check(st.value)
+        try:
+            out = {}
+            for i in range(_lib().nmn_metalist_len(h)):
+                v = _Value()
+                _check(_lib().nmn_metalist_value(h, i, C.byref(v)))
+                out[_lib().nmn_metalist_name(h, i).decode()] = _py_value(v)
+            return out
+        finally:
+            _lib().nmn_metalist_free(h)
+
+    def update_metadata(self, key, metadata):
+        arr, m, keep = _meta_array(metadata)
+        _check(_lib().nmn_engine_update_metadata(self._h, key.encode(), arr, m))
+
+    def remove_metadata_field(self, key, field):
+        _check(_lib().nmn_engine_remove_metadata_field(self._h, key.encode(), field.encode()))
+
+    def has_metadata_field(self, key, field):
+        return bool(_lib().nmn_engine_has_metadata_field(self._h, key.encode(), field.encode()))
+
+    def get_metadata_field(self, key, field):
+        v, present = _Value(), C.c_int32()
+        _check(_lib().nmn_engine_get_metadata_field(self._h, key.encode(), field.encode(), C.byref(v), C.byref(present)))
+        return _py_value(v) if present.value else None
+
+    def estimate_filter_selectivity(self, filter):
+        out = C.c_float()
+        with _OwnedFilter(filter) as f:
+            _check(_lib().nmn_engine_estimate_filter_selectivity(self._h, f, C.byref(out)))
+        return float(out.value)
+
+    def list_keys_matching(self, filter):
+        with _OwnedFilter(filter) as f:
+            return self._take_list(_lib().nmn_engine_list_keys_matching(self._h, f))
+
+    def batch_delete_embeddings(self, keys):
+        ks = (C.c_char_p * max(len(keys), 1))(*[k.encode() for k in keys])
+        n = C.c_uint64()
+        _check(_lib().nmn_engine_batch_delete(self._h, ks, len(keys), C.byref(n)))
+        return int(n.value)
+
+    def dimension(self):
+        d = int(_lib().nmn_engine_dimension(self._h))
+        return d or None
+
+    def exists_in_collection(self, collection, key):
+        return bool(_lib().nmn_engine_exists_in_collection(self._h, collection.encode(), key.encode()))
+
+    def list_collection_keys(self, collection):
+        return self._take_list(_lib().nmn_engine_list_collection_keys(self._h, collection.encode()))
+
+    def _paginated(self, fn, query, top_k, pagination):
+        a, p, n = _vec(query)
+        h, total, more = vp(), C.c_int64(), C.c_int32()
+        _check(fn(self._h, p, n, int(top_k), int(pagination.skip), -1 if pagination.limit is None else int(pagination.limit),
+                  int(pagination.count_total), C.byref(h), C.byref(total), C.byref(more)))
+        return PagedResult(self._take_results(h), None if total.value < 0 else int(total.value), bool(more.value))
+
+    def search_similar_paginated(self, query, top_k, pagination):
+        return self._paginated(_lib().nmn_engine_search_similar_paginated, query, top_k, pagination)
+
+    def search_entities_paginated(self, query, top_k, pagination):
+        return self._paginated(_lib().nmn_engine_search_entities_paginated, query, top_k, pagination)
 
     def count_matching(self, filter):
         with _OwnedFilter(filter) as f:

@@ -505,6 +505,81 @@ def test_top_k_beyond_4096_returns_the_full_ranking(E):
     assert [r.key for r in res] == [f"k{i}" for i in er if i % 2 == 0][:1500]
 
 
+# ---- metadata CRUD + pagination (lib.rs:5367-5396, 6693-6855) -----------------------------------------------
+def test_metadata_crud(E):
+    engine = E.VectorEngine()
+    engine.store_embedding_with_metadata("item", [1.0, 2.0], {"color": "red"})
+    engine.update_metadata("item", {"size": "large", "color": "blue"})            # update_metadata_basic
+    md = engine.get_metadata("item")
+    assert md == {"color": "blue", "size": "large"}
+    assert np.array_equal(engine.get_embedding("item"), np.array([1.0, 2.0], F))  # the vector is untouched
+    for call in (lambda: engine.get_metadata("nope"), lambda: engine.update_metadata("nope", {"a": 1}),
+                 lambda: engine.remove_metadata_field("nope", "a"), lambda: engine.get_metadata_field("nope", "a")):
+        with pytest.raises(E.VectorError) as e:
+            call()
+        assert e.value.kind == "NotFound"
+    engine.remove_metadata_field("item", "color")                                  # remove_metadata_field_basic
+    assert not engine.has_metadata_field("item", "color") and engine.has_metadata_field("item", "size")
+    engine.remove_metadata_field("item", "never_there")                            # not an error
+    assert not engine.has_metadata_field("nope", "size")
+    assert engine.get_metadata_field("item", "size") == "large"
+    assert engine.get_metadata_field("item", "missing") is None                    # Ok(None)
+    engine.update_metadata("item", {"n": 3, "f": 0.5, "b": True, "z": None})
+    assert engine.get_metadata("item") == {"size": "large", "n": 3, "f": 0.5, "b": True, "z": None}
+    engine.store_embedding("plain", [1.0, 0.0])
+    assert engine.get_metadata("plain") == {}
+
+
+def test_metadata_updates_reach_the_device_columns(E):
+    """update_metadata / remove_metadata_field patch single cells of the HBM columns; the next filtered search sees them."""
+    FC, PRE = E.FilterCondition, E.FilteredSearchConfig.pre_filter()
+    rng = np.random.default_rng(4)
+    n, d = 300, 8
+    A = rng.standard_normal((n, d)).astype(F)
+    engine = E.VectorEngine()
+    for i in range(n):
+        engine.store_embedding_with_metadata(f"k{i}", A[i], {"g": i % 3})
+    q = rng.standard_normal(d).astype(F)
+    assert len(engine.search_similar_filtered(q, n, FC.Eq("g", 7), PRE)) == 0     # builds mirror + columns
+    engine.update_metadata("k5", {"g": 7, "tag": "x"})                             # changed cell + a brand-new column
+    engine.update_metadata("k9", {"g": 7.0})                                       # the cell changes type: Float 7.0 == Int 7
+    engine.remove_metadata_field("k12", "g")
+    assert sorted(r.key for r in engine.search_similar_filtered(q, n, FC.Eq("g", 7), PRE)) == ["k5", "k9"]
+    assert [r.key for r in engine.search_similar_filtered(q, n, FC.Exists("tag"), PRE)] == ["k5"]
+    got = {r.key for r in engine.search_similar_filtered(q, n, FC.Exists("g"), PRE)}
+    assert got == {f"k{i}" for i in range(n)} - {"k12"}
+    assert engine.column_builds() == 1 and engine.mirror_builds() == 1
+    assert engine.list_keys_matching(FC.Eq("g", 7)) == ["k5", "k9"] and engine.count_matching(FC.Eq("g", 7)) == 2
+    assert engine.estimate_filter_selectivity(FC.Exists("g")) == pytest.approx(0.99)   # first 100 keys, k12 among them
+    assert engine.batch_delete_embeddings(["k5", "nope", "k6"]) == 2               # lib.rs:2924-2940
+    assert [r.key for r in engine.search_similar_filtered(q, n, FC.Eq("g", 7), PRE)] == ["k9"]
+    assert engine.dimension() == d and E.VectorEngine().dimension() is None
+
+
+def test_paginated_searches(E):
+    engine = E.VectorEngine()
+    for i in range(10):
+        engine.store_embedding(f"v{i}", [float(i), 1.0])
+    P = E.Pagination
+    res = engine.search_similar_paginated([5.0, 1.0], 10, P(0, 3).with_total())   # search_similar_paginated_basic
+    full = engine.search_similar([5.0, 1.0], 10)
+    assert [r.key for r in res.items] == [r.key for r in full[:3]]
+    assert res.total_count == 3 and not res.has_more                               # min(skip + limit, top_k) results were searched
+    res = engine.search_similar_paginated([5.0, 1.0], 10, P(2, 3).with_total())
+    assert [r.key for r in res.items] == [r.key for r in full[2:5]] and res.total_count == 5 and not res.has_more
+    res = engine.search_similar_paginated([5.0, 1.0], 4, P(1, None))               # no limit: skip + top_k, capped at top_k
+    assert [r.key for r in res.items] == [r.key for r in full[1:4]] and res.total_count is None and not res.has_more
+    res = engine.search_similar_paginated([5.0, 1.0], 10, P(20, 5).with_total())   # skip past the end
+    assert res.items == [] and res.total_count == 10 and not res.has_more
+    for i in range(5):
+        engine.set_entity_embedding(f"user:{i}", [float(i), 1.0])
+    res = engine.search_entities_paginated([2.0, 1.0], 5, P(0, 2).with_total())    # search_entities_paginated_basic
+    assert len(res.items) == 2 and res.items[0].key == "user:2"
+    engine.store_in_collection("c", "a", [1.0])
+    assert engine.exists_in_collection("c", "a") and not engine.exists_in_collection("c", "b")
+    assert engine.list_collection_keys("c") == ["a"] and engine.list_collection_keys("nope") == []
+
+
 # ---- unified entity mode (lib.rs:4692-4867) -----------------------------------------------------------------
 def test_entity_embedding_crud(E):  # lib.rs:4692-4770, 4815-4840
     engine = E.VectorEngine()
