@@ -357,6 +357,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1 or args.always_gather:
+        dist.barrier()  # every rank is done with its collectives before any of them tears the group down
         dist.destroy_process_group()
 
 
