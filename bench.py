@@ -214,12 +214,19 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NMN_BENCH_DEVICE pins every rank to one device: lets the N>1 code path run on a 1-GPU box where the
+    # collective library tolerates several ranks per GPU (debugging aid, never used by the driver)
+    dev_index = int(os.environ.get("NMN_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1 or args.always_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29571")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("NMN_BENCH_BACKEND", "nccl")  # "gloo": control-flow check of the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -234,7 +241,7 @@ def main():
     r0, r1 = shard_range(total_rows, world, rank)
     local_rows = r1 - r0
 
-    idx = GpuFlatIndex(args.dim, local_rows, row_base=r0, device=local_rank)
+    idx = GpuFlatIndex(args.dim, local_rows, row_base=r0, device=dev_index)
     t_fill = time.perf_counter()
     idx.fill_synthetic(SEED_CORPUS, local_rows)
     torch.cuda.synchronize()
