@@ -71,3 +71,25 @@ def test_rccl_gather_and_device_merge_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """bench.py's N>1 path end to end — two processes, row-range shards, per-step gather + device merge, max-over-ranks
+    timing, the cross-shard exactness certificate — with both ranks pinned to GPU 0 and gloo as the transport (RCCL
+    refuses two ranks on one device; its own calls are covered by the single-rank test above)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMN_BENCH_DEVICE="0", NMN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "300000", "--steps", "6",
+           "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 150000 and d["scaling"] == "strong"
+    assert d["parity"]["exact_topk_certified"] and d["parity"]["returned"] == 100
+    assert d["value"] > 0 and d["cpu_baseline"] is None
