@@ -56,6 +56,9 @@ static void ws_free(Workspace* w) {
                     w->h_counts2, w->lk_keys};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (w->h_pack) (void)hipFree(w->h_pack);
+    if (w->pin_in) (void)hipHostFree(w->pin_in);
+    if (w->pin_out) (void)hipHostFree(w->pin_out);
     for (auto& e : w->ev)
         if (e) (void)hipEventDestroy(e);
     delete w;
@@ -72,6 +75,17 @@ static hipError_t grow(T** p, size_t* cap, size_t need) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(need, 1) * sizeof(T));
     if (e == hipSuccess) *cap = need;
+    return e;
+}
+
+static hipError_t grow_pinned(uint8_t** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = std::max<size_t>(need + need / 2, 4096);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(p), want, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = want;
     return e;
 }
 
@@ -602,11 +616,15 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     if (st != NMN_OK) return st;
     const size_t qn = (size_t)nq * idx->dim, on = (size_t)nq * k;
     const size_t words = (size_t)((idx->rows + 63) / 64);
+    // packed result block: rows (8-byte aligned) | scores | counts
+    const size_t off_scores = on * sizeof(uint64_t), off_counts = off_scores + on * sizeof(float);
+    const size_t pack_bytes = off_counts + (size_t)nq * sizeof(uint32_t);
     HIP_TRY(grow(&w->h_queries, &w->h_queries_cap, qn));
-    HIP_TRY(grow(&w->h_out_rows, &w->h_out_rows_cap, on));
-    HIP_TRY(grow(&w->h_out_scores, &w->h_out_scores_cap, on));
-    HIP_TRY(grow(&w->h_out_counts, &w->h_cnt_cap, (size_t)nq));
-    HIP_TRY(hipMemcpyAsync(w->h_queries, queries, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(grow(&w->h_pack, &w->h_pack_cap, pack_bytes));
+    HIP_TRY(grow_pinned(&w->pin_in, &w->pin_in_cap, qn * sizeof(float)));
+    HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes));
+    memcpy(w->pin_in, queries, qn * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
     const uint64_t* mask_dev = nullptr;
     if (mask && words && mask_on_device) {
         mask_dev = mask;
@@ -615,13 +633,16 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
         HIP_TRY(hipMemcpyAsync(w->h_mask, mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         mask_dev = w->h_mask;
     }
-    st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)metric, mask_dev, w->h_out_rows, w->h_out_scores,
-                        w->h_out_counts, s);
+    uint64_t* d_rows = reinterpret_cast<uint64_t*>(w->h_pack);
+    float* d_scores = reinterpret_cast<float*>(w->h_pack + off_scores);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(w->h_pack + off_counts);
+    st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)metric, mask_dev, d_rows, d_scores, d_counts, s);
     if (st != NMN_OK) return st;
-    HIP_TRY(hipMemcpyAsync(out_rows, w->h_out_rows, on * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_scores, w->h_out_scores, on * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_counts, w->h_out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out_rows, w->pin_out, on * sizeof(uint64_t));
+    memcpy(out_scores, w->pin_out + off_scores, on * sizeof(float));
+    memcpy(out_counts, w->pin_out + off_counts, (size_t)nq * sizeof(uint32_t));
     return stats_collect(idx, w, stats);
 }
 

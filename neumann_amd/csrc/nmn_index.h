@@ -36,6 +36,11 @@ struct Workspace {
     uint64_t* h_mask = nullptr;  size_t h_mask_cap = 0;
     uint64_t* h_out_rows = nullptr; float* h_out_scores = nullptr; uint32_t* h_out_counts = nullptr;
     size_t h_out_rows_cap = 0, h_out_scores_cap = 0, h_cnt_cap = 0;
+    // host-buffer API: ONE packed device block [rows | scores | counts] and pinned host staging for the query and the
+    // results, so a call is one true-async H2D, the pipeline, one D2H and one wait (pageable copies cost ~10 us each)
+    uint8_t* h_pack = nullptr; size_t h_pack_cap = 0;        // device
+    uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
+    uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
     uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
     float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
     unsigned long long* h_counts2 = nullptr;
