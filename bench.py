@@ -17,6 +17,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded
                 row sample of the same workload, extrapolated linearly to the full row count
   parity        the GPU result of the last timed query checked against the oracle / exact certificate
+  batched       (default single-GPU run) config 3: 64 queries per step on the MFMA sweep, same resident corpus
+  other_configs (default single-GPU run) config 2 (1M x 768) and config 5 (10M x 1536 L2 TOP-1000, mask 1.0 / 0.5 /
+                0.1), each as a child run of this script with its own corpus, each with its exactness certificate
 """
 import argparse
 import json
@@ -54,6 +57,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra legs of the default single-GPU run: BASELINE.json's other single-GPU "
+                         "configurations (config 2: 1M x 768 cosine TOP-100; config 5: 10M x 1536 L2 TOP-1000 with mask "
+                         "1.0 / 0.5 / 0.1) measured as child runs of this script and reported under \"other_configs\"")
     ap.add_argument("--always-gather", action="store_true",
                     help="run the RCCL all-gather + device merge even with one rank (measures what the N>1 step adds "
                          "on a 1-GPU box; the group has one member)")
@@ -76,7 +83,7 @@ def cpu_baseline(args, metric, total_rows, device):
     t0 = time.perf_counter()
     er, es = oc.search(A, Q[1], args.k, metric, partial=True, nthreads=cores, native=True)
     t1 = time.perf_counter() - t0
-    reps = int(max(3, min(200, args.cpu_seconds / max(t1, 1e-4))))
+    reps = int(max(3, min(2000, args.cpu_seconds / max(t1, 1e-4))))
     t0 = time.perf_counter()
     for i in range(reps):
         oc.search(A, Q[i % 4], args.k, metric, partial=True, nthreads=cores, native=True)
@@ -102,6 +109,32 @@ def cpu_baseline(args, metric, total_rows, device):
         "gbps": sample_rows * args.dim * 4 / dt / 1e9,
         "gpu_matches_oracle_on_sample": sample_ok,
     }
+
+
+def other_configs():
+    """BASELINE.json configs 2 and 5 as child runs (each needs its own resident corpus: 3 GB and 61 GB)."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--batched", "0",
+            "--warmup", "3"]
+    runs = [("config2_1Mx768_cosine_top100", ["--rows", "1000000", "--steps", "200"]),
+            ("config5_10Mx1536_l2_top1000_mask1.0", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12"]),
+            ("config5_10Mx1536_l2_top1000_mask0.5", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12",
+                                                     "--mask", "0.5"]),
+            ("config5_10Mx1536_l2_top1000_mask0.1", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "30",
+                                                     "--mask", "0.1"])]
+    out = {}
+    for name, extra in runs:
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            out[name] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                         "ms_per_step": d["ms_per_step"], "roofline_frac": d["roofline"]["frac"],
+                         "achieved_GBps": d["roofline"]["achieved"], "kernel": d["roofline"]["kernel"],
+                         "exact_topk_certified": d["parity"]["exact_topk_certified"] if d["parity"] else None}
+        except Exception as e:  # a child failing must not take the headline line down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def pmc_traffic(rows_per_gpu, args):
@@ -336,6 +369,12 @@ def main():
         cpu = cpu_baseline(args, metric, total_rows, local_rank)
 
     traffic, traffic_src = pmc_traffic(local_rows, args)
+    others = None
+    default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
+                        args.metric == "cosine" and args.mask >= 1.0)
+    if world == 1 and default_workload and not args.no_other_configs and not args.always_gather:
+        idx.close()  # the children need the HBM (config 5 alone is 61 GB + workspace)
+        others = other_configs()
     if rank == 0:
         line = {
             "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
@@ -360,6 +399,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "batched": batched,
+            "other_configs": others,
             "fill_s": t_fill,
         }
         print(json.dumps(line), flush=True)
