@@ -49,6 +49,37 @@ nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, wh
         if (_e != hipSuccess) return fail_hip(_e, #expr);    \
     } while (0)
 
+// ---- host slots ------------------------------------------------------------------------------------
+// caller holds idx->mu through `lk`
+static nmn_status slot_acquire(nmn_index* idx, std::unique_lock<std::mutex>& lk, int* slot_out) {
+    for (;;) {
+        for (int i = 0; i < nmn_index::kHostSlots; i++) {
+            if (idx->slot_busy[i]) continue;
+            if (!idx->host_slots[i]) {
+                if (i == 0) idx->host_slots[0] = idx->host_stream;
+                else HIP_TRY(hipStreamCreateWithFlags(&idx->host_slots[i], hipStreamNonBlocking));
+            }
+            idx->slot_busy[i] = true;
+            idx->slots_busy++;
+            *slot_out = i;
+            return NMN_OK;
+        }
+        idx->cv.wait(lk);
+    }
+}
+static void slot_release(nmn_index* idx, int slot) {  // takes idx->mu itself
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        idx->slot_busy[slot] = false;
+        idx->slots_busy--;
+    }
+    idx->cv.notify_all();
+}
+// before changing the shard (or using the host stream's workspace exclusively): no host-buffer search in flight
+static void wait_idle(nmn_index* idx, std::unique_lock<std::mutex>& lk) {
+    idx->cv.wait(lk, [&] { return idx->slots_busy == 0; });
+}
+
 static void ws_free(Workspace* w) {
     if (!w) return;
     void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
@@ -254,6 +285,8 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->split) (void)hipFree(idx->split);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
+    for (int i = 1; i < nmn_index::kHostSlots; i++)
+        if (idx->host_slots[i]) (void)hipStreamDestroy(idx->host_slots[i]);
     if (idx->host_stream) (void)hipStreamDestroy(idx->host_stream);
     delete idx;
     return NMN_OK;
@@ -305,7 +338,8 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
 
 extern "C" nmn_status nmn_index_upload(nmn_index* idx, const float* rows_host, uint64_t row0, uint64_t n) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     nmn_status st = upload_common(idx, rows_host, true, row0, n, idx->host_stream);
     if (st != NMN_OK) return st;
     HIP_TRY(hipStreamSynchronize(idx->host_stream));
@@ -315,7 +349,8 @@ extern "C" nmn_status nmn_index_upload(nmn_index* idx, const float* rows_host, u
 extern "C" nmn_status nmn_index_upload_device(nmn_index* idx, const float* rows_dev, uint64_t row0, uint64_t n,
                                               void* stream) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     return upload_common(idx, rows_dev, false, row0, n, static_cast<hipStream_t>(stream));
 }
 
@@ -609,8 +644,20 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
                                       out_rows, out_scores, out_counts);
     if (st != NMN_OK) return st;
     HIP_TRY(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> g(idx->mu);
-    hipStream_t s = idx->host_stream;
+    std::unique_lock<std::mutex> lk(idx->mu);
+    int slot = -1;
+    st = slot_acquire(idx, lk, &slot);
+    if (st != NMN_OK) return st;
+    struct SlotGuard {  // releases the slot on every exit path (it re-takes idx->mu: `lk` must be unlocked by then)
+        nmn_index* idx;
+        int slot;
+        std::unique_lock<std::mutex>* lk;
+        ~SlotGuard() {
+            if (lk->owns_lock()) lk->unlock();
+            slot_release(idx, slot);
+        }
+    } slot_guard{idx, slot, &lk};
+    hipStream_t s = idx->host_slots[slot];
     Workspace* w = nullptr;
     st = ws_get(idx, s, nq, k, &w);
     if (st != NMN_OK) return st;
@@ -639,6 +686,7 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)metric, mask_dev, d_rows, d_scores, d_counts, s);
     if (st != NMN_OK) return st;
     HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
+    lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(out_rows, w->pin_out, on * sizeof(uint64_t));
     memcpy(out_scores, w->pin_out + off_scores, on * sizeof(float));
@@ -665,7 +713,8 @@ extern "C" nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double
     *gbps_out = 0.0;
     if (idx->rows == 0) return NMN_OK;
     HIP_TRY(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     hipStream_t s = idx->host_stream;
     float* sink = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sink), 4));
@@ -700,7 +749,8 @@ extern "C" nmn_status nmn_index_score_rows(nmn_index* idx, const float* queries,
     for (uint32_t i = 0; i < n_rows; i++)
         if (local_rows[i] >= idx->rows) return fail_arg(NMN_ERR_NOT_FOUND, "row out of range");
     HIP_TRY(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     hipStream_t s = idx->host_stream;
     // private small buffers: nq may exceed the per-pass query count of the search workspace
     float *dq = nullptr, *dqpad = nullptr, *dout = nullptr;
@@ -736,7 +786,8 @@ extern "C" nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, 
                                             uint64_t* n_equal) {
     if (!idx || !query || !n_greater || !n_equal) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     hipStream_t s = idx->host_stream;
     Workspace* w = nullptr;
     nmn_status st = ws_get(idx, s, 1, 1, &w);
@@ -859,7 +910,8 @@ extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, ui
     if (row0 + n > idx->cap) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
     if (n == 0) return NMN_OK;
     HIP_TRY(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     hipStream_t s = idx->host_stream;
     HIP_TRY(launch_synth_fill(idx->corpus, idx->ld, idx->dim, seed, idx->row_base + row0, row0, n, s));
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, s));
@@ -873,7 +925,8 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
     if (!idx || !vec_host) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (row >= idx->rows) return fail_arg(NMN_ERR_NOT_FOUND, "row out of range");
     HIP_TRY(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::mutex> lk(idx->mu);
+    wait_idle(idx, lk);
     hipStream_t s = idx->host_stream;
     HIP_TRY(hipMemcpyAsync(idx->corpus + row * (uint64_t)idx->ld, vec_host, (size_t)idx->dim * 4,
                            hipMemcpyHostToDevice, s));

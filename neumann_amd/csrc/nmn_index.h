@@ -1,6 +1,7 @@
 // nmn_index.h — the shard object behind the opaque `nmn_index` handle and the entry points other
 // translation units of libneumann_gpu.so use (nmn_ivf.hip).  Internal: never installed.
 #pragma once
+#include <condition_variable>
 #include <mutex>
 #include <unordered_map>
 
@@ -64,10 +65,18 @@ struct nmn_index {
     bool split_failed = false;   // allocation failed once: stay on the VALU sweeps
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;
-    hipStream_t host_stream = nullptr;
-    std::mutex mu;       // guards `ws` and the host-buffer API
+    hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot
+    std::mutex mu;       // guards every field below and all enqueueing; NOT held while a host-buffer search waits
     std::unordered_map<hipStream_t, Workspace*> ws;
     bool timing = false;
+    // Host-buffer searches from several threads overlap on the GPU: each takes one of kHostSlots (stream + workspace),
+    // enqueues under `mu`, releases `mu` and waits for its own stream.  Anything that changes the shard (upload,
+    // set_row, ...) first waits under `mu` until no slot is busy.
+    static constexpr int kHostSlots = 4;
+    hipStream_t host_slots[kHostSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool slot_busy[kHostSlots] = {false, false, false, false};
+    int slots_busy = 0;
+    std::condition_variable cv;
 };
 
 namespace nmn {

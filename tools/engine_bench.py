@@ -4,7 +4,9 @@
   python tools/engine_bench.py [--rows 1000000] [--dim 768] [--k 100] [--threads 1,4]
 
 Measures search_similar through neumann_amd.engine (ctypes -> C++ nmn_engine -> libneumann_gpu host-buffer API),
-from 1..N Python threads (ctypes releases the GIL during the call), plus the store rate of the incremental mirror."""
+from 1..N Python threads, plus the store rate of the incremental mirror.  NOTE: with more than one Python thread the
+numbers are dominated by the GIL hand-over around result marshalling (they drop); the library's own multi-thread scaling
+is measured without Python by tools/micro/engine_mt.cpp."""
 import argparse
 import json
 import os

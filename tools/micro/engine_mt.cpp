@@ -1,0 +1,61 @@
+// Multi-threaded throughput of the C++ VectorEngine mirror (no Python, no GIL):
+//   g++ -O2 -std=c++17 -I include -o engine_mt tools/micro/engine_mt.cpp -L neumann_amd/lib -lneumann_gpu -lpthread -Wl,-rpath,$PWD/neumann_amd/lib
+//   ./engine_mt rows dim k queries_per_thread threads...
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "neumann_engine.h"
+#include "neumann_gpu.h"
+
+int main(int argc, char** argv) {
+    const uint64_t rows = argc > 1 ? atoll(argv[1]) : 1000000;
+    const uint32_t dim = argc > 2 ? atoi(argv[2]) : 768;
+    const uint64_t k = argc > 3 ? atoll(argv[3]) : 100;
+    const int per = argc > 4 ? atoi(argv[4]) : 200;
+    nmn_engine_config cfg;
+    nmn_engine_config_default(&cfg);
+    nmn_engine* e = nullptr;
+    if (nmn_engine_create(&cfg, &e) != 0) { printf("create failed: %s\n", nmn_engine_last_error()); return 1; }
+    const uint64_t chunk = 50000;
+    std::vector<float> buf((size_t)chunk * dim);
+    std::vector<std::string> names(chunk);
+    std::vector<const char*> keys(chunk);
+    for (uint64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const uint64_t n = std::min(chunk, rows - r0);
+        nmn_synth_fill_host(buf.data(), 7, r0, n, dim);
+        for (uint64_t i = 0; i < n; i++) { names[i] = "k" + std::to_string(r0 + i); keys[i] = names[i].c_str(); }
+        if (nmn_engine_batch_store(e, keys.data(), buf.data(), n, dim) != 0) { printf("store failed\n"); return 1; }
+    }
+    std::vector<float> Q((size_t)64 * dim);
+    nmn_synth_fill_host(Q.data(), 8, 0, 64, dim);
+    nmn_results* r = nullptr;
+    if (nmn_engine_search_similar(e, Q.data(), dim, k, &r) != 0) { printf("search failed: %s\n", nmn_engine_last_error()); return 1; }
+    nmn_results_free(r);
+    for (int a = 5; a < argc; a++) {
+        const int nt = atoi(argv[a]);
+        std::atomic<int> bad{0};
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                for (int i = 0; i < per; i++) {
+                    nmn_results* rr = nullptr;
+                    if (nmn_engine_search_similar(e, Q.data() + (size_t)((t * per + i) % 64) * dim, dim, k, &rr) != 0 ||
+                        nmn_results_len(rr) != std::min<uint64_t>(k, rows))
+                        bad++;
+                    nmn_results_free(rr);
+                }
+            });
+        for (auto& x : th) x.join();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("rows=%lu dim=%u k=%lu threads=%d: %.0f queries/s (%.3f ms per query per thread)%s\n", (unsigned long)rows, dim,
+               (unsigned long)k, nt, nt * per / dt, dt / per * 1e3, bad ? "  ERRORS" : "");
+    }
+    nmn_engine_destroy(e);
+    return 0;
+}
