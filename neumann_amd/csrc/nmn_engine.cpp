@@ -8,6 +8,7 @@
 // Built with -ffp-contract=off: the zero-magnitude-query rule needs `simd::magnitude(query)` in
 // reference order on the host (validation, not the hot path).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include <shared_mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -275,6 +277,7 @@ struct nmn_engine {
     // on the GPU (libneumann_gpu gives each caller its own stream); everything that writes the store, builds a mirror
     // or evaluates a predicate (the column set keeps its result bitmap) takes the exclusive lock.
     std::shared_mutex mu;
+    std::atomic<int> writers_waiting{0};  // readers stand back while a writer waits (glibc's rwlock prefers readers)
     Collection dflt;
     Collection entities;                              // unified entity mode: keys whose TensorData has `_embedding`
     Collection artifacts;                             // tensor_blob: `_blob:meta:{id}` records that carry `_embedding`
@@ -295,6 +298,16 @@ struct nmn_engine {
 };
 
 namespace {
+
+// exclusive lock of the engine; announces itself so that new shared-lock searches wait for it
+struct WriteLock {
+    std::unique_lock<std::shared_mutex> l;
+    explicit WriteLock(nmn_engine* e) {
+        e->writers_waiting.fetch_add(1);
+        l = std::unique_lock<std::shared_mutex>(e->mu);
+        e->writers_waiting.fetch_sub(1);
+    }
+};
 
 Mirror* mirror_of(Collection* c, uint64_t dim) {
     auto it = c->mirrors.find(dim);
@@ -714,13 +727,14 @@ template <typename Resolve>
 nmn_status locked_search(nmn_engine* e, Resolve resolve, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
                          const char* op, const Deadline& dl, nmn_results* res) {
     {
+        while (e->writers_waiting.load() > 0) std::this_thread::yield();
         std::shared_lock<std::shared_mutex> rd(e->mu);
         Collection* c = resolve();
         if (!c) return NMN_OK;
         auto it = c->mirrors.find(dim);
         if (it != c->mirrors.end()) return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, it->second.get(), res);
     }
-    std::unique_lock<std::shared_mutex> wr(e->mu);
+    WriteLock wr(e);
     Collection* c = resolve();
     if (!c) return NMN_OK;
     return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, nullptr, res);
@@ -946,7 +960,7 @@ nmn_status nmn_engine_store_embedding_with_metadata(nmn_engine* e, const char* k
     if (!e || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (!v || dim == 0) return err_empty();  // lib.rs:1841-1843
     if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return store_into(e, &e->dflt, key, v, dim, meta, n_meta);
 }
 
@@ -959,7 +973,7 @@ nmn_status nmn_engine_batch_store(nmn_engine* e, const char* const* keys, const 
     if (!e || !keys || (!rows && n)) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (n && dim == 0) return err_empty();
     if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     for (uint64_t i = 0; i < n; i++) {
         if (!keys[i]) return fail(NMN_ERR_INVALID_ARGUMENT, "null key");
         store_into(e, &e->dflt, keys[i], rows + i * dim, dim, nullptr, 0);
@@ -980,32 +994,32 @@ static nmn_status get_from(Collection* c, const std::string& key, const std::str
 
 nmn_status nmn_engine_get_embedding(nmn_engine* e, const char* key, float* out, uint64_t cap, uint64_t* dim_out) {
     if (!e || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return get_from(&e->dflt, key, key, out, cap, dim_out);
 }
 
 nmn_status nmn_engine_delete_embedding(nmn_engine* e, const char* key) {
     if (!e || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return delete_from(&e->dflt, key, key);
 }
 
 int32_t nmn_engine_exists(nmn_engine* e, const char* key) {
     if (!e || !key) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->dflt.by_key.count(key) ? 1 : 0;
 }
 
 uint64_t nmn_engine_count(nmn_engine* e) {
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->dflt.live;
 }
 
 nmn_strlist* nmn_engine_list_keys(nmn_engine* e) {
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !l) return l;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     for (const auto& ent : e->dflt.slots)
         if (ent.live) l->items.push_back(ent.key);
     return l;
@@ -1013,7 +1027,7 @@ nmn_strlist* nmn_engine_list_keys(nmn_engine* e) {
 
 nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed) {
     if (!e) return fail(NMN_ERR_INVALID_ARGUMENT, "null engine");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     if (removed) *removed = e->dflt.live;
     e->dflt = Collection();
     return NMN_OK;
@@ -1076,7 +1090,7 @@ nmn_metalist* nmn_engine_get_metadata(nmn_engine* e, const char* key, nmn_status
         *status = fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
         return nullptr;
     }
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto it = e->dflt.by_key.find(key);
     if (it == e->dflt.by_key.end()) {
         *status = err_not_found(key);
@@ -1106,7 +1120,7 @@ void nmn_metalist_free(nmn_metalist* l) { delete l; }
 // update_metadata (lib.rs:3329-3351): set the given fields, keep the others and the vector
 nmn_status nmn_engine_update_metadata(nmn_engine* e, const char* key, const nmn_meta_field* meta, uint32_t n_meta) {
     if (!e || !key || (n_meta && !meta)) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto it = e->dflt.by_key.find(key);
     if (it == e->dflt.by_key.end()) return err_not_found(key);
     Entry& ent = e->dflt.slots[it->second];
@@ -1124,7 +1138,7 @@ nmn_status nmn_engine_update_metadata(nmn_engine* e, const char* key, const nmn_
 // remove_metadata_field (lib.rs:3353-3364): NotFound only for a missing key; a missing field is not an error
 nmn_status nmn_engine_remove_metadata_field(nmn_engine* e, const char* key, const char* field) {
     if (!e || !key || !field) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto it = e->dflt.by_key.find(key);
     if (it == e->dflt.by_key.end()) return err_not_found(key);
     Entry& ent = e->dflt.slots[it->second];
@@ -1143,7 +1157,7 @@ nmn_status nmn_engine_remove_metadata_field(nmn_engine* e, const char* key, cons
 
 int32_t nmn_engine_has_metadata_field(nmn_engine* e, const char* key, const char* field) {  // lib.rs:3366-3372
     if (!e || !key || !field) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto it = e->dflt.by_key.find(key);
     return (it != e->dflt.by_key.end() && e->dflt.slots[it->second].meta.count(field)) ? 1 : 0;
 }
@@ -1155,7 +1169,7 @@ nmn_status nmn_engine_get_metadata_field(nmn_engine* e, const char* key, const c
     if (!e || !key || !field || !out || !present) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     static thread_local Value hold;
     *present = 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto it = e->dflt.by_key.find(key);
     if (it == e->dflt.by_key.end()) return err_not_found(key);
     const Meta& meta = e->dflt.slots[it->second].meta;
@@ -1170,7 +1184,7 @@ nmn_status nmn_engine_get_metadata_field(nmn_engine* e, const char* key, const c
 // estimate_filter_selectivity (lib.rs:3695-3711): the first min(100, count) keys
 nmn_status nmn_engine_estimate_filter_selectivity(nmn_engine* e, const nmn_filter* f, float* out) {
     if (!e || !f || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     uint64_t sample = 0, matches = 0;
     for (const auto& ent : e->dflt.slots) {
         if (!ent.live) continue;
@@ -1185,7 +1199,7 @@ nmn_status nmn_engine_estimate_filter_selectivity(nmn_engine* e, const nmn_filte
 nmn_strlist* nmn_engine_list_keys_matching(nmn_engine* e, const nmn_filter* f) {  // lib.rs:3720-3725
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !f || !l) return l;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     for (const auto& ent : e->dflt.slots)
         if (ent.live && evaluate_filter(ent.meta, *f)) l->items.push_back(ent.key);
     return l;
@@ -1194,7 +1208,7 @@ nmn_strlist* nmn_engine_list_keys_matching(nmn_engine* e, const nmn_filter* f) {
 // batch_delete_embeddings (lib.rs:2924-2940): missing keys are skipped, the number deleted is returned
 nmn_status nmn_engine_batch_delete(nmn_engine* e, const char* const* keys, uint64_t n, uint64_t* deleted) {
     if (!e || (n && !keys)) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     uint64_t cnt = 0;
     for (uint64_t i = 0; i < n; i++)
         if (keys[i] && e->dflt.by_key.count(keys[i]) && delete_from(&e->dflt, keys[i], keys[i]) == NMN_OK) cnt++;
@@ -1204,7 +1218,7 @@ nmn_status nmn_engine_batch_delete(nmn_engine* e, const char* const* keys, uint6
 
 uint64_t nmn_engine_dimension(nmn_engine* e) {  // lib.rs:2298-2308: the first stored vector's length; 0 = None
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     for (const auto& ent : e->dflt.slots)
         if (ent.live) return ent.vec.size();
     return 0;
@@ -1212,7 +1226,7 @@ uint64_t nmn_engine_dimension(nmn_engine* e) {  // lib.rs:2298-2308: the first s
 
 int32_t nmn_engine_exists_in_collection(nmn_engine* e, const char* coll, const char* key) {  // lib.rs:1537-1540
     if (!e || !coll || !key) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     Collection* c = e->storage(coll, false);
     return (c && c->by_key.count(key)) ? 1 : 0;
 }
@@ -1220,7 +1234,7 @@ int32_t nmn_engine_exists_in_collection(nmn_engine* e, const char* coll, const c
 nmn_strlist* nmn_engine_list_collection_keys(nmn_engine* e, const char* coll) {  // lib.rs:1543-1550
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !coll || !l) return l;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     Collection* c = e->storage(coll, false);
     if (c)
         for (const auto& ent : c->slots)
@@ -1294,13 +1308,13 @@ nmn_status nmn_engine_blob_set_embedding(nmn_engine* e, const char* artifact_id,
     mf.name = "_filename";
     mf.value.kind = NMN_VAL_STRING;
     mf.value.s = filename ? filename : "";
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return store_into(e, &e->artifacts, artifact_id, v, dim, &mf, 1);
 }
 
 nmn_status nmn_engine_blob_remove(nmn_engine* e, const char* artifact_id) {  // BlobStore::delete drops the record
     if (!e || !artifact_id) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return delete_from(&e->artifacts, artifact_id, artifact_id);
 }
 
@@ -1344,7 +1358,7 @@ nmn_status nmn_engine_blob_similar(nmn_engine* e, const char* artifact_id, uint6
     *out = nullptr;
     std::vector<float> emb;
     {
-        std::unique_lock<std::shared_mutex> g(e->mu);
+        WriteLock g(e);
         auto it = e->artifacts.by_key.find(artifact_id);
         if (it == e->artifacts.by_key.end()) return err_not_found(artifact_id);  // BlobError::NotFound
         emb = e->artifacts.slots[it->second].vec;
@@ -1388,7 +1402,7 @@ nmn_status nmn_engine_build_ivf_index(nmn_engine* e, const nmn_ivf_options* opti
     auto res = std::unique_ptr<nmn_engine_ivf>(new (std::nothrow) nmn_engine_ivf());
     if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "ivf alloc");
     res->nprobe = o.nprobe ? o.nprobe : (uint64_t)std::ceil(std::sqrt((float)o.num_clusters));
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     // `let keys = self.list_keys()` then every vector in that order; one dimension only (lib.rs:2653-2668)
     std::vector<float> rows;
     uint64_t dim = 0;
@@ -1494,33 +1508,33 @@ nmn_status nmn_engine_set_entity_embedding(nmn_engine* e, const char* entity_key
     if (!e || !entity_key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (!v || dim == 0) return err_empty();  // lib.rs:3073-3075
     if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);  // 3077-3084
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return store_into(e, &e->entities, entity_key, v, dim, nullptr, 0);
 }
 
 nmn_status nmn_engine_get_entity_embedding(nmn_engine* e, const char* entity_key, float* out, uint64_t cap,
                                            uint64_t* dim_out) {
     if (!e || !entity_key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return get_from(&e->entities, entity_key, entity_key, out, cap, dim_out);  // NotFound(entity_key), lib.rs:3110-3119
 }
 
 int32_t nmn_engine_entity_has_embedding(nmn_engine* e, const char* entity_key) {  // lib.rs:3123-3128
     if (!e || !entity_key) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->entities.by_key.count(entity_key) ? 1 : 0;
 }
 
 nmn_status nmn_engine_remove_entity_embedding(nmn_engine* e, const char* entity_key) {  // lib.rs:3135-3147
     if (!e || !entity_key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return delete_from(&e->entities, entity_key, entity_key);
 }
 
 nmn_strlist* nmn_engine_scan_entities_with_embeddings(nmn_engine* e) {  // lib.rs:3224-3232
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !l) return l;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     for (const auto& ent : e->entities.slots)
         if (ent.live) l->items.push_back(ent.key);
     return l;
@@ -1528,7 +1542,7 @@ nmn_strlist* nmn_engine_scan_entities_with_embeddings(nmn_engine* e) {  // lib.r
 
 uint64_t nmn_engine_count_entities_with_embeddings(nmn_engine* e) {  // lib.rs:3235-3237
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->entities.live;
 }
 
@@ -1592,7 +1606,7 @@ nmn_status nmn_engine_search_similar_filtered(nmn_engine* e, const float* q, uin
     else nmn_filtered_config_default(&cfg);
     nmn_results* res = new_results();
     if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     int strategy = cfg.strategy == NMN_FILTER_AUTO ? choose_strategy(&e->dflt, *filter, cfg) : cfg.strategy;
     if (dl.expired()) {
         delete res;
@@ -1628,7 +1642,7 @@ nmn_status nmn_engine_compute_similarity(nmn_engine* e, const float* a, uint64_t
     if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (!a || !b || na == 0 || nb == 0) return err_empty();  // lib.rs:2279-2281
     if (na != nb) return err_dim(na, nb);                    // lib.rs:2282-2287
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto& slot = e->scratch[na];
     if (!slot) {
         slot = std::make_unique<Mirror>();
@@ -1653,7 +1667,7 @@ nmn_status nmn_engine_compute_similarity(nmn_engine* e, const float* a, uint64_t
 // ---- collections ---------------------------------------------------------------------------------
 nmn_status nmn_engine_create_collection(nmn_engine* e, const char* name, uint64_t dimension, int32_t metric) {
     if (!e || !name) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     if (e->configs.count(name)) return fail(NMN_ERR_COLLECTION_EXISTS, std::string("Collection already exists: ") + name);
     e->configs[name] = CollectionConfig{dimension, metric};
     return NMN_OK;
@@ -1661,7 +1675,7 @@ nmn_status nmn_engine_create_collection(nmn_engine* e, const char* name, uint64_
 
 nmn_status nmn_engine_delete_collection(nmn_engine* e, const char* name) {
     if (!e || !name) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     if (!e->configs.count(name)) return fail(NMN_ERR_COLLECTION_NOT_FOUND, std::string("Collection not found: ") + name);
     e->configs.erase(name);
     e->colls.erase(name);  // "Delete all embeddings in the collection"
@@ -1670,13 +1684,13 @@ nmn_status nmn_engine_delete_collection(nmn_engine* e, const char* name) {
 
 int32_t nmn_engine_collection_exists(nmn_engine* e, const char* name) {
     if (!e || !name) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->configs.count(name) ? 1 : 0;
 }
 
 uint64_t nmn_engine_collection_count(nmn_engine* e, const char* name) {
     if (!e || !name) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     Collection* c = e->storage(name, false);
     return c ? c->live : 0;
 }
@@ -1684,7 +1698,7 @@ uint64_t nmn_engine_collection_count(nmn_engine* e, const char* name) {
 nmn_strlist* nmn_engine_list_collections(nmn_engine* e) {
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !l) return l;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     for (const auto& kv : e->configs) l->items.push_back(kv.first);
     return l;
 }
@@ -1693,7 +1707,7 @@ nmn_status nmn_engine_store_in_collection(nmn_engine* e, const char* coll, const
                                           uint64_t dim, const nmn_meta_field* meta, uint32_t n_meta) {
     if (!e || !coll || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (!v || dim == 0) return err_empty();  // lib.rs:1454-1456
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto cit = e->configs.find(coll);
     if (cit != e->configs.end() && cit->second.dimension && dim != cit->second.dimension)
         return err_dim(cit->second.dimension, dim);  // lib.rs:1459-1469
@@ -1704,13 +1718,13 @@ nmn_status nmn_engine_store_in_collection(nmn_engine* e, const char* coll, const
 nmn_status nmn_engine_get_from_collection(nmn_engine* e, const char* coll, const char* key, float* out,
                                           uint64_t cap, uint64_t* dim_out) {
     if (!e || !coll || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return get_from(e->storage(coll, false), key, std::string(coll) + ":" + key, out, cap, dim_out);
 }
 
 nmn_status nmn_engine_delete_from_collection(nmn_engine* e, const char* coll, const char* key) {
     if (!e || !coll || !key) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     Collection* c = e->storage(coll, false);
     const std::string shown = std::string(coll) + ":" + key;
     if (!c) return err_not_found(shown);
@@ -1757,7 +1771,7 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
     nmn_filtered_config cfg;
     if (config) cfg = *config;
     else nmn_filtered_config_default(&cfg);
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     auto cit = e->configs.find(coll);
     int32_t coll_metric = NMN_METRIC_COSINE;
     if (cit != e->configs.end()) {
@@ -1880,7 +1894,7 @@ void nmn_filter_free(nmn_filter* f) { delete f; }
 
 uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f) {
     if (!e || !f) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     uint64_t n = 0;
     for (const auto& ent : e->dflt.slots)
         if (ent.live && evaluate_filter(ent.meta, *f)) n++;
@@ -1889,25 +1903,25 @@ uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f) {
 
 uint64_t nmn_engine_device_filter_evals(nmn_engine* e) {
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->device_filters;
 }
 
 uint64_t nmn_engine_column_builds(nmn_engine* e) {
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->column_builds;
 }
 
 uint64_t nmn_engine_mirror_builds(nmn_engine* e) {
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     return e->mirror_builds;
 }
 
 int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll) {
     if (!e) return 0;
-    std::unique_lock<std::shared_mutex> g(e->mu);
+    WriteLock g(e);
     Collection* c = e->storage(coll, false);
     return (c && !c->mirrors.empty()) ? 1 : 0;
 }
