@@ -53,7 +53,7 @@ nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, wh
 // caller holds idx->mu through `lk`
 static nmn_status slot_acquire(nmn_index* idx, std::unique_lock<std::mutex>& lk, int* slot_out) {
     for (;;) {
-        for (int i = 0; i < nmn_index::kHostSlots && idx->writers_waiting == 0; i++) {
+        for (int i = 0; i < nmn_index::kHostSlots; i++) {
             if (idx->slot_busy[i]) continue;
             if (!idx->host_slots[i]) {
                 if (i == 0) idx->host_slots[0] = idx->host_stream;
@@ -77,10 +77,7 @@ static void slot_release(nmn_index* idx, int slot) {  // takes idx->mu itself
 }
 // before changing the shard (or using the host stream's workspace exclusively): no host-buffer search in flight
 static void wait_idle(nmn_index* idx, std::unique_lock<std::mutex>& lk) {
-    idx->writers_waiting++;
     idx->cv.wait(lk, [&] { return idx->slots_busy == 0; });
-    idx->writers_waiting--;
-    idx->cv.notify_all();  // searches that stood back for this writer will find `mu` free once the caller is done
 }
 
 static void ws_free(Workspace* w) {

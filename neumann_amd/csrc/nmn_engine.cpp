@@ -277,7 +277,16 @@ struct nmn_engine {
     // on the GPU (libneumann_gpu gives each caller its own stream); everything that writes the store, builds a mirror
     // or evaluates a predicate (the column set keeps its result bitmap) takes the exclusive lock.
     std::shared_mutex mu;
-    std::atomic<int> writers_waiting{0};  // readers stand back while a writer waits (glibc's rwlock prefers readers)
+    // FIFO turnstile in front of `mu`: glibc's rwlock prefers readers (a steady stream of searches would starve every
+    // store), and naive writer preference starves the searches under a steady stream of stores.  Everybody takes a
+    // ticket; a reader gives it back as soon as it holds the shared lock (readers behind it then overlap with it), a
+    // writer keeps it for its whole critical section.
+    std::atomic<uint64_t> ticket_next{0}, ticket_serving{0};
+    void gate_enter() {
+        const uint64_t t = ticket_next.fetch_add(1);
+        while (ticket_serving.load(std::memory_order_acquire) != t) std::this_thread::yield();
+    }
+    void gate_leave() { ticket_serving.fetch_add(1, std::memory_order_release); }
     Collection dflt;
     Collection entities;                              // unified entity mode: keys whose TensorData has `_embedding`
     Collection artifacts;                             // tensor_blob: `_blob:meta:{id}` records that carry `_embedding`
@@ -301,11 +310,24 @@ namespace {
 
 // exclusive lock of the engine; announces itself so that new shared-lock searches wait for it
 struct WriteLock {
+    nmn_engine* e;
     std::unique_lock<std::shared_mutex> l;
-    explicit WriteLock(nmn_engine* e) {
-        e->writers_waiting.fetch_add(1);
+    explicit WriteLock(nmn_engine* e_) : e(e_) {
+        e->gate_enter();
         l = std::unique_lock<std::shared_mutex>(e->mu);
-        e->writers_waiting.fetch_sub(1);
+    }
+    ~WriteLock() {
+        l.unlock();
+        e->gate_leave();
+    }
+};
+// shared lock of the engine, taken in ticket order
+struct ReadLock {
+    std::shared_lock<std::shared_mutex> l;
+    explicit ReadLock(nmn_engine* e) {
+        e->gate_enter();
+        l = std::shared_lock<std::shared_mutex>(e->mu);
+        e->gate_leave();
     }
 };
 
@@ -727,8 +749,7 @@ template <typename Resolve>
 nmn_status locked_search(nmn_engine* e, Resolve resolve, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
                          const char* op, const Deadline& dl, nmn_results* res) {
     {
-        while (e->writers_waiting.load() > 0) std::this_thread::yield();
-        std::shared_lock<std::shared_mutex> rd(e->mu);
+        ReadLock rd(e);
         Collection* c = resolve();
         if (!c) return NMN_OK;
         auto it = c->mirrors.find(dim);
@@ -1345,7 +1366,7 @@ nmn_status nmn_engine_blob_search_by_embedding(nmn_engine* e, const float* q, ui
             delete res;
             return st;
         }
-        std::shared_lock<std::shared_mutex> rd(e->mu);
+        ReadLock rd(e);
         fill_filenames(&e->artifacts, res);
     }
     *out = res;
@@ -1740,7 +1761,7 @@ nmn_status nmn_engine_search_in_collection(nmn_engine* e, const char* coll, cons
     if (st != NMN_OK) return st;
     int32_t metric = NMN_METRIC_COSINE;
     {
-        std::shared_lock<std::shared_mutex> rd(e->mu);
+        ReadLock rd(e);
         auto cit = e->configs.find(coll);
         if (cit != e->configs.end()) {
             if (cit->second.dimension && dim != cit->second.dimension) return err_dim(cit->second.dimension, dim);

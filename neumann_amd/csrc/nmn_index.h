@@ -76,7 +76,6 @@ struct nmn_index {
     hipStream_t host_slots[kHostSlots] = {nullptr, nullptr, nullptr, nullptr};
     bool slot_busy[kHostSlots] = {false, false, false, false};
     int slots_busy = 0;
-    int writers_waiting = 0;  // searches do not take a slot while a writer waits for the slots to drain
     std::condition_variable cv;
 };
 

@@ -684,3 +684,24 @@ def test_concurrent_search_and_store(E):
         t.join()
     assert not errors, errors
     assert engine.count() == 220
+
+
+def test_native_threads_searching_while_writers_write():
+    """C++ threads on the engine ABI (no GIL): 6 searchers overlap on the GPU through the shard's host slots while 2
+    writers overwrite, append and delete — no error, no crash, every search returns a full result list."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "micro", "engine_mt")
+    lib = os.path.join(root, "neumann_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tools", "micro", "engine_mt.cpp"), "-L", lib, "-lneumann_gpu", "-lpthread",
+                           "-Wl,-rpath," + lib])
+    import torch  # the harness must resolve libamdhip64.so.7 the way the Python processes do (torch's bundled runtime)
+    env = dict(os.environ, ENGINE_MT_WRITERS="2",
+               LD_LIBRARY_PATH=os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, "30000", "64", "50", "300", "1", "6"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rows=")]
+    assert len(lines) == 2 and not any("ERRORS" in l for l in lines), out.stdout
+    assert all("writers=2" in l for l in lines)

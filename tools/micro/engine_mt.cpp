@@ -39,6 +39,24 @@ int main(int argc, char** argv) {
     for (int a = 5; a < argc; a++) {
         const int nt = atoi(argv[a]);
         std::atomic<int> bad{0};
+        std::atomic<bool> stop{false};
+        std::atomic<long> writes{0};
+        // ENGINE_MT_WRITERS=n: n threads keep overwriting existing keys and storing / deleting extra ones meanwhile
+        const int writers = getenv("ENGINE_MT_WRITERS") ? atoi(getenv("ENGINE_MT_WRITERS")) : 0;
+        std::vector<std::thread> wr;
+        for (int w = 0; w < writers; w++)
+            wr.emplace_back([&, w] {
+                std::vector<float> v(dim, 0.5f);
+                for (long i = 0; !stop; i++) {
+                    const std::string extra = "extra" + std::to_string(w) + "_" + std::to_string(i % 64);
+                    const std::string existing = "k" + std::to_string((i * 7919 + w) % rows);
+                    v[i % dim] = (float)(i % 13) - 6.0f;
+                    if (nmn_engine_store_embedding(e, extra.c_str(), v.data(), dim) != 0) bad++;
+                    if (nmn_engine_store_embedding(e, existing.c_str(), v.data(), dim) != 0) bad++;
+                    if (i % 3 == 2 && nmn_engine_delete_embedding(e, extra.c_str()) != 0) bad++;
+                    writes += 2;
+                }
+            });
         auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++)
@@ -46,15 +64,18 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < per; i++) {
                     nmn_results* rr = nullptr;
                     if (nmn_engine_search_similar(e, Q.data() + (size_t)((t * per + i) % 64) * dim, dim, k, &rr) != 0 ||
-                        nmn_results_len(rr) != std::min<uint64_t>(k, rows))
+                        nmn_results_len(rr) < std::min<uint64_t>(k, rows))
                         bad++;
                     nmn_results_free(rr);
                 }
             });
         for (auto& x : th) x.join();
+        stop = true;
+        for (auto& x : wr) x.join();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        printf("rows=%lu dim=%u k=%lu threads=%d: %.0f queries/s (%.3f ms per query per thread)%s\n", (unsigned long)rows, dim,
-               (unsigned long)k, nt, nt * per / dt, dt / per * 1e3, bad ? "  ERRORS" : "");
+        printf("rows=%lu dim=%u k=%lu threads=%d writers=%d (%ld writes): %.0f queries/s (%.3f ms per query per thread)%s\n",
+               (unsigned long)rows, dim, (unsigned long)k, nt, writers, writes.load(), nt * per / dt, dt / per * 1e3,
+               bad ? "  ERRORS" : "");
     }
     nmn_engine_destroy(e);
     return 0;
