@@ -205,7 +205,7 @@ typedef struct nmn_ivf_options {   /* IVFBuildOptions / IVFConfig (Flat storage)
 } nmn_ivf_options;
 typedef struct nmn_engine_ivf nmn_engine_ivf; /* (IVFIndex, Vec<String> key_mapping) */
 void nmn_ivf_options_default(nmn_ivf_options* o);
-/* build_ivf_index (lib.rs:2641-2694): k-means on the host in the reference's operation order, lists on the GPU */
+/* build_ivf_index (lib.rs:2641-2694): k-means (bit for bit) and list assignment on the GPU, see nmn_ivf_build */
 nmn_status nmn_engine_build_ivf_index(nmn_engine* e, const nmn_ivf_options* options, nmn_engine_ivf** out);
 void nmn_engine_ivf_free(nmn_engine_ivf* ivf);
 uint64_t nmn_engine_ivf_len(const nmn_engine_ivf* ivf);

@@ -294,6 +294,21 @@ typedef struct nmn_ivf nmn_ivf;
 /* desc: dim, capacity_rows (vectors that can be added), device; centroids: HOST, n_clusters x dim. */
 nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters, nmn_ivf** out);
 nmn_status nmn_ivf_destroy(nmn_ivf* ivf);
+/* IVFIndex::train(vectors) followed by add(v) for every vector (ivf.rs:222-316), the k-means
+ * (tensor_store/src/delta_vector.rs:737-901, KMeans::fit) run on the GPU bit for bit: assignment = the exact
+ * centroid sweep, centroid update = one thread per (cluster, dimension) adding the members in vector order,
+ * k-means++ distances on the device with the f32 running sums on the host.  rows_host: n x dim; the index gets
+ * min(num_clusters, n) lists; desc->capacity_rows >= n. */
+typedef struct nmn_kmeans_options {
+    uint64_t max_iterations;      /* KMeansConfig::max_iterations (100)        */
+    float convergence_threshold;  /* KMeansConfig::convergence_threshold (1e-4) */
+    uint64_t seed;                /* KMeansConfig::seed (42)                   */
+    int32_t init_method;          /* 0 = KMeansInit::Random, 1 = KMeansPlusPlus */
+} nmn_kmeans_options;
+nmn_status nmn_ivf_build(const nmn_index_desc* desc, const float* rows_host, uint64_t n, uint32_t num_clusters,
+                         const nmn_kmeans_options* opt, nmn_ivf** out);
+/* The centroids, row-major n_clusters x dim, into HOST memory. */
+nmn_status nmn_ivf_centroids(nmn_ivf* ivf, float* out, uint64_t cap_floats);
 /* IVFIndex::add for n vectors (HOST, n x dim): each goes to the list of its nearest centroid
  * (squared Euclidean, first minimum: find_nearest_centroid, ivf.rs:490-497) and gets the next id.
  * clusters_out (nullable, HOST [n]) receives the chosen clusters. */

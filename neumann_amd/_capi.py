@@ -50,6 +50,12 @@ class SearchStats(C.Structure):
                 ("scan_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+class KMeansOptions(C.Structure):
+    """nmn_kmeans_options (KMeansConfig, tensor_store/src/delta_vector.rs:691-711)."""
+    _fields_ = [("max_iterations", C.c_uint64), ("convergence_threshold", C.c_float), ("seed", C.c_uint64),
+                ("init_method", C.c_int32)]
+
+
 class PredOp(C.Structure):
     """nmn_pred_op: one step of a WHERE-predicate program (include/neumann_gpu.h, NMN_PRED_*)."""
     _fields_ = [("op", C.c_uint32), ("cmp", C.c_uint32), ("vkind", C.c_uint32), ("column", C.c_uint32),
@@ -105,6 +111,8 @@ SIGNATURES = {
     "nmn_columns_read_mask": (C.c_int32, [vp, vp, C.c_uint64]),
     "nmn_ivf_create": (C.c_int32, [C.POINTER(IndexDesc), vp, C.c_uint32, C.POINTER(vp)]),
     "nmn_ivf_destroy": (C.c_int32, [vp]),
+    "nmn_ivf_build": (C.c_int32, [C.POINTER(IndexDesc), vp, C.c_uint64, C.c_uint32, C.POINTER(KMeansOptions), C.POINTER(vp)]),
+    "nmn_ivf_centroids": (C.c_int32, [vp, vp, C.c_uint64]),
     "nmn_ivf_add": (C.c_int32, [vp, vp, C.c_uint64, vp]),
     "nmn_ivf_len": (C.c_uint64, [vp]),
     "nmn_ivf_clusters": (C.c_uint32, [vp]),

@@ -26,7 +26,8 @@ SOURCES = {
     "nmn_synth.hip": ["-ffp-contract=off"],
     "nmn_sortk.hip": [],
     "nmn_columns.hip": [],
-    "nmn_ivf.hip": [],
+    "nmn_ivf.hip": ["-ffp-contract=off"],
+    "nmn_kmeans.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_api.hip": [],
     "nmn_engine.cpp": ["-ffp-contract=off"],
 }

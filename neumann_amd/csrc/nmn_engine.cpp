@@ -341,130 +341,6 @@ Mirror* mirror_of(Collection* c, uint64_t dim) {
     return it->second.get();
 }
 
-// ---- IVF-Flat index built from the store (lib.rs:2641-2694) ------------------------------------------
-// KMeans::fit (tensor_store/src/delta_vector.rs:737-777) restated on the host in the reference's own
-// operation order — training is not on the SIMILAR path and its result (the centroids) must be the
-// reference's bit for bit, or every list assignment downstream differs.  This file is compiled with
-// -ffp-contract=off.
-namespace kmeans {
-
-inline uint64_t lcg(uint64_t s) { return s * 6364136223846793005ull + 1ull; }  // wrapping_mul + wrapping_add
-
-// euclidean_distance_sq (delta_vector.rs:896-901): strictly sequential f32 sum, `.sum()` folds from -0.0
-float dist_sq(const float* a, const float* b, uint64_t dim) {
-    float s = -0.0f;
-    for (uint64_t i = 0; i < dim; i++) {
-        const float d = a[i] - b[i];
-        const float p = d * d;
-        s = s + p;
-    }
-    return s;
-}
-
-// nearest_centroid (856-863): min_by keeps the earlier element unless the later one is strictly less
-uint32_t nearest(const float* v, const std::vector<float>& cents, uint32_t k, uint64_t dim) {
-    uint32_t best = 0;
-    float best_d = dist_sq(v, cents.data(), dim);
-    for (uint32_t c = 1; c < k; c++) {
-        const float d = dist_sq(v, cents.data() + (size_t)c * dim, dim);
-        if (d < best_d) {
-            best = c;
-            best_d = d;
-        }
-    }
-    return best;
-}
-
-std::vector<float> init_random(const float* rows, uint64_t n, uint64_t dim, uint32_t k, uint64_t seed) {  // 781-800
-    std::vector<uint64_t> idx(n);
-    for (uint64_t i = 0; i < n; i++) idx[i] = i;
-    uint64_t state = seed;
-    for (uint64_t i = n - 1; i >= 1; i--) {
-        state = lcg(state);
-        std::swap(idx[i], idx[state % (i + 1)]);
-    }
-    std::vector<float> c((size_t)k * dim);
-    for (uint32_t j = 0; j < k; j++) memcpy(c.data() + (size_t)j * dim, rows + idx[j] * dim, dim * sizeof(float));
-    return c;
-}
-
-std::vector<float> init_plusplus(const float* rows, uint64_t n, uint64_t dim, uint32_t k, uint64_t seed) {  // 805-853
-    std::vector<float> c;
-    c.reserve((size_t)k * dim);
-    uint64_t state = lcg(seed);
-    const float* first = rows + (state % n) * dim;
-    c.insert(c.end(), first, first + dim);
-    std::vector<float> dist(n, std::numeric_limits<float>::max());
-    for (uint32_t j = 1; j < k; j++) {
-        const float* last = c.data() + (size_t)(j - 1) * dim;
-        for (uint64_t i = 0; i < n; i++) dist[i] = std::fmin(dist[i], dist_sq(rows + i * dim, last, dim));  // f32::min
-        float total = -0.0f;
-        for (uint64_t i = 0; i < n; i++) total = total + dist[i];
-        state = lcg(state);
-        uint64_t pick;
-        if (total == 0.0f) {
-            pick = state % n;
-        } else {
-            const float frac = (float)state / (float)UINT64_MAX;  // `rng_state as f32 / u64::MAX as f32`
-            const float threshold = frac * total;
-            float cumulative = 0.0f;
-            pick = 0;
-            for (uint64_t i = 0; i < n; i++) {
-                cumulative = cumulative + dist[i];
-                if (cumulative >= threshold) {
-                    pick = i;
-                    break;
-                }
-            }
-        }
-        const float* src = rows + pick * dim;
-        c.insert(c.end(), src, src + dim);
-    }
-    return c;
-}
-
-// KMeans::fit; rows is n x dim row-major.  Returns k' = min(k, n) centroids.
-std::vector<float> fit(const float* rows, uint64_t n, uint64_t dim, uint64_t k_in, const nmn_ivf_options& o,
-                       uint32_t* k_out) {
-    *k_out = 0;
-    if (n == 0 || k_in == 0) return {};
-    const uint32_t k = (uint32_t)std::min<uint64_t>(k_in, n);
-    *k_out = k;
-    std::vector<float> cents = o.init_method == NMN_KMEANS_INIT_RANDOM ? init_random(rows, n, dim, k, o.seed)
-                                                                       : init_plusplus(rows, n, dim, k, o.seed);
-    std::vector<uint32_t> assign(n, 0);
-    std::vector<float> sums((size_t)k * dim);
-    std::vector<uint64_t> counts(k);
-    for (uint64_t it = 0; it < o.max_iterations; it++) {
-        for (uint64_t i = 0; i < n; i++) assign[i] = nearest(rows + i * dim, cents, k, dim);
-        // update_centroids (867-893): sequential f32 sums in vector order, then sum / count as f32
-        std::fill(sums.begin(), sums.end(), 0.0f);
-        std::fill(counts.begin(), counts.end(), 0ull);
-        for (uint64_t i = 0; i < n; i++) {
-            float* sm = sums.data() + (size_t)assign[i] * dim;
-            const float* v = rows + i * dim;
-            counts[assign[i]]++;
-            for (uint64_t j = 0; j < dim; j++) sm[j] = sm[j] + v[j];
-        }
-        for (uint32_t c = 0; c < k; c++) {
-            float* sm = sums.data() + (size_t)c * dim;
-            if (counts[c] == 0) std::fill(sm, sm + dim, 0.0f);
-            else {
-                const float cnt = (float)counts[c];
-                for (uint64_t j = 0; j < dim; j++) sm[j] = sm[j] / cnt;
-            }
-        }
-        float movement = 0.0f;  // fold(0.0f32, f32::max)
-        for (uint32_t c = 0; c < k; c++)
-            movement = std::fmax(movement, std::sqrt(dist_sq(cents.data() + (size_t)c * dim, sums.data() + (size_t)c * dim, dim)));
-        cents.swap(sums);
-        if (movement < o.convergence_threshold) break;
-    }
-    return cents;
-}
-
-}  // namespace kmeans
-
 // ---- metadata columns of a mirror -------------------------------------------------------------------
 // ScalarValue -> (kind, payload) cell; strings get (or take) an id in the field's dictionary
 void encode_cell(FieldColumn& fc, const Value& v, uint8_t* kind, uint64_t* payload) {
@@ -1441,19 +1317,23 @@ nmn_status nmn_engine_build_ivf_index(nmn_engine* e, const nmn_ivf_options* opti
     }
     if (e->cfg.max_dimension && dim > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, dim);  // lib.rs:2671-2680
     res->dim = dim;
-    res->centroids = kmeans::fit(rows.data(), n, dim, o.num_clusters, o, &res->n_clusters);  // index.train
-    if (res->n_clusters == 0) {
-        *out = res.release();
-        return NMN_OK;
-    }
+    // index.train(&vectors) then index.add(v) for every vector — both on the GPU, the k-means bit for bit
+    // (nmn_ivf_build: exact centroid sweeps for the assignments, sequential per-(cluster, dimension) sums for the update)
     nmn_index_desc d{};
     d.dim = (uint32_t)dim;
     d.capacity_rows = n;
     d.device = e->cfg.device;
     d.cand_cap = e->cfg.cand_cap;
-    nmn_status st = nmn_ivf_create(&d, res->centroids.data(), res->n_clusters, &res->index);
+    nmn_kmeans_options ko{};
+    ko.max_iterations = o.max_iterations;
+    ko.convergence_threshold = o.convergence_threshold;
+    ko.seed = o.seed;
+    ko.init_method = o.init_method == NMN_KMEANS_INIT_RANDOM ? 0 : 1;
+    nmn_status st = nmn_ivf_build(&d, rows.data(), n, (uint32_t)std::min<uint64_t>(o.num_clusters, UINT32_MAX), &ko, &res->index);
     if (st != NMN_OK) return err_gpu(st);
-    st = nmn_ivf_add(res->index, rows.data(), n, nullptr);  // `for vector in &vectors { index.add(vector) }`
+    res->n_clusters = nmn_ivf_clusters(res->index);
+    res->centroids.resize((size_t)res->n_clusters * dim);
+    st = nmn_ivf_centroids(res->index, res->centroids.data(), res->centroids.size());
     if (st != NMN_OK) return err_gpu(st);
     *out = res.release();
     return NMN_OK;

@@ -206,6 +206,11 @@ uint64_t largek_sort_len(uint64_t n_rows);
 hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* keys, uint32_t k, uint64_t row_base,
                          uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s);
 
+// k-means training of an IVF index (nmn_kmeans.hip)
+hipError_t launch_kmeans_update(const float* corpus, uint32_t ld, uint32_t dim, const uint32_t* members,
+                                const uint64_t* offsets, uint32_t k, float* new_centroids, hipStream_t s);
+hipError_t launch_kmeans_min_update(float* dist, const uint32_t* neg_bits, uint64_t n, hipStream_t s);
+
 // synthetic data
 hipError_t launch_synth_fill(float* corpus, uint32_t ld, uint32_t dim, uint64_t seed, uint64_t global_row0,
                              uint64_t local_row0, uint64_t n, hipStream_t s);

@@ -14,6 +14,7 @@
 // distances keep candidate order = probe order of the cluster, then list (= id) order (stable sort,
 // ivf.rs:402).  `add` picks the first nearest centroid (`min_by`, ivf.rs:490-497).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -94,6 +95,7 @@ struct nmn_ivf {
     uint64_t cap = 0;
     uint32_t* assign = nullptr;          // device [cap]
     std::vector<uint32_t> assign_host;   // same, for cluster_sizes and the tie order of equal distances
+    std::vector<float> centroids_host;   // trained centroids (nmn_ivf_build), row-major n_clusters x dim
     hipStream_t stream = nullptr;
     uint32_t* cscores = nullptr;         // exact -d^2 of a chunk of queries vs every centroid (tile-major)
     size_t cscores_cap = 0;
@@ -136,9 +138,8 @@ extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
     return NMN_OK;
 }
 
-extern "C" nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters,
-                                     nmn_ivf** out) {
-    if (!desc || !centroids || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+// allocate the index; `centroids` may be null (nmn_ivf_build trains them afterwards)
+static nmn_status ivf_new(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters, nmn_ivf** out) {
     *out = nullptr;
     if (n_clusters == 0) return set_error(NMN_ERR_INVALID_ARGUMENT, "an IVF index needs at least one centroid");
     nmn_ivf* ivf = new (std::nothrow) nmn_ivf();
@@ -155,8 +156,10 @@ extern "C" nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* ce
     cd.device = ivf->vectors->device;
     st = nmn_index_create(&cd, &ivf->centroids);
     if (st != NMN_OK) return bail(st);
-    st = nmn_index_upload(ivf->centroids, centroids, 0, n_clusters);
-    if (st != NMN_OK) return bail(st);
+    if (centroids) {
+        st = nmn_index_upload(ivf->centroids, centroids, 0, n_clusters);
+        if (st != NMN_OK) return bail(st);
+    }
     ivf->n_clusters = n_clusters;
     ivf->dim = desc->dim;
     ivf->device = ivf->vectors->device;
@@ -191,6 +194,12 @@ extern "C" nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* ce
     return NMN_OK;
 }
 
+extern "C" nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters,
+                                     nmn_ivf** out) {
+    if (!desc || !centroids || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    return ivf_new(desc, centroids, n_clusters, out);
+}
+
 extern "C" uint64_t nmn_ivf_len(const nmn_ivf* ivf) { return ivf ? ivf->vectors->rows : 0; }
 extern "C" uint32_t nmn_ivf_clusters(const nmn_ivf* ivf) { return ivf ? ivf->n_clusters : 0; }
 extern "C" nmn_index* nmn_ivf_vectors(nmn_ivf* ivf) { return ivf ? ivf->vectors : nullptr; }
@@ -223,6 +232,25 @@ static nmn_status centroid_scores(nmn_ivf* ivf, const float* qpad_dev, uint32_t 
     return NMN_OK;
 }
 
+// nearest centroid (first minimum of the exact squared distances) of rows [row0, row0 + n) -> assign / assign_host
+static nmn_status assign_rows(nmn_ivf* ivf, uint64_t row0, uint64_t n) {
+    const uint32_t ld = ivf->vectors->ld;
+    if (ivf->assign_host.size() < row0 + n) ivf->assign_host.resize(row0 + n);
+    for (uint64_t off = 0; off < n; off += ivf->assign_chunk) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(ivf->assign_chunk, n - off);
+        // the rows are laid out exactly like padded queries: score them against the centroids in place
+        nmn_status st = centroid_scores(ivf, ivf->vectors->corpus + (row0 + off) * (uint64_t)ld, cnt);
+        if (st != NMN_OK) return st;
+        hipLaunchKernelGGL(ivf_assign_kernel, dim3((cnt * 64 + 255) / 256), dim3(256), 0, ivf->stream, ivf->cscores,
+                           ivf->n_clusters, cnt, cnt, ivf->assign + row0 + off);
+        IVF_TRY(hipGetLastError());
+        IVF_TRY(hipMemcpyAsync(ivf->assign_host.data() + row0 + off, ivf->assign + row0 + off, (size_t)cnt * 4,
+                               hipMemcpyDeviceToHost, ivf->stream));
+    }
+    IVF_TRY(hipStreamSynchronize(ivf->stream));
+    return NMN_OK;
+}
+
 extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t n, uint32_t* clusters_out) {
     if (!ivf || (n && !rows_host)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return NMN_OK;
@@ -232,21 +260,192 @@ extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t
     if (st != NMN_OK) return st;
     IVF_TRY(hipSetDevice(ivf->device));
     IVF_TRY(hipStreamSynchronize(ivf->vectors->host_stream));  // rows are in place before another stream reads them
-    const uint32_t ld = ivf->vectors->ld;
-    ivf->assign_host.resize(row0 + n);
-    for (uint64_t off = 0; off < n; off += ivf->assign_chunk) {
-        const uint32_t cnt = (uint32_t)std::min<uint64_t>(ivf->assign_chunk, n - off);
-        // the new rows are laid out exactly like padded queries: score them against the centroids in place
-        st = centroid_scores(ivf, ivf->vectors->corpus + (row0 + off) * (uint64_t)ld, cnt);
-        if (st != NMN_OK) return st;
-        hipLaunchKernelGGL(ivf_assign_kernel, dim3((cnt * 64 + 255) / 256), dim3(256), 0, ivf->stream, ivf->cscores,
-                           ivf->n_clusters, cnt, cnt, ivf->assign + row0 + off);
-        IVF_TRY(hipGetLastError());
-        IVF_TRY(hipMemcpyAsync(ivf->assign_host.data() + row0 + off, ivf->assign + row0 + off, (size_t)cnt * 4,
-                               hipMemcpyDeviceToHost, ivf->stream));
-    }
-    IVF_TRY(hipStreamSynchronize(ivf->stream));
+    st = assign_rows(ivf, row0, n);
+    if (st != NMN_OK) return st;
     if (clusters_out) memcpy(clusters_out, ivf->assign_host.data() + row0, n * 4);
+    return NMN_OK;
+}
+
+// ---- IVFIndex::train + add on the GPU (ivf.rs:222-316; KMeans::fit, delta_vector.rs:737-901) ----------------------
+namespace {
+
+inline uint64_t lcg(uint64_t s) { return s * 6364136223846793005ull + 1ull; }  // wrapping_mul / wrapping_add
+
+// euclidean_distance_sq (delta_vector.rs:896-901) on the host: k * dim per iteration (centroid movement only)
+float host_dist_sq(const float* a, const float* b, uint64_t dim) {
+    float s = -0.0f;
+    for (uint64_t i = 0; i < dim; i++) {
+        const float d = a[i] - b[i];
+        const float p = d * d;
+        s = s + p;
+    }
+    return s;
+}
+
+}  // namespace
+
+extern "C" nmn_status nmn_ivf_build(const nmn_index_desc* desc, const float* rows_host, uint64_t n, uint32_t num_clusters,
+                                    const nmn_kmeans_options* opt, nmn_ivf** out) {
+    if (!desc || !rows_host || !opt || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (n == 0 || num_clusters == 0) return set_error(NMN_ERR_INVALID_ARGUMENT, "nothing to train on");
+    if (desc->capacity_rows < n) return set_error(NMN_ERR_CAPACITY, "capacity_rows < n");
+    const uint32_t k = (uint32_t)std::min<uint64_t>(num_clusters, n);  // `k.min(vectors.len())`
+    const uint64_t dim = desc->dim;
+    nmn_ivf* ivf = nullptr;
+    nmn_status st = ivf_new(desc, nullptr, k, &ivf);
+    if (st != NMN_OK) return st;
+    auto bail = [&](nmn_status code) {
+        nmn_ivf_destroy(ivf);
+        return code;
+    };
+    std::lock_guard<std::mutex> g(ivf->mu);
+    st = nmn_index_upload(ivf->vectors, rows_host, 0, n);  // ids = order of the input (ivf.rs:287-289)
+    if (st != NMN_OK) return bail(st);
+    hipError_t he = hipSetDevice(ivf->device);
+    if (he == hipSuccess) he = hipStreamSynchronize(ivf->vectors->host_stream);
+    if (he != hipSuccess) return bail(set_error_hip(he, "nmn_ivf_build"));
+    const uint32_t ld = ivf->vectors->ld;
+    hipStream_t s = ivf->stream;
+    std::vector<float> cents((size_t)k * dim);  // current centroids, host copy (row-major k x dim)
+
+    // ---- initialisation -----------------------------------------------------------------------------------
+    if (opt->init_method == 0) {  // KMeansInit::Random: Fisher-Yates with the LCG, first k indices (delta_vector.rs:781-800)
+        std::vector<uint64_t> idx(n);
+        for (uint64_t i = 0; i < n; i++) idx[i] = i;
+        uint64_t state = opt->seed;
+        for (uint64_t i = n - 1; i >= 1; i--) {
+            state = lcg(state);
+            std::swap(idx[i], idx[state % (i + 1)]);
+        }
+        for (uint32_t j = 0; j < k; j++) memcpy(cents.data() + (size_t)j * dim, rows_host + idx[j] * dim, dim * sizeof(float));
+    } else {  // KMeansPlusPlus (delta_vector.rs:805-853): distances on the GPU, the f32 running sums on the host
+        uint32_t* sweep = nullptr;
+        float* dist_dev = nullptr;
+        const uint64_t n_pad = (n + 63) & ~63ull;
+        he = hipMalloc(reinterpret_cast<void**>(&sweep), n_pad * 4);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&dist_dev), n * 4);
+        std::vector<float> dist(n, 3.402823466e+38f);  // f32::MAX
+        if (he == hipSuccess) he = hipMemcpyAsync(dist_dev, dist.data(), n * 4, hipMemcpyHostToDevice, s);
+        uint64_t state = lcg(opt->seed);
+        uint64_t pick = state % n;
+        memcpy(cents.data(), rows_host + pick * dim, dim * sizeof(float));
+        for (uint32_t j = 1; j < k && he == hipSuccess; j++) {
+            // dist[i] = min(dist[i], |v_i - last centroid|^2): the last centroid is row `pick`, already a padded query
+            ExactScanParams ep{};
+            ep.corpus = ivf->vectors->corpus;
+            ep.norms = ivf->vectors->norms;
+            ep.qpad = ivf->vectors->corpus + pick * (uint64_t)ld;
+            ep.qinfo = ivf->qinfo;
+            ep.scores = sweep;
+            ep.n_rows = n;
+            ep.nql = 1;
+            ep.ld = ld;
+            ep.dim = (uint32_t)dim;
+            ep.nq = 1;
+            ep.metric = kMetricNegL2Sq;
+            he = launch_exact_scan(ep, s);
+            if (he == hipSuccess) he = launch_kmeans_min_update(dist_dev, sweep, n, s);
+            if (he == hipSuccess) he = hipMemcpyAsync(dist.data(), dist_dev, n * 4, hipMemcpyDeviceToHost, s);
+            if (he == hipSuccess) he = hipStreamSynchronize(s);
+            if (he != hipSuccess) break;
+            float total = -0.0f;  // `distances.iter().sum()`
+            for (uint64_t i = 0; i < n; i++) total = total + dist[i];
+            state = lcg(state);
+            if (total == 0.0f) {
+                pick = state % n;
+            } else {
+                const float frac = (float)state / (float)UINT64_MAX;  // `rng_state as f32 / u64::MAX as f32`
+                const float threshold = frac * total;
+                float cumulative = 0.0f;
+                pick = 0;
+                for (uint64_t i = 0; i < n; i++) {
+                    cumulative = cumulative + dist[i];
+                    if (cumulative >= threshold) {
+                        pick = i;
+                        break;
+                    }
+                }
+            }
+            memcpy(cents.data() + (size_t)j * dim, rows_host + pick * dim, dim * sizeof(float));
+        }
+        if (sweep) (void)hipFree(sweep);
+        if (dist_dev) (void)hipFree(dist_dev);
+        if (he != hipSuccess) return bail(set_error_hip(he, "k-means++ initialisation"));
+    }
+
+    // ---- Lloyd iterations ---------------------------------------------------------------------------------
+    uint32_t* members_dev = nullptr;
+    uint64_t* offsets_dev = nullptr;
+    float* new_dev = nullptr;
+    he = hipMalloc(reinterpret_cast<void**>(&members_dev), n * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&offsets_dev), ((size_t)k + 1) * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&new_dev), (size_t)k * ld * 4);
+    auto free_tmp = [&] {
+        for (void* p : {(void*)members_dev, (void*)offsets_dev, (void*)new_dev})
+            if (p) (void)hipFree(p);
+    };
+    if (he != hipSuccess) {
+        free_tmp();
+        return bail(set_error_hip(he, "k-means buffers"));
+    }
+    std::vector<uint32_t> members(n);
+    std::vector<uint64_t> offsets((size_t)k + 1);
+    std::vector<float> new_pad((size_t)k * ld), new_cents((size_t)k * dim);
+    st = nmn_index_upload(ivf->centroids, cents.data(), 0, k);
+    for (uint64_t it = 0; it < opt->max_iterations && st == NMN_OK; it++) {
+        he = hipStreamSynchronize(ivf->centroids->host_stream);
+        if (he != hipSuccess) break;
+        st = assign_rows(ivf, 0, n);  // nearest_centroid for every vector (delta_vector.rs:755-757)
+        if (st != NMN_OK) break;
+        // update_centroids (867-893): members of each cluster in vector order (stable counting sort)
+        std::fill(offsets.begin(), offsets.end(), 0ull);
+        for (uint64_t i = 0; i < n; i++) offsets[ivf->assign_host[i] + 1]++;
+        for (uint32_t c = 0; c < k; c++) offsets[c + 1] += offsets[c];
+        {
+            std::vector<uint64_t> cur(offsets.begin(), offsets.end() - 1);
+            for (uint64_t i = 0; i < n; i++) members[cur[ivf->assign_host[i]]++] = (uint32_t)i;
+        }
+        he = hipMemcpyAsync(members_dev, members.data(), n * 4, hipMemcpyHostToDevice, s);
+        if (he == hipSuccess) he = hipMemcpyAsync(offsets_dev, offsets.data(), ((size_t)k + 1) * 8, hipMemcpyHostToDevice, s);
+        if (he == hipSuccess) he = launch_kmeans_update(ivf->vectors->corpus, ld, (uint32_t)dim, members_dev, offsets_dev, k, new_dev, s);
+        if (he == hipSuccess) he = hipMemcpyAsync(new_pad.data(), new_dev, (size_t)k * ld * 4, hipMemcpyDeviceToHost, s);
+        if (he == hipSuccess) he = hipStreamSynchronize(s);
+        if (he != hipSuccess) break;
+        float movement = 0.0f;  // `.fold(0.0f32, f32::max)` of the centroid displacements (763-767)
+        for (uint32_t c = 0; c < k; c++) {
+            memcpy(new_cents.data() + (size_t)c * dim, new_pad.data() + (size_t)c * ld, dim * sizeof(float));
+            movement = std::fmax(movement, std::sqrt(host_dist_sq(cents.data() + (size_t)c * dim, new_cents.data() + (size_t)c * dim, dim)));
+        }
+        cents.swap(new_cents);
+        st = nmn_index_upload(ivf->centroids, cents.data(), 0, k);
+        if (movement < opt->convergence_threshold) break;
+    }
+    free_tmp();
+    if (he != hipSuccess) return bail(set_error_hip(he, "k-means iteration"));
+    if (st != NMN_OK) return bail(st);
+    // ---- `for vector in &vectors { index.add(vector) }` under the trained centroids --------------------------
+    he = hipStreamSynchronize(ivf->centroids->host_stream);
+    if (he != hipSuccess) return bail(set_error_hip(he, "nmn_ivf_build"));
+    st = assign_rows(ivf, 0, n);
+    if (st != NMN_OK) return bail(st);
+    ivf->centroids_host = cents;
+    *out = ivf;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_ivf_centroids(nmn_ivf* ivf, float* out, uint64_t cap_floats) {
+    if (!ivf || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ivf->mu);
+    const uint64_t need = (uint64_t)ivf->n_clusters * ivf->dim;
+    if (cap_floats < need) return set_error(NMN_ERR_BUFFER_TOO_SMALL, "centroid buffer too small");
+    if (ivf->centroids_host.size() == need) {
+        memcpy(out, ivf->centroids_host.data(), need * sizeof(float));
+        return NMN_OK;
+    }
+    IVF_TRY(hipSetDevice(ivf->device));
+    IVF_TRY(hipMemcpy2D(out, (size_t)ivf->dim * 4, ivf->centroids->corpus, (size_t)ivf->centroids->ld * 4, (size_t)ivf->dim * 4,
+                        ivf->n_clusters, hipMemcpyDeviceToHost));
     return NMN_OK;
 }
 

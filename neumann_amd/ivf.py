@@ -25,6 +25,31 @@ class GpuIvfFlat:
         _capi.check(self._lib.nmn_ivf_create(C.byref(desc), C.c_void_p(c.ctypes.data), self.n_clusters, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def build(cls, rows, num_clusters, nprobe=None, max_iterations=100, convergence_threshold=1e-4, seed=42,
+              init_method="kmeans++", capacity_rows=None, device=-1):
+        """IVFIndex::train(rows) + add(every row) on the GPU (`nmn_ivf_build`): k-means exactly as the reference runs it."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        r = np.ascontiguousarray(rows, dtype=np.float32)
+        n, self.dim = int(r.shape[0]), int(r.shape[1])
+        desc = _capi.IndexDesc(dim=self.dim, flags=0, capacity_rows=int(capacity_rows or n), row_base=0, device=int(device),
+                               cand_cap=0)
+        opt = _capi.KMeansOptions(max_iterations=int(max_iterations), convergence_threshold=float(convergence_threshold),
+                                  seed=int(seed), init_method=0 if init_method == "random" else 1)
+        h = C.c_void_p()
+        _capi.check(self._lib.nmn_ivf_build(C.byref(desc), C.c_void_p(r.ctypes.data), n, int(num_clusters), C.byref(opt),
+                                            C.byref(h)))
+        self._h = h
+        self.n_clusters = int(self._lib.nmn_ivf_clusters(h))
+        self.nprobe = int(np.ceil(np.sqrt(np.float32(num_clusters)))) if nprobe is None else int(nprobe)
+        return self
+
+    def centroids(self):
+        out = np.empty((self.n_clusters, self.dim), dtype=np.float32)
+        _capi.check(self._lib.nmn_ivf_centroids(self._h, C.c_void_p(out.ctypes.data), out.size))
+        return out
+
     def close(self):
         if self._h:
             self._lib.nmn_ivf_destroy(self._h)

@@ -174,3 +174,40 @@ def test_engine_ivf_edge_cases(E):  # lib.rs:2643-2647, 2717-2722; ivf.rs:326-32
     with pytest.raises(E.VectorError) as e:
         engine.build_ivf_index_default()
     assert e.value.kind == "DimensionMismatch"
+
+
+@pytest.mark.parametrize("init", ["random", "kmeans++"])
+def test_gpu_kmeans_training_matches_oracle(init):
+    """nmn_ivf_build: k-means on the GPU (exact centroid sweeps + sequential per-(cluster, dimension) sums) gives the
+    oracle's centroids bit for bit, hence the same lists and the same search results."""
+    from neumann_amd.ivf import GpuIvfFlat
+    rng = np.random.default_rng(3)
+    n, d, c = 4000, 40, 24
+    V = (rng.standard_normal((n, d)) + 2.5 * rng.integers(0, 4, (n, 1))).astype(F)
+    V[100] = V[7]
+    cfg = dict(max_iterations=12, convergence_threshold=1e-4, seed=2024, init_method=init)
+    orc = io.IVFFlat(c, nprobe=5, kmeans=io.KMeansConfig(**cfg))
+    orc.train(V)
+    for v in V:
+        orc.add(v)
+    with GpuIvfFlat.build(V, c, nprobe=5, **cfg) as gpu:
+        assert np.array_equal(gpu.centroids(), orc.centroids)
+        assert len(gpu) == n and gpu.cluster_sizes().tolist() == orc.cluster_sizes()
+        for q in rng.standard_normal((5, d)).astype(F) + F(2.5):
+            check_same(orc, gpu, q, 20)
+            check_same(orc, gpu, q, 20, nprobe=c)
+    # vectors added after training go to the nearest trained centroid (capacity above was exactly n: head room here)
+    extra = rng.standard_normal((50, d)).astype(F)
+    with GpuIvfFlat.build(V, c, nprobe=5, capacity_rows=n + 64, **cfg) as gpu:
+        got = gpu.add(extra)
+        for v in extra:
+            orc.add(v)
+        assert got.tolist() == orc.assign[n:]
+        check_same(orc, gpu, extra[3], 10)
+    # more clusters than vectors, a single vector, zero iterations
+    with GpuIvfFlat.build(V[:5], 100, **cfg) as gpu:
+        assert gpu.n_clusters == 5 and gpu.cluster_sizes().tolist() == [1, 1, 1, 1, 1]
+    o0 = io.IVFFlat(3, kmeans=io.KMeansConfig(0, 1e-4, 9, init))
+    o0.train(V[:50])
+    with GpuIvfFlat.build(V[:50], 3, max_iterations=0, seed=9, init_method=init) as gpu:
+        assert np.array_equal(gpu.centroids(), o0.centroids)
