@@ -288,8 +288,8 @@ nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t
 /* ---- IVF-Flat probe ------------------------------------------------------ */
 
 /* `tensor_store::ivf::IVFIndex` with `IVFStorage::Flat` (tensor_store/src/ivf.rs:160-406), searched on the
- * GPU.  Training (k-means, ivf.rs:222-233) stays with the caller: the index is created from trained
- * centroids.  Vectors live in id (insertion) order; ids are the row numbers `add` assigns (ivf.rs:287-289). */
+ * GPU.  nmn_ivf_create takes centroids trained elsewhere; nmn_ivf_build trains them (ivf.rs:222-233) on the GPU.
+ * Vectors live in id (insertion) order; ids are the row numbers `add` assigns (ivf.rs:287-289). */
 typedef struct nmn_ivf nmn_ivf;
 /* desc: dim, capacity_rows (vectors that can be added), device; centroids: HOST, n_clusters x dim. */
 nmn_status nmn_ivf_create(const nmn_index_desc* desc, const float* centroids, uint32_t n_clusters, nmn_ivf** out);

@@ -2,8 +2,8 @@
 
 Mirrors `tensor_store::ivf::IVFIndex` with `IVFStorage::Flat` (tensor_store/src/ivf.rs:160-406) for
 the parts on the SIMILAR path: `add` (nearest-centroid assignment) and `search` / `search_with_nprobe`.
-Training is the caller's (the engine ports the reference's k-means, neumann_amd/csrc/nmn_engine.cpp);
-the index is created from trained centroids."""
+`GpuIvfFlat.build` trains on the GPU exactly as the reference's k-means does (`nmn_ivf_build`); the plain constructor
+takes centroids trained elsewhere."""
 import ctypes as C
 
 import numpy as np

@@ -1,7 +1,7 @@
 """CPU restatement of the reference's IVF-Flat index and its k-means — TEST INFRASTRUCTURE ONLY.
 
 Only tests/ may import this module (rule in oracle/nmn_oracle.c's header); the product runs the probe
-on the GPU (neumann_amd/csrc/nmn_ivf.hip) and the k-means in neumann_amd/csrc/nmn_engine.cpp.
+and the k-means on the GPU (neumann_amd/csrc/nmn_ivf.hip: nmn_ivf_search / nmn_ivf_add / nmn_ivf_build).
 
 Follows (paths relative to the reference root):
   tensor_store/src/ivf.rs            IVFIndex::train 222-274, add 276-316, search_with_nprobe 325-406,
