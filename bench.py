@@ -329,12 +329,15 @@ def main():
     idx.set_timing(True)
     scan_ms, total_ms = [], []
     n_meas = min(max(args.steps, 5), 30)
+    elem_bytes = 4  # bytes per corpus element the dominant kernel reads: 4 (f32 corpus) or 2 (its bf16 mirror)
     for i in range(n_meas):
         step(i)
         st = idx.last_stats(streams[i % n_streams])
         if st.scan_ms > 0:
             scan_ms.append(st.scan_ms)
             total_ms.append(st.total_ms)
+        if st.rows_scanned:
+            elem_bytes = int(st.bytes_scanned // (st.rows_scanned * args.dim))
     idx.set_timing(False)
     fence()
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
@@ -347,7 +350,7 @@ def main():
     passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
-    alg_bytes = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
+    alg_bytes = (kept_rows * args.dim * elem_bytes + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
 
     # ---- read ceiling of this device: the scan's access pattern with the arithmetic removed (rank 0 reports) ----
@@ -392,6 +395,7 @@ def main():
                          "kernel": ("nmn::exact_scan_kernel" if args.k > 4096 else
                                     "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel"), "avg_kernel_ms": scan_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_corpus_element": elem_bytes,
                          "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None,
                          # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
                          "measured_read_ceiling": read_ceiling,

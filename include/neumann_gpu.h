@@ -79,7 +79,7 @@ typedef struct nmn_index_desc {
 /* Timing / accounting of the most recent search on a workspace (nullable everywhere). */
 typedef struct nmn_search_stats {
     uint64_t rows_scanned;        /* rows whose vectors were read (mask-excluded rows are not) */
-    uint64_t bytes_scanned;       /* algorithmic bytes of the scan: rows_scanned * dim * 4 */
+    uint64_t bytes_scanned;       /* algorithmic bytes of the scan: rows_scanned * dim * (4: f32 corpus, 2: bf16 mirror) */
     uint32_t candidates_rescored; /* max over queries of rows re-scored in reference order */
     uint32_t fallback_queries;    /* queries that took the exact-fallback path */
     float scan_ms;                /* hipEvent span of the scan kernel(s); -1 if not timed */

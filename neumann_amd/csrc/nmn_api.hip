@@ -283,6 +283,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     idx->ws.clear();
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->split) (void)hipFree(idx->split);
+    if (idx->half) (void)hipFree(idx->half);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
     for (int i = 1; i < nmn_index::kHostSlots; i++)
@@ -332,7 +333,8 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
     idx->rows = std::max(idx->rows, row0 + n);
-    idx->split_rows = std::min(idx->split_rows, row0);  // the mirror is re-derived from row0 on, lazily
+    idx->split_rows = std::min(idx->split_rows, row0);  // the mirrors are re-derived from row0 on, lazily
+    idx->half_rows = std::min(idx->half_rows, row0);
     return NMN_OK;
 }
 
@@ -367,6 +369,7 @@ static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* quer
     w->timed = idx->timing;
     w->last_nq = nq;
     w->last_rows_scanned = n_rows;
+    w->last_elem_bytes = 4;
     w->last_masked = mask_dev != nullptr;
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
@@ -444,11 +447,35 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 idx->split_rows = n_rows;
             }
         }
+        // 1-4 queries, cosine / dot: sweep the bf16 mirror (half the bytes of the f32 corpus) — same lifecycle as `split`
+        bool use_half = !use_mfma && n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
+                        getenv("NMN_NO_HALF") == nullptr;
+        if (use_half) {
+            if (!idx->half) {
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half), (size_t)idx->cap_pad * idx->ld * 2);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    idx->half = nullptr;
+                    idx->half_failed = true;  // not enough HBM for the mirror: the f32 sweep serves
+                    use_half = false;
+                } else {
+                    idx->half_rows = 0;
+                    HIP_TRY(hipMemsetAsync(idx->half, 0, (size_t)idx->cap_pad * idx->ld * 2, stream));
+                }
+            }
+            if (use_half && idx->half_rows < n_rows) {
+                HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, idx->half_rows, n_rows - idx->half_rows, stream));
+                HIP_TRY(hipStreamSynchronize(stream));  // as for `split`: later searches on other streams rely on it
+                idx->half_rows = n_rows;
+            }
+        }
+        w->last_elem_bytes = use_half ? 2u : 4u;
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
-                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : 0, stream));
+                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : (use_half ? 2 : 0), stream));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
+            sp.corpus_half = use_half ? idx->half : nullptr;
             sp.corpus_split = idx->split;
             sp.norms = idx->norms;
             sp.qpad = w->qpad;
@@ -617,7 +644,7 @@ static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* 
         stats->fallback_queries += q.overflow ? 1 : 0;
     }
     stats->rows_scanned = w->last_rows_scanned;  // upper bound when masked (excluded rows are skipped)
-    stats->bytes_scanned = w->last_rows_scanned * (uint64_t)idx->dim * 4ull;
+    stats->bytes_scanned = w->last_rows_scanned * (uint64_t)idx->dim * (uint64_t)w->last_elem_bytes;
     if (w->timed) {
         float a = 0.f, b = 0.f;
         if (w->last_rows_scanned && hipEventElapsedTime(&a, w->ev[1], w->ev[2]) == hipSuccess) stats->scan_ms = a;
@@ -918,6 +945,7 @@ extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, ui
     HIP_TRY(hipStreamSynchronize(s));
     idx->rows = std::max(idx->rows, row0 + n);
     idx->split_rows = std::min(idx->split_rows, row0);
+    idx->half_rows = std::min(idx->half_rows, row0);
     return NMN_OK;
 }
 
@@ -932,6 +960,7 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
                            hipMemcpyHostToDevice, s));
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
     if (idx->split && row < idx->split_rows) HIP_TRY(launch_split_rows(idx->corpus, idx->split, idx->ld, row, 1, s));
+    if (idx->half && row < idx->half_rows) HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row, 1, s));
     HIP_TRY(hipStreamSynchronize(s));
     return NMN_OK;
 }

@@ -51,6 +51,7 @@ struct Workspace {
     bool timed = false;
     uint32_t last_nq = 0;
     uint64_t last_rows_scanned = 0;
+    uint32_t last_elem_bytes = 4;  // bytes per corpus element the last sweep read (2 on the bf16 mirror)
     bool last_masked = false;
 };
 
@@ -63,6 +64,9 @@ struct nmn_index {
     float* split = nullptr;      // split-bf16 mirror for the batched (MFMA) sweep; allocated on first use
     uint64_t split_rows = 0;     // rows [0, split_rows) of `split` are current
     bool split_failed = false;   // allocation failed once: stay on the VALU sweeps
+    float* half = nullptr;       // bf16 mirror the cosine / dot sweeps of 1-4 queries read (half the bytes); lazy
+    uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current
+    bool half_failed = false;    // allocation failed once: stay on the f32 sweep
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;
     hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot

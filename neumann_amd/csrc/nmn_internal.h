@@ -80,6 +80,7 @@ __host__ __device__ inline uint64_t score_at(uint64_t row, uint32_t q, uint32_t 
 // ---- kernel launchers (each defined in the .hip file named above) ---------------------------
 struct ScanParams {
     const float* corpus;     // [rows][ld]
+    const float* corpus_half;   // nullable: bf16 mirror (row stride ld/2 floats) the VALU sweep reads instead of `corpus`
     const float* corpus_split;  // split-bf16 mirror of corpus (MFMA sweep only), same shape and stride
     const float* norms;      // [rows]
     const float* qpad;       // [nq][ld] zero padded
@@ -102,6 +103,8 @@ struct ScanParams {
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
+hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s);
+bool scan_half_supported(uint32_t ld, int metric);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
@@ -160,8 +163,8 @@ hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_
 hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,
                         uint32_t* max_norm_bits, hipStream_t s);
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
-                        const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
-                        hipStream_t s);
+                        const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
+                        hipStream_t s);  // approx_pass: 0 = f32 sweep, 1 = split-bf16 MFMA sweep, 2 = bf16-mirror sweep
 struct RescoreParams {
     const float* corpus;
     const float* norms;

@@ -55,9 +55,12 @@ __device__ __forceinline__ v4f load4(const v4f* p) {
 
 // dot (or squared-difference sum) of ONE corpus row against NQ staged queries, this lane's share:
 // lane j of a 16-lane DPP row takes float4 columns j, j+16, ...; the caller reduces across the row.
-template <int METRIC, int NQ, int CH, bool FULL, bool NT>
+// HALF: the row comes from the bf16 mirror (nmn_api.hip: `half`) — a 16-byte chunk holds 8 elements, each dword
+// element 2i in its low and 2i+1 in its high 16 bits; `ld4` then counts the row's 16-byte chunks (ld / 8) and `qld4`
+// the float4s of one staged query (ld / 4).
+template <int METRIC, int NQ, int CH, bool FULL, bool NT, bool HALF>
 __device__ __forceinline__ void row_partial(const v4f* __restrict__ rowp, bool active, uint32_t j, uint32_t ld4,
-                                            const v4f* __restrict__ qs4, float (&acc)[NQ]) {
+                                            uint32_t qld4, const v4f* __restrict__ qs4, float (&acc)[NQ]) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = 0.f;
     for (uint32_t c0 = 0; c0 < ld4; c0 += 16u * CH) {
@@ -73,6 +76,27 @@ __device__ __forceinline__ void row_partial(const v4f* __restrict__ rowp, bool a
         for (int c = 0; c < CH; c++) {
             uint32_t col = c0 + (uint32_t)c * 16u + j;
             if constexpr (!FULL) col = min(col, ld4 - 1u);  // x is zero there; keep the LDS read in range
+            if constexpr (HALF) {
+                const uint32_t w0 = __float_as_uint(x[c].x), w1 = __float_as_uint(x[c].y), w2 = __float_as_uint(x[c].z),
+                               w3 = __float_as_uint(x[c].w);
+                const v4f lo = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 << 16),
+                                __uint_as_float(w1 & 0xFFFF0000u)};
+                const v4f hi = {__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xFFFF0000u), __uint_as_float(w3 << 16),
+                                __uint_as_float(w3 & 0xFFFF0000u)};
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const v4f qa = qs4[(uint32_t)q * qld4 + 2u * col], qb = qs4[(uint32_t)q * qld4 + 2u * col + 1u];
+                    acc[q] = __builtin_fmaf(lo.x, qa.x, acc[q]);
+                    acc[q] = __builtin_fmaf(lo.y, qa.y, acc[q]);
+                    acc[q] = __builtin_fmaf(lo.z, qa.z, acc[q]);
+                    acc[q] = __builtin_fmaf(lo.w, qa.w, acc[q]);
+                    acc[q] = __builtin_fmaf(hi.x, qb.x, acc[q]);
+                    acc[q] = __builtin_fmaf(hi.y, qb.y, acc[q]);
+                    acc[q] = __builtin_fmaf(hi.z, qb.z, acc[q]);
+                    acc[q] = __builtin_fmaf(hi.w, qb.w, acc[q]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const v4f qv = qs4[(uint32_t)q * ld4 + col];
@@ -101,10 +125,14 @@ constexpr uint32_t kCompactMaxRows = 40;
 // METRIC: nmn_metric.  MASKED: predicate bitmap present.  NQ: queries per pass over the corpus.
 // CH: float4 loads per lane per chunk (CH KiB in flight per wave).  FULL: ld4 % (16*CH) == 0, no
 // column predicate.  NT: non-temporal corpus loads.
-template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT>
+template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT, bool HALF = false>
 __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [NQ][ld]
     const uint32_t ld = p.ld, ld4 = ld >> 2;
+    // the streamed matrix: the f32 corpus, or its bf16 mirror (half the bytes; the rounding is covered by the margin)
+    const float* const mat = HALF ? p.corpus_half : p.corpus;
+    const uint32_t mat_ld = HALF ? ld >> 1 : ld;      // row stride in floats
+    const uint32_t chunks = HALF ? ld >> 3 : ld4;     // 16-byte chunks per row
     const uint32_t q0 = blockIdx.y * NQ;
     {
         v4f* qs4 = reinterpret_cast<v4f*>(qs);
@@ -161,9 +189,9 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
                         if (grp == g2) pos = b ? (uint32_t)__builtin_ctzll(b) : 0u;
                     }
                     const bool active = s0 + grp < cnt;
-                    const v4f* rowp = reinterpret_cast<const v4f*>(p.corpus + (r0 + pos) * (uint64_t)ld);
+                    const v4f* rowp = reinterpret_cast<const v4f*>(mat + (r0 + pos) * (uint64_t)mat_ld);
                     float acc[NQ];
-                    row_partial<METRIC, NQ, CH, FULL, NT>(rowp, active, j, ld4, qs4, acc);
+                    row_partial<METRIC, NQ, CH, FULL, NT, HALF>(rowp, active, j, chunks, ld4, qs4, acc);
 #pragma unroll
                     for (int q = 0; q < NQ; q++) {
                         const float t = row16_sum(acc[q]);
@@ -186,9 +214,9 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
                 }
                 const uint32_t rbit = s * 4 + grp;
                 const bool active = MASKED ? ((mword >> rbit) & 1ull) != 0 : true;
-                const v4f* rowp = reinterpret_cast<const v4f*>(p.corpus + (r0 + rbit) * (uint64_t)ld);
+                const v4f* rowp = reinterpret_cast<const v4f*>(mat + (r0 + rbit) * (uint64_t)mat_ld);
                 float acc[NQ];
-                row_partial<METRIC, NQ, CH, FULL, NT>(rowp, active, j, ld4, qs4, acc);
+                row_partial<METRIC, NQ, CH, FULL, NT, HALF>(rowp, active, j, chunks, ld4, qs4, acc);
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     const float t = row16_sum(acc[q]);
@@ -237,13 +265,13 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
     }
 }
 
-template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT>
+template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT, bool HALF = false>
 static hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
     // queries, plus (masked kernels) one [NQ][64] staging array per wave for the compacted tiles
     const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) : 0);
-    auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT>;
+    auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT, HALF>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -265,8 +293,33 @@ static hipError_t launch_layout(const ScanParams& p, hipStream_t s, bool nt) {
     return launch_one<METRIC, MASKED, NQ, 4, false, false>(p, s);
 }
 
+// bf16 mirror: ld / 8 chunks per row (768 -> 96 = 16 * 6, 1536 -> 192 = 16 * 12)
+template <int METRIC, bool MASKED, int NQ>
+static hipError_t launch_layout_half(const ScanParams& p, hipStream_t s, bool nt) {
+    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+        return hipErrorInvalidValue;  // the bf16 pass serves cosine / dot only (see scan_half_supported)
+    } else {
+        const uint32_t lc = p.ld >> 3;
+        if (lc % (16 * 12) == 0) {
+            if (nt && !MASKED) return launch_one<METRIC, MASKED, NQ, 12, true, true, true>(p, s);
+            return launch_one<METRIC, MASKED, NQ, 12, true, false, true>(p, s);
+        }
+        if (lc % (16 * 6) == 0) {
+            if (nt && !MASKED) return launch_one<METRIC, MASKED, NQ, 6, true, true, true>(p, s);
+            return launch_one<METRIC, MASKED, NQ, 6, true, false, true>(p, s);
+        }
+        if (lc % (16 * 2) == 0) return launch_one<METRIC, MASKED, NQ, 2, true, false, true>(p, s);
+        return launch_one<METRIC, MASKED, NQ, 4, false, false, true>(p, s);
+    }
+}
+
 template <int METRIC, bool MASKED>
 static hipError_t launch_nq(const ScanParams& p, hipStream_t s, bool nt) {
+    if (p.corpus_half) {
+        if (p.nq >= 3) return launch_layout_half<METRIC, MASKED, 4>(p, s, nt);
+        if (p.nq == 2) return launch_layout_half<METRIC, MASKED, 2>(p, s, nt);
+        return launch_layout_half<METRIC, MASKED, 1>(p, s, nt);
+    }
     if (p.nq >= 3) return launch_layout<METRIC, MASKED, 4>(p, s, nt);
     if (p.nq == 2) return launch_layout<METRIC, MASKED, 2>(p, s, nt);
     return launch_layout<METRIC, MASKED, 1>(p, s, nt);
@@ -284,6 +337,44 @@ static bool scan_nt_enabled() {
         v = (e && e[0] == '0') ? 0 : 1;
     }
     return v != 0;
+}
+
+// ---- the bf16 mirror ----------------------------------------------------------------------------------
+// half[row][c] = bf16(corpus[row][c]), round to nearest even, same row order, half the row stride.  The approximate
+// sweep of the cosine / dot metrics reads THIS matrix: the result stays exact because the rounding (relative 2^-8
+// per element, hence at most 2^-8 |q||v| on a dot product) is added to the candidate margin and every candidate is
+// re-scored from the f32 corpus.
+__global__ void __launch_bounds__(256) half_rows_kernel(const float* __restrict__ corpus, float* __restrict__ half,
+                                                        uint32_t ld, uint64_t row0, uint64_t n) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const uint32_t per_row = ld >> 3;  // 8-element groups per row
+    const uint64_t total = n * per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = row0 + i / per_row;
+        const uint32_t g = (uint32_t)(i % per_row);
+        const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
+        const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
+        v4f out;
+        const f2 p0 = {a.x, a.y}, p1 = {a.z, a.w}, p2 = {b.x, b.y}, p3 = {b.z, b.w};
+        out.x = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf2)));
+        out.y = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf2)));
+        out.z = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p2, bf2)));
+        out.w = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p3, bf2)));
+        *reinterpret_cast<v4f*>(half + r * (ld >> 1) + g * 4u) = out;
+    }
+}
+
+hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(half_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, half, ld, row0, n);
+    return hipGetLastError();
+}
+
+// cosine-type and dot metrics, rows made of whole 16-byte bf16 chunks
+bool scan_half_supported(uint32_t ld, int metric) {
+    return (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_SPARSE_COSINE_F64) &&
+           ld % 8u == 0;
 }
 
 // ---- read-ceiling probe -----------------------------------------------------------------------------
