@@ -137,7 +137,7 @@ def other_configs():
     return out
 
 
-def pmc_traffic(rows_per_gpu, args):
+def pmc_traffic(rows_per_gpu, args, elem_bytes=4):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if this
     exact workload was profiled; bench.py cannot collect PMC counters itself (they need a rocprofv3 wrapper)."""
     try:
@@ -145,8 +145,8 @@ def pmc_traffic(rows_per_gpu, args):
     except (OSError, ValueError, KeyError):
         return None, None
     for e in ent:
-        if (e["rows_per_gpu"], e["dim"], e["metric"], e["nq"], e["mask"]) == (rows_per_gpu, args.dim, args.metric,
-                                                                              args.nq, args.mask):
+        if (e["rows_per_gpu"], e["dim"], e["metric"], e["nq"], e["mask"], e.get("bytes_per_corpus_element", 4)) == (
+                rows_per_gpu, args.dim, args.metric, args.nq, args.mask, elem_bytes):
             return e["hbm_bytes_per_launch"], e["source"]
     return None, None
 
@@ -371,7 +371,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, metric, total_rows, local_rank)
 
-    traffic, traffic_src = pmc_traffic(local_rows, args)
+    traffic, traffic_src = pmc_traffic(local_rows, args, elem_bytes)
     others = None
     default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
                         args.metric == "cosine" and args.mask >= 1.0)
