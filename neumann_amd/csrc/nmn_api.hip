@@ -284,6 +284,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->split) (void)hipFree(idx->split);
     if (idx->half) (void)hipFree(idx->half);
+    if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
     for (int i = 1; i < nmn_index::kHostSlots; i++)
@@ -460,18 +461,27 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                     use_half = false;
                 } else {
                     idx->half_rows = 0;
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_err_bits), 8));
+                    HIP_TRY(hipMemsetAsync(idx->half_err_bits, 0, 8, stream));
                     HIP_TRY(hipMemsetAsync(idx->half, 0, (size_t)idx->cap_pad * idx->ld * 2, stream));
                 }
             }
             if (use_half && idx->half_rows < n_rows) {
-                HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, idx->half_rows, n_rows - idx->half_rows, stream));
-                HIP_TRY(hipStreamSynchronize(stream));  // as for `split`: later searches on other streams rely on it
+                const uint64_t cnt = n_rows - idx->half_rows;
+                float* scratch = nullptr;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), cnt * sizeof(float)));
+                hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, idx->half_rows, cnt, idx->norms, scratch,
+                                                 idx->half_err_bits, stream);
+                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // as for `split`: other streams rely on the mirror
+                (void)hipFree(scratch);
+                if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
                 idx->half_rows = n_rows;
             }
         }
         w->last_elem_bytes = use_half ? 2u : 4u;
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
-                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : (use_half ? 2 : 0), stream));
+                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : (use_half ? 2 : 0), stream,
+                             use_half ? idx->half_err_bits : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
@@ -960,7 +970,14 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
                            hipMemcpyHostToDevice, s));
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
     if (idx->split && row < idx->split_rows) HIP_TRY(launch_split_rows(idx->corpus, idx->split, idx->ld, row, 1, s));
-    if (idx->half && row < idx->half_rows) HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row, 1, s));
+    if (idx->half && row < idx->half_rows) {
+        float* scratch = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(float)));
+        hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, row, 1, idx->norms, scratch, idx->half_err_bits, s);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+        (void)hipFree(scratch);
+        if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
+    }
     HIP_TRY(hipStreamSynchronize(s));
     return NMN_OK;
 }

@@ -191,7 +191,8 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
 __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ queries, uint32_t dim, uint32_t ld,
                                                    int metric, const uint32_t* __restrict__ max_norm_bits,
                                                    float* __restrict__ qpad, QInfo* __restrict__ qinfo,
-                                                   QState* __restrict__ qstate, int mfma_pass) {
+                                                   QState* __restrict__ qstate, int mfma_pass,
+                                                   const uint32_t* __restrict__ half_err_bits) {
     const uint32_t q = blockIdx.x;
     const float* src = queries + (size_t)q * dim;
     float* dst = qpad + (size_t)q * ld;
@@ -204,10 +205,18 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         QInfo qi;
         qi.qmag = qmag;
         qi.pad = 0.f;
-        // what the approximate sweep adds on top of f32 summation error, relative to |q||v|: split-bf16 MFMA sweep
-        // 2^-15 per product (2^-14 budgeted); bf16 mirror: every corpus element rounded with relative error <= 2^-8,
-        // hence |dot error| <= 2^-8 sum|q_i v_i| <= 2^-8 |q||v| (budgeted with a little slack)
-        const float split = mfma_pass == 1 ? 6.1035156e-05f /* 2^-14 */ : (mfma_pass == 2 ? 3.92e-03f /* > 2^-8 */ : 0.0f);
+        // What the approximate sweep adds on top of f32 summation error, relative to |q||v|.  The margin is applied ONCE
+        // below the k-th approximate score and must cover the error twice (k rows with approx >= T have exact >= T - e, so
+        // the exact k-th is >= T - e, and a row with exact >= T - e has approx >= T - 2e).
+        //   split-bf16 MFMA sweep: e = 2^-15 per product -> 2^-14;
+        //   bf16 mirror: row r is stored as v + e_r, so |dot error| = |q . e_r| <= |q||e_r| <= |q||v_r| * rho with
+        //   rho = max_r |e_r| / |v_r| MEASURED when the mirror was written (<= 2^-8, typically 0.4 * 2^-8) -> 2 rho.
+        float split = 0.0f, half_abs = 0.0f;
+        if (mfma_pass == 1) split = 6.1035156e-05f;  // 2^-14
+        if (mfma_pass == 2) {
+            split = half_err_bits ? 2.0f * u2f(half_err_bits[1]) : 7.9e-03f;                            // worst case 2 * 2^-8
+            half_abs = half_err_bits ? 2.0f * u2f(half_err_bits[0]) : 7.9e-03f * u2f(*max_norm_bits);  // 2 max|e_r|
+        }
         if (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_SPARSE_COSINE_F64) {
             qi.margin_abs = 3.0f * (dd + 10.0f) * u + split;
             qi.margin_rel = 0.0f;
@@ -218,6 +227,13 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         } else {
             qi.margin_abs = 0.0f;
             qi.margin_rel = 4.0f * (dd + 8.0f) * u;
+            if (mfma_pass == 2) {
+                // bf16 mirror under a Euclidean metric: v~ = v + e_r, so by the triangle inequality
+                // |d(q, v~) - d(q, v)| <= |e_r| <= max_r |e_r| =: D, an ABSOLUTE error on the distance (twice, as above)
+                const float two_d = half_abs;
+                if (metric == kMetricNegL2) qi.margin_abs = two_d;  // score = -d
+                else qi.pad = two_d;  // score = 1/(1+d): threshold T -> T / (1 + 2D T), applied by margin_key
+            }
         }
         qinfo[q] = qi;
         QState st;
@@ -231,9 +247,9 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
 
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
-                        hipStream_t s) {
+                        hipStream_t s, const uint32_t* half_err_bits) {
     hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), 0, s, queries, dim, ld, metric, max_norm_bits, qpad,
-                       qinfo, qstate, mfma_pass);
+                       qinfo, qstate, mfma_pass, half_err_bits);
     return hipGetLastError();
 }
 

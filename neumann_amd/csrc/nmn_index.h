@@ -67,6 +67,7 @@ struct nmn_index {
     float* half = nullptr;       // bf16 mirror the cosine / dot sweeps of 1-4 queries read (half the bytes); lazy
     uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current
     bool half_failed = false;    // allocation failed once: stay on the f32 sweep
+    uint32_t* half_err_bits = nullptr;  // device [2]: max_r |e_r| and max_r |e_r|/|v_r| of the mirror's rounding (f32 bits)
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;
     hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot

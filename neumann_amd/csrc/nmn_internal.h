@@ -33,7 +33,7 @@ struct QInfo {
     float qmag;        // simd::magnitude(query), reference order
     float margin_abs;  // candidates: approx >= tau - margin_abs - |tau|*margin_rel
     float margin_rel;
-    float pad;
+    float pad;         // bf16-mirror sweep under the Euclidean score: two-sided absolute error of the distance (else 0)
 };
 
 // Per-query selection state shared by select / fallback / rescore / final.
@@ -103,7 +103,10 @@ struct ScanParams {
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
-hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s);
+// converts rows [row0, row0+n) into the bf16 mirror and folds their rounding-error norms into err_bits[0..1]
+// (row_err2_scratch: n floats of device scratch)
+hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+                            float* row_err2_scratch, uint32_t* err_bits, hipStream_t s);
 bool scan_half_supported(uint32_t ld, int metric);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
@@ -164,7 +167,9 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
                         uint32_t* max_norm_bits, hipStream_t s);
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
-                        hipStream_t s);  // approx_pass: 0 = f32 sweep, 1 = split-bf16 MFMA sweep, 2 = bf16-mirror sweep
+                        hipStream_t s, const uint32_t* half_err_bits = nullptr);
+// approx_pass: 0 = f32 sweep, 1 = split-bf16 MFMA sweep, 2 = bf16-mirror sweep (half_err_bits = the mirror's measured
+// rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|)
 struct RescoreParams {
     const float* corpus;
     const float* norms;

@@ -13,6 +13,8 @@
 // adds.  Lane L keeps the dot of tile row (L&15)*4 + (L>>4), so after 16 steps the wave finishes
 // 64 scores at once: one permuted-but-contiguous 256-B norm load, one 256-B score store, one wave
 // max.  Nothing is read twice; algorithmic bytes = rows * dim * 4.
+#include <algorithm>
+
 #include "nmn_internal.h"
 
 namespace nmn {
@@ -86,14 +88,26 @@ __device__ __forceinline__ void row_partial(const v4f* __restrict__ rowp, bool a
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     const v4f qa = qs4[(uint32_t)q * qld4 + 2u * col], qb = qs4[(uint32_t)q * qld4 + 2u * col + 1u];
-                    acc[q] = __builtin_fmaf(lo.x, qa.x, acc[q]);
-                    acc[q] = __builtin_fmaf(lo.y, qa.y, acc[q]);
-                    acc[q] = __builtin_fmaf(lo.z, qa.z, acc[q]);
-                    acc[q] = __builtin_fmaf(lo.w, qa.w, acc[q]);
-                    acc[q] = __builtin_fmaf(hi.x, qb.x, acc[q]);
-                    acc[q] = __builtin_fmaf(hi.y, qb.y, acc[q]);
-                    acc[q] = __builtin_fmaf(hi.z, qb.z, acc[q]);
-                    acc[q] = __builtin_fmaf(hi.w, qb.w, acc[q]);
+                    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                        const v4f da = lo - qa, db = hi - qb;
+                        acc[q] = __builtin_fmaf(da.x, da.x, acc[q]);
+                        acc[q] = __builtin_fmaf(da.y, da.y, acc[q]);
+                        acc[q] = __builtin_fmaf(da.z, da.z, acc[q]);
+                        acc[q] = __builtin_fmaf(da.w, da.w, acc[q]);
+                        acc[q] = __builtin_fmaf(db.x, db.x, acc[q]);
+                        acc[q] = __builtin_fmaf(db.y, db.y, acc[q]);
+                        acc[q] = __builtin_fmaf(db.z, db.z, acc[q]);
+                        acc[q] = __builtin_fmaf(db.w, db.w, acc[q]);
+                    } else {
+                        acc[q] = __builtin_fmaf(lo.x, qa.x, acc[q]);
+                        acc[q] = __builtin_fmaf(lo.y, qa.y, acc[q]);
+                        acc[q] = __builtin_fmaf(lo.z, qa.z, acc[q]);
+                        acc[q] = __builtin_fmaf(lo.w, qa.w, acc[q]);
+                        acc[q] = __builtin_fmaf(hi.x, qb.x, acc[q]);
+                        acc[q] = __builtin_fmaf(hi.y, qb.y, acc[q]);
+                        acc[q] = __builtin_fmaf(hi.z, qb.z, acc[q]);
+                        acc[q] = __builtin_fmaf(hi.w, qb.w, acc[q]);
+                    }
                 }
                 continue;
             }
@@ -296,9 +310,7 @@ static hipError_t launch_layout(const ScanParams& p, hipStream_t s, bool nt) {
 // bf16 mirror: ld / 8 chunks per row (768 -> 96 = 16 * 6, 1536 -> 192 = 16 * 12)
 template <int METRIC, bool MASKED, int NQ>
 static hipError_t launch_layout_half(const ScanParams& p, hipStream_t s, bool nt) {
-    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
-        return hipErrorInvalidValue;  // the bf16 pass serves cosine / dot only (see scan_half_supported)
-    } else {
+    {
         const uint32_t lc = p.ld >> 3;
         if (lc % (16 * 12) == 0) {
             if (nt && !MASKED) return launch_one<METRIC, MASKED, NQ, 12, true, true, true>(p, s);
@@ -341,11 +353,14 @@ static bool scan_nt_enabled() {
 
 // ---- the bf16 mirror ----------------------------------------------------------------------------------
 // half[row][c] = bf16(corpus[row][c]), round to nearest even, same row order, half the row stride.  The approximate
-// sweep of the cosine / dot metrics reads THIS matrix: the result stays exact because the rounding (relative 2^-8
-// per element, hence at most 2^-8 |q||v| on a dot product) is added to the candidate margin and every candidate is
-// re-scored from the f32 corpus.
+// sweep of 1-4 queries reads THIS matrix: the result stays exact because the rounding (relative 2^-8 per element:
+// at most 2^-8 |q||v| on a dot product, at most 2^-8 |v| on a Euclidean distance) is added to the candidate margin
+// (qprep_kernel) and every candidate is re-scored from the f32 corpus.
+// row_err2[r - row0] accumulates |v - bf16(v)|^2 of row r (cleared by the caller): the candidate margins use the
+// MEASURED rounding error of the mirror — max_r |e_r| and max_r |e_r| / |v_r| — which is rigorous like the worst case
+// 2^-8 |v| but about 2.5x smaller (the rounding error of a bf16 is uniform in +-half an ulp, not always the maximum).
 __global__ void __launch_bounds__(256) half_rows_kernel(const float* __restrict__ corpus, float* __restrict__ half,
-                                                        uint32_t ld, uint64_t row0, uint64_t n) {
+                                                        uint32_t ld, uint64_t row0, uint64_t n, float* __restrict__ row_err2) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     const uint32_t per_row = ld >> 3;  // 8-element groups per row
@@ -355,26 +370,54 @@ __global__ void __launch_bounds__(256) half_rows_kernel(const float* __restrict_
         const uint32_t g = (uint32_t)(i % per_row);
         const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
         const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
-        v4f out;
-        const f2 p0 = {a.x, a.y}, p1 = {a.z, a.w}, p2 = {b.x, b.y}, p3 = {b.z, b.w};
-        out.x = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf2)));
-        out.y = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf2)));
-        out.z = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p2, bf2)));
-        out.w = __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(p3, bf2)));
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t pk[4];
+        float err2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const f2 pr = {x[2 * t], x[2 * t + 1]};
+            pk[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf2));
+            const float e0 = x[2 * t] - __uint_as_float(pk[t] << 16), e1 = x[2 * t + 1] - __uint_as_float(pk[t] & 0xFFFF0000u);
+            err2 = __builtin_fmaf(e0, e0, err2);
+            err2 = __builtin_fmaf(e1, e1, err2);
+        }
+        const v4f out = {__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
         *reinterpret_cast<v4f*>(half + r * (ld >> 1) + g * 4u) = out;
+        if (err2 > 0.f) atomicAdd(row_err2 + (r - row0), err2);
     }
 }
 
-hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s) {
+// err_bits[0] = max_r |e_r|, err_bits[1] = max_r |e_r| / |v_r| (both with slack for the summation order of the atomics)
+__global__ void __launch_bounds__(256) half_err_kernel(const float* __restrict__ row_err2, const float* __restrict__ norms,
+                                                       uint64_t row0, uint64_t n, uint32_t* __restrict__ err_bits) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float e = __builtin_sqrtf(row_err2[i]) * 1.0005f;
+        const float vn = norms[row0 + i];
+        if (e == e && e > 0.f) {  // e >= 0: bit order == value order
+            atomicMax(err_bits, __float_as_uint(e));
+            if (vn > 0.f) {
+                const float rel = e / vn * 1.0005f;
+                if (rel == rel) atomicMax(err_bits + 1, __float_as_uint(rel));
+            }
+        }
+    }
+}
+
+hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+                            float* row_err2_scratch, uint32_t* err_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(half_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, half, ld, row0, n);
+    hipError_t e = hipMemsetAsync(row_err2_scratch, 0, n * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(half_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, half, ld, row0, n, row_err2_scratch);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(half_err_kernel, dim3(blocks), dim3(256), 0, s, row_err2_scratch, norms, row0, n, err_bits);
     return hipGetLastError();
 }
 
-// cosine-type and dot metrics, rows made of whole 16-byte bf16 chunks
+// every metric the VALU sweep serves, as long as the rows are made of whole 16-byte bf16 chunks
 bool scan_half_supported(uint32_t ld, int metric) {
-    return (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_SPARSE_COSINE_F64) &&
-           ld % 8u == 0;
+    (void)metric;
+    return ld % 8u == 0;
 }
 
 // ---- read-ceiling probe -----------------------------------------------------------------------------

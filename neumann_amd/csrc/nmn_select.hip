@@ -71,7 +71,10 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
 __device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
     uint32_t Tc = kKeyNaN;
     if (T > kKeyNegInf) {
-        const float tau = key_to_score(T);
+        float tau = key_to_score(T);
+        // Euclidean score 1/(1+d) swept over the bf16 mirror: the distance may be off by up to qi.pad (two-sided), i.e.
+        // the threshold distance 1/tau - 1 grows by qi.pad
+        if (qi.pad > 0.0f && tau > 0.0f) tau = tau / (1.0f + qi.pad * tau);
         const float thr = tau - qi.margin_abs - fabsf(tau) * qi.margin_rel;
         if (thr == thr) {
             Tc = score_to_key(thr);
