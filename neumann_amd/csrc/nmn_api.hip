@@ -82,7 +82,7 @@ static void wait_idle(nmn_index* idx, std::unique_lock<std::mutex>& lk) {
 
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qinfo_f32, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
                     w->h_counts2, w->lk_keys};
     for (void* p : ptrs)
@@ -175,6 +175,7 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->k_extra), 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qpad), nq * w->ld * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo), nq * sizeof(QInfo)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo_f32), nq * sizeof(QInfo)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_rows), nq * w->cand_cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
@@ -479,6 +480,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }
         }
         w->last_elem_bytes = use_half ? 2u : 4u;
+        // A bf16 pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
+        // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
+        const bool f32_retry = use_half && n_rows >= (1u << 18);
+        if (f32_retry)
+            HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric, idx->max_norm_bits,
+                                 w->qpad, w->qinfo_f32, w->qstate, 0, stream));
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : (use_half ? 2 : 0), stream,
                              use_half ? idx->half_err_bits : nullptr));
@@ -558,11 +565,23 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.cand_cap = w->cand_cap;
             sel.skip_key = sp.skip_key;
             sel.k_extra = nullptr;
+            sel.retry = 0;
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
                 sel.k_extra = w->k_extra;
             }
             HIP_TRY(launch_select(sel, stream));
+            if (f32_retry) {  // both launches return at once for queries whose first selection did not overflow
+                ScanParams sr = sp;
+                sr.corpus_half = nullptr;
+                sr.qinfo = w->qinfo_f32;
+                sr.retry_state = w->qstate;
+                HIP_TRY(launch_scan(sr, stream));
+                SelectParams sel2 = sel;
+                sel2.qinfo = w->qinfo_f32;
+                sel2.retry = 1;
+                HIP_TRY(launch_select(sel2, stream));
+            }
 
             RescoreParams rp{};
             rp.corpus = idx->corpus;

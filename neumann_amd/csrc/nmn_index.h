@@ -29,6 +29,7 @@ struct Workspace {
     uint64_t tmax_stride = 0;
     float* qpad = nullptr;
     QInfo* qinfo = nullptr;
+    QInfo* qinfo_f32 = nullptr;    // margins of the f32 sweep, for the retry after an overflowing bf16 pass
     QState* qstate = nullptr;
     uint32_t* cand_rows = nullptr;
     float* cand_scores = nullptr;

@@ -81,6 +81,7 @@ __host__ __device__ inline uint64_t score_at(uint64_t row, uint32_t q, uint32_t 
 struct ScanParams {
     const float* corpus;     // [rows][ld]
     const float* corpus_half;   // nullable: bf16 mirror (row stride ld/2 floats) the VALU sweep reads instead of `corpus`
+    const QState* retry_state;  // nullable: sweep only the queries whose candidate list overflowed (f32 retry of a bf16 pass)
     const float* corpus_split;  // split-bf16 mirror of corpus (MFMA sweep only), same shape and stride
     const float* norms;      // [rows]
     const float* qpad;       // [nq][ld] zero padded
@@ -135,6 +136,7 @@ struct SelectParams {
     uint32_t cand_cap;
     const uint32_t* skip_key;  // nullable [nq]: scores of tiles whose maximum is below it were never written
     const uint32_t* k_extra;   // nullable: added to k for the threshold rank (rows forced to +inf, f64 similarity)
+    int retry;                 // 1: second selection after the f32 retry sweep — only queries flagged `overflow` take part
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);

@@ -148,6 +148,12 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
     const uint32_t mat_ld = HALF ? ld >> 1 : ld;      // row stride in floats
     const uint32_t chunks = HALF ? ld >> 3 : ld4;     // 16-byte chunks per row
     const uint32_t q0 = blockIdx.y * NQ;
+    if (p.retry_state) {  // f32 retry after a bf16 pass: nothing to do unless one of this block's queries overflowed
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) any = any || (q0 + q < p.nq && p.retry_state[q0 + q].overflow != 0);
+        if (!any) return;
+    }
     {
         v4f* qs4 = reinterpret_cast<v4f*>(qs);
         for (uint32_t i = threadIdx.x; i < NQ * ld4; i += 256) {

@@ -281,3 +281,24 @@ def test_large_k_on_empty_and_tiny_shards():
         idx.upload(np.eye(4, dtype=np.float32))
         rows, scores, counts = idx.search(np.array([1, 0.5, 0, 0], np.float32), 5000, 0)
         assert counts[0] == 4 and rows[0, :4].tolist() == [0, 1, 2, 3]
+
+
+def test_bf16_pass_overflow_is_retried_in_f32():
+    """6000 rows packed within 2e-4 of each other in cosine: the bf16-mirror pass (margin ~3e-3) admits more than the
+    4096-row candidate capacity, the f32 retry sweep (margin ~1e-5) does not — the answer is the oracle's and no query
+    ends in the exact-scan fallback."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(99)
+    n, d, k = 300_000, 64, 50
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    crowd = rng.choice(n, 6000, replace=False)
+    A[crowd] = (q[None, :] + 0.05 * rng.standard_normal((6000, d))).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for metric in (0, 2, 1):
+            rows, scores, counts, stats = idx.search(q, k, metric, with_stats=True)
+            er, es = oc.search(A, q, k, metric)
+            assert counts[0] == k and np.array_equal(rows[0], er) and np.all(scores[0] == es)
+            assert stats.fallback_queries == 0, metric
+            assert stats.bytes_scanned == n * d * 2          # the (first) sweep read the bf16 mirror
