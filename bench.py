@@ -209,11 +209,14 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
     rows, scores, counts = (t.cpu().numpy().copy() for t in out)
     idx.set_timing(True)
     sweep_ms = []
+    elem_bytes = 4
     for i in range(4):
         step(i)
         st = idx.last_stats(streams[i % 2])
         if st.scan_ms > 0:
             sweep_ms.append(st.scan_ms)
+        if st.rows_scanned:
+            elem_bytes = int(st.bytes_scanned // (st.rows_scanned * args.dim))
     idx.set_timing(False)
     torch.cuda.synchronize()
     qh = q_host[(steps - 1) % 4]
@@ -226,12 +229,13 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
     per_sweep = 64 if args.dim // 128 <= 6 else 32
     sweeps = (nq + per_sweep - 1) // per_sweep
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
-    gbps = idx.rows * args.dim * 4 * sweeps / (sweep * 1e-3) / 1e9
+    gbps = idx.rows * args.dim * elem_bytes * sweeps / (sweep * 1e-3) / 1e9
     return {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
             "value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "sweep_ms_incl_sampling_pass": sweep,
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbps / HBM_PEAK_GBS, "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)"},
+                         "frac": gbps / HBM_PEAK_GBS, "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)",
+                         "bytes_per_corpus_element": elem_bytes},
             "exact_topk_certified_3_of_batch": bool(ok) if not args.no_parity else None}
 
 

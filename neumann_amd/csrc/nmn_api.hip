@@ -283,7 +283,6 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     for (auto& kv : idx->ws) ws_free(kv.second);
     idx->ws.clear();
     if (idx->corpus) (void)hipFree(idx->corpus);
-    if (idx->split) (void)hipFree(idx->split);
     if (idx->half) (void)hipFree(idx->half);
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->norms) (void)hipFree(idx->norms);
@@ -335,8 +334,7 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
     idx->rows = std::max(idx->rows, row0 + n);
-    idx->split_rows = std::min(idx->split_rows, row0);  // the mirrors are re-derived from row0 on, lazily
-    idx->half_rows = std::min(idx->half_rows, row0);
+    idx->half_rows = std::min(idx->half_rows, row0);  // the mirror is re-derived from row0 on, lazily
     return NMN_OK;
 }
 
@@ -424,41 +422,21 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
-        // >= 5 queries in a pass: one corpus sweep per 64 queries on the matrix cores, else 4 per sweep on VALU
-        bool use_mfma = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
-                        !idx->split_failed && getenv("NMN_NO_MFMA") == nullptr;
-        if (use_mfma) {
-            // bring the split-bf16 mirror up to date (allocation + conversion of new rows happen once)
-            if (!idx->split) {
-                hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->split), (size_t)idx->cap_pad * idx->ld * sizeof(float));
-                if (e != hipSuccess) {
-                    (void)hipGetLastError();
-                    idx->split = nullptr;
-                    idx->split_failed = true;  // not enough HBM for the mirror: VALU sweeps (4 queries each) instead
-                    use_mfma = false;
-                } else {
-                    idx->split_rows = 0;
-                    HIP_TRY(hipMemsetAsync(idx->split, 0, (size_t)idx->cap_pad * idx->ld * sizeof(float), stream));
-                }
-            }
-            if (use_mfma && idx->split_rows < n_rows) {
-                HIP_TRY(launch_split_rows(idx->corpus, idx->split, idx->ld, idx->split_rows, n_rows - idx->split_rows, stream));
-                // rare (first batched search, or rows uploaded since): wait here so that searches enqueued on
-                // OTHER streams afterwards may rely on the mirror without cross-stream events
-                HIP_TRY(hipStreamSynchronize(stream));
-                idx->split_rows = n_rows;
-            }
-        }
-        // 1-4 queries, cosine / dot: sweep the bf16 mirror (half the bytes of the f32 corpus) — same lifecycle as `split`
-        bool use_half = !use_mfma && n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
-                        getenv("NMN_NO_HALF") == nullptr;
+        // The approximate sweep reads the shard's bf16 MIRROR (half the bytes of the f32 corpus; its measured rounding
+        // error is part of the candidate margin): >= 5 queries of a cosine / dot batch go through the matrix cores (one
+        // sweep per 64 or 32 queries), everything else through the VALU sweep (4 queries per sweep).  The mirror is
+        // allocated and filled on first use and extended when rows were uploaded since.
+        const bool mfma_shape = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
+                                getenv("NMN_NO_MFMA") == nullptr;
+        bool use_half = n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
+                        (mfma_shape || getenv("NMN_NO_HALF") == nullptr);
         if (use_half) {
             if (!idx->half) {
                 hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half), (size_t)idx->cap_pad * idx->ld * 2);
                 if (e != hipSuccess) {
                     (void)hipGetLastError();
                     idx->half = nullptr;
-                    idx->half_failed = true;  // not enough HBM for the mirror: the f32 sweep serves
+                    idx->half_failed = true;  // not enough HBM for the mirror: f32 VALU sweeps serve everything
                     use_half = false;
                 } else {
                     idx->half_rows = 0;
@@ -473,27 +451,29 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), cnt * sizeof(float)));
                 hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, idx->half_rows, cnt, idx->norms, scratch,
                                                  idx->half_err_bits, stream);
-                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // as for `split`: other streams rely on the mirror
+                // rare (first search, or rows uploaded since): wait here so that searches enqueued on OTHER streams
+                // afterwards may rely on the mirror without cross-stream events
+                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
                 (void)hipFree(scratch);
                 if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
                 idx->half_rows = n_rows;
             }
         }
+        const bool use_mfma = mfma_shape && use_half;  // the matrix-core sweep has no f32 variant
         w->last_elem_bytes = use_half ? 2u : 4u;
         // A bf16 pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
-        const bool f32_retry = use_half && n_rows >= (1u << 18);
+        const bool f32_retry = use_half && !use_mfma && n_rows >= (1u << 18);
         if (f32_retry)
             HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric, idx->max_norm_bits,
                                  w->qpad, w->qinfo_f32, w->qstate, 0, stream));
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
-                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, use_mfma ? 1 : (use_half ? 2 : 0), stream,
+                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, (use_mfma ? 1 : 0) | (use_half ? 2 : 0), stream,
                              use_half ? idx->half_err_bits : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
             sp.corpus_half = use_half ? idx->half : nullptr;
-            sp.corpus_split = idx->split;
             sp.norms = idx->norms;
             sp.qpad = w->qpad;
             sp.qinfo = w->qinfo;
@@ -973,7 +953,6 @@ extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, ui
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, s));
     HIP_TRY(hipStreamSynchronize(s));
     idx->rows = std::max(idx->rows, row0 + n);
-    idx->split_rows = std::min(idx->split_rows, row0);
     idx->half_rows = std::min(idx->half_rows, row0);
     return NMN_OK;
 }
@@ -988,7 +967,6 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
     HIP_TRY(hipMemcpyAsync(idx->corpus + row * (uint64_t)idx->ld, vec_host, (size_t)idx->dim * 4,
                            hipMemcpyHostToDevice, s));
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
-    if (idx->split && row < idx->split_rows) HIP_TRY(launch_split_rows(idx->corpus, idx->split, idx->ld, row, 1, s));
     if (idx->half && row < idx->half_rows) {
         float* scratch = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(float)));

@@ -212,9 +212,9 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         //   bf16 mirror: row r is stored as v + e_r, so |dot error| = |q . e_r| <= |q||e_r| <= |q||v_r| * rho with
         //   rho = max_r |e_r| / |v_r| MEASURED when the mirror was written (<= 2^-8, typically 0.4 * 2^-8) -> 2 rho.
         float split = 0.0f, half_abs = 0.0f;
-        if (mfma_pass == 1) split = 6.1035156e-05f;  // 2^-14
-        if (mfma_pass == 2) {
-            split = half_err_bits ? 2.0f * u2f(half_err_bits[1]) : 7.9e-03f;                            // worst case 2 * 2^-8
+        if (mfma_pass & 1) split = 6.1035156e-05f;  // 2^-14: hi + lo split of the QUERIES on the MFMA sweep
+        if (mfma_pass & 2) {                          // bf16 mirror of the CORPUS (VALU and MFMA sweeps)
+            split += half_err_bits ? 2.0f * u2f(half_err_bits[1]) : 7.9e-03f;                          // worst case 2 * 2^-8
             half_abs = half_err_bits ? 2.0f * u2f(half_err_bits[0]) : 7.9e-03f * u2f(*max_norm_bits);  // 2 max|e_r|
         }
         if (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_SPARSE_COSINE_F64) {
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         } else {
             qi.margin_abs = 0.0f;
             qi.margin_rel = 4.0f * (dd + 8.0f) * u;
-            if (mfma_pass == 2) {
+            if (mfma_pass & 2) {
                 // bf16 mirror under a Euclidean metric: v~ = v + e_r, so by the triangle inequality
                 // |d(q, v~) - d(q, v)| <= |e_r| <= max_r |e_r| =: D, an ABSOLUTE error on the distance (twice, as above)
                 const float two_d = half_abs;

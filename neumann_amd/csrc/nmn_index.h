@@ -62,10 +62,7 @@ struct nmn_index {
     int device = 0;
     uint32_t cand_cap = kDefaultCandCap;
     float* corpus = nullptr;
-    float* split = nullptr;      // split-bf16 mirror for the batched (MFMA) sweep; allocated on first use
-    uint64_t split_rows = 0;     // rows [0, split_rows) of `split` are current
-    bool split_failed = false;   // allocation failed once: stay on the VALU sweeps
-    float* half = nullptr;       // bf16 mirror the cosine / dot sweeps of 1-4 queries read (half the bytes); lazy
+    float* half = nullptr;       // bf16 mirror of `corpus` every approximate sweep reads (half the bytes); lazy
     uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current
     bool half_failed = false;    // allocation failed once: stay on the f32 sweep
     uint32_t* half_err_bits = nullptr;  // device [2]: max_r |e_r| and max_r |e_r|/|v_r| of the mirror's rounding (f32 bits)

@@ -82,7 +82,6 @@ struct ScanParams {
     const float* corpus;     // [rows][ld]
     const float* corpus_half;   // nullable: bf16 mirror (row stride ld/2 floats) the VALU sweep reads instead of `corpus`
     const QState* retry_state;  // nullable: sweep only the queries whose candidate list overflowed (f32 retry of a bf16 pass)
-    const float* corpus_split;  // split-bf16 mirror of corpus (MFMA sweep only), same shape and stride
     const float* norms;      // [rows]
     const float* qpad;       // [nq][ld] zero padded
     const QInfo* qinfo;      // [nq]
@@ -115,7 +114,6 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 uint32_t scan_mfma_queries_per_sweep(uint32_t ld);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
 // (re)build rows [row0,row0+n) of the split-bf16 mirror from the f32 corpus
-hipError_t launch_split_rows(const float* corpus, float* split, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s);
 
 struct SelectParams {
     const uint32_t* scores;  // score_at(row, q, nql)
@@ -170,8 +168,8 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
                         hipStream_t s, const uint32_t* half_err_bits = nullptr);
-// approx_pass: 0 = f32 sweep, 1 = split-bf16 MFMA sweep, 2 = bf16-mirror sweep (half_err_bits = the mirror's measured
-// rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|)
+// approx_pass bits: 1 = queries split hi+lo (MFMA sweep), 2 = the sweep reads the bf16 mirror of the corpus
+// (half_err_bits = the mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep
 struct RescoreParams {
     const float* corpus;
     const float* norms;

@@ -1,34 +1,29 @@
 // nmn_scan_mfma.hip — batched-query scan (5..64 queries per corpus sweep) on the CDNA4 matrix cores.
 //
 // With nq queries the scan is a [rows x dim] x [dim x nq] product.  At nq = 64 the f32 VALU / f32-MFMA
-// rate (157 TFLOP/s) would bound it at 6.25 ms per 10M x 768 sweep, above the 3.84 ms HBM floor
-// (SURVEY.md §7 hard part b), so the APPROXIMATE pass runs on bf16 MFMA with every f32 operand split
-// into hi + lo bf16 (x = hi + lo + O(2^-16 x)) and three products hi*hi + hi*lo + lo*hi: relative error
-// <= 2^-15 * sum|q_i v_i| — the same class as f32 summation error; it only widens the candidate margin
-// (qprep adds 2^-14), the exact rescore (nmn_exact.hip) restores bit parity.
+// rate (157 TFLOP/s) would bound it at 6.25 ms per 10M x 768 sweep, above the HBM floor (SURVEY.md §7 hard
+// part b), so the APPROXIMATE pass runs on bf16 MFMA.
 //
-// The corpus side of the split is NOT done in the sweep: the shard keeps a split-bf16 MIRROR of the
-// corpus in HBM (split_rows_kernel below; built lazily on the first batched search, 288 GB per GPU
-// makes the second copy affordable) with the SAME 4 bytes per element and the same row stride: each
-// 32-float k-step of a row (128 B) becomes [32 bf16 hi | 32 bf16 lo].  A sweep therefore moves exactly
-// the algorithmic rows*dim*4 bytes, and its inner loop is ds_read_b128 -> MFMA with no conversion VALU
-// (converting in-register made the sweep VALU/issue-bound at 12 VALU per MFMA: 6.3 ms instead of the
-// ~4.6 ms the HBM stream allows).  The f32 corpus stays the source of truth for the exact kernels.
+// Corpus side: the sweep streams the shard's bf16 MIRROR (`half`, nmn_scan.hip: half_rows_kernel) — 2 bytes per
+// element, the same matrix the 1-4 query VALU sweep reads — so a sweep moves rows*dim*2 bytes.  Its rounding is
+// not compensated in the sweep: the mirror's MEASURED error norms (max |e_r| / |v_r|) go into the candidate margin
+// (qprep_kernel) and the exact rescore (nmn_exact.hip) restores bit parity.  (An earlier version streamed a
+// split hi+lo mirror at 4 bytes per element with three MFMAs per product; with the margin machinery in place the
+// lo half bought nothing but traffic.)
+// Query side: every f32 query element is split into hi + lo bf16 (x = hi + lo + O(2^-16 x)) and both halves are
+// multiplied against the corpus element: two MFMAs per product, query error 2^-15 relative (2^-14 budgeted).
 //
 // Structure (one workgroup = 4 waves = 64 queries x 64-row tiles, persistent over a tile range):
-//   * queries are STATIONARY in registers: wave w owns queries 16w..16w+15 as MFMA B-fragments
-//     (v_mfma_f32_16x16x32_bf16; hi and lo; 8 VGPRs per 32-wide k-step -> 192 VGPRs at dim 768);
-//   * the corpus STREAMS through LDS: [64 rows][128 floats] stages (32 KiB) filled by
-//     global_load_lds_dwordx4 (LDS-DMA: full 512-B row segments, no VGPRs), double buffered;
-//     every wave reads each stage as A-fragments (ds_read_b128), splits hi/lo and issues 3 MFMAs per
-//     16-row block and k-step;
-//   * the LDS image is XOR-swizzled through the DMA SOURCE address (chunk ^= row & 15) so that the
-//     16 rows of a ds_read_b128 service group fall on 16 different bank slots;
-//   * the k index inside a k-step is permuted (lane group g takes floats 4g..4g+3 and 16+4g..16+4g+3)
-//     so each ds_read_b128 / query load is one contiguous 16 B — any permutation is legal as long as A
-//     and B use the same one;
-//   * epilogue per tile: scores (float4 per lane), per-(query,tile) maxima, per-(query,block) maxima —
-//     the same three-level hierarchy select_kernel consumes after the VALU scan.
+//   * queries are STATIONARY in registers as MFMA B-fragments (v_mfma_f32_16x16x32_bf16; hi and lo; 8 VGPRs per
+//     32-wide k-step and query group -> 192 VGPRs at dim 768);
+//   * the corpus STREAMS through LDS: [64 rows][128 bf16] stages (16 KiB) filled by global_load_lds_dwordx4
+//     (LDS-DMA: full 256-B row segments, no VGPRs) in a ring of 8 (7 in flight, 112 KiB per CU);
+//   * the LDS image is XOR-swizzled through the DMA SOURCE address (chunk ^= row & 15) so that the 16 rows of a
+//     ds_read_b128 service group fall on 16 different bank slots;
+//   * wave w owns k-step w (32 of the 128 elements) of every stage: one ds_read_b128 per 16-row block (8 bf16 of
+//     one row per lane: exactly the A fragment), two MFMAs per row block and query group;
+//   * epilogue per tile: the four K-quarter partial sums meet through LDS, then scores (float4 per lane),
+//     per-(query,tile) maxima, per-(query,workgroup) maxima — the hierarchy select_kernel consumes.
 // Rows longer than 768 floats (up to 1536) keep HALF the queries stationary (QG = 2 groups of 16: the
 // B-fragments still cost 192 VGPRs) and sweep the corpus once per 32 queries.
 // Cosine and dot product only: the Euclidean score needs |x-q|^2, whose expansion cancels
@@ -42,8 +37,10 @@ typedef short s8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaQ = 64;       // queries per sweep when 4 query groups fit the registers (dim <= 768)
-constexpr int kStageK = 128;     // floats of every row per LDS stage
-constexpr int kStageBytes = kTileRows * kStageK * 4;  // 32 KiB
+constexpr int kStageK = 128;     // granularity of the row length this kernel accepts (elements)
+// A stage is [64 rows][128*KS bf16] (KS = 1 or 2 k-steps per wave and stage): 16 KiB or 32 KiB.  Rows whose length is a
+// multiple of 256 use KS = 2: half as many stage hand-overs (a counted wait and a workgroup barrier each) per byte.
+constexpr int kRingBytes = 128 * 1024;  // LDS given to the DMA ring: 8 stages of 16 KiB or 4 of 32 KiB
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -71,21 +68,21 @@ __device__ __forceinline__ void split8(const f4& a, const f4& b, s8& hi, s8& lo)
     lo = __builtin_bit_cast(s8, l);
 }
 
-constexpr int kRing = 4;         // LDS stages in the DMA ring (3 in flight while one is consumed: ~96 KiB per CU)
+constexpr int kMaxRing = 8;      // stages of the deepest ring (norm slots are sized for it)
 
-// issue the LDS-DMA of one stage into LDS buffer `buf`.  `stage_base` = corpus + (tile*64*ld + kc*128)
-// (wave-uniform); `loff[pp]` = this lane's byte offset for piece pp, computed once per kernel.
-// wave w moves pieces 8w..8w+7; piece p = rows 2p,2p+1 (2 x 512 B); lane i -> row 2p+(i>>5), LDS chunk
-// i&31, global chunk (i&31) ^ (row&15)  (the swizzle lives on the source side: the LDS side of an
-// LDS-DMA is always wave-base + lane*16).
-template <int AUX>
-__device__ __forceinline__ void stage_dma(const float* stage_base, const uint32_t (&loff)[8], float* buf,
+// issue the LDS-DMA of one stage into LDS buffer `buf`.  `stage_base` = mirror + (tile*64*ld + kc*128) elements
+// (wave-uniform); `loff[pp]` = this lane's byte offset for piece pp, computed once per kernel.  A piece is one 1-KiB
+// DMA instruction = 64/LR rows of LR = 16*KS chunks; wave w moves pieces PIECES*w .. PIECES*w + PIECES-1; lane i -> row
+// (64/LR)*p + i/LR, LDS chunk i%LR, global chunk (i%LR) ^ (row&15)  (the swizzle lives on the source side: the LDS side
+// of an LDS-DMA is always wave-base + lane*16).
+template <int AUX, int PIECES>
+__device__ __forceinline__ void stage_dma(const char* stage_base, const uint32_t (&loff)[PIECES], float* buf,
                                           uint32_t wave) {
 #pragma unroll
-    for (int pp = 0; pp < 8; pp++) {
-        const char* src = reinterpret_cast<const char*>(stage_base) + loff[pp];
+    for (int pp = 0; pp < PIECES; pp++) {
+        const char* src = stage_base + loff[pp];
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(buf + (wave * 8u + (uint32_t)pp) * 256u),
+                                         (__attribute__((address_space(3))) void*)(buf + (wave * PIECES + (uint32_t)pp) * 256u),
                                          16, 0, AUX);  // AUX = 2: non-temporal
     }
 }
@@ -97,14 +94,21 @@ __device__ __forceinline__ void norms_dma(const float* __restrict__ norms, uint6
                                      (__attribute__((address_space(3))) void*)nbuf, 4, 0, 0);
 }
 
-// wait until at most `stages_after` younger stages (8 DMA ops each) are still in flight.  vmcnt retires
+// wait until at most `stages_after` younger stages (PIECES DMA ops each) are still in flight.  vmcnt retires
 // in issue order on gfx9-class parts, so this guarantees the oldest stage has landed; the few extra
 // ops some waves carry (norm DMA, epilogue stores) only make the wait slightly conservative.
+template <int PIECES>
 __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
-    if (stages_after >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (stages_after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (stages_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(PIECES == 4 || PIECES == 8, "vmcnt immediates below");
+    switch (stages_after * PIECES) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    }
 }
 
 // Workgroup = 4 waves, one per SIMD (the kernel needs ~300 of the 512 registers a lone wave may use).
@@ -115,12 +119,19 @@ __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
 // (192 at dim 768), the 4 row-blocks x 4 query-groups of accumulators 64.  The four K-quarter partial
 // sums of a tile meet once per tile through LDS; wave w then finishes query group w.
 // QG = query groups of 16 kept stationary (4: 64 queries per sweep, 2: 32).  Waves 0..QG-1 finish one group each.
-template <int KC, int QG, int METRIC, bool MASKED, int AUX>
+// KC = stages per row (ld / (128*KS)), KS = k-steps per wave and stage.
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX>
 __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
+    constexpr int kStageElems = 128 * KS;                        // elements of a row per stage
+    constexpr int kStageBytes = kTileRows * kStageElems * 2;     // 16 / 32 KiB of bf16
+    constexpr int kRowPitch = kStageElems / 2;                   // LDS row pitch of a stage, in floats
+    constexpr int kRing = kRingBytes / kStageBytes;              // 8 / 4 stages (all but one in flight)
+    constexpr int kPieces = 4 * KS;                              // 1-KiB DMA instructions per wave and stage
+    constexpr uint32_t LR = 16 * KS;                             // lanes (16-B chunks) per row of a stage
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | exchange | norms
-    float* xch = lds + kRing * (kStageBytes / 4);                // [4 src waves][64 lanes][4 rb] f4, reused per round
-    float* nrm = xch + 4 * 64 * 16;                              // [kRing tiles][64] row magnitudes (with one-stage
-                                                                 // tiles, dim 128, kRing tiles are in flight at once)
+    float* xch = lds + kRingBytes / 4;                           // [4 src waves][64 lanes][4 rb] f4, reused per round
+    float* nrm = xch + 4 * 64 * 16;                              // [kMaxRing tiles][64] row magnitudes (with one-stage
+                                                                 // tiles up to kRing tiles are in flight at once)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
@@ -128,15 +139,15 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
 
     // ---- stationary operand: QG*16 queries x this wave's k-step of every stage -----------------
-    s8 bhi[KC][QG], blo[KC][QG];
+    s8 bhi[KC * KS][QG], blo[KC * KS][QG];  // k-step ks of stage kc: this wave owns k-step ks*4 + wave of the stage
 #pragma unroll
     for (int qg = 0; qg < QG; qg++) {
         const uint32_t qq = q0 + (uint32_t)qg * 16u + n;
         const bool ok = qq < p.nq;
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
 #pragma unroll
-        for (int kc = 0; kc < KC; kc++) {
-            const uint32_t k0 = (uint32_t)kc * kStageK + wave * 32u + g * 8u;  // lane group g: k0..k0+7
+        for (int kc = 0; kc < KC * KS; kc++) {
+            const uint32_t k0 = (uint32_t)(kc / KS) * kStageElems + ((uint32_t)(kc % KS) * 4u + wave) * 32u + g * 8u;  // k0..k0+7
             f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 a = *reinterpret_cast<const f4*>(qv + k0);
@@ -157,14 +168,15 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
     const uint32_t n_stage = (t1 - t0) * KC;
 
-    uint32_t loff[8];  // per-lane source byte offsets of the 8 DMA pieces this wave moves per stage
+    uint32_t loff[kPieces];  // per-lane source byte offsets of the DMA pieces this wave moves per stage
 #pragma unroll
-    for (int pp = 0; pp < 8; pp++) {
-        const uint32_t r = 2u * (wave * 8u + (uint32_t)pp) + (lane >> 5);
-        loff[pp] = (r * ld + (((lane & 31u) ^ (r & 15u)) * 4u)) * 4u;
+    for (int pp = 0; pp < kPieces; pp++) {
+        const uint32_t r = (64u / LR) * (wave * kPieces + (uint32_t)pp) + lane / LR;
+        loff[pp] = r * ld * 2u + (((lane % LR) ^ (r & 15u)) * 16u);
     }
-    auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const float* {
-        return p.corpus_split + (uint64_t)tile_ * tstep * kTileRows * ld + kc_ * kStageK;
+    const char* const mirror = reinterpret_cast<const char*>(p.corpus_half);
+    auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const char* {
+        return mirror + ((uint64_t)tile_ * tstep * kTileRows * ld + kc_ * kStageElems) * 2ull;
     };
 
     // prologue: stages 0..kRing-2 in flight (stage s lives in ring slot s % kRing)
@@ -173,13 +185,15 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         if (s0 < n_stage) {
             if (METRIC == NMN_METRIC_COSINE && wave == 0 && s0 % KC == 0)
                 norms_dma(p.norms, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kRing) * 64u, lane);
-            stage_dma<AUX>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
+            stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         }
     }
 
-    // LDS offsets of this lane's two 16-B reads per row block (swizzled chunk ^ (row & 15), row & 15 == n)
-    const uint32_t off0 = n * kStageK + (((wave * 8u + g) ^ n) * 4u);
-    const uint32_t off1 = n * kStageK + (((wave * 8u + 4u + g) ^ n) * 4u);
+    // LDS offset (floats) of this lane's 16-B read per row block and k-step ks: row n, chunk (ks*4+w)*4+g of the row's
+    // 16*KS (swizzled ^ n)
+    uint32_t off[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) off[ks] = n * kRowPitch + (((((uint32_t)ks * 4u + wave) * 4u + g) ^ n) * 4u);
 
     uint32_t wmax = kKeyMasked;
     uint32_t sidx = 0;  // running stage index of this workgroup
@@ -196,7 +210,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             // younger stages stay in flight) and all waves met at the barrier.  WAR: a wave reaches this
             // barrier only after consuming (lgkmcnt) its reads of stage sidx-1, whose ring slot is the
             // one the DMA issued right below (stage sidx+kRing-1) overwrites.
-            wait_stage(min(n_stage - 1u - sidx, (uint32_t)(kRing - 2)));
+            wait_stage<kPieces>(min(n_stage - 1u - sidx, (uint32_t)(kRing - 2)));
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             {
@@ -205,21 +219,30 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                     const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
                     if (METRIC == NMN_METRIC_COSINE && wave == 0 && nkc == 0)
                         norms_dma(p.norms, (uint64_t)nt * tstep, nrm + ((nt - t0) % kRing) * 64u, lane);
-                    stage_dma<AUX>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
+                    stage_dma<AUX, kPieces>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
                 }
             }
-            // A fragments straight from the split-bf16 stage: chunk g of this wave's k-step holds 8 hi
-            // values, chunk 4+g the matching 8 lo values (both one ds_read_b128)
+            // A fragments straight from the bf16 stage: chunk g of this wave's k-step = 8 consecutive elements of row n.
+            // All hi products first, then all lo products: the two MFMAs that share an accumulator are 4*QG
+            // independent MFMAs apart instead of back to back (a dependent pair waits out the full MFMA latency).
+            s8 a[KS][4];
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++) {
-                const s8 ahi = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kStageK + off0));
-                const s8 alo = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kStageK + off1));
+            for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-                for (int qg = 0; qg < QG; qg++) {
-                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
-                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo[kc][qg], acc[rb][qg], 0, 0, 0);
-                    acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi[kc][qg], acc[rb][qg], 0, 0, 0);
-                }
+                for (int rb = 0; rb < 4; rb++)
+                    a[ks][rb] = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kRowPitch + off[ks]));
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                    for (int qg = 0; qg < QG; qg++)
+                        acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * KS + ks][qg], acc[rb][qg], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                    for (int qg = 0; qg < QG; qg++)
+                        acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], blo[kc * KS + ks][qg], acc[rb][qg], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -318,12 +341,12 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     if (q_ok && g == 0) p.wmax[(size_t)qn * p.wmax_stride + blockIdx.x] = wmax;
 }
 
-template <int KC, int QG, int METRIC, bool MASKED>
+template <int KC, int KS, int QG, int METRIC, bool MASKED>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid(blocks, (p.nq + QG * 16 - 1) / (QG * 16));
-    const size_t lds = kRing * kStageBytes + 4 * 64 * 16 * 4 + kRing * 64 * 4;
-    auto kern = scan_mfma_kernel<KC, QG, METRIC, MASKED, 2>;  // AUX = 2: non-temporal LDS-DMA (the corpus is read once)
+    const size_t lds = kRingBytes + 4 * 64 * 16 * 4 + kMaxRing * 64 * 4;
+    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;  // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -331,54 +354,26 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int KC, int QG, int METRIC>
+template <int KC, int KS, int QG, int METRIC>
 static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
-    return p.mask ? launch_one_mfma<KC, QG, METRIC, true>(p, s) : launch_one_mfma<KC, QG, METRIC, false>(p, s);
+    return p.mask ? launch_one_mfma<KC, KS, QG, METRIC, true>(p, s) : launch_one_mfma<KC, KS, QG, METRIC, false>(p, s);
 }
 
+// row length / 128: rows that are a multiple of 256 elements stream in 32-KiB stages (KS = 2), the others in 16-KiB ones
 template <int METRIC>
 static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
     switch (p.ld / kStageK) {
-        case 1: return launch_kc<1, 4, METRIC>(p, s);
-        case 2: return launch_kc<2, 4, METRIC>(p, s);
-        case 3: return launch_kc<3, 4, METRIC>(p, s);
-        case 4: return launch_kc<4, 4, METRIC>(p, s);
-        case 5: return launch_kc<5, 4, METRIC>(p, s);
-        case 6: return launch_kc<6, 4, METRIC>(p, s);
-        case 8: return launch_kc<8, 2, METRIC>(p, s);    // 1024
-        case 10: return launch_kc<10, 2, METRIC>(p, s);  // 1280
-        case 12: return launch_kc<12, 2, METRIC>(p, s);  // 1536
+        case 1: return launch_kc<1, 1, 4, METRIC>(p, s);   // 128
+        case 2: return launch_kc<1, 2, 4, METRIC>(p, s);   // 256
+        case 3: return launch_kc<3, 1, 4, METRIC>(p, s);   // 384
+        case 4: return launch_kc<2, 2, 4, METRIC>(p, s);   // 512
+        case 5: return launch_kc<5, 1, 4, METRIC>(p, s);   // 640
+        case 6: return launch_kc<3, 2, 4, METRIC>(p, s);   // 768
+        case 8: return launch_kc<4, 2, 2, METRIC>(p, s);   // 1024: 32 stationary queries
+        case 10: return launch_kc<5, 2, 2, METRIC>(p, s);  // 1280
+        case 12: return launch_kc<6, 2, 2, METRIC>(p, s);  // 1536
         default: return hipErrorInvalidValue;
     }
-}
-
-// ---- the split-bf16 mirror ----------------------------------------------------------------------
-// One thread per 8 consecutive floats: thread t of a k-step (t = 0..3) turns floats 8t..8t+7 into 16 B of
-// hi (written to chunk t of the 128-B k-step) and 16 B of lo (chunk 4+t).
-__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ corpus, float* __restrict__ split,
-                                                         uint32_t ld, uint64_t row0, uint64_t n) {
-    const uint32_t per_row = ld >> 3;  // 8-float groups per row (ld % 32 == 0 on this path)
-    const uint64_t total = n * per_row;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = row0 + i / per_row;
-        const uint32_t grp = (uint32_t)(i % per_row);
-        const uint32_t ks = grp >> 2, t = grp & 3u;
-        const float* src = corpus + r * ld + ks * 32u + t * 8u;
-        const f4 a = *reinterpret_cast<const f4*>(src);
-        const f4 b = *reinterpret_cast<const f4*>(src + 4);
-        s8 hi, lo;
-        split8(a, b, hi, lo);
-        float* dst = split + r * ld + ks * 32u;
-        *reinterpret_cast<u4*>(dst + t * 4u) = __builtin_bit_cast(u4, hi);
-        *reinterpret_cast<u4*>(dst + 16u + t * 4u) = __builtin_bit_cast(u4, lo);
-    }
-}
-
-hipError_t launch_split_rows(const float* corpus, float* split, uint32_t ld, uint64_t row0, uint64_t n, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(split_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, split, ld, row0, n);
-    return hipGetLastError();
 }
 
 // Can the MFMA sweep serve this shape?  Cosine / dot, row length a multiple of 128 floats: up to 768 with 64
