@@ -198,6 +198,18 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
     float* dst = qpad + (size_t)q * ld;
     for (uint32_t i = threadIdx.x; i < ld; i += 64) dst[i] = i < dim ? src[i] : 0.0f;
     const float ss = dot8_group<32>(src, src, dim, threadIdx.x & 7u);
+    // MFMA sweep: the stationary copy of this query is bf16 — its rounding error |q - bf16(q)| goes into the margin
+    float qerr2 = 0.0f;
+    if (mfma_pass & 1) {
+        for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+            const float x = src[i];
+            const uint32_t b = f2u(x);
+            const float h = u2f((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);  // round to nearest even (finite x)
+            const float e = x - h;
+            qerr2 = qerr2 + e * e;
+        }
+        for (int off = 32; off > 0; off >>= 1) qerr2 = qerr2 + __shfl_down(qerr2, off);
+    }
     if (threadIdx.x == 0) {
         const float qmag = sqrt_rn(ss);
         const float u = 5.9604645e-08f;  // 2^-24
@@ -212,10 +224,16 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         //   bf16 mirror: row r is stored as v + e_r, so |dot error| = |q . e_r| <= |q||e_r| <= |q||v_r| * rho with
         //   rho = max_r |e_r| / |v_r| MEASURED when the mirror was written (<= 2^-8, typically 0.4 * 2^-8) -> 2 rho.
         float split = 0.0f, half_abs = 0.0f;
-        if (mfma_pass & 1) split = 6.1035156e-05f;  // 2^-14: hi + lo split of the QUERIES on the MFMA sweep
-        if (mfma_pass & 2) {                          // bf16 mirror of the CORPUS (VALU and MFMA sweeps)
-            split += half_err_bits ? 2.0f * u2f(half_err_bits[1]) : 7.9e-03f;                          // worst case 2 * 2^-8
+        const float rho_v = (mfma_pass & 2) ? (half_err_bits ? u2f(half_err_bits[1]) : 3.95e-03f) : 0.0f;  // worst case 2^-8
+        if (mfma_pass & 2) {  // bf16 mirror of the CORPUS (VALU and MFMA sweeps)
+            split += 2.0f * rho_v;
             half_abs = half_err_bits ? 2.0f * u2f(half_err_bits[0]) : 7.9e-03f * u2f(*max_norm_bits);  // 2 max|e_r|
+        }
+        if (mfma_pass & 1) {
+            // bf16 QUERY on the MFMA sweep: q~ = q + e_q, v~ = v + e_v: |q~.v~ - q.v| <= |e_q||v~| + |q||e_v|
+            //   <= |q||v| (rho_q (1 + rho_v) + rho_v) with rho_q = |e_q| / |q| measured just above (<= 2^-8)
+            const float rho_q = qmag > 0.0f ? __builtin_sqrtf(qerr2) * 1.0005f / qmag : 0.0f;
+            split += 2.0f * rho_q * (1.0f + rho_v) * 1.0005f;
         }
         if (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_SPARSE_COSINE_F64) {
             qi.margin_abs = 3.0f * (dd + 10.0f) * u + split;

@@ -168,7 +168,7 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
                         hipStream_t s, const uint32_t* half_err_bits = nullptr);
-// approx_pass bits: 1 = queries split hi+lo (MFMA sweep), 2 = the sweep reads the bf16 mirror of the corpus
+// approx_pass bits: 1 = queries rounded to bf16 (MFMA sweep), 2 = the sweep reads the bf16 mirror of the corpus
 // (half_err_bits = the mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep
 struct RescoreParams {
     const float* corpus;

@@ -10,12 +10,13 @@
 // (qprep_kernel) and the exact rescore (nmn_exact.hip) restores bit parity.  (An earlier version streamed a
 // split hi+lo mirror at 4 bytes per element with three MFMAs per product; with the margin machinery in place the
 // lo half bought nothing but traffic.)
-// Query side: every f32 query element is split into hi + lo bf16 (x = hi + lo + O(2^-16 x)) and both halves are
-// multiplied against the corpus element: two MFMAs per product, query error 2^-15 relative (2^-14 budgeted).
+// Query side: the stationary queries are rounded to bf16 as well (one MFMA per product); qprep_kernel measures each
+// query's rounding error |q - bf16(q)| / |q| and adds it to that query's margin.  (Keeping a lo half of the queries —
+// a second MFMA per product — cost 10 % of the sweep and bought a margin nobody needed.)
 //
 // Structure (one workgroup = 4 waves = 64 queries x 64-row tiles, persistent over a tile range):
-//   * queries are STATIONARY in registers as MFMA B-fragments (v_mfma_f32_16x16x32_bf16; hi and lo; 8 VGPRs per
-//     32-wide k-step and query group -> 192 VGPRs at dim 768);
+//   * queries are STATIONARY in registers as MFMA B-fragments (v_mfma_f32_16x16x32_bf16; 4 VGPRs per 32-wide k-step
+//     and query group -> 96 VGPRs at dim 768);
 //   * the corpus STREAMS through LDS: [64 rows][128 bf16] stages (16 KiB) filled by global_load_lds_dwordx4
 //     (LDS-DMA: full 256-B row segments, no VGPRs) in a ring of 8 (7 in flight, 112 KiB per CU);
 //   * the LDS image is XOR-swizzled through the DMA SOURCE address (chunk ^= row & 15) so that the 16 rows of a
@@ -52,20 +53,14 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
 }
 
-// x[0..7] (f32) -> hi (8 bf16, RNE) and lo = bf16(x - hi): x = hi + lo + O(2^-16 |x|)
-__device__ __forceinline__ void split8(const f4& a, const f4& b, s8& hi, s8& lo) {
-    u4 h, l;
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t pk = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
-        const float h0 = __uint_as_float(pk << 16);
-        const float h1 = __uint_as_float(pk & 0xFFFF0000u);
-        h[i] = pk;
-        l[i] = cvt_pk_bf16(x[2 * i] - h0, x[2 * i + 1] - h1);
-    }
-    hi = __builtin_bit_cast(s8, h);
-    lo = __builtin_bit_cast(s8, l);
+// x[0..7] (f32) -> 8 bf16, round to nearest even
+__device__ __forceinline__ s8 to_bf16x8(const f4& a, const f4& b) {
+    u4 h;
+    h[0] = cvt_pk_bf16(a.x, a.y);
+    h[1] = cvt_pk_bf16(a.z, a.w);
+    h[2] = cvt_pk_bf16(b.x, b.y);
+    h[3] = cvt_pk_bf16(b.z, b.w);
+    return __builtin_bit_cast(s8, h);
 }
 
 constexpr int kMaxRing = 8;      // stages of the deepest ring (norm slots are sized for it)
@@ -139,7 +134,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
 
     // ---- stationary operand: QG*16 queries x this wave's k-step of every stage -----------------
-    s8 bhi[KC * KS][QG], blo[KC * KS][QG];  // k-step ks of stage kc: this wave owns k-step ks*4 + wave of the stage
+    s8 bhi[KC * KS][QG];  // k-step ks of stage kc: this wave owns k-step ks*4 + wave of the stage
 #pragma unroll
     for (int qg = 0; qg < QG; qg++) {
         const uint32_t qq = q0 + (uint32_t)qg * 16u + n;
@@ -153,7 +148,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 a = *reinterpret_cast<const f4*>(qv + k0);
                 b = *reinterpret_cast<const f4*>(qv + k0 + 4u);
             }
-            split8(a, b, bhi[kc][qg], blo[kc][qg]);
+            bhi[kc][qg] = to_bf16x8(a, b);
         }
     }
     const uint32_t qn = q0 + wave * 16u + n;  // the query this lane FINISHES (C column of group `wave`)
@@ -223,8 +218,6 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 }
             }
             // A fragments straight from the bf16 stage: chunk g of this wave's k-step = 8 consecutive elements of row n.
-            // All hi products first, then all lo products: the two MFMAs that share an accumulator are 4*QG
-            // independent MFMAs apart instead of back to back (a dependent pair waits out the full MFMA latency).
             s8 a[KS][4];
 #pragma unroll
             for (int ks = 0; ks < KS; ks++)
@@ -238,11 +231,6 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #pragma unroll
                     for (int qg = 0; qg < QG; qg++)
                         acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * KS + ks][qg], acc[rb][qg], 0, 0, 0);
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-                    for (int qg = 0; qg < QG; qg++)
-                        acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], blo[kc * KS + ks][qg], acc[rb][qg], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -306,20 +294,44 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             if (left < 64) mword &= (1ull << left) - 1ull;
             uint32_t tkey = kKeyMasked;
             u4 bits[4];
+            const float inv_q = qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag);
+            if (mword == ~0ull) {
+                // every row of the tile takes part (the common case): the tile maximum is taken on the scores themselves
+                // (v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its true key) and converted once
+                float m = -__builtin_inff();
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++) {
-                const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
-                f4 vn = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (METRIC == NMN_METRIC_COSINE)
-                    vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + rr);
+                for (int rb = 0; rb < 4; rb++) {
+                    f4 sc = fin[rb];
+                    if constexpr (METRIC == NMN_METRIC_COSINE) {
+                        // approximate score: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the margin
+                        // has 1000x that slack.  A zero norm gives rcp = +inf: forced to 0 like cosine_similarity does.
+                        const f4 vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + (uint32_t)rb * 16u + g * 4u);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
-                    float sc = fin[rb][e];
+                        for (int e = 0; e < 4; e++) sc[e] = vn[e] == 0.f ? 0.f : sc[e] * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        bits[rb][e] = f2u(sc[e]);
+                        m = __builtin_fmaxf(m, sc[e]);
+                    }
+                }
+                tkey = score_to_key(m);
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
+                    f4 vn = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (METRIC == NMN_METRIC_COSINE)
-                        sc = (vn[e] == 0.f || qmag == 0.f) ? 0.f : sc / (qmag * vn[e]);
-                    bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
-                    if (valid) tkey = max(tkey, score_to_key(sc));
+                        vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + rr);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
+                        float sc = fin[rb][e];
+                        if constexpr (METRIC == NMN_METRIC_COSINE)
+                            sc = vn[e] == 0.f ? 0.f : sc * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
+                        bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
+                        if (valid) tkey = max(tkey, score_to_key(sc));
+                    }
                 }
             }
             // tile maximum of query n: combine the four lane groups
