@@ -13,7 +13,10 @@ and merged on-device (strong scaling: total work per query is fixed).  `--scalin
 keeps 10M rows PER GPU (config 4: 80M rows on 8 GPUs).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (scan) algorithmic bytes / measured kernel time vs HBM peak
+  roofline      dominant kernel (scan) algorithmic bytes / measured kernel time vs HBM peak.  The approximate sweep reads
+                the shard's bf16 mirror (2 bytes per corpus element; the exact f32 rescore keeps the answer bit-equal), so
+                the algorithmic bytes per query are rows*dim*2 — reported by the library (bytes_scanned) and echoed as
+                bytes_per_corpus_element; NMN_NO_HALF=1 measures the sweep of the f32 corpus instead
   cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded
                 row sample of the same workload, extrapolated linearly to the full row count
   parity        the GPU result of the last timed query checked against the oracle / exact certificate
