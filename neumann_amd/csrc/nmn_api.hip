@@ -285,6 +285,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->half) (void)hipFree(idx->half);
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
+    if (idx->half_stats) (void)hipFree(idx->half_stats);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
     for (int i = 1; i < nmn_index::kHostSlots; i++)
@@ -429,7 +430,21 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         const bool mfma_shape = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
                                 getenv("NMN_NO_MFMA") == nullptr;
         bool use_half = n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
-                        (mfma_shape || getenv("NMN_NO_HALF") == nullptr);
+                        (mfma_shape || (getenv("NMN_NO_HALF") == nullptr && idx->half_calls >= idx->half_off_until));
+        if (!mfma_shape && idx->half_stats && (++idx->half_calls & 255u) == 0 && idx->half_calls >= idx->half_off_until) {
+            uint32_t now[2] = {0, 0};  // a plain read of two counters other streams may still be adding to: good enough
+            if (hipMemcpy(now, idx->half_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                const uint32_t total = now[0] - idx->half_seen[0], retried = now[1] - idx->half_seen[1];
+                idx->half_seen[0] = now[0];
+                idx->half_seen[1] = now[1];
+                if (total >= 64 && retried * 2 > total) {
+                    idx->half_off_until = idx->half_calls + 8192;
+                    use_half = false;
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         if (use_half) {
             if (!idx->half) {
                 hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half), (size_t)idx->cap_pad * idx->ld * 2);
@@ -442,6 +457,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                     idx->half_rows = 0;
                     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_err_bits), 8));
                     HIP_TRY(hipMemsetAsync(idx->half_err_bits, 0, 8, stream));
+                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_stats), 8));
+                    HIP_TRY(hipMemsetAsync(idx->half_stats, 0, 8, stream));
                     HIP_TRY(hipMemsetAsync(idx->half, 0, (size_t)idx->cap_pad * idx->ld * 2, stream));
                 }
             }
@@ -546,6 +563,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.skip_key = sp.skip_key;
             sel.k_extra = nullptr;
             sel.retry = 0;
+            sel.half_stats = f32_retry ? idx->half_stats : nullptr;
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
                 sel.k_extra = w->k_extra;

@@ -65,6 +65,13 @@ struct nmn_index {
     float* half = nullptr;       // bf16 mirror of `corpus` every approximate sweep reads (half the bytes); lazy
     uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current
     bool half_failed = false;    // allocation failed once: stay on the f32 sweep
+    // Mirror on/off switch: data whose rounding margin keeps overflowing the candidate capacity (a row of enormous norm
+    // under a Euclidean metric, ...) pays a bf16 pass AND an f32 retry per query.  select_kernel counts both in
+    // half_stats; every 256th search the host reads them and, if more than half of the recent queries were retried, leaves
+    // the mirror alone for the next 8192 searches.
+    uint32_t* half_stats = nullptr;     // device [2]
+    uint32_t half_seen[2] = {0, 0};     // counters at the last look
+    uint64_t half_calls = 0, half_off_until = 0;
     uint32_t* half_err_bits = nullptr;  // device [2]: max_r |e_r| and max_r |e_r|/|v_r| of the mirror's rounding (f32 bits)
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;

@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t nql = p.nql;
     if (p.retry && p.qstate[q].overflow == 0) return;  // block-uniform: this query's first selection stood
+    if (p.half_stats && tid == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
     auto score_bits = [&](uint64_t row) -> uint32_t { return p.scores[score_at(row, q, nql)]; };
     const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
     const uint32_t* wmax = p.wmax + (uint64_t)q * p.wmax_stride;

@@ -302,3 +302,26 @@ def test_bf16_pass_overflow_is_retried_in_f32():
             assert counts[0] == k and np.array_equal(rows[0], er) and np.all(scores[0] == es)
             assert stats.fallback_queries == 0, metric
             assert stats.bytes_scanned == n * d * 2          # the (first) sweep read the bf16 mirror
+
+
+def test_mirror_switches_itself_off_when_its_margin_is_useless():
+    """One row of enormous norm makes the mirror's Euclidean margin (2 max|e_r|) swallow every row: each query then pays
+    a bf16 pass plus the f32 retry.  After 256 searches the shard notices (select_kernel counts retries) and sweeps the
+    f32 corpus directly; answers are the oracle's throughout."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(123)
+    n, d, k = 270_000, 32, 20
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[1234] *= np.float32(1e6)
+    Q = rng.standard_normal((8, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        seen = set()
+        for i in range(300):
+            rows, scores, counts, stats = idx.search(Q[i % 8], k, 1, with_stats=True)
+            seen.add(stats.bytes_scanned // (n * d))
+            if i in (0, 100, 299):
+                er, es = oc.search(A, Q[i % 8], k, 1)
+                assert counts[0] == k and np.array_equal(rows[0], er) and np.all(scores[0] == es)
+                assert stats.fallback_queries == 0          # the retry, not the exact scan of everything
+        assert seen == {2, 4} and stats.bytes_scanned == n * d * 4
