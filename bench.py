@@ -395,6 +395,8 @@ def main():
                                    + (f", WHERE mask selectivity {args.mask}" if args.mask < 1.0 else ""),
                        "rows_total": total_rows, "rows_per_gpu": local_rows, "dim": args.dim, "k": args.k,
                        "nq": args.nq, "streams": n_streams,
+                       "approximate_sweep": ("bf16 mirror of the corpus, f32 accumulate" if elem_bytes == 2 else "f32 corpus")
+                                            + "; every candidate re-scored from the f32 corpus in the reference's order",
                        "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": traffic,
