@@ -14,6 +14,8 @@
 // Work split: 8 consecutive threads own one (query,row) pair, thread l runs accumulator lane l's
 // dependent chain; the 8 partial sums are then added left to right by every thread of the group
 // (shuffles inside the 8-lane group), so no reassociation ever happens.
+#include <algorithm>
+
 #include "nmn_internal.h"
 
 // Belt and braces: even if a build forgets -ffp-contract=off, nothing below may be contracted.
@@ -310,7 +312,11 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
 }
 
 hipError_t launch_rescore(const RescoreParams& p, hipStream_t s) {
-    dim3 grid(128, p.nq);  // 4096 candidates = one step; the fallback duty grid-strides over all rows
+    // 4096 candidates = one step of 128 workgroups.  The fallback duty grid-strides over all rows of the
+    // shard, so a launch with few queries still gets >= 2048 workgroups (the spare ones of the normal duty
+    // find c0 >= count and leave at once).
+    const uint32_t gx = std::max<uint32_t>(128u, (2048u + p.nq - 1) / p.nq);
+    dim3 grid(gx, p.nq);
     hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -362,34 +362,44 @@ static bool scan_nt_enabled() {
 // sweep of 1-4 queries reads THIS matrix: the result stays exact because the rounding (relative 2^-8 per element:
 // at most 2^-8 |q||v| on a dot product, at most 2^-8 |v| on a Euclidean distance) is added to the candidate margin
 // (qprep_kernel) and every candidate is re-scored from the f32 corpus.
-// row_err2[r - row0] accumulates |v - bf16(v)|^2 of row r (cleared by the caller): the candidate margins use the
+// row_err2[r - row0] = |v - bf16(v)|^2 of row r: the candidate margins use the
 // MEASURED rounding error of the mirror — max_r |e_r| and max_r |e_r| / |v_r| — which is rigorous like the worst case
 // 2^-8 |v| but about 2.5x smaller (the rounding error of a bf16 is uniform in +-half an ulp, not always the maximum).
+// `lpr` lanes (a power of two <= 64) share one row and fold their partial sums with shuffles: one plain store per
+// row (atomics per 8 elements made this kernel 8x slower than its traffic).
 __global__ void __launch_bounds__(256) half_rows_kernel(const float* __restrict__ corpus, float* __restrict__ half,
-                                                        uint32_t ld, uint64_t row0, uint64_t n, float* __restrict__ row_err2) {
+                                                        uint32_t ld, uint64_t row0, uint64_t n, float* __restrict__ row_err2,
+                                                        uint32_t lpr) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     const uint32_t per_row = ld >> 3;  // 8-element groups per row
-    const uint64_t total = n * per_row;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = row0 + i / per_row;
-        const uint32_t g = (uint32_t)(i % per_row);
-        const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
-        const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
-        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint32_t pk[4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & (lpr - 1u), slot = lane / lpr, rows_per_wave = 64u / lpr;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t rb = wave * rows_per_wave; rb < n; rb += n_waves * rows_per_wave) {
+        const uint64_t ri = rb + slot;
+        const bool live = ri < n;
+        const uint64_t r = row0 + (live ? ri : 0);
         float err2 = 0.f;
+        for (uint32_t g = sub; live && g < per_row; g += lpr) {
+            const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
+            const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t pk[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const f2 pr = {x[2 * t], x[2 * t + 1]};
-            pk[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf2));
-            const float e0 = x[2 * t] - __uint_as_float(pk[t] << 16), e1 = x[2 * t + 1] - __uint_as_float(pk[t] & 0xFFFF0000u);
-            err2 = __builtin_fmaf(e0, e0, err2);
-            err2 = __builtin_fmaf(e1, e1, err2);
+            for (int t = 0; t < 4; t++) {
+                const f2 pr = {x[2 * t], x[2 * t + 1]};
+                pk[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf2));
+                const float e0 = x[2 * t] - __uint_as_float(pk[t] << 16), e1 = x[2 * t + 1] - __uint_as_float(pk[t] & 0xFFFF0000u);
+                err2 = __builtin_fmaf(e0, e0, err2);
+                err2 = __builtin_fmaf(e1, e1, err2);
+            }
+            const v4f out = {__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
+            *reinterpret_cast<v4f*>(half + r * (ld >> 1) + g * 4u) = out;
         }
-        const v4f out = {__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
-        *reinterpret_cast<v4f*>(half + r * (ld >> 1) + g * 4u) = out;
-        if (err2 > 0.f) atomicAdd(row_err2 + (r - row0), err2);
+        for (uint32_t off = lpr >> 1; off > 0; off >>= 1) err2 += __shfl_xor(err2, (int)off);
+        if (live && sub == 0) row_err2[ri] = err2;
     }
 }
 
@@ -412,9 +422,9 @@ __global__ void __launch_bounds__(256) half_err_kernel(const float* __restrict__
 hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                             float* row_err2_scratch, uint32_t* err_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(row_err2_scratch, 0, n * sizeof(float), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(half_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, half, ld, row0, n, row_err2_scratch);
+    uint32_t lpr = 1;
+    while (lpr < 64u && lpr < (ld >> 3)) lpr <<= 1;
+    hipLaunchKernelGGL(half_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, half, ld, row0, n, row_err2_scratch, lpr);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(half_err_kernel, dim3(blocks), dim3(256), 0, s, row_err2_scratch, norms, row0, n, err_bits);
     return hipGetLastError();

@@ -415,56 +415,95 @@ hipError_t launch_select(const SelectParams& p, hipStream_t s) {
 // ties: a 64-bit radix select, 11+11+10 bits of score key, then (only if the ties at the k-th score
 // straddle it) 11+11+10 bits of ~row.  One workgroup walks all rows up to six times: slow by design,
 // this path only runs when more than cand_cap rows sit within the rounding margin of the k-th score.
+// One walk of a query's exact scores by the whole workgroup: thread t takes rows 4t..4t+3 of every chunk of
+// 4096 rows (one 16-byte load: the four rows sit together in the tile-major layout), four chunks in flight per
+// thread.  f(row, key) runs once per row slot in [0, round_up(n_pad, 4096)), key = kKeyMasked outside the shard
+// or the filter; every lane of every wave makes the same number of calls (wave_append inside f is legal).
+template <class F>
+__device__ __forceinline__ void walk_scores(const uint32_t* __restrict__ scores, uint32_t q, uint32_t nql,
+                                            uint64_t n_pad, F&& f) {
+    constexpr uint64_t kChunk = 4ull * kSelThreads;
+    const uint64_t t4 = 4ull * threadIdx.x;
+    uint64_t base = 0;
+    for (; base + 4 * kChunk <= n_pad; base += 4 * kChunk) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            v[u] = *reinterpret_cast<const uint4*>(scores + score_at(base + u * kChunk + t4, q, nql));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + u * kChunk + t4;
+            f(i, bits_to_key(v[u].x));
+            f(i + 1, bits_to_key(v[u].y));
+            f(i + 2, bits_to_key(v[u].z));
+            f(i + 3, bits_to_key(v[u].w));
+        }
+    }
+    for (; base < n_pad; base += kChunk) {
+        const uint64_t i = base + t4;
+        uint4 v = make_uint4(kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits);
+        if (i < n_pad) v = *reinterpret_cast<const uint4*>(scores + score_at(i, q, nql));  // n_pad % 64 == 0
+        f(i, bits_to_key(v.x));
+        f(i + 1, bits_to_key(v.y));
+        f(i + 2, bits_to_key(v.z));
+        f(i + 3, bits_to_key(v.w));
+    }
+}
+
 __device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint32_t q, uint32_t nql, uint64_t n_rows,
                                       uint32_t k,
                                       unsigned long long* list, uint32_t* hist, PickResult* pick,
                                       uint32_t* s_misc /* >= 2 words */) {
     const uint32_t tid = threadIdx.x;
     const uint64_t n_pad = (n_rows + 63) & ~63ull;
-    auto comp = [&](uint64_t i) -> unsigned long long {
-        const uint32_t key = i < n_pad ? bits_to_key(scores[score_at(i, q, nql)]) : kKeyMasked;
+    auto comp = [](uint64_t i, uint32_t key) -> unsigned long long {
         return key == kKeyMasked ? 0ull : (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i));
     };
     // digit layout over the 64-bit composite, most significant first
     const int shifts[6] = {53, 42, 32, 21, 10, 0};
     const int widths[6] = {11, 11, 10, 11, 11, 10};
     if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
-    __syncthreads();
-    uint32_t loc = 0;
-    for (uint64_t i = tid; i < n_pad; i += kSelThreads) loc += comp(i) != 0ull;
-    atomicAdd(&s_misc[0], loc);
-    __syncthreads();
-    const uint32_t total = s_misc[0];
-    uint32_t kk = min(k, total);
-    if (kk == 0) return 0;
     unsigned long long prefix = 0ull;  // digits fixed so far (high bits)
-    uint32_t need = kk;                // rank of the wanted composite among those matching the prefix
+    uint32_t need = 0;                 // rank of the wanted composite among those matching the prefix
+    uint32_t kk = 0;
     for (int d = 0; d < 6; d++) {
         const int nb = 1 << widths[d];
         for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
         __syncthreads();
         const int hi_shift = shifts[d] + widths[d];
-        for (uint64_t i = tid; i < n_pad; i += kSelThreads) {
-            const unsigned long long c = comp(i);
-            if (c == 0ull) continue;
-            if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) continue;
+        uint32_t loc = 0;
+        walk_scores(scores, q, nql, n_pad, [&](uint64_t i, uint32_t key) {
+            const unsigned long long c = comp(i, key);
+            if (c == 0ull) return;
+            loc++;
+            if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) return;
             atomicAdd(&hist[(uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1)], 1u);
+        });
+        if (d == 0) {  // the first walk also counts the participating rows
+            atomicAdd(&s_misc[0], loc);
+            __syncthreads();
+            kk = min(k, s_misc[0]);
+            if (kk == 0) return 0;
+            need = kk;
         }
         __syncthreads();
         pick_bin(hist, nb, need, pick);
         __syncthreads();
         prefix |= (unsigned long long)pick->bin << shifts[d];
         need -= pick->above;
+        // score key fixed and every row holding it is wanted: the row digits cannot change the cut
+        const bool done = d == 2 && hist[pick->bin] == need;
         __syncthreads();
+        if (done) break;
     }
-    // prefix is now the kk-th largest composite; collect everything >= it (exactly kk entries)
-    const uint64_t n_round = (n_pad + kSelThreads - 1) / kSelThreads * kSelThreads;
-    for (uint64_t i = tid; i < n_round; i += kSelThreads) {
-        const unsigned long long c = comp(i);
+    // prefix is now the kk-th largest composite (or the score key of the cut with zero row digits, which
+    // admits the same set); collect everything >= it (exactly kk entries)
+    walk_scores(scores, q, nql, n_pad, [&](uint64_t i, uint32_t key) {
+        const unsigned long long c = comp(i, key);
         const bool pred = c != 0ull && c >= prefix;
         const uint32_t pos = wave_append(pred, &s_misc[1]);
         if (pred && pos < NMN_MAX_TOP_K) list[pos] = c;
-    }
+    });
     __syncthreads();
     return min(s_misc[1], (uint32_t)NMN_MAX_TOP_K);
 }
