@@ -214,7 +214,7 @@ uint64_t nmn_engine_ivf_nprobe(const nmn_engine_ivf* ivf);
 const char* nmn_engine_ivf_key(const nmn_engine_ivf* ivf, uint64_t id);
 nmn_status nmn_engine_ivf_centroids(const nmn_engine_ivf* ivf, float* out, uint64_t cap_floats);
 nmn_status nmn_engine_ivf_cluster_sizes(nmn_engine_ivf* ivf, uint64_t* out);
-/* search_with_ivf (nprobe = 0) / search_with_ivf_nprobe (lib.rs:2708-2812): score = 1 / (1 + distance) */
+/* search_with_ivf (nprobe = 0) / search_with_ivf_nprobe (lib.rs:2731-2812): score = 1 / (1 + distance) */
 nmn_status nmn_engine_search_with_ivf(nmn_engine* e, nmn_engine_ivf* ivf, const float* q, uint64_t dim, uint64_t top_k,
                                       uint64_t nprobe, nmn_results** out);
 

@@ -1359,7 +1359,7 @@ nmn_status nmn_engine_ivf_cluster_sizes(nmn_engine_ivf* ivf, uint64_t* out) {
     return st == NMN_OK ? NMN_OK : err_gpu(st);
 }
 
-// search_with_ivf / search_with_ivf_nprobe (lib.rs:2708-2812); nprobe == 0 = the index's own
+// search_with_ivf / search_with_ivf_nprobe (lib.rs:2731-2812); nprobe == 0 = the index's own
 nmn_status nmn_engine_search_with_ivf(nmn_engine* e, nmn_engine_ivf* ivf, const float* q, uint64_t dim, uint64_t top_k,
                                       uint64_t nprobe, nmn_results** out) {
     if (!e || !ivf || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");

@@ -10,7 +10,7 @@ Follows (paths relative to the reference root):
   tensor_store/src/delta_vector.rs   KMeans::fit 737-777, init_random 781-800, init_kmeans_plusplus 805-853,
                                      nearest_centroid 856-863, update_centroids 867-893,
                                      euclidean_distance_sq 896-901
-  vector_engine/src/lib.rs           search_with_ivf 2708-2745 (score = 1/(1+distance))
+  vector_engine/src/lib.rs           search_with_ivf 2731-2766 (score = 1/(1+distance), 2762)
 
 Arithmetic: every distance is a strictly sequential f32 sum of (x-y)*(x-y) (iterator `.sum()`, which folds
 from -0.0); centroid means are sequential f32 sums divided by `count as f32`; the k-means++ threshold is
@@ -224,5 +224,5 @@ def _sort_key(x):
 
 
 def ivf_score(distance):
-    """search_with_ivf (lib.rs:2737-2741): score = 1.0 / (1.0 + distance), f32."""
+    """search_with_ivf (lib.rs:2762): score = 1.0 / (1.0 + distance), f32."""
     return F(F(1.0) / F(F(1.0) + F(distance)))
