@@ -285,6 +285,14 @@ nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t
                                   nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                   float* out_scores, uint32_t* out_counts, nmn_search_stats* stats);
 
+/* Request coalescing of the host-buffer searches (nmn_index_search / _dmask): callers that arrive while a search is
+ * running on the shard wait and leave together as ONE query batch (same metric and mask, <= 64 queries, k <= 4096),
+ * i.e. one corpus sweep instead of one each.  The reference serves concurrent `search_similar` calls of an
+ * `Arc<VectorEngine>` (query_router/src/lib.rs:710, 5615-5666) one scan per call; results here are the same per
+ * call whatever the batch.  Counters: batches that merged >= 2 calls, and the calls merged.  NMN_NO_COALESCE=1
+ * turns it off. */
+nmn_status nmn_index_coalesce_stats(nmn_index* idx, uint64_t* batches, uint64_t* requests);
+
 /* ---- IVF-Flat probe ------------------------------------------------------ */
 
 /* `tensor_store::ivf::IVFIndex` with `IVFStorage::Flat` (tensor_store/src/ivf.rs:160-406), searched on the

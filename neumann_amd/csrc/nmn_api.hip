@@ -50,35 +50,66 @@ nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, wh
     } while (0)
 
 // ---- host slots ------------------------------------------------------------------------------------
-// caller holds idx->mu through `lk`
-static nmn_status slot_acquire(nmn_index* idx, std::unique_lock<std::mutex>& lk, int* slot_out) {
-    for (;;) {
-        for (int i = 0; i < nmn_index::kHostSlots; i++) {
-            if (idx->slot_busy[i]) continue;
-            if (!idx->host_slots[i]) {
-                if (i == 0) idx->host_slots[0] = idx->host_stream;
-                else HIP_TRY(hipStreamCreateWithFlags(&idx->host_slots[i], hipStreamNonBlocking));
-            }
-            idx->slot_busy[i] = true;
-            idx->slots_busy++;
-            *slot_out = i;
-            return NMN_OK;
-        }
-        idx->cv.wait(lk);
+static bool coalesce_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("NMN_NO_COALESCE");
+        return !(e && e[0] && e[0] != '0');
+    }();
+    return on;
+}
+
+// Searches in flight before a new caller queues instead of starting its own.  A sweep over a large shard is
+// HBM-bound: two of them side by side each take twice as long, while a second QUERY in the same sweep is nearly
+// free, so callers queue behind ONE running batch and leave together in the next (1M x 768, 64 threads through the
+// engine: 4.1k -> 59k queries/s).  Small shards are latency-bound (a dozen launches, a few tens of microseconds):
+// two batches in flight keep the device busy while results are handed out (100k x 128: 17.7k -> 114k queries/s).
+// NMN_HOST_INFLIGHT overrides (1..kHostSlots).
+static int lead_limit(const nmn_index* idx) {
+    static const int forced = [] {
+        const char* e = getenv("NMN_HOST_INFLIGHT");
+        const int v = e ? atoi(e) : 0;
+        return v < 0 ? 0 : std::min(v, (int)nmn_index::kHostSlots);
+    }();
+    if (forced) return forced;
+    if (!coalesce_enabled()) return nmn_index::kHostSlots;
+    const uint64_t sweep_bytes = idx->rows * (uint64_t)idx->ld * 2ull;
+    return sweep_bytes >= (256ull << 20) ? 1 : 2;
+}
+
+// caller holds idx->mu and has checked slots_busy < kHostSlots
+static int slot_take(nmn_index* idx) {
+    for (int i = 0; i < nmn_index::kHostSlots; i++) {
+        if (idx->slot_busy[i]) continue;
+        idx->slot_busy[i] = true;
+        idx->slots_busy++;
+        return i;
+    }
+    return -1;
+}
+// caller holds idx->mu: hand free slots to the oldest waiting requests; each becomes the leader of a batch
+static void designate_leaders(nmn_index* idx) {
+    while (!idx->host_queue.empty() && idx->writers_waiting == 0 && idx->slots_busy < lead_limit(idx)) {
+        HostReq* r = idx->host_queue.front();
+        idx->host_queue.erase(idx->host_queue.begin());
+        r->slot = slot_take(idx);
+        std::lock_guard<std::mutex> g(r->m);
+        r->lead = true;
+        r->cv.notify_one();  // under r->m: the sleeper cannot return (and destroy *r) before this call is over
     }
 }
-static void slot_release(nmn_index* idx, int slot) {  // takes idx->mu itself
-    {
-        std::lock_guard<std::mutex> g(idx->mu);
-        idx->slot_busy[slot] = false;
-        idx->slots_busy--;
+// Before changing the shard (or using the host stream's workspace exclusively): no host-buffer search in flight and
+// none starting.  Declared right after the unique_lock on idx->mu, so it is destroyed while the lock is still held.
+struct IdleGuard {
+    nmn_index* idx;
+    IdleGuard(nmn_index* i, std::unique_lock<std::mutex>& lk) : idx(i) {
+        idx->writers_waiting++;
+        idx->cv.wait(lk, [&] { return idx->slots_busy == 0; });
     }
-    idx->cv.notify_all();
-}
-// before changing the shard (or using the host stream's workspace exclusively): no host-buffer search in flight
-static void wait_idle(nmn_index* idx, std::unique_lock<std::mutex>& lk) {
-    idx->cv.wait(lk, [&] { return idx->slots_busy == 0; });
-}
+    ~IdleGuard() {
+        idx->writers_waiting--;
+        designate_leaders(idx);
+    }
+};
 
 static void ws_free(Workspace* w) {
     if (!w) return;
@@ -342,7 +373,7 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
 extern "C" nmn_status nmn_index_upload(nmn_index* idx, const float* rows_host, uint64_t row0, uint64_t n) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     nmn_status st = upload_common(idx, rows_host, true, row0, n, idx->host_stream);
     if (st != NMN_OK) return st;
     HIP_TRY(hipStreamSynchronize(idx->host_stream));
@@ -353,7 +384,7 @@ extern "C" nmn_status nmn_index_upload_device(nmn_index* idx, const float* rows_
                                               void* stream) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     return upload_common(idx, rows_dev, false, row0, n, static_cast<hipStream_t>(stream));
 }
 
@@ -691,31 +722,39 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
     return stats_collect(idx, it == idx->ws.end() ? nullptr : it->second, stats);
 }
 
-nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
-                                    const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
-                                    uint32_t* out_counts, nmn_search_stats* stats) {
-    nmn_status st = check_search_args(idx, queries, nq, k, metric == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : (nmn_metric)metric,
-                                      out_rows, out_scores, out_counts);
-    if (st != NMN_OK) return st;
-    HIP_TRY(hipSetDevice(idx->device));
-    std::unique_lock<std::mutex> lk(idx->mu);
-    int slot = -1;
-    st = slot_acquire(idx, lk, &slot);
-    if (st != NMN_OK) return st;
-    struct SlotGuard {  // releases the slot on every exit path (it re-takes idx->mu: `lk` must be unlocked by then)
-        nmn_index* idx;
-        int slot;
-        std::unique_lock<std::mutex>* lk;
-        ~SlotGuard() {
-            if (lk->owns_lock()) lk->unlock();
-            slot_release(idx, slot);
-        }
-    } slot_guard{idx, slot, &lk};
+// ---- host-buffer searches: coalescing of concurrent callers into query batches ------------------------
+// requests that may share a batch: the candidate pipeline (k <= NMN_MAX_TOP_K), at most one sweep's worth of queries
+static bool mergeable(const HostReq& r) {
+    return coalesce_enabled() && r.k <= NMN_MAX_TOP_K && r.nq <= nmn_index::kCoalesceQueries;
+}
+// Same metric and same filter.  The filter is compared by address: two calls blocked in here with the same mask
+// pointer necessarily mean the same bits (a caller changing them under a running search races with its own call).
+static bool same_batch_key(const HostReq& a, const HostReq& b) {
+    return a.metric == b.metric && a.mask == b.mask && (a.mask == nullptr || a.mask_on_device == b.mask_on_device);
+}
+
+// One packed search for `reqs` (queries concatenated, k = the largest asked for) on host slot `slot`.
+// `lk` holds idx->mu on entry; it is released once everything is enqueued (may still be held on an error return).
+static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& lk, int slot, HostReq* const* reqs,
+                                  size_t n_reqs) {
+    if (!idx->host_slots[slot]) {
+        if (slot == 0) idx->host_slots[0] = idx->host_stream;
+        else HIP_TRY(hipStreamCreateWithFlags(&idx->host_slots[slot], hipStreamNonBlocking));
+    }
     hipStream_t s = idx->host_slots[slot];
+    uint32_t nq = 0, k = 0;
+    bool want_stats = false;
+    for (size_t i = 0; i < n_reqs; i++) {
+        nq += reqs[i]->nq;
+        k = std::max(k, reqs[i]->k);
+        want_stats |= reqs[i]->stats != nullptr;
+    }
+    const HostReq& first = *reqs[0];
     Workspace* w = nullptr;
-    st = ws_get(idx, s, nq, k, &w);
+    nmn_status st = ws_get(idx, s, nq, k, &w);
     if (st != NMN_OK) return st;
-    const size_t qn = (size_t)nq * idx->dim, on = (size_t)nq * k;
+    const size_t dim = idx->dim;
+    const size_t qn = (size_t)nq * dim, on = (size_t)nq * k;
     const size_t words = (size_t)((idx->rows + 63) / 64);
     // packed result block: rows (8-byte aligned) | scores | counts
     const size_t off_scores = on * sizeof(uint64_t), off_counts = off_scores + on * sizeof(float);
@@ -724,28 +763,137 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     HIP_TRY(grow(&w->h_pack, &w->h_pack_cap, pack_bytes));
     HIP_TRY(grow_pinned(&w->pin_in, &w->pin_in_cap, qn * sizeof(float)));
     HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes));
-    memcpy(w->pin_in, queries, qn * sizeof(float));
+    {
+        float* dst = reinterpret_cast<float*>(w->pin_in);
+        for (size_t i = 0; i < n_reqs; i++) {
+            memcpy(dst, reqs[i]->queries, (size_t)reqs[i]->nq * dim * sizeof(float));
+            dst += (size_t)reqs[i]->nq * dim;
+        }
+    }
     HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
     const uint64_t* mask_dev = nullptr;
-    if (mask && words && mask_on_device) {
-        mask_dev = mask;
-    } else if (mask && words) {
+    if (first.mask && words && first.mask_on_device) {
+        mask_dev = first.mask;
+    } else if (first.mask && words) {
         HIP_TRY(grow(&w->h_mask, &w->h_mask_cap, words));
-        HIP_TRY(hipMemcpyAsync(w->h_mask, mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->h_mask, first.mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         mask_dev = w->h_mask;
     }
     uint64_t* d_rows = reinterpret_cast<uint64_t*>(w->h_pack);
     float* d_scores = reinterpret_cast<float*>(w->h_pack + off_scores);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(w->h_pack + off_counts);
-    st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)metric, mask_dev, d_rows, d_scores, d_counts, s);
+    st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s);
     if (st != NMN_OK) return st;
     HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
     lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
     HIP_TRY(hipStreamSynchronize(s));
-    memcpy(out_rows, w->pin_out, on * sizeof(uint64_t));
-    memcpy(out_scores, w->pin_out + off_scores, on * sizeof(float));
-    memcpy(out_counts, w->pin_out + off_counts, (size_t)nq * sizeof(uint32_t));
-    return stats_collect(idx, w, stats);
+    // hand the results out: the first k_i of each query's k-list are that request's answer (same total order)
+    const uint64_t* h_rows = reinterpret_cast<const uint64_t*>(w->pin_out);
+    const float* h_scores = reinterpret_cast<const float*>(w->pin_out + off_scores);
+    const uint32_t* h_counts = reinterpret_cast<const uint32_t*>(w->pin_out + off_counts);
+    size_t q0 = 0;
+    for (size_t i = 0; i < n_reqs; i++) {
+        HostReq& r = *reqs[i];
+        for (uint32_t j = 0; j < r.nq; j++) {
+            memcpy(r.out_rows + (size_t)j * r.k, h_rows + (q0 + j) * k, (size_t)r.k * sizeof(uint64_t));
+            memcpy(r.out_scores + (size_t)j * r.k, h_scores + (q0 + j) * k, (size_t)r.k * sizeof(float));
+            r.out_counts[j] = std::min(h_counts[q0 + j], r.k);
+        }
+        q0 += r.nq;
+    }
+    if (want_stats) {
+        nmn_search_stats batch_stats;
+        st = stats_collect(idx, w, &batch_stats);
+        if (st != NMN_OK) return st;
+        for (size_t i = 0; i < n_reqs; i++)
+            if (reqs[i]->stats) *reqs[i]->stats = batch_stats;
+    }
+    return NMN_OK;
+}
+
+nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
+                                    const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
+                                    uint32_t* out_counts, nmn_search_stats* stats) {
+    nmn_status st = check_search_args(idx, queries, nq, k, metric == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : (nmn_metric)metric,
+                                      out_rows, out_scores, out_counts);
+    if (st != NMN_OK) return st;
+    HIP_TRY(hipSetDevice(idx->device));
+    HostReq me;
+    me.queries = queries;
+    me.nq = nq;
+    me.k = k;
+    me.metric = metric;
+    me.mask = mask;
+    me.mask_on_device = mask_on_device;
+    me.out_rows = out_rows;
+    me.out_scores = out_scores;
+    me.out_counts = out_counts;
+    me.stats = stats;
+    std::unique_lock<std::mutex> lk(idx->mu);
+    if (idx->host_queue.empty() && idx->writers_waiting == 0 && idx->slots_busy < lead_limit(idx)) {
+        me.slot = slot_take(idx);  // the shard can take another search right now: lead a batch of one
+    } else {
+        idx->host_queue.push_back(&me);
+        lk.unlock();
+        {
+            std::unique_lock<std::mutex> ml(me.m);
+            me.cv.wait(ml, [&] { return me.done || me.lead; });
+            if (me.done) {  // rode in somebody's batch
+                ml.unlock();
+                if (me.st != NMN_OK) return fail_arg(me.st, me.err.c_str());  // the leader's failure text, on this thread
+                return NMN_OK;
+            }
+        }
+        lk.lock();  // told to lead: already out of the queue, me.slot is ours
+    }
+    // lead a batch: this request plus every queued one that can share its sweep
+    std::vector<HostReq*> batch{&me};
+    if (mergeable(me)) {
+        uint32_t total = nq;
+        auto& qu = idx->host_queue;
+        for (auto it = qu.begin(); it != qu.end();) {
+            HostReq* r = *it;
+            if (mergeable(*r) && same_batch_key(me, *r) && total + r->nq <= nmn_index::kCoalesceQueries) {
+                total += r->nq;
+                batch.push_back(r);
+                it = qu.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    if (batch.size() > 1) {
+        idx->coalesced_batches++;
+        idx->coalesced_requests += batch.size();
+    }
+    const int slot = me.slot;
+    st = host_batch_body(idx, lk, slot, batch.data(), batch.size());
+    const std::string err = st == NMN_OK ? std::string() : std::string(nmn_last_error());
+    // wake the riders first (their results are in place), then pass the slot on
+    for (HostReq* r : batch) {
+        if (r == &me) continue;
+        std::lock_guard<std::mutex> g(r->m);
+        r->st = st;
+        r->err = err;
+        r->done = true;
+        r->cv.notify_one();  // under r->m, see designate_leaders
+    }
+    if (!lk.owns_lock()) lk.lock();
+    idx->slot_busy[slot] = false;
+    idx->slots_busy--;
+    designate_leaders(idx);
+    const bool idle = idx->slots_busy == 0;
+    lk.unlock();
+    if (idle) idx->cv.notify_all();  // writers waiting for the slots to drain
+    return st;
+}
+
+extern "C" nmn_status nmn_index_coalesce_stats(nmn_index* idx, uint64_t* batches, uint64_t* requests) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (batches) *batches = idx->coalesced_batches;
+    if (requests) *requests = idx->coalesced_requests;
+    return NMN_OK;
 }
 
 extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
@@ -768,7 +916,7 @@ extern "C" nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double
     if (idx->rows == 0) return NMN_OK;
     HIP_TRY(hipSetDevice(idx->device));
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     hipStream_t s = idx->host_stream;
     float* sink = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sink), 4));
@@ -804,7 +952,7 @@ extern "C" nmn_status nmn_index_score_rows(nmn_index* idx, const float* queries,
         if (local_rows[i] >= idx->rows) return fail_arg(NMN_ERR_NOT_FOUND, "row out of range");
     HIP_TRY(hipSetDevice(idx->device));
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     hipStream_t s = idx->host_stream;
     // private small buffers: nq may exceed the per-pass query count of the search workspace
     float *dq = nullptr, *dqpad = nullptr, *dout = nullptr;
@@ -841,7 +989,7 @@ extern "C" nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, 
     if (!idx || !query || !n_greater || !n_equal) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(idx->device));
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     hipStream_t s = idx->host_stream;
     Workspace* w = nullptr;
     nmn_status st = ws_get(idx, s, 1, 1, &w);
@@ -965,7 +1113,7 @@ extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, ui
     if (n == 0) return NMN_OK;
     HIP_TRY(hipSetDevice(idx->device));
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     hipStream_t s = idx->host_stream;
     HIP_TRY(launch_synth_fill(idx->corpus, idx->ld, idx->dim, seed, idx->row_base + row0, row0, n, s));
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, s));
@@ -980,7 +1128,7 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
     if (row >= idx->rows) return fail_arg(NMN_ERR_NOT_FOUND, "row out of range");
     HIP_TRY(hipSetDevice(idx->device));
     std::unique_lock<std::mutex> lk(idx->mu);
-    wait_idle(idx, lk);
+    IdleGuard idle(idx, lk);
     hipStream_t s = idx->host_stream;
     HIP_TRY(hipMemcpyAsync(idx->corpus + row * (uint64_t)idx->ld, vec_host, (size_t)idx->dim * 4,
                            hipMemcpyHostToDevice, s));

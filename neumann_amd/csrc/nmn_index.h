@@ -3,7 +3,9 @@
 #pragma once
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "nmn_internal.h"
 
@@ -56,6 +58,26 @@ struct Workspace {
     bool last_masked = false;
 };
 
+// one host-buffer search call waiting for, or riding in, a batch (lives on its caller's stack)
+struct HostReq {
+    const float* queries;
+    uint32_t nq, k;
+    int metric;
+    const uint64_t* mask;
+    bool mask_on_device;
+    uint64_t* out_rows;
+    float* out_scores;
+    uint32_t* out_counts;
+    nmn_search_stats* stats;
+    nmn_status st = NMN_OK;
+    std::string err;  // text of a failure, for the caller's thread-local nmn_last_error
+    int slot = -1;    // host slot handed to this request when it is told to lead a batch
+    // its caller sleeps on `cv` until the request is done (rode in somebody's batch) or told to lead the next one
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, lead = false;  // guarded by m
+};
+
 struct nmn_index {
     uint32_t dim = 0, ld = 0;
     uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
@@ -87,6 +109,15 @@ struct nmn_index {
     bool slot_busy[kHostSlots] = {false, false, false, false};
     int slots_busy = 0;
     std::condition_variable cv;
+    // Request coalescing: host-buffer searches that arrive while the shard is busy wait in `host_queue`; when a slot
+    // frees, the oldest waiter is woken to lead: it runs ITS request together with every queued one of the same
+    // (metric, mask) as one query batch — one corpus sweep for up to kCoalesceQueries queries instead of one sweep
+    // each — and hands the results out (each rider is woken on its own condition variable: no thundering herd).
+    // Results do not depend on the batch (exact rescore), so callers cannot tell, except by the clock.
+    static constexpr uint32_t kCoalesceQueries = 64;
+    std::vector<HostReq*> host_queue;   // arrival order
+    int writers_waiting = 0;            // uploads etc. waiting for the slots to drain: no new batch starts meanwhile
+    uint64_t coalesced_batches = 0, coalesced_requests = 0;  // batches of >= 2 requests, and the requests in them
 };
 
 namespace nmn {

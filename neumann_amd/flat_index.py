@@ -189,6 +189,12 @@ class GpuFlatIndex:
         _capi.check(self._lib.nmn_index_read_probe(self._h, int(reps), C.byref(out)))
         return float(out.value)
 
+    def coalesce_stats(self):
+        """(batches that merged >= 2 concurrent host-buffer searches, searches merged)."""
+        b, r = C.c_uint64(), C.c_uint64()
+        _capi.check(self._lib.nmn_index_coalesce_stats(self._h, C.byref(b), C.byref(r)))
+        return b.value, r.value
+
     def count_exact(self, query, score, metric=DistanceMetric.Cosine, mask=None):
         """(#rows with exact score > score, #rows with exact score == score) — a full exact pass."""
         q = _f32(query).reshape(-1)

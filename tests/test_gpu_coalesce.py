@@ -1,0 +1,110 @@
+"""Concurrent host-buffer searches (`Arc<VectorEngine>` shared by many threads, query_router/src/lib.rs:710,
+5615-5666): the shim merges callers that arrive while the shard is busy into one query batch.  Every caller must
+get exactly what it gets alone — here: what the oracle says — whatever batch it rode in."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _hammer(idx, jobs, n_threads):
+    """jobs: list of (query, k, metric, mask); every thread walks its share; returns results in job order."""
+    out = [None] * len(jobs)
+    errs = []
+    start = threading.Barrier(n_threads)
+
+    def work(t):
+        try:
+            start.wait()
+            for j in range(t, len(jobs), n_threads):
+                q, k, metric, mask = jobs[j]
+                out[j] = idx.search(q, k, metric, mask=mask)
+        except Exception as e:  # noqa: BLE001 - reported below
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("n,d,threads", [(20_000, 128, 32), (300_000, 512, 24)])  # two / one batches in flight
+def test_concurrent_callers_get_their_own_exact_answers(n, d, threads):
+    from neumann_amd import GpuFlatIndex
+    A = oc.synth(91, 0, n, d)
+    rng = np.random.default_rng(3)
+    mask = rng.integers(0, 2**64, size=(n + 63) // 64, dtype=np.uint64)
+    jobs = []
+    for j in range(threads * 6):
+        q = oc.synth(92, j, 1, d)[0]
+        metric = (0, 0, 2, 1)[j % 4]                    # mostly the metrics that share the MFMA sweep
+        k = (1, 10, 100, 37, 250)[j % 5]
+        jobs.append((q, k, metric, mask if j % 7 == 3 else None))
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        got = _hammer(idx, jobs, threads)
+        batches, merged = idx.coalesce_stats()
+        assert batches > 0 and merged >= 2 * batches, (batches, merged)
+        # every 8th job against the oracle (the oracle is slow), all of them against a single-threaded run
+        for j, (q, k, metric, m) in enumerate(jobs):
+            rows, scores, counts = got[j]
+            r1, s1, c1 = idx.search(q, k, metric, mask=m)
+            assert counts[0] == c1[0]
+            assert np.array_equal(rows, r1) and np.array_equal(scores.view(np.uint32), s1.view(np.uint32)), j
+            if j % 8 == 0:
+                er, es = oc.search(A, q, k, metric, mask=m)
+                c = er.size
+                assert counts[0] == c
+                assert np.array_equal(rows[0, :c], er) and np.all(scores[0, :c] == es)
+                assert np.all(rows[0, c:] == U64_MAX)
+
+
+def test_multi_query_calls_merge_too():
+    from neumann_amd import GpuFlatIndex
+    n, d = 50_000, 256
+    A = oc.synth(93, 0, n, d)
+    jobs = [(oc.synth(94, 3 * j, 3, d), 20 + j % 3, 0, None) for j in range(64)]
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        got = _hammer(idx, jobs, 16)
+        for j, (Q, k, metric, _) in enumerate(jobs):
+            rows, scores, counts = got[j]
+            r1, s1, c1 = idx.search(Q, k, metric)
+            assert np.array_equal(rows, r1) and np.array_equal(scores.view(np.uint32), s1.view(np.uint32))
+            assert np.array_equal(counts, c1)
+        er, es = oc.search(A, jobs[5][0][1], jobs[5][1], 0)
+        assert np.array_equal(got[5][0][1, :er.size], er) and np.all(got[5][1][1, :er.size] == es)
+
+
+def test_an_invalid_call_does_not_poison_its_neighbours():
+    from neumann_amd import GpuFlatIndex, _capi
+    n, d = 10_000, 64
+    A = oc.synth(95, 0, n, d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        good = [(oc.synth(96, j, 1, d)[0], 5, 0, None) for j in range(40)]
+        bad_seen = []
+
+        def bad():
+            for _ in range(20):
+                try:
+                    idx.search(np.zeros(d, np.float32), 0, 0)   # k == 0: rejected before it can join a batch
+                except _capi.NeumannGpuError as e:
+                    bad_seen.append(e.status)
+
+        t = threading.Thread(target=bad)
+        t.start()
+        got = _hammer(idx, good, 8)
+        t.join()
+        assert bad_seen and all(c == _capi.ERR_INVALID_TOP_K for c in bad_seen)
+        for j, (q, k, metric, _) in enumerate(good):
+            er, es = oc.search(A, q, k, metric)
+            assert np.array_equal(got[j][0][0, :er.size], er) and np.all(got[j][1][0, :er.size] == es)
