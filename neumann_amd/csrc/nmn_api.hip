@@ -3,6 +3,7 @@
 // kernel lives in nmn_scan/nmn_select/nmn_exact/nmn_synth.hip.  No CPU compute path exists here:
 // without a HIP device every entry point fails with NMN_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -74,6 +75,20 @@ static int lead_limit(const nmn_index* idx) {
     if (!coalesce_enabled()) return nmn_index::kHostSlots;
     const uint64_t sweep_bytes = idx->rows * (uint64_t)idx->ld * 2ull;
     return sweep_bytes >= (256ull << 20) ? 1 : 2;
+}
+
+// How long a batch leader waits for the callers of the previous batch to come back (see last_batch_requests): a
+// fraction of the sweep it is about to pay for everybody, only on shards whose sweep is long enough to be worth
+// sharing (those that run one batch at a time).  NMN_GATHER_US overrides (0 = never wait).
+static uint32_t gather_window_us(const nmn_index* idx) {
+    static const int forced = [] {
+        const char* e = getenv("NMN_GATHER_US");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) return (uint32_t)forced;
+    if (!coalesce_enabled() || lead_limit(idx) != 1) return 0;
+    const double sweep_us = (double)idx->rows * idx->ld * 2.0 / 5.0e6;  // bytes / (5 TB/s) in microseconds
+    return (uint32_t)std::min(200.0, std::max(30.0, 0.08 * sweep_us));
 }
 
 // caller holds idx->mu and has checked slots_busy < kHostSlots
@@ -438,6 +453,20 @@ static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* quer
     return NMN_OK;
 }
 
+// Smallest batch that takes the matrix-core sweep.  Its time does not depend on the number of queries (<= 64) while the
+// VALU sweep slows with every query it adds: measured crossover at 3 queries for rows of >= 768 dimensions (10M x 768:
+// 3.00 vs 2.69 ms; 5M x 1536: 2.55 vs 2.33 ms), at 5 (= a second VALU sweep) for short rows (10M x 128: 1.30 vs
+// 1.62 ms at 3 queries).  NMN_MFMA_MIN_NQ overrides, for measurements.
+static uint32_t mfma_min_queries(const nmn_index* idx) {
+    static const uint32_t forced = [] {
+        const char* e = getenv("NMN_MFMA_MIN_NQ");
+        const int x = e ? atoi(e) : 0;
+        return (uint32_t)(x >= 1 ? x : 0);
+    }();
+    if (forced) return forced;
+    return idx->dim >= 768 ? 3u : 5u;
+}
+
 static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* queries_dev, uint32_t nq, uint32_t k,
                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                  float* out_scores, uint32_t* out_counts, hipStream_t stream) {
@@ -455,10 +484,10 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
         // The approximate sweep reads the shard's bf16 MIRROR (half the bytes of the f32 corpus; its measured rounding
-        // error is part of the candidate margin): >= 5 queries of a cosine / dot batch go through the matrix cores (one
+        // error is part of the candidate margin): >= 3-5 queries of a cosine / dot batch go through the matrix cores (one
         // sweep per 64 or 32 queries), everything else through the VALU sweep (4 queries per sweep).  The mirror is
         // allocated and filled on first use and extended when rows were uploaded since.
-        const bool mfma_shape = nqc >= 5 && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
+        const bool mfma_shape = nqc >= mfma_min_queries(idx) && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
                                 getenv("NMN_NO_MFMA") == nullptr;
         bool use_half = n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
                         (mfma_shape || (getenv("NMN_NO_HALF") == nullptr && idx->half_calls >= idx->half_off_until));
@@ -834,7 +863,9 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
         me.slot = slot_take(idx);  // the shard can take another search right now: lead a batch of one
     } else {
         idx->host_queue.push_back(&me);
+        const bool tell = idx->gathering > 0;
         lk.unlock();
+        if (tell) idx->gather_cv.notify_all();
         {
             std::unique_lock<std::mutex> ml(me.m);
             me.cv.wait(ml, [&] { return me.done || me.lead; });
@@ -849,6 +880,17 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     // lead a batch: this request plus every queued one that can share its sweep
     std::vector<HostReq*> batch{&me};
     if (mergeable(me)) {
+        const uint32_t gather_us = gather_window_us(idx);
+        if (gather_us && idx->last_batch_requests > 1) {
+            // 3/4 of the previous batch is "everybody is back" (the rest may have left for good)
+            const size_t want = (size_t)idx->last_batch_requests - idx->last_batch_requests / 4;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us);
+            idx->gathering++;
+            while (1 + idx->host_queue.size() < want &&
+                   idx->gather_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+            }
+            idx->gathering--;
+        }
         uint32_t total = nq;
         auto& qu = idx->host_queue;
         for (auto it = qu.begin(); it != qu.end();) {
@@ -862,6 +904,7 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
             }
         }
     }
+    idx->last_batch_requests = (uint32_t)batch.size();
     if (batch.size() > 1) {
         idx->coalesced_batches++;
         idx->coalesced_requests += batch.size();

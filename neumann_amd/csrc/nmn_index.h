@@ -116,6 +116,11 @@ struct nmn_index {
     // Results do not depend on the batch (exact rescore), so callers cannot tell, except by the clock.
     static constexpr uint32_t kCoalesceQueries = 64;
     std::vector<HostReq*> host_queue;   // arrival order
+    // A leader that finds fewer waiters than the previous batch carried gives the stragglers (callers of that batch still
+    // waking up and coming back) a moment to arrive, instead of sweeping the shard for itself alone.
+    uint32_t last_batch_requests = 0;
+    int gathering = 0;                  // leaders inside their gather window (arrivals then signal gather_cv)
+    std::condition_variable gather_cv;
     int writers_waiting = 0;            // uploads etc. waiting for the slots to drain: no new batch starts meanwhile
     uint64_t coalesced_batches = 0, coalesced_requests = 0;  // batches of >= 2 requests, and the requests in them
 };
