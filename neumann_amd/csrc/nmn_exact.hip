@@ -247,7 +247,23 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         } else {
             qi.margin_abs = 0.0f;
             qi.margin_rel = 4.0f * (dd + 8.0f) * u;
-            if (mfma_pass & 2) {
+            if ((mfma_pass & 1) && metric == NMN_METRIC_EUCLIDEAN) {
+                // Matrix-core sweep: d~^2 = |q|^2 + |v|^2 - 2 q~.v~ with bf16 q~ = q + e_q, v~ = v + e_r.  Absolute
+                // error of d~^2 (A):
+                //   2 |q~.v~ - q.v|  <= 2 (|q||e_r| + |e_q||v| + |e_q||e_r|) <= 2 |q| (E + rho_q (V + E))
+                //                       E = max_r |e_r| and rho_q = |e_q|/|q| measured, V = max_r |v_r|;
+                //   f32 accumulation of the products (any order): 2 * 3 (d + 10) u |q| V  (the bound the cosine / dot
+                //   matrix-core margins use); |v|^2 and |q|^2 from reference-order magnitudes: (d + 10) u (V^2 + |q|^2);
+                //   the three roundings of the final expression: 3 u (|q| + V)^2.
+                // Applied twice (see above) in squared-distance space by margin_key: pad = -2 A.
+                const float V = u2f(*max_norm_bits);
+                const float E = half_err_bits ? u2f(half_err_bits[0]) : 3.95e-03f * V;
+                const float rho_q = qmag > 0.0f ? __builtin_sqrtf(qerr2) * 1.0005f / qmag : 0.0f;
+                const float a_round = 2.0f * qmag * (E + rho_q * (V + E));
+                const float a_fp = (dd + 10.0f) * u * (6.0f * qmag * V + V * V + qmag * qmag) + 3.0f * u * (qmag + V) * (qmag + V);
+                qi.pad = -2.0f * 1.001f * (a_round + a_fp);
+                qi.margin_rel = 16.0f * u;  // v_sqrt, v_rcp and the arithmetic of margin_key itself
+            } else if (mfma_pass & 2) {
                 // bf16 mirror under a Euclidean metric: v~ = v + e_r, so by the triangle inequality
                 // |d(q, v~) - d(q, v)| <= |e_r| <= max_r |e_r| =: D, an ABSOLUTE error on the distance (twice, as above)
                 const float two_d = half_abs;

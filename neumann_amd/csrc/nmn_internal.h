@@ -33,7 +33,8 @@ struct QInfo {
     float qmag;        // simd::magnitude(query), reference order
     float margin_abs;  // candidates: approx >= tau - margin_abs - |tau|*margin_rel
     float margin_rel;
-    float pad;         // bf16-mirror sweep under the Euclidean score: two-sided absolute error of the distance (else 0)
+    float pad;         // Euclidean score over the bf16 mirror: > 0 two-sided absolute error of the distance (VALU sweep);
+                       // < 0 minus the two-sided absolute error of the SQUARED distance (matrix-core sweep); else 0
 };
 
 // Per-query selection state shared by select / fallback / rescore / final.

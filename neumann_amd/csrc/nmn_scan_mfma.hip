@@ -115,6 +115,14 @@ __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
 // sums of a tile meet once per tile through LDS; wave w then finishes query group w.
 // QG = query groups of 16 kept stationary (4: 64 queries per sweep, 2: 32).  Waves 0..QG-1 finish one group each.
 // KC = stages per row (ld / (128*KS)), KS = k-steps per wave and stage.
+// Euclidean score from the matrix-core dot product: |q - v|^2 = |q|^2 + |v|^2 - 2 q.v, score = 1 / (1 + sqrt(.)).
+// The cancellation makes the ABSOLUTE error of the squared distance the quantity the margin bounds (qprep_kernel:
+// QInfo.pad < 0); a slightly negative result of the subtraction is a distance of zero.  v_sqrt / v_rcp: 1 ulp each.
+__device__ __forceinline__ float l2_score(float qq, float vn, float dot) {
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, __builtin_fmaf(vn, vn, qq)), 0.0f);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(d2));
+}
+
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX>
 __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     constexpr int kStageElems = 128 * KS;                        // elements of a row per stage
@@ -123,6 +131,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     constexpr int kRing = kRingBytes / kStageBytes;              // 8 / 4 stages (all but one in flight)
     constexpr int kPieces = 4 * KS;                              // 1-KiB DMA instructions per wave and stage
     constexpr uint32_t LR = 16 * KS;                             // lanes (16-B chunks) per row of a stage
+    constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_EUCLIDEAN;  // |v| of the tile's rows
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | exchange | norms
     float* xch = lds + kRingBytes / 4;                           // [4 src waves][64 lanes][4 rb] f4, reused per round
     float* nrm = xch + 4 * 64 * 16;                              // [kMaxRing tiles][64] row magnitudes (with one-stage
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #pragma unroll
     for (uint32_t s0 = 0; s0 < kRing - 1; s0++) {
         if (s0 < n_stage) {
-            if (METRIC == NMN_METRIC_COSINE && wave == 0 && s0 % KC == 0)
+            if (kNeedNorms && wave == 0 && s0 % KC == 0)
                 norms_dma(p.norms, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kRing) * 64u, lane);
             stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         }
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 const uint32_t ns = sidx + (kRing - 1);
                 if (ns < n_stage) {
                     const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
-                    if (METRIC == NMN_METRIC_COSINE && wave == 0 && nkc == 0)
+                    if (kNeedNorms && wave == 0 && nkc == 0)
                         norms_dma(p.norms, (uint64_t)nt * tstep, nrm + ((nt - t0) % kRing) * 64u, lane);
                     stage_dma<AUX, kPieces>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
                 }
@@ -295,6 +304,9 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             uint32_t tkey = kKeyMasked;
             u4 bits[4];
             const float inv_q = qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag);
+            const float qq = qmag * qmag;
+            (void)inv_q;
+            (void)qq;
             if (mword == ~0ull) {
                 // every row of the tile takes part (the common case): the tile maximum is taken on the scores themselves
                 // (v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its true key) and converted once
@@ -309,6 +321,11 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) sc[e] = vn[e] == 0.f ? 0.f : sc[e] * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
                     }
+                    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                        const f4 vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + (uint32_t)rb * 16u + g * 4u);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) sc[e] = l2_score(qq, vn[e], sc[e]);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         bits[rb][e] = f2u(sc[e]);
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 for (int rb = 0; rb < 4; rb++) {
                     const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
                     f4 vn = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (METRIC == NMN_METRIC_COSINE)
+                    if constexpr (kNeedNorms)
                         vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + rr);
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -329,6 +346,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                         float sc = fin[rb][e];
                         if constexpr (METRIC == NMN_METRIC_COSINE)
                             sc = vn[e] == 0.f ? 0.f : sc * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
+                        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_score(qq, vn[e], sc);
                         bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
                         if (valid) tkey = max(tkey, score_to_key(sc));
                     }
@@ -388,10 +406,12 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
     }
 }
 
-// Can the MFMA sweep serve this shape?  Cosine / dot, row length a multiple of 128 floats: up to 768 with 64
+// Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768 with 64
 // stationary queries per sweep, 1024 / 1280 / 1536 with 32 (the stationary B-fragments must fit 192 VGPRs).
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
-    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT) || ld != dim || ld % kStageK != 0) return false;
+    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN) || ld != dim ||
+        ld % kStageK != 0)
+        return false;
     const uint32_t kc = ld / kStageK;
     return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12;
 }
@@ -401,8 +421,11 @@ uint32_t scan_mfma_queries_per_sweep(uint32_t ld) { return ld / kStageK <= 6 ? 6
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
-    return p.metric == NMN_METRIC_COSINE ? launch_metric<NMN_METRIC_COSINE>(p, s)
-                                         : launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+    switch (p.metric) {
+        case NMN_METRIC_COSINE: return launch_metric<NMN_METRIC_COSINE>(p, s);
+        case NMN_METRIC_EUCLIDEAN: return launch_metric<NMN_METRIC_EUCLIDEAN>(p, s);
+        default: return launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+    }
 }
 
 }  // namespace nmn

@@ -1,5 +1,6 @@
-"""Batched queries (config 3): the MFMA sweep (>= 5 queries, cosine/dot, dim % 128 == 0) and the VALU
-multi-sweep path must both return exactly the oracle's rows and scores for every query."""
+"""Batched queries (config 3): the MFMA sweep (>= 3-5 queries, dim % 128 == 0; cosine / dot directly, Euclidean as
+|q|^2 + |v|^2 - 2 q.v) and the VALU multi-sweep path must both return exactly the oracle's rows and scores for
+every query."""
 import numpy as np
 import pytest
 
@@ -21,7 +22,7 @@ def check_batch(idx, A, Q, k, metric, mask=None):
     return st
 
 
-@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("n,d,nq,k", [(20000, 768, 64, 100), (20000, 768, 5, 10), (9000, 128, 16, 20),
                                       (30000, 256, 70, 50), (4000, 384, 33, 7), (70000, 512, 64, 100),
                                       (100, 640, 8, 200),
@@ -56,18 +57,39 @@ def test_mfma_batch_with_planted_near_ties_and_duplicates():
     A[5000:5010] = A[4999]                       # exact duplicates
     with GpuFlatIndex(d, n) as idx:
         idx.upload(A)
-        for metric in (0, 2):
+        for metric in (0, 1, 2):
             check_batch(idx, A, Q, k, metric)
 
 
-def test_euclidean_batches_use_valu_sweeps():
+def test_euclidean_batches_on_rows_the_matrix_core_sweep_cannot_take():
     from neumann_amd import GpuFlatIndex
-    n, d, nq, k = 15000, 256, 11, 30
+    n, d, nq, k = 15000, 200, 11, 30             # 200 is not a multiple of 128: four queries per VALU sweep
     A = oc.synth(77, 0, n, d)
     Q = oc.synth(78, 0, nq, d)
     with GpuFlatIndex(d, n) as idx:
         idx.fill_synthetic(77, n)
         check_batch(idx, A, Q, k, 1)
+
+
+def test_euclidean_matrix_core_sweep_near_the_query():
+    """The cancellation regime of |q|^2 + |v|^2 - 2 q.v: rows a hair away from the queries (distances ~1e-3 against
+    norms ~28), exact copies (distance 0), a zero query and rows of very different norms in one shard."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(8)
+    n, d, nq, k = 30000, 768, 12, 40
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[:3000] *= 0.01
+    A[3000:6000] *= 30.0
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[0] = 0.0
+    for qi in range(1, 6):
+        for j in range(25):
+            A[rng.integers(6000, n)] = Q[qi] + (1e-3 * (j + 1)) * rng.standard_normal(d).astype(np.float32) / np.float32(np.sqrt(d))
+        A[rng.integers(6000, n)] = Q[qi]
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        check_batch(idx, A, Q, k, 1)
+        check_batch(idx, A, Q, k, 1, mask=oc.mask_from_bool(rng.random(n) < 0.5))
 
 
 def test_batch_matches_single_query_calls():
@@ -93,7 +115,7 @@ def test_mfma_sampling_pass_large_shard():
     Q[3] = A[1_234_567]
     with GpuFlatIndex(d, n) as idx:
         idx.fill_synthetic(4242, n)
-        for metric in (0, 2):
+        for metric in (0, 1, 2):
             rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
             assert st.fallback_queries == 0
             for qi in range(nq):
