@@ -348,13 +348,13 @@ def main():
     idx.set_timing(False)
     fence()
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
-    # corpus sweeps per step: 64 (dim <= 768) or 32 (1024/1280/1536) queries per sweep on the MFMA path (>= 3
+    # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3
     # queries at dim >= 768, else >= 5; cosine/dot), else 4 (VALU) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
     kc = args.dim // 128
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and args.dim % 128 == 0 and (kc <= 6 or kc in (8, 10, 12))
             and args.k <= 4096)
-    per_sweep = 64 if kc <= 6 else 32  # stationary queries of the MFMA sweep (scan_mfma_queries_per_sweep)
+    per_sweep = 64  # stationary queries of the MFMA sweep (scan_mfma_queries_per_sweep)
     passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch

@@ -485,7 +485,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
         // The approximate sweep reads the shard's bf16 MIRROR (half the bytes of the f32 corpus; its measured rounding
         // error is part of the candidate margin): >= 3-5 queries of a cosine / dot batch go through the matrix cores (one
-        // sweep per 64 or 32 queries), everything else through the VALU sweep (4 queries per sweep).  The mirror is
+        // sweep per 64 queries; Euclidean too), everything else through the VALU sweep (4 queries per sweep).  The mirror is
         // allocated and filled on first use and extended when rows were uploaded since.
         const bool mfma_shape = nqc >= mfma_min_queries(idx) && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
                                 getenv("NMN_NO_MFMA") == nullptr;

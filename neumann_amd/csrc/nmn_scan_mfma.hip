@@ -25,10 +25,10 @@
 //     one row per lane: exactly the A fragment), two MFMAs per row block and query group;
 //   * epilogue per tile: the four K-quarter partial sums meet through LDS, then scores (float4 per lane),
 //     per-(query,tile) maxima, per-(query,workgroup) maxima — the hierarchy select_kernel consumes.
-// Rows longer than 768 floats (up to 1536) keep HALF the queries stationary (QG = 2 groups of 16: the
-// B-fragments still cost 192 VGPRs) and sweep the corpus once per 32 queries.
-// Cosine and dot product only: the Euclidean score needs |x-q|^2, whose expansion cancels
-// catastrophically for near neighbours; Euclidean batches use the VALU kernel (4 queries per sweep).
+// Rows of 1024 / 1280 / 1536 floats keep the same 64 queries stationary (192 VGPRs of bf16 B-fragments at 1536).
+// Euclidean batches ride the same sweep: |q - v|^2 = |q|^2 + |v|^2 - 2 q.v from the dot product and the stored row
+// magnitudes.  The expansion cancels for near neighbours, so its error is bounded in SQUARED-distance space
+// (qprep_kernel: QInfo.pad < 0, applied by margin_key) and every candidate is re-scored exactly as always.
 #include "nmn_internal.h"
 
 namespace nmn {
@@ -399,15 +399,15 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
         case 4: return launch_kc<2, 2, 4, METRIC>(p, s);   // 512
         case 5: return launch_kc<5, 1, 4, METRIC>(p, s);   // 640
         case 6: return launch_kc<3, 2, 4, METRIC>(p, s);   // 768
-        case 8: return launch_kc<4, 2, 2, METRIC>(p, s);   // 1024: 32 stationary queries
-        case 10: return launch_kc<5, 2, 2, METRIC>(p, s);  // 1280
-        case 12: return launch_kc<6, 2, 2, METRIC>(p, s);  // 1536
+        case 8: return launch_kc<4, 2, 4, METRIC>(p, s);   // 1024
+        case 10: return launch_kc<5, 2, 4, METRIC>(p, s);  // 1280
+        case 12: return launch_kc<6, 2, 4, METRIC>(p, s);  // 1536
         default: return hipErrorInvalidValue;
     }
 }
 
-// Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768 with 64
-// stationary queries per sweep, 1024 / 1280 / 1536 with 32 (the stationary B-fragments must fit 192 VGPRs).
+// Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768, or 1024 / 1280 /
+// 1536; 64 stationary queries per sweep (their bf16 B-fragments take up to 192 VGPRs at 1536).
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
     if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN) || ld != dim ||
         ld % kStageK != 0)
@@ -417,7 +417,10 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
 }
 
 // queries one corpus sweep of the MFMA kernel serves at this row length
-uint32_t scan_mfma_queries_per_sweep(uint32_t ld) { return ld / kStageK <= 6 ? 64u : 32u; }
+uint32_t scan_mfma_queries_per_sweep(uint32_t ld) {
+    (void)ld;
+    return 64u;
+}
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
