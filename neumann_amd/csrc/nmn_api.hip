@@ -171,7 +171,7 @@ constexpr uint32_t kSampleStep = 32;  // sampling pass of the batched sweep: eve
 // queries per pipeline pass: bound the score matrix to ~4 GiB
 static uint32_t pass_queries(const nmn_index* idx, uint32_t nq) {
     const uint64_t per_q = std::max<uint64_t>(idx->cap_pad, 64) * 4ull;
-    uint64_t m = (4ull << 30) / per_q;
+    uint64_t m = (8ull << 30) / per_q;  // score matrix of one pass <= 8 GiB (128 queries x 10M rows = 5 GiB)
     m = std::max<uint64_t>(1, std::min<uint64_t>(m, 256));
     return (uint32_t)std::min<uint64_t>(m, nq);
 }
@@ -752,9 +752,16 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
 }
 
 // ---- host-buffer searches: coalescing of concurrent callers into query batches ------------------------
+// Queries one batch may carry: what ONE corpus sweep serves — 128 (rows of <= 768 elements) or 64 stationary queries
+// on the matrix-core sweep, 4 on the VALU sweep (a longer batch there would only make every rider wait for the
+// later sweeps of the others).
+static uint32_t batch_queries(const nmn_index* idx, int metric) {
+    if (!scan_mfma_supported(idx->ld, idx->dim, metric) || getenv("NMN_NO_MFMA") != nullptr) return 4;
+    return idx->ld / 128u <= 6u ? 2u * nmn_index::kCoalesceQueries : nmn_index::kCoalesceQueries;
+}
 // requests that may share a batch: the candidate pipeline (k <= NMN_MAX_TOP_K), at most one sweep's worth of queries
-static bool mergeable(const HostReq& r) {
-    return coalesce_enabled() && r.k <= NMN_MAX_TOP_K && r.nq <= nmn_index::kCoalesceQueries;
+static bool mergeable(const nmn_index* idx, const HostReq& r) {
+    return coalesce_enabled() && r.k <= NMN_MAX_TOP_K && r.nq <= batch_queries(idx, r.metric);
 }
 // Same metric and same filter.  The filter is compared by address: two calls blocked in here with the same mask
 // pointer necessarily mean the same bits (a caller changing them under a running search races with its own call).
@@ -879,7 +886,8 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     }
     // lead a batch: this request plus every queued one that can share its sweep
     std::vector<HostReq*> batch{&me};
-    if (mergeable(me)) {
+    if (mergeable(idx, me)) {
+        const uint32_t limit = batch_queries(idx, metric);
         const uint32_t gather_us = gather_window_us(idx);
         if (gather_us && idx->last_batch_requests > 1) {
             // 3/4 of the previous batch is "everybody is back" (the rest may have left for good)
@@ -895,7 +903,7 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
         auto& qu = idx->host_queue;
         for (auto it = qu.begin(); it != qu.end();) {
             HostReq* r = *it;
-            if (mergeable(*r) && same_batch_key(me, *r) && total + r->nq <= nmn_index::kCoalesceQueries) {
+            if (mergeable(idx, *r) && same_batch_key(me, *r) && total + r->nq <= limit) {
                 total += r->nq;
                 batch.push_back(r);
                 it = qu.erase(it);

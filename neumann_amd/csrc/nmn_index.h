@@ -111,7 +111,7 @@ struct nmn_index {
     std::condition_variable cv;
     // Request coalescing: host-buffer searches that arrive while the shard is busy wait in `host_queue`; when a slot
     // frees, the oldest waiter is woken to lead: it runs ITS request together with every queued one of the same
-    // (metric, mask) as one query batch — one corpus sweep for up to kCoalesceQueries queries instead of one sweep
+    // (metric, mask) as one query batch — one corpus sweep for up to 64-128 queries instead of one sweep
     // each — and hands the results out (each rider is woken on its own condition variable: no thundering herd).
     // Results do not depend on the batch (exact rescore), so callers cannot tell, except by the clock.
     static constexpr uint32_t kCoalesceQueries = 64;

@@ -1,4 +1,4 @@
-// nmn_scan_mfma.hip — batched-query scan (5..64 queries per corpus sweep) on the CDNA4 matrix cores.
+// nmn_scan_mfma.hip — batched-query scan (3..128 queries per corpus sweep) on the CDNA4 matrix cores.
 //
 // With nq queries the scan is a [rows x dim] x [dim x nq] product.  At nq = 64 the f32 VALU / f32-MFMA
 // rate (157 TFLOP/s) would bound it at 6.25 ms per 10M x 768 sweep, above the HBM floor (SURVEY.md §7 hard
@@ -14,21 +14,27 @@
 // query's rounding error |q - bf16(q)| / |q| and adds it to that query's margin.  (Keeping a lo half of the queries —
 // a second MFMA per product — cost 10 % of the sweep and bought a margin nobody needed.)
 //
-// Structure (one workgroup = 4 waves = 64 queries x 64-row tiles, persistent over a tile range):
+// Structure (one workgroup = 4 waves = 64 or 128 queries x 64-row tiles, persistent over a tile range):
 //   * queries are STATIONARY in registers as MFMA B-fragments (v_mfma_f32_16x16x32_bf16; 4 VGPRs per 32-wide k-step
-//     and query group -> 96 VGPRs at dim 768);
-//   * the corpus STREAMS through LDS: [64 rows][128 bf16] stages (16 KiB) filled by global_load_lds_dwordx4
-//     (LDS-DMA: full 256-B row segments, no VGPRs) in a ring of 8 (7 in flight, 112 KiB per CU);
+//     and query group).  Wave w owns query groups w (and w + 4 when the pass holds more than 64 queries) for the WHOLE
+//     row: 96 VGPRs per group at dim 768, 192 at 1536;
+//   * the corpus STREAMS through LDS: [64 rows][128*KS bf16] stages (16 / 32 KiB) filled by global_load_lds_dwordx4
+//     (LDS-DMA: full row segments, no VGPRs) in a ring of 8 / 4 (all but one in flight, 112 / 96 KiB per CU);
 //   * the LDS image is XOR-swizzled through the DMA SOURCE address (chunk ^= row & 15) so that the 16 rows of a
 //     ds_read_b128 service group fall on 16 different bank slots;
-//   * wave w owns k-step w (32 of the 128 elements) of every stage: one ds_read_b128 per 16-row block (8 bf16 of
-//     one row per lane: exactly the A fragment), two MFMAs per row block and query group;
-//   * epilogue per tile: the four K-quarter partial sums meet through LDS, then scores (float4 per lane),
-//     per-(query,tile) maxima, per-(query,workgroup) maxima — the hierarchy select_kernel consumes.
-// Rows of 1024 / 1280 / 1536 floats keep the same 64 queries stationary (192 VGPRs of bf16 B-fragments at 1536).
+//   * every wave reads the whole stage (one ds_read_b128 per 16-row block and k-step: 8 bf16 of one row per lane,
+//     exactly the A fragment) — 4x the LDS traffic of splitting K over the waves, about a third of the LDS bandwidth at
+//     the HBM rate — and in exchange its accumulators ARE the final dot products: no partial sums meeting through
+//     LDS, no barrier beyond the stage hand-over (the K-split layout this replaced was 5-45 % slower at 64 queries,
+//     45 % at dim 128, and could not go beyond 64);
+//   * epilogue per tile and query group: scores (float4 per lane), per-(query,tile) maxima, per-(query,workgroup)
+//     maxima — the hierarchy select_kernel consumes.
 // Euclidean batches ride the same sweep: |q - v|^2 = |q|^2 + |v|^2 - 2 q.v from the dot product and the stored row
 // magnitudes.  The expansion cancels for near neighbours, so its error is bounded in SQUARED-distance space
 // (qprep_kernel: QInfo.pad < 0, applied by margin_key) and every candidate is re-scored exactly as always.
+#include <cstdlib>
+#include <type_traits>
+
 #include "nmn_internal.h"
 
 namespace nmn {
@@ -106,15 +112,9 @@ __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
     }
 }
 
-// Workgroup = 4 waves, one per SIMD (the kernel needs ~300 of the 512 registers a lone wave may use).
-// Wave w owns k-step w (32 of the 128 floats) of EVERY stage, for all 64 rows and all 64 queries: every
-// corpus element is therefore read from LDS and split into hi/lo bf16 exactly once per workgroup (an
-// earlier layout with the queries spread over the waves converted each element four times and was
-// VALU-bound at 12 VALU per MFMA).  Its 64 queries x 32 k stationary B-fragments cost KC*32 VGPRs
-// (192 at dim 768), the 4 row-blocks x 4 query-groups of accumulators 64.  The four K-quarter partial
-// sums of a tile meet once per tile through LDS; wave w then finishes query group w.
-// QG = query groups of 16 kept stationary (4: 64 queries per sweep, 2: 32).  Waves 0..QG-1 finish one group each.
-// KC = stages per row (ld / (128*KS)), KS = k-steps per wave and stage.
+// Workgroup = 4 waves, one per SIMD (the kernel needs 300-440 of the 512 registers a lone wave may use).
+// QG = query groups of 16 kept stationary by the workgroup (4: 64 queries per sweep, 8: 128); wave w multiplies and
+// finishes groups w, w + 4.  KC = stages per row (ld / (128*KS)), KS = 128-element k-blocks per stage.
 // Euclidean score from the matrix-core dot product: |q - v|^2 = |q|^2 + |v|^2 - 2 q.v, score = 1 / (1 + sqrt(.)).
 // The cancellation makes the ABSOLUTE error of the squared distance the quantity the margin bounds (qprep_kernel:
 // QInfo.pad < 0); a slightly negative result of the subtraction is a distance of zero.  v_sqrt / v_rcp: 1 ulp each.
@@ -132,9 +132,8 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     constexpr int kPieces = 4 * KS;                              // 1-KiB DMA instructions per wave and stage
     constexpr uint32_t LR = 16 * KS;                             // lanes (16-B chunks) per row of a stage
     constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_EUCLIDEAN;  // |v| of the tile's rows
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | exchange | norms
-    float* xch = lds + kRingBytes / 4;                           // [4 src waves][64 lanes][4 rb] f4, reused per round
-    float* nrm = xch + 4 * 64 * 16;                              // [kMaxRing tiles][64] row magnitudes (with one-stage
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | norms
+    float* nrm = lds + kRingBytes / 4;                           // [kMaxRing tiles][64] row magnitudes (with one-stage
                                                                  // tiles up to kRing tiles are in flight at once)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -143,15 +142,18 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
 
     // ---- stationary operand: QG*16 queries x this wave's k-step of every stage -----------------
-    s8 bhi[KC * KS][QG];  // k-step ks of stage kc: this wave owns k-step ks*4 + wave of the stage
+    constexpr int kBK = KC * KS * 4;  // k-steps of 32 elements per row
+    constexpr int kBG = QG / 4;       // query groups of this wave: groups wave, wave + 4, ...
+    s8 bhi[kBK][kBG];
+    static_assert(QG % 4 == 0, "query groups come in fours (one per wave)");
 #pragma unroll
-    for (int qg = 0; qg < QG; qg++) {
-        const uint32_t qq = q0 + (uint32_t)qg * 16u + n;
+    for (int qg = 0; qg < kBG; qg++) {
+        const uint32_t qq = q0 + ((uint32_t)qg * 4u + wave) * 16u + n;
         const bool ok = qq < p.nq;
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
 #pragma unroll
-        for (int kc = 0; kc < KC * KS; kc++) {
-            const uint32_t k0 = (uint32_t)(kc / KS) * kStageElems + ((uint32_t)(kc % KS) * 4u + wave) * 32u + g * 8u;  // k0..k0+7
+        for (int kc = 0; kc < kBK; kc++) {
+            const uint32_t k0 = (uint32_t)kc * 32u + g * 8u;  // k0..k0+7
             f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 a = *reinterpret_cast<const f4*>(qv + k0);
@@ -160,10 +162,20 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             bhi[kc][qg] = to_bf16x8(a, b);
         }
     }
-    const uint32_t qn = q0 + wave * 16u + n;  // the query this lane FINISHES (C column of group `wave`)
-    const bool q_ok = wave < (uint32_t)QG && qn < p.nq;
-    const float qmag = q_ok ? p.qinfo[qn].qmag : 0.f;
-    const uint32_t skip = (q_ok && p.skip_key) ? p.skip_key[qn] : kKeyNaN;  // kKeyNaN: write every tile
+    // The queries of this lane: C column n of query group h*4 + wave for each of the wave's kBG groups.
+    constexpr int kHalves = kBG;
+    constexpr int kAccGroups = kBG;
+    uint32_t qn_h[kHalves], skip_h[kHalves], wmax_h[kHalves];
+    bool q_ok_h[kHalves];
+    float qmag_h[kHalves];
+#pragma unroll
+    for (int h = 0; h < kHalves; h++) {
+        qn_h[h] = q0 + ((uint32_t)h * 4u + wave) * 16u + n;
+        q_ok_h[h] = (uint32_t)h * 4u + wave < (uint32_t)QG && qn_h[h] < p.nq;
+        qmag_h[h] = q_ok_h[h] ? p.qinfo[qn_h[h]].qmag : 0.f;
+        skip_h[h] = (q_ok_h[h] && p.skip_key) ? p.skip_key[qn_h[h]] : kKeyNaN;  // kKeyNaN: write every tile
+        wmax_h[h] = kKeyMasked;
+    }
 
     const uint32_t tstep = p.tile_step;                  // 1, or S on the sampling pass (tile index i -> tile i*S)
     const bool sampling = tstep > 1;
@@ -193,20 +205,20 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         }
     }
 
-    // LDS offset (floats) of this lane's 16-B read per row block and k-step ks: row n, chunk (ks*4+w)*4+g of the row's
-    // 16*KS (swizzled ^ n)
-    uint32_t off[KS];
+    // LDS offset (floats) of this lane's 16-B read per row block and k-step ks: row n, chunk ks*4+g of the row's 16*KS
+    // (swizzled ^ n)
+    constexpr int kSteps = 4 * KS;  // k-steps of a stage
+    uint32_t off[kSteps];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) off[ks] = n * kRowPitch + (((((uint32_t)ks * 4u + wave) * 4u + g) ^ n) * 4u);
+    for (int ks = 0; ks < kSteps; ks++) off[ks] = n * kRowPitch + ((((uint32_t)ks * 4u + g) ^ n) * 4u);
 
-    uint32_t wmax = kKeyMasked;
     uint32_t sidx = 0;  // running stage index of this workgroup
     for (uint32_t tile = t0; tile < t1; tile++) {
-        f4 acc[4][4];  // [row block][query group]; groups >= QG stay zero and are never published
+        f4 acc[4][kAccGroups];  // [row block][query group of this wave]
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-            for (int qg = 0; qg < 4; qg++) acc[rb][qg] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int qg = 0; qg < kAccGroups; qg++) acc[rb][qg] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < KC; kc++, sidx++) {
             const float* buf = lds + (sidx % kRing) * (kStageBytes / 4);
@@ -227,72 +239,32 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                 }
             }
             // A fragments straight from the bf16 stage: chunk g of this wave's k-step = 8 consecutive elements of row n.
-            s8 a[KS][4];
+            s8 a[kSteps][4];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++)
+            for (int ks = 0; ks < kSteps; ks++)
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++)
                     a[ks][rb] = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kRowPitch + off[ks]));
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
+            for (int ks = 0; ks < kSteps; ks++) {
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-                    for (int qg = 0; qg < QG; qg++)
-                        acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * KS + ks][qg], acc[rb][qg], 0, 0, 0);
+                    for (int qg = 0; qg < kBG; qg++)
+                        acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        // ---- the four K-quarters meet.  Three rounds through one 16 KiB exchange area (the LDS is
-        // better spent on a deeper DMA ring): in round j wave w publishes its partial of query group
-        // (w+1+j) % 4 and collects, from wave (w-1-j) % 4, that wave's partial of group w.
+        // ---- the accumulators are the final dot products: scores, tile maxima, score writes per query group
+        auto finish_half = [&](auto half_c) __attribute__((always_inline)) {
+        constexpr int H = decltype(half_c)::value;
+        const uint32_t qn = qn_h[H];
+        const bool q_ok = q_ok_h[H];
+        const float qmag = qmag_h[H];
+        const uint32_t skip = skip_h[H];
         f4 fin[4];
-#define NMN_XCH_PUT(W, J)                                                                          \
-    if ((((W) + 1 + (J)) & 3) < QG) {                                                              \
-        _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                           \
-            *reinterpret_cast<f4*>(xch + (((W) * 64u + lane) * 4u + (uint32_t)rb) * 4u) = acc[rb][((W) + 1 + (J)) & 3]; \
-    }
-#define NMN_XCH_ROUND(J)                                                                           \
-    switch (wave) {                                                                                \
-        case 0: NMN_XCH_PUT(0, J) break;                                                           \
-        case 1: NMN_XCH_PUT(1, J) break;                                                           \
-        case 2: NMN_XCH_PUT(2, J) break;                                                           \
-        default: NMN_XCH_PUT(3, J) break;                                                          \
-    }                                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-    __builtin_amdgcn_s_barrier();                                                                  \
-    asm volatile("" ::: "memory");                                                                 \
-    if (wave < (uint32_t)QG) {                                                                     \
-        const uint32_t src = (wave + 3u - (uint32_t)(J)) & 3u;                                     \
-        _Pragma("unroll") for (int rb = 0; rb < 4; rb++)                                           \
-            fin[rb] += *reinterpret_cast<const f4*>(xch + ((src * 64u + lane) * 4u + (uint32_t)rb) * 4u); \
-    }                                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-    __builtin_amdgcn_s_barrier();                                                                  \
-    asm volatile("" ::: "memory");
-        switch (wave) {
-            case 0:
 #pragma unroll
-                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][0];
-                break;
-            case 1:
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][1];
-                break;
-            case 2:
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][2];
-                break;
-            default:
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][3];
-                break;
-        }
-        NMN_XCH_ROUND(0)
-        NMN_XCH_ROUND(1)
-        NMN_XCH_ROUND(2)
-#undef NMN_XCH_ROUND
-#undef NMN_XCH_PUT
+        for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][H];
         {
             // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
             const uint64_t rtile = (uint64_t)tile * tstep;  // real tile index (sampling pass: every tstep-th)
@@ -356,7 +328,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 16));
             tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 32));
             if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + tile] = tkey;
-            wmax = max(wmax, tkey);
+            wmax_h[H] = max(wmax_h[H], tkey);
             // Scores are only worth their HBM write when the tile can still hold a candidate: with a
             // per-query bound from the sampling pass ~2 % of the tiles qualify (64 queries x 10M rows would
             // otherwise write 2.56 GB per sweep, measured at +1.45 ms on a 5.3 ms sweep).
@@ -366,17 +338,23 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                     *reinterpret_cast<u4*>(p.scores + score_at(r0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = bits[rb];
             }
         }
+        };
+        finish_half(std::integral_constant<int, 0>{});
+        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{});
     }
     if (sampling) return;  // the sampling pass leaves only tmax
-    if (q_ok && g == 0) p.wmax[(size_t)qn * p.wmax_stride + blockIdx.x] = wmax;
+#pragma unroll
+    for (int h = 0; h < kHalves; h++)
+        if (q_ok_h[h] && g == 0) p.wmax[(size_t)qn_h[h] * p.wmax_stride + blockIdx.x] = wmax_h[h];
 }
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid(blocks, (p.nq + QG * 16 - 1) / (QG * 16));
-    const size_t lds = kRingBytes + 4 * 64 * 16 * 4 + kMaxRing * 64 * 4;
-    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;  // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
+    const size_t lds = kRingBytes + kMaxRing * 64 * 4;
+    // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
+    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -392,6 +370,19 @@ static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
 // row length / 128: rows that are a multiple of 256 elements stream in 32-KiB stages (KS = 2), the others in 16-KiB ones
 template <int METRIC>
 static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
+    // more than 64 queries in the pass and rows of <= 768 elements: 128 stationary queries per workgroup (the matrix
+    // cores are ~16 % busy at 64; B-fragments 192 VGPRs + accumulators 128)
+    if (p.nq > 64) {
+        switch (p.ld / kStageK) {
+            case 1: return launch_kc<1, 1, 8, METRIC>(p, s);
+            case 2: return launch_kc<1, 2, 8, METRIC>(p, s);
+            case 3: return launch_kc<3, 1, 8, METRIC>(p, s);
+            case 4: return launch_kc<2, 2, 8, METRIC>(p, s);
+            case 5: return launch_kc<5, 1, 8, METRIC>(p, s);
+            case 6: return launch_kc<3, 2, 8, METRIC>(p, s);
+            default: break;  // longer rows: the B-fragments of 128 queries (256+ VGPRs) plus a stage of A-fragments spill
+        }
+    }
     switch (p.ld / kStageK) {
         case 1: return launch_kc<1, 1, 4, METRIC>(p, s);   // 128
         case 2: return launch_kc<1, 2, 4, METRIC>(p, s);   // 256

@@ -26,6 +26,9 @@ def check_batch(idx, A, Q, k, metric, mask=None):
 @pytest.mark.parametrize("n,d,nq,k", [(20000, 768, 64, 100), (20000, 768, 5, 10), (9000, 128, 16, 20),
                                       (30000, 256, 70, 50), (4000, 384, 33, 7), (70000, 512, 64, 100),
                                       (100, 640, 8, 200),
+                                      # more than 64 queries on rows of <= 768: 128 stationary queries per workgroup
+                                      (20000, 768, 128, 50), (9000, 256, 100, 20), (5000, 640, 65, 10),
+                                      (15000, 128, 200, 10), (7000, 384, 129, 30),
                                       # rows longer than 768 floats: the B-fragments of the 64 stationary queries fill 128-192 VGPRs
                                       (20000, 1024, 64, 50), (12000, 1536, 33, 100), (9000, 1280, 7, 10),
                                       (30000, 1536, 70, 20)])
