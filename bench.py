@@ -229,13 +229,15 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
             c = certificate(idx, qh[qi], metric, rows.view(np.uint64)[qi:qi + 1], scores[qi:qi + 1], counts[qi:qi + 1],
                             1, dev)
             ok = ok and c["exact_topk_certified"]
-    per_sweep = 64 if args.dim // 128 <= 6 else 32
+    # stationary queries of one matrix-core sweep (launch_metric in nmn_scan_mfma.hip): 128 when the pass holds more
+    # than 64 queries and the rows are <= 768 elements long, else 64
+    per_sweep = 128 if (args.dim // 128 <= 6 and nq > 64) else 64
     sweeps = (nq + per_sweep - 1) // per_sweep
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
     gbps = idx.rows * args.dim * elem_bytes * sweeps / (sweep * 1e-3) / 1e9
     return {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
             "value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "sweep_ms_incl_sampling_pass": sweep,
+            "sweep_ms_incl_sampling_pass": sweep, "corpus_sweeps_per_step": sweeps,
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBS, "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)",
                          "bytes_per_corpus_element": elem_bytes},
@@ -354,7 +356,7 @@ def main():
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and args.dim % 128 == 0 and (kc <= 6 or kc in (8, 10, 12))
             and args.k <= 4096)
-    per_sweep = 64  # stationary queries of the MFMA sweep (scan_mfma_queries_per_sweep)
+    per_sweep = 128 if (kc <= 6 and args.nq > 64) else 64  # stationary queries of one MFMA sweep (launch_metric)
     passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
