@@ -21,6 +21,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 row sample of the same workload, extrapolated linearly to the full row count
   parity        the GPU result of the last timed query checked against the oracle / exact certificate
   batched       (default single-GPU run) config 3: 64 queries per step on the MFMA sweep, same resident corpus
+  concurrent_callers  (default single-GPU run) 64 native host threads, each a loop of single-query nmn_index_search calls on
+                the same resident corpus: the C ABI merges callers that arrive while the shard is busy into one batch
   other_configs (default single-GPU run) config 2 (1M x 768) and config 5 (10M x 1536 L2 TOP-1000, mask 1.0 / 0.5 /
                 0.1), each as a child run of this script with its own corpus, each with its exactness certificate
 """
@@ -58,6 +60,7 @@ def parse():
     ap.add_argument("--mask", type=float, default=1.0,
                     help="selectivity of a synthetic WHERE-predicate bitmap (config 5); 1.0 = no mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--callers", type=int, default=64, help="host threads of the concurrent-callers leg (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -117,7 +120,7 @@ def cpu_baseline(args, metric, total_rows, device):
 def other_configs():
     """BASELINE.json configs 2 and 5 as child runs (each needs its own resident corpus: 3 GB and 61 GB)."""
     import subprocess
-    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--batched", "0",
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--batched", "0", "--callers", "0",
             "--warmup", "3"]
     runs = [("config2_1Mx768_cosine_top100", ["--rows", "1000000", "--steps", "200"]),
             ("config5_10Mx1536_l2_top1000_mask1.0", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12"]),
@@ -377,6 +380,18 @@ def main():
     if world == 1 and args.batched > 0 and args.nq == 1 and args.mask >= 1.0:
         batched = measure_batched(args, idx, dev, metric, total_rows, torch)
 
+    # Single-query calls from many host threads at once (the reference's Arc<VectorEngine> under concurrent clients):
+    # the C ABI merges callers that arrive while the shard is busy into one query batch.  Native threads, 1 second.
+    callers = None
+    if world == 1 and args.callers > 0 and args.nq == 1 and args.mask >= 1.0 and args.k <= 4096:
+        cq = _synth(SEED_QUERY + 2, 0, args.callers, args.dim)
+        r = idx.callers_probe(cq, args.k, metric, seconds=1.0)
+        callers = {"workload": f"{args.callers} host threads, each nmn_index_search(nq=1, k={args.k}) in a loop, "
+                               f"{total_rows}x{args.dim} f32 {args.metric}",
+                   "value": r["calls_per_s"], "unit": "queries/s", "threads": args.callers,
+                   "sweeps_carrying_2_or_more_calls": r["merged_batches"], "calls_in_them": r["merged_calls"],
+                   "answers_differing_from_a_lone_call": r["mismatches"]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, metric, total_rows, local_rank)
@@ -415,6 +430,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "batched": batched,
+            "concurrent_callers": callers,
             "other_configs": others,
             "fill_s": t_fill,
         }

@@ -173,6 +173,14 @@ nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, nmn_metric 
  * `reps` runs, in GB/s.  What a read-only kernel can reach on this device; bench.py reports the scan against it. */
 nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double* gbps_out);
 
+/* Measurement aid: `threads` host threads call nmn_index_search(nq = 1, k, metric) in a loop for `seconds`, thread t
+ * with query t of `queries` (HOST, threads x dim).  Reports calls per second, how many sweeps carried >= 2 calls and
+ * how many calls rode in them, and how many of the checked answers differed bit-wise from the same query searched
+ * alone before the threads started (must be 0).  bench.py reports it as `concurrent_callers`. */
+nmn_status nmn_index_callers_probe(nmn_index* idx, const float* queries, uint32_t threads, uint32_t k, nmn_metric metric,
+                                   double seconds, double* calls_per_s, uint64_t* merged_batches,
+                                   uint64_t* merged_calls, uint64_t* mismatches);
+
 /* ---- shard merge (multi-GPU) -------------------------------------------------------------- */
 
 /* Merge `n_lists` per-shard top-k lists (each nq x k, padded as nmn_index_search pads) into one:

@@ -91,6 +91,8 @@ SIGNATURES = {
     "nmn_index_count_exact": (C.c_int32, [vp, vp, C.c_int32, vp, C.c_float, u64p, u64p]),
     "nmn_index_read_probe": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double)]),
     "nmn_index_coalesce_stats": (C.c_int32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "nmn_index_callers_probe": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_double, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nmn_merge_topk_host": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "nmn_merge_topk_device": (C.c_int32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
     "nmn_merge_topk_device_strided": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,

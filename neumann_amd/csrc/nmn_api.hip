@@ -3,6 +3,8 @@
 // kernel lives in nmn_scan/nmn_select/nmn_exact/nmn_synth.hip.  No CPU compute path exists here:
 // without a HIP device every entry point fails with NMN_ERR_NO_DEVICE.
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -937,6 +939,67 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     lk.unlock();
     if (idle) idx->cv.notify_all();  // writers waiting for the slots to drain
     return st;
+}
+
+extern "C" nmn_status nmn_index_callers_probe(nmn_index* idx, const float* queries, uint32_t threads, uint32_t k,
+                                              nmn_metric metric, double seconds, double* calls_per_s,
+                                              uint64_t* merged_batches, uint64_t* merged_calls, uint64_t* mismatches) {
+    if (!idx || !queries || !calls_per_s) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (threads == 0 || threads > 1024 || k == 0 || k > NMN_MAX_TOP_K || !(seconds > 0.0))
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "threads in 1..1024, k in 1..4096, seconds > 0");
+    const size_t dim = idx->dim;
+    const uint32_t check_every = 16;  // every 16th thread compares each of its answers with the reference
+    std::vector<uint64_t> ref_rows((size_t)threads * k);
+    std::vector<float> ref_scores((size_t)threads * k);
+    uint32_t cnt = 0;
+    for (uint32_t t = 0; t < threads; t += check_every) {
+        nmn_status st = nmn_index_search(idx, queries + t * dim, 1, k, metric, nullptr, ref_rows.data() + (size_t)t * k,
+                                         ref_scores.data() + (size_t)t * k, &cnt, nullptr);
+        if (st != NMN_OK) return st;
+    }
+    uint64_t b0 = 0, r0 = 0, b1 = 0, r1 = 0;
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        b0 = idx->coalesced_batches;
+        r0 = idx->coalesced_requests;
+    }
+    std::atomic<uint64_t> calls{0}, bad{0};
+    std::atomic<int> failed{0};
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            std::vector<uint64_t> rows(k);
+            std::vector<float> scores(k);
+            uint32_t c = 0;
+            while (!stop.load(std::memory_order_relaxed)) {
+                if (nmn_index_search(idx, queries + t * dim, 1, k, metric, nullptr, rows.data(), scores.data(), &c,
+                                     nullptr) != NMN_OK) {
+                    failed = 1;
+                    break;
+                }
+                if (t % check_every == 0 && (memcmp(rows.data(), ref_rows.data() + (size_t)t * k, (size_t)k * 8) != 0 ||
+                                             memcmp(scores.data(), ref_scores.data() + (size_t)t * k, (size_t)k * 4) != 0))
+                    bad++;
+                calls++;
+            }
+        });
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop = true;
+    for (auto& x : th) x.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        b1 = idx->coalesced_batches;
+        r1 = idx->coalesced_requests;
+    }
+    if (failed) return fail_arg(NMN_ERR_STORAGE, "a search of the callers probe failed");
+    *calls_per_s = (double)calls.load() / dt;
+    if (merged_batches) *merged_batches = b1 - b0;
+    if (merged_calls) *merged_calls = r1 - r0;
+    if (mismatches) *mismatches = bad.load();
+    return NMN_OK;
 }
 
 extern "C" nmn_status nmn_index_coalesce_stats(nmn_index* idx, uint64_t* batches, uint64_t* requests) {

@@ -189,6 +189,15 @@ class GpuFlatIndex:
         _capi.check(self._lib.nmn_index_read_probe(self._h, int(reps), C.byref(out)))
         return float(out.value)
 
+    def callers_probe(self, queries, k, metric=DistanceMetric.Cosine, seconds=1.0):
+        """len(queries) native threads each calling the single-query host API in a loop: dict(calls_per_s,
+        merged_batches, merged_calls, mismatches)."""
+        q = _f32(queries)
+        qps, b, r, bad = C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _capi.check(self._lib.nmn_index_callers_probe(self._h, _ptr(q), q.shape[0], int(k), int(metric), float(seconds),
+                                                      C.byref(qps), C.byref(b), C.byref(r), C.byref(bad)))
+        return {"calls_per_s": qps.value, "merged_batches": b.value, "merged_calls": r.value, "mismatches": bad.value}
+
     def coalesce_stats(self):
         """(batches that merged >= 2 concurrent host-buffer searches, searches merged)."""
         b, r = C.c_uint64(), C.c_uint64()
