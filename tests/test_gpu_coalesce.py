@@ -108,3 +108,37 @@ def test_an_invalid_call_does_not_poison_its_neighbours():
         for j, (q, k, metric, _) in enumerate(good):
             er, es = oc.search(A, q, k, metric)
             assert np.array_equal(got[j][0][0, :er.size], er) and np.all(got[j][1][0, :er.size] == es)
+
+
+def test_writers_drain_the_queue_and_hand_the_slot_back():
+    """set_row / upload wait for the running batch, keep new ones from starting, and restart the queue when done.  The
+    writer re-writes rows with their own content, so every answer must stay what it was."""
+    from neumann_amd import GpuFlatIndex
+    n, d = 60_000, 256
+    A = oc.synth(97, 0, n, d)
+    jobs = [(oc.synth(98, j, 1, d)[0], 10 + j % 4, (0, 1, 2)[j % 3], None) for j in range(24 * 8)]
+    with GpuFlatIndex(d, n + 1000) as idx:
+        idx.upload(A)
+        want = [idx.search(q, k, m) for q, k, m, _ in jobs]
+        stop = threading.Event()
+        writes = [0]
+
+        def writer():
+            r = 0
+            while not stop.is_set():
+                idx.set_row(r % n, A[r % n])
+                if r % 50 == 0:
+                    idx.upload(A[n - 16:], row0=n - 16)     # overwrite the tail in place
+                r += 1
+                writes[0] += 1
+
+        t = threading.Thread(target=writer)
+        t.start()
+        try:
+            got = _hammer(idx, jobs, 24)
+        finally:
+            stop.set()
+            t.join()
+        assert writes[0] > 0
+        for (r0, s0, c0), (r1, s1, c1) in zip(want, got):
+            assert np.array_equal(r0, r1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and c0[0] == c1[0]
