@@ -136,6 +136,7 @@ static void ws_free(Workspace* w) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->h_pack) (void)hipFree(w->h_pack);
+    if (w->h_qmasks) (void)hipFree(w->h_qmasks);
     if (w->pin_in) (void)hipHostFree(w->pin_in);
     if (w->pin_out) (void)hipHostFree(w->pin_out);
     for (auto& e : w->ev)
@@ -469,19 +470,32 @@ static uint32_t mfma_min_queries(const nmn_index* idx) {
     return idx->dim >= 768 ? 3u : 5u;
 }
 
+// qmasks_dev / qmasks_host (both or neither): one bitmap pointer per query — the same nq device pointers as an array in
+// device memory (what the matrix-core sweep reads) and in host memory (for the passes that cannot take that sweep:
+// those run query by query, each with its own bitmap).  `mask_dev` must be null when they are given.
 static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* queries_dev, uint32_t nq, uint32_t k,
                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
-                                 float* out_scores, uint32_t* out_counts, hipStream_t stream) {
+                                 float* out_scores, uint32_t* out_counts, hipStream_t stream,
+                                 const uint64_t* const* qmasks_dev = nullptr, const uint64_t* const* qmasks_host = nullptr) {
     nmn_status st = ws_alloc(idx, w);
     if (st != NMN_OK) return st;
-    if (k > NMN_MAX_TOP_K)
+    if (k > NMN_MAX_TOP_K) {
+        if (qmasks_host) {
+            for (uint32_t i = 0; i < nq; i++) {
+                st = search_large_k(idx, w, queries_dev + (size_t)i * idx->dim, 1, k, metric, qmasks_host[i],
+                                    out_rows + (size_t)i * k, out_scores + (size_t)i * k, out_counts + i, stream);
+                if (st != NMN_OK) return st;
+            }
+            return NMN_OK;
+        }
         return search_large_k(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows, out_scores, out_counts, stream);
+    }
     const uint64_t n_rows = idx->rows;
     const uint32_t n_tiles = (uint32_t)((n_rows + kTileRows - 1) / kTileRows);
     w->timed = idx->timing;
     w->last_nq = nq;
     w->last_rows_scanned = n_rows;
-    w->last_masked = mask_dev != nullptr;
+    w->last_masked = mask_dev != nullptr || qmasks_dev != nullptr;
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
@@ -539,6 +553,17 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }
         }
         const bool use_mfma = mfma_shape && use_half;  // the matrix-core sweep has no f32 variant
+        if (qmasks_host && !use_mfma) {
+            // per-query bitmaps need the matrix-core sweep: this pass runs query by query instead
+            for (uint32_t i = 0; i < nqc; i++) {
+                st = search_enqueue(idx, w, queries_dev + (size_t)(qa + i) * idx->dim, 1, k, metric, qmasks_host[qa + i],
+                                    out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i,
+                                    stream);
+                if (st != NMN_OK) return st;
+            }
+            w->last_nq = nq;
+            continue;
+        }
         w->last_elem_bytes = use_half ? 2u : 4u;
         // A bf16 pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
@@ -557,6 +582,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.qpad = w->qpad;
             sp.qinfo = w->qinfo;
             sp.mask = mask_dev;
+            sp.qmasks = qmasks_dev ? qmasks_dev + qa : nullptr;
             sp.scores = w->scores;
             sp.tmax = w->tmax;
             sp.wmax = w->wmax;
@@ -652,6 +678,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             rp.cand_rows = w->cand_rows;
             rp.cand_scores = w->cand_scores;
             rp.mask = mask_dev;       // fallback duty of the same launch
+            rp.qmasks = qmasks_dev ? qmasks_dev + qa : nullptr;
             rp.scores = w->scores;
             rp.n_rows = n_rows;
             rp.nql = nqc;
@@ -765,10 +792,18 @@ static uint32_t batch_queries(const nmn_index* idx, int metric) {
 static bool mergeable(const nmn_index* idx, const HostReq& r) {
     return coalesce_enabled() && r.k <= NMN_MAX_TOP_K && r.nq <= batch_queries(idx, r.metric);
 }
-// Same metric and same filter.  The filter is compared by address: two calls blocked in here with the same mask
-// pointer necessarily mean the same bits (a caller changing them under a running search races with its own call).
-static bool same_batch_key(const HostReq& a, const HostReq& b) {
-    return a.metric == b.metric && a.mask == b.mask && (a.mask == nullptr || a.mask_on_device == b.mask_on_device);
+// Same metric, and filters that can share a sweep.  Filters are compared by address: two calls blocked in here with
+// the same mask pointer necessarily mean the same bits (a caller changing them under a running search races with its
+// own call).  DIFFERENT filters share a sweep too when both are bitmaps in device memory (or absent) and the shard's
+// batches take the matrix-core sweep, which reads one bitmap per query.
+static bool same_mask(const HostReq& a, const HostReq& b) {
+    return a.mask == b.mask && (a.mask == nullptr || a.mask_on_device == b.mask_on_device);
+}
+static bool same_batch_key(const nmn_index* idx, const HostReq& a, const HostReq& b) {
+    if (a.metric != b.metric) return false;
+    if (same_mask(a, b)) return true;
+    const bool dev_a = a.mask == nullptr || a.mask_on_device, dev_b = b.mask == nullptr || b.mask_on_device;
+    return dev_a && dev_b && batch_queries(idx, a.metric) > 4;
 }
 
 // One packed search for `reqs` (queries concatenated, k = the largest asked for) on host slot `slot`.
@@ -809,8 +844,18 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         }
     }
     HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    bool one_mask = true;
+    for (size_t i = 1; i < n_reqs; i++) one_mask = one_mask && same_mask(first, *reqs[i]);
     const uint64_t* mask_dev = nullptr;
-    if (first.mask && words && first.mask_on_device) {
+    std::vector<const uint64_t*> qmasks;  // one device bitmap (or null) per query when the batch mixes filters
+    if (!one_mask) {
+        if (words) {
+            for (size_t i = 0; i < n_reqs; i++) qmasks.insert(qmasks.end(), reqs[i]->nq, reqs[i]->mask);
+            HIP_TRY(grow(&w->h_qmasks, &w->h_qmasks_cap, (size_t)nq));
+            // pageable -> device is a staged copy: the vector may go out of scope once the call returns
+            HIP_TRY(hipMemcpyAsync(w->h_qmasks, qmasks.data(), (size_t)nq * sizeof(uint64_t*), hipMemcpyHostToDevice, s));
+        }
+    } else if (first.mask && words && first.mask_on_device) {
         mask_dev = first.mask;
     } else if (first.mask && words) {
         HIP_TRY(grow(&w->h_mask, &w->h_mask_cap, words));
@@ -820,7 +865,11 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     uint64_t* d_rows = reinterpret_cast<uint64_t*>(w->h_pack);
     float* d_scores = reinterpret_cast<float*>(w->h_pack + off_scores);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(w->h_pack + off_counts);
-    st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s);
+    if (!qmasks.empty())
+        st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, nullptr, d_rows, d_scores, d_counts, s,
+                            w->h_qmasks, qmasks.data());
+    else
+        st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s);
     if (st != NMN_OK) return st;
     HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
     lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
@@ -905,7 +954,7 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
         auto& qu = idx->host_queue;
         for (auto it = qu.begin(); it != qu.end();) {
             HostReq* r = *it;
-            if (mergeable(idx, *r) && same_batch_key(me, *r) && total + r->nq <= limit) {
+            if (mergeable(idx, *r) && same_batch_key(idx, me, *r) && total + r->nq <= limit) {
                 total += r->nq;
                 batch.push_back(r);
                 it = qu.erase(it);

@@ -301,11 +301,12 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
     const float* qv = p.qpad + (size_t)q * p.ld;
     const float qmag = p.qinfo[q].qmag;
     if (p.qstate[q].overflow) {
+        const uint64_t* mask = p.qmasks ? p.qmasks[q] : p.mask;
         const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
         for (uint64_t base = (uint64_t)blockIdx.x * 32u; base < n_pad; base += (uint64_t)gridDim.x * 32u) {
             const uint64_t row = base + (threadIdx.x >> 3);
             bool valid = row < p.n_rows;
-            if (valid && p.mask) valid = ((p.mask[row >> 6] >> (row & 63)) & 1ull) != 0;
+            if (valid && mask) valid = ((mask[row >> 6] >> (row & 63)) & 1ull) != 0;
             uint32_t bits = kScoreSentinelBits;
             if (valid) {  // uniform per 8-lane group
                 const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;

@@ -43,6 +43,7 @@ struct Workspace {
     // host-buffer API: ONE packed device block [rows | scores | counts] and pinned host staging for the query and the
     // results, so a call is one true-async H2D, the pipeline, one D2H and one wait (pageable copies cost ~10 us each)
     uint8_t* h_pack = nullptr; size_t h_pack_cap = 0;        // device
+    const uint64_t** h_qmasks = nullptr; size_t h_qmasks_cap = 0;  // device: per-query bitmap pointers of a merged batch
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
     uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
     uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;

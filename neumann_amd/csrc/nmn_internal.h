@@ -87,6 +87,8 @@ struct ScanParams {
     const float* qpad;       // [nq][ld] zero padded
     const QInfo* qinfo;      // [nq]
     const uint64_t* mask;    // nullable, ceil(rows/64) words
+    const uint64_t* const* qmasks;  // nullable [nq] (MFMA sweep only): one bitmap pointer PER QUERY (null entry = every
+                                    // row takes part) — a batch of differently filtered searches in one sweep
     uint32_t* scores;        // score_at(row, q, nql): f32 bits (sentinel for non-participating rows)
     uint32_t* tmax;          // [nq][tmax_stride] tile maximum key (0 = empty tile)
     uint32_t* wmax;          // [nq][wmax_stride] maximum key over the tiles of each scan wave
@@ -182,6 +184,7 @@ struct RescoreParams {
     float* cand_scores;
     // exact-fallback duty (queries with qstate.overflow): exact score of EVERY row -> scores
     const uint64_t* mask;
+    const uint64_t* const* qmasks;  // nullable [nq]: per-query bitmaps (see ScanParams)
     uint32_t* scores;
     uint64_t n_rows;
     uint32_t nql;

@@ -270,7 +270,11 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             const uint64_t rtile = (uint64_t)tile * tstep;  // real tile index (sampling pass: every tstep-th)
             const uint64_t r0 = rtile * kTileRows;
             uint64_t mword = ~0ull;
-            if constexpr (MASKED) mword = p.mask[rtile];
+            if constexpr (MASKED) {
+                // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
+                const uint64_t* mq = p.qmasks ? (q_ok ? p.qmasks[qn] : nullptr) : p.mask;
+                if (mq) mword = mq[rtile];
+            }
             const uint64_t left = p.n_rows - r0;
             if (left < 64) mword &= (1ull << left) - 1ull;
             uint32_t tkey = kKeyMasked;
@@ -364,7 +368,8 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
 
 template <int KC, int KS, int QG, int METRIC>
 static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
-    return p.mask ? launch_one_mfma<KC, KS, QG, METRIC, true>(p, s) : launch_one_mfma<KC, KS, QG, METRIC, false>(p, s);
+    return (p.mask || p.qmasks) ? launch_one_mfma<KC, KS, QG, METRIC, true>(p, s)
+                                : launch_one_mfma<KC, KS, QG, METRIC, false>(p, s);
 }
 
 // row length / 128: rows that are a multiple of 256 elements stream in 32-KiB stages (KS = 2), the others in 16-KiB ones

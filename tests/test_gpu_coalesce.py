@@ -142,3 +142,59 @@ def test_writers_drain_the_queue_and_hand_the_slot_back():
         assert writes[0] > 0
         for (r0, s0, c0), (r1, s1, c1) in zip(want, got):
             assert np.array_equal(r0, r1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and c0[0] == c1[0]
+
+
+@pytest.mark.parametrize("n,d", [(40_000, 768), (30_000, 256), (25_000, 200)])  # matrix-core sweep from 3 / 5 queries / never
+def test_differently_filtered_callers_share_a_sweep(n, d):
+    """Concurrent searches whose WHERE bitmaps differ (each in device memory, as the predicate kernel leaves them)
+    ride one matrix-core sweep that reads one bitmap per query; where that sweep does not apply they must still
+    come out right (query by query)."""
+    import torch
+    from neumann_amd import GpuFlatIndex
+    A = oc.synth(101, 0, n, d)
+    rng = np.random.default_rng(12)
+    words = (n + 63) // 64
+    n_masks = 12
+    host_masks = [oc.mask_from_bool(rng.random(n) < sel) for sel in np.linspace(0.02, 0.9, n_masks)]
+    host_masks[3][:] = 0                                    # a filter nothing passes
+    dev = torch.device("cuda:0")
+    dev_masks = [torch.from_numpy(m[:words].view(np.int64).copy()).to(dev) for m in host_masks]
+    torch.cuda.synchronize()
+    jobs = []
+    for j in range(24 * 5):
+        mi = j % (n_masks + 1)                              # the last one: no filter at all
+        jobs.append((oc.synth(102, j, 1, d)[0], (5, 40, 100)[j % 3], (0, 1, 2)[j % 3 if d != 200 else 0], mi))
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        out = [None] * len(jobs)
+        errs = []
+        start = threading.Barrier(24)
+
+        def work(t):
+            try:
+                start.wait()
+                for j in range(t, len(jobs), 24):
+                    q, k, metric, mi = jobs[j]
+                    if mi == n_masks:
+                        out[j] = idx.search(q, k, metric)
+                    else:
+                        out[j] = idx.search_dmask(q, k, metric, dev_masks[mi].data_ptr())
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(24)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errs, errs
+        batches, merged = idx.coalesce_stats()
+        assert batches > 0
+        for j, (q, k, metric, mi) in enumerate(jobs):
+            rows, scores, counts = out[j]
+            er, es = oc.search(A, q, k, metric, mask=None if mi == n_masks else host_masks[mi])
+            c = er.size
+            assert counts[0] == c, (j, mi, counts[0], c)
+            assert np.array_equal(rows[0, :c], er), (j, mi)
+            assert np.all(scores[0, :c] == es), (j, mi)
+            assert np.all(rows[0, c:] == U64_MAX)
