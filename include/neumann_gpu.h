@@ -280,7 +280,17 @@ nmn_status nmn_columns_write_valid(nmn_columns* cols, uint64_t word0, uint64_t n
  * search_with_pre_filter (lib.rs:3526-3530) and of search_filtered_in_collection (lib.rs:1776-1784). */
 nmn_status nmn_columns_eval(nmn_columns* cols, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
                             uint64_t n_consts, uint64_t n_rows, uint64_t* count_out);
-/* Device bitmap of the last evaluation, ceil(capacity_rows/64) words. */
+/* The same evaluation for concurrent callers (filtered searches of many threads under a shared lock): the result goes
+ * to a bitmap of its own, *mask_out (device, ceil(capacity_rows/64) words), which the caller holds — together with the
+ * stream and staging the evaluation ran on — as slot *slot_out until nmn_columns_eval_release.  Evaluations of
+ * different slots overlap on the device; searches that pass different slot bitmaps to nmn_index_search_dmask share one
+ * corpus sweep (request coalescing, one bitmap per query).  Must not run concurrently with the nmn_columns_write*
+ * family (the engine's writers hold its exclusive lock). */
+nmn_status nmn_columns_eval_acquire(nmn_columns* cols, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
+                                    uint64_t n_consts, uint64_t n_rows, uint64_t* count_out, uint32_t* slot_out,
+                                    const uint64_t** mask_out);
+nmn_status nmn_columns_eval_release(nmn_columns* cols, uint32_t slot);
+/* Device bitmap of the last nmn_columns_eval, ceil(capacity_rows/64) words. */
 const uint64_t* nmn_columns_mask_device(const nmn_columns* cols);
 /* Device row-validity bitmap (a ready-made mask of the live rows). */
 const uint64_t* nmn_columns_valid_device(const nmn_columns* cols);
@@ -292,6 +302,12 @@ nmn_status nmn_columns_read_mask(nmn_columns* cols, uint64_t* out_words, uint64_
 nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
                                   nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                   float* out_scores, uint32_t* out_counts, nmn_search_stats* stats);
+/* The same, with the number of rows the bitmap selects (the predicate kernel's count) as a hint for the request
+ * coalescer: concurrent searches with DIFFERENT device bitmaps share one sweep (one bitmap per query, every row read)
+ * once their selectivities add up to a whole sweep; below that each is swept alone and skips what it excludes. */
+nmn_status nmn_index_search_dmask_hint(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                                       const uint64_t* mask_dev, uint64_t mask_rows, uint64_t* out_rows,
+                                       float* out_scores, uint32_t* out_counts, nmn_search_stats* stats);
 
 /* Request coalescing of the host-buffer searches (nmn_index_search / _dmask): callers that arrive while a search is
  * running on the shard wait and leave together as ONE query batch (same metric and mask, <= 64 queries, k <= 4096),

@@ -109,6 +109,9 @@ SIGNATURES = {
     "nmn_columns_clear_row": (C.c_int32, [vp, C.c_uint64]),
     "nmn_columns_write_valid": (C.c_int32, [vp, C.c_uint64, C.c_uint64, vp]),
     "nmn_columns_eval": (C.c_int32, [vp, C.POINTER(PredOp), C.c_uint32, vp, C.c_uint64, C.c_uint64, u64p]),
+    "nmn_columns_eval_acquire": (C.c_int32, [vp, C.POINTER(PredOp), C.c_uint32, vp, C.c_uint64, C.c_uint64, u64p,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
+    "nmn_columns_eval_release": (C.c_int32, [vp, C.c_uint32]),
     "nmn_columns_mask_device": (vp, [vp]),
     "nmn_columns_valid_device": (vp, [vp]),
     "nmn_columns_read_mask": (C.c_int32, [vp, vp, C.c_uint64]),
@@ -124,6 +127,8 @@ SIGNATURES = {
     "nmn_ivf_vectors": (vp, [vp]),
     "nmn_index_search_dmask": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp,
                                            C.POINTER(SearchStats)]),
+    "nmn_index_search_dmask_hint": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_uint64, vp, vp, vp,
+                                                C.POINTER(SearchStats)]),
 }
 
 _lib = None

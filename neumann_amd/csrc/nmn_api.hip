@@ -67,7 +67,7 @@ static bool coalesce_enabled() {
 // engine: 4.1k -> 59k queries/s).  Small shards are latency-bound (a dozen launches, a few tens of microseconds):
 // two batches in flight keep the device busy while results are handed out (100k x 128: 17.7k -> 114k queries/s).
 // NMN_HOST_INFLIGHT overrides (1..kHostSlots).
-static int lead_limit(const nmn_index* idx) {
+static int lead_limit(const nmn_index* idx, double selectivity = 1.0) {
     static const int forced = [] {
         const char* e = getenv("NMN_HOST_INFLIGHT");
         const int v = e ? atoi(e) : 0;
@@ -75,8 +75,21 @@ static int lead_limit(const nmn_index* idx) {
     }();
     if (forced) return forced;
     if (!coalesce_enabled()) return nmn_index::kHostSlots;
-    const uint64_t sweep_bytes = idx->rows * (uint64_t)idx->ld * 2ull;
-    return sweep_bytes >= (256ull << 20) ? 1 : 2;
+    // a filtered search reads only what its bitmap selects: several selective ones may run side by side
+    const double sweep_bytes = (double)idx->rows * idx->ld * 2.0 * selectivity;
+    return sweep_bytes >= (double)(256ull << 20) ? 1 : sweep_bytes >= (double)(32ull << 20) ? 2 : nmn_index::kHostSlots;
+}
+static double selectivity_of(const nmn_index* idx, const HostReq& r) {
+    if (!r.mask || r.mask_rows == UINT64_MAX) return 1.0;
+    return std::min(1.0, (double)r.mask_rows / (double)std::max<uint64_t>(idx->rows, 1));
+}
+// In-flight limit when `r` is next to lead.  The extra room a selective filter earns is for light load only: with a
+// crowd waiting, ONE leader should take them all (possibly as one mixed-filter sweep) rather than four leaders
+// starting four sweeps side by side.
+static int lead_limit_for(const nmn_index* idx, const HostReq& r) {
+    const int base = lead_limit(idx);
+    if (idx->host_queue.size() >= 8) return base;
+    return std::max(base, lead_limit(idx, selectivity_of(idx, r)));
 }
 
 // How long a batch leader waits for the callers of the previous batch to come back (see last_batch_requests): a
@@ -105,7 +118,8 @@ static int slot_take(nmn_index* idx) {
 }
 // caller holds idx->mu: hand free slots to the oldest waiting requests; each becomes the leader of a batch
 static void designate_leaders(nmn_index* idx) {
-    while (!idx->host_queue.empty() && idx->writers_waiting == 0 && idx->slots_busy < lead_limit(idx)) {
+    while (!idx->host_queue.empty() && idx->writers_waiting == 0 &&
+           idx->slots_busy < lead_limit_for(idx, *idx->host_queue.front())) {
         HostReq* r = idx->host_queue.front();
         idx->host_queue.erase(idx->host_queue.begin());
         r->slot = slot_take(idx);
@@ -900,7 +914,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
 
 nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
                                     const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
-                                    uint32_t* out_counts, nmn_search_stats* stats) {
+                                    uint32_t* out_counts, nmn_search_stats* stats, uint64_t mask_rows) {
     nmn_status st = check_search_args(idx, queries, nq, k, metric == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : (nmn_metric)metric,
                                       out_rows, out_scores, out_counts);
     if (st != NMN_OK) return st;
@@ -912,12 +926,13 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     me.metric = metric;
     me.mask = mask;
     me.mask_on_device = mask_on_device;
+    me.mask_rows = mask ? mask_rows : UINT64_MAX;
     me.out_rows = out_rows;
     me.out_scores = out_scores;
     me.out_counts = out_counts;
     me.stats = stats;
     std::unique_lock<std::mutex> lk(idx->mu);
-    if (idx->host_queue.empty() && idx->writers_waiting == 0 && idx->slots_busy < lead_limit(idx)) {
+    if (idx->host_queue.empty() && idx->writers_waiting == 0 && idx->slots_busy < lead_limit_for(idx, me)) {
         me.slot = slot_take(idx);  // the shard can take another search right now: lead a batch of one
     } else {
         idx->host_queue.push_back(&me);
@@ -952,9 +967,28 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
         }
         uint32_t total = nq;
         auto& qu = idx->host_queue;
+        // Differently filtered searches share a sweep that reads EVERY row (one bitmap per query), while a sweep with
+        // one bitmap skips what it excludes: mixing pays once the filters waiting here would cost more than a whole
+        // sweep when served one by one.  Otherwise each filter is led separately.
+        bool mix = false;
+        {
+            // separately: each distinct filter costs max(a fixed launch-bound search, its share of a sweep);
+            // together: one whole sweep (+ the fixed part)
+            const double sweep_us = (double)idx->rows * idx->ld * 2.0 / 5.5e6, fixed_us = 100.0;
+            auto alone_us = [&](const HostReq& r) { return std::max(fixed_us, selectivity_of(idx, r) * sweep_us); };
+            double sum = alone_us(me);
+            std::vector<const uint64_t*> seen{me.mask};
+            for (HostReq* r : qu) {
+                if (!mergeable(idx, *r) || !same_batch_key(idx, me, *r) || same_mask(me, *r)) continue;
+                if (std::find(seen.begin(), seen.end(), r->mask) != seen.end()) continue;
+                seen.push_back(r->mask);
+                sum += alone_us(*r);
+            }
+            mix = sum >= 1.1 * sweep_us + fixed_us;
+        }
         for (auto it = qu.begin(); it != qu.end();) {
             HostReq* r = *it;
-            if (mergeable(idx, *r) && same_batch_key(idx, me, *r) && total + r->nq <= limit) {
+            if (mergeable(idx, *r) && same_batch_key(idx, me, *r) && (mix || same_mask(me, *r)) && total + r->nq <= limit) {
                 total += r->nq;
                 batch.push_back(r);
                 it = qu.erase(it);
@@ -1073,6 +1107,14 @@ extern "C" nmn_status nmn_index_search_dmask(nmn_index* idx, const float* querie
 
 // Pure read sweep over the shard's rows (no arithmetic): the bandwidth a read-only kernel reaches on this device
 // with the scan's own access pattern.  *gbps_out = rows * ld * 4 bytes / best-of-`reps` kernel time.
+extern "C" nmn_status nmn_index_search_dmask_hint(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t mask_rows,
+                                                  uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                                  nmn_search_stats* stats) {
+    return index_search_hostio(idx, queries, nq, k, (int)metric, mask_dev, true, out_rows, out_scores, out_counts, stats,
+                               mask_rows);
+}
+
 extern "C" nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double* gbps_out) {
     if (!idx || !gbps_out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     *gbps_out = 0.0;

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <memory>
+#include <condition_variable>
 #include <new>
 #include <vector>
 
@@ -205,6 +207,21 @@ struct nmn_columns {
     bool kinds_tab_dirty = true;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // Concurrent evaluations (nmn_columns_eval_acquire): each holds a slot — its own stream, program staging, counters
+    // and RESULT BITMAP — until the search that consumes the bitmap is done.  Slots are created on demand.
+    struct EvalSlot {
+        hipStream_t stream = nullptr;
+        uint8_t* prog = nullptr;
+        size_t prog_cap = 0;
+        unsigned long long* count = nullptr;
+        uint64_t* mask = nullptr;
+        uint8_t* pin = nullptr;   // pinned host staging: [count readback (8 B) | program + constants]
+        size_t pin_cap = 0;
+        bool busy = false;
+    };
+    std::vector<std::unique_ptr<EvalSlot>> slots;
+    std::condition_variable slot_cv;
+    static constexpr size_t kMaxSlots = 256;
 };
 
 #define COL_TRY(expr)                                              \
@@ -259,6 +276,15 @@ extern "C" nmn_status nmn_columns_destroy(nmn_columns* c) {
     for (void* p : {(void*)c->valid, (void*)c->mask, (void*)c->count, (void*)c->prog, (void*)c->kinds_tab})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto& sl : c->slots) {
+        if (sl->stream) {
+            (void)hipStreamSynchronize(sl->stream);
+            (void)hipStreamDestroy(sl->stream);
+        }
+        for (void* p : {(void*)sl->prog, (void*)sl->count, (void*)sl->mask})
+            if (p) (void)hipFree(p);
+        if (sl->pin) (void)hipHostFree(sl->pin);
+    }
     delete c;
     return NMN_OK;
 }
@@ -346,14 +372,11 @@ extern "C" nmn_status nmn_columns_write_valid(nmn_columns* c, uint64_t word0, ui
     return NMN_OK;
 }
 
-extern "C" nmn_status nmn_columns_eval(nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
-                                       uint64_t n_consts, uint64_t n_rows, uint64_t* count_out) {
-    if (!c || !prog || n_ops == 0 || !count_out || (n_consts && !consts))
-        return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(c->mu);
-    if (n_rows > c->cap) return set_error(NMN_ERR_CAPACITY, "n_rows beyond capacity_rows");
-    // validate the program on the host: column ids, constant ranges, stack discipline
-    std::vector<DevOp> dops(n_ops);
+// validate a program on the host (column ids, constant ranges, stack discipline) and resolve its column pointers
+static nmn_status pred_compile(const nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, uint64_t n_consts,
+                               std::vector<DevOp>* out) {
+    std::vector<DevOp>& dops = *out;
+    dops.resize(n_ops);
     int64_t depth = 0;
     for (uint32_t i = 0; i < n_ops; i++) {
         const nmn_pred_op& o = prog[i];
@@ -393,35 +416,137 @@ extern "C" nmn_status nmn_columns_eval(nmn_columns* c, const nmn_pred_op* prog, 
         dops[i] = d;
     }
     if (depth != 1) return set_error(NMN_ERR_INVALID_ARGUMENT, "program: must leave exactly one value");
-    *count_out = 0;
-    if (n_rows == 0) return NMN_OK;
-    COL_TRY(hipSetDevice(c->device));
+    return NMN_OK;
+}
+
+// upload the program, run the predicate and the count reduction on `s`, wait, return the number of selected rows.
+// `*prog_buf` (device staging, grown as needed), `count` (1 + kPredMaxBlocks words) and `mask` belong to the caller.
+static nmn_status pred_run(nmn_columns* c, const std::vector<DevOp>& dops, const uint64_t* consts, uint64_t n_consts,
+                           uint64_t n_rows, hipStream_t s, uint8_t** prog_buf, size_t* prog_cap, unsigned long long* count,
+                           uint64_t* mask, uint64_t* count_out, uint8_t** pin = nullptr, size_t* pin_cap = nullptr) {
+    const uint32_t n_ops = (uint32_t)dops.size();
     const size_t ops_bytes = (size_t)n_ops * sizeof(DevOp), need = ops_bytes + (size_t)n_consts * 8 + 8;
-    if (need > c->prog_cap) {
-        if (c->prog) COL_TRY(hipFree(c->prog));
-        c->prog = nullptr;
-        c->prog_cap = 0;
-        COL_TRY(hipMalloc(reinterpret_cast<void**>(&c->prog), need * 2));
-        c->prog_cap = need * 2;
+    if (need > *prog_cap) {
+        if (*prog_buf) COL_TRY(hipFree(*prog_buf));
+        *prog_buf = nullptr;
+        *prog_cap = 0;
+        COL_TRY(hipMalloc(reinterpret_cast<void**>(prog_buf), need * 2));
+        *prog_cap = need * 2;
     }
-    hipStream_t s = c->stream;
-    // one H2D copy for the program and its constants
-    std::vector<uint8_t> staging(ops_bytes + (size_t)n_consts * 8);
-    memcpy(staging.data(), dops.data(), ops_bytes);
-    if (n_consts) memcpy(staging.data() + ops_bytes, consts, (size_t)n_consts * 8);
-    COL_TRY(hipMemcpyAsync(c->prog, staging.data(), staging.size(), hipMemcpyHostToDevice, s));
+    // one H2D copy for the program and its constants — through pinned memory when the caller has some (concurrent
+    // evaluations: pageable copies serialise in the runtime)
+    const size_t stage_bytes = ops_bytes + (size_t)n_consts * 8;
+    std::vector<uint8_t> staging;
+    uint8_t* stage = nullptr;
+    unsigned long long* cnt_host = nullptr;
+    unsigned long long cnt_local = 0;
+    if (pin) {
+        if (8 + stage_bytes > *pin_cap) {
+            if (*pin) (void)hipHostFree(*pin);
+            *pin = nullptr;
+            *pin_cap = 0;
+            COL_TRY(hipHostMalloc(reinterpret_cast<void**>(pin), (8 + stage_bytes) * 2, hipHostMallocDefault));
+            *pin_cap = (8 + stage_bytes) * 2;
+        }
+        cnt_host = reinterpret_cast<unsigned long long*>(*pin);
+        stage = *pin + 8;
+    } else {
+        staging.resize(stage_bytes);
+        stage = staging.data();
+        cnt_host = &cnt_local;
+    }
+    memcpy(stage, dops.data(), ops_bytes);
+    if (n_consts) memcpy(stage + ops_bytes, consts, (size_t)n_consts * 8);
+    COL_TRY(hipMemcpyAsync(*prog_buf, stage, stage_bytes, hipMemcpyHostToDevice, s));
     const uint64_t n_words = (n_rows + 63) / 64;
     const uint64_t wave_trips = (n_words + kPredUnroll - 1) / kPredUnroll;  // one trip = kPredUnroll words of one wave
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((wave_trips + 3) / 4, kPredMaxBlocks);
-    hipLaunchKernelGGL(pred_eval_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const DevOp*>(c->prog), n_ops,
-                       reinterpret_cast<const uint64_t*>(c->prog + ops_bytes), c->valid, n_rows, c->mask, c->count + 1);
+    hipLaunchKernelGGL(pred_eval_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const DevOp*>(*prog_buf), n_ops,
+                       reinterpret_cast<const uint64_t*>(*prog_buf + ops_bytes), c->valid, n_rows, mask, count + 1);
     COL_TRY(hipGetLastError());
-    hipLaunchKernelGGL(count_reduce_kernel, dim3(1), dim3(256), 0, s, c->count + 1, blocks, c->count);
+    hipLaunchKernelGGL(count_reduce_kernel, dim3(1), dim3(256), 0, s, count + 1, blocks, count);
     COL_TRY(hipGetLastError());
-    unsigned long long cnt = 0;
-    COL_TRY(hipMemcpyAsync(&cnt, c->count, 8, hipMemcpyDeviceToHost, s));
+    COL_TRY(hipMemcpyAsync(cnt_host, count, 8, hipMemcpyDeviceToHost, s));
     COL_TRY(hipStreamSynchronize(s));  // also keeps `staging` alive until the H2D copy has been consumed
-    *count_out = cnt;
+    *count_out = *cnt_host;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_eval(nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
+                                       uint64_t n_consts, uint64_t n_rows, uint64_t* count_out) {
+    if (!c || !prog || n_ops == 0 || !count_out || (n_consts && !consts))
+        return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_rows > c->cap) return set_error(NMN_ERR_CAPACITY, "n_rows beyond capacity_rows");
+    std::vector<DevOp> dops;
+    nmn_status st = pred_compile(c, prog, n_ops, n_consts, &dops);
+    if (st != NMN_OK) return st;
+    *count_out = 0;
+    if (n_rows == 0) return NMN_OK;
+    COL_TRY(hipSetDevice(c->device));
+    return pred_run(c, dops, consts, n_consts, n_rows, c->stream, &c->prog, &c->prog_cap, c->count, c->mask, count_out);
+}
+
+extern "C" nmn_status nmn_columns_eval_acquire(nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops,
+                                               const uint64_t* consts, uint64_t n_consts, uint64_t n_rows,
+                                               uint64_t* count_out, uint32_t* slot_out, const uint64_t** mask_out) {
+    if (!c || !prog || n_ops == 0 || !count_out || !slot_out || !mask_out || (n_consts && !consts))
+        return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *count_out = 0;
+    *mask_out = nullptr;
+    if (n_rows > c->cap) return set_error(NMN_ERR_CAPACITY, "n_rows beyond capacity_rows");
+    COL_TRY(hipSetDevice(c->device));
+    std::vector<DevOp> dops;
+    nmn_columns::EvalSlot* slot = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        nmn_status st = pred_compile(c, prog, n_ops, n_consts, &dops);
+        if (st != NMN_OK) return st;
+        for (;;) {
+            for (size_t i = 0; i < c->slots.size() && !slot; i++)
+                if (!c->slots[i]->busy) {
+                    slot = c->slots[i].get();
+                    *slot_out = (uint32_t)i;
+                }
+            if (slot || c->slots.size() < nmn_columns::kMaxSlots) break;
+            c->slot_cv.wait(lk);
+        }
+        if (!slot) {
+            auto fresh = std::make_unique<nmn_columns::EvalSlot>();
+            hipError_t e = hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&fresh->count), (1 + (size_t)kPredMaxBlocks) * 8);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&fresh->mask), (c->words + 1) * 8);
+            if (e != hipSuccess) {
+                if (fresh->stream) (void)hipStreamDestroy(fresh->stream);
+                if (fresh->count) (void)hipFree(fresh->count);
+                if (fresh->mask) (void)hipFree(fresh->mask);
+                return nmn::set_error_hip(e, "predicate slot");
+            }
+            *slot_out = (uint32_t)c->slots.size();
+            c->slots.push_back(std::move(fresh));
+            slot = c->slots.back().get();
+        }
+        slot->busy = true;
+    }
+    nmn_status st = NMN_OK;
+    if (n_rows) st = pred_run(c, dops, consts, n_consts, n_rows, slot->stream, &slot->prog, &slot->prog_cap, slot->count,
+                              slot->mask, count_out, &slot->pin, &slot->pin_cap);
+    if (st != NMN_OK) {
+        std::lock_guard<std::mutex> g(c->mu);
+        slot->busy = false;
+        c->slot_cv.notify_one();
+        return st;
+    }
+    *mask_out = slot->mask;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_columns_eval_release(nmn_columns* c, uint32_t slot) {
+    if (!c) return set_error(NMN_ERR_INVALID_ARGUMENT, "null columns");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (slot >= c->slots.size() || !c->slots[slot]->busy) return set_error(NMN_ERR_INVALID_ARGUMENT, "slot not held");
+    c->slots[slot]->busy = false;
+    c->slot_cv.notify_one();
     return NMN_OK;
 }
 

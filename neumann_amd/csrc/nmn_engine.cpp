@@ -294,7 +294,7 @@ struct nmn_engine {
     std::map<std::string, CollectionConfig> configs;  // `collections` map (configured ones only)
     uint64_t mirror_builds = 0;
     uint64_t column_builds = 0;    // metadata column sets built from the store
-    uint64_t device_filters = 0;   // predicates evaluated by the GPU kernel
+    std::atomic<uint64_t> device_filters{0};   // predicates evaluated by the GPU kernel (bumped under the shared lock too)
     std::unordered_map<uint64_t, std::unique_ptr<Mirror>> scratch;  // compute_similarity, by dim
 
     Collection* storage(const char* coll, bool create) {
@@ -588,8 +588,8 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
     uint32_t count = 0;
     nmn_status st;
     if (selected) {
-        st = nmn_index_search_dmask(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, selected->mask_dev,
-                                    out_rows.data(), out_scores.data(), &count, nullptr);
+        st = nmn_index_search_dmask_hint(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, selected->mask_dev, selected->count,
+                                         out_rows.data(), out_scores.data(), &count, nullptr);
     } else {
         // deleted rows stay in the matrix until the next rebuild: the live bitmap keeps them out of every scan
         st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, m->n_dead ? m->live.data() : nullptr,
@@ -783,25 +783,52 @@ Code compile_filter(const nmn_filter& f, const Mirror& m, Program& p) {
 
 // Pre-filter strategy (lib.rs:3514-3557 / 1776-1796): the predicate runs on the GPU over the mirror's
 // metadata columns and leaves the selection bitmap in HBM; the masked scan reads it in place.  Exact.
+// A filtered search first runs under the SHARED lock (so that many of them overlap: each predicate evaluation gets a
+// bitmap of its own, and the searches that consume them share corpus sweeps); anything that would have to change the
+// engine — building the mirror or its metadata columns — makes it return this and run again under the exclusive lock.
+constexpr nmn_status kRetryExclusive = 0x7e7e;
+
 nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k,
-                             const nmn_filter& f, const char* op, const Deadline& dl, nmn_results* res) {
+                             const nmn_filter& f, const char* op, const Deadline& dl, nmn_results* res, bool shared) {
     Mirror* m = nullptr;
-    nmn_status st = get_mirror(e, c, dim, &m);
-    if (st != NMN_OK) return st;
+    if (shared) {
+        auto it = c->mirrors.find(dim);
+        if (it == c->mirrors.end()) return kRetryExclusive;
+        m = it->second.get();
+        if (m->idx && !m->cols) return kRetryExclusive;
+    } else {
+        nmn_status st = get_mirror(e, c, dim, &m);
+        if (st != NMN_OK) return st;
+    }
     if (!m->idx) return NMN_OK;
-    st = columns_build(e, c, m);
+    nmn_status st = shared ? NMN_OK : columns_build(e, c, m);
     if (st != NMN_OK) return st;
     Program p;
     Code code = compile_filter(f, *m, p);
     p.ops = std::move(code.ops);
     DeviceSelection sel{nullptr, 0};
-    st = nmn_columns_eval(m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(),
-                          m->row_to_slot.size(), &sel.count);
+    uint32_t slot = 0;
+    st = nmn_columns_eval_acquire(m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(),
+                                  m->row_to_slot.size(), &sel.count, &slot, &sel.mask_dev);
     if (st != NMN_OK) return err_gpu(st);
     e->device_filters++;
-    if (sel.count == 0) return NMN_OK;  // `if matching_keys.is_empty() { return Vec::new() }`
-    sel.mask_dev = nmn_columns_mask_device(m->cols);
-    return search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &sel, m, res);
+    st = NMN_OK;
+    if (sel.count != 0)  // else `if matching_keys.is_empty() { return Vec::new() }`
+        st = search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &sel, m, res);
+    (void)nmn_columns_eval_release(m->cols, slot);
+    return st;
+}
+
+// search_common for the post-filter arm: under the shared lock only when the mirror exists already
+nmn_status search_common_mode(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
+                              const char* op, const Deadline& dl, nmn_results* res, bool shared) {
+    Mirror* prebuilt = nullptr;
+    if (shared) {
+        auto it = c->mirrors.find(dim);
+        if (it == c->mirrors.end()) return kRetryExclusive;
+        prebuilt = it->second.get();
+    }
+    return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, prebuilt, res);
 }
 
 }  // namespace
@@ -1505,37 +1532,43 @@ nmn_status nmn_engine_search_similar_filtered(nmn_engine* e, const float* q, uin
     nmn_filtered_config cfg;
     if (config) cfg = *config;
     else nmn_filtered_config_default(&cfg);
-    nmn_results* res = new_results();
-    if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
-    WriteLock g(e);
-    int strategy = cfg.strategy == NMN_FILTER_AUTO ? choose_strategy(&e->dflt, *filter, cfg) : cfg.strategy;
-    if (dl.expired()) {
-        delete res;
-        return err_timeout("search_similar_filtered", dl.ms);
-    }
-    if (strategy == NMN_FILTER_POST) {
-        // search_with_post_filter (lib.rs:3560-3579): search_similar(k * oversample) then filter, take k
-        uint64_t over = top_k * cfg.oversample_factor;
-        if (cfg.oversample_factor && over / cfg.oversample_factor != top_k) over = UINT64_MAX;  // saturating_mul
-        over = std::max(over, top_k);
-        nmn_results cand;
-        if (!zero_magnitude(q, dim)) {
-            st = search_common(e, &e->dflt, q, dim, over, NMN_METRIC_COSINE, "search_similar", dl, nullptr, nullptr, &cand);
-            if (st != NMN_OK) {
-                delete res;
-                return st;
-            }
-        }
-        post_filter(&e->dflt, *filter, &cand, top_k, true, res);
-    } else if (!zero_magnitude(q, dim)) {  // search_with_pre_filter (lib.rs:3520-3523)
-        st = pre_filter_search(e, &e->dflt, q, dim, top_k, *filter, "search_similar_filtered", dl, res);
-        if (st != NMN_OK) {
+    auto run = [&](bool shared) -> nmn_status {
+        nmn_results* res = new_results();
+        if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
+        int strategy = cfg.strategy == NMN_FILTER_AUTO ? choose_strategy(&e->dflt, *filter, cfg) : cfg.strategy;
+        if (dl.expired()) {
             delete res;
-            return st;
+            return err_timeout("search_similar_filtered", dl.ms);
         }
+        nmn_status rs = NMN_OK;
+        if (strategy == NMN_FILTER_POST) {
+            // search_with_post_filter (lib.rs:3560-3579): search_similar(k * oversample) then filter, take k
+            uint64_t over = top_k * cfg.oversample_factor;
+            if (cfg.oversample_factor && over / cfg.oversample_factor != top_k) over = UINT64_MAX;  // saturating_mul
+            over = std::max(over, top_k);
+            nmn_results cand;
+            if (!zero_magnitude(q, dim))
+                rs = search_common_mode(e, &e->dflt, q, dim, over, NMN_METRIC_COSINE, "search_similar", dl, &cand, shared);
+            if (rs == NMN_OK) post_filter(&e->dflt, *filter, &cand, top_k, true, res);
+        } else if (!zero_magnitude(q, dim)) {  // search_with_pre_filter (lib.rs:3520-3523)
+            rs = pre_filter_search(e, &e->dflt, q, dim, top_k, *filter, "search_similar_filtered", dl, res, shared);
+        }
+        if (rs != NMN_OK) {
+            delete res;
+            return rs;
+        }
+        *out = res;
+        return NMN_OK;
+    };
+    {
+        ReadLock rd(e);
+        st = run(true);
     }
-    *out = res;
-    return NMN_OK;
+    if (st == kRetryExclusive) {
+        WriteLock g(e);
+        st = run(false);
+    }
+    return st;
 }
 
 nmn_status nmn_engine_compute_similarity(nmn_engine* e, const float* a, uint64_t na, const float* b, uint64_t nb,
@@ -1672,7 +1705,7 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
     nmn_filtered_config cfg;
     if (config) cfg = *config;
     else nmn_filtered_config_default(&cfg);
-    WriteLock g(e);
+    auto run = [&](bool shared) -> nmn_status {
     auto cit = e->configs.find(coll);
     int32_t coll_metric = NMN_METRIC_COSINE;
     if (cit != e->configs.end()) {
@@ -1709,10 +1742,10 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
         if (cfg.oversample_factor && over / cfg.oversample_factor != top_k) over = UINT64_MAX;
         over = std::max(over, top_k);
         nmn_results cand;
-        st = search_common(e, c, q, dim, over, coll_metric, "search_in_collection", dl, nullptr, nullptr, &cand);
-        if (st != NMN_OK) {
+        nmn_status rs = search_common_mode(e, c, q, dim, over, coll_metric, "search_in_collection", dl, &cand, shared);
+        if (rs != NMN_OK) {
             delete res;
-            return st;
+            return rs;
         }
         post_filter(c, *filter, &cand, top_k, false, res);
         if (res->keys.size() > top_k) {  // results.truncate(top_k) — candidates are already sorted
@@ -1720,10 +1753,10 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
             res->scores.resize(top_k);
         }
     } else {
-        st = pre_filter_search(e, c, q, dim, top_k, *filter, "search_filtered_in_collection", dl, res);
-        if (st != NMN_OK) {
+        nmn_status rs = pre_filter_search(e, c, q, dim, top_k, *filter, "search_filtered_in_collection", dl, res, shared);
+        if (rs != NMN_OK) {
             delete res;
-            return st;
+            return rs;
         }
     }
     if (dl.expired()) {
@@ -1732,6 +1765,16 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
     }
     *out = res;
     return NMN_OK;
+    };
+    {
+        ReadLock rd(e);
+        st = run(true);
+    }
+    if (st == kRetryExclusive) {
+        WriteLock g(e);
+        st = run(false);
+    }
+    return st;
 }
 
 // ---- results / lists / filters -------------------------------------------------------------------

@@ -66,6 +66,7 @@ struct HostReq {
     int metric;
     const uint64_t* mask;
     bool mask_on_device;
+    uint64_t mask_rows;  // rows the mask selects when the caller knows (UINT64_MAX: unknown), for the mixing decision
     uint64_t* out_rows;
     float* out_scores;
     uint32_t* out_counts;
@@ -131,7 +132,7 @@ namespace nmn {
 // nmn_index_search / nmn_index_search_dmask with the internal metrics allowed (host queries and outputs)
 nmn_status index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
                                const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
-                               uint32_t* out_counts, nmn_search_stats* stats);
+                               uint32_t* out_counts, nmn_search_stats* stats, uint64_t mask_rows = UINT64_MAX);
 
 // nmn_index_search_device with the internal metrics allowed (everything in device memory, asynchronous)
 nmn_status index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric,

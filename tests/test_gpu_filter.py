@@ -371,3 +371,52 @@ def test_engine_prefilter_in_collection_and_no_metadata(E):
         plain.store_embedding(f"k{i}", A[i])
     check_filtered(E, plain, A[:50], [{}] * 50, [True] * 50, q, 5, ("true",))
     check_filtered(E, plain, A[:50], [{}] * 50, [True] * 50, q, 5, ("exists", "g"))
+
+
+def test_engine_concurrent_prefiltered_searches_share_sweeps(E):
+    """Filtered searches of many threads run under the engine's shared lock: each predicate evaluation gets its own
+    device bitmap, and the searches consuming them merge into query batches with one bitmap per query.  Every thread
+    must get exactly the answer of its own filter (checked against the oracle)."""
+    import threading
+    rng = np.random.default_rng(91)
+    n, d, k = 6000, 768, 15                      # 768: batches take the matrix-core sweep from 3 queries
+    A = rng.standard_normal((n, d)).astype(F)
+    metas = [random_meta(rng) for _ in range(n)]
+    live = [True] * n
+    engine = E.VectorEngine()
+    for i in range(n):
+        engine.store_embedding_with_metadata(f"k{i}", A[i], metas[i])
+    conds = [random_cond(rng) for _ in range(48)]
+    qs = rng.standard_normal((48, d)).astype(F)
+    cfg = E.FilteredSearchConfig.pre_filter()
+    engine.search_similar_filtered(qs[0], k, to_fc(E, conds[0]), cfg)     # builds mirror + columns (exclusive lock)
+    fcs = [to_fc(E, c) for c in conds]
+    out = [None] * 48
+    errs = []
+    start = threading.Barrier(16)
+
+    def work(t):
+        try:
+            start.wait()
+            for rep in range(3):
+                for j in range(t, 48, 16):
+                    out[j] = engine.search_similar_filtered(qs[j], k, fcs[j], cfg)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    assert engine.column_builds() == 1 and engine.mirror_builds() == 1
+    assert engine.device_filter_evals() == 1 + 48 * 3
+    for j in range(48):
+        keep = np.array([fo.evaluate(metas[i], conds[j]) for i in range(n)], bool)
+        if not keep.any():
+            assert out[j] == []
+            continue
+        er, es = oc.search(A, qs[j], k, 0, mask=oc.mask_from_bool(keep))
+        assert [r.key for r in out[j]] == [f"k{i}" for i in er], conds[j]
+        assert np.all(np.array([r.score for r in out[j]], F) == es), conds[j]

@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     const int per = argc > 4 ? atoi(argv[4]) : 200;
     nmn_engine_config cfg;
     nmn_engine_config_default(&cfg);
+    const int filtered = getenv("ENGINE_MT_FILTER") ? atoi(getenv("ENGINE_MT_FILTER")) : 0;
     nmn_engine* e = nullptr;
     if (nmn_engine_create(&cfg, &e) != 0) { printf("create failed: %s\n", nmn_engine_last_error()); return 1; }
     const uint64_t chunk = 50000;
@@ -29,13 +30,36 @@ int main(int argc, char** argv) {
         const uint64_t n = std::min(chunk, rows - r0);
         nmn_synth_fill_host(buf.data(), 7, r0, n, dim);
         for (uint64_t i = 0; i < n; i++) { names[i] = "k" + std::to_string(r0 + i); keys[i] = names[i].c_str(); }
-        if (nmn_engine_batch_store(e, keys.data(), buf.data(), n, dim) != 0) { printf("store failed\n"); return 1; }
+        if (filtered) {
+            // ENGINE_MT_FILTER=B: every row carries bucket = row % B; thread t searches WHERE bucket = t % B (pre-filter)
+            for (uint64_t i = 0; i < n; i++) {
+                nmn_meta_field mf;
+                mf.name = "bucket";
+                mf.value.kind = NMN_VAL_INT;
+                mf.value.b = 0;
+                mf.value.i = (int64_t)((r0 + i) % (uint64_t)filtered);
+                mf.value.f = 0.0;
+                mf.value.s = nullptr;
+                if (nmn_engine_store_embedding_with_metadata(e, keys[i], buf.data() + i * dim, dim, &mf, 1) != 0) { printf("store failed\n"); return 1; }
+            }
+        } else if (nmn_engine_batch_store(e, keys.data(), buf.data(), n, dim) != 0) { printf("store failed\n"); return 1; }
     }
     std::vector<float> Q((size_t)64 * dim);
     nmn_synth_fill_host(Q.data(), 8, 0, 64, dim);
     nmn_results* r = nullptr;
     if (nmn_engine_search_similar(e, Q.data(), dim, k, &r) != 0) { printf("search failed: %s\n", nmn_engine_last_error()); return 1; }
     nmn_results_free(r);
+    if (filtered) {  // first filtered search builds the metadata columns
+        nmn_value v;
+        v.kind = NMN_VAL_INT; v.b = 0; v.i = 0; v.f = 0.0; v.s = nullptr;
+        nmn_filter* f0 = nmn_filter_cmp(NMN_OP_EQ, "bucket", &v);
+        nmn_filtered_config fc;
+        nmn_filtered_config_default(&fc);
+        fc.strategy = NMN_FILTER_PRE;
+        if (nmn_engine_search_similar_filtered(e, Q.data(), dim, k, f0, &fc, &r) != 0) { printf("filtered search failed: %s\n", nmn_engine_last_error()); return 1; }
+        nmn_results_free(r);
+        nmn_filter_free(f0);
+    }
     for (int a = 5; a < argc; a++) {
         const int nt = atoi(argv[a]);
         std::atomic<int> bad{0};
@@ -61,13 +85,28 @@ int main(int argc, char** argv) {
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++)
             th.emplace_back([&, t] {
+                nmn_filter* flt = nullptr;
+                nmn_filtered_config fc;
+                nmn_filtered_config_default(&fc);
+                fc.strategy = NMN_FILTER_PRE;
+                if (filtered) {
+                    nmn_value v;
+                    v.kind = NMN_VAL_INT;
+                    v.b = 0;
+                    v.i = t % filtered;
+                    v.f = 0.0;
+                    v.s = nullptr;
+                    flt = nmn_filter_cmp(NMN_OP_EQ, "bucket", &v);
+                }
                 for (int i = 0; i < per; i++) {
                     nmn_results* rr = nullptr;
-                    if (nmn_engine_search_similar(e, Q.data() + (size_t)((t * per + i) % 64) * dim, dim, k, &rr) != 0 ||
-                        nmn_results_len(rr) < std::min<uint64_t>(k, rows))
-                        bad++;
+                    const float* q = Q.data() + (size_t)((t * per + i) % 64) * dim;
+                    const nmn_status st = filtered ? nmn_engine_search_similar_filtered(e, q, dim, k, flt, &fc, &rr)
+                                                   : nmn_engine_search_similar(e, q, dim, k, &rr);
+                    if (st != 0 || nmn_results_len(rr) < std::min<uint64_t>(k, filtered ? rows / filtered : rows)) bad++;
                     nmn_results_free(rr);
                 }
+                if (flt) nmn_filter_free(flt);
             });
         for (auto& x : th) x.join();
         stop = true;
