@@ -114,9 +114,7 @@ bool scan_half_supported(uint32_t ld, int metric);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
-uint32_t scan_mfma_queries_per_sweep(uint32_t ld);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
-// (re)build rows [row0,row0+n) of the split-bf16 mirror from the f32 corpus
 
 struct SelectParams {
     const uint32_t* scores;  // score_at(row, q, nql)

@@ -43,7 +43,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef short s8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaQ = 64;       // queries per sweep when 4 query groups fit the registers (dim <= 768)
 constexpr int kStageK = 128;     // granularity of the row length this kernel accepts (elements)
 // A stage is [64 rows][128*KS bf16] (KS = 1 or 2 k-steps per wave and stage): 16 KiB or 32 KiB.  Rows whose length is a
 // multiple of 256 use KS = 2: half as many stage hand-overs (a counted wait and a workgroup barrier each) per byte.
@@ -410,12 +409,6 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
         return false;
     const uint32_t kc = ld / kStageK;
     return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12;
-}
-
-// queries one corpus sweep of the MFMA kernel serves at this row length
-uint32_t scan_mfma_queries_per_sweep(uint32_t ld) {
-    (void)ld;
-    return 64u;
 }
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
