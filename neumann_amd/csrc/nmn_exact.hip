@@ -222,7 +222,6 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         // What the approximate sweep adds on top of f32 summation error, relative to |q||v|.  The margin is applied ONCE
         // below the k-th approximate score and must cover the error twice (k rows with approx >= T have exact >= T - e, so
         // the exact k-th is >= T - e, and a row with exact >= T - e has approx >= T - 2e).
-        //   split-bf16 MFMA sweep: e = 2^-15 per product -> 2^-14;
         //   bf16 mirror: row r is stored as v + e_r, so |dot error| = |q . e_r| <= |q||e_r| <= |q||v_r| * rho with
         //   rho = max_r |e_r| / |v_r| MEASURED when the mirror was written (<= 2^-8, typically 0.4 * 2^-8) -> 2 rho.
         float split = 0.0f, half_abs = 0.0f;
