@@ -144,7 +144,7 @@ struct IdleGuard {
 
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qinfo_f32, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+    void* ptrs[] = {w->crowd_ctr, w->crowd_rows, w->crowd_scores, w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qinfo_f32, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
                     w->h_counts2, w->lk_keys};
     for (void* p : ptrs)
@@ -222,6 +222,11 @@ static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32
     return NMN_OK;
 }
 
+// Crowd path (nmn_select.hip, CrowdParams): shards of at least 2^18 rows — below, the exact scan of everything costs
+// less than the three extra launches — with a pool of 4M (row, score) pairs per workspace (32 MiB).
+constexpr uint64_t kCrowdMinRows = 1ull << 18;
+constexpr uint64_t kCrowdPool = 4ull << 20;
+
 static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     if (w->scores) return NMN_OK;
     w->ld = idx->ld;
@@ -243,6 +248,13 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_rows), nq * w->cand_cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->h_counts2), 2 * sizeof(unsigned long long)));
+    if (idx->cap_pad >= kCrowdMinRows) {
+        w->crowd_cap = (uint32_t)std::min<uint64_t>(kCrowdPool, idx->cap_pad);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_ctr), 3 * nq * 4));
+        HIP_TRY(hipMemset(w->crowd_ctr, 0, 3 * nq * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_rows), (size_t)w->crowd_cap * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_scores), (size_t)w->crowd_cap * 4));
+    }
     for (auto& e : w->ev) HIP_TRY(hipEventCreate(&e));
     return NMN_OK;
 }
@@ -671,6 +683,25 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel.k_extra = w->k_extra;
             }
             HIP_TRY(launch_select(sel, stream));
+            const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && getenv("NMN_NO_CROWD") == nullptr;
+            if (crowd) {  // three launches that return at once unless a candidate list overflowed
+                CrowdParams cp{};
+                cp.qstate = w->qstate;
+                cp.tmax = w->tmax;
+                cp.tmax_stride = w->tmax_stride;
+                cp.scores = w->scores;
+                cp.nql = nqc;
+                cp.nq = nqc;
+                cp.n_tiles = n_tiles;
+                cp.n_rows = n_rows;
+                cp.count = w->crowd_ctr;
+                cp.offset = w->crowd_ctr + w->nq_cap;
+                cp.fill = w->crowd_ctr + 2 * (size_t)w->nq_cap;
+                cp.pool_rows = w->crowd_rows;
+                cp.pool_scores = w->crowd_scores;
+                cp.pool_cap = w->crowd_cap;
+                HIP_TRY(launch_crowd_collect(cp, stream));
+            }
             if (f32_retry) {  // both launches return at once for queries whose first selection did not overflow
                 ScanParams sr = sp;
                 sr.corpus_half = nullptr;
@@ -693,6 +724,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             rp.cand_scores = w->cand_scores;
             rp.mask = mask_dev;       // fallback duty of the same launch
             rp.qmasks = qmasks_dev ? qmasks_dev + qa : nullptr;
+            rp.crowd_offset = w->crowd_ctr ? w->crowd_ctr + w->nq_cap : nullptr;
+            rp.crowd_rows = w->crowd_rows;
+            rp.crowd_scores = w->crowd_scores;
             rp.scores = w->scores;
             rp.n_rows = n_rows;
             rp.nql = nqc;
@@ -704,6 +738,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             HIP_TRY(launch_rescore(rp, stream));
         }
         FinalParams fp{};
+        fp.crowd_offset = w->crowd_ctr ? w->crowd_ctr + w->nq_cap : nullptr;
+        fp.crowd_rows = w->crowd_rows;
+        fp.crowd_scores = w->crowd_scores;
         fp.cand_rows = w->cand_rows;
         fp.cand_scores = w->cand_scores;
         fp.qstate = w->qstate;
@@ -771,7 +808,7 @@ static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* 
     if (nqc) HIP_TRY(hipMemcpy(qs.data(), w->qstate, nqc * sizeof(QState), hipMemcpyDeviceToHost));
     for (auto& q : qs) {
         stats->candidates_rescored = std::max(stats->candidates_rescored, q.cand_count);
-        stats->fallback_queries += q.overflow ? 1 : 0;
+        stats->fallback_queries += q.overflow == 1 ? 1 : 0;  // 2 = crowd list: re-scored like candidates, just more of them
     }
     stats->rows_scanned = w->last_rows_scanned;  // upper bound when masked (excluded rows are skipped)
     stats->bytes_scanned = w->last_rows_scanned * (uint64_t)idx->dim * (uint64_t)w->last_elem_bytes;

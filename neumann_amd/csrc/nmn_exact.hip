@@ -299,6 +299,20 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
     const uint32_t l = threadIdx.x & 7u;
     const float* qv = p.qpad + (size_t)q * p.ld;
     const float qmag = p.qinfo[q].qmag;
+    if (p.qstate[q].overflow == 2) {
+        // crowd duty: exact score of every row of the query's slice (32 per workgroup step)
+        const uint32_t count = p.qstate[q].cand_count;
+        const uint32_t* rows = p.crowd_rows + p.crowd_offset[q];
+        float* out = p.crowd_scores + p.crowd_offset[q];
+        for (uint32_t c0 = blockIdx.x * 32u; c0 < count; c0 += gridDim.x * 32u) {
+            const uint32_t c = c0 + (threadIdx.x >> 3);
+            const uint32_t row = rows[c < count ? c : count - 1];  // keep every 8-lane group converged
+            const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+            const float sc = exact_score(qv, p.corpus + (uint64_t)row * p.ld, p.dim, qmag, vmag, p.metric, l);
+            if (c < count && l == 0) out[c] = sc;
+        }
+        return;
+    }
     if (p.qstate[q].overflow) {
         const uint64_t* mask = p.qmasks ? p.qmasks[q] : p.mask;
         const uint64_t n_pad = (p.n_rows + 63) & ~63ull;

@@ -27,6 +27,12 @@ struct Workspace {
     uint32_t* tsample = nullptr;   // [nq][n_sample_cap] tile maxima of the sampling pass (batched sweep)
     uint32_t* skip_key = nullptr;  // [nq] score-write threshold of the batched sweep
     uint32_t* k_extra = nullptr;   // [1] rows forced into the candidates (f64 artifact similarity)
+    // crowd path (CrowdParams): per-query counters [3][nq] and the shared pool of (row, exact score) pairs; only on
+    // shards large enough for the exact scan of everything to hurt
+    uint32_t* crowd_ctr = nullptr;
+    uint32_t* crowd_rows = nullptr;
+    float* crowd_scores = nullptr;
+    uint32_t crowd_cap = 0;
     uint64_t n_sample_cap = 0;
     uint64_t tmax_stride = 0;
     float* qpad = nullptr;

@@ -40,7 +40,8 @@ struct QInfo {
 // Per-query selection state shared by select / fallback / rescore / final.
 struct QState {
     uint32_t cand_count;  // candidates written to cand_rows
-    uint32_t overflow;    // 1 = candidate list overflowed -> exact fallback takes over
+    uint32_t overflow;    // 1 = candidate list overflowed -> exact fallback takes over; 2 = overflowed, but every row
+                          // within the margin went to the crowd list (CrowdParams) and is re-scored from there
     uint32_t n_valid;     // participating keys seen by select (rows or tiles)
     uint32_t thr_key;     // collection threshold key (diagnostics)
 };
@@ -144,7 +145,31 @@ hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t*
 hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uint32_t n_sample, const QInfo* qinfo,
                                uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s);
 
+// Crowd path: a query with more than cand_cap rows within the margin of its k-th score (masses of duplicates,
+// near-duplicates) does not fall back to the exact scan of the whole shard at once: the rows with approximate key >=
+// the selection's threshold — the only ones that can be in the answer — are written to a slice of a shared pool,
+// re-scored exactly from there, and the top-k is selected among them.  Pool full (or slice too large) -> the query
+// keeps overflow == 1 and takes the f32 retry / exact fallback as before.
+struct CrowdParams {
+    QState* qstate;
+    const uint32_t* tmax;      // [nq][tmax_stride]
+    uint64_t tmax_stride;
+    const uint32_t* scores;    // approximate scores, score_at(row, q, nql)
+    uint32_t nql, nq, n_tiles;
+    uint64_t n_rows;
+    uint32_t* count;           // [nq] rows found (zeroed between searches by the alloc kernel)
+    uint32_t* offset;          // [nq] slice start in the pool
+    uint32_t* fill;            // [nq] append cursor
+    uint32_t* pool_rows;       // [pool_cap]
+    float* pool_scores;        // [pool_cap] exact scores (crowd_rescore)
+    uint32_t pool_cap;
+};
+hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s);  // count -> allocate slices -> fill
+
 struct FinalParams {
+    const uint32_t* crowd_offset;  // nullable: slices of the crowd pool (queries with overflow == 2)
+    const uint32_t* crowd_rows;
+    const float* crowd_scores;
     const uint32_t* cand_rows;   // [nq][cand_cap]
     const float* cand_scores;    // [nq][cand_cap] exact
     QState* qstate;
@@ -180,7 +205,11 @@ struct RescoreParams {
     const QState* qstate;
     const uint32_t* cand_rows;
     float* cand_scores;
-    // exact-fallback duty (queries with qstate.overflow): exact score of EVERY row -> scores
+    // crowd duty (queries with qstate.overflow == 2): exact score of the rows of the query's slice of the crowd pool
+    const uint32_t* crowd_offset;
+    const uint32_t* crowd_rows;
+    float* crowd_scores;
+    // exact-fallback duty (queries with qstate.overflow == 1): exact score of EVERY row -> scores
     const uint64_t* mask;
     const uint64_t* const* qmasks;  // nullable [nq]: per-query bitmaps (see ScanParams)
     uint32_t* scores;

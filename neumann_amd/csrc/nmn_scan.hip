@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
     if (p.retry_state) {  // f32 retry after a bf16 pass: nothing to do unless one of this block's queries overflowed
         bool any = false;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) any = any || (q0 + q < p.nq && p.retry_state[q0 + q].overflow != 0);
+        for (int q = 0; q < NQ; q++) any = any || (q0 + q < p.nq && p.retry_state[q0 + q].overflow == 1);
         if (!any) return;
     }
     {

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t nql = p.nql;
-    if (p.retry && p.qstate[q].overflow == 0) return;  // block-uniform: this query's first selection stood
+    if (p.retry && p.qstate[q].overflow != 1) return;  // block-uniform: this query's first selection stood (or its crowd list did)
     if (p.half_stats && tid == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
     auto score_bits = [&](uint64_t row) -> uint32_t { return p.scores[score_at(row, q, nql)]; };
     const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
@@ -414,6 +414,90 @@ hipError_t launch_select(const SelectParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- crowd path: the rows within the margin, when there are more than cand_cap of them ---------------
+// Walk of the tiles of query q whose maximum reaches Tc (64 tile maxima per wave and step, then the qualifying tiles one
+// by one, 64 rows each): f(row, pred) for every row of such a tile, pred = its approximate key >= Tc.  Tiles below Tc
+// hold no candidate (and, on the matrix-core path, possibly no scores at all: Tc >= skip_key).
+template <class F>
+__device__ __forceinline__ void crowd_walk(const CrowdParams& p, uint32_t q, uint32_t Tc, F&& f) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t t0 = wave * 64; t0 < p.n_tiles; t0 += n_waves * 64) {
+        const uint64_t t = t0 + lane;
+        const uint32_t tk = t < p.n_tiles ? tmax[t] : kKeyMasked;
+        unsigned long long hot = __ballot(tk != kKeyMasked && tk >= Tc);
+        while (hot) {
+            const int b = __builtin_ctzll(hot);
+            hot &= hot - 1;
+            const uint64_t row = (t0 + (uint64_t)b) * kTileRows + lane;
+            const uint32_t key = row < p.n_rows ? bits_to_key(p.scores[score_at(row, q, p.nql)]) : kKeyMasked;
+            f(row, key != kKeyMasked && key >= Tc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void crowd_count_kernel(CrowdParams p) {
+    const uint32_t q = blockIdx.y;
+    const QState st = p.qstate[q];
+    if (st.overflow != 1) return;
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    crowd_walk(p, q, st.thr_key, [&](uint64_t, bool pred) {
+        const unsigned long long m = __ballot(pred);
+        if ((threadIdx.x & 63u) == 0) mine += (uint32_t)__builtin_popcountll(m);
+    });
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) {
+        // saturating: a count beyond the pool is just "too many"
+        const uint32_t old = atomicAdd(&p.count[q], s_cnt);
+        if (old + s_cnt < old) p.count[q] = 0xFFFFFFFFu;
+    }
+}
+
+// slices of the pool, first come first served in query order; resets the counters for the next search
+__global__ void crowd_alloc_kernel(CrowdParams p) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t cursor = 0;
+    for (uint32_t q = 0; q < p.nq; q++) {
+        const uint32_t c = p.count[q];
+        p.count[q] = 0;
+        p.fill[q] = 0;
+        if (p.qstate[q].overflow != 1 || c == 0) continue;
+        // a threshold that lets more than an eighth of the shard through is not a crowd around the query but a useless
+        // margin (one row of enormous norm under a Euclidean metric): that is the f32 retry's case
+        if (c <= p.pool_cap - cursor && (uint64_t)c * 8u <= p.n_rows) {
+            p.offset[q] = cursor;
+            cursor += c;
+            p.qstate[q].overflow = 2;
+            p.qstate[q].cand_count = c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void crowd_fill_kernel(CrowdParams p) {
+    const uint32_t q = blockIdx.y;
+    const QState st = p.qstate[q];
+    if (st.overflow != 2) return;
+    uint32_t* dst = p.pool_rows + p.offset[q];
+    crowd_walk(p, q, st.thr_key, [&](uint64_t row, bool pred) {
+        const uint32_t pos = wave_append(pred, &p.fill[q]);
+        if (pred && pos < st.cand_count) dst[pos] = (uint32_t)row;
+    });
+}
+
+hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s) {
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((p.n_tiles + 64 * 4 - 1) / (64 * 4), 512));
+    hipLaunchKernelGGL(crowd_count_kernel, dim3(gx, p.nq), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crowd_alloc_kernel, dim3(1), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(crowd_fill_kernel, dim3(gx, p.nq), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // ---- exact-fallback selection (device function of final_kernel) ----------------------------------
 // For a query whose candidate list overflowed, rescore_kernel has replaced scores[] by the EXACT score
 // of every row.  Composite keys (score key << 32 | ~row) are unique, so the k-th largest composite is
@@ -456,12 +540,11 @@ __device__ __forceinline__ void walk_scores(const uint32_t* __restrict__ scores,
     }
 }
 
-__device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint32_t q, uint32_t nql, uint64_t n_rows,
-                                      uint32_t k,
-                                      unsigned long long* list, uint32_t* hist, PickResult* pick,
+// `walk(f)`: calls f(row, key) for every element, the same number of times on every lane (key == kKeyMasked: skip).
+template <class Walk>
+__device__ uint32_t exact_select_walk(Walk&& walk, uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
                                       uint32_t* s_misc /* >= 2 words */) {
     const uint32_t tid = threadIdx.x;
-    const uint64_t n_pad = (n_rows + 63) & ~63ull;
     auto comp = [](uint64_t i, uint32_t key) -> unsigned long long {
         return key == kKeyMasked ? 0ull : (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i));
     };
@@ -478,7 +561,7 @@ __device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint3
         __syncthreads();
         const int hi_shift = shifts[d] + widths[d];
         uint32_t loc = 0;
-        walk_scores(scores, q, nql, n_pad, [&](uint64_t i, uint32_t key) {
+        walk([&](uint64_t i, uint32_t key) {
             const unsigned long long c = comp(i, key);
             if (c == 0ull) return;
             loc++;
@@ -504,7 +587,7 @@ __device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint3
     }
     // prefix is now the kk-th largest composite (or the score key of the cut with zero row digits, which
     // admits the same set); collect everything >= it (exactly kk entries)
-    walk_scores(scores, q, nql, n_pad, [&](uint64_t i, uint32_t key) {
+    walk([&](uint64_t i, uint32_t key) {
         const unsigned long long c = comp(i, key);
         const bool pred = c != 0ull && c >= prefix;
         const uint32_t pos = wave_append(pred, &s_misc[1]);
@@ -512,6 +595,28 @@ __device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint3
     });
     __syncthreads();
     return min(s_misc[1], (uint32_t)NMN_MAX_TOP_K);
+}
+
+// the exact scores of every row (exact fallback) ...
+__device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint32_t q, uint32_t nql, uint64_t n_rows,
+                                      uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
+                                      uint32_t* s_misc) {
+    const uint64_t n_pad = (n_rows + 63) & ~63ull;
+    return exact_select_walk([&](auto&& f) { walk_scores(scores, q, nql, n_pad, f); }, k, list, hist, pick, s_misc);
+}
+// ... or of the rows of a crowd slice
+__device__ uint32_t crowd_select_into(const uint32_t* __restrict__ rows, const float* __restrict__ scores, uint32_t n,
+                                      uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
+                                      uint32_t* s_misc) {
+    const uint32_t n_round = (n + kSelThreads - 1) / kSelThreads * kSelThreads;
+    return exact_select_walk(
+        [&](auto&& f) {
+            for (uint32_t e = threadIdx.x; e < n_round; e += kSelThreads) {
+                const bool in = e < n;
+                f(in ? rows[e] : 0u, in ? score_to_key(scores[e]) : kKeyMasked);
+            }
+        },
+        k, list, hist, pick, s_misc);
 }
 
 // ---- final sort: candidates by (exact score desc, row asc) -> top-k ---------------------------
@@ -523,7 +628,11 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     uint32_t n;
-    if (p.qstate[q].overflow) {
+    const uint32_t mode = p.qstate[q].overflow;
+    if (mode == 2) {
+        const uint32_t off = p.crowd_offset[q];
+        n = crowd_select_into(p.crowd_rows + off, p.crowd_scores + off, p.qstate[q].cand_count, p.k, list, hist, &pick, s_misc);
+    } else if (mode) {
         n = exact_select_into(p.scores, q, p.nql, p.n_rows, p.k, list, hist, &pick, s_misc);
         if (tid == 0) p.qstate[q].cand_count = n;
     } else {

@@ -325,3 +325,31 @@ def test_mirror_switches_itself_off_when_its_margin_is_useless():
                 assert counts[0] == k and np.array_equal(rows[0], er) and np.all(scores[0] == es)
                 assert stats.fallback_queries == 0          # the retry, not the exact scan of everything
         assert seen == {2, 4} and stats.bytes_scanned == n * d * 4
+
+
+def test_crowd_of_duplicates_on_a_large_shard_is_resolved_from_the_crowd_list():
+    """20 000 exact copies of one row (far more than the candidate capacity) on a shard large enough for the crowd
+    path: the rows within the margin go to the crowd list, are re-scored exactly there, and the ties at the cut are
+    broken by row id — no exact scan of the whole shard (fallback_queries == 0), answers as the oracle's."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(17)
+    n, d, k = 300_000, 128, 64
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    dup = np.sort(rng.choice(n, 20_000, replace=False))
+    A[dup] = (q * np.float32(1.5)).astype(np.float32)          # identical rows: 20 000 ties at the top
+    near = rng.choice(np.setdiff1d(np.arange(n), dup), 9000, replace=False)
+    A[near] = (q[None, :] * np.float32(1.5) + 1e-3 * rng.standard_normal((9000, d))).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for metric in (0, 1, 2):
+            rows, scores, counts, stats = idx.search(q, k, metric, with_stats=True)
+            er, es = oc.search(A, q, k, metric)
+            assert counts[0] == k and np.array_equal(rows[0], er) and np.all(scores[0] == es), metric
+            assert stats.fallback_queries == 0, metric
+            assert stats.candidates_rescored >= 20_000, (metric, stats.candidates_rescored)
+        Q = np.stack([q, q * np.float32(0.5), rng.standard_normal(d).astype(np.float32), q + np.float32(1e-3)])
+        rows, scores, counts = idx.search(Q, k, 0)
+        for i in range(4):
+            er, es = oc.search(A, Q[i], k, 0)
+            assert np.array_equal(rows[i], er) and np.all(scores[i] == es), i
