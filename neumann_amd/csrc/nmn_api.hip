@@ -223,9 +223,9 @@ static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32
 }
 
 // Crowd path (nmn_select.hip, CrowdParams): shards of at least 2^18 rows — below, the exact scan of everything costs
-// less than the three extra launches — with a pool of 4M (row, score) pairs per workspace (32 MiB).
+// less than the three extra launches — with a pool of 8M (row, score) pairs per workspace (64 MiB).
 constexpr uint64_t kCrowdMinRows = 1ull << 18;
-constexpr uint64_t kCrowdPool = 4ull << 20;
+constexpr uint64_t kCrowdPool = 8ull << 20;
 
 static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     if (w->scores) return NMN_OK;
