@@ -290,6 +290,16 @@ nmn_status nmn_columns_eval_acquire(nmn_columns* cols, const nmn_pred_op* prog, 
                                     uint64_t n_consts, uint64_t n_rows, uint64_t* count_out, uint32_t* slot_out,
                                     const uint64_t** mask_out);
 nmn_status nmn_columns_eval_release(nmn_columns* cols, uint32_t slot);
+/* Filtered search in ONE call: evaluate `prog` over `cols` (rows [0, nmn_index_rows(idx)), same row numbering as the
+ * shard) and search the rows it selects — `search_with_pre_filter` (lib.rs:3514-3557) end to end.  For concurrent
+ * callers this is the fast form: the request coalescer hands the predicates of all the calls riding one query batch
+ * to a single launch on the batch's stream, right before the ONE sweep that serves them (one bitmap per query), so
+ * a filtered search waits for one batch, not for an evaluation and then a batch.  *selected_out (nullable) = rows the
+ * predicate selected; results as nmn_index_search_dmask over that bitmap (k <= NMN_MAX_TOP_K).  queries HOST nq x dim. */
+nmn_status nmn_index_search_pred(nmn_index* idx, nmn_columns* cols, const nmn_pred_op* prog, uint32_t n_ops,
+                                 const uint64_t* consts, uint64_t n_consts, const float* queries, uint32_t nq, uint32_t k,
+                                 nmn_metric metric, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                 uint64_t* selected_out, nmn_search_stats* stats);
 /* Device bitmap of the last nmn_columns_eval, ceil(capacity_rows/64) words. */
 const uint64_t* nmn_columns_mask_device(const nmn_columns* cols);
 /* Device row-validity bitmap (a ready-made mask of the live rows). */

@@ -112,6 +112,8 @@ SIGNATURES = {
     "nmn_columns_eval_acquire": (C.c_int32, [vp, C.POINTER(PredOp), C.c_uint32, vp, C.c_uint64, C.c_uint64, u64p,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
     "nmn_columns_eval_release": (C.c_int32, [vp, C.c_uint32]),
+    "nmn_index_search_pred": (C.c_int32, [vp, vp, C.POINTER(PredOp), C.c_uint32, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32,
+                                          C.c_int32, vp, vp, vp, u64p, C.POINTER(SearchStats)]),
     "nmn_columns_mask_device": (vp, [vp]),
     "nmn_columns_valid_device": (vp, [vp]),
     "nmn_columns_read_mask": (C.c_int32, [vp, vp, C.c_uint64]),

@@ -80,7 +80,7 @@ static int lead_limit(const nmn_index* idx, double selectivity = 1.0) {
     return sweep_bytes >= (double)(256ull << 20) ? 1 : sweep_bytes >= (double)(32ull << 20) ? 2 : nmn_index::kHostSlots;
 }
 static double selectivity_of(const nmn_index* idx, const HostReq& r) {
-    if (!r.mask || r.mask_rows == UINT64_MAX) return 1.0;
+    if (r.pred_cols || !r.mask || r.mask_rows == UINT64_MAX) return 1.0;
     return std::min(1.0, (double)r.mask_rows / (double)std::max<uint64_t>(idx->rows, 1));
 }
 // In-flight limit when `r` is next to lead.  The extra room a selective filter earns is for light load only: with a
@@ -151,6 +151,9 @@ static void ws_free(Workspace* w) {
         if (p) (void)hipFree(p);
     if (w->h_pack) (void)hipFree(w->h_pack);
     if (w->h_qmasks) (void)hipFree(w->h_qmasks);
+    for (void* p : {(void*)w->pred_block, (void*)w->pred_masks, (void*)w->pred_counts})
+        if (p) (void)hipFree(p);
+    if (w->pin_pred) (void)hipHostFree(w->pin_pred);
     if (w->pin_in) (void)hipHostFree(w->pin_in);
     if (w->pin_out) (void)hipHostFree(w->pin_out);
     for (auto& e : w->ev)
@@ -848,12 +851,15 @@ static bool mergeable(const nmn_index* idx, const HostReq& r) {
 // own call).  DIFFERENT filters share a sweep too when both are bitmaps in device memory (or absent) and the shard's
 // batches take the matrix-core sweep, which reads one bitmap per query.
 static bool same_mask(const HostReq& a, const HostReq& b) {
+    if (a.pred_cols || b.pred_cols) return false;  // a predicate yields its own bitmap
     return a.mask == b.mask && (a.mask == nullptr || a.mask_on_device == b.mask_on_device);
 }
 static bool same_batch_key(const nmn_index* idx, const HostReq& a, const HostReq& b) {
     if (a.metric != b.metric) return false;
+    if (a.pred_cols && b.pred_cols && a.pred_cols != b.pred_cols) return false;  // one set of columns per batch
     if (same_mask(a, b)) return true;
-    const bool dev_a = a.mask == nullptr || a.mask_on_device, dev_b = b.mask == nullptr || b.mask_on_device;
+    const bool dev_a = a.pred_cols || a.mask == nullptr || a.mask_on_device;
+    const bool dev_b = b.pred_cols || b.mask == nullptr || b.mask_on_device;
     return dev_a && dev_b && batch_queries(idx, a.metric) > 4;
 }
 
@@ -895,13 +901,66 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         }
     }
     HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    // ---- predicates of the batch: one launch on this stream, each into its own bitmap -------------------------
+    size_t n_pred = 0;
+    for (size_t i = 0; i < n_reqs; i++) n_pred += reqs[i]->pred_cols ? 1 : 0;
+    std::vector<const uint64_t*> eff_mask(n_reqs);  // the bitmap each request's queries are searched with
+    size_t pred_words = 0, pred_count_stride = 0, pred_block_bytes = 0;
+    if (n_pred && words) {
+        const nmn_columns* cols = nullptr;
+        for (size_t i = 0; i < n_reqs; i++)
+            if (reqs[i]->pred_cols) cols = reqs[i]->pred_cols;
+        pred_words = (size_t)columns_words(cols);
+        if (pred_words < words || columns_device(cols) != idx->device)
+            return fail_arg(NMN_ERR_INVALID_ARGUMENT, "metadata columns do not cover the shard's rows (or live on another device)");
+        const uint32_t blocks = pred_batch_blocks(idx->rows, (uint32_t)n_pred);
+        pred_count_stride = 1 + (size_t)blocks;
+        HIP_TRY(grow(&w->pred_masks, &w->pred_masks_cap, n_pred * pred_words));
+        HIP_TRY(grow(&w->pred_counts, &w->pred_counts_cap, n_pred * pred_count_stride));
+        size_t off = n_pred * pred_desc_bytes();
+        std::vector<uint32_t> ops_off(n_pred), consts_off(n_pred);
+        size_t j = 0;
+        for (size_t i = 0; i < n_reqs; i++) {
+            if (!reqs[i]->pred_cols) continue;
+            ops_off[j] = (uint32_t)off;
+            off += reqs[i]->pred_ops.size();
+            consts_off[j] = (uint32_t)off;
+            off += (size_t)reqs[i]->pred_n_consts * 8 + 8;
+            j++;
+        }
+        const size_t block_bytes = off;
+        HIP_TRY(grow(&w->pred_block, &w->pred_block_cap, block_bytes));
+        pred_block_bytes = (block_bytes + 15) & ~(size_t)15;  // the counts come back right behind the staged block
+        HIP_TRY(grow_pinned(&w->pin_pred, &w->pin_pred_cap, pred_block_bytes + n_pred * pred_count_stride * 8));
+        j = 0;
+        for (size_t i = 0; i < n_reqs; i++) {
+            if (!reqs[i]->pred_cols) continue;
+            pred_desc_write(w->pin_pred + j * pred_desc_bytes(), ops_off[j], (uint32_t)(reqs[i]->pred_ops.size() / pred_op_bytes()),
+                            consts_off[j], w->pred_masks + j * pred_words, w->pred_counts + j * pred_count_stride);
+            memcpy(w->pin_pred + ops_off[j], reqs[i]->pred_ops.data(), reqs[i]->pred_ops.size());
+            if (reqs[i]->pred_n_consts) memcpy(w->pin_pred + consts_off[j], reqs[i]->pred_consts, (size_t)reqs[i]->pred_n_consts * 8);
+            j++;
+        }
+        HIP_TRY(hipMemcpyAsync(w->pred_block, w->pin_pred, block_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_pred_batch(cols, w->pred_block, (uint32_t)n_pred, idx->rows, s));
+    }
+    {
+        size_t j = 0;
+        for (size_t i = 0; i < n_reqs; i++) {
+            if (reqs[i]->pred_cols) eff_mask[i] = (n_pred && words) ? w->pred_masks + (j++) * pred_words : nullptr;
+            else eff_mask[i] = reqs[i]->mask;
+        }
+    }
     bool one_mask = true;
-    for (size_t i = 1; i < n_reqs; i++) one_mask = one_mask && same_mask(first, *reqs[i]);
+    for (size_t i = 1; i < n_reqs; i++)
+        one_mask = one_mask && !reqs[i]->pred_cols && !first.pred_cols && same_mask(first, *reqs[i]);
     const uint64_t* mask_dev = nullptr;
     std::vector<const uint64_t*> qmasks;  // one device bitmap (or null) per query when the batch mixes filters
-    if (!one_mask) {
+    if (n_reqs == 1 && first.pred_cols) {
+        mask_dev = eff_mask[0];  // a lone filtered search: the ordinary masked sweep (skips what the bitmap excludes)
+    } else if (!one_mask) {
         if (words) {
-            for (size_t i = 0; i < n_reqs; i++) qmasks.insert(qmasks.end(), reqs[i]->nq, reqs[i]->mask);
+            for (size_t i = 0; i < n_reqs; i++) qmasks.insert(qmasks.end(), reqs[i]->nq, eff_mask[i]);
             HIP_TRY(grow(&w->h_qmasks, &w->h_qmasks_cap, (size_t)nq));
             // pageable -> device is a staged copy: the vector may go out of scope once the call returns
             HIP_TRY(hipMemcpyAsync(w->h_qmasks, qmasks.data(), (size_t)nq * sizeof(uint64_t*), hipMemcpyHostToDevice, s));
@@ -916,15 +975,50 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     uint64_t* d_rows = reinterpret_cast<uint64_t*>(w->h_pack);
     float* d_scores = reinterpret_cast<float*>(w->h_pack + off_scores);
     uint32_t* d_counts = reinterpret_cast<uint32_t*>(w->h_pack + off_counts);
-    if (!qmasks.empty())
+    // A mixed batch reads every row once; its members one by one read what their bitmaps select.  With predicates in
+    // the batch the selectivities are known only now: fetch their counts (the launches above are tens of microseconds)
+    // and serve the members separately when that is the cheaper way (few, selective filters).
+    bool separately = false;
+    if (!qmasks.empty() && n_pred && n_reqs <= 16) {
+        HIP_TRY(hipMemcpyAsync(w->pin_pred + pred_block_bytes, w->pred_counts, n_pred * pred_count_stride * 8,
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const double sweep_us = (double)idx->rows * idx->ld * 2.0 / 5.5e6, fixed_us = 100.0;
+        double sum = 0.0;
+        size_t j = 0;
+        for (size_t i = 0; i < n_reqs; i++) {
+            double sel = selectivity_of(idx, *reqs[i]);
+            if (reqs[i]->pred_cols)
+                sel = (double)reinterpret_cast<const unsigned long long*>(w->pin_pred + pred_block_bytes)[(j++) * pred_count_stride] /
+                      (double)std::max<uint64_t>(idx->rows, 1);
+            sum += std::max(fixed_us, sel * sweep_us);
+        }
+        separately = sum < 1.1 * sweep_us + fixed_us;
+    }
+    if (separately) {
+        size_t q0 = 0;
+        for (size_t i = 0; i < n_reqs && st == NMN_OK; i++) {
+            st = search_enqueue(idx, w, w->h_queries + q0 * dim, reqs[i]->nq, k, (nmn_metric)first.metric, eff_mask[i],
+                                d_rows + q0 * k, d_scores + q0 * k, d_counts + q0, s);
+            q0 += reqs[i]->nq;
+        }
+    } else if (!qmasks.empty())
         st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, nullptr, d_rows, d_scores, d_counts, s,
                             w->h_qmasks, qmasks.data());
     else
         st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s);
     if (st != NMN_OK) return st;
     HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
+    std::vector<unsigned long long> pred_selected(n_pred, 0ull);
+    if (n_pred && words) {  // the predicates' counts (word 0 of each counter block): small, one strided copy
+        HIP_TRY(hipMemcpyAsync(w->pin_pred + pred_block_bytes, w->pred_counts, n_pred * pred_count_stride * 8,
+                               hipMemcpyDeviceToHost, s));
+    }
     lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
     HIP_TRY(hipStreamSynchronize(s));
+    if (n_pred && words)
+        for (size_t j = 0; j < n_pred; j++)
+            pred_selected[j] = reinterpret_cast<const unsigned long long*>(w->pin_pred + pred_block_bytes)[j * pred_count_stride];
     // hand the results out: the first k_i of each query's k-list are that request's answer (same total order)
     const uint64_t* h_rows = reinterpret_cast<const uint64_t*>(w->pin_out);
     const float* h_scores = reinterpret_cast<const float*>(w->pin_out + off_scores);
@@ -939,6 +1033,14 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         }
         q0 += r.nq;
     }
+    {
+        size_t j = 0;
+        for (size_t i = 0; i < n_reqs; i++)
+            if (reqs[i]->pred_cols) {
+                if (reqs[i]->selected_out) *reqs[i]->selected_out = (n_pred && words) ? pred_selected[j] : 0;
+                j++;
+            }
+    }
     if (want_stats) {
         nmn_search_stats batch_stats;
         st = stats_collect(idx, w, &batch_stats);
@@ -948,6 +1050,8 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     }
     return NMN_OK;
 }
+
+static nmn_status host_submit(nmn_index* idx, HostReq& me);
 
 nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
                                     const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
@@ -968,6 +1072,45 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
     me.out_scores = out_scores;
     me.out_counts = out_counts;
     me.stats = stats;
+    return host_submit(idx, me);
+}
+
+extern "C" nmn_status nmn_index_search_pred(nmn_index* idx, nmn_columns* cols, const nmn_pred_op* prog, uint32_t n_ops,
+                                            const uint64_t* consts, uint64_t n_consts, const float* queries, uint32_t nq,
+                                            uint32_t k, nmn_metric metric, uint64_t* out_rows, float* out_scores,
+                                            uint32_t* out_counts, uint64_t* selected_out, nmn_search_stats* stats) {
+    nmn_status st = check_search_args(idx, queries, nq, k, metric, out_rows, out_scores, out_counts);
+    if (st != NMN_OK) return st;
+    if (!cols || !prog || n_ops == 0 || (n_consts && !consts)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null predicate");
+    if (k > NMN_MAX_TOP_K) return fail_arg(NMN_ERR_TOP_K_TOO_LARGE, "nmn_index_search_pred serves k <= NMN_MAX_TOP_K");
+    HIP_TRY(hipSetDevice(idx->device));
+    HostReq me;
+    me.queries = queries;
+    me.nq = nq;
+    me.k = k;
+    me.metric = (int)metric;
+    me.mask = nullptr;
+    me.mask_on_device = true;
+    me.mask_rows = UINT64_MAX;
+    me.out_rows = out_rows;
+    me.out_scores = out_scores;
+    me.out_counts = out_counts;
+    me.stats = stats;
+    me.pred_cols = cols;
+    me.pred_consts = consts;
+    me.pred_n_consts = n_consts;
+    me.selected_out = selected_out;
+    if (selected_out) *selected_out = 0;
+    st = columns_compile(cols, prog, n_ops, n_consts, idx->rows, &me.pred_ops);  // rows: read without the lock; re-checked by the leader
+    if (st != NMN_OK) return st;
+    return host_submit(idx, me);
+}
+
+// queue / lead / ride: the coalescer proper
+static nmn_status host_submit(nmn_index* idx, HostReq& me) {
+    const uint32_t nq = me.nq;
+    const int metric = me.metric;
+    nmn_status st = NMN_OK;
     std::unique_lock<std::mutex> lk(idx->mu);
     if (idx->host_queue.empty() && idx->writers_waiting == 0 && idx->slots_busy < lead_limit_for(idx, me)) {
         me.slot = slot_take(idx);  // the shard can take another search right now: lead a batch of one
@@ -1017,8 +1160,10 @@ nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32
             std::vector<const uint64_t*> seen{me.mask};
             for (HostReq* r : qu) {
                 if (!mergeable(idx, *r) || !same_batch_key(idx, me, *r) || same_mask(me, *r)) continue;
-                if (std::find(seen.begin(), seen.end(), r->mask) != seen.end()) continue;
-                seen.push_back(r->mask);
+                if (!r->pred_cols) {  // (a predicate is a filter of its own, whatever its bitmap will be)
+                    if (std::find(seen.begin(), seen.end(), r->mask) != seen.end()) continue;
+                    seen.push_back(r->mask);
+                }
                 sum += alone_us(*r);
             }
             mix = sum >= 1.1 * sweep_us + fixed_us;

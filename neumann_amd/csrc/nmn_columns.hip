@@ -71,11 +71,11 @@ __device__ __forceinline__ bool cmp_cell(uint32_t ck, uint64_t cp, uint32_t vk, 
 constexpr int kPredUnroll = 4;
 constexpr uint32_t kPredMaxBlocks = 4096;
 
-__global__ __launch_bounds__(256) void pred_eval_kernel(const DevOp* __restrict__ ops, uint32_t n_ops,
-                                                        const uint64_t* __restrict__ consts,
-                                                        const uint64_t* __restrict__ valid, uint64_t n_rows,
-                                                        uint64_t* __restrict__ mask,
-                                                        unsigned long long* __restrict__ partial) {
+__device__ __forceinline__ void pred_eval_body(const DevOp* __restrict__ ops, uint32_t n_ops,
+                                               const uint64_t* __restrict__ consts,
+                                               const uint64_t* __restrict__ valid, uint64_t n_rows,
+                                               uint64_t* __restrict__ mask,
+                                               unsigned long long* __restrict__ partial) {
     constexpr int U = kPredUnroll;
     __shared__ unsigned long long wave_sel[4];
     const uint32_t lane = threadIdx.x & 63u;
@@ -165,6 +165,42 @@ __global__ __launch_bounds__(256) void pred_eval_kernel(const DevOp* __restrict_
     if (lane == 0) wave_sel[threadIdx.x >> 6] = selected;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = wave_sel[0] + wave_sel[1] + wave_sel[2] + wave_sel[3];
+}
+
+__global__ __launch_bounds__(256) void pred_eval_kernel(const DevOp* __restrict__ ops, uint32_t n_ops,
+                                                        const uint64_t* __restrict__ consts,
+                                                        const uint64_t* __restrict__ valid, uint64_t n_rows,
+                                                        uint64_t* __restrict__ mask,
+                                                        unsigned long long* __restrict__ partial) {
+    pred_eval_body(ops, n_ops, consts, valid, n_rows, mask, partial);
+}
+
+// Several programs in one launch (blockIdx.y = program): the predicates of the filtered searches that ride one query
+// batch (nmn_index_search_pred) are evaluated together, on the batch's stream, right before its sweep.
+struct ProgDesc {
+    uint32_t ops_off, n_ops;     // byte offset of the DevOps in the staged block
+    uint32_t consts_off, pad;    // byte offset of the constants
+    uint64_t* mask;              // result bitmap of this program
+    unsigned long long* counts;  // [0] total, [1 ..] per-block partials
+};
+__global__ __launch_bounds__(256) void pred_eval_batch_kernel(const uint8_t* __restrict__ base,
+                                                              const uint64_t* __restrict__ valid, uint64_t n_rows) {
+    const ProgDesc d = reinterpret_cast<const ProgDesc*>(base)[blockIdx.y];
+    pred_eval_body(reinterpret_cast<const DevOp*>(base + d.ops_off), d.n_ops,
+                   reinterpret_cast<const uint64_t*>(base + d.consts_off), valid, n_rows, d.mask, d.counts + 1);
+}
+__global__ __launch_bounds__(256) void count_reduce_batch_kernel(const uint8_t* __restrict__ base, uint32_t n_blocks) {
+    __shared__ unsigned long long acc[256];
+    const ProgDesc d = reinterpret_cast<const ProgDesc*>(base)[blockIdx.x];
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < n_blocks; i += 256) s += d.counts[1 + i];
+    acc[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t step = 128; step > 0; step >>= 1) {
+        if (threadIdx.x < step) acc[threadIdx.x] += acc[threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d.counts[0] = acc[0];
 }
 
 __global__ __launch_bounds__(256) void count_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n,
@@ -471,6 +507,54 @@ static nmn_status pred_run(nmn_columns* c, const std::vector<DevOp>& dops, const
     *count_out = *cnt_host;
     return NMN_OK;
 }
+
+// ---- what nmn_api.hip needs to evaluate the predicates of a query batch on the batch's own stream ------------
+namespace nmn {
+
+nmn_status columns_compile(const nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, uint64_t n_consts,
+                           uint64_t n_rows, std::vector<uint8_t>* ops_bytes) {
+    if (!c || !prog || n_ops == 0 || !ops_bytes) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_rows > c->cap) return set_error(NMN_ERR_CAPACITY, "n_rows beyond capacity_rows");
+    std::vector<DevOp> dops;
+    nmn_status st = pred_compile(c, prog, n_ops, n_consts, &dops);  // reads c->cols: stable while no writer runs
+    if (st != NMN_OK) return st;
+    ops_bytes->resize(dops.size() * sizeof(DevOp));
+    memcpy(ops_bytes->data(), dops.data(), ops_bytes->size());
+    return NMN_OK;
+}
+size_t pred_desc_bytes() { return sizeof(ProgDesc); }
+size_t pred_op_bytes() { return sizeof(DevOp); }
+void pred_desc_write(uint8_t* dst, uint32_t ops_off, uint32_t n_ops, uint32_t consts_off, uint64_t* mask,
+                     unsigned long long* counts) {
+    ProgDesc d;
+    d.ops_off = ops_off;
+    d.n_ops = n_ops;
+    d.consts_off = consts_off;
+    d.pad = 0;
+    d.mask = mask;
+    d.counts = counts;
+    memcpy(dst, &d, sizeof d);
+}
+// blocks per program (the grid stays around kPredMaxBlocks); counts of a program: 1 + pred_batch_blocks words
+uint32_t pred_batch_blocks(uint64_t n_rows, uint32_t n_prog) {
+    const uint64_t n_words = (n_rows + 63) / 64;
+    const uint64_t wave_trips = (n_words + kPredUnroll - 1) / kPredUnroll;
+    return (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>((wave_trips + 3) / 4, std::max<uint64_t>(kPredMaxBlocks / std::max(n_prog, 1u), 64)));
+}
+// dev_block: [ProgDesc x n_prog | ops and constants], already on the device (same stream)
+hipError_t launch_pred_batch(const nmn_columns* c, const uint8_t* dev_block, uint32_t n_prog, uint64_t n_rows,
+                             hipStream_t s) {
+    if (n_prog == 0 || n_rows == 0) return hipSuccess;
+    const uint32_t blocks = pred_batch_blocks(n_rows, n_prog);
+    hipLaunchKernelGGL(pred_eval_batch_kernel, dim3(blocks, n_prog), dim3(256), 0, s, dev_block, c->valid, n_rows);
+    hipLaunchKernelGGL(count_reduce_batch_kernel, dim3(n_prog), dim3(256), 0, s, dev_block, blocks);
+    return hipGetLastError();
+}
+uint64_t columns_words(const nmn_columns* c) { return c ? c->words : 0; }
+int columns_device(const nmn_columns* c) { return c ? c->device : -1; }
+
+}  // namespace nmn
 
 extern "C" nmn_status nmn_columns_eval(nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, const uint64_t* consts,
                                        uint64_t n_consts, uint64_t n_rows, uint64_t* count_out) {

@@ -806,17 +806,43 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
     Program p;
     Code code = compile_filter(f, *m, p);
     p.ops = std::move(code.ops);
-    DeviceSelection sel{nullptr, 0};
-    uint32_t slot = 0;
-    st = nmn_columns_eval_acquire(m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(),
-                                  m->row_to_slot.size(), &sel.count, &slot, &sel.mask_dev);
+    // predicate and search in one call (nmn_index_search_pred): concurrent filtered searches then wait for ONE batch —
+    // their predicates are evaluated together on the batch's stream, right before the sweep that serves them all
+    if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2005-2010
+    const uint64_t rows = nmn_index_rows(m->idx);
+    const uint64_t k = std::min<uint64_t>(std::min<uint64_t>(top_k, rows), NMN_MAX_TOP_K);
+    if (k == 0 || rows != m->row_to_slot.size()) {
+        if (k == 0) return NMN_OK;
+        return fail(NMN_ERR_STORAGE, "mirror and metadata columns disagree on the row count");
+    }
+    if (top_k > NMN_MAX_TOP_K) {
+        // beyond the candidate pipeline: evaluate, then the large-k path over the bitmap (the two-step form)
+        DeviceSelection sel{nullptr, 0};
+        uint32_t slot = 0;
+        st = nmn_columns_eval_acquire(m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(),
+                                      m->row_to_slot.size(), &sel.count, &slot, &sel.mask_dev);
+        if (st != NMN_OK) return err_gpu(st);
+        e->device_filters++;
+        st = NMN_OK;
+        if (sel.count != 0)  // else `if matching_keys.is_empty() { return Vec::new() }`
+            st = search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &sel, m, res);
+        (void)nmn_columns_eval_release(m->cols, slot);
+        return st;
+    }
+    std::vector<uint64_t> out_rows(k);
+    std::vector<float> out_scores(k);
+    uint32_t count = 0;
+    uint64_t selected = 0;
+    st = nmn_index_search_pred(m->idx, m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(), q, 1,
+                               (uint32_t)k, NMN_METRIC_COSINE, out_rows.data(), out_scores.data(), &count, &selected, nullptr);
     if (st != NMN_OK) return err_gpu(st);
     e->device_filters++;
-    st = NMN_OK;
-    if (sel.count != 0)  // else `if matching_keys.is_empty() { return Vec::new() }`
-        st = search_common(e, c, q, dim, top_k, NMN_METRIC_COSINE, op, dl, &sel, m, res);
-    (void)nmn_columns_eval_release(m->cols, slot);
-    return st;
+    for (uint32_t i = 0; i < count; i++) {
+        res->keys.push_back(c->slots[m->row_to_slot[out_rows[i]]].key);
+        res->scores.push_back(out_scores[i]);
+    }
+    if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2019-2024
+    return NMN_OK;
 }
 
 // search_common for the post-filter arm: under the shared lock only when the mirror exists already

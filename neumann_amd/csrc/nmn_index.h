@@ -50,6 +50,11 @@ struct Workspace {
     // results, so a call is one true-async H2D, the pipeline, one D2H and one wait (pageable copies cost ~10 us each)
     uint8_t* h_pack = nullptr; size_t h_pack_cap = 0;        // device
     const uint64_t** h_qmasks = nullptr; size_t h_qmasks_cap = 0;  // device: per-query bitmap pointers of a merged batch
+    // predicates of a batch: staged programs, result bitmaps [requests][words], counters [requests][1 + blocks]
+    uint8_t* pred_block = nullptr; size_t pred_block_cap = 0;            // device
+    uint64_t* pred_masks = nullptr; size_t pred_masks_cap = 0;           // device
+    unsigned long long* pred_counts = nullptr; size_t pred_counts_cap = 0;  // device
+    uint8_t* pin_pred = nullptr; size_t pin_pred_cap = 0;                // pinned host staging of pred_block
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
     uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
     uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
@@ -73,6 +78,13 @@ struct HostReq {
     const uint64_t* mask;
     bool mask_on_device;
     uint64_t mask_rows;  // rows the mask selects when the caller knows (UINT64_MAX: unknown), for the mixing decision
+    // a WHERE predicate instead of a ready bitmap (nmn_index_search_pred): the leader evaluates the predicates of its
+    // whole batch in one launch on the batch's stream, right before the sweep
+    const nmn_columns* pred_cols = nullptr;
+    std::vector<uint8_t> pred_ops;     // compiled program (device op records)
+    const uint64_t* pred_consts = nullptr;
+    uint64_t pred_n_consts = 0;
+    uint64_t* selected_out = nullptr;  // rows the predicate selected
     uint64_t* out_rows;
     float* out_scores;
     uint32_t* out_counts;
@@ -133,7 +145,21 @@ struct nmn_index {
     uint64_t coalesced_batches = 0, coalesced_requests = 0;  // batches of >= 2 requests, and the requests in them
 };
 
+struct nmn_columns;
 namespace nmn {
+
+// predicates of a query batch, evaluated on the batch's stream (nmn_columns.hip)
+nmn_status columns_compile(const nmn_columns* c, const nmn_pred_op* prog, uint32_t n_ops, uint64_t n_consts,
+                           uint64_t n_rows, std::vector<uint8_t>* ops_bytes);
+size_t pred_desc_bytes();
+size_t pred_op_bytes();
+void pred_desc_write(uint8_t* dst, uint32_t ops_off, uint32_t n_ops, uint32_t consts_off, uint64_t* mask,
+                     unsigned long long* counts);
+uint32_t pred_batch_blocks(uint64_t n_rows, uint32_t n_prog);
+hipError_t launch_pred_batch(const nmn_columns* c, const uint8_t* dev_block, uint32_t n_prog, uint64_t n_rows,
+                             hipStream_t s);
+uint64_t columns_words(const nmn_columns* c);
+int columns_device(const nmn_columns* c);
 
 // nmn_index_search / nmn_index_search_dmask with the internal metrics allowed (host queries and outputs)
 nmn_status index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
