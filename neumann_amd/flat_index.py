@@ -135,6 +135,28 @@ class GpuFlatIndex:
                                                      _ptr(out_rows), _ptr(out_scores), _ptr(out_counts), None))
         return out_rows, out_scores, out_counts
 
+    def search_pred(self, columns, ops, consts, queries, k, metric=DistanceMetric.Cosine):
+        """Filtered search in one call: evaluate the predicate program over `columns` (a GpuColumns covering this
+        shard's rows) and search what it selects.  Returns (rows, scores, counts, selected)."""
+        from ._capi import PredOp
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, k = q.shape[0], int(k)
+        arr = (PredOp * max(len(ops), 1))()
+        for i, o in enumerate(ops):
+            arr[i] = o if isinstance(o, PredOp) else PredOp(*o)
+        cs = np.ascontiguousarray(np.asarray(list(consts), dtype=np.uint64))
+        out_rows = np.empty((nq, max(k, 1)), dtype=np.uint64)
+        out_scores = np.empty((nq, max(k, 1)), dtype=np.float32)
+        out_counts = np.empty(nq, dtype=np.uint32)
+        sel = C.c_uint64()
+        _capi.check(self._lib.nmn_index_search_pred(self._h, columns._h, arr, len(ops),
+                                                    C.c_void_p(cs.ctypes.data) if cs.size else None, cs.size, _ptr(q), nq, k,
+                                                    int(metric), _ptr(out_rows), _ptr(out_scores), _ptr(out_counts),
+                                                    C.byref(sel), None))
+        return out_rows, out_scores, out_counts, int(sel.value)
+
     def search_device(self, queries_t, k, metric=DistanceMetric.Cosine, mask_t=None, out=None, stream=None):
         """Asynchronous search with torch device tensors.
 

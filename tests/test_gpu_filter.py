@@ -420,3 +420,72 @@ def test_engine_concurrent_prefiltered_searches_share_sweeps(E):
         er, es = oc.search(A, qs[j], k, 0, mask=oc.mask_from_bool(keep))
         assert [r.key for r in out[j]] == [f"k{i}" for i in er], conds[j]
         assert np.all(np.array([r.score for r in out[j]], F) == es), conds[j]
+
+
+@pytest.mark.parametrize("n,d", [(30000, 768), (30000, 96)])   # with and without the matrix-core sweep for batches
+def test_search_pred_one_call_equals_eval_then_search(n, d):
+    """nmn_index_search_pred: predicate + search in one call, alone and from many threads with different predicates
+    (their evaluations share one launch, their searches one sweep) — always the oracle's answer for that filter."""
+    import threading
+    from neumann_amd import GpuFlatIndex
+    from neumann_amd import columns as g
+    k = 30
+    A = oc.synth(15, 0, n, d)
+    Q = oc.synth(16, 0, 40, d)
+    bucket = np.arange(n) % 13
+    price = (np.arange(n) * 7919) % 1000
+    with GpuFlatIndex(d, n) as idx, g.GpuColumns(n) as gc:
+        idx.upload(A)
+        cb, cp = gc.add_column(), gc.add_column()
+        gc.write(cb, 0, np.full(n, g.CELL_INT, np.uint8), bucket.astype(np.uint64))
+        gc.write(cp, 0, np.full(n, g.CELL_INT, np.uint8), price.astype(np.uint64))
+        gc.write_valid(0, np.full((n + 63) // 64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+        progs = []
+        for j in range(40):
+            if j % 4 == 0:    # bucket == b
+                progs.append(([(g.PRED_CMP, g.CMP_EQ, g.CELL_INT, cb, j % 13, 0)], bucket == j % 13))
+            elif j % 4 == 1:  # price < t
+                t = 50 + 20 * j
+                progs.append(([(g.PRED_CMP, g.CMP_LT, g.CELL_INT, cp, t, 0)], price < t))
+            elif j % 4 == 2:  # bucket == b AND price >= t
+                t = 300
+                progs.append(([(g.PRED_CMP, g.CMP_EQ, g.CELL_INT, cb, j % 13, 0), (g.PRED_CMP, g.CMP_GE, g.CELL_INT, cp, t, 0),
+                               (g.PRED_AND, 0, 0, 0, 0, 0)], (bucket == j % 13) & (price >= t)))
+            else:             # nothing passes
+                progs.append(([(g.PRED_CMP, g.CMP_GT, g.CELL_INT, cp, 5000, 0)], np.zeros(n, bool)))
+
+        def check(j, out, metric):
+            rows, scores, counts, selected = out
+            keep = progs[j][1]
+            assert selected == int(keep.sum()), j
+            if not keep.any():
+                assert counts[0] == 0
+                return
+            er, es = oc.search(A, Q[j], k, metric, mask=oc.mask_from_bool(keep))
+            c = er.size
+            assert counts[0] == c and np.array_equal(rows[0, :c], er) and np.all(scores[0, :c] == es), j
+
+        for j in (0, 1, 2, 3):                                  # alone
+            for metric in (0, 1, 2):
+                check(j, idx.search_pred(gc, progs[j][0], [], Q[j], k, metric), metric)
+        out = [None] * 40
+        errs = []
+        start = threading.Barrier(20)
+
+        def work(t):
+            try:
+                start.wait()
+                for rep in range(3):
+                    for j in range(t, 40, 20):
+                        out[j] = idx.search_pred(gc, progs[j][0], [], Q[j], k, 0)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(20)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for j in range(40):
+            check(j, out[j], 0)
