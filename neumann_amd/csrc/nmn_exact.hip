@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         } else {
             qi.margin_abs = 0.0f;
             qi.margin_rel = 4.0f * (dd + 8.0f) * u;
-            if ((mfma_pass & 1) && metric == NMN_METRIC_EUCLIDEAN) {
+            if ((mfma_pass & 1) && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) {
                 // Matrix-core sweep: d~^2 = |q|^2 + |v|^2 - 2 q~.v~ with bf16 q~ = q + e_q, v~ = v + e_r.  Absolute
                 // error of d~^2 (A):
                 //   2 |q~.v~ - q.v|  <= 2 (|q||e_r| + |e_q||v| + |e_q||e_r|) <= 2 |q| (E + rho_q (V + E))
@@ -262,6 +262,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                 const float a_fp = (dd + 10.0f) * u * (6.0f * qmag * V + V * V + qmag * qmag) + 3.0f * u * (qmag + V) * (qmag + V);
                 qi.pad = -2.0f * 1.001f * (a_round + a_fp);
                 qi.margin_rel = 16.0f * u;  // v_sqrt, v_rcp and the arithmetic of margin_key itself
+                if (metric == kMetricNegL2) qi.margin_abs = -1.0f;  // flag for margin_key: the score is -d, not 1/(1+d)
             } else if (mfma_pass & 2) {
                 // bf16 mirror under a Euclidean metric: v~ = v + e_r, so by the triangle inequality
                 // |d(q, v~) - d(q, v)| <= |e_r| <= max_r |e_r| =: D, an ABSOLUTE error on the distance (twice, as above)

@@ -17,6 +17,9 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <condition_variable>
+#include <memory>
+#include <shared_mutex>
 #include <new>
 #include <vector>
 
@@ -168,12 +171,32 @@ struct nmn_ivf {
     QState* qstate = nullptr;
     uint32_t* assign_tmp = nullptr;      // [kAssignChunk]
     uint32_t assign_chunk = kAssignChunk;
-    // results of the list scan, one packed device block [ids u64 x kk | distances f32 x kk | count u32] and its pinned
-    // host twin: one D2H per attempt; the query goes up through pinned memory too (pageable copies cost ~10 us each)
-    uint8_t* res_pack = nullptr; size_t res_pack_cap = 0;
-    uint8_t* pin_res = nullptr; size_t pin_res_cap = 0;
-    float* pin_q = nullptr;
-    std::mutex mu;
+    // Searches hold `rw` shared (add / build / the accessors exclusive) and take a PROBE SLOT each: stream and scratch of
+    // one centroid ranking + selection bitmap, created on demand.  The list scans themselves go through the flat index's
+    // host API, whose coalescer lets several selective probes run side by side.
+    std::shared_mutex rw;
+    struct ProbeSlot {
+        hipStream_t stream = nullptr;
+        uint32_t* cscores = nullptr;     // [centroids padded]
+        uint64_t* ckeys = nullptr;       // large-k sort buffer (more than kRankMax centroids only)
+        uint64_t* probe_rows = nullptr;  // [n_clusters]
+        float* probe_scores = nullptr;
+        uint32_t* probe_count = nullptr;
+        uint32_t* probe_rank = nullptr;
+        uint64_t* mask = nullptr;
+        float* qraw = nullptr;
+        float* qpad = nullptr;
+        QInfo* qinfo = nullptr;
+        QState* qstate = nullptr;
+        uint8_t* pin = nullptr;          // pinned: [query dim x 4 | probe rows n_clusters x 8]
+        bool busy = false;
+    };
+    std::vector<std::unique_ptr<ProbeSlot>> slots;
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::vector<uint64_t> list_sizes;    // rows per cluster (host), for the selectivity hint of a probe
+    uint64_t list_sizes_rows = 0;        // rows accounted for in list_sizes
+    static constexpr size_t kMaxSlots = 64;
 };
 
 #define IVF_TRY(expr)                                         \
@@ -189,10 +212,19 @@ extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
     for (void* p : {(void*)ivf->assign, (void*)ivf->cscores, (void*)ivf->ckeys, (void*)ivf->probe_rows,
                     (void*)ivf->probe_scores, (void*)ivf->probe_count, (void*)ivf->probe_rank, (void*)ivf->mask,
                     (void*)ivf->qraw, (void*)ivf->qpad, (void*)ivf->qinfo, (void*)ivf->qstate, (void*)ivf->assign_tmp,
-                    (void*)ivf->res_pack})
+                    })
         if (p) (void)hipFree(p);
-    if (ivf->pin_res) (void)hipHostFree(ivf->pin_res);
-    if (ivf->pin_q) (void)hipHostFree(ivf->pin_q);
+    for (auto& sl : ivf->slots) {
+        if (sl->stream) {
+            (void)hipStreamSynchronize(sl->stream);
+            (void)hipStreamDestroy(sl->stream);
+        }
+        for (void* p : {(void*)sl->cscores, (void*)sl->ckeys, (void*)sl->probe_rows, (void*)sl->probe_scores,
+                        (void*)sl->probe_count, (void*)sl->probe_rank, (void*)sl->mask, (void*)sl->qraw, (void*)sl->qpad,
+                        (void*)sl->qinfo, (void*)sl->qstate})
+            if (p) (void)hipFree(p);
+        if (sl->pin) (void)hipHostFree(sl->pin);
+    }
     if (ivf->stream) (void)hipStreamDestroy(ivf->stream);
     if (ivf->vectors) nmn_index_destroy(ivf->vectors);
     if (ivf->centroids) nmn_index_destroy(ivf->centroids);
@@ -249,7 +281,6 @@ static nmn_status ivf_new(const nmn_index_desc* desc, const float* centroids, ui
     alloc(reinterpret_cast<void**>(&ivf->qinfo), sizeof(QInfo) * kAssignChunk);
     alloc(reinterpret_cast<void**>(&ivf->qstate), sizeof(QState) * kAssignChunk);
     alloc(reinterpret_cast<void**>(&ivf->assign_tmp), 4 * kAssignChunk);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ivf->pin_q), (size_t)desc->dim * 4, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(ivf->qinfo, 0, sizeof(QInfo) * kAssignChunk, ivf->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ivf->stream);
     if (e != hipSuccess) return bail(set_error_hip(e, "nmn_ivf_create"));
@@ -269,7 +300,7 @@ extern "C" nmn_index* nmn_ivf_vectors(nmn_ivf* ivf) { return ivf ? ivf->vectors 
 
 extern "C" nmn_status nmn_ivf_cluster_sizes(nmn_ivf* ivf, uint64_t* out_sizes) {
     if (!ivf || !out_sizes) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(ivf->mu);
+    std::unique_lock<std::shared_mutex> g(ivf->rw);
     std::fill(out_sizes, out_sizes + ivf->n_clusters, 0ull);
     for (uint32_t c : ivf->assign_host) out_sizes[c]++;
     return NMN_OK;
@@ -311,13 +342,19 @@ static nmn_status assign_rows(nmn_ivf* ivf, uint64_t row0, uint64_t n) {
                                hipMemcpyDeviceToHost, ivf->stream));
     }
     IVF_TRY(hipStreamSynchronize(ivf->stream));
+    if (row0 == 0 || ivf->list_sizes.size() != ivf->n_clusters) {
+        ivf->list_sizes.assign(ivf->n_clusters, 0);
+        for (uint64_t r = 0; r < row0; r++) ivf->list_sizes[ivf->assign_host[r]]++;
+    }
+    for (uint64_t r = row0; r < row0 + n; r++) ivf->list_sizes[ivf->assign_host[r]]++;
+    ivf->list_sizes_rows = row0 + n;
     return NMN_OK;
 }
 
 extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t n, uint32_t* clusters_out) {
     if (!ivf || (n && !rows_host)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return NMN_OK;
-    std::lock_guard<std::mutex> g(ivf->mu);
+    std::unique_lock<std::shared_mutex> g(ivf->rw);
     const uint64_t row0 = ivf->vectors->rows;
     nmn_status st = nmn_index_upload(ivf->vectors, rows_host, row0, n);  // ids = insertion order (ivf.rs:287-289)
     if (st != NMN_OK) return st;
@@ -362,7 +399,7 @@ extern "C" nmn_status nmn_ivf_build(const nmn_index_desc* desc, const float* row
         nmn_ivf_destroy(ivf);
         return code;
     };
-    std::lock_guard<std::mutex> g(ivf->mu);
+    std::unique_lock<std::shared_mutex> g(ivf->rw);
     st = nmn_index_upload(ivf->vectors, rows_host, 0, n);  // ids = order of the input (ivf.rs:287-289)
     if (st != NMN_OK) return bail(st);
     hipError_t he = hipSetDevice(ivf->device);
@@ -499,7 +536,7 @@ extern "C" nmn_status nmn_ivf_build(const nmn_index_desc* desc, const float* row
 
 extern "C" nmn_status nmn_ivf_centroids(nmn_ivf* ivf, float* out, uint64_t cap_floats) {
     if (!ivf || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(ivf->mu);
+    std::unique_lock<std::shared_mutex> g(ivf->rw);
     const uint64_t need = (uint64_t)ivf->n_clusters * ivf->dim;
     if (cap_floats < need) return set_error(NMN_ERR_BUFFER_TOO_SMALL, "centroid buffer too small");
     if (ivf->centroids_host.size() == need) {
@@ -512,15 +549,61 @@ extern "C" nmn_status nmn_ivf_centroids(nmn_ivf* ivf, float* out, uint64_t cap_f
     return NMN_OK;
 }
 
-template <typename T>
-static hipError_t grow_dev(T** p, size_t* cap, size_t need) {
-    if (need <= *cap && *p) return hipSuccess;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(need, 1) * sizeof(T));
-    if (e == hipSuccess) *cap = need;
-    return e;
+// a free probe slot (created on demand; waits when kMaxSlots are all busy)
+static nmn_status probe_slot_acquire(nmn_ivf* ivf, nmn_ivf::ProbeSlot** out) {
+    std::unique_lock<std::mutex> lk(ivf->slot_mu);
+    for (;;) {
+        for (auto& sl : ivf->slots)
+            if (!sl->busy) {
+                sl->busy = true;
+                *out = sl.get();
+                return NMN_OK;
+            }
+        if (ivf->slots.size() < nmn_ivf::kMaxSlots) break;
+        ivf->slot_cv.wait(lk);
+    }
+    auto sl = std::make_unique<nmn_ivf::ProbeSlot>();
+    const size_t c_pad = ivf->centroids->cap_pad;
+    const uint32_t ld = ivf->vectors->ld;
+    hipError_t e = hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking);
+    auto alloc = [&](void** p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, std::max<size_t>(bytes, 64));
+    };
+    alloc(reinterpret_cast<void**>(&sl->cscores), c_pad * 4);
+    if (ivf->n_clusters > kRankMax) alloc(reinterpret_cast<void**>(&sl->ckeys), largek_sort_len(ivf->n_clusters) * 8);
+    alloc(reinterpret_cast<void**>(&sl->probe_rows), (size_t)ivf->n_clusters * 8);
+    alloc(reinterpret_cast<void**>(&sl->probe_scores), (size_t)ivf->n_clusters * 4);
+    alloc(reinterpret_cast<void**>(&sl->probe_count), 8);
+    alloc(reinterpret_cast<void**>(&sl->probe_rank), (size_t)ivf->n_clusters * 4);
+    alloc(reinterpret_cast<void**>(&sl->mask), ((ivf->cap + 63) / 64 + 1) * 8);
+    alloc(reinterpret_cast<void**>(&sl->qraw), (size_t)ivf->dim * 4);
+    alloc(reinterpret_cast<void**>(&sl->qpad), (size_t)ld * 4);
+    alloc(reinterpret_cast<void**>(&sl->qinfo), sizeof(QInfo));
+    alloc(reinterpret_cast<void**>(&sl->qstate), sizeof(QState));
+    if (e == hipSuccess) e = hipMemsetAsync(sl->qinfo, 0, sizeof(QInfo), sl->stream);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void**>(&sl->pin), (size_t)ivf->dim * 4 + (size_t)ivf->n_clusters * 8 + 16,
+                          hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (sl->stream) (void)hipStreamDestroy(sl->stream);
+        for (void* p : {(void*)sl->cscores, (void*)sl->ckeys, (void*)sl->probe_rows, (void*)sl->probe_scores,
+                        (void*)sl->probe_count, (void*)sl->probe_rank, (void*)sl->mask, (void*)sl->qraw, (void*)sl->qpad,
+                        (void*)sl->qinfo, (void*)sl->qstate})
+            if (p) (void)hipFree(p);
+        if (sl->pin) (void)hipHostFree(sl->pin);
+        return set_error_hip(e, "IVF probe slot");
+    }
+    sl->busy = true;
+    *out = sl.get();
+    ivf->slots.push_back(std::move(sl));
+    return NMN_OK;
+}
+static void probe_slot_release(nmn_ivf* ivf, nmn_ivf::ProbeSlot* sl) {
+    {
+        std::lock_guard<std::mutex> g(ivf->slot_mu);
+        sl->busy = false;
+    }
+    ivf->slot_cv.notify_one();
 }
 
 extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_t nq, uint32_t k, uint32_t nprobe,
@@ -530,15 +613,24 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
         return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (k == 0) return set_error(NMN_ERR_INVALID_TOP_K, "k == 0");
     if (nq == 0) return NMN_OK;
-    std::lock_guard<std::mutex> g(ivf->mu);
+    std::shared_lock<std::shared_mutex> g(ivf->rw);  // concurrent with other searches, not with add / build
     IVF_TRY(hipSetDevice(ivf->device));
     const uint64_t n_rows = ivf->vectors->rows;
     const uint32_t np = std::min<uint32_t>(nprobe, ivf->n_clusters);  // ivf.rs:339
-    hipStream_t s = ivf->stream;
-    std::vector<uint64_t> probe_host(np);
     std::vector<uint32_t> rank_host;
     std::vector<uint64_t> tmp_ids;
     std::vector<float> tmp_dist;
+    nmn_ivf::ProbeSlot* sl = nullptr;
+    nmn_status st = probe_slot_acquire(ivf, &sl);
+    if (st != NMN_OK) return st;
+    struct Release {
+        nmn_ivf* ivf;
+        nmn_ivf::ProbeSlot* sl;
+        ~Release() { probe_slot_release(ivf, sl); }
+    } release{ivf, sl};
+    hipStream_t s = sl->stream;
+    float* pin_q = reinterpret_cast<float*>(sl->pin);
+    uint64_t* probe_host = reinterpret_cast<uint64_t*>(sl->pin + (((size_t)ivf->dim * 4 + 15) & ~(size_t)15));
     for (uint32_t q = 0; q < nq; q++) {
         uint64_t* o_ids = out_ids + (size_t)q * k;
         float* o_dist = out_distances + (size_t)q * k;
@@ -546,74 +638,75 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
         std::fill(o_dist, o_dist + k, __builtin_inff());
         out_counts[q] = 0;
         if (n_rows == 0 || np == 0) continue;
-        // Everything below is enqueued on ONE stream; the host waits once per attempt.
-        // 1. rank the centroids by squared distance (ascending; ties by index) and keep the first nprobe
-        memcpy(ivf->pin_q, queries + (size_t)q * ivf->dim, (size_t)ivf->dim * 4);
-        IVF_TRY(hipMemcpyAsync(ivf->qraw, ivf->pin_q, (size_t)ivf->dim * 4, hipMemcpyHostToDevice, s));
-        IVF_TRY(launch_qprep(ivf->qraw, 1, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits,
-                             ivf->qpad, ivf->qinfo, ivf->qstate, 0, s));
-        nmn_status st = centroid_scores(ivf, ivf->qpad, 1);
-        if (st != NMN_OK) return st;
+        const float* qh = queries + (size_t)q * ivf->dim;
+        // 1. rank the centroids by squared distance (ascending; ties by index), keep the first nprobe, turn `assign`
+        //    into the selection bitmap — all on this slot's stream, one wait
+        memcpy(pin_q, qh, (size_t)ivf->dim * 4);
+        IVF_TRY(hipMemcpyAsync(sl->qraw, pin_q, (size_t)ivf->dim * 4, hipMemcpyHostToDevice, s));
+        IVF_TRY(launch_qprep(sl->qraw, 1, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits, sl->qpad,
+                             sl->qinfo, sl->qstate, 0, s));
+        {
+            ExactScanParams ep{};
+            ep.corpus = ivf->centroids->corpus;
+            ep.norms = ivf->centroids->norms;
+            ep.qpad = sl->qpad;
+            ep.qinfo = sl->qinfo;
+            ep.scores = sl->cscores;
+            ep.n_rows = ivf->n_clusters;
+            ep.nql = 1;
+            ep.ld = ivf->centroids->ld;
+            ep.dim = ivf->dim;
+            ep.nq = 1;
+            ep.metric = kMetricNegL2Sq;
+            IVF_TRY(launch_exact_scan(ep, s));
+        }
         if (ivf->n_clusters <= kRankMax) {
             uint32_t np2 = 2;
             while (np2 < ivf->n_clusters) np2 <<= 1;
-            hipLaunchKernelGGL(ivf_rank_kernel, dim3(1), dim3(1024), 0, s, ivf->cscores, ivf->n_clusters, np2, np,
-                               ivf->probe_rows, ivf->probe_count, ivf->probe_rank);
+            hipLaunchKernelGGL(ivf_rank_kernel, dim3(1), dim3(1024), 0, s, sl->cscores, ivf->n_clusters, np2, np, sl->probe_rows,
+                               sl->probe_count, sl->probe_rank);
         } else {
-            IVF_TRY(launch_largek(ivf->cscores, ivf->n_clusters, ivf->ckeys, np, 0, ivf->probe_rows, ivf->probe_scores,
-                                  ivf->probe_count, s));
-            // 2. clusters -> probe rank -> selection bitmap over the rows
-            IVF_TRY(hipMemsetAsync(ivf->probe_rank, 0xFF, (size_t)ivf->n_clusters * 4, s));
-            hipLaunchKernelGGL(ivf_probe_rank_kernel, dim3((np + 255) / 256), dim3(256), 0, s, ivf->probe_rows,
-                               ivf->probe_count, ivf->probe_rank);
+            IVF_TRY(launch_largek(sl->cscores, ivf->n_clusters, sl->ckeys, np, 0, sl->probe_rows, sl->probe_scores,
+                                  sl->probe_count, s));
+            IVF_TRY(hipMemsetAsync(sl->probe_rank, 0xFF, (size_t)ivf->n_clusters * 4, s));
+            hipLaunchKernelGGL(ivf_probe_rank_kernel, dim3((np + 255) / 256), dim3(256), 0, s, sl->probe_rows, sl->probe_count,
+                               sl->probe_rank);
         }
         const uint64_t n_words = (n_rows + 63) / 64;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
-        hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, ivf->probe_rank, n_rows, ivf->mask);
+        hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, sl->probe_rank, n_rows, sl->mask);
         IVF_TRY(hipGetLastError());
-        // 3. masked scan ranking by distance (negated so that nearest = largest).  One result more than asked
-        //    for: the scan breaks equal distances by id, the reference by candidate order, so a run of equal
-        //    distances that straddles the cut must be seen whole before it is reordered and cut.
+        IVF_TRY(hipMemcpyAsync(probe_host, sl->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost, s));
+        IVF_TRY(hipStreamSynchronize(s));
+        // rows in the probed lists: the selectivity hint of the list scan (how the flat index's coalescer decides what may
+        // run side by side) and the most the scan can return
+        uint64_t probed_rows = 0;
+        for (uint32_t i = 0; i < np; i++)
+            if (probe_host[i] < ivf->list_sizes.size()) probed_rows += ivf->list_sizes[probe_host[i]];
+        if (ivf->list_sizes_rows != n_rows) probed_rows = UINT64_MAX;  // sizes not current (never after add / build)
+        // 2. masked scan ranking by distance (negated so that nearest = largest).  One result more than asked for: the scan
+        //    breaks equal distances by id, the reference by candidate order, so a run of equal distances that straddles
+        //    the cut must be seen whole before it is reordered and cut.
         uint64_t kk = std::min<uint64_t>((uint64_t)k + 1, std::max<uint64_t>(n_rows, 1));
         uint32_t cnt = 0;
         for (;;) {
-            const size_t off_d = (size_t)kk * 8, off_c = off_d + (size_t)kk * 4, pack = off_c + 4;
-            IVF_TRY(grow_dev(&ivf->res_pack, &ivf->res_pack_cap, pack));
-            if (pack > ivf->pin_res_cap) {
-                if (ivf->pin_res) (void)hipHostFree(ivf->pin_res);
-                ivf->pin_res = nullptr;
-                ivf->pin_res_cap = 0;
-                IVF_TRY(hipHostMalloc(reinterpret_cast<void**>(&ivf->pin_res), pack, hipHostMallocDefault));
-                ivf->pin_res_cap = pack;
-            }
-            tmp_ids.resize(kk);
-            tmp_dist.resize(kk);
-            st = index_search_device(ivf->vectors, ivf->qraw, 1, (uint32_t)kk, kMetricNegL2, ivf->mask,
-                                     reinterpret_cast<uint64_t*>(ivf->res_pack),
-                                     reinterpret_cast<float*>(ivf->res_pack + off_d),
-                                     reinterpret_cast<uint32_t*>(ivf->res_pack + off_c), s);
+            tmp_ids.assign(kk, UINT64_MAX);
+            tmp_dist.assign(kk, 0.f);
+            st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, sl->mask, true, tmp_ids.data(),
+                                     tmp_dist.data(), &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_rows);
             if (st != NMN_OK) return st;
-            IVF_TRY(hipMemcpyAsync(ivf->pin_res, ivf->res_pack, pack, hipMemcpyDeviceToHost, s));
-            IVF_TRY(hipStreamSynchronize(s));
-            memcpy(tmp_ids.data(), ivf->pin_res, (size_t)kk * 8);
-            memcpy(tmp_dist.data(), ivf->pin_res + off_d, (size_t)kk * 4);
-            memcpy(&cnt, ivf->pin_res + off_c, 4);
             const bool cut_inside_run = cnt > k && tmp_dist[k] == tmp_dist[k - 1];
             if (!cut_inside_run || cnt < kk || kk >= n_rows) break;  // run seen whole, or nothing more to fetch
             kk = std::min<uint64_t>(kk * 2, n_rows);
         }
-        if (stats && q + 1 == nq) {
-            st = nmn_index_last_stats(ivf->vectors, s, stats);
-            if (st != NMN_OK) return st;
-        }
         for (uint32_t i = 0; i < cnt; i++) tmp_dist[i] = -tmp_dist[i];
-        // 4. equal distances keep candidate order: probe order of the cluster, then id (stable sort, ivf.rs:402)
+        // 3. equal distances keep candidate order: probe order of the cluster, then id (stable sort, ivf.rs:402)
         bool any_tie = false;
         for (uint32_t i = 1; i < cnt && !any_tie; i++) any_tie = tmp_dist[i] == tmp_dist[i - 1];
         if (any_tie) {
-            IVF_TRY(hipMemcpy(probe_host.data(), ivf->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost));
             rank_host.assign(ivf->n_clusters, kNoRank);
-            for (uint32_t i = 0; i < np; i++) rank_host[probe_host[i]] = i;
+            for (uint32_t i = 0; i < np; i++)
+                if (probe_host[i] < ivf->n_clusters) rank_host[probe_host[i]] = i;
             const uint64_t base = ivf->vectors->row_base;
             for (uint32_t a = 0; a < cnt;) {
                 uint32_t b = a + 1;

@@ -117,9 +117,12 @@ __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
 // Euclidean score from the matrix-core dot product: |q - v|^2 = |q|^2 + |v|^2 - 2 q.v, score = 1 / (1 + sqrt(.)).
 // The cancellation makes the ABSOLUTE error of the squared distance the quantity the margin bounds (qprep_kernel:
 // QInfo.pad < 0); a slightly negative result of the subtraction is a distance of zero.  v_sqrt / v_rcp: 1 ulp each.
+// NEG: the IVF list-scan metric, score = -distance.
+template <bool NEG>
 __device__ __forceinline__ float l2_score(float qq, float vn, float dot) {
     const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, __builtin_fmaf(vn, vn, qq)), 0.0f);
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(d2));
+    const float d = __builtin_amdgcn_sqrtf(d2);
+    return NEG ? -d : __builtin_amdgcn_rcpf(1.0f + d);
 }
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX>
@@ -130,7 +133,8 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     constexpr int kRing = kRingBytes / kStageBytes;              // 8 / 4 stages (all but one in flight)
     constexpr int kPieces = 4 * KS;                              // 1-KiB DMA instructions per wave and stage
     constexpr uint32_t LR = 16 * KS;                             // lanes (16-B chunks) per row of a stage
-    constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_EUCLIDEAN;  // |v| of the tile's rows
+    constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;  // 1/(1+d), or -d (IVF list scans)
+    constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || kL2;  // |v| of the tile's rows
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | norms
     float* nrm = lds + kRingBytes / 4;                           // [kMaxRing tiles][64] row magnitudes (with one-stage
                                                                  // tiles up to kRing tiles are in flight at once)
@@ -296,10 +300,10 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) sc[e] = vn[e] == 0.f ? 0.f : sc[e] * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
                     }
-                    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                    if constexpr (kL2) {
                         const f4 vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + (uint32_t)rb * 16u + g * 4u);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) sc[e] = l2_score(qq, vn[e], sc[e]);
+                        for (int e = 0; e < 4; e++) sc[e] = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc[e]);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                         float sc = fin[rb][e];
                         if constexpr (METRIC == NMN_METRIC_COSINE)
                             sc = vn[e] == 0.f ? 0.f : sc * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
-                        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_score(qq, vn[e], sc);
+                        if constexpr (kL2) sc = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc);
                         bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
                         if (valid) tkey = max(tkey, score_to_key(sc));
                     }
@@ -404,7 +408,9 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 // Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768, or 1024 / 1280 /
 // 1536; 64 stationary queries per sweep (their bf16 B-fragments take up to 192 VGPRs at 1536).
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
-    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN) || ld != dim ||
+    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN ||
+          metric == kMetricNegL2) ||
+        ld != dim ||
         ld % kStageK != 0)
         return false;
     const uint32_t kc = ld / kStageK;
@@ -416,6 +422,7 @@ hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
     switch (p.metric) {
         case NMN_METRIC_COSINE: return launch_metric<NMN_METRIC_COSINE>(p, s);
         case NMN_METRIC_EUCLIDEAN: return launch_metric<NMN_METRIC_EUCLIDEAN>(p, s);
+        case kMetricNegL2: return launch_metric<kMetricNegL2>(p, s);
         default: return launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
     }
 }

@@ -77,11 +77,16 @@ __device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
         if (qi.pad > 0.0f && tau > 0.0f) tau = tau / (1.0f + qi.pad * tau);
         // ... swept by the matrix cores (|q|^2 + |v|^2 - 2 q.v): the SQUARED distance may be off by up to -qi.pad
         // (two-sided), i.e. the threshold distance d = 1/tau - 1 grows to sqrt(d^2 - qi.pad)
-        if (qi.pad < 0.0f && tau > 0.0f) {
+        float m_abs = qi.margin_abs;
+        if (qi.pad < 0.0f && qi.margin_abs < 0.0f) {  // ... with the score -d of the IVF list scan (flag: margin_abs < 0)
+            const float d = fmaxf(-tau, 0.0f);
+            tau = -sqrtf(d * d - qi.pad);
+            m_abs = 0.0f;
+        } else if (qi.pad < 0.0f && tau > 0.0f) {
             const float d = fmaxf(1.0f / tau - 1.0f, 0.0f);
             tau = 1.0f / (1.0f + sqrtf(d * d - qi.pad));
         }
-        const float thr = tau - qi.margin_abs - fabsf(tau) * qi.margin_rel;
+        const float thr = tau - m_abs - fabsf(tau) * qi.margin_rel;
         if (thr == thr) {
             Tc = score_to_key(thr);
             if (Tc > T) Tc = T;

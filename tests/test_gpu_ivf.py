@@ -211,3 +211,44 @@ def test_gpu_kmeans_training_matches_oracle(init):
     o0.train(V[:50])
     with GpuIvfFlat.build(V[:50], 3, max_iterations=0, seed=9, init_method=init) as gpu:
         assert np.array_equal(gpu.centroids(), o0.centroids)
+
+
+@pytest.mark.parametrize("d", [64, 128, 768])   # VALU list scans only / mixed-filter matrix-core sweeps from 5 / 3 probes
+def test_concurrent_probes_equal_sequential_probes(d):
+    """Searches of one IVF index from many threads (each with a probe slot of its own; the list scans go through the
+    flat index's coalescer) return exactly what the same searches return one at a time."""
+    import threading
+    from neumann_amd.ivf import GpuIvfFlat
+    rng = np.random.default_rng(31)
+    n, nlist, k = (60_000 if d < 768 else 24_000), 48, 12
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X[1000:1040] = X[999]                                  # ties across and inside lists
+    ivf = GpuIvfFlat.build(X[:12_000], nlist, nprobe=6, max_iterations=3, seed=7, init_method="random", capacity_rows=n)
+    with ivf:
+        ivf.add(X[12_000:])
+        Q = rng.standard_normal((64, d)).astype(np.float32)
+        Q[5] = X[999]
+        want = [ivf.search(q, k) for q in Q]
+        got = [None] * 64
+        errs = []
+        start = threading.Barrier(16)
+
+        def work(t):
+            try:
+                start.wait()
+                for rep in range(3):
+                    for j in range(t, 64, 16):
+                        got[j] = ivf.search(Q[j], k, nprobe=6 if j % 2 else 9)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        want = [ivf.search(Q[j], k, nprobe=6 if j % 2 else 9) for j in range(64)]
+        th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for j in range(64):
+            for a, b in zip(want[j], got[j]):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), j

@@ -62,6 +62,28 @@ def main():
         dt = (time.perf_counter() - t0) / len(Q)
         out["probe_ms_per_query"] = round(dt * 1e3, 3)
         out["probe_queries_per_s"] = round(1 / dt, 1)
+        # concurrent callers (probe slots + the flat index's coalescer): T threads, each its own queries
+        import threading
+        conc = {}
+        for T in (4, 16, 64):
+            QT = synth_rows(0x1F8, 0, T, d)
+            reps = 40
+            start = threading.Barrier(T + 1)
+
+            def work(t):
+                start.wait()
+                for _ in range(reps):
+                    ivf.search(QT[t], args.k)
+
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            for x in th:
+                x.start()
+            start.wait()
+            t0 = time.perf_counter()
+            for x in th:
+                x.join()
+            conc[str(T)] = round(T * reps / (time.perf_counter() - t0), 1)
+        out["probe_queries_per_s_by_threads"] = conc
         # exhaustive Euclidean scan over the same rows through the same C ABI
         lib = _capi.load()
         vec = lib.nmn_ivf_vectors(ivf._h)
