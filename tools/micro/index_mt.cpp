@@ -27,15 +27,48 @@ int main(int argc, char** argv) {
     nmn_index* idx = nullptr;
     if (nmn_index_create(&d, &idx) != 0) { printf("create failed: %s\n", nmn_last_error()); return 1; }
     if (nmn_index_fill_synthetic(idx, 20240601, 0, rows) != 0) { printf("fill failed: %s\n", nmn_last_error()); return 1; }
+    const int max_threads_q = 512;
+    std::vector<float> Q((size_t)max_threads_q * dim);
+    nmn_synth_fill_host(Q.data(), 8, 0, max_threads_q, dim);
+    // INDEX_MT_FILTER=B: an int column bucket = row % B; thread t searches WHERE bucket = t % B through
+    // nmn_index_search_pred (predicate + search in one call)
+    const int filt = getenv("INDEX_MT_FILTER") ? atoi(getenv("INDEX_MT_FILTER")) : 0;
+    nmn_columns* cols = nullptr;
+    uint32_t col = 0;
+    if (filt) {
+        if (nmn_columns_create(0, rows, &cols) != 0 || nmn_columns_add(cols, &col) != 0) { printf("columns failed: %s\n", nmn_last_error()); return 1; }
+        const uint64_t chunk = 1 << 20;
+        std::vector<uint8_t> kinds(chunk, NMN_CELL_INT);
+        std::vector<uint64_t> pay(chunk);
+        for (uint64_t r0 = 0; r0 < rows; r0 += chunk) {
+            const uint64_t n = std::min(chunk, rows - r0);
+            for (uint64_t i = 0; i < n; i++) pay[i] = (r0 + i) % (uint64_t)filt;
+            if (nmn_columns_write(cols, col, r0, n, kinds.data(), pay.data()) != 0) { printf("columns write failed\n"); return 1; }
+        }
+        std::vector<uint64_t> ones((rows + 63) / 64, ~0ull);
+        if (rows & 63) ones.back() = (1ull << (rows & 63)) - 1ull;
+        if (nmn_columns_write_valid(cols, 0, ones.size(), ones.data()) != 0) { printf("valid failed\n"); return 1; }
+    }
+    auto one_search = [&](int t, uint64_t* rws, float* sc, uint32_t* c) -> int {
+        if (!filt)
+            return nmn_index_search(idx, Q.data() + (size_t)t * dim, 1, k, metric, nullptr, rws, sc, c, nullptr);
+        nmn_pred_op op;
+        memset(&op, 0, sizeof op);
+        op.op = NMN_PRED_CMP;
+        op.cmp = NMN_CMP_EQ;
+        op.vkind = NMN_CELL_INT;
+        op.column = col;
+        op.a = (uint64_t)(t % filt);
+        uint64_t selected = 0;
+        return nmn_index_search_pred(idx, cols, &op, 1, nullptr, 0, Q.data() + (size_t)t * dim, 1, k, metric, rws, sc, c,
+                                     &selected, nullptr);
+    };
     const int max_threads = 512;
-    std::vector<float> Q((size_t)max_threads * dim);
-    nmn_synth_fill_host(Q.data(), 8, 0, max_threads, dim);
     std::vector<uint64_t> ref_rows((size_t)max_threads * k);
     std::vector<float> ref_scores((size_t)max_threads * k);
     uint32_t cnt = 0;
     for (int t = 0; t < max_threads; t += 37)  // reference answers, one caller at a time
-        if (nmn_index_search(idx, Q.data() + (size_t)t * dim, 1, k, metric, nullptr, ref_rows.data() + (size_t)t * k,
-                             ref_scores.data() + (size_t)t * k, &cnt, nullptr) != 0) { printf("search failed: %s\n", nmn_last_error()); return 1; }
+        if (one_search(t, ref_rows.data() + (size_t)t * k, ref_scores.data() + (size_t)t * k, &cnt) != 0) { printf("search failed: %s\n", nmn_last_error()); return 1; }
     for (int a = 6; a < argc; a++) {
         const int nt = std::min(atoi(argv[a]), max_threads);
         std::atomic<long> done{0};
@@ -51,7 +84,7 @@ int main(int argc, char** argv) {
                 std::vector<float> sc(k);
                 uint32_t c = 0;
                 while (!stop) {
-                    if (nmn_index_search(idx, Q.data() + (size_t)t * dim, 1, k, metric, nullptr, rws.data(), sc.data(), &c, nullptr) != 0) { bad++; break; }
+                    if (one_search(t, rws.data(), sc.data(), &c) != 0) { bad++; break; }
                     if (t % 37 == 0 && (memcmp(rws.data(), ref_rows.data() + (size_t)t * k, (size_t)k * 8) != 0 ||
                                         memcmp(sc.data(), ref_scores.data() + (size_t)t * k, (size_t)k * 4) != 0)) bad++;
                     done++;
