@@ -304,7 +304,7 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
     if (!d || !out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->dim == 0) return fail_arg(NMN_ERR_EMPTY_VECTOR, "dim == 0");
-    const uint32_t ld = (d->dim + 3u) & ~3u;
+    const uint32_t ld = (d->dim + 7u) & ~7u;  // whole 16-byte chunks of the bf16 mirror too: every row length gets it
     if ((uint64_t)ld * 4ull > 160ull * 1024ull)
         return fail_arg(NMN_ERR_INVALID_ARGUMENT, "dim too large: one query must fit the 160 KiB LDS");
     if (d->capacity_rows >= 0xFFFFFFC0ull)

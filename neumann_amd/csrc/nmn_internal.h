@@ -100,7 +100,7 @@ struct ScanParams {
     // MFMA sweep only: sampling and score-write suppression (nmn_scan_mfma.hip)
     uint32_t tile_step;      // 1: every tile; S: sample pass over tiles 0,S,2S,.. (tile maxima only -> tmax[q][i])
     const uint32_t* skip_key;  // nullable [nq]: scores of a tile are written only if its maximum key >= skip_key[q]
-    uint32_t ld;             // floats per row, multiple of 4
+    uint32_t ld;             // floats per row, multiple of 8
     uint32_t n_tiles;
     uint32_t nq;
     uint32_t tiles_per_wave;
