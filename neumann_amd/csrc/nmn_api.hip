@@ -363,6 +363,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->corpus) (void)hipFree(idx->corpus);
     if (idx->half) (void)hipFree(idx->half);
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
+    if (idx->half_scratch) (void)hipFree(idx->half_scratch);
     if (idx->half_stats) (void)hipFree(idx->half_stats);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
@@ -485,6 +486,29 @@ static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* quer
     return NMN_OK;
 }
 
+// scratch of the mirror conversion: persistent up to 1M rows (4 MiB); a bulk build's larger buffer is returned afterwards.
+// Caller holds idx->mu and waits for the conversion before anybody else can ask.
+static hipError_t half_scratch_get(nmn_index* idx, uint64_t rows, float** out) {
+    if (rows > idx->half_scratch_cap) {
+        if (idx->half_scratch) (void)hipFree(idx->half_scratch);
+        idx->half_scratch = nullptr;
+        idx->half_scratch_cap = 0;
+        const size_t want = (size_t)std::max<uint64_t>(rows, 4096);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half_scratch), want * sizeof(float));
+        if (e != hipSuccess) return e;
+        idx->half_scratch_cap = want;
+    }
+    *out = idx->half_scratch;
+    return hipSuccess;
+}
+static void half_scratch_trim(nmn_index* idx) {
+    if (idx->half_scratch_cap > (1u << 20)) {
+        (void)hipFree(idx->half_scratch);
+        idx->half_scratch = nullptr;
+        idx->half_scratch_cap = 0;
+    }
+}
+
 // Smallest batch that takes the matrix-core sweep.  Its time does not depend on the number of queries (<= 64) while the
 // VALU sweep slows with every query it adds: measured crossover at 3 queries for rows of >= 768 dimensions (10M x 768:
 // 3.00 vs 2.69 ms; 5M x 1536: 2.55 vs 2.33 ms), at 5 (= a second VALU sweep) for short rows (10M x 128: 1.30 vs
@@ -570,13 +594,13 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             if (use_half && idx->half_rows < n_rows) {
                 const uint64_t cnt = n_rows - idx->half_rows;
                 float* scratch = nullptr;
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), cnt * sizeof(float)));
+                HIP_TRY(half_scratch_get(idx, cnt, &scratch));
                 hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, idx->half_rows, cnt, idx->norms, scratch,
                                                  idx->half_err_bits, stream);
                 // rare (first search, or rows uploaded since): wait here so that searches enqueued on OTHER streams
                 // afterwards may rely on the mirror without cross-stream events
                 if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
-                (void)hipFree(scratch);
+                half_scratch_trim(idx);
                 if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
                 idx->half_rows = n_rows;
             }
@@ -1522,10 +1546,9 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
     if (idx->half && row < idx->half_rows) {
         float* scratch = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(float)));
+        HIP_TRY(half_scratch_get(idx, 1, &scratch));
         hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, row, 1, idx->norms, scratch, idx->half_err_bits, s);
         if (ce == hipSuccess) ce = hipStreamSynchronize(s);
-        (void)hipFree(scratch);
         if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
     }
     HIP_TRY(hipStreamSynchronize(s));

@@ -115,6 +115,8 @@ struct nmn_index {
     uint32_t half_seen[2] = {0, 0};     // counters at the last look
     uint64_t half_calls = 0, half_off_until = 0;
     uint32_t* half_err_bits = nullptr;  // device [2]: max_r |e_r| and max_r |e_r|/|v_r| of the mirror's rounding (f32 bits)
+    float* half_scratch = nullptr;      // |e_r|^2 of the rows being converted; kept (hipMalloc / hipFree per store or per
+    size_t half_scratch_cap = 0;        // search after a store would synchronise the whole device every time)
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;
     hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot
