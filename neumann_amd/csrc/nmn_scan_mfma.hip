@@ -143,20 +143,28 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t g = lane >> 4, n = lane & 15u;
     const uint32_t ld = p.ld;
     const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
+    // QG = 2 (rows of 2048 / 3072 elements: one group's B-fragments already take 128 / 192 VGPRs): the workgroup keeps 32
+    // queries, and a group is shared by TWO waves that split the k-steps of every stage between them (kh = 0 / 1); their
+    // partial sums meet once per tile through LDS and the kh = 0 wave finishes the group.
+    constexpr bool kHalfK = QG == 2;
+    const uint32_t grp = kHalfK ? (wave & 1u) : wave;  // the (first) query group this wave multiplies
+    const uint32_t kh = kHalfK ? (wave >> 1) : 0u;     // its half of the k-steps of a stage
 
-    // ---- stationary operand: QG*16 queries x this wave's k-step of every stage -----------------
-    constexpr int kBK = KC * KS * 4;  // k-steps of 32 elements per row
-    constexpr int kBG = QG / 4;       // query groups of this wave: groups wave, wave + 4, ...
+    // ---- stationary operand: the wave's query groups x its k-steps of every stage -----------------
+    constexpr int kSteps = kHalfK ? 2 * KS : 4 * KS;  // k-steps (32 elements) of a stage this wave multiplies
+    constexpr int kBK = KC * kSteps;                  // ... of a row
+    constexpr int kBG = kHalfK ? 1 : QG / 4;          // query groups of this wave: groups wave, wave + 4, ...
     s8 bhi[kBK][kBG];
-    static_assert(QG % 4 == 0, "query groups come in fours (one per wave)");
+    static_assert(QG == 2 || QG % 4 == 0, "query groups come in fours (one per wave), or two split over wave pairs");
 #pragma unroll
     for (int qg = 0; qg < kBG; qg++) {
-        const uint32_t qq = q0 + ((uint32_t)qg * 4u + wave) * 16u + n;
+        const uint32_t qq = q0 + ((uint32_t)qg * 4u + grp) * 16u + n;
         const bool ok = qq < p.nq;
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
 #pragma unroll
         for (int kc = 0; kc < kBK; kc++) {
-            const uint32_t k0 = (uint32_t)kc * 32u + g * 8u;  // k0..k0+7
+            // k-step kc of this wave = k-step kh*kSteps + kc % kSteps of stage kc / kSteps
+            const uint32_t k0 = ((uint32_t)(kc / kSteps) * (4u * KS) + kh * (uint32_t)kSteps + (uint32_t)(kc % kSteps)) * 32u + g * 8u;  // k0..k0+7
             f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 a = *reinterpret_cast<const f4*>(qv + k0);
@@ -173,8 +181,8 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     float qmag_h[kHalves];
 #pragma unroll
     for (int h = 0; h < kHalves; h++) {
-        qn_h[h] = q0 + ((uint32_t)h * 4u + wave) * 16u + n;
-        q_ok_h[h] = (uint32_t)h * 4u + wave < (uint32_t)QG && qn_h[h] < p.nq;
+        qn_h[h] = q0 + ((uint32_t)h * 4u + grp) * 16u + n;
+        q_ok_h[h] = kh == 0 && (uint32_t)h * 4u + grp < (uint32_t)QG && qn_h[h] < p.nq;
         qmag_h[h] = q_ok_h[h] ? p.qinfo[qn_h[h]].qmag : 0.f;
         skip_h[h] = (q_ok_h[h] && p.skip_key) ? p.skip_key[qn_h[h]] : kKeyNaN;  // kKeyNaN: write every tile
         wmax_h[h] = kKeyMasked;
@@ -210,10 +218,10 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 
     // LDS offset (floats) of this lane's 16-B read per row block and k-step ks: row n, chunk ks*4+g of the row's 16*KS
     // (swizzled ^ n)
-    constexpr int kSteps = 4 * KS;  // k-steps of a stage
     uint32_t off[kSteps];
 #pragma unroll
-    for (int ks = 0; ks < kSteps; ks++) off[ks] = n * kRowPitch + ((((uint32_t)ks * 4u + g) ^ n) * 4u);
+    for (int ks = 0; ks < kSteps; ks++)
+        off[ks] = n * kRowPitch + ((((kh * (uint32_t)kSteps + (uint32_t)ks) * 4u + g) ^ n) * 4u);
 
     uint32_t sidx = 0;  // running stage index of this workgroup
     for (uint32_t tile = t0; tile < t1; tile++) {
@@ -255,6 +263,25 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #pragma unroll
                     for (int qg = 0; qg < kBG; qg++)
                         acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if constexpr (kHalfK) {
+            // the two K-halves of a group meet: wave kh = 1 publishes, wave kh = 0 adds and finishes.  (The next
+            // publication is a whole tile of stage barriers away: no second barrier needed.)
+            float* xch = nrm + kMaxRing * 64;  // [2 groups][64 lanes][4 row blocks] f4
+            if (kh == 1) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+                    *reinterpret_cast<f4*>(xch + ((grp * 64u + lane) * 4u + (uint32_t)rb) * 4u) = acc[rb][0];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kh == 0) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+                    acc[rb][0] += *reinterpret_cast<const f4*>(xch + ((grp * 64u + lane) * 4u + (uint32_t)rb) * 4u);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -346,7 +373,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             }
         }
         };
-        finish_half(std::integral_constant<int, 0>{});
+        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{});
         if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{});
     }
     if (sampling) return;  // the sampling pass leaves only tmax
@@ -359,7 +386,7 @@ template <int KC, int KS, int QG, int METRIC, bool MASKED>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid(blocks, (p.nq + QG * 16 - 1) / (QG * 16));
-    const size_t lds = kRingBytes + kMaxRing * 64 * 4;
+    const size_t lds = kRingBytes + kMaxRing * 64 * 4 + (QG == 2 ? 2 * 64 * 4 * 16 : 0);  // + the K-halves' exchange
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
     auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -401,12 +428,14 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
         case 8: return launch_kc<4, 2, 4, METRIC>(p, s);   // 1024
         case 10: return launch_kc<5, 2, 4, METRIC>(p, s);  // 1280
         case 12: return launch_kc<6, 2, 4, METRIC>(p, s);  // 1536
+        case 16: return launch_kc<8, 2, 2, METRIC>(p, s);  // 2048: 32 stationary queries, K-halves on wave pairs
+        case 24: return launch_kc<12, 2, 2, METRIC>(p, s); // 3072
         default: return hipErrorInvalidValue;
     }
 }
 
 // Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768, or 1024 / 1280 /
-// 1536; 64 stationary queries per sweep (their bf16 B-fragments take up to 192 VGPRs at 1536).
+// 1536 with 64 stationary queries per workgroup (their bf16 B-fragments take up to 192 VGPRs at 1536), or 2048 / 3072 with 32.
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
     if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN ||
           metric == kMetricNegL2) ||
@@ -414,7 +443,7 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
         ld % kStageK != 0)
         return false;
     const uint32_t kc = ld / kStageK;
-    return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12;
+    return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12 || kc == 16 || kc == 24;
 }
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
