@@ -1,11 +1,13 @@
 // nmn_api.hip — the C ABI of libneumann_gpu.so (declared in include/neumann_gpu.h): shard
-// lifecycle, upload, the SIMILAR TOP-K pipeline, shard merge, synthetic data.  Host code only; every
-// kernel lives in nmn_scan/nmn_select/nmn_exact/nmn_synth.hip.  No CPU compute path exists here:
-// without a HIP device every entry point fails with NMN_ERR_NO_DEVICE.
+// lifecycle, upload, the SIMILAR TOP-K pipeline (search_enqueue: mirror lifecycle, sweep choice, crowd path, retry,
+// fallback), the request coalescer of the host-buffer searches (host_submit / host_batch_body: concurrent callers,
+// mixed filters, predicates evaluated with the batch), shard merge, synthetic data.  Host code only; every kernel
+// lives in nmn_scan / nmn_scan_mfma / nmn_select / nmn_exact / nmn_sortk / nmn_columns / nmn_synth.hip.  No CPU
+// compute path exists here: without a HIP device every entry point fails with NMN_ERR_NO_DEVICE.
 #include <algorithm>
-#include <thread>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
