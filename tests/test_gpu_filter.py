@@ -489,3 +489,31 @@ def test_search_pred_one_call_equals_eval_then_search(n, d):
         assert not errs, errs
         for j in range(40):
             check(j, out[j], 0)
+
+
+def test_search_pred_with_several_queries_and_few_matches():
+    """One predicate, several queries in the call; fewer matching rows than k; and an empty selection."""
+    from neumann_amd import GpuFlatIndex
+    from neumann_amd import columns as g
+    n, d, k = 20000, 768, 25
+    A = oc.synth(25, 0, n, d)
+    Q = oc.synth(26, 0, 5, d)
+    tag = np.arange(n) % 2000
+    with GpuFlatIndex(d, n) as idx, g.GpuColumns(n) as gc:
+        idx.upload(A)
+        c = gc.add_column()
+        gc.write(c, 0, np.full(n, g.CELL_INT, np.uint8), tag.astype(np.uint64))
+        gc.write_valid(0, np.full((n + 63) // 64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+        for value, metric in ((7, 0), (7, 1), (1999, 2), (5000, 0)):
+            keep = tag == value                                   # 10 rows match (or none)
+            rows, scores, counts, selected = idx.search_pred(gc, [(g.PRED_CMP, g.CMP_EQ, g.CELL_INT, c, value, 0)], [], Q, k, metric)
+            assert selected == int(keep.sum())
+            for qi in range(5):
+                if not keep.any():
+                    assert counts[qi] == 0
+                    continue
+                er, es = oc.search(A, Q[qi], k, metric, mask=oc.mask_from_bool(keep))
+                cnt = er.size
+                assert counts[qi] == cnt == 10
+                assert np.array_equal(rows[qi, :cnt], er) and np.all(scores[qi, :cnt] == es)
+                assert np.all(rows[qi, cnt:] == np.uint64(0xFFFFFFFFFFFFFFFF))
