@@ -399,6 +399,9 @@ extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
     return NMN_OK;
 }
 
+static hipError_t half_scratch_get(nmn_index* idx, uint64_t rows, float** out);
+static void half_scratch_trim(nmn_index* idx);
+
 static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_host, uint64_t row0, uint64_t n,
                                 hipStream_t stream) {
     if (!idx || (!src && n)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
@@ -416,7 +419,18 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
     idx->rows = std::max(idx->rows, row0 + n);
-    idx->half_rows = std::min(idx->half_rows, row0);  // the mirror is re-derived from row0 on, lazily
+    if (idx->half && row0 < idx->half_rows) {
+        // rows the mirror already holds are patched in place (re-deriving the mirror "from row0 on" made one overwritten
+        // row near the top cost a conversion of the whole shard at the next search); rows beyond it are converted lazily
+        const uint64_t cnt = std::min(row0 + n, idx->half_rows) - row0;
+        float* scratch = nullptr;
+        HIP_TRY(half_scratch_get(idx, cnt, &scratch));
+        HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row0, cnt, idx->norms, scratch, idx->half_err_bits, stream));
+        if (idx->half_scratch_cap > (1u << 20)) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            half_scratch_trim(idx);
+        }
+    }
     return NMN_OK;
 }
 

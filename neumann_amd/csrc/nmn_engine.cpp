@@ -230,6 +230,11 @@ struct Mirror {
     std::vector<uint64_t> live;  // bit r of word r/64: row r takes part
     uint64_t cap = 0, n_dead = 0;
     int32_t device = -1;
+    // Rows whose vector changed on the host since the last upload (stores of existing keys, appended keys).  A store
+    // only records the row; the next search of this mirror uploads all of them in runs of consecutive rows (one store =
+    // one H2D + two kernels + two stream waits, ~25 us: 45k stores/s against 350k without a mirror).  Rows beyond
+    // nmn_index_rows() are always dirty (appends are contiguous).
+    std::vector<uint64_t> dirty;
     nmn_columns* cols = nullptr;  // null until a filtered search needs it (or after a device error)
     std::unordered_map<std::string, FieldColumn> fields;
     void drop_columns() {
@@ -249,6 +254,7 @@ struct Collection {
     std::vector<uint32_t> free_slots;
     uint64_t live = 0;
     std::unordered_map<uint64_t, std::unique_ptr<Mirror>> mirrors;  // by dimension
+    bool has_dirty = false;                                          // some mirror here has stores pending
     void invalidate() { mirrors.clear(); }  // full drop (delete_collection / clear)
 };
 
@@ -296,6 +302,7 @@ struct nmn_engine {
                 if (--waiting_readers == 0) readers_turn = false;  // the cohort is in: the next writer's turn
             }
             active_readers++;
+            reader_entries++;
         }
         void read_unlock() {
             std::lock_guard<std::mutex> g(m);
@@ -308,6 +315,14 @@ struct nmn_engine {
             waiting_writers--;
             writer_active = true;
         }
+        uint64_t reader_entries = 0;  // searches that entered so far
+        // searches are waiting right now, or some ran since the caller last looked (*seen is updated)
+        bool readers_around(uint64_t* seen) {
+            std::lock_guard<std::mutex> g(m);
+            const bool around = waiting_readers > 0 || reader_entries != *seen;
+            *seen = reader_entries;
+            return around;
+        }
         void write_unlock() {
             std::lock_guard<std::mutex> g(m);
             writer_active = false;
@@ -319,6 +334,10 @@ struct nmn_engine {
             }
         }
     } rw;
+    // A writer that finds searches waiting for the lock — or that searches ran since the previous write — uploads the
+    // pending stores (Mirror::dirty, Collection::has_dirty) before it leaves: it already holds the exclusive lock the
+    // upload needs.  With no search around they stay pending and a burst of stores becomes one upload.
+    uint64_t reader_entries_seen = 0;
     Collection dflt;
     Collection entities;                              // unified entity mode: keys whose TensorData has `_embedding`
     Collection artifacts;                             // tensor_blob: `_blob:meta:{id}` records that carry `_embedding`
@@ -341,10 +360,14 @@ struct nmn_engine {
 namespace {
 
 // exclusive / shared lock of the engine (nmn_engine::PhaseFairLock)
+void flush_dirty_mirrors(nmn_engine* e);
 struct WriteLock {
     nmn_engine* e;
     explicit WriteLock(nmn_engine* e_) : e(e_) { e->rw.write_lock(); }
-    ~WriteLock() { e->rw.write_unlock(); }
+    ~WriteLock() {
+        if (e->rw.readers_around(&e->reader_entries_seen)) flush_dirty_mirrors(e);
+        e->rw.write_unlock();
+    }
     WriteLock(const WriteLock&) = delete;
     WriteLock& operator=(const WriteLock&) = delete;
 };
@@ -462,15 +485,23 @@ void mirror_tombstone(Collection* c, uint64_t dim, int64_t row) {
     else columns_sync_valid(m, (uint64_t)row >> 6);
 }
 
+void mark_dirty(Collection* c, Mirror* m, uint64_t dim, uint64_t row) {
+    (void)dim;
+    m->dirty.push_back(row);
+    c->has_dirty = true;
+}
+
 // append one vector to the mirror of its dimension; returns its row, or -1 (mirror absent / dropped)
 int64_t mirror_append(Collection* c, uint64_t dim, const float* v, uint32_t slot, const Meta& meta) {
     Mirror* m = mirror_of(c, dim);
     if (!m) return -1;
     const uint64_t row = m->row_to_slot.size();
-    if (row >= m->cap || nmn_index_upload(m->idx, v, row, 1) != NMN_OK) {
-        c->mirrors.erase(dim);  // out of spare capacity (or a device error): rebuild on the next search
+    (void)v;  // uploaded by mirror_flush from the slot's host copy
+    if (row >= m->cap) {
+        c->mirrors.erase(dim);  // out of spare capacity: rebuild on the next search
         return -1;
     }
+    mark_dirty(c, m, dim, row);
     m->row_to_slot.push_back(slot);
     if ((row >> 6) >= m->live.size()) m->live.push_back(0ull);
     m->live[row >> 6] |= 1ull << (row & 63);
@@ -494,12 +525,9 @@ nmn_status store_into(nmn_engine* e, Collection* c, const char* key, const float
         const uint64_t old_dim = old.vec.size();
         Mirror* m = old.mrow >= 0 ? mirror_of(c, old_dim) : nullptr;
         if (m && old_dim == dim) {
-            if (nmn_index_set_row(m->idx, (uint64_t)old.mrow, v) == NMN_OK) {
-                ent.mrow = old.mrow;
-                columns_write_row(m, (uint64_t)old.mrow, ent.meta, true);
-            } else {
-                c->mirrors.erase(old_dim);
-            }
+            mark_dirty(c, m, dim, (uint64_t)old.mrow);
+            ent.mrow = old.mrow;
+            columns_write_row(m, (uint64_t)old.mrow, ent.meta, true);
         } else {
             if (m) mirror_tombstone(c, old_dim, old.mrow);
             ent.mrow = mirror_append(c, dim, v, it->second, ent.meta);
@@ -535,12 +563,60 @@ nmn_status delete_from(Collection* c, const std::string& key, const std::string&
     return NMN_OK;
 }
 
+// Upload the vectors recorded in m->dirty (exclusive lock held): runs of consecutive rows, one nmn_index_upload each.
+// A row that died meanwhile still gets a vector (appends must stay contiguous; the live bitmap keeps it out of every
+// scan).  On a device error the mirror is dropped and rebuilt by the caller's get_mirror.
+bool mirror_flush(Collection* c, Mirror* m, uint64_t dim) {
+    if (m->dirty.empty() || !m->idx) {
+        m->dirty.clear();
+        return true;
+    }
+    std::sort(m->dirty.begin(), m->dirty.end());
+    m->dirty.erase(std::unique(m->dirty.begin(), m->dirty.end()), m->dirty.end());
+    std::vector<float> buf;
+    size_t i = 0;
+    while (i < m->dirty.size()) {
+        size_t j = i + 1;
+        while (j < m->dirty.size() && m->dirty[j] == m->dirty[j - 1] + 1 && j - i < 65536) j++;
+        buf.assign((j - i) * dim, 0.0f);
+        for (size_t r = i; r < j; r++) {
+            const uint64_t row = m->dirty[r];
+            if (row >= m->row_to_slot.size()) continue;
+            const Entry& ent = c->slots[m->row_to_slot[row]];
+            if (ent.live && ent.mrow == (int64_t)row && ent.vec.size() == dim)
+                memcpy(buf.data() + (r - i) * dim, ent.vec.data(), dim * sizeof(float));
+        }
+        if (nmn_index_upload(m->idx, buf.data(), m->dirty[i], j - i) != NMN_OK) return false;
+        i = j;
+    }
+    m->dirty.clear();
+    return true;
+}
+
+void flush_collection(Collection* c) {
+    if (!c->has_dirty) return;
+    c->has_dirty = false;
+    for (auto it = c->mirrors.begin(); it != c->mirrors.end();) {
+        if (!it->second->dirty.empty() && !mirror_flush(c, it->second.get(), it->first)) it = c->mirrors.erase(it);
+        else ++it;
+    }
+}
+void flush_dirty_mirrors(nmn_engine* e) {  // exclusive lock held
+    flush_collection(&e->dflt);
+    flush_collection(&e->entities);
+    flush_collection(&e->artifacts);
+    for (auto& kv : e->colls) flush_collection(&kv.second);
+}
+
 // Lazily (re)build the GPU mirror of the rows of `c` with dimension `dim`.
 nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) {
     auto it = c->mirrors.find(dim);
     if (it != c->mirrors.end()) {
-        *out = it->second.get();
-        return NMN_OK;
+        if (mirror_flush(c, it->second.get(), dim)) {
+            *out = it->second.get();
+            return NMN_OK;
+        }
+        c->mirrors.erase(it);  // device error while patching: rebuild from the store
     }
     auto m = std::make_unique<Mirror>();
     m->device = e->cfg.device;
@@ -649,14 +725,25 @@ nmn_status search_common(nmn_engine* e, Collection* c, const float* q, uint64_t 
 template <typename Resolve>
 nmn_status locked_search(nmn_engine* e, Resolve resolve, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
                          const char* op, const Deadline& dl, nmn_results* res) {
-    {
-        ReadLock rd(e);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        {
+            ReadLock rd(e);
+            Collection* c = resolve();
+            if (!c) return NMN_OK;
+            auto it = c->mirrors.find(dim);
+            if (it != c->mirrors.end() && it->second->dirty.empty())
+                return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, it->second.get(), res);
+        }
+        // the mirror is missing or has stores pending: build / patch it under the exclusive lock, then search under
+        // the shared one like everybody else (a search under the exclusive lock cannot share a sweep with anybody)
+        WriteLock wr(e);
         Collection* c = resolve();
         if (!c) return NMN_OK;
-        auto it = c->mirrors.find(dim);
-        if (it != c->mirrors.end()) return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, it->second.get(), res);
+        Mirror* m = nullptr;
+        nmn_status st = get_mirror(e, c, dim, &m);
+        if (st != NMN_OK) return st;
     }
-    WriteLock wr(e);
+    WriteLock wr(e);  // stores keep arriving between our two locks: serve this one exclusively
     Collection* c = resolve();
     if (!c) return NMN_OK;
     return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, nullptr, res);
@@ -820,7 +907,7 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
         auto it = c->mirrors.find(dim);
         if (it == c->mirrors.end()) return kRetryExclusive;
         m = it->second.get();
-        if (m->idx && !m->cols) return kRetryExclusive;
+        if (!m->dirty.empty() || (m->idx && !m->cols)) return kRetryExclusive;
     } else {
         nmn_status st = get_mirror(e, c, dim, &m);
         if (st != NMN_OK) return st;
@@ -870,13 +957,21 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
     return NMN_OK;
 }
 
+// what a shared-lock filtered search needs to find in place (exclusive lock held)
+nmn_status prepare_filtered(nmn_engine* e, Collection* c, uint64_t dim) {
+    Mirror* m = nullptr;
+    nmn_status st = get_mirror(e, c, dim, &m);
+    if (st != NMN_OK || !m->idx) return st;
+    return columns_build(e, c, m);
+}
+
 // search_common for the post-filter arm: under the shared lock only when the mirror exists already
 nmn_status search_common_mode(nmn_engine* e, Collection* c, const float* q, uint64_t dim, uint64_t top_k, int32_t metric,
                               const char* op, const Deadline& dl, nmn_results* res, bool shared) {
     Mirror* prebuilt = nullptr;
     if (shared) {
         auto it = c->mirrors.find(dim);
-        if (it == c->mirrors.end()) return kRetryExclusive;
+        if (it == c->mirrors.end() || !it->second->dirty.empty()) return kRetryExclusive;
         prebuilt = it->second.get();
     }
     return search_common(e, c, q, dim, top_k, metric, op, dl, nullptr, prebuilt, res);
@@ -1615,6 +1710,14 @@ nmn_status nmn_engine_search_similar_filtered(nmn_engine* e, const float* q, uin
         ReadLock rd(e);
         st = run(true);
     }
+    if (st == kRetryExclusive) {  // build / patch the mirror and its columns exclusively, then search shared again
+        {
+            WriteLock g(e);
+            (void)prepare_filtered(e, &e->dflt, dim);
+        }
+        ReadLock rd(e);
+        st = run(true);
+    }
     if (st == kRetryExclusive) {
         WriteLock g(e);
         st = run(false);
@@ -1818,6 +1921,15 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
     return NMN_OK;
     };
     {
+        ReadLock rd(e);
+        st = run(true);
+    }
+    if (st == kRetryExclusive) {
+        {
+            WriteLock g(e);
+            Collection* c = e->storage(coll, false);
+            if (c) (void)prepare_filtered(e, c, dim);
+        }
         ReadLock rd(e);
         st = run(true);
     }
