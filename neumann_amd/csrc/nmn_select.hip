@@ -465,22 +465,37 @@ __global__ __launch_bounds__(256) void crowd_count_kernel(CrowdParams p) {
 }
 
 // slices of the pool, first come first served in query order; resets the counters for the next search
-__global__ void crowd_alloc_kernel(CrowdParams p) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t cursor = 0;
-    for (uint32_t q = 0; q < p.nq; q++) {
-        const uint32_t c = p.count[q];
+__global__ __launch_bounds__(256) void crowd_alloc_kernel(CrowdParams p) {  // one workgroup, nq <= 256
+    __shared__ uint32_t s_cnt[256], s_off[256];
+    const uint32_t q = threadIdx.x;
+    uint32_t c = 0;
+    if (q < p.nq) {  // loads and resets in parallel; only the slice cursor is sequential
+        c = p.count[q];
         p.count[q] = 0;
         p.fill[q] = 0;
-        if (p.qstate[q].overflow != 1 || c == 0) continue;
+        if (p.qstate[q].overflow != 1) c = 0;
         // a threshold that lets more than an eighth of the shard through is not a crowd around the query but a useless
         // margin (one row of enormous norm under a Euclidean metric): that is the f32 retry's case
-        if (c <= p.pool_cap - cursor && (uint64_t)c * 8u <= p.n_rows) {
-            p.offset[q] = cursor;
-            cursor += c;
-            p.qstate[q].overflow = 2;
-            p.qstate[q].cand_count = c;
+        if ((uint64_t)c * 8u > p.n_rows) c = 0;
+    }
+    s_cnt[threadIdx.x] = c;
+    s_off[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t cursor = 0;
+        for (uint32_t i = 0; i < p.nq && i < 256u; i++) {
+            const uint32_t ci = s_cnt[i];
+            if (ci != 0 && ci <= p.pool_cap - cursor) {
+                s_off[i] = cursor;
+                cursor += ci;
+            }
         }
+    }
+    __syncthreads();
+    if (q < p.nq && s_off[q] != 0xFFFFFFFFu) {
+        p.offset[q] = s_off[q];
+        p.qstate[q].overflow = 2;
+        p.qstate[q].cand_count = c;
     }
 }
 
@@ -496,9 +511,11 @@ __global__ __launch_bounds__(256) void crowd_fill_kernel(CrowdParams p) {
 }
 
 hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s) {
-    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((p.n_tiles + 64 * 4 - 1) / (64 * 4), 512));
+    // ~4096 workgroups in all: with many queries in the pass the (normally empty) launches stay cheap
+    const uint32_t gx_cap = std::max<uint32_t>(8, std::min<uint32_t>(512, 4096 / std::max<uint32_t>(p.nq, 1)));
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((p.n_tiles + 64 * 4 - 1) / (64 * 4), gx_cap));
     hipLaunchKernelGGL(crowd_count_kernel, dim3(gx, p.nq), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(crowd_alloc_kernel, dim3(1), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(crowd_alloc_kernel, dim3(1), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_fill_kernel, dim3(gx, p.nq), dim3(256), 0, s, p);
     return hipGetLastError();
 }
