@@ -705,3 +705,56 @@ def test_native_threads_searching_while_writers_write():
     lines = [l for l in out.stdout.splitlines() if l.startswith("rows=")]
     assert len(lines) == 2 and not any("ERRORS" in l for l in lines), out.stdout
     assert all("writers=2" in l for l in lines)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
+    """Stores are only recorded next to a live mirror and uploaded in batches before the next search: any order of
+    new keys, overwrites, deletes, re-inserts and searches (three metrics, random k) must answer like the oracle over
+    the current contents."""
+    rng = np.random.default_rng(400 + seed)
+    d = int(rng.choice([8, 48, 100, 128]))
+    model = {}                                     # key -> vector
+    eng = E.VectorEngine()
+    next_key = 0
+
+    def check():
+        keys = sorted(model, key=lambda s: int(s[1:]))
+        if not keys:
+            return
+        A = np.stack([model[k_] for k_ in keys])
+        q = rng.standard_normal(d).astype(np.float32)
+        k = int(rng.choice([1, 3, 10, 50]))
+        metric = (E.DistanceMetric.Cosine, E.DistanceMetric.Euclidean, E.DistanceMetric.DotProduct)[int(rng.integers(0, 3))]
+        res = eng.search_similar_with_metric(q, k, metric)
+        er, es = oc.search(A, q, k, int(metric))
+        got = {r.key: np.float32(r.score) for r in res}
+        # ties: the reference's order among equal scores is unspecified (HashSet scan order); compare as score lists and
+        # as sets above the last score
+        assert [np.float32(r.score) for r in res] == list(es)
+        last = es[-1] if len(es) else None
+        for i, s_ in zip(er, es):
+            if s_ != last:
+                assert keys[int(i)] in got and got[keys[int(i)]] == s_
+
+    for step in range(260):
+        op = rng.random()
+        if op < 0.45 or not model:                 # new key
+            key = f"k{next_key}"
+            next_key += 1
+            v = rng.standard_normal(d).astype(np.float32)
+            eng.store_embedding(key, v)
+            model[key] = v
+        elif op < 0.65:                            # overwrite
+            key = list(model)[int(rng.integers(0, len(model)))]
+            v = rng.standard_normal(d).astype(np.float32)
+            eng.store_embedding(key, v)
+            model[key] = v
+        elif op < 0.8:                             # delete
+            key = list(model)[int(rng.integers(0, len(model)))]
+            eng.delete_embedding(key)
+            del model[key]
+        else:
+            check()
+    check()
+    assert eng.count() == len(model)
