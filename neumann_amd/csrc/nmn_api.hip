@@ -254,7 +254,10 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->h_counts2), 2 * sizeof(unsigned long long)));
     if (idx->cap_pad >= kCrowdMinRows) {
-        w->crowd_cap = (uint32_t)std::min<uint64_t>(kCrowdPool, idx->cap_pad);
+        // 8M entries, or 128K per query of the pass when that is more (a 128-query batch of crowded queries)
+        // (never more than the pass can use: a crowd is at most an eighth of the shard per query)
+        w->crowd_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(kCrowdPool, (uint64_t)nq << 17),
+                                                    std::max<uint64_t>(idx->cap_pad, (uint64_t)nq * (idx->cap_pad / 8)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_ctr), 3 * nq * 4));
         HIP_TRY(hipMemset(w->crowd_ctr, 0, 3 * nq * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_rows), (size_t)w->crowd_cap * 4));
