@@ -198,3 +198,85 @@ def test_differently_filtered_callers_share_a_sweep(n, d):
             assert np.array_equal(rows[0, :c], er), (j, mi)
             assert np.all(scores[0, :c] == es), (j, mi)
             assert np.all(rows[0, c:] == U64_MAX)
+
+
+@pytest.mark.parametrize("n,d", [(30_000, 768), (40_000, 128)])
+def test_chaos_of_concurrent_call_kinds_is_batch_invariant(n, d):
+    """Every kind of host-buffer search at once — three metrics, k from 1 to 300, 1-3 queries per call, no filter, one
+    shared host bitmap, several device bitmaps, predicates — from 32 threads, with a writer re-writing rows in place.
+    Whatever batches form, each call must return what the same call returns alone afterwards (and the oracle agrees on
+    a sample)."""
+    import torch
+    from neumann_amd import GpuFlatIndex
+    from neumann_amd import columns as g
+    A = oc.synth(201, 0, n, d)
+    rng = np.random.default_rng(77)
+    words = (n + 63) // 64
+    host_mask = oc.mask_from_bool(rng.random(n) < 0.4)
+    dev_bool = [rng.random(n) < s for s in (0.05, 0.5, 0.95)]
+    dev_host = [oc.mask_from_bool(b) for b in dev_bool]
+    dev = torch.device("cuda:0")
+    dev_masks = [torch.from_numpy(m[:words].view(np.int64).copy()).to(dev) for m in dev_host]
+    torch.cuda.synchronize()
+    bucket = np.arange(n) % 7
+    jobs = []
+    for j in range(32 * 12):
+        kind = int(rng.integers(0, 4))
+        nq = int(rng.choice([1, 1, 1, 2, 3]))
+        Q = oc.synth(202, 3 * j, nq, d)
+        k = int(rng.choice([1, 7, 40, 100, 300]))
+        metric = int(rng.integers(0, 3))
+        jobs.append((kind, Q, k, metric, int(rng.integers(0, 3)), int(rng.integers(0, 7))))
+    with GpuFlatIndex(d, n) as idx, g.GpuColumns(n) as gc:
+        idx.upload(A)
+        c = gc.add_column()
+        gc.write(c, 0, np.full(n, g.CELL_INT, np.uint8), bucket.astype(np.uint64))
+        gc.write_valid(0, np.full(words, 0xFFFFFFFFFFFFFFFF, np.uint64))
+
+        def run(job):
+            kind, Q, k, metric, mi, b = job
+            if kind == 0:
+                return idx.search(Q, k, metric)
+            if kind == 1:
+                return idx.search(Q, k, metric, mask=host_mask)
+            if kind == 2:
+                return idx.search_dmask(Q, k, metric, dev_masks[mi].data_ptr())
+            return idx.search_pred(gc, [(g.PRED_CMP, g.CMP_EQ, g.CELL_INT, c, b, 0)], [], Q, k, metric)[:3]
+
+        out = [None] * len(jobs)
+        errs = []
+        stop = threading.Event()
+        start = threading.Barrier(33)
+
+        def work(t):
+            try:
+                start.wait()
+                for j in range(t, len(jobs), 32):
+                    out[j] = run(jobs[j])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        def writer():
+            start.wait()
+            r = 0
+            while not stop.is_set():
+                idx.set_row(r % n, A[r % n])
+                r += 97
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(32)] + [threading.Thread(target=writer)]
+        for x in th:
+            x.start()
+        for x in th[:-1]:
+            x.join()
+        stop.set()
+        th[-1].join()
+        assert not errs, errs
+        for j, job in enumerate(jobs):
+            want = run(job)
+            for a, b_ in zip(want, out[j]):
+                assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b_).view(np.uint8)), (j, job[0], job[2], job[3])
+            if j % 16 == 0:
+                kind, Q, k, metric, mi, b = job
+                m = None if kind == 0 else host_mask if kind == 1 else dev_host[mi] if kind == 2 else oc.mask_from_bool(bucket == b)
+                er, es = oc.search(A, Q[0], k, metric, mask=m)
+                assert np.array_equal(out[j][0][0, :er.size], er) and np.all(out[j][1][0, :er.size] == es), j
