@@ -54,6 +54,16 @@ nmn_status set_error_hip(hipError_t e, const char* what) { return fail_hip(e, wh
         if (_e != hipSuccess) return fail_hip(_e, #expr);    \
     } while (0)
 
+// measurement knobs, read once (README.md lists them)
+static bool env_set(const char* name) {
+    const char* e = getenv(name);
+    return e != nullptr;
+}
+static bool no_mfma() { static const bool v = env_set("NMN_NO_MFMA"); return v; }
+static bool no_half() { static const bool v = env_set("NMN_NO_HALF"); return v; }
+static bool no_sample() { static const bool v = env_set("NMN_NO_SAMPLE"); return v; }
+static bool no_crowd() { static const bool v = env_set("NMN_NO_CROWD"); return v; }
+
 // ---- host slots ------------------------------------------------------------------------------------
 static bool coalesce_enabled() {
     static const bool on = [] {
@@ -576,9 +586,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // sweep per 64 queries; Euclidean too), everything else through the VALU sweep (4 queries per sweep).  The mirror is
         // allocated and filled on first use and extended when rows were uploaded since.
         const bool mfma_shape = nqc >= mfma_min_queries(idx) && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
-                                getenv("NMN_NO_MFMA") == nullptr;
+                                !no_mfma();
         bool use_half = n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
-                        (mfma_shape || (getenv("NMN_NO_HALF") == nullptr && idx->half_calls >= idx->half_off_until));
+                        (mfma_shape || (!no_half() && idx->half_calls >= idx->half_off_until));
         if (!mfma_shape && idx->half_stats && (++idx->half_calls & 255u) == 0 && idx->half_calls >= idx->half_off_until) {
             uint32_t now[2] = {0, 0};  // a plain read of two counters other streams may still be adding to: good enough
             if (hipMemcpy(now, idx->half_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -688,7 +698,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // the k-th best score of each query from below, so the main sweep writes scores only for the few
             // tiles that can still hold a candidate.
             const uint32_t n_sample = (n_tiles + kSampleStep - 1) / kSampleStep;
-            const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && getenv("NMN_NO_SAMPLE") == nullptr;
+            const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
             if (sample) {
                 ScanParams ss = sp;
                 ss.tile_step = kSampleStep;
@@ -729,7 +739,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel.k_extra = w->k_extra;
             }
             HIP_TRY(launch_select(sel, stream));
-            const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && getenv("NMN_NO_CROWD") == nullptr;
+            const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && !no_crowd();
             if (crowd) {  // three launches that return at once unless a candidate list overflowed
                 CrowdParams cp{};
                 cp.qstate = w->qstate;
@@ -882,7 +892,7 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
 // on the matrix-core sweep, 4 on the VALU sweep (a longer batch there would only make every rider wait for the
 // later sweeps of the others).
 static uint32_t batch_queries(const nmn_index* idx, int metric) {
-    if (!scan_mfma_supported(idx->ld, idx->dim, metric) || getenv("NMN_NO_MFMA") != nullptr) return 4;
+    if (!scan_mfma_supported(idx->ld, idx->dim, metric) || no_mfma()) return 4;
     return idx->ld / 128u <= 6u ? 2u * nmn_index::kCoalesceQueries : nmn_index::kCoalesceQueries;
 }
 // requests that may share a batch: the candidate pipeline (k <= NMN_MAX_TOP_K), at most one sweep's worth of queries
@@ -1228,7 +1238,11 @@ static nmn_status host_submit(nmn_index* idx, HostReq& me) {
         idx->coalesced_requests += batch.size();
     }
     const int slot = me.slot;
-    st = host_batch_body(idx, lk, slot, batch.data(), batch.size());
+    try {
+        st = host_batch_body(idx, lk, slot, batch.data(), batch.size());
+    } catch (const std::exception& ex) {  // (host allocation failure: the riders must still be released)
+        st = fail_arg(NMN_ERR_OUT_OF_MEMORY, ex.what());
+    }
     const std::string err = st == NMN_OK ? std::string() : std::string(nmn_last_error());
     // wake the riders first (their results are in place), then pass the slot on
     for (HostReq* r : batch) {
