@@ -707,7 +707,7 @@ def test_native_threads_searching_while_writers_write():
     assert all("writers=2" in l for l in lines)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("NMN_FUZZ_SEEDS", "6"))))
 def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
     """Stores are only recorded next to a live mirror and uploaded in batches before the next search: any order of
     new keys, overwrites, deletes, re-inserts and searches (three metrics, random k) must answer like the oracle over
