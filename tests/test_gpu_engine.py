@@ -715,6 +715,7 @@ def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
     rng = np.random.default_rng(400 + seed)
     d = int(rng.choice([8, 48, 100, 128]))
     model = {}                                     # key -> vector
+    tags = {}                                      # key -> metadata value "b" (every store writes one)
     eng = E.VectorEngine()
     next_key = 0
 
@@ -726,8 +727,17 @@ def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
         q = rng.standard_normal(d).astype(np.float32)
         k = int(rng.choice([1, 3, 10, 50]))
         metric = (E.DistanceMetric.Cosine, E.DistanceMetric.Euclidean, E.DistanceMetric.DotProduct)[int(rng.integers(0, 3))]
-        res = eng.search_similar_with_metric(q, k, metric)
-        er, es = oc.search(A, q, k, int(metric))
+        if rng.random() < 0.4:                     # pre-filtered (always cosine, lib.rs:3514-3557)
+            b = int(rng.integers(0, 4))
+            keep = np.array([tags[k_] == b for k_ in keys], bool)
+            res = eng.search_similar_filtered(q, k, E.FilterCondition.Eq("b", b), E.FilteredSearchConfig.pre_filter())
+            if not keep.any():
+                assert res == []
+                return
+            er, es = oc.search(A, q, k, 0, mask=oc.mask_from_bool(keep))
+        else:
+            res = eng.search_similar_with_metric(q, k, metric)
+            er, es = oc.search(A, q, k, int(metric))
         got = {r.key: np.float32(r.score) for r in res}
         # ties: the reference's order among equal scores is unspecified (HashSet scan order); compare as score lists and
         # as sets above the last score
@@ -743,17 +753,20 @@ def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
             key = f"k{next_key}"
             next_key += 1
             v = rng.standard_normal(d).astype(np.float32)
-            eng.store_embedding(key, v)
+            tags[key] = int(rng.integers(0, 4))
+            eng.store_embedding_with_metadata(key, v, {"b": tags[key]})
             model[key] = v
         elif op < 0.65:                            # overwrite
             key = list(model)[int(rng.integers(0, len(model)))]
             v = rng.standard_normal(d).astype(np.float32)
-            eng.store_embedding(key, v)
+            tags[key] = int(rng.integers(0, 4))
+            eng.store_embedding_with_metadata(key, v, {"b": tags[key]})
             model[key] = v
         elif op < 0.8:                             # delete
             key = list(model)[int(rng.integers(0, len(model)))]
             eng.delete_embedding(key)
             del model[key]
+            del tags[key]
         else:
             check()
     check()
