@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t g = lane >> 4, n = lane & 15u;
     const uint32_t ld = p.ld;
     const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
-    // QG = 2 (rows of 2048 / 3072 elements: one group's B-fragments already take 128 / 192 VGPRs): the workgroup keeps 32
+    // QG = 2 (rows of 2048 / 3072 / 4096 elements: half a group's B-fragments already take 128 / 192 / 256 VGPRs): the workgroup keeps 32
     // queries, and a group is shared by TWO waves that split the k-steps of every stage between them (kh = 0 / 1); their
     // partial sums meet once per tile through LDS and the kh = 0 wave finishes the group.
     constexpr bool kHalfK = QG == 2;
@@ -430,12 +430,14 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
         case 12: return launch_kc<6, 2, 4, METRIC>(p, s);  // 1536
         case 16: return launch_kc<8, 2, 2, METRIC>(p, s);  // 2048: 32 stationary queries, K-halves on wave pairs
         case 24: return launch_kc<12, 2, 2, METRIC>(p, s); // 3072
+        case 32: return launch_kc<32, 1, 2, METRIC>(p, s); // 4096 (256 VGPRs of B-fragments: the compiler spills ~100 registers,
+                                                           // in the one-time fragment build only — 5.7 TB/s measured)
         default: return hipErrorInvalidValue;
     }
 }
 
 // Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768, or 1024 / 1280 /
-// 1536 with 64 stationary queries per workgroup (their bf16 B-fragments take up to 192 VGPRs at 1536), or 2048 / 3072 with 32.
+// 1536 with 64 stationary queries per workgroup (their bf16 B-fragments take up to 192 VGPRs at 1536), or 2048 / 3072 / 4096 with 32.
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
     if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN ||
           metric == kMetricNegL2) ||
@@ -443,7 +445,7 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
         ld % kStageK != 0)
         return false;
     const uint32_t kc = ld / kStageK;
-    return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12 || kc == 16 || kc == 24;
+    return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12 || kc == 16 || kc == 24 || kc == 32;
 }
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
