@@ -234,7 +234,7 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
             ok = ok and c["exact_topk_certified"]
     # stationary queries of one matrix-core sweep (launch_metric in nmn_scan_mfma.hip): 128 when the pass holds more
     # than 64 queries and the rows are <= 768 elements long, else 64
-    per_sweep = 128 if (args.dim // 128 <= 6 and nq > 64) else 32 if args.dim // 128 in (16, 24, 32) else 64
+    per_sweep = 128 if ((args.dim // 128 <= 6 or args.dim // 128 in (8, 10)) and nq > 64) else 32 if args.dim // 128 in (16, 24, 32) else 64
     sweeps = (nq + per_sweep - 1) // per_sweep
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
     gbps = idx.rows * args.dim * elem_bytes * sweeps / (sweep * 1e-3) / 1e9
@@ -359,7 +359,7 @@ def main():
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and args.dim % 128 == 0 and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
             and args.k <= 4096)
-    per_sweep = 128 if (kc <= 6 and args.nq > 64) else 32 if kc in (16, 24, 32) else 64  # stationary queries of one MFMA sweep (launch_metric)
+    per_sweep = 128 if ((kc <= 6 or kc in (8, 10)) and args.nq > 64) else 32 if kc in (16, 24, 32) else 64  # stationary queries of one MFMA sweep (launch_metric)
     passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch

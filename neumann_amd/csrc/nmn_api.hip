@@ -888,12 +888,13 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
 }
 
 // ---- host-buffer searches: coalescing of concurrent callers into query batches ------------------------
-// Queries one batch may carry: what ONE corpus sweep serves — 128 (rows of <= 768 elements) or 64 stationary queries
+// Queries one batch may carry: what ONE corpus sweep serves — 128 (rows of <= 768, 1024, 1280 elements) or 64 stationary queries
 // on the matrix-core sweep, 4 on the VALU sweep (a longer batch there would only make every rider wait for the
 // later sweeps of the others).
 static uint32_t batch_queries(const nmn_index* idx, int metric) {
     if (!scan_mfma_supported(idx->ld, idx->dim, metric) || no_mfma()) return 4;
-    return idx->ld / 128u <= 6u ? 2u * nmn_index::kCoalesceQueries : nmn_index::kCoalesceQueries;
+    const uint32_t kc = idx->ld / 128u;
+    return (kc <= 6u || kc == 8u || kc == 10u) ? 2u * nmn_index::kCoalesceQueries : nmn_index::kCoalesceQueries;
 }
 // requests that may share a batch: the candidate pipeline (k <= NMN_MAX_TOP_K), at most one sweep's worth of queries
 static bool mergeable(const nmn_index* idx, const HostReq& r) {

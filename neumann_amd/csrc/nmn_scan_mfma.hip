@@ -405,8 +405,10 @@ static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
 // row length / 128: rows that are a multiple of 256 elements stream in 32-KiB stages (KS = 2), the others in 16-KiB ones
 template <int METRIC>
 static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
-    // more than 64 queries in the pass and rows of <= 768 elements: 128 stationary queries per workgroup (the matrix
-    // cores are ~16 % busy at 64; B-fragments 192 VGPRs + accumulators 128)
+    // more than 64 queries in the pass and rows of <= 768, 1024 or 1280 elements: 128 stationary queries per workgroup
+    // (the matrix cores are ~16 % busy at 64).  B-fragments: 192 VGPRs at 768, 256 / 320 at 1024 / 1280 — there the compiler
+    // spills in the one-time fragment build, not in the loop (5M x 1024: two 64-query sweeps 3.43 ms, one of 128 2.18 ms).
+    // 1536 would need 384 for the fragments alone.
     if (p.nq > 64) {
         switch (p.ld / kStageK) {
             case 1: return launch_kc<1, 1, 8, METRIC>(p, s);
@@ -415,7 +417,9 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
             case 4: return launch_kc<2, 2, 8, METRIC>(p, s);
             case 5: return launch_kc<5, 1, 8, METRIC>(p, s);
             case 6: return launch_kc<3, 2, 8, METRIC>(p, s);
-            default: break;  // longer rows: the B-fragments of 128 queries (256+ VGPRs) plus a stage of A-fragments spill
+            case 8: return launch_kc<4, 2, 8, METRIC>(p, s);
+            case 10: return launch_kc<5, 2, 8, METRIC>(p, s);
+            default: break;
         }
     }
     switch (p.ld / kStageK) {

@@ -28,7 +28,7 @@ def check_batch(idx, A, Q, k, metric, mask=None):
                                       (100, 640, 8, 200),
                                       # more than 64 queries on rows of <= 768: 128 stationary queries per workgroup
                                       (20000, 768, 128, 50), (9000, 256, 100, 20), (5000, 640, 65, 10),
-                                      (15000, 128, 200, 10), (7000, 384, 129, 30),
+                                      (15000, 128, 200, 10), (7000, 384, 129, 30), (6000, 1024, 100, 20), (5000, 1280, 128, 10),
                                       # rows longer than 768 floats: the B-fragments of the 64 stationary queries fill 128-192 VGPRs
                                       (20000, 1024, 64, 50), (12000, 1536, 33, 100), (9000, 1280, 7, 10),
                                       (30000, 1536, 70, 20),
