@@ -355,9 +355,10 @@ def main():
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
     # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3
     # queries at dim >= 768, else >= 5; cosine/dot), else 4 (VALU) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
-    kc = args.dim // 128
+    ld128 = (args.dim + 127) // 128 * 128  # nmn_index_create pads rows just short of a multiple of 128 up to it
+    kc = ld128 // 128 if (ld128 - args.dim) * 8 <= args.dim else 0
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
-    mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and args.dim % 128 == 0 and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
+    mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and kc and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
             and args.k <= 4096)
     per_sweep = 128 if ((kc <= 6 or kc in (8, 10)) and args.nq > 64) else 32 if kc in (16, 24, 32) else 64  # stationary queries of one MFMA sweep (launch_metric)
     passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)

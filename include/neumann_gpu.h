@@ -101,7 +101,7 @@ const char* nmn_last_error(void);
 /* Library version "major.minor.patch". */
 const char* nmn_version(void);
 
-/* Allocate one shard: corpus[capacity_rows][ld] f32 row-major (ld = dim rounded up to 8, zero
+/* Allocate one shard: corpus[capacity_rows][ld] f32 row-major (ld = dim rounded up to 8, or to the next multiple of 128 if that is at most 1/8 more; zero
  * padded), norms[capacity_rows] f32.  Replaces the per-row `TensorStore` reads of the hot loop
  * (vector_engine/src/lib.rs:2121-2138; tensor_store/src/lib.rs:948-963) by one resident matrix. */
 nmn_status nmn_index_create(const nmn_index_desc* desc, nmn_index** out);

@@ -319,7 +319,14 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
     if (!d || !out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->dim == 0) return fail_arg(NMN_ERR_EMPTY_VECTOR, "dim == 0");
-    const uint32_t ld = (d->dim + 7u) & ~7u;  // whole 16-byte chunks of the bf16 mirror too: every row length gets it
+    uint32_t ld = (d->dim + 7u) & ~7u;  // whole 16-byte chunks of the bf16 mirror too: every row length gets it
+    {
+        // a row length just short of a multiple of 128 (1000, 960, 1500, 3000, ...) is padded up to it when that costs at
+        // most 1/8 more bytes per sweep: query batches then take the matrix-core sweep (64-128 queries per sweep instead
+        // of 4); the padding is zero in the corpus, the mirror and the queries, and the exact kernels never read it
+        const uint32_t ld128 = (d->dim + 127u) & ~127u;
+        if (ld128 != ld && (uint64_t)(ld128 - d->dim) * 8u <= d->dim && scan_mfma_supported(ld128, ld128, NMN_METRIC_COSINE)) ld = ld128;
+    }
     if ((uint64_t)ld * 4ull > 160ull * 1024ull)
         return fail_arg(NMN_ERR_INVALID_ARGUMENT, "dim too large: one query must fit the 160 KiB LDS");
     if (d->capacity_rows >= 0xFFFFFFC0ull)

@@ -445,8 +445,7 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
     if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN ||
           metric == kMetricNegL2) ||
-        ld != dim ||
-        ld % kStageK != 0)
+        dim > ld || ld % kStageK != 0)  // (ld > dim: zero padding up to the next multiple of 128, nmn_index_create)
         return false;
     const uint32_t kc = ld / kStageK;
     return (kc >= 1 && kc <= 6) || kc == 8 || kc == 10 || kc == 12 || kc == 16 || kc == 24 || kc == 32;

@@ -33,7 +33,9 @@ def check_batch(idx, A, Q, k, metric, mask=None):
                                       (20000, 1024, 64, 50), (12000, 1536, 33, 100), (9000, 1280, 7, 10),
                                       (30000, 1536, 70, 20),
                                       # 2048 / 3072 / 4096: 32 stationary queries, the k-steps of a stage split over wave pairs
-                                      (6000, 2048, 40, 10), (5000, 3072, 33, 20), (3000, 3072, 70, 5), (2500, 4096, 40, 10)])
+                                      (6000, 2048, 40, 10), (5000, 3072, 33, 20), (3000, 3072, 70, 5), (2500, 4096, 40, 10),
+                                      # just short of a multiple of 128: the stride is padded up to it (zeros), same sweep
+                                      (6000, 1000, 40, 10), (4000, 960, 64, 20), (2500, 3000, 33, 5), (5000, 720, 100, 10)])
 def test_mfma_batch_matches_oracle(metric, n, d, nq, k):
     from neumann_amd import GpuFlatIndex
     A = oc.synth(1000 + n + d, 0, n, d)

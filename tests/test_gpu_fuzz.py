@@ -11,7 +11,7 @@ U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def _case(rng):
-    d = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 31, 64, 100, 127, 128, 129, 200, 256, 300, 384, 768]))
+    d = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 31, 64, 100, 120, 127, 128, 129, 200, 250, 256, 300, 384, 720, 768]))
     n = int(rng.choice([1, 2, 63, 64, 65, 127, 500, 1000, 2500, 4097, 4097, 20000]))
     nq = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8, 17, 64, 65, 140]))
     k = int(rng.choice([1, 2, 5, 10, 64, 100, 333]))
