@@ -99,6 +99,7 @@ struct ScanParams {
     uint32_t nql;            // queries interleaved per tile in `scores` (= queries of this pass)
     // MFMA sweep only: sampling and score-write suppression (nmn_scan_mfma.hip)
     uint32_t tile_step;      // 1: every tile; S: sample pass over tiles 0,S,2S,.. (tile maxima only -> tmax[q][i])
+    uint32_t fold_ny;        // > 1: 1-D grid folded over this many query blocks (set by the launcher)
     const uint32_t* skip_key;  // nullable [nq]: scores of a tile are written only if its maximum key >= skip_key[q]
     uint32_t ld;             // floats per row, multiple of 8
     uint32_t n_tiles;

@@ -142,7 +142,17 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
     const uint32_t ld = p.ld;
-    const uint32_t q0 = blockIdx.y * (uint32_t)(QG * 16);
+    // Workgroup -> (tile range bx, query block by).  With several query blocks the grid is 1-D and folded so that the
+    // workgroups that stream the SAME tiles for different query blocks get ids 8 apart: same XCD (ids go round the 8 XCDs),
+    // dispatched together — the second reader of a tile then finds it in that XCD's L2 / the infinity cache instead of
+    // going to HBM again (gridDim.y == 1 marks the folded form; p.tile_step is unaffected).
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (p.fold_ny > 1) {
+        const uint32_t span = 8u * p.fold_ny, grp_ = blockIdx.x / span, r_ = blockIdx.x % span;
+        by = r_ / 8u;
+        bx = grp_ * 8u + (r_ % 8u);
+    }
+    const uint32_t q0 = by * (uint32_t)(QG * 16);
     // QG = 2 (rows of 2048 / 3072 / 4096 elements: half a group's B-fragments already take 128 / 192 / 256 VGPRs): the workgroup keeps 32
     // queries, and a group is shared by TWO waves that split the k-steps of every stage between them (kh = 0 / 1); their
     // partial sums meet once per tile through LDS and the kh = 0 wave finishes the group.
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 
     const uint32_t tstep = p.tile_step;                  // 1, or S on the sampling pass (tile index i -> tile i*S)
     const bool sampling = tstep > 1;
-    const uint32_t t0 = blockIdx.x * p.tiles_per_wave;  // tiles per WORKGROUP on this path
+    const uint32_t t0 = bx * p.tiles_per_wave;  // tiles per WORKGROUP on this path
     if (t0 >= p.n_tiles) return;
     const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
     const uint32_t n_stage = (t1 - t0) * KC;
@@ -379,20 +389,27 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     if (sampling) return;  // the sampling pass leaves only tmax
 #pragma unroll
     for (int h = 0; h < kHalves; h++)
-        if (q_ok_h[h] && g == 0) p.wmax[(size_t)qn_h[h] * p.wmax_stride + blockIdx.x] = wmax_h[h];
+        if (q_ok_h[h] && g == 0) p.wmax[(size_t)qn_h[h] * p.wmax_stride + bx] = wmax_h[h];
 }
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
-    dim3 grid(blocks, (p.nq + QG * 16 - 1) / (QG * 16));
+    const uint32_t ny = (p.nq + QG * 16 - 1) / (QG * 16);
+    ScanParams pf = p;
+    dim3 grid(blocks, ny);
+    static const bool no_fold = getenv("NMN_MFMA_NO_FOLD") != nullptr;
+    if (ny > 1 && !no_fold) {  // folded 1-D grid (see the kernel): tile ranges padded to a multiple of 8
+        pf.fold_ny = ny;
+        grid = dim3(((blocks + 7u) / 8u) * 8u * ny, 1);
+    }
     const size_t lds = kRingBytes + kMaxRing * 64 * 4 + (QG == 2 ? 2 * 64 * 4 * 16 : 0);  // + the K-halves' exchange
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
     auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pf);
     return hipGetLastError();
 }
 
