@@ -237,13 +237,16 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
     per_sweep = 128 if ((args.dim // 128 <= 6 or args.dim // 128 in (8, 10)) and nq > 64) else 32 if args.dim // 128 in (16, 24, 32) else 64
     sweeps = (nq + per_sweep - 1) // per_sweep
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
-    gbps = idx.rows * args.dim * elem_bytes * sweeps / (sweep * 1e-3) / 1e9
+    # ONE launch carries every query block; the workgroups that stream the same tiles for different blocks sit on the
+    # same XCD (ids 8 apart) and share its L2, so the algorithmic HBM bytes are one corpus read per launch.  The bytes
+    # the workgroups REQUEST (query blocks x corpus) are reported beside it.
+    gbps = idx.rows * args.dim * elem_bytes / (sweep * 1e-3) / 1e9
     return {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
             "value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "sweep_ms_incl_sampling_pass": sweep, "corpus_sweeps_per_step": sweeps,
+            "sweep_ms_incl_sampling_pass": sweep, "query_blocks_per_launch": sweeps,
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBS, "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)",
-                         "bytes_per_corpus_element": elem_bytes},
+                         "bytes_per_corpus_element": elem_bytes, "requested_GBs_all_query_blocks": gbps * sweeps},
             "exact_topk_certified_3_of_batch": bool(ok) if not args.no_parity else None}
 
 
@@ -360,8 +363,9 @@ def main():
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and kc and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
             and args.k <= 4096)
-    per_sweep = 128 if ((kc <= 6 or kc in (8, 10)) and args.nq > 64) else 32 if kc in (16, 24, 32) else 64  # stationary queries of one MFMA sweep (launch_metric)
-    passes = (args.nq + per_sweep - 1) // per_sweep if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
+    # the matrix-core sweep is ONE launch whatever the number of query blocks (they share the tiles through the XCD's L2);
+    # VALU sweeps are one launch per 4 queries
+    passes = 1 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
     alg_bytes = (kept_rows * args.dim * elem_bytes + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
