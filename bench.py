@@ -358,8 +358,10 @@ def main():
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
     # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3
     # queries at dim >= 768, else >= 5; cosine/dot), else 4 (VALU) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
-    ld128 = (args.dim + 127) // 128 * 128  # nmn_index_create pads rows just short of a multiple of 128 up to it
-    kc = ld128 // 128 if (ld128 - args.dim) * 8 <= args.dim else 0
+    ld128 = (args.dim + 127) // 128 * 128  # nmn_index_create pads rows just short of a supported multiple of 128 up to it
+    while ld128 <= 4096 and not (ld128 // 128 <= 6 or ld128 // 128 in (8, 10, 12, 16, 24, 32)):
+        ld128 += 128
+    kc = ld128 // 128 if (ld128 <= 4096 and (ld128 - args.dim) * 8 <= args.dim) else 0
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and kc and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
             and args.k <= 4096)

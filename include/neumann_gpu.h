@@ -67,6 +67,12 @@ typedef enum nmn_metric {
 
 typedef struct nmn_index nmn_index; /* opaque: one row-range shard resident on one GPU */
 
+/* nmn_index_desc.flags.  By default a row length is padded up to the next multiple of 128 elements only when that costs at
+ * most 1/8 more bytes per sweep (1000 -> 1024); with NMN_INDEX_WIDE_ROWS also when it costs up to 1/2 more (300 -> 384,
+ * 200 -> 256, 100 -> 128): batches of queries and concurrent callers then take the matrix-core sweep (up to 128 queries per
+ * corpus read instead of 4) at the price of that much more HBM and single-query sweep time.  Results are the same. */
+#define NMN_INDEX_WIDE_ROWS 1u
+
 typedef struct nmn_index_desc {
     uint32_t dim;            /* vector dimension d (>0) */
     uint32_t flags;          /* NMN_INDEX_* bits, 0 = defaults */
@@ -120,6 +126,8 @@ nmn_status nmn_index_set_rows(nmn_index* idx, uint64_t rows);
 
 uint64_t nmn_index_rows(const nmn_index* idx);
 uint32_t nmn_index_dim(const nmn_index* idx);
+/* Elements per stored row including the zero padding (>= dim; a multiple of 128 when batches take the matrix-core sweep). */
+uint32_t nmn_index_row_stride(const nmn_index* idx);
 uint64_t nmn_index_row_base(const nmn_index* idx);
 /* Device pointers of the resident data (for zero-copy producers and for tests). */
 const float* nmn_index_corpus_device(const nmn_index* idx, uint32_t* ld_out);

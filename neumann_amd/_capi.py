@@ -79,6 +79,7 @@ SIGNATURES = {
     "nmn_index_set_rows": (C.c_int32, [vp, C.c_uint64]),
     "nmn_index_rows": (C.c_uint64, [vp]),
     "nmn_index_dim": (C.c_uint32, [vp]),
+    "nmn_index_row_stride": (C.c_uint32, [vp]),
     "nmn_index_row_base": (C.c_uint64, [vp]),
     "nmn_index_corpus_device": (vp, [vp, u32p]),
     "nmn_index_norms_device": (vp, [vp]),

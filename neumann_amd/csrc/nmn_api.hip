@@ -319,13 +319,17 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
     if (!d || !out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->dim == 0) return fail_arg(NMN_ERR_EMPTY_VECTOR, "dim == 0");
+    if (d->flags & ~NMN_INDEX_WIDE_ROWS) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "unknown nmn_index_desc.flags bit");
     uint32_t ld = (d->dim + 7u) & ~7u;  // whole 16-byte chunks of the bf16 mirror too: every row length gets it
     {
         // a row length just short of a multiple of 128 (1000, 960, 1500, 3000, ...) is padded up to it when that costs at
         // most 1/8 more bytes per sweep: query batches then take the matrix-core sweep (64-128 queries per sweep instead
         // of 4); the padding is zero in the corpus, the mirror and the queries, and the exact kernels never read it
-        const uint32_t ld128 = (d->dim + 127u) & ~127u;
-        if (ld128 != ld && (uint64_t)(ld128 - d->dim) * 8u <= d->dim && scan_mfma_supported(ld128, ld128, NMN_METRIC_COSINE)) ld = ld128;
+        // (the next multiple the sweep is built for: 896 -> 1024, 1152 -> 1280, 1408 -> 1536, 2560 -> 3072, ...)
+        uint32_t ld128 = (d->dim + 127u) & ~127u;
+        while (ld128 <= 4096u && !scan_mfma_supported(ld128, ld128, NMN_METRIC_COSINE)) ld128 += 128u;
+        const uint64_t pad_div = (d->flags & NMN_INDEX_WIDE_ROWS) ? 2u : 8u;  // the caller trades bytes for batches
+        if (ld128 <= 4096u && ld128 != ld && (uint64_t)(ld128 - d->dim) * pad_div <= d->dim) ld = ld128;
     }
     if ((uint64_t)ld * 4ull > 160ull * 1024ull)
         return fail_arg(NMN_ERR_INVALID_ARGUMENT, "dim too large: one query must fit the 160 KiB LDS");
@@ -398,6 +402,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
 
 extern "C" uint64_t nmn_index_rows(const nmn_index* idx) { return idx ? idx->rows : 0; }
 extern "C" uint32_t nmn_index_dim(const nmn_index* idx) { return idx ? idx->dim : 0; }
+extern "C" uint32_t nmn_index_row_stride(const nmn_index* idx) { return idx ? idx->ld : 0; }
 extern "C" uint64_t nmn_index_row_base(const nmn_index* idx) { return idx ? idx->row_base : 0; }
 extern "C" const float* nmn_index_corpus_device(const nmn_index* idx, uint32_t* ld_out) {
     if (!idx) return nullptr;

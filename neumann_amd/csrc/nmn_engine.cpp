@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -626,6 +627,11 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
     if (n > 0) {
         nmn_index_desc d{};
         d.dim = (uint32_t)dim;
+        // an engine serves concurrent search_similar callers, which share sweeps: rows of 300 / 200 / 100 floats are
+        // stored with a stride of 384 / 256 / 128 so those batches take the matrix-core sweep (10M x 300, 64 queries:
+        // 2.3 k -> 39.4 k q/s; one query alone 800 -> 718 q/s).  NMN_ENGINE_TIGHT_ROWS=1 keeps the stride at dim.
+        static const bool tight_rows = getenv("NMN_ENGINE_TIGHT_ROWS") != nullptr;
+        d.flags = tight_rows ? 0u : NMN_INDEX_WIDE_ROWS;
         m->cap = n + std::max<uint64_t>(n / 2, 1024);  // spare rows for appended keys
         d.capacity_rows = m->cap;
         d.row_base = 0;

@@ -35,7 +35,9 @@ def check_batch(idx, A, Q, k, metric, mask=None):
                                       # 2048 / 3072 / 4096: 32 stationary queries, the k-steps of a stage split over wave pairs
                                       (6000, 2048, 40, 10), (5000, 3072, 33, 20), (3000, 3072, 70, 5), (2500, 4096, 40, 10),
                                       # just short of a multiple of 128: the stride is padded up to it (zeros), same sweep
-                                      (6000, 1000, 40, 10), (4000, 960, 64, 20), (2500, 3000, 33, 5), (5000, 720, 100, 10)])
+                                      (6000, 1000, 40, 10), (4000, 960, 64, 20), (2500, 3000, 33, 5), (5000, 720, 100, 10),
+                                      # ... or of the next row length the sweep is built for (1152 -> 1280, 1408 -> 1536)
+                                      (4000, 1152, 40, 10), (3000, 1408, 70, 5)])
 def test_mfma_batch_matches_oracle(metric, n, d, nq, k):
     from neumann_amd import GpuFlatIndex
     A = oc.synth(1000 + n + d, 0, n, d)
@@ -47,6 +49,27 @@ def test_mfma_batch_matches_oracle(metric, n, d, nq, k):
         assert st.fallback_queries == 0
         rng = np.random.default_rng(n)
         check_batch(idx, A, Q, k, metric, mask=oc.mask_from_bool(rng.random(n) < 0.3))
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(9000, 300, 64, 20), (7000, 200, 33, 10), (12000, 100, 128, 10), (5000, 96, 40, 5),
+                                      (3000, 896, 40, 10), (2000, 2560, 33, 5)])
+def test_wide_rows_flag_pads_to_the_matrix_core_stride(n, d, nq, k):
+    # NMN_INDEX_WIDE_ROWS: 300 -> 384, 200 -> 256, 100 -> 128, 96 -> 128, 896 -> 1024, 2560 -> 3072; same answers,
+    # batches on the matrix cores
+    from neumann_amd import GpuFlatIndex
+    A = oc.synth(3000 + n + d, 0, n, d)
+    Q = oc.synth(4000 + nq, 0, nq, d)
+    Q[1] = A[n // 2]
+    with GpuFlatIndex(d, n) as plain, GpuFlatIndex(d, n, wide_rows=True) as wide:
+        built_for = [128 * c for c in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32)]
+        assert plain.row_stride == (d + 7) // 8 * 8 and wide.row_stride == min(x for x in built_for if x >= d)
+        wide.upload(A[: n // 2])
+        wide.upload(A[n // 2:], row0=n // 2)     # appended rows keep the padding zero
+        for metric in (0, 1, 2):
+            check_batch(wide, A, Q, k, metric)
+            check_batch(wide, A, Q[:1], k, metric)
+        rng = np.random.default_rng(d)
+        check_batch(wide, A, Q, k, 0, mask=oc.mask_from_bool(rng.random(n) < 0.4))
 
 
 def test_mfma_batch_with_planted_near_ties_and_duplicates():
