@@ -43,6 +43,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef short s8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
+#ifndef NMN_MFMA_BATCH
+#define NMN_MFMA_BATCH 8  // A-fragment reads issued together, one batch ahead of the MFMAs that consume them
+#endif
 constexpr int kStageK = 128;     // granularity of the row length this kernel accepts (elements)
 // A stage is [64 rows][128*KS bf16] (KS = 1 or 2 k-steps per wave and stage): 16 KiB or 32 KiB.  Rows whose length is a
 // multiple of 256 use KS = 2: half as many stage hand-overs (a counted wait and a workgroup barrier each) per byte.
@@ -274,6 +277,28 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                     for (int qg = 0; qg < kBG; qg++)
                         acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
             }
+#ifndef NMN_MFMA_NO_SCHED
+            // Left alone the scheduler emits read, wait lgkmcnt(0), MFMAs, read, ... (the 256 architectural VGPRs are
+            // full, and with LDS-DMA in flight every LDS wait the compiler inserts is a full drain): each LDS round
+            // trip is exposed and the matrix cores idle two cycles out of three.  Order the stage in batches of
+            // kBatch fragment reads: the reads of batch b+1 are issued in one go BEFORE the MFMAs of batch b, so the
+            // drain in front of batch b+1's MFMAs finds reads that are a whole batch of MFMAs old.
+            // (dot product, 128 queries of 1024-element rows: the ordered version spills DMA addresses inside the loop —
+            // a reload there is a vmcnt(0), which drains the whole DMA ring; left to the scheduler it does not)
+            if constexpr (!(METRIC == NMN_METRIC_DOT_PRODUCT && kBK * kBG * 4 == 256)) {
+                // (stationary fragments of 256+ VGPRs leave room for a quarter batch only: more spills in the loop)
+                constexpr int kWant = (kBK * kBG * 4 >= 256) ? NMN_MFMA_BATCH / 4 : NMN_MFMA_BATCH;
+                constexpr int kReads = kSteps * 4, kBatch = kReads < kWant ? kReads : kWant;
+                static_assert(kReads % kBatch == 0, "batches tile the stage");
+                __builtin_amdgcn_sched_group_barrier(0x100, kBatch, 0);
+#pragma unroll
+                for (int b = 1; b < kReads / kBatch; b++) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, kBatch, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, kBatch * kBG, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, kBatch * kBG, 0);
+            }
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if constexpr (kHalfK) {
