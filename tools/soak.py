@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--corpora", default="iid,clustered,duplicated")
     ap.add_argument("--metrics", default="cosine,euclidean,dot")
+    ap.add_argument("--wide-rows", action="store_true", help="NMN_INDEX_WIDE_ROWS: 300 -> 384 etc., batches on the matrix cores")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +126,7 @@ def main():
 
     # --- iid corpus (the bench's) --------------------------------------------------------------
     if "iid" in corpora:
-        with GpuFlatIndex(d, n, row_base=0, device=0) as idx:
+        with GpuFlatIndex(d, n, row_base=0, device=0, wide_rows=args.wide_rows) as idx:
             idx.fill_synthetic(20240601, n)
             q = synth_rows(777, 0, nq, d)
             # half the queries ARE corpus rows (self-match at the top), the rest fresh
@@ -142,7 +143,7 @@ def main():
             scale = noise[torch.randint(0, 3, (m,), device=dev, generator=g)]
             return centres[which] + scale[:, None] * torch.randn(m, d, device=dev, generator=g)
 
-        with GpuFlatIndex(d, n, row_base=0, device=0) as idx:
+        with GpuFlatIndex(d, n, row_base=0, device=0, wide_rows=args.wide_rows) as idx:
             fill_chunks(idx, clustered)
             q = (centres[torch.arange(nq, device=dev) % args.clusters]
                  + 1e-3 * torch.randn(nq, d, device=dev, generator=g)).cpu().numpy().astype(np.float32)
@@ -152,7 +153,7 @@ def main():
     if "duplicated" in corpora:
         base_rows = 100_003
         base = torch.randn(base_rows, d, device=dev, generator=g)
-        with GpuFlatIndex(d, n, row_base=0, device=0) as idx:
+        with GpuFlatIndex(d, n, row_base=0, device=0, wide_rows=args.wide_rows) as idx:
             fill_chunks(idx, lambda r0, m: base[(torch.arange(r0, r0 + m, device=dev) * 7919) % base_rows])
             q = base[:nq].cpu().numpy().astype(np.float32)
             q[nq // 2:] += 0.05 * rng.standard_normal((nq - nq // 2, d)).astype(np.float32)
