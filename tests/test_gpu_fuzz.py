@@ -46,7 +46,8 @@ def test_random_shapes_match_the_oracle(seed):
     for _ in range(14):
         A, Q, k, metric, mask = _case(rng)
         n, d = A.shape
-        with GpuFlatIndex(d, n + int(rng.integers(0, 70))) as idx:
+        # every other index stores its rows with NMN_INDEX_WIDE_ROWS (stride padded to the matrix-core sweep's)
+        with GpuFlatIndex(d, n + int(rng.integers(0, 70)), wide_rows=bool(rng.integers(0, 2))) as idx:
             idx.upload(A)
             rows, scores, counts = idx.search(Q, k, metric, mask=mask)
             for qi in range(Q.shape[0]):
