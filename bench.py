@@ -398,6 +398,11 @@ def main():
                    "value": r["calls_per_s"], "unit": "queries/s", "threads": args.callers,
                    "sweeps_carrying_2_or_more_calls": r["merged_batches"], "calls_in_them": r["merged_calls"],
                    "answers_differing_from_a_lone_call": r["mismatches"]}
+        # twice the threads: one sweep carries up to 128 callers
+        cq2 = _synth(SEED_QUERY + 3, 0, 2 * args.callers, args.dim)
+        r2 = idx.callers_probe(cq2, args.k, metric, seconds=1.0)
+        callers["with_twice_the_threads"] = {"threads": 2 * args.callers, "value": r2["calls_per_s"], "unit": "queries/s",
+                                             "answers_differing_from_a_lone_call": r2["mismatches"]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
