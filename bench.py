@@ -13,10 +13,14 @@ and merged on-device (strong scaling: total work per query is fixed).  `--scalin
 keeps 10M rows PER GPU (config 4: 80M rows on 8 GPUs).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (scan) algorithmic bytes / measured kernel time vs HBM peak.  The approximate sweep reads
-                the shard's bf16 mirror (2 bytes per corpus element; the exact f32 rescore keeps the answer bit-equal), so
-                the algorithmic bytes per query are rows*dim*2 — reported by the library (bytes_scanned) and echoed as
-                bytes_per_corpus_element; NMN_NO_HALF=1 measures the sweep of the f32 corpus instead
+  roofline      dominant kernel of the headline configuration (scan_kernel over the shard's bf16 mirror: 2 bytes per corpus
+                element; the exact f32 rescore keeps the answer bit-equal).  `achieved` / `frac` count the bytes that kernel is
+                asked to read (rows*dim*2, `pricing` says so, `bytes_per_corpus_element` = 2); SURVEY.md §8(d) prices a query
+                at rows*dim*4 (the f32 corpus): `achieved_priced_as_survey_8d` / `frac_priced_as_survey_8d` give the same
+                kernel time under that pricing (an EFFECTIVE rate; it exceeds the HBM peak because half the bytes are moved)
+  roofline_f32_corpus  (default single-GPU run) the same index, same queries, same 2-stream loop with
+                nmn_index_set_mirror(0): the sweep of the row-major f32 corpus §8(d) describes, priced at rows*dim*4 —
+                queries/s, HIP-event kernel average, achieved GB/s, frac of 8 TB/s, exactness certificate
   cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded
                 row sample of the same workload, extrapolated linearly to the full row count
   parity        the GPU result of the last timed query checked against the oracle / exact certificate
@@ -29,6 +33,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -67,6 +72,11 @@ def parse():
                     help="skip the extra legs of the default single-GPU run: BASELINE.json's other single-GPU "
                          "configurations (config 2: 1M x 768 cosine TOP-100; config 5: 10M x 1536 L2 TOP-1000 with mask "
                          "1.0 / 0.5 / 0.1) measured as child runs of this script and reported under \"other_configs\"")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child runs (then it comes from profiles/pmc_traffic.json)")
+    ap.add_argument("--no-f32-leg", action="store_true",
+                    help="skip the roofline_f32_corpus leg (the same loop with the bf16 mirror switched off)")
     ap.add_argument("--always-gather", action="store_true",
                     help="run the RCCL all-gather + device merge even with one rank (measures what the N>1 step adds "
                          "on a 1-GPU box; the group has one member)")
@@ -121,7 +131,7 @@ def other_configs():
     """BASELINE.json configs 2 and 5 as child runs (each needs its own resident corpus: 3 GB and 61 GB)."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--batched", "0", "--callers", "0",
-            "--warmup", "3"]
+            "--no-f32-leg", "--no-live-pmc", "--warmup", "3"]
     runs = [("config2_1Mx768_cosine_top100", ["--rows", "1000000", "--steps", "200"]),
             ("config5_10Mx1536_l2_top1000_mask1.0", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12"]),
             ("config5_10Mx1536_l2_top1000_mask0.5", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12",
@@ -155,6 +165,79 @@ def pmc_traffic(rows_per_gpu, args, elem_bytes=4):
                 rows_per_gpu, args.dim, args.metric, args.nq, args.mask, elem_bytes):
             return e["hbm_bytes_per_launch"], e["source"]
     return None, None
+
+
+def live_pmc(args):
+    """HBM bytes per launch of the two nq=1 sweeps, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes, no other trace
+    domain — MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"), each a handful of sweeps of the same synthetic shard over
+    the bf16 mirror and over the f32 corpus.  Corrections as that guide prescribes: both counters are KiB; on gfx950
+    FETCH_SIZE reports half the bytes of a 16-B-per-lane streaming read, so read bytes = FETCH_SIZE * 1024 * 2.
+    Returns {"mirror": {...}, "f32": {...}} or None when rocprofv3 is not usable here."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--rows", str(args.rows), "--dim", str(args.dim),
+             "--k", str(args.k), "--metric", args.metric]
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="nmn_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--"] + child,
+                               capture_output=True, text=True, timeout=240, cwd="/tmp", env=env)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            rows = list(db.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)))
+            for half, tag in ((True, "mirror"), (False, "f32")):
+                # scan_kernel<METRIC, MASKED, NQ, CHUNKS, .., .., HALF>: the sweeps proper are the launches within 2x of the
+                # largest (the f32 retry launches of a mirror pass share the f32 template and return at once)
+                want = "true" if half else "false"
+                v = [val for name, val in rows
+                     if (m := re.search(r"scan_kernel<[^>]*?(true|false)>", name)) and m.group(1) == want]
+                if not v:
+                    return None
+                big = [x for x in v if x * 2 >= max(v)]
+                per.setdefault(tag, {})[counter] = (float(np.mean(big)), len(big))
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for tag, d in per.items():
+        rd = d["FETCH_SIZE"][0] * 1024 * 2
+        wr = d["WRITE_SIZE"][0] * 1024
+        res[tag] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr,
+                    "launches_counted": d["FETCH_SIZE"][1],
+                    "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace and --pmc WRITE_SIZE "
+                              "--kernel-trace (separate passes) around child runs of bench.py --pmc-child; "
+                              "FETCH_SIZE*1024*2 (gfx950 correction, MI355X_MICROARCH.md), WRITE_SIZE*1024"}
+    return res
+
+
+def pmc_child(args):
+    """What live_pmc() profiles: a few nq=1 sweeps over the bf16 mirror, then over the f32 corpus; no output."""
+    import torch
+    from neumann_amd import GpuFlatIndex
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    idx = GpuFlatIndex(args.dim, args.rows, device=0)
+    idx.fill_synthetic(SEED_CORPUS, args.rows)
+    q = torch.from_numpy(_synth(SEED_QUERY, 0, 4, args.dim)).to(dev)
+    for mirror in (True, False):
+        idx.set_mirror(mirror)
+        for i in range(8):
+            idx.search_device(q[i % 4:i % 4 + 1], args.k, METRICS[args.metric])
+        torch.cuda.synchronize()
+    idx.close()
 
 
 def certificate(idx, q_host, metric, rows, scores, counts, world, dev, mask_host=None):
@@ -252,6 +335,8 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     import torch
     import torch.distributed as dist
 
@@ -324,37 +409,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run():
+        """W untimed steps, K timed steps between fences (max over ranks), then the dominant kernel's HIP-event average
+        over up to 30 more steps.  Returns (elapsed_s, last result, scan_ms list, total_ms list, bytes per element)."""
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        last = tuple(t.cpu().numpy().copy() for t in out)  # result of the last timed step
+        # dominant-kernel timing: HIP events on the launch stream, recorded inside the library
+        idx.set_timing(True)
+        scan_ms, total_ms = [], []
+        eb = 4  # bytes per corpus element the dominant kernel reads: 4 (f32 corpus) or 2 (its bf16 mirror)
+        for i in range(min(max(args.steps, 5), 30)):
+            step(i)
+            st = idx.last_stats(streams[i % n_streams])
+            if st.scan_ms > 0:
+                scan_ms.append(st.scan_ms)
+                total_ms.append(st.total_ms)
+            if st.rows_scanned:
+                eb = int(st.bytes_scanned // (st.rows_scanned * args.dim))
+        idx.set_timing(False)
+        fence()
+        return elapsed, last, scan_ms, total_ms, eb
+
+    elapsed, last_out, scan_ms, total_ms, elem_bytes = timed_run()
     ms_per_step = elapsed / args.steps * 1e3
     value = args.nq * args.steps / elapsed
-    last_out = tuple(t.cpu().numpy().copy() for t in out)  # result of the last timed step
-
-    # ---- dominant-kernel timing (HIP events on the launch stream, recorded inside the library) ----
-    idx.set_timing(True)
-    scan_ms, total_ms = [], []
-    n_meas = min(max(args.steps, 5), 30)
-    elem_bytes = 4  # bytes per corpus element the dominant kernel reads: 4 (f32 corpus) or 2 (its bf16 mirror)
-    for i in range(n_meas):
-        step(i)
-        st = idx.last_stats(streams[i % n_streams])
-        if st.scan_ms > 0:
-            scan_ms.append(st.scan_ms)
-            total_ms.append(st.total_ms)
-        if st.rows_scanned:
-            elem_bytes = int(st.bytes_scanned // (st.rows_scanned * args.dim))
-    idx.set_timing(False)
-    fence()
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
     # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3
     # queries at dim >= 768, else >= 5; cosine/dot), else 4 (VALU) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
@@ -382,6 +471,31 @@ def main():
         o_rows, o_scores, o_counts = last_out
         parity = certificate(idx, q_host[(args.steps - 1) % n_query_sets][0], metric,
                              o_rows.view(np.uint64), o_scores, o_counts, world, dev, mask_host)
+
+    # ---- the sweep SURVEY §8(d) prices: the row-major f32 corpus itself, same index / queries / loop ----
+    f32_leg = None
+    if world == 1 and elem_bytes == 2 and not args.no_f32_leg and args.k <= 4096 and args.nq == 1:
+        idx.set_mirror(False)
+        e2, out2, scan2, total2, eb2 = timed_run()
+        idx.set_mirror(True)
+        k_ms = float(np.mean(scan2)) if scan2 else float("nan")
+        bytes4 = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes
+        ach = bytes4 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
+        cert2 = None
+        if not args.no_parity:
+            cert2 = certificate(idx, q_host[(args.steps - 1) % n_query_sets][0], metric, out2[0].view(np.uint64), out2[1],
+                                out2[2], world, dev, mask_host)
+        same = bool(np.array_equal(out2[0], last_out[0]) and np.array_equal(out2[1].view(np.uint32), last_out[1].view(np.uint32)))
+        f32_leg = {"what": "nmn_index_set_mirror(0): scan_kernel streams the row-major f32 corpus (SURVEY §8(d): rows*dim*4 "
+                           "bytes per query); same index, queries, streams, steps and warmup as the headline loop",
+                   "value": args.nq * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
+                   "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS if scan2 else None,
+                   "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes4, "bytes_per_corpus_element": eb2,
+                   "pricing": "SURVEY §8(d): rows*dim*4",
+                   "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
+                   "traffic": pmc_traffic(local_rows, args, 4)[0], "traffic_source": pmc_traffic(local_rows, args, 4)[1],
+                   "exact_topk_certified": cert2["exact_topk_certified"] if cert2 else None,
+                   "same_answer_as_mirror_sweep": same}
 
     batched = None
     if world == 1 and args.batched > 0 and args.nq == 1 and args.mask >= 1.0:
@@ -412,6 +526,21 @@ def main():
     others = None
     default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
                         args.metric == "cosine" and args.mask >= 1.0)
+    # HBM traffic of the dominant kernel from PMC counters collected in THIS run (the committed profiles/pmc_traffic.json
+    # figure above is the fallback where rocprofv3 is not usable)
+    if rank == 0 and world == 1 and default_workload and not args.no_live_pmc and not args.always_gather:
+        live = live_pmc(args)
+        if live:
+            key = "mirror" if elem_bytes == 2 else "f32"
+            traffic, traffic_src = live[key]["hbm_bytes_per_launch"], live[key]["source"]
+            if f32_leg is not None:
+                f32_leg["traffic"], f32_leg["traffic_source"] = live["f32"]["hbm_bytes_per_launch"], live["f32"]["source"]
+                f32_leg["traffic_read_write"] = [live["f32"]["read_bytes_corrected"], live["f32"]["write_bytes"]]
+            traffic_rw = [live[key]["read_bytes_corrected"], live[key]["write_bytes"]]
+        else:
+            traffic_rw = None
+    else:
+        traffic_rw = None
     if world == 1 and default_workload and not args.no_other_configs and not args.always_gather:
         idx.close()  # the children need the HBM (config 5 alone is 61 GB + workspace)
         others = other_configs()
@@ -430,15 +559,21 @@ def main():
                        "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_read_write": traffic_rw,
                          "kernel": ("nmn::exact_scan_kernel" if args.k > 4096 else
                                     "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel"), "avg_kernel_ms": scan_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_corpus_element": elem_bytes,
+                         "pricing": ("bytes the kernel is asked to read: rows*dim*2, the bf16 mirror" if elem_bytes == 2
+                                     else "SURVEY §8(d): rows*dim*4, the f32 corpus"),
+                         # the same kernel time priced as SURVEY §8(d) writes it (N*d*4 per query): an EFFECTIVE rate
+                         "achieved_priced_as_survey_8d": achieved * 4 / elem_bytes if scan_ms else None,
+                         "frac_priced_as_survey_8d": achieved * 4 / elem_bytes / HBM_PEAK_GBS if scan_ms else None,
                          "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None,
                          # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
                          "measured_read_ceiling": read_ceiling,
                          "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None},
+            "roofline_f32_corpus": f32_leg,
             "cpu_baseline": cpu,
             "parity": parity,
             "batched": batched,

@@ -162,6 +162,11 @@ nmn_status nmn_index_search_device(nmn_index* idx, const float* queries_dev, uin
 
 /* Stats of the last search enqueued on `stream` (synchronises that stream). */
 nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_search_stats* stats);
+/* Which matrix the approximate sweep streams.  enabled != 0 (default): the shard's bf16 mirror (2 bytes per corpus
+ * element; built on first use).  enabled == 0: the row-major f32 corpus itself — the sweep SURVEY.md §8(d) prices at
+ * rows * dim * 4 bytes per query (bench.py's `roofline_f32_corpus` leg); query batches then run as VALU sweeps of 4.
+ * Results are identical either way (every candidate is re-scored from the f32 corpus in the reference's order). */
+nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled);
 /* Turn hipEvent timing of the scan kernel on/off for `*_device` searches (default off). */
 nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled);
 

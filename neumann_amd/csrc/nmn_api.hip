@@ -242,8 +242,25 @@ static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32
 constexpr uint64_t kCrowdMinRows = 1ull << 18;
 constexpr uint64_t kCrowdPool = 8ull << 20;
 
-static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
-    if (w->scores) return NMN_OK;
+// Frees what ws_alloc allocates (and only that), leaving the workspace as ws_get made it.
+static void ws_release_core(Workspace* w) {
+    void** ptrs[] = {(void**)&w->scores, (void**)&w->tmax, (void**)&w->wmax, (void**)&w->tsample, (void**)&w->skip_key,
+                     (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
+                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
+                     (void**)&w->crowd_rows, (void**)&w->crowd_scores};
+    for (void** p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    w->crowd_cap = 0;
+    for (auto& e : w->ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    w->allocated = false;
+}
+
+static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
     w->ld = idx->ld;
     w->score_stride = idx->cap_pad;
     w->n_tiles_cap = (uint32_t)(idx->cap_pad / kTileRows);
@@ -274,6 +291,22 @@ static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_scores), (size_t)w->crowd_cap * 4));
     }
     for (auto& e : w->ev) HIP_TRY(hipEventCreate(&e));
+    return NMN_OK;
+}
+
+// All or nothing: a workspace counts as allocated only once EVERY buffer exists.  A failure half way (a nearly full
+// HBM, a 128-query pass) frees what it got, so the next search on this stream retries — or fails again with
+// NMN_ERR_OUT_OF_MEMORY — instead of launching kernels on null pointers.
+static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
+    if (w->allocated) return NMN_OK;
+    const nmn_status st = ws_alloc_core(idx, w);
+    if (st != NMN_OK) {
+        const std::string keep = g_last_error;
+        ws_release_core(w);
+        g_last_error = keep;
+        return st;
+    }
+    w->allocated = true;
     return NMN_OK;
 }
 
@@ -391,6 +424,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->half_scratch) (void)hipFree(idx->half_scratch);
     if (idx->half_stats) (void)hipFree(idx->half_stats);
+    if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
     for (int i = 1; i < nmn_index::kHostSlots; i++)
@@ -418,6 +452,13 @@ extern "C" nmn_status nmn_index_set_rows(nmn_index* idx, uint64_t rows) {
     return NMN_OK;
 }
 
+extern "C" nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->mirror_off = enabled == 0;
+    return NMN_OK;
+}
+
 extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     idx->timing = enabled != 0;
@@ -431,7 +472,7 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
                                 hipStream_t stream) {
     if (!idx || (!src && n)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (row0 > idx->rows) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "row0 leaves a gap (row0 > rows)");
-    if (row0 + n > idx->cap) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
+    if (n > idx->cap || row0 > idx->cap - n) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");  // (no u64 wrap)
     if (n == 0) return NMN_OK;
     HIP_TRY(hipSetDevice(idx->device));
     float* dst = idx->corpus + row0 * (uint64_t)idx->ld;
@@ -469,12 +510,33 @@ extern "C" nmn_status nmn_index_upload(nmn_index* idx, const float* rows_host, u
     return NMN_OK;
 }
 
+// Asynchronous uploads are ordered against later searches on ANY stream by one event: every upload first makes its
+// stream wait for the previous upload's event (so the latest event covers all earlier ones), records the event anew
+// behind its own work, and search_enqueue makes a stream that has not yet seen that upload wait for it.
+static nmn_status upload_fence_record(nmn_index* idx, hipStream_t stream) {
+    if (!idx->upload_ev) HIP_TRY(hipEventCreateWithFlags(&idx->upload_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(idx->upload_ev, stream));
+    idx->upload_seq++;
+    return NMN_OK;
+}
+static nmn_status upload_fence_wait(nmn_index* idx, Workspace* w, hipStream_t stream) {
+    if (w->seen_upload_seq == idx->upload_seq) return NMN_OK;
+    if (idx->upload_ev) HIP_TRY(hipStreamWaitEvent(stream, idx->upload_ev, 0));
+    w->seen_upload_seq = idx->upload_seq;
+    return NMN_OK;
+}
+
 extern "C" nmn_status nmn_index_upload_device(nmn_index* idx, const float* rows_dev, uint64_t row0, uint64_t n,
                                               void* stream) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     std::unique_lock<std::mutex> lk(idx->mu);
     IdleGuard idle(idx, lk);
-    return upload_common(idx, rows_dev, false, row0, n, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(idx->device));
+    if (idx->upload_ev && idx->upload_seq) HIP_TRY(hipStreamWaitEvent(s, idx->upload_ev, 0));  // chain behind earlier uploads
+    nmn_status st = upload_common(idx, rows_dev, false, row0, n, s);
+    if (st != NMN_OK || n == 0) return st;
+    return upload_fence_record(idx, s);
 }
 
 // ---- the search pipeline ------------------------------------------------------------------------
@@ -573,6 +635,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                                  const uint64_t* const* qmasks_dev = nullptr, const uint64_t* const* qmasks_host = nullptr) {
     nmn_status st = ws_alloc(idx, w);
     if (st != NMN_OK) return st;
+    st = upload_fence_wait(idx, w, stream);  // rows uploaded asynchronously on another stream must have landed
+    if (st != NMN_OK) return st;
     if (k > NMN_MAX_TOP_K) {
         if (qmasks_host) {
             for (uint32_t i = 0; i < nq; i++) {
@@ -600,7 +664,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         const bool mfma_shape = nqc >= mfma_min_queries(idx) && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
                                 !no_mfma();
         bool use_half = n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
-                        (mfma_shape || (!no_half() && idx->half_calls >= idx->half_off_until));
+                        !idx->mirror_off && (mfma_shape || (!no_half() && idx->half_calls >= idx->half_off_until));
         if (!mfma_shape && idx->half_stats && (++idx->half_calls & 255u) == 0 && idx->half_calls >= idx->half_off_until) {
             uint32_t now[2] = {0, 0};  // a plain read of two counters other streams may still be adding to: good enough
             if (hipMemcpy(now, idx->half_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -904,7 +968,7 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
 // on the matrix-core sweep, 4 on the VALU sweep (a longer batch there would only make every rider wait for the
 // later sweeps of the others).
 static uint32_t batch_queries(const nmn_index* idx, int metric) {
-    if (!scan_mfma_supported(idx->ld, idx->dim, metric) || no_mfma()) return 4;
+    if (!scan_mfma_supported(idx->ld, idx->dim, metric) || no_mfma() || idx->mirror_off) return 4;
     // 128 callers per sweep for every row length: either 128 stationary queries per workgroup (rows <= 768, 1024, 1280)
     // or several query blocks whose workgroups share the streamed tiles through their XCD's L2 (nmn_scan_mfma.hip);
     // 2M x 3072: 64 queries 2.9 ms, 128 queries 4.3 ms.
@@ -1151,6 +1215,9 @@ extern "C" nmn_status nmn_index_search_pred(nmn_index* idx, nmn_columns* cols, c
     if (st != NMN_OK) return st;
     if (!cols || !prog || n_ops == 0 || (n_consts && !consts)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null predicate");
     if (k > NMN_MAX_TOP_K) return fail_arg(NMN_ERR_TOP_K_TOO_LARGE, "nmn_index_search_pred serves k <= NMN_MAX_TOP_K");
+    // checked per REQUEST, before it can ride in anybody's batch: a bad set of columns fails its own caller only
+    if (columns_device(cols) != idx->device || columns_words(cols) < (idx->rows + 63) / 64)
+        return fail_arg(NMN_ERR_INVALID_ARGUMENT, "metadata columns do not cover the shard's rows (or live on another device)");
     HIP_TRY(hipSetDevice(idx->device));
     HostReq me;
     me.queries = queries;
@@ -1568,7 +1635,7 @@ extern "C" nmn_status nmn_synth_fill_host(float* out, uint64_t seed, uint64_t ro
 extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, uint64_t row0, uint64_t n) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     if (row0 > idx->rows) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "row0 leaves a gap (row0 > rows)");
-    if (row0 + n > idx->cap) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
+    if (n > idx->cap || row0 > idx->cap - n) return fail_arg(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");  // (no u64 wrap)
     if (n == 0) return NMN_OK;
     HIP_TRY(hipSetDevice(idx->device));
     std::unique_lock<std::mutex> lk(idx->mu);

@@ -625,6 +625,9 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
     for (const auto& ent : c->slots)
         if (ent.live && ent.vec.size() == dim) n++;  // `if stored_vec.len() != query.len() { return None }`
     if (n > 0) {
+        // (an FFI caller's u64 dimension must not be truncated into a smaller, valid one; nmn_index_create's own limit is
+        // one query in LDS: 40960 floats)
+        if (dim > 0xFFFFFFFFull) return fail(NMN_ERR_INVALID_ARGUMENT, "dimension does not fit the device index (> 2^32 - 1)");
         nmn_index_desc d{};
         d.dim = (uint32_t)dim;
         // an engine serves concurrent search_similar callers, which share sweeps: rows of 300 / 200 / 100 floats are
@@ -1498,6 +1501,7 @@ nmn_status nmn_engine_build_ivf_index(nmn_engine* e, const nmn_ivf_options* opti
     res->dim = dim;
     // index.train(&vectors) then index.add(v) for every vector — both on the GPU, the k-means bit for bit
     // (nmn_ivf_build: exact centroid sweeps for the assignments, sequential per-(cluster, dimension) sums for the update)
+    if (dim > 0xFFFFFFFFull) return fail(NMN_ERR_INVALID_ARGUMENT, "dimension does not fit the device index (> 2^32 - 1)");
     nmn_index_desc d{};
     d.dim = (uint32_t)dim;
     d.capacity_rows = n;
@@ -1736,6 +1740,7 @@ nmn_status nmn_engine_compute_similarity(nmn_engine* e, const float* a, uint64_t
     if (!e || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (!a || !b || na == 0 || nb == 0) return err_empty();  // lib.rs:2279-2281
     if (na != nb) return err_dim(na, nb);                    // lib.rs:2282-2287
+    if (na > 0xFFFFFFFFull) return fail(NMN_ERR_INVALID_ARGUMENT, "dimension does not fit the device index (> 2^32 - 1)");
     WriteLock g(e);
     auto& slot = e->scratch[na];
     if (!slot) {

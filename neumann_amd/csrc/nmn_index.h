@@ -64,6 +64,8 @@ struct Workspace {
     // timing + stats of the last search
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
+    uint64_t seen_upload_seq = 0;  // last asynchronous upload this workspace's stream has been ordered behind
+    bool allocated = false;  // every buffer of ws_alloc exists (set last; a partial allocation is rolled back)
     uint32_t last_nq = 0;
     uint64_t last_rows_scanned = 0;
     uint32_t last_elem_bytes = 4;  // bytes per corpus element the last sweep read (2 on the bf16 mirror)
@@ -107,6 +109,7 @@ struct nmn_index {
     float* half = nullptr;       // bf16 mirror of `corpus` every approximate sweep reads (half the bytes); lazy
     uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current
     bool half_failed = false;    // allocation failed once: stay on the f32 sweep
+    bool mirror_off = false;     // nmn_index_set_mirror(idx, 0): every sweep reads the f32 corpus (SURVEY §8(d)'s bytes)
     // Mirror on/off switch: data whose rounding margin keeps overflowing the candidate capacity (a row of enormous norm
     // under a Euclidean metric, ...) pays a bf16 pass AND an f32 retry per query.  select_kernel counts both in
     // half_stats; every 256th search the host reads them and, if more than half of the recent queries were retried, leaves
@@ -119,6 +122,8 @@ struct nmn_index {
     size_t half_scratch_cap = 0;        // search after a store would synchronise the whole device every time)
     float* norms = nullptr;
     uint32_t* max_norm_bits = nullptr;
+    hipEvent_t upload_ev = nullptr;     // recorded behind the latest nmn_index_upload_device (nmn_api.hip: upload_fence_*)
+    uint64_t upload_seq = 0;
     hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot
     std::mutex mu;       // guards every field below and all enqueueing; NOT held while a host-buffer search waits
     std::unordered_map<hipStream_t, Workspace*> ws;

@@ -696,7 +696,10 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
                                      tmp_dist.data(), &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_rows);
             if (st != NMN_OK) return st;
             const bool cut_inside_run = cnt > k && tmp_dist[k] == tmp_dist[k - 1];
-            if (!cut_inside_run || cnt < kk || kk >= n_rows) break;  // run seen whole, or nothing more to fetch
+            // the run is seen whole as soon as it ENDS inside the fetched list (its last fetched entry differs from the
+            // k-th); only a run that reaches the end of a full list may continue beyond it
+            const bool run_ends_inside = cut_inside_run && tmp_dist[cnt - 1] != tmp_dist[k - 1];
+            if (!cut_inside_run || run_ends_inside || cnt < kk || kk >= n_rows) break;  // nothing more to learn / fetch
             kk = std::min<uint64_t>(kk * 2, n_rows);
         }
         for (uint32_t i = 0; i < cnt; i++) tmp_dist[i] = -tmp_dist[i];

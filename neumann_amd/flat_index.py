@@ -192,6 +192,10 @@ class GpuFlatIndex:
             _stream_ptr(stream)))
         return rows, scores, counts
 
+    def set_mirror(self, enabled):
+        """False: approximate sweeps read the f32 corpus (rows*dim*4 bytes per query) instead of its bf16 mirror."""
+        _capi.check(self._lib.nmn_index_set_mirror(self._h, 1 if enabled else 0))
+
     def set_timing(self, enabled):
         _capi.check(self._lib.nmn_index_set_timing(self._h, 1 if enabled else 0))
 

@@ -29,18 +29,26 @@ def main():
     for name, rows in (("FETCH_SIZE", f), ("WRITE_SIZE", w)):
         for k, n, a, mn, mx in rows:
             print(f"{k[:80]:<82} {name:<11} {n:>8} {a:>14.1f} {mn:>14.1f} {mx:>14.1f}")
-    scan_f = next((r for r in f if "scan_kernel" in r[0]), None)
-    scan_w = next((r for r in w if "scan_kernel" in r[0]), None)
+    # the sweeps proper: nmn::scan_kernel<...> (NOT exact_scan_kernel, whose name contains the same substring and which
+    # reads the f32 corpus: that mismatch once printed "read 30.825 GB" under a 15.40 GB table) and scan_mfma_kernel
+    def pick(rows, needle):
+        return [r for r in rows if needle in r[0] and "exact_scan" not in r[0]]
     fill_w = next((r for r in w if "synth_fill" in r[0]), None)
-    out = {"title": title}
-    if scan_f and scan_w:
-        rd = scan_f[2] * 1024 * 2
-        wr = scan_w[2] * 1024
-        out.update({"kernel": scan_f[0], "fetch_size_kib_avg": scan_f[2], "write_size_kib_avg": scan_w[2],
-                    "read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr,
-                    "hbm_bytes_per_launch": rd + wr,
-                    "correction": "FETCH_SIZE*1024*2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE*1024"})
-        print(f"# scan_kernel HBM traffic per launch: read {rd / 1e9:.3f} GB (corrected) + write {wr / 1e9:.3f} GB")
+    out = {"title": title, "kernels": []}
+    for needle in ("::scan_kernel<", "scan_mfma_kernel<"):
+        for rf in pick(f, needle):
+            rw = next((r for r in pick(w, needle) if r[0] == rf[0]), None)
+            # a template that serves both real sweeps and launches that return at once (the f32 retry of a mirror pass, the
+            # sampling pass of a batch): the sweeps are the launches at the maximum
+            rd = rf[4] * 1024 * 2
+            wr = (rw[4] if rw else 0.0) * 1024
+            out["kernels"].append({"kernel": rf[0], "launches": rf[1], "fetch_size_kib_max": rf[4], "fetch_size_kib_avg": rf[2],
+                                   "write_size_kib_max": rw[4] if rw else None,
+                                   "read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr,
+                                   "hbm_bytes_per_launch": rd + wr,
+                                   "correction": "FETCH_SIZE*1024*2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE*1024; "
+                                                 "max over the launches of the template (= the full sweeps)"})
+            print(f"# {rf[0][:70]}: HBM traffic per full sweep: read {rd / 1e9:.3f} GB (corrected) + write {wr / 1e9:.3f} GB")
     if fill_w:
         out["write_calibration_synth_fill_bytes"] = fill_w[2] * 1024
     json.dump(out, open(out_json, "w"), indent=1)
