@@ -217,6 +217,64 @@ nmn_status nmn_merge_topk_device_strided(const uint64_t* rows_dev, const float* 
                                          uint32_t nq, uint32_t k, uint64_t* out_rows_dev, float* out_scores_dev,
                                          uint32_t* out_counts_dev, void* stream);
 
+/* ---- multi-GPU in ONE process: row-range shards over the GPUs of a node --------------------- */
+
+/* The reference host is one process sharing an Arc<VectorEngine> (query_router/src/lib.rs:710); what it offers for
+ * spreading a SIMILAR over several holders of the data is the distributed planner's scatter-gather — every shard runs
+ * the query, ResultMerger::merge_top_k concatenates, sorts by score descending and truncates
+ * (query_router/src/distributed.rs:173-180, 413-433).  nmn_sharded is that with GPUs as shards, behind one handle a
+ * single host process drives (SURVEY.md §8b `nmn_index_desc{.., n_gpus, gpu_ids[]}`, §8e): shard g holds the global
+ * rows [g*ceil(N/G), (g+1)*ceil(N/G)) on devices[g]; a search replicates the queries, runs the single-shard pipeline
+ * on every device's own stream, gathers the per-shard top-k blocks with ONE collective — an RCCL all-gather over xGMI
+ * (ncclCommInitAll communicators, grouped calls) when every shard has a device of its own, peer copies when several
+ * LOGICAL shards share a device — and merges them on the device of shard 0 (nmn_merge_topk_device_strided's kernel).
+ * The answer is the unsharded one: rows, scores, tie order (global top-k is a subset of the union of the local ones).
+ * Calls on one handle are serialised; use one handle per concurrent client group, or the per-shard handles
+ * (nmn_sharded_shard) with nmn_merge_topk_* directly. */
+typedef struct nmn_sharded nmn_sharded;
+
+#define NMN_MAX_SHARDS 64u
+#define NMN_GATHER_AUTO 0u /* RCCL when the shards' devices are distinct (and there are >= 2), else peer copies */
+#define NMN_GATHER_RCCL 1u /* ncclAllGather, one communicator rank per shard; needs distinct devices (1 shard is legal) */
+#define NMN_GATHER_PEER 2u /* hipMemcpyPeerAsync of every block into the merging device's gather buffer */
+
+typedef struct nmn_sharded_desc {
+    uint32_t dim;            /* vector dimension d (>0) */
+    uint32_t flags;          /* NMN_INDEX_* bits, applied to every shard */
+    uint64_t capacity_rows;  /* rows of the WHOLE corpus; shard g gets the rows [g*ceil(N/G), ...) */
+    uint64_t row_base;       /* global id of row 0 of the whole corpus */
+    uint32_t n_shards;       /* G, 1..NMN_MAX_SHARDS */
+    uint32_t gather;         /* NMN_GATHER_* */
+    const int32_t* devices;  /* [n_shards] HIP device ordinal of each shard (repeats = logical shards on one GPU);
+                                NULL = round-robin over the node's devices */
+    uint32_t cand_cap;       /* as nmn_index_desc.cand_cap */
+    uint32_t reserved;       /* 0 */
+} nmn_sharded_desc;
+
+nmn_status nmn_sharded_create(const nmn_sharded_desc* desc, nmn_sharded** out);
+nmn_status nmn_sharded_destroy(nmn_sharded* s);
+/* nmn_index_upload over the GLOBAL row numbering: rows [row0, row0+n) (HOST, row-major n x dim) go to the shards whose
+ * ranges they fall into.  Rows must arrive in global order (each shard, like nmn_index_upload, takes no gaps). */
+nmn_status nmn_sharded_upload(nmn_sharded* s, const float* rows_host, uint64_t row0, uint64_t n);
+/* nmn_index_fill_synthetic over the global numbering: the shards together hold exactly the unsharded corpus. */
+nmn_status nmn_sharded_fill_synthetic(nmn_sharded* s, uint64_t seed, uint64_t row0, uint64_t n);
+/* nmn_index_search over all shards: same arguments (HOST buffers; `mask` is ONE bitmap over the global rows, bit i =
+ * row row_base + i, sliced per shard here), same outputs, same ranking.  stats: rows / bytes summed over the shards,
+ * times = the slowest shard's (they run side by side).  Synchronous. */
+nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                              const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                              nmn_search_stats* stats);
+uint32_t nmn_sharded_shards(const nmn_sharded* s);
+uint64_t nmn_sharded_rows(const nmn_sharded* s);               /* rows held, all shards */
+nmn_index* nmn_sharded_shard(nmn_sharded* s, uint32_t g);      /* the shard's own handle (owned by s) */
+int32_t nmn_sharded_device(const nmn_sharded* s, uint32_t g);  /* HIP device of shard g */
+uint32_t nmn_sharded_gather_mode(const nmn_sharded* s);        /* NMN_GATHER_RCCL or NMN_GATHER_PEER: what create chose */
+nmn_status nmn_sharded_set_timing(nmn_sharded* s, int32_t enabled);  /* hipEvent timing of the shards' sweeps and of gather+merge */
+nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled);  /* nmn_index_set_mirror on every shard */
+/* hipEvent span of the last search's collective + merge on the merging device (ms; -1 when not timed).  It starts when
+ * shard 0's pipeline is done, so it includes waiting for slower shards. */
+nmn_status nmn_sharded_last_gather_ms(const nmn_sharded* s, float* ms);
+
 /* ---- columnar metadata + WHERE-predicate programs ----------------------- */
 
 /* Filtered SIMILAR in the reference evaluates the predicate per key on the host: one `store.get`

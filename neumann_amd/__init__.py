@@ -8,4 +8,6 @@ from ._capi import NeumannGpuError, load as load_library  # noqa: F401
 from .flat_index import (DistanceMetric, GpuFlatIndex, merge_topk_device, merge_topk_device_packed,  # noqa: F401
                          merge_topk_host, packed_layout, synth_rows)
 
-__version__ = "0.1.0"
+from .sharded import GpuShardedIndex  # noqa: F401,E402
+
+__version__ = "0.2.0"

@@ -44,6 +44,16 @@ class IndexDesc(C.Structure):
                 ("row_base", C.c_uint64), ("device", C.c_int32), ("cand_cap", C.c_uint32)]
 
 
+class ShardedDesc(C.Structure):
+    """nmn_sharded_desc: one corpus row-range sharded over several devices of ONE process."""
+    _fields_ = [("dim", C.c_uint32), ("flags", C.c_uint32), ("capacity_rows", C.c_uint64), ("row_base", C.c_uint64),
+                ("n_shards", C.c_uint32), ("gather", C.c_uint32), ("devices", C.POINTER(C.c_int32)),
+                ("cand_cap", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
+
+
 class SearchStats(C.Structure):
     _fields_ = [("rows_scanned", C.c_uint64), ("bytes_scanned", C.c_uint64),
                 ("candidates_rescored", C.c_uint32), ("fallback_queries", C.c_uint32),
@@ -129,6 +139,19 @@ SIGNATURES = {
     "nmn_ivf_cluster_sizes": (C.c_int32, [vp, vp]),
     "nmn_ivf_search": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(SearchStats)]),
     "nmn_ivf_vectors": (vp, [vp]),
+    "nmn_sharded_create": (C.c_int32, [C.POINTER(ShardedDesc), C.POINTER(vp)]),
+    "nmn_sharded_destroy": (C.c_int32, [vp]),
+    "nmn_sharded_upload": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64]),
+    "nmn_sharded_fill_synthetic": (C.c_int32, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "nmn_sharded_search": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp, C.POINTER(SearchStats)]),
+    "nmn_sharded_shards": (C.c_uint32, [vp]),
+    "nmn_sharded_rows": (C.c_uint64, [vp]),
+    "nmn_sharded_shard": (vp, [vp, C.c_uint32]),
+    "nmn_sharded_device": (C.c_int32, [vp, C.c_uint32]),
+    "nmn_sharded_gather_mode": (C.c_uint32, [vp]),
+    "nmn_sharded_set_timing": (C.c_int32, [vp, C.c_int32]),
+    "nmn_sharded_set_mirror": (C.c_int32, [vp, C.c_int32]),
+    "nmn_sharded_last_gather_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
     "nmn_index_search_dmask": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp,
                                            C.POINTER(SearchStats)]),
     "nmn_index_search_dmask_hint": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_uint64, vp, vp, vp,

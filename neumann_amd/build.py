@@ -29,6 +29,7 @@ SOURCES = {
     "nmn_ivf.hip": ["-ffp-contract=off"],
     "nmn_kmeans.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_api.hip": [],
+    "nmn_sharded.hip": [],
     "nmn_engine.cpp": ["-ffp-contract=off"],
 }
 HEADERS = ["nmn_internal.h", "nmn_index.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
@@ -81,7 +82,7 @@ def build(force=False, verbose=False):
                 if verbose and warn.strip():
                     print(warn)
     if force or jobs or _newer(objs, LIB):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     return LIB
 
 

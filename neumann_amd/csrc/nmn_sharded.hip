@@ -1,0 +1,475 @@
+// nmn_sharded.hip — ONE process, N devices: the row-range sharded index behind the opaque `nmn_sharded` handle
+// (include/neumann_gpu.h, "multi-GPU in one process").
+//
+// The reference host is one process holding an Arc<VectorEngine> (query_router/src/lib.rs:710); its model for fanning a
+// SIMILAR out and merging the answers is the distributed planner's scatter-gather: every shard answers the same query,
+// ResultMerger::merge_top_k concatenates, sorts by score descending and truncates (query_router/src/distributed.rs:173-180,
+// 413-433).  Here a shard is a row range resident on one GPU (shard g owns rows [g*ceil(N/G), ...)); one
+// call = queries replicated to every device -> the single-shard pipeline on each device's own stream, writing a PACKED
+// block [rows u64 | scores f32 | counts u32] -> ONE collective that brings every block to the merging device ->
+// merge_kernel (nmn_select.hip) -> one D2H.  The collective:
+//   * RCCL (all devices distinct): ncclAllGather of the packed blocks inside one ncclGroupStart/End, one communicator per
+//     device from ncclCommInitAll — over xGMI between the GPUs of a node; payload nq*k*12 B per shard, latency-bound.
+//     librccl is dlopen'ed on first use (no link-time dependency: the library loads on hosts without it, and a process
+//     that already carries a copy — PyTorch bundles one — keeps a single instance).
+//   * peer copies (several LOGICAL shards on one device, which a communicator cannot express, or RCCL unavailable):
+//     hipMemcpyPeerAsync of each block into the merging device's gather buffer, ordered by events.
+// Global top-k is a subset of the union of the shards' top-k lists, so the answer is exactly the unsharded one.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nmn_index.h"
+
+using namespace nmn;
+
+#define S_TRY(expr)                                                   \
+    do {                                                              \
+        hipError_t _e = (expr);                                       \
+        if (_e != hipSuccess) return set_error_hip(_e, #expr);        \
+    } while (0)
+
+// ---- the slice of the RCCL API this file uses, resolved at run time ---------------------------------------------------
+namespace {
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;  // 0 = ncclSuccess
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.so) break;
+        }
+        if (!r.so) {
+            r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+            return;
+        }
+        auto sym = [&](const char* n) { return dlsym(r.so, n); };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+        r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd;
+        if (!r.ok) r.why = "librccl lacks ncclCommInitAll / ncclAllGather / ncclGroupStart";
+    });
+    return r;
+}
+nmn_status fail_nccl(ncclResult_t e, const char* what) {
+    Rccl& r = rccl();
+    std::string m = std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error") + " (" + std::to_string(e) + ")";
+    return set_error(NMN_ERR_STORAGE, m.c_str());
+}
+
+struct PackLayout {
+    size_t size, off_scores, off_counts;
+};
+PackLayout pack_layout(uint32_t nq, uint32_t k) {
+    PackLayout p;
+    p.off_scores = (size_t)nq * k * 8;
+    p.off_counts = p.off_scores + (size_t)nq * k * 4;
+    p.size = (p.off_counts + (size_t)nq * 4 + 15) & ~(size_t)15;
+    return p;
+}
+}  // namespace
+
+struct ShardLane {  // what one shard needs for one search in flight
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float* queries = nullptr;      size_t queries_cap = 0;  // device, nq x dim
+    uint8_t* block = nullptr;      size_t block_cap = 0;    // device, this shard's packed result block
+    uint8_t* gathered = nullptr;   size_t gathered_cap = 0; // device, n_shards packed blocks (RCCL: every shard; peer: shard 0)
+    uint64_t* mask = nullptr;      size_t mask_cap = 0;     // device, this shard's slice of the selection bitmap
+};
+
+struct nmn_sharded {
+    uint32_t dim = 0, n_shards = 0;
+    uint64_t cap = 0, per = 0;  // total capacity, rows per shard (= ceil(cap / n_shards); the last one may hold fewer)
+    uint32_t gather = NMN_GATHER_PEER;
+    std::vector<nmn_index*> shard;
+    std::vector<int> device;
+    std::vector<ShardLane> lane;
+    std::vector<ncclComm_t> comm;  // RCCL mode: one per shard
+    // merging device (= shard 0's): merged output, pinned staging
+    uint8_t* out_block = nullptr;  size_t out_cap = 0;       // device
+    uint8_t* pin_in = nullptr;     size_t pin_in_cap = 0;    // pinned: queries (+ per-shard mask slices)
+    uint8_t* pin_out = nullptr;    size_t pin_out_cap = 0;   // pinned: merged block
+    std::vector<uint64_t> mask_tmp;
+    uint64_t searches = 0;
+    float last_gather_ms = -1.f;
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;  // around the collective + merge on the merging device (when timed)
+    bool timing = false;
+    std::mutex mu;  // one search (or upload) at a time per handle: the shards' own coalescers are not involved here
+};
+
+template <typename T>
+static hipError_t grow_dev(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(need, 16) * sizeof(T));
+    if (e == hipSuccess) *cap = need;
+    return e;
+}
+static hipError_t grow_pin(uint8_t** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = std::max<size_t>(need + need / 2, 4096);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(p), want, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+static void shard_bounds(const nmn_sharded* s, uint32_t g, uint64_t total, uint64_t* r0, uint64_t* r1) {
+    *r0 = std::min<uint64_t>((uint64_t)g * s->per, total);
+    *r1 = std::min<uint64_t>(*r0 + s->per, total);
+}
+
+extern "C" nmn_status nmn_sharded_destroy(nmn_sharded* s) {
+    if (!s) return NMN_OK;
+    for (uint32_t g = 0; g < s->lane.size(); g++) {
+        (void)hipSetDevice(s->device[g]);
+        ShardLane& l = s->lane[g];
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        for (void* p : {(void*)l.queries, (void*)l.block, (void*)l.gathered, (void*)l.mask})
+            if (p) (void)hipFree(p);
+        if (l.done) (void)hipEventDestroy(l.done);
+    }
+    for (ncclComm_t c : s->comm)
+        if (c && rccl().ok) (void)rccl().CommDestroy(c);
+    if (!s->device.empty()) (void)hipSetDevice(s->device[0]);
+    if (s->out_block) (void)hipFree(s->out_block);
+    if (s->pin_in) (void)hipHostFree(s->pin_in);
+    if (s->pin_out) (void)hipHostFree(s->pin_out);
+    if (s->ev_g0) (void)hipEventDestroy(s->ev_g0);
+    if (s->ev_g1) (void)hipEventDestroy(s->ev_g1);
+    for (uint32_t g = 0; g < s->shard.size(); g++) {
+        // the shards own their streams; lanes used them (no stream of our own to destroy)
+        if (s->shard[g]) (void)nmn_index_destroy(s->shard[g]);
+    }
+    delete s;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_sharded_create(const nmn_sharded_desc* d, nmn_sharded** out) {
+    if (!d || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (d->dim == 0) return set_error(NMN_ERR_EMPTY_VECTOR, "dim == 0");
+    if (d->n_shards == 0 || d->n_shards > NMN_MAX_SHARDS) return set_error(NMN_ERR_INVALID_ARGUMENT, "n_shards out of range (1..NMN_MAX_SHARDS)");
+    if (d->gather > NMN_GATHER_PEER) return set_error(NMN_ERR_INVALID_ARGUMENT, "unknown gather mode");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return set_error(NMN_ERR_NO_DEVICE, "no HIP device");
+    }
+    nmn_sharded* s = new (std::nothrow) nmn_sharded();
+    if (!s) return set_error(NMN_ERR_OUT_OF_MEMORY, "sharded alloc");
+    s->dim = d->dim;
+    s->n_shards = d->n_shards;
+    s->cap = d->capacity_rows;
+    s->per = (d->capacity_rows + d->n_shards - 1) / d->n_shards;  // shard g owns [g*ceil(N/G), ...)
+    bool distinct = true;
+    for (uint32_t g = 0; g < d->n_shards; g++) {
+        int dev = d->devices ? d->devices[g] : (int)(g % (uint32_t)ndev);  // no list: round-robin over the node's GPUs
+        if (dev < 0 || dev >= ndev) {
+            nmn_sharded_destroy(s);
+            return set_error(NMN_ERR_NO_DEVICE, "device ordinal out of range");
+        }
+        for (int e : s->device) distinct = distinct && e != dev;
+        s->device.push_back(dev);
+    }
+    // which collective: RCCL needs one rank per DEVICE; logical shards sharing a device take the peer-copy gather
+    if (d->gather == NMN_GATHER_RCCL && !distinct) {
+        nmn_sharded_destroy(s);
+        return set_error(NMN_ERR_INVALID_ARGUMENT, "NMN_GATHER_RCCL needs distinct devices (one communicator rank per GPU)");
+    }
+    s->gather = NMN_GATHER_PEER;
+    if (d->gather == NMN_GATHER_RCCL || (d->gather == NMN_GATHER_AUTO && distinct && d->n_shards > 1)) {
+        if (rccl().ok) s->gather = NMN_GATHER_RCCL;
+        else if (d->gather == NMN_GATHER_RCCL) {
+            nmn_sharded_destroy(s);
+            return set_error(NMN_ERR_CONFIGURATION, rccl().why.c_str());
+        }
+    }
+    for (uint32_t g = 0; g < d->n_shards; g++) {
+        nmn_index_desc id{};
+        id.dim = d->dim;
+        id.flags = d->flags;
+        uint64_t r0, r1;
+        shard_bounds(s, g, s->cap, &r0, &r1);
+        id.capacity_rows = r1 - r0;
+        id.row_base = d->row_base + r0;
+        id.device = s->device[g];
+        id.cand_cap = d->cand_cap;
+        nmn_index* idx = nullptr;
+        nmn_status st = nmn_index_create(&id, &idx);
+        if (st != NMN_OK) {
+            nmn_sharded_destroy(s);
+            return st;
+        }
+        s->shard.push_back(idx);
+    }
+    s->lane.resize(d->n_shards);
+    for (uint32_t g = 0; g < d->n_shards; g++) {
+        hipError_t e = hipSetDevice(s->device[g]);
+        // the search of shard g runs on a stream of ITS device; logical shards on one device get a stream each, so their
+        // pipelines overlap like those of different GPUs would
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->lane[g].stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->lane[g].done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            nmn_sharded_destroy(s);
+            return set_error_hip(e, "stream / event of a shard");
+        }
+    }
+    if (s->gather == NMN_GATHER_PEER) {
+        // peer access between the merging device and the others makes hipMemcpyPeerAsync a direct xGMI copy
+        (void)hipSetDevice(s->device[0]);
+        for (uint32_t g = 1; g < d->n_shards; g++) {
+            if (s->device[g] == s->device[0]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, s->device[0], s->device[g]) == hipSuccess && can) {
+                hipError_t e = hipDeviceEnablePeerAccess(s->device[g], 0);
+                if (e != hipSuccess) (void)hipGetLastError();  // already enabled / not supported: the copy still works (staged)
+            }
+        }
+    } else {
+        s->comm.assign(d->n_shards, nullptr);
+        ncclResult_t r = rccl().CommInitAll(s->comm.data(), (int)d->n_shards, s->device.data());
+        if (r != 0) {
+            nmn_status st = fail_nccl(r, "ncclCommInitAll");
+            s->comm.clear();
+            nmn_sharded_destroy(s);
+            return st;
+        }
+    }
+    (void)hipSetDevice(s->device[0]);
+    (void)hipEventCreate(&s->ev_g0);
+    (void)hipEventCreate(&s->ev_g1);
+    *out = s;
+    return NMN_OK;
+}
+
+extern "C" uint32_t nmn_sharded_shards(const nmn_sharded* s) { return s ? s->n_shards : 0; }
+extern "C" nmn_index* nmn_sharded_shard(nmn_sharded* s, uint32_t g) { return (s && g < s->n_shards) ? s->shard[g] : nullptr; }
+extern "C" int32_t nmn_sharded_device(const nmn_sharded* s, uint32_t g) { return (s && g < s->n_shards) ? s->device[g] : -1; }
+extern "C" uint32_t nmn_sharded_gather_mode(const nmn_sharded* s) { return s ? s->gather : NMN_GATHER_AUTO; }
+extern "C" uint64_t nmn_sharded_rows(const nmn_sharded* s) {
+    uint64_t n = 0;
+    if (s)
+        for (nmn_index* i : s->shard) n += nmn_index_rows(i);
+    return n;
+}
+extern "C" nmn_status nmn_sharded_set_timing(nmn_sharded* s, int32_t enabled) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    s->timing = enabled != 0;
+    for (nmn_index* i : s->shard) (void)nmn_index_set_timing(i, enabled);
+    return NMN_OK;
+}
+extern "C" nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    for (nmn_index* i : s->shard) (void)nmn_index_set_mirror(i, enabled);
+    return NMN_OK;
+}
+
+// rows [row0, row0+n) of the GLOBAL numbering: each shard gets the part that falls into its range.  Like nmn_index_upload
+// rows must arrive without gaps, i.e. in global order (a shard fills up before the next one starts).
+template <typename F>
+static nmn_status for_each_part(nmn_sharded* s, uint64_t row0, uint64_t n, F&& f) {
+    if (n > s->cap || row0 > s->cap - n) return set_error(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
+    for (uint32_t g = 0; g < s->n_shards && n; g++) {
+        uint64_t r0, r1;
+        shard_bounds(s, g, s->cap, &r0, &r1);
+        const uint64_t a = std::max(row0, r0), b = std::min(row0 + n, r1);
+        if (a >= b) continue;
+        nmn_status st = f(g, a - r0, a - row0, b - a);
+        if (st != NMN_OK) return st;
+    }
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_sharded_upload(nmn_sharded* s, const float* rows_host, uint64_t row0, uint64_t n) {
+    if (!s || (!rows_host && n)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(s->mu);
+    return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t src0, uint64_t cnt) {
+        return nmn_index_upload(s->shard[sh], rows_host + src0 * (uint64_t)s->dim, local0, cnt);
+    });
+}
+
+extern "C" nmn_status nmn_sharded_fill_synthetic(nmn_sharded* s, uint64_t seed, uint64_t row0, uint64_t n) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> g(s->mu);
+    return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t, uint64_t cnt) {
+        return nmn_index_fill_synthetic(s->shard[sh], seed, local0, cnt);  // value(seed, row_base + row, col): global ids
+    });
+}
+
+// bits [b0, b0+nbits) of `src` (LSB first) -> dst[0 .. ceil(nbits/64)), bit 0 of dst = bit b0 of src
+static void bitmap_slice(const uint64_t* src, uint64_t b0, uint64_t nbits, uint64_t* dst) {
+    const uint64_t words = (nbits + 63) / 64, w0 = b0 >> 6;
+    const unsigned sh = (unsigned)(b0 & 63);
+    const uint64_t src_words = (b0 + nbits + 63) / 64;
+    for (uint64_t i = 0; i < words; i++) {
+        uint64_t lo = src[w0 + i] >> sh;
+        if (sh && w0 + i + 1 < src_words) lo |= src[w0 + i + 1] << (64 - sh);
+        dst[i] = lo;
+    }
+    if (nbits & 63) dst[words - 1] &= (~0ull) >> (64 - (nbits & 63));
+}
+
+extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                                         const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                         nmn_search_stats* stats) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    if (k == 0) return set_error(NMN_ERR_INVALID_TOP_K, "k == 0");
+    if (nq == 0 || nq > NMN_MAX_QUERIES) return set_error(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
+    if (!queries || !out_rows || !out_scores || !out_counts) return set_error(NMN_ERR_INVALID_ARGUMENT, "null buffer");
+    if ((int)metric < 0 || (int)metric > 3) return set_error(NMN_ERR_INVALID_ARGUMENT, "bad metric");
+    std::lock_guard<std::mutex> guard(s->mu);
+    const uint32_t G = s->n_shards;
+    const PackLayout pl = pack_layout(nq, k);
+    const size_t qbytes = (size_t)nq * s->dim * sizeof(float);
+    // ---- stage the replicated inputs once in pinned memory ------------------------------------------------------------
+    std::vector<uint64_t> rows_of(G), base_of(G);
+    for (uint32_t g = 0; g < G; g++) {
+        rows_of[g] = nmn_index_rows(s->shard[g]);
+        base_of[g] = (uint64_t)g * s->per;
+    }
+    size_t mask_words_total = 0;
+    std::vector<size_t> mask_off(G, 0);
+    if (mask)
+        for (uint32_t g = 0; g < G; g++) {
+            mask_off[g] = mask_words_total;
+            mask_words_total += (size_t)((rows_of[g] + 63) / 64);
+        }
+    S_TRY(hipSetDevice(s->device[0]));
+    S_TRY(grow_pin(&s->pin_in, &s->pin_in_cap, qbytes + mask_words_total * 8 + 16));
+    S_TRY(grow_pin(&s->pin_out, &s->pin_out_cap, pl.size));
+    memcpy(s->pin_in, queries, qbytes);
+    uint64_t* pin_mask = reinterpret_cast<uint64_t*>(s->pin_in + ((qbytes + 15) & ~(size_t)15));
+    if (mask)
+        for (uint32_t g = 0; g < G; g++)
+            if (rows_of[g]) bitmap_slice(mask, base_of[g], rows_of[g], pin_mask + mask_off[g]);
+    // ---- every shard: H2D of the queries (and its bitmap slice), the single-shard pipeline, into its packed block --------
+    for (uint32_t g = 0; g < G; g++) {
+        ShardLane& l = s->lane[g];
+        S_TRY(hipSetDevice(s->device[g]));
+        S_TRY(grow_dev(&l.queries, &l.queries_cap, (size_t)nq * s->dim));
+        S_TRY(grow_dev(&l.block, &l.block_cap, pl.size));
+        const bool holds_all = s->gather == NMN_GATHER_RCCL || g == 0;
+        if (holds_all) S_TRY(grow_dev(&l.gathered, &l.gathered_cap, pl.size * G));
+        S_TRY(hipMemcpyAsync(l.queries, s->pin_in, qbytes, hipMemcpyHostToDevice, l.stream));
+        const uint64_t* mask_dev = nullptr;
+        if (mask && rows_of[g]) {
+            const size_t words = (size_t)((rows_of[g] + 63) / 64);
+            S_TRY(grow_dev(&l.mask, &l.mask_cap, words));
+            S_TRY(hipMemcpyAsync(l.mask, pin_mask + mask_off[g], words * 8, hipMemcpyHostToDevice, l.stream));
+            mask_dev = l.mask;
+        }
+        nmn_status st = index_search_device(s->shard[g], l.queries, nq, k, (int)metric, mask_dev,
+                                            reinterpret_cast<uint64_t*>(l.block), reinterpret_cast<float*>(l.block + pl.off_scores),
+                                            reinterpret_cast<uint32_t*>(l.block + pl.off_counts), l.stream);
+        if (st != NMN_OK) return st;
+    }
+    // ---- the collective: every packed block to the merging device (RCCL: to every device) ---------------------------------
+    ShardLane& root = s->lane[0];
+    if (s->timing) {
+        S_TRY(hipSetDevice(s->device[0]));
+        S_TRY(hipEventRecord(s->ev_g0, root.stream));
+    }
+    if (s->gather == NMN_GATHER_RCCL) {
+        Rccl& r = rccl();
+        ncclResult_t e = r.GroupStart();
+        if (e != 0) return fail_nccl(e, "ncclGroupStart");
+        for (uint32_t g = 0; g < G && e == 0; g++) {
+            // (grouped calls may be issued from one thread for all the devices it drives; RCCL sets the device itself)
+            e = r.AllGather(s->lane[g].block, s->lane[g].gathered, pl.size, kNcclChar, s->comm[g], s->lane[g].stream);
+        }
+        ncclResult_t e2 = r.GroupEnd();
+        if (e != 0) return fail_nccl(e, "ncclAllGather");
+        if (e2 != 0) return fail_nccl(e2, "ncclGroupEnd");
+    } else {
+        for (uint32_t g = 0; g < G; g++) {
+            ShardLane& l = s->lane[g];
+            S_TRY(hipSetDevice(s->device[g]));
+            // enqueued on the PRODUCING shard's stream (right behind its pipeline); the merging stream waits for the event
+            if (s->device[g] == s->device[0])
+                S_TRY(hipMemcpyAsync(root.gathered + (size_t)g * pl.size, l.block, pl.size, hipMemcpyDeviceToDevice, l.stream));
+            else
+                S_TRY(hipMemcpyPeerAsync(root.gathered + (size_t)g * pl.size, s->device[0], l.block, s->device[g], pl.size, l.stream));
+            if (g != 0) S_TRY(hipEventRecord(l.done, l.stream));
+        }
+        S_TRY(hipSetDevice(s->device[0]));
+        for (uint32_t g = 1; g < G; g++) S_TRY(hipStreamWaitEvent(root.stream, s->lane[g].done, 0));
+    }
+    // ---- merge_top_k on the merging device, one D2H ---------------------------------------------------------------------
+    S_TRY(hipSetDevice(s->device[0]));
+    S_TRY(grow_dev(&s->out_block, &s->out_cap, pl.size));
+    S_TRY(launch_merge(reinterpret_cast<const uint64_t*>(root.gathered), reinterpret_cast<const float*>(root.gathered + pl.off_scores),
+                       reinterpret_cast<const uint32_t*>(root.gathered + pl.off_counts), pl.size, G, nq, k,
+                       reinterpret_cast<uint64_t*>(s->out_block), reinterpret_cast<float*>(s->out_block + pl.off_scores),
+                       reinterpret_cast<uint32_t*>(s->out_block + pl.off_counts), root.stream));
+    if (s->timing) S_TRY(hipEventRecord(s->ev_g1, root.stream));
+    S_TRY(hipMemcpyAsync(s->pin_out, s->out_block, pl.size, hipMemcpyDeviceToHost, root.stream));
+    S_TRY(hipStreamSynchronize(root.stream));
+    if (s->gather == NMN_GATHER_RCCL)
+        for (uint32_t g = 1; g < G; g++) {  // the other ranks of the collective must be done before their buffers are reused
+            S_TRY(hipSetDevice(s->device[g]));
+            S_TRY(hipStreamSynchronize(s->lane[g].stream));
+        }
+    memcpy(out_rows, s->pin_out, (size_t)nq * k * 8);
+    memcpy(out_scores, s->pin_out + pl.off_scores, (size_t)nq * k * 4);
+    memcpy(out_counts, s->pin_out + pl.off_counts, (size_t)nq * 4);
+    s->searches++;
+    if (s->timing) {
+        float ms = -1.f;
+        (void)hipSetDevice(s->device[0]);
+        if (hipEventElapsedTime(&ms, s->ev_g0, s->ev_g1) == hipSuccess) s->last_gather_ms = ms;
+        (void)hipGetLastError();
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->scan_ms = -1.f;
+        stats->total_ms = -1.f;
+        for (uint32_t g = 0; g < G; g++) {
+            nmn_search_stats one;
+            if (nmn_index_last_stats(s->shard[g], s->lane[g].stream, &one) != NMN_OK) continue;
+            stats->rows_scanned += one.rows_scanned;
+            stats->bytes_scanned += one.bytes_scanned;
+            stats->candidates_rescored = std::max(stats->candidates_rescored, one.candidates_rescored);
+            stats->fallback_queries += one.fallback_queries;
+            stats->scan_ms = std::max(stats->scan_ms, one.scan_ms);  // the shards run side by side: the slowest counts
+            stats->total_ms = std::max(stats->total_ms, one.total_ms);
+        }
+    }
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_sharded_last_gather_ms(const nmn_sharded* s, float* ms) {
+    if (!s || !ms) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *ms = s->last_gather_ms;
+    return NMN_OK;
+}

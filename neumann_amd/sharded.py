@@ -27,6 +27,121 @@ def shard_range(total_rows, world_size, rank):
     return r0, r1
 
 
+class GpuShardedIndex:
+    """ONE process, several devices: the `nmn_sharded` handle of the C ABI (include/neumann_gpu.h) — what a Rust
+    `vector_engine` holding an Arc<VectorEngine> binds to use every GPU of the node.  Shard g holds the global rows
+    [g*ceil(N/G), ...) on devices[g]; `search` replicates the queries, runs every shard's pipeline on its own stream,
+    gathers the per-shard top-k blocks with one RCCL all-gather (distinct devices) or peer copies (logical shards on one
+    device) and merges them on shard 0's device — `ResultMerger::merge_top_k` (distributed.rs:413-433)."""
+
+    def __init__(self, dim, capacity_rows, n_shards, devices=None, row_base=0, gather=0, cand_cap=0, wide_rows=False):
+        import ctypes as C
+        from . import _capi
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        self.dim, self.capacity_rows, self.n_shards, self.row_base = int(dim), int(capacity_rows), int(n_shards), int(row_base)
+        devs = None
+        if devices is not None:
+            assert len(devices) == n_shards
+            devs = (C.c_int32 * n_shards)(*[int(d) for d in devices])
+        desc = _capi.ShardedDesc(dim=self.dim, flags=1 if wide_rows else 0, capacity_rows=self.capacity_rows,
+                                 row_base=self.row_base, n_shards=self.n_shards, gather=int(gather),
+                                 devices=devs, cand_cap=int(cand_cap), reserved=0)
+        _capi.check(self._lib.nmn_sharded_create(C.byref(desc), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            import ctypes as C
+            self._lib.nmn_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def rows(self):
+        return int(self._lib.nmn_sharded_rows(self._h))
+
+    @property
+    def gather_mode(self):
+        """1 = RCCL all-gather, 2 = peer copies (what nmn_sharded_create chose)."""
+        return int(self._lib.nmn_sharded_gather_mode(self._h))
+
+    def device_of(self, shard):
+        return int(self._lib.nmn_sharded_device(self._h, int(shard)))
+
+    def shard_rows(self, shard):
+        return int(self._lib.nmn_index_rows(self._lib.nmn_sharded_shard(self._h, int(shard))))
+
+    def upload(self, rows, row0=None):
+        import ctypes as C
+        from . import _capi
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.ndim == 2 and rows.shape[1] == self.dim
+        if row0 is None:
+            row0 = self.rows
+        _capi.check(self._lib.nmn_sharded_upload(self._h, C.c_void_p(rows.ctypes.data), int(row0), rows.shape[0]))
+
+    def fill_synthetic(self, seed, n, row0=None):
+        from . import _capi
+        if row0 is None:
+            row0 = self.rows
+        _capi.check(self._lib.nmn_sharded_fill_synthetic(self._h, int(seed), int(row0), int(n)))
+
+    def set_timing(self, enabled):
+        from . import _capi
+        _capi.check(self._lib.nmn_sharded_set_timing(self._h, 1 if enabled else 0))
+
+    def set_mirror(self, enabled):
+        from . import _capi
+        _capi.check(self._lib.nmn_sharded_set_mirror(self._h, 1 if enabled else 0))
+
+    def last_gather_ms(self):
+        import ctypes as C
+        from . import _capi
+        ms = C.c_float()
+        _capi.check(self._lib.nmn_sharded_last_gather_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def search(self, queries, k, metric=0, mask=None, with_stats=False):
+        """As GpuFlatIndex.search: (rows u64 [nq,k], scores f32 [nq,k], counts u32 [nq]); `mask` covers the GLOBAL rows."""
+        import ctypes as C
+        from . import _capi
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.size == 0 or q.shape[1] == 0:
+            raise _capi.NeumannGpuError(_capi.ERR_EMPTY_VECTOR)
+        if q.shape[1] != self.dim:
+            raise _capi.NeumannGpuError(_capi.ERR_DIMENSION_MISMATCH, f"expected {self.dim}, got {q.shape[1]}")
+        nq, k = q.shape[0], int(k)
+        out_rows = np.empty((nq, max(k, 1)), dtype=np.uint64)
+        out_scores = np.empty((nq, max(k, 1)), dtype=np.float32)
+        out_counts = np.empty(nq, dtype=np.uint32)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint64)
+            if m.size < (self.capacity_rows + 63) // 64 and m.size < (self.rows + 63) // 64:
+                raise _capi.NeumannGpuError(_capi.ERR_BUFFER_TOO_SMALL, "mask must cover the global rows")
+        stats = _capi.SearchStats()
+        _capi.check(self._lib.nmn_sharded_search(self._h, C.c_void_p(q.ctypes.data), nq, k, int(metric),
+                                                 None if m is None else C.c_void_p(m.ctypes.data),
+                                                 C.c_void_p(out_rows.ctypes.data), C.c_void_p(out_scores.ctypes.data),
+                                                 C.c_void_p(out_counts.ctypes.data), C.byref(stats)))
+        if with_stats:
+            return out_rows, out_scores, out_counts, stats
+        return out_rows, out_scores, out_counts
+
+
 class ShardedSearcher:
     """Per-rank driver: local shard search -> all-gather -> merge.  World size 1 skips the collective."""
 
