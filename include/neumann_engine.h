@@ -46,6 +46,8 @@ typedef struct nmn_engine_config {
     int64_t search_timeout_ms;   /* <0 = None */
     int32_t device;              /* GPU ordinal, -1 = current (new knob, additive) */
     uint32_t cand_cap;           /* 0 = default (new knob, additive) */
+    int64_t max_index_file_bytes; /* lib.rs:644, 660: 100 MiB; < 0 = None; 0 is a ConfigurationError (lib.rs:740-746) */
+    int64_t max_index_entries;    /* lib.rs:646, 661: 1 000 000; < 0 = None; 0 is a ConfigurationError (lib.rs:747-753) */
 } nmn_engine_config;
 
 /* ScalarValue / FilterValue payload (tensor_store ScalarValue; lib.rs:342-353). */
@@ -228,6 +230,27 @@ nmn_strlist* nmn_engine_scan_entities_with_embeddings(nmn_engine* e);
 uint64_t nmn_engine_count_entities_with_embeddings(nmn_engine* e);
 /* search_entities (lib.rs:3155-3219): cosine TOP-K over every entity that has an embedding */
 nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, nmn_results** out);
+
+/* ---- index persistence (lib.rs:500-623, 3733-4000) ------------------------------------------------- */
+/* `collection`: VectorEngine::DEFAULT_COLLECTION = "default" for the non-collection embeddings.
+ * save_index / load_index: PersistentVectorIndex as serde_json writes it (either side reads the other's file).
+ * save_index_binary / load_index_binary: the reference's second format is bitcode (an absent third-party crate's
+ * bit-packed encoding); the binary format here is this library's own — the same snapshot with the vectors as flat
+ * shard sections (include/neumann_gpu.h "persistence of the device layout"): a load is bulk reads + H2D copies, the
+ * GPU mirror is rebuilt at once and every row's device-computed magnitude is checked against the stored one.
+ * Loads apply max_index_file_bytes before reading and max_index_entries after decoding (ConfigurationError,
+ * "index file size {} exceeds limit {}" / "index entry count {} exceeds limit {}").  name_out (nullable) receives the
+ * collection's name, NUL-terminated, truncated to name_cap - 1 bytes. */
+nmn_status nmn_engine_save_index(nmn_engine* e, const char* collection, const char* path);                 /* 3794-3801 */
+nmn_status nmn_engine_load_index(nmn_engine* e, const char* path, char* name_out, uint64_t name_cap);      /* 3827-3866 */
+nmn_status nmn_engine_save_index_binary(nmn_engine* e, const char* collection, const char* path);          /* 3811-3817 */
+nmn_status nmn_engine_load_index_binary(nmn_engine* e, const char* path, char* name_out, uint64_t name_cap); /* 3868-3899 */
+nmn_strlist* nmn_engine_save_all_indices(nmn_engine* e, const char* dir, nmn_status* status);              /* 3944-3971 */
+nmn_strlist* nmn_engine_load_all_indices(nmn_engine* e, const char* dir, nmn_status* status);              /* 3980-3999 */
+/* The (IVFIndex, key_mapping) pair of build_ivf_index with its trained centroids and lists: a restart restores it
+ * without k-means (the reference rebuilds: lib.rs:2641-2694). */
+nmn_status nmn_engine_ivf_save(nmn_engine_ivf* ivf, const char* path);
+nmn_status nmn_engine_ivf_load(nmn_engine* e, const char* path, nmn_engine_ivf** out);
 
 /* count_matching / estimate_filter_selectivity (lib.rs:3698-3722) */
 uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f);

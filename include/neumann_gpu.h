@@ -39,6 +39,8 @@ typedef int32_t nmn_status;
 #define NMN_ERR_COLLECTION_EXISTS (-7)    /* VectorError::CollectionExists    */
 #define NMN_ERR_COLLECTION_NOT_FOUND (-8) /* VectorError::CollectionNotFound  */
 #define NMN_ERR_SEARCH_TIMEOUT (-9)       /* VectorError::SearchTimeout       */
+#define NMN_ERR_IO (-10)                  /* VectorError::IoError             (index files: open / read / write) */
+#define NMN_ERR_SERIALIZATION (-11)       /* VectorError::SerializationError  (index files: not decodable / corrupt) */
 /* Shim-only codes (no VectorError counterpart). */
 #define NMN_ERR_INVALID_ARGUMENT (-20)
 #define NMN_ERR_NO_DEVICE (-21)
@@ -438,6 +440,28 @@ nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_t nq, uint3
                           uint64_t* out_ids, float* out_distances, uint32_t* out_counts, nmn_search_stats* stats);
 /* The flat index holding the vectors (exhaustive search over the same rows, stats, ...). */
 nmn_index* nmn_ivf_vectors(nmn_ivf* ivf);
+
+/* ---- persistence of the device layout ----------------------------------- */
+
+/* The reference persists a collection as PersistentVectorIndex — (key, vector, metadata) entries in JSON or bitcode —
+ * and guards every load with VectorEngineConfig::max_index_file_bytes / max_index_entries (vector_engine/src/lib.rs:
+ * 509-531, 644-646, 660-661, 3794-3899).  These entry points persist what the GPU path adds to that: the matrix of a
+ * shard as it sits in HBM.  File: 64-byte header | rows x dim f32 (row stride removed) | rows f32 magnitudes.  A load
+ * is sequential reads + bulk H2D copies; the magnitudes the upload recomputes on the GPU (reference order) must equal
+ * the stored ones bit for bit, which is the file's integrity check.  The bf16 mirror is re-derived on first search.
+ *   overrides   nullable: device, capacity_rows (>= the file's rows; spare room for appends), flags, cand_cap,
+ *               row_base (0 = keep the file's); dim 0 or equal to the file's (else NMN_ERR_DIMENSION_MISMATCH)
+ *   max_file_bytes / max_entries   0 = no limit; otherwise the reference's checks, in its order (file size before
+ *               reading, entry count after the header) and with its texts: NMN_ERR_CONFIGURATION
+ *               "index file size {} exceeds limit {}" / "index entry count {} exceeds limit {}". */
+nmn_status nmn_index_save(nmn_index* idx, const char* path);
+nmn_status nmn_index_load(const char* path, const nmn_index_desc* overrides, uint64_t max_file_bytes,
+                          uint64_t max_entries, nmn_index** out);
+/* The same for an IVF index: trained centroids, the list of every vector (`assign[]`) and the vectors in id order, so a
+ * restart neither re-runs k-means (tensor_store/src/ivf.rs:222-233) nor re-assigns a single vector. */
+nmn_status nmn_ivf_save(nmn_ivf* ivf, const char* path);
+nmn_status nmn_ivf_load(const char* path, const nmn_index_desc* overrides, uint64_t max_file_bytes, uint64_t max_entries,
+                        nmn_ivf** out);
 
 /* ---- synthetic data (bench / tests) ------------------------------------------------------- */
 

@@ -20,6 +20,8 @@ ERR_CONFIGURATION = -6
 ERR_COLLECTION_EXISTS = -7
 ERR_COLLECTION_NOT_FOUND = -8
 ERR_SEARCH_TIMEOUT = -9
+ERR_IO = -10
+ERR_SERIALIZATION = -11
 ERR_INVALID_ARGUMENT = -20
 ERR_NO_DEVICE = -21
 ERR_OUT_OF_MEMORY = -22
@@ -139,6 +141,10 @@ SIGNATURES = {
     "nmn_ivf_cluster_sizes": (C.c_int32, [vp, vp]),
     "nmn_ivf_search": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(SearchStats)]),
     "nmn_ivf_vectors": (vp, [vp]),
+    "nmn_index_save": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_index_load": (C.c_int32, [C.c_char_p, C.POINTER(IndexDesc), C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_ivf_save": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_ivf_load": (C.c_int32, [C.c_char_p, C.POINTER(IndexDesc), C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "nmn_sharded_create": (C.c_int32, [C.POINTER(ShardedDesc), C.POINTER(vp)]),
     "nmn_sharded_destroy": (C.c_int32, [vp]),
     "nmn_sharded_upload": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64]),

@@ -30,9 +30,10 @@ SOURCES = {
     "nmn_kmeans.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_api.hip": [],
     "nmn_sharded.hip": [],
+    "nmn_persist.hip": [],
     "nmn_engine.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["nmn_internal.h", "nmn_index.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
+HEADERS = ["nmn_internal.h", "nmn_index.h", "nmn_persist.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
            os.path.join("..", "..", "include", "neumann_engine.h")]
 
 

@@ -335,6 +335,8 @@ extern "C" const char* nmn_status_str(nmn_status s) {
         case NMN_ERR_COLLECTION_EXISTS: return "Collection already exists";
         case NMN_ERR_COLLECTION_NOT_FOUND: return "Collection not found";
         case NMN_ERR_SEARCH_TIMEOUT: return "search timeout";
+        case NMN_ERR_IO: return "IO error";
+        case NMN_ERR_SERIALIZATION: return "Serialization error";
         case NMN_ERR_INVALID_ARGUMENT: return "invalid argument";
         case NMN_ERR_NO_DEVICE: return "no usable HIP device (libneumann_gpu has no CPU fallback)";
         case NMN_ERR_OUT_OF_MEMORY: return "out of device memory";

@@ -27,6 +27,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dirent.h>
+#include <sys/stat.h>
+
 #include "../../include/neumann_engine.h"
 
 namespace {
@@ -259,9 +262,11 @@ struct Collection {
     void invalidate() { mirrors.clear(); }  // full drop (delete_collection / clear)
 };
 
-struct CollectionConfig {
+struct CollectionConfig {  // VectorCollectionConfig (lib.rs:455-475)
     uint64_t dimension = 0;  // 0 = None
     int32_t metric = NMN_METRIC_COSINE;
+    bool auto_index = false;               // HNSW auto-indexing: carried through index files, not acted on (CPU structure)
+    uint64_t auto_index_threshold = 1000;
 };
 
 struct Deadline {  // lib.rs:216-249
@@ -1002,6 +1007,8 @@ void nmn_engine_config_default(nmn_engine_config* c) {  // lib.rs:648-664
     c->search_timeout_ms = -1;
     c->device = -1;
     c->cand_cap = 0;
+    c->max_index_file_bytes = 100ll * 1024 * 1024;  // lib.rs:660
+    c->max_index_entries = 1000000;                 // lib.rs:661
 }
 
 void nmn_filtered_config_default(nmn_filtered_config* c) {  // lib.rs:412-420
@@ -1027,6 +1034,14 @@ nmn_status nmn_engine_create(const nmn_engine_config* config, nmn_engine** out) 
     if (e->cfg.parallel_threshold == 0) {
         delete e;
         return fail(NMN_ERR_CONFIGURATION, "Configuration error: parallel_threshold must be greater than 0");
+    }
+    if (e->cfg.max_index_file_bytes == 0) {  // lib.rs:740-746
+        delete e;
+        return fail(NMN_ERR_CONFIGURATION, "Configuration error: max_index_file_bytes must be greater than 0");
+    }
+    if (e->cfg.max_index_entries == 0) {  // lib.rs:747-753
+        delete e;
+        return fail(NMN_ERR_CONFIGURATION, "Configuration error: max_index_entries must be greater than 0");
     }
     *out = e;
     return NMN_OK;
@@ -1768,7 +1783,10 @@ nmn_status nmn_engine_create_collection(nmn_engine* e, const char* name, uint64_
     if (!e || !name) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
     WriteLock g(e);
     if (e->configs.count(name)) return fail(NMN_ERR_COLLECTION_EXISTS, std::string("Collection already exists: ") + name);
-    e->configs[name] = CollectionConfig{dimension, metric};
+    CollectionConfig cc;
+    cc.dimension = dimension;
+    cc.metric = metric;
+    e->configs[name] = cc;
     return NMN_OK;
 }
 
@@ -2042,6 +2060,799 @@ int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll) {
     WriteLock g(e);
     Collection* c = e->storage(coll, false);
     return (c && !c->mirrors.empty()) ? 1 : 0;
+}
+
+
+// ---- index persistence (lib.rs:500-623, 3733-4000) --------------------------------------------------------------------------
+// save_index / load_index: PersistentVectorIndex { collection, config, vectors: [{key, vector, metadata}], created_at,
+// version } as serde_json writes it (externally tagged MetadataValue: "Null", {"Bool": b}, {"Int": i}, {"Float": f},
+// {"String": s}; DistanceMetric as "Cosine" / "Euclidean" / "DotProduct"; Option::None as null) — a file either side can
+// read.  save_index_binary / load_index_binary: the reference's second format is bitcode, an undocumented bit-packed
+// encoding of an absent third-party crate; the binary format here is this library's own (nmn_persist.h): the same
+// snapshot with the vectors as flat shard sections — the matrix as the GPU mirror holds it, magnitudes included — so a
+// load is sequential reads + bulk H2D copies, and the mirror is rebuilt (and checked against the stored magnitudes) at
+// once instead of on the first search.  Both loads apply max_index_file_bytes BEFORE reading and max_index_entries after
+// decoding, with the reference's texts (lib.rs:3831-3856).
+}  // extern "C"
+
+#include "nmn_persist.h"
+
+namespace {
+
+constexpr const char* kDefaultCollection = "default";  // VectorEngine::DEFAULT_COLLECTION (lib.rs:1359)
+constexpr uint32_t kPersistVersion = 1;                // PersistentVectorIndex::CURRENT_VERSION (lib.rs:579)
+
+nmn_status err_serialization(const std::string& what) { return fail(NMN_ERR_SERIALIZATION, "Serialization error: " + what); }
+nmn_status err_io(const std::string& what) { return fail(NMN_ERR_IO, "IO error: " + what); }
+nmn_status err_config(const std::string& what) { return fail(NMN_ERR_CONFIGURATION, "Configuration error: " + what); }
+
+// ---- a small JSON reader / writer: exactly what serde_json's output of PersistentVectorIndex needs ---------------------
+struct JVal {
+    enum T { Null, Bool, Num, Str, Arr, Obj } t = Null;
+    bool b = false;
+    bool is_int = false;  // the number token had no fraction / exponent and fits i64
+    int64_t i = 0;
+    double d = 0.0;
+    std::string s;
+    std::vector<double> nums;                          // an array of numbers only (a vector): kept flat
+    std::vector<JVal> arr;                             // any other array
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* get(const char* k) const {
+        for (auto& kv : obj)
+            if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char* p;
+    const char* end;
+    std::string err;
+    bool fail_at(const char* what) {
+        if (err.empty()) err = std::string(what) + " at byte " + std::to_string((size_t)(p - begin));
+        return false;
+    }
+    const char* begin;
+    JParser(const char* b, size_t n) : p(b), end(b + n), begin(b) {}
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++;
+    }
+    bool lit(const char* w) {
+        const size_t n = strlen(w);
+        if ((size_t)(end - p) < n || memcmp(p, w, n) != 0) return fail_at("invalid literal");
+        p += n;
+        return true;
+    }
+    static void utf8(std::string& o, uint32_t c) {
+        if (c < 0x80) o += (char)c;
+        else if (c < 0x800) { o += (char)(0xC0 | (c >> 6)); o += (char)(0x80 | (c & 0x3F)); }
+        else if (c < 0x10000) { o += (char)(0xE0 | (c >> 12)); o += (char)(0x80 | ((c >> 6) & 0x3F)); o += (char)(0x80 | (c & 0x3F)); }
+        else { o += (char)(0xF0 | (c >> 18)); o += (char)(0x80 | ((c >> 12) & 0x3F)); o += (char)(0x80 | ((c >> 6) & 0x3F)); o += (char)(0x80 | (c & 0x3F)); }
+    }
+    bool hex4(uint32_t* out) {
+        if (end - p < 4) return fail_at("bad \\u escape");
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char c = p[k];
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= (uint32_t)(c - '0');
+            else if (c >= 'a' && c <= 'f') v |= (uint32_t)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') v |= (uint32_t)(c - 'A' + 10);
+            else return fail_at("bad \\u escape");
+        }
+        p += 4;
+        *out = v;
+        return true;
+    }
+    bool str(std::string* o) {
+        if (p >= end || *p != '"') return fail_at("expected string");
+        p++;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return fail_at("bad escape");
+                const char c = *p++;
+                switch (c) {
+                    case '"': *o += '"'; break;
+                    case '\\': *o += '\\'; break;
+                    case '/': *o += '/'; break;
+                    case 'b': *o += '\b'; break;
+                    case 'f': *o += '\f'; break;
+                    case 'n': *o += '\n'; break;
+                    case 'r': *o += '\r'; break;
+                    case 't': *o += '\t'; break;
+                    case 'u': {
+                        uint32_t c1;
+                        if (!hex4(&c1)) return false;
+                        if (c1 >= 0xD800 && c1 < 0xDC00 && end - p >= 6 && p[0] == '\\' && p[1] == 'u') {
+                            p += 2;
+                            uint32_t c2;
+                            if (!hex4(&c2)) return false;
+                            c1 = 0x10000 + ((c1 - 0xD800) << 10) + (c2 - 0xDC00);
+                        }
+                        utf8(*o, c1);
+                        break;
+                    }
+                    default: return fail_at("bad escape");
+                }
+            } else {
+                *o += *p++;
+            }
+        }
+        if (p >= end) return fail_at("unterminated string");
+        p++;
+        return true;
+    }
+    bool num(JVal* v) {
+        const char* s0 = p;
+        bool integral = true;
+        if (p < end && *p == '-') p++;
+        while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) {
+            if (*p == '.' || *p == 'e' || *p == 'E') integral = false;
+            p++;
+        }
+        if (p == s0) return fail_at("expected value");
+        const std::string tok(s0, p);
+        char* e2 = nullptr;
+        v->t = JVal::Num;
+        v->d = strtod(tok.c_str(), &e2);
+        if (!e2 || *e2) return fail_at("bad number");
+        if (integral) {
+            errno = 0;
+            const long long ll = strtoll(tok.c_str(), &e2, 10);
+            if (errno == 0 && e2 && !*e2) {
+                v->is_int = true;
+                v->i = ll;
+            }
+        }
+        return true;
+    }
+    bool value(JVal* v, int depth) {
+        if (depth > 64) return fail_at("nesting too deep");
+        ws();
+        if (p >= end) return fail_at("unexpected end");
+        switch (*p) {
+            case '{': {
+                v->t = JVal::Obj;
+                p++;
+                ws();
+                if (p < end && *p == '}') { p++; return true; }
+                for (;;) {
+                    ws();
+                    std::string k;
+                    if (!str(&k)) return false;
+                    ws();
+                    if (p >= end || *p != ':') return fail_at("expected ':'");
+                    p++;
+                    v->obj.emplace_back(std::move(k), JVal());
+                    if (!value(&v->obj.back().second, depth + 1)) return false;
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == '}') { p++; return true; }
+                    return fail_at("expected ',' or '}'");
+                }
+            }
+            case '[': {
+                v->t = JVal::Arr;
+                p++;
+                ws();
+                if (p < end && *p == ']') { p++; return true; }
+                bool flat = true;  // numbers only so far: stays in `nums`
+                for (;;) {
+                    ws();
+                    const bool numeric = p < end && (*p == '-' || (*p >= '0' && *p <= '9'));
+                    if (flat && numeric) {
+                        JVal n;
+                        if (!num(&n)) return false;
+                        v->nums.push_back(n.d);
+                    } else {
+                        if (flat) {  // first non-number: move what we have into the general form
+                            for (double d : v->nums) {
+                                JVal n;
+                                n.t = JVal::Num;
+                                n.d = d;
+                                v->arr.push_back(std::move(n));
+                            }
+                            v->nums.clear();
+                            flat = false;
+                        }
+                        v->arr.emplace_back();
+                        if (!value(&v->arr.back(), depth + 1)) return false;
+                    }
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == ']') { p++; return true; }
+                    return fail_at("expected ',' or ']'");
+                }
+            }
+            case '"': v->t = JVal::Str; return str(&v->s);
+            case 't': v->t = JVal::Bool; v->b = true; return lit("true");
+            case 'f': v->t = JVal::Bool; v->b = false; return lit("false");
+            case 'n': v->t = JVal::Null; return lit("null");
+            default: return num(v);
+        }
+    }
+};
+
+void json_str(std::string& o, const std::string& s) {
+    o += '"';
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            default:
+                if (c < 0x20) {
+                    char b[8];
+                    snprintf(b, sizeof b, "\\u%04x", c);
+                    o += b;
+                } else {
+                    o += (char)c;
+                }
+        }
+    }
+    o += '"';
+}
+// shortest decimal that reads back as the same value (what serde_json's ryu prints), always with a fraction or exponent;
+// non-finite values become null as serde_json writes them
+void json_f32(std::string& o, float v) {
+    if (!std::isfinite(v)) { o += "null"; return; }
+    char b[40];
+    for (int prec = 1; prec <= 9; prec++) {
+        snprintf(b, sizeof b, "%.*g", prec, (double)v);
+        if (strtof(b, nullptr) == v) break;
+    }
+    o += b;
+    if (!strpbrk(b, ".eE")) o += ".0";
+}
+void json_f64(std::string& o, double v) {
+    if (!std::isfinite(v)) { o += "null"; return; }
+    char b[48];
+    for (int prec = 1; prec <= 17; prec++) {
+        snprintf(b, sizeof b, "%.*g", prec, v);
+        if (strtod(b, nullptr) == v) break;
+    }
+    o += b;
+    if (!strpbrk(b, ".eE")) o += ".0";
+}
+const char* metric_name(int32_t m) {
+    return m == NMN_METRIC_EUCLIDEAN ? "Euclidean" : m == NMN_METRIC_DOT_PRODUCT ? "DotProduct" : "Cosine";
+}
+bool metric_from(const std::string& s, int32_t* m) {
+    if (s == "Cosine") *m = NMN_METRIC_COSINE;
+    else if (s == "Euclidean") *m = NMN_METRIC_EUCLIDEAN;
+    else if (s == "DotProduct") *m = NMN_METRIC_DOT_PRODUCT;
+    else return false;
+    return true;
+}
+void json_meta_value(std::string& o, const Value& v) {  // MetadataValue, externally tagged (lib.rs:534-546)
+    switch (v.kind) {
+        case NMN_VAL_BOOL: o += v.b ? "{\"Bool\": true}" : "{\"Bool\": false}"; break;
+        case NMN_VAL_INT: o += "{\"Int\": " + std::to_string(v.i) + "}"; break;
+        case NMN_VAL_FLOAT: o += "{\"Float\": "; json_f64(o, v.f); o += "}"; break;
+        case NMN_VAL_STRING: o += "{\"String\": "; json_str(o, v.s); o += "}"; break;
+        default: o += "\"Null\""; break;
+    }
+}
+bool meta_value_from(const JVal& j, Value* out) {
+    if (j.t == JVal::Str && j.s == "Null") { out->kind = NMN_VAL_NULL; return true; }
+    if (j.t != JVal::Obj || j.obj.size() != 1) return false;
+    const std::string& tag = j.obj[0].first;
+    const JVal& x = j.obj[0].second;
+    if (tag == "Bool" && x.t == JVal::Bool) { out->kind = NMN_VAL_BOOL; out->b = x.b; return true; }
+    if (tag == "Int" && x.t == JVal::Num && x.is_int) { out->kind = NMN_VAL_INT; out->i = x.i; return true; }
+    if (tag == "Float" && x.t == JVal::Num) { out->kind = NMN_VAL_FLOAT; out->f = x.d; return true; }
+    if (tag == "Float" && x.t == JVal::Null) { out->kind = NMN_VAL_FLOAT; out->f = std::nan(""); return true; }
+    if (tag == "String" && x.t == JVal::Str) { out->kind = NMN_VAL_STRING; out->s = x.s; return true; }
+    return false;
+}
+
+// snapshot_collection (lib.rs:3738-3784): the live entries of one collection, in storage order
+struct Snapshot {
+    std::string collection;
+    CollectionConfig config;
+    bool has_config = false;
+    uint64_t created_at = 0;
+    std::vector<const Entry*> entries;
+};
+Snapshot snapshot_collection(nmn_engine* e, const char* collection) {
+    Snapshot s;
+    s.collection = collection;
+    const bool is_default = s.collection == kDefaultCollection;
+    auto cit = e->configs.find(s.collection);
+    if (!is_default && cit != e->configs.end()) {  // get_collection_config(..).unwrap_or_default()
+        s.config = cit->second;
+        s.has_config = true;
+    }
+    s.created_at = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    Collection* c = is_default ? &e->dflt : e->storage(collection, false);
+    if (c)
+        for (const Entry& ent : c->slots)
+            if (ent.live) s.entries.push_back(&ent);
+    return s;
+}
+void json_header(std::string& o, const Snapshot& s) {
+    o += "{\n  \"collection\": ";
+    json_str(o, s.collection);
+    o += ",\n  \"config\": {\n    \"dimension\": ";
+    o += s.config.dimension ? std::to_string(s.config.dimension) : "null";
+    o += ",\n    \"distance_metric\": \"";
+    o += metric_name(s.config.metric);
+    o += "\",\n    \"auto_index\": ";
+    o += s.config.auto_index ? "true" : "false";
+    o += ",\n    \"auto_index_threshold\": " + std::to_string(s.config.auto_index_threshold) + "\n  },\n";
+}
+void json_metadata(std::string& o, const Meta& m, const char* indent) {
+    if (m.empty()) { o += "null"; return; }  // `if metadata.is_empty() { None }`
+    o += "{";
+    bool first = true;
+    for (auto& kv : m) {
+        o += first ? "\n" : ",\n";
+        first = false;
+        o += indent;
+        o += "  ";
+        json_str(o, kv.first);
+        o += ": ";
+        json_meta_value(o, kv.second);
+    }
+    o += "\n";
+    o += indent;
+    o += "}";
+}
+
+nmn_status write_file(const char* path, const std::string& bytes) {
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return err_io(std::string("cannot create '") + path + "': " + strerror(errno));
+    const bool ok = fwrite(bytes.data(), 1, bytes.size(), fp) == bytes.size();
+    if (fclose(fp) != 0 || !ok) return err_io(std::string("cannot write '") + path + "': " + strerror(errno));
+    return NMN_OK;
+}
+
+// decoded PersistentVectorIndex, before it is restored
+struct Decoded {
+    std::string collection;
+    CollectionConfig config;
+    struct Ent {
+        std::string key;
+        std::vector<float> vec;
+        Meta meta;
+    };
+    std::vector<Ent> entries;
+};
+bool decode_config(const JVal* cfg, CollectionConfig* out, std::string* why) {
+    if (!cfg || cfg->t != JVal::Obj) { *why = "missing field `config`"; return false; }
+    const JVal* d = cfg->get("dimension");
+    const JVal* m = cfg->get("distance_metric");
+    if (!d || !m) { *why = "missing field in `config`"; return false; }
+    if (d->t == JVal::Null) out->dimension = 0;
+    else if (d->t == JVal::Num && d->is_int && d->i >= 0) out->dimension = (uint64_t)d->i;
+    else { *why = "invalid `dimension`"; return false; }
+    if (m->t != JVal::Str || !metric_from(m->s, &out->metric)) { *why = "unknown variant of DistanceMetric"; return false; }
+    const JVal* ai = cfg->get("auto_index");
+    const JVal* at = cfg->get("auto_index_threshold");
+    if (!ai || ai->t != JVal::Bool || !at || at->t != JVal::Num || !at->is_int || at->i < 0) { *why = "missing field in `config`"; return false; }
+    out->auto_index = ai->b;
+    out->auto_index_threshold = (uint64_t)at->i;
+    return true;
+}
+bool decode_metadata(const JVal* mj, Meta* out, std::string* why) {
+    if (!mj || mj->t == JVal::Null) return true;
+    if (mj->t != JVal::Obj) { *why = "invalid `metadata`"; return false; }
+    for (auto& kv : mj->obj) {
+        Value v;
+        if (!meta_value_from(kv.second, &v)) { *why = "invalid MetadataValue for `" + kv.first + "`"; return false; }
+        (*out)[kv.first] = v;
+    }
+    return true;
+}
+
+// restore_from_index (lib.rs:3902-3934): collection config (named collections), then every entry through the ordinary
+// store path — the same validation (EmptyVector, collection dimension, max_dimension) and the same overwrite semantics
+nmn_status restore_from_index(nmn_engine* e, Decoded& d) {
+    const bool is_default = d.collection == kDefaultCollection;
+    if (!is_default) e->configs[d.collection] = d.config;
+    Collection* c = is_default ? &e->dflt : e->storage(d.collection.c_str(), true);
+    for (auto& ent : d.entries) {
+        if (ent.vec.empty()) return err_empty();
+        if (!is_default && d.config.dimension && ent.vec.size() != d.config.dimension) return err_dim(d.config.dimension, ent.vec.size());
+        if (e->cfg.max_dimension && ent.vec.size() > e->cfg.max_dimension) return err_dim(e->cfg.max_dimension, ent.vec.size());
+        std::vector<nmn_meta_field> mf;
+        mf.reserve(ent.meta.size());
+        for (auto& kv : ent.meta) {
+            nmn_meta_field f{};
+            f.name = kv.first.c_str();
+            f.value.kind = kv.second.kind;
+            f.value.b = kv.second.b ? 1 : 0;
+            f.value.i = kv.second.i;
+            f.value.f = kv.second.f;
+            f.value.s = kv.second.s.c_str();
+            mf.push_back(f);
+        }
+        nmn_status st = store_into(e, c, ent.key.c_str(), ent.vec.data(), ent.vec.size(), mf.data(), (uint32_t)mf.size());
+        if (st != NMN_OK) return st;
+    }
+    return NMN_OK;
+}
+
+nmn_status check_file_limit(nmn_engine* e, const char* path) {  // lib.rs:3831-3840
+    const nmn_status st = nmn::persist_check_file_size(path, e->cfg.max_index_file_bytes > 0 ? (uint64_t)e->cfg.max_index_file_bytes : 0, nullptr);
+    if (st == NMN_ERR_CONFIGURATION) return err_config(nmn_last_error());
+    if (st != NMN_OK) return err_io(nmn_last_error());
+    return NMN_OK;
+}
+nmn_status check_entry_limit(nmn_engine* e, uint64_t n) {  // lib.rs:3847-3856
+    if (e->cfg.max_index_entries > 0 && n > (uint64_t)e->cfg.max_index_entries)
+        return err_config("index entry count " + std::to_string(n) + " exceeds limit " + std::to_string(e->cfg.max_index_entries));
+    return NMN_OK;
+}
+void copy_name(const std::string& s, char* out, uint64_t cap) {
+    if (!out || !cap) return;
+    const size_t n = std::min<size_t>(s.size(), cap - 1);
+    memcpy(out, s.data(), n);
+    out[n] = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// save_index (lib.rs:3794-3801)
+nmn_status nmn_engine_save_index(nmn_engine* e, const char* collection, const char* path) {
+    if (!e || !collection || !path) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::string o;
+    {
+        WriteLock g(e);
+        const Snapshot s = snapshot_collection(e, collection);
+        json_header(o, s);
+        o += "  \"vectors\": [";
+        bool first = true;
+        for (const Entry* ent : s.entries) {
+            o += first ? "\n" : ",\n";
+            first = false;
+            o += "    {\n      \"key\": ";
+            json_str(o, ent->key);
+            o += ",\n      \"vector\": [";
+            for (size_t i = 0; i < ent->vec.size(); i++) {
+                o += i ? ",\n        " : "\n        ";
+                json_f32(o, ent->vec[i]);
+            }
+            o += ent->vec.empty() ? "]" : "\n      ]";
+            o += ",\n      \"metadata\": ";
+            json_metadata(o, ent->meta, "      ");
+            o += "\n    }";
+        }
+        o += s.entries.empty() ? "]" : "\n  ]";
+        o += ",\n  \"created_at\": " + std::to_string(s.created_at) + ",\n  \"version\": " + std::to_string(kPersistVersion) + "\n}";
+    }
+    return write_file(path, o);
+}
+
+// load_index (lib.rs:3827-3866); the collection's name goes to name_out (truncated to cap - 1 bytes)
+nmn_status nmn_engine_load_index(nmn_engine* e, const char* path, char* name_out, uint64_t name_cap) {
+    if (!e || !path) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    nmn_status st = check_file_limit(e, path);
+    if (st != NMN_OK) return st;
+    std::string text;
+    {
+        FILE* fp = fopen(path, "rb");
+        if (!fp) return err_io(std::string("cannot open '") + path + "': " + strerror(errno));
+        char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
+        fclose(fp);
+    }
+    JVal root;
+    JParser jp(text.data(), text.size());
+    if (!jp.value(&root, 0)) return err_serialization(jp.err);
+    jp.ws();
+    if (jp.p != jp.end) return err_serialization("trailing characters");
+    if (root.t != JVal::Obj) return err_serialization("invalid type: expected struct PersistentVectorIndex");
+    Decoded d;
+    const JVal* jc = root.get("collection");
+    const JVal* jv = root.get("vectors");
+    if (!jc || jc->t != JVal::Str) return err_serialization("missing field `collection`");
+    if (!jv || jv->t != JVal::Arr) return err_serialization("missing field `vectors`");
+    if (!root.get("created_at") || !root.get("version")) return err_serialization("missing field `created_at` / `version`");
+    d.collection = jc->s;
+    std::string why;
+    if (!decode_config(root.get("config"), &d.config, &why)) return err_serialization(why);
+    if (!jv->nums.empty()) return err_serialization("invalid type in `vectors`");
+    d.entries.resize(jv->arr.size());
+    for (size_t i = 0; i < jv->arr.size(); i++) {
+        const JVal& je = jv->arr[i];
+        const JVal* k = je.t == JVal::Obj ? je.get("key") : nullptr;
+        const JVal* v = je.t == JVal::Obj ? je.get("vector") : nullptr;
+        if (!k || k->t != JVal::Str || !v || v->t != JVal::Arr || !v->arr.empty()) return err_serialization("invalid VectorEntry");
+        d.entries[i].key = k->s;
+        d.entries[i].vec.resize(v->nums.size());
+        for (size_t x = 0; x < v->nums.size(); x++) d.entries[i].vec[x] = (float)v->nums[x];  // f64 token -> `as f32`
+        if (!decode_metadata(je.get("metadata"), &d.entries[i].meta, &why)) return err_serialization(why);
+    }
+    st = check_entry_limit(e, d.entries.size());
+    if (st != NMN_OK) return st;
+    WriteLock g(e);
+    st = restore_from_index(e, d);
+    if (st == NMN_OK) copy_name(d.collection, name_out, name_cap);
+    return st;
+}
+
+// save_index_binary (lib.rs:3811-3817), in this library's own format (see the section comment):
+// Header{kind = engine, rows = entries, aux = bytes of the text block} | text block = the JSON snapshot with every
+// "vector" replaced by its "dim" | one flat shard section per distinct dimension, ascending, rows in entry order
+nmn_status nmn_engine_save_index_binary(nmn_engine* e, const char* collection, const char* path) {
+    if (!e || !collection || !path) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    WriteLock g(e);
+    const Snapshot s = snapshot_collection(e, collection);
+    std::string o;
+    json_header(o, s);
+    o += "  \"vectors\": [";
+    std::map<uint64_t, std::vector<const Entry*>> by_dim;
+    bool first = true;
+    for (const Entry* ent : s.entries) {
+        o += first ? "\n" : ",\n";
+        first = false;
+        o += "    {\"key\": ";
+        json_str(o, ent->key);
+        o += ", \"dim\": " + std::to_string(ent->vec.size()) + ", \"metadata\": ";
+        json_metadata(o, ent->meta, "    ");
+        o += "}";
+        by_dim[ent->vec.size()].push_back(ent);
+    }
+    o += s.entries.empty() ? "]" : "\n  ]";
+    o += ",\n  \"created_at\": " + std::to_string(s.created_at) + ",\n  \"version\": " + std::to_string(kPersistVersion) + "\n}";
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return err_io(std::string("cannot create '") + path + "': " + strerror(errno));
+    nmn::PersistHeader h{};
+    memcpy(h.magic, "NMNIDX\0\1", 8);
+    h.version = 1;
+    h.kind = nmn::kPersistEngine;
+    h.rows = s.entries.size();
+    h.aux = o.size();
+    h.reserved = by_dim.size();
+    nmn_status st = NMN_OK;
+    if (fwrite(&h, sizeof h, 1, fp) != 1 || fwrite(o.data(), 1, o.size(), fp) != o.size()) st = err_io(std::string("cannot write '") + path + "'");
+    std::vector<float> rows, norms;
+    for (auto& kv : by_dim) {
+        if (st != NMN_OK) break;
+        const uint64_t dim = kv.first, n = kv.second.size();
+        if (dim > 0xFFFFFFFFull) { st = fail(NMN_ERR_INVALID_ARGUMENT, "dimension does not fit the index file"); break; }
+        rows.resize((size_t)n * dim);
+        norms.resize((size_t)n);
+        for (uint64_t r = 0; r < n; r++) {
+            memcpy(rows.data() + r * dim, kv.second[r]->vec.data(), dim * sizeof(float));
+            // simd::magnitude in reference order (hnsw.rs:198-229): the load compares it, bit for bit, with what the GPU
+            // computes from the same row — a per-row checksum that doubles as a host/device parity check
+            norms[r] = std::sqrt(sumsq8_host(kv.second[r]->vec.data(), dim));
+        }
+        if (nmn::persist_write_rows_host(fp, path, (uint32_t)dim, n, 0, rows.data(), norms.data()) != NMN_OK) st = err_io(nmn_last_error());
+    }
+    if (fclose(fp) != 0 && st == NMN_OK) st = err_io(std::string("cannot close '") + path + "'");
+    return st;
+}
+
+// load_index_binary (lib.rs:3868-3899)
+nmn_status nmn_engine_load_index_binary(nmn_engine* e, const char* path, char* name_out, uint64_t name_cap) {
+    if (!e || !path) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    nmn_status st = check_file_limit(e, path);
+    if (st != NMN_OK) return st;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return err_io(std::string("cannot open '") + path + "': " + strerror(errno));
+    struct Closer {
+        FILE* f;
+        ~Closer() { fclose(f); }
+    } closer{fp};
+    nmn::PersistHeader h{};
+    if (nmn::persist_read_header(fp, path, &h) != NMN_OK || h.kind != nmn::kPersistEngine) return err_serialization("not a neumann_gpu collection file");
+    st = check_entry_limit(e, h.rows);
+    if (st != NMN_OK) return st;
+    if (h.aux > (1ull << 40)) return err_serialization("text block too large");
+    std::string text((size_t)h.aux, '\0');
+    if (h.aux && fread(&text[0], 1, (size_t)h.aux, fp) != h.aux) return err_serialization("file truncated (text block)");
+    JVal root;
+    JParser jp(text.data(), text.size());
+    if (!jp.value(&root, 0) || root.t != JVal::Obj) return err_serialization(jp.err.empty() ? "invalid text block" : jp.err);
+    Decoded d;
+    const JVal* jc = root.get("collection");
+    const JVal* jv = root.get("vectors");
+    if (!jc || jc->t != JVal::Str || !jv || jv->t != JVal::Arr) return err_serialization("missing field `collection` / `vectors`");
+    d.collection = jc->s;
+    std::string why;
+    if (!decode_config(root.get("config"), &d.config, &why)) return err_serialization(why);
+    if (jv->arr.size() != h.rows) return err_serialization("entry count differs from the header");
+    d.entries.resize(jv->arr.size());
+    std::map<uint64_t, std::vector<size_t>> by_dim;
+    for (size_t i = 0; i < jv->arr.size(); i++) {
+        const JVal& je = jv->arr[i];
+        const JVal* k = je.t == JVal::Obj ? je.get("key") : nullptr;
+        const JVal* dj = je.t == JVal::Obj ? je.get("dim") : nullptr;
+        if (!k || k->t != JVal::Str || !dj || dj->t != JVal::Num || !dj->is_int || dj->i < 0) return err_serialization("invalid entry");
+        d.entries[i].key = k->s;
+        if (!decode_metadata(je.get("metadata"), &d.entries[i].meta, &why)) return err_serialization(why);
+        by_dim[(uint64_t)dj->i].push_back(i);
+    }
+    // the matrix sections, ascending dimension: rows go straight into the entries; magnitudes are kept for the check below
+    std::map<uint64_t, std::vector<float>> stored_norms;
+    std::vector<float> rows;
+    for (auto& kv : by_dim) {
+        nmn::PersistHeader hs{};
+        if (nmn::persist_read_header(fp, path, &hs) != NMN_OK) return err_serialization(nmn_last_error());
+        if (hs.dim != kv.first || hs.rows != kv.second.size()) return err_serialization("matrix section does not match the entries");
+        if (nmn::persist_read_rows_host(fp, hs, &rows, &stored_norms[kv.first]) != NMN_OK) return err_serialization(nmn_last_error());
+        for (size_t r = 0; r < kv.second.size(); r++)
+            d.entries[kv.second[r]].vec.assign(rows.begin() + r * kv.first, rows.begin() + (r + 1) * kv.first);
+    }
+    WriteLock g(e);
+    st = restore_from_index(e, d);
+    if (st != NMN_OK) return st;
+    // Rebuild the GPU mirrors now (a restart should not pay for it on the first query) and check the device layout against
+    // the file: the magnitude the GPU computed for every restored row must equal the stored one bit for bit.
+    const bool is_default = d.collection == kDefaultCollection;
+    Collection* c = is_default ? &e->dflt : e->storage(d.collection.c_str(), false);
+    for (auto& kv : by_dim) {
+        if (!c || kv.first == 0) continue;
+        Mirror* m = nullptr;
+        st = get_mirror(e, c, kv.first, &m);
+        if (st != NMN_OK) return st;
+        if (!m || !m->idx) continue;
+        const uint64_t n_rows = nmn_index_rows(m->idx);
+        std::vector<float> dev((size_t)n_rows);
+        // (device pointer of the magnitudes through the public accessor; one D2H)
+        if (n_rows && hipMemcpy(dev.data(), nmn_index_norms_device(m->idx), (size_t)n_rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(NMN_ERR_STORAGE, "Storage error: reading the magnitudes back");
+        const std::vector<float>& want = stored_norms[kv.first];
+        for (size_t r = 0; r < kv.second.size(); r++) {
+            auto it = c->by_key.find(d.entries[kv.second[r]].key);
+            if (it == c->by_key.end()) continue;
+            const Entry& ent = c->slots[it->second];
+            if (ent.mrow < 0 || (uint64_t)ent.mrow >= n_rows || ent.vec.size() != kv.first) continue;  // overwritten by a later duplicate key
+            uint32_t a, b;
+            memcpy(&a, &dev[(size_t)ent.mrow], 4);
+            memcpy(&b, &want[r], 4);
+            if (a != b && d.entries[kv.second[r]].vec == ent.vec)
+                return err_serialization("index file corrupt: magnitude of '" + ent.key + "' differs from the stored one");
+        }
+    }
+    copy_name(d.collection, name_out, name_cap);
+    return NMN_OK;
+}
+
+// save_all_indices (lib.rs:3944-3971): default.json + one {collection}.json per non-empty collection
+nmn_strlist* nmn_engine_save_all_indices(nmn_engine* e, const char* dir, nmn_status* status) {
+    nmn_status dummy;
+    if (!status) status = &dummy;
+    *status = NMN_OK;
+    if (!e || !dir) { *status = fail(NMN_ERR_INVALID_ARGUMENT, "null argument"); return nullptr; }
+    std::string cmd_dir = dir;
+    // fs::create_dir_all
+    for (size_t i = 1; i <= cmd_dir.size(); i++)
+        if (i == cmd_dir.size() || cmd_dir[i] == '/') {
+            const std::string part = cmd_dir.substr(0, i);
+            if (mkdir(part.c_str(), 0777) != 0 && errno != EEXIST) { *status = err_io("cannot create '" + part + "': " + strerror(errno)); return nullptr; }
+        }
+    auto* out = new (std::nothrow) nmn_strlist();
+    if (!out) { *status = fail(NMN_ERR_OUT_OF_MEMORY, "list alloc"); return nullptr; }
+    std::vector<std::string> names;
+    {
+        WriteLock g(e);
+        if (e->dflt.live > 0) names.push_back(kDefaultCollection);
+        for (auto& kv : e->configs) {  // list_collections(): the configured ones
+            Collection* c = e->storage(kv.first.c_str(), false);
+            if (c && c->live > 0) names.push_back(kv.first);
+        }
+    }
+    for (auto& n : names) {
+        const std::string path = cmd_dir + "/" + n + ".json";
+        *status = nmn_engine_save_index(e, n.c_str(), path.c_str());
+        if (*status != NMN_OK) { delete out; return nullptr; }
+        out->items.push_back(n);
+    }
+    return out;
+}
+
+// load_all_indices (lib.rs:3980-3999): every *.json of the directory; a file that fails to load is skipped
+nmn_strlist* nmn_engine_load_all_indices(nmn_engine* e, const char* dir, nmn_status* status) {
+    nmn_status dummy;
+    if (!status) status = &dummy;
+    *status = NMN_OK;
+    if (!e || !dir) { *status = fail(NMN_ERR_INVALID_ARGUMENT, "null argument"); return nullptr; }
+    DIR* dp = opendir(dir);
+    if (!dp) { *status = err_io(std::string("cannot read '") + dir + "': " + strerror(errno)); return nullptr; }
+    std::vector<std::string> files;
+    while (dirent* de = readdir(dp)) {
+        const std::string f = de->d_name;
+        if (f.size() > 5 && f.compare(f.size() - 5, 5, ".json") == 0) files.push_back(f);
+    }
+    closedir(dp);
+    std::sort(files.begin(), files.end());
+    auto* out = new (std::nothrow) nmn_strlist();
+    if (!out) { *status = fail(NMN_ERR_OUT_OF_MEMORY, "list alloc"); return nullptr; }
+    for (auto& f : files) {
+        char name[1024];
+        if (nmn_engine_load_index(e, (std::string(dir) + "/" + f).c_str(), name, sizeof name) == NMN_OK) out->items.push_back(name);
+    }
+    return out;
+}
+
+// (IVFIndex, key_mapping) of build_ivf_index, persisted: Header{kind = engine, aux = text bytes} | {"nprobe", "dim", "keys"}
+// | the IVF section (centroids, lists, vectors) — a restart restores the trained index without k-means
+nmn_status nmn_engine_ivf_save(nmn_engine_ivf* ivf, const char* path) {
+    if (!ivf || !path) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::string o = "{\"nprobe\": " + std::to_string(ivf->nprobe) + ", \"dim\": " + std::to_string(ivf->dim) + ", \"trained\": " +
+                    (ivf->index ? "true" : "false") + ", \"keys\": [";
+    for (size_t i = 0; i < ivf->keys.size(); i++) {
+        if (i) o += ", ";
+        json_str(o, ivf->keys[i]);
+    }
+    o += "]}";
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return err_io(std::string("cannot create '") + path + "': " + strerror(errno));
+    nmn::PersistHeader h{};
+    memcpy(h.magic, "NMNIDX\0\1", 8);
+    h.version = 1;
+    h.kind = nmn::kPersistEngine;
+    h.rows = ivf->keys.size();
+    h.aux = o.size();
+    h.flags = 1;  // an IVF index follows
+    nmn_status st = NMN_OK;
+    if (fwrite(&h, sizeof h, 1, fp) != 1 || fwrite(o.data(), 1, o.size(), fp) != o.size()) st = err_io(std::string("cannot write '") + path + "'");
+    if (st == NMN_OK && ivf->index && nmn::persist_write_ivf(ivf->index, fp, path) != NMN_OK) st = err_gpu(NMN_ERR_STORAGE);
+    if (fclose(fp) != 0 && st == NMN_OK) st = err_io(std::string("cannot close '") + path + "'");
+    return st;
+}
+
+nmn_status nmn_engine_ivf_load(nmn_engine* e, const char* path, nmn_engine_ivf** out) {
+    if (!e || !path || !out) return fail(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    nmn_status st = check_file_limit(e, path);
+    if (st != NMN_OK) return st;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return err_io(std::string("cannot open '") + path + "': " + strerror(errno));
+    struct Closer {
+        FILE* f;
+        ~Closer() { fclose(f); }
+    } closer{fp};
+    nmn::PersistHeader h{};
+    if (nmn::persist_read_header(fp, path, &h) != NMN_OK || h.kind != nmn::kPersistEngine || h.flags != 1)
+        return err_serialization("not a neumann_gpu IVF index file");
+    st = check_entry_limit(e, h.rows);
+    if (st != NMN_OK) return st;
+    if (h.aux > (1ull << 40)) return err_serialization("text block too large");
+    std::string text((size_t)h.aux, '\0');
+    if (h.aux && fread(&text[0], 1, (size_t)h.aux, fp) != h.aux) return err_serialization("file truncated (text block)");
+    JVal root;
+    JParser jp(text.data(), text.size());
+    if (!jp.value(&root, 0) || root.t != JVal::Obj) return err_serialization(jp.err.empty() ? "invalid text block" : jp.err);
+    const JVal* jn = root.get("nprobe");
+    const JVal* jd = root.get("dim");
+    const JVal* jt = root.get("trained");
+    const JVal* jk = root.get("keys");
+    if (!jn || !jn->is_int || !jd || !jd->is_int || !jt || jt->t != JVal::Bool || !jk || jk->t != JVal::Arr || !jk->nums.empty())
+        return err_serialization("invalid text block");
+    auto res = std::make_unique<nmn_engine_ivf>();
+    res->nprobe = (uint64_t)jn->i;
+    res->dim = (uint64_t)jd->i;
+    for (auto& k : jk->arr) {
+        if (k.t != JVal::Str) return err_serialization("invalid key");
+        res->keys.push_back(k.s);
+    }
+    if (res->keys.size() != h.rows) return err_serialization("key count differs from the header");
+    if (jt->b) {
+        nmn::PersistHeader hi{};
+        if (nmn::persist_read_header(fp, path, &hi) != NMN_OK) return err_serialization(nmn_last_error());
+        nmn_index_desc d{};
+        d.device = e->cfg.device;
+        d.cand_cap = e->cfg.cand_cap;
+        if (nmn::persist_read_ivf(fp, path, hi, &d, &res->index) != NMN_OK) return err_gpu(NMN_ERR_STORAGE);
+        if (nmn_ivf_len(res->index) != res->keys.size() || hi.dim != res->dim) return err_serialization("IVF section does not match the keys");
+        res->n_clusters = nmn_ivf_clusters(res->index);
+        res->centroids.resize((size_t)res->n_clusters * res->dim);
+        if (nmn_ivf_centroids(res->index, res->centroids.data(), res->centroids.size()) != NMN_OK) return err_gpu(NMN_ERR_STORAGE);
+    }
+    *out = res.release();
+    return NMN_OK;
 }
 
 }  // extern "C"

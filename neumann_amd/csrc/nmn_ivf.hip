@@ -729,3 +729,126 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
     }
     return NMN_OK;
 }
+
+// ---- persistence of the device layout ------------------------------------------------------------------
+// File = Header{kind = ivf, dim, rows = vectors, aux = clusters} | centroids clusters x dim f32 | assign[] rows x u32 | a flat
+// shard section (nmn_persist.hip) holding the vectors in id order.  A load re-creates the index WITHOUT re-running k-means or
+// the list assignment: centroids and lists come back exactly as saved (the reference rebuilds its IVF index from the
+// vectors after a restart; the trained centroids are the expensive part — tensor_store/src/ivf.rs:222-233).
+#include "nmn_persist.h"
+
+namespace nmn {
+nmn_status persist_write_ivf(nmn_ivf* ivf, FILE* fp, const char* path) {
+    std::unique_lock<std::shared_mutex> g(ivf->rw);
+    const uint64_t rows = ivf->vectors->rows;
+    std::vector<float> cents((size_t)ivf->n_clusters * ivf->dim);
+    IVF_TRY(hipSetDevice(ivf->device));
+    if (ivf->centroids_host.size() == cents.size()) cents = ivf->centroids_host;
+    else
+        IVF_TRY(hipMemcpy2D(cents.data(), (size_t)ivf->dim * 4, ivf->centroids->corpus, (size_t)ivf->centroids->ld * 4,
+                            (size_t)ivf->dim * 4, ivf->n_clusters, hipMemcpyDeviceToHost));
+    if (ivf->assign_host.size() < rows) return set_error(NMN_ERR_STORAGE, "IVF lists are not current");
+    PersistHeader h{};
+    memcpy(h.magic, "NMNIDX\0\1", 8);
+    h.version = 1;
+    h.kind = kPersistIvf;
+    h.dim = ivf->dim;
+    h.rows = rows;
+    h.aux = ivf->n_clusters;
+    if (fwrite(&h, sizeof h, 1, fp) != 1 || fwrite(cents.data(), 4, cents.size(), fp) != cents.size() ||
+        (rows && fwrite(ivf->assign_host.data(), 4, rows, fp) != rows))
+        return persist_io_error("cannot write", path);
+    return persist_write_shard(ivf->vectors, fp, path);
+}
+
+// the section persist_write_ivf wrote, header already read into h
+nmn_status persist_read_ivf(FILE* fp, const char* path, const PersistHeader& h, const nmn_index_desc* overrides, nmn_ivf** out) {
+    *out = nullptr;
+    if (h.kind != kPersistIvf || h.dim == 0 || h.aux == 0 || h.aux > 0xFFFFFFFFull)
+        return set_error(NMN_ERR_SERIALIZATION, "not an IVF index file");
+    const uint32_t n_clusters = (uint32_t)h.aux;
+    std::vector<float> cents((size_t)n_clusters * h.dim);
+    std::vector<uint32_t> assign((size_t)h.rows);
+    if (fread(cents.data(), 4, cents.size(), fp) != cents.size() || (h.rows && fread(assign.data(), 4, h.rows, fp) != h.rows))
+        return set_error(NMN_ERR_SERIALIZATION, "index file truncated (centroids / lists)");
+    for (uint32_t a : assign)
+        if (a >= n_clusters) return set_error(NMN_ERR_SERIALIZATION, "index file corrupt: a list id is out of range");
+    PersistHeader hv{};
+    nmn_status st = persist_read_header(fp, path, &hv);
+    if (st != NMN_OK) return st;
+    if (hv.kind != kPersistFlat || hv.dim != h.dim || hv.rows != h.rows) return set_error(NMN_ERR_SERIALIZATION, "index file header is inconsistent");
+    nmn_index_desc d{};
+    d.dim = h.dim;
+    d.flags = overrides ? overrides->flags : 0;
+    d.capacity_rows = std::max<uint64_t>(overrides ? overrides->capacity_rows : 0, std::max<uint64_t>(h.rows, 1));
+    d.device = overrides ? overrides->device : -1;
+    d.cand_cap = overrides ? overrides->cand_cap : 0;
+    nmn_ivf* ivf = nullptr;
+    st = ivf_new(&d, cents.data(), n_clusters, &ivf);
+    if (st != NMN_OK) return st;
+    // the vectors: stream the shard section into ivf->vectors (rows + integrity check of the magnitudes)
+    {
+        const size_t row_bytes = (size_t)h.dim * 4;
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (32ull << 20) / row_bytes);
+        std::vector<float> buf((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(h.rows, 1)) * h.dim);
+        for (uint64_t r = 0; r < h.rows && st == NMN_OK; r += chunk_rows) {
+            const uint64_t n = std::min(chunk_rows, h.rows - r);
+            if (fread(buf.data(), row_bytes, n, fp) != n) st = set_error(NMN_ERR_SERIALIZATION, "index file truncated (rows)");
+            else st = nmn_index_upload(ivf->vectors, buf.data(), r, n);
+        }
+        if (st == NMN_OK && h.rows) {
+            std::vector<float> want((size_t)h.rows), got((size_t)h.rows);
+            if (fread(want.data(), 4, h.rows, fp) != h.rows) st = set_error(NMN_ERR_SERIALIZATION, "index file truncated (magnitudes)");
+            if (st == NMN_OK) {
+                hipError_t e = hipSetDevice(ivf->device);
+                if (e == hipSuccess) e = hipMemcpy(got.data(), ivf->vectors->norms, (size_t)h.rows * 4, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) st = set_error_hip(e, "reading the magnitudes back");
+                else if (memcmp(want.data(), got.data(), (size_t)h.rows * 4) != 0)
+                    st = set_error(NMN_ERR_SERIALIZATION, "index file corrupt: row magnitudes differ from the stored ones");
+            }
+        }
+    }
+    if (st == NMN_OK && h.rows) {
+        hipError_t e = hipSetDevice(ivf->device);
+        if (e == hipSuccess) e = hipMemcpy(ivf->assign, assign.data(), (size_t)h.rows * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = set_error_hip(e, "uploading the lists");
+    }
+    if (st != NMN_OK) {
+        const std::string keep = nmn_last_error();
+        nmn_ivf_destroy(ivf);
+        return set_error(st, keep.c_str());
+    }
+    ivf->assign_host = std::move(assign);
+    ivf->centroids_host = std::move(cents);
+    ivf->list_sizes.assign(n_clusters, 0);
+    for (uint32_t a : ivf->assign_host) ivf->list_sizes[a]++;
+    ivf->list_sizes_rows = h.rows;
+    *out = ivf;
+    return NMN_OK;
+}
+}  // namespace nmn
+
+extern "C" nmn_status nmn_ivf_save(nmn_ivf* ivf, const char* path) {
+    if (!ivf || !path) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return persist_io_error("cannot create", path);
+    nmn_status st = persist_write_ivf(ivf, fp, path);
+    if (fclose(fp) != 0 && st == NMN_OK) st = persist_io_error("cannot close", path);
+    return st;
+}
+
+extern "C" nmn_status nmn_ivf_load(const char* path, const nmn_index_desc* overrides, uint64_t max_file_bytes,
+                                   uint64_t max_entries, nmn_ivf** out) {
+    if (!path || !out) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    nmn_status st = persist_check_file_size(path, max_file_bytes, nullptr);
+    if (st != NMN_OK) return st;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return persist_io_error("cannot open", path);
+    PersistHeader h{};
+    st = persist_read_header(fp, path, &h);
+    if (st == NMN_OK) st = persist_check_entries(h.rows, max_entries);
+    if (st == NMN_OK) st = persist_read_ivf(fp, path, h, overrides, out);
+    fclose(fp);
+    return st;
+}

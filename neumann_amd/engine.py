@@ -24,7 +24,8 @@ class _EngineConfig(C.Structure):
     _fields_ = [("default_dimension", C.c_uint64), ("sparse_threshold", C.c_float),
                 ("parallel_threshold", C.c_uint64), ("default_metric", C.c_int32),
                 ("max_dimension", C.c_uint64), ("max_keys_per_scan", C.c_uint64),
-                ("search_timeout_ms", C.c_int64), ("device", C.c_int32), ("cand_cap", C.c_uint32)]
+                ("search_timeout_ms", C.c_int64), ("device", C.c_int32), ("cand_cap", C.c_uint32),
+                ("max_index_file_bytes", C.c_int64), ("max_index_entries", C.c_int64)]
 
 
 class _Value(C.Structure):
@@ -135,6 +136,14 @@ ENGINE_SIGNATURES = {
     "nmn_engine_device_filter_evals": (C.c_uint64, [vp]),
     "nmn_engine_column_builds": (C.c_uint64, [vp]),
     "nmn_engine_mirror_cached": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_save_index": (C.c_int32, [vp, C.c_char_p, C.c_char_p]),
+    "nmn_engine_load_index": (C.c_int32, [vp, C.c_char_p, C.c_char_p, C.c_uint64]),
+    "nmn_engine_save_index_binary": (C.c_int32, [vp, C.c_char_p, C.c_char_p]),
+    "nmn_engine_load_index_binary": (C.c_int32, [vp, C.c_char_p, C.c_char_p, C.c_uint64]),
+    "nmn_engine_save_all_indices": (vp, [vp, C.c_char_p, C.POINTER(C.c_int32)]),
+    "nmn_engine_load_all_indices": (vp, [vp, C.c_char_p, C.POINTER(C.c_int32)]),
+    "nmn_engine_ivf_save": (C.c_int32, [vp, C.c_char_p]),
+    "nmn_engine_ivf_load": (C.c_int32, [vp, C.c_char_p, C.POINTER(vp)]),
 }
 
 _bound = False
@@ -159,7 +168,7 @@ class VectorError(Exception):
         _capi.ERR_EMPTY_VECTOR: "EmptyVector", _capi.ERR_INVALID_TOP_K: "InvalidTopK",
         _capi.ERR_STORAGE: "StorageError", _capi.ERR_CONFIGURATION: "ConfigurationError",
         _capi.ERR_COLLECTION_EXISTS: "CollectionExists", _capi.ERR_COLLECTION_NOT_FOUND: "CollectionNotFound",
-        _capi.ERR_SEARCH_TIMEOUT: "SearchTimeout",
+        _capi.ERR_SEARCH_TIMEOUT: "SearchTimeout", _capi.ERR_IO: "IoError", _capi.ERR_SERIALIZATION: "SerializationError",
     }
 
     def __init__(self, status, message):
@@ -223,6 +232,8 @@ class VectorEngineConfig:
     search_timeout: float = None  # seconds
     device: int = -1
     cand_cap: int = 0
+    max_index_file_bytes: int = 100 * 1024 * 1024   # lib.rs:660; None = no limit
+    max_index_entries: int = 1_000_000              # lib.rs:661; None = no limit
 
 
 @dataclass
@@ -440,6 +451,8 @@ class VectorEngine:
             cfg.search_timeout_ms = -1 if config.search_timeout is None else int(config.search_timeout * 1000)
             cfg.device = config.device
             cfg.cand_cap = config.cand_cap
+            cfg.max_index_file_bytes = -1 if config.max_index_file_bytes is None else int(config.max_index_file_bytes)
+            cfg.max_index_entries = -1 if config.max_index_entries is None else int(config.max_index_entries)
         self._h = vp()
         _check(lib.nmn_engine_create(C.byref(cfg), C.byref(self._h)))
 
@@ -560,6 +573,56 @@ class VectorEngine:
                          init_method=0 if o.init_method == "random" else 1)
         h = vp()
         _check(_lib().nmn_engine_build_ivf_index(self._h, C.byref(co), C.byref(h)))
+        index = IVFIndex(h)
+        return index, index.keys
+
+    # -- index persistence (lib.rs:3733-4000) -----------------------------------------------------
+    DEFAULT_COLLECTION = "default"
+
+    def save_index(self, collection, path):
+        """PersistentVectorIndex as serde_json writes it (lib.rs:3794-3801)."""
+        _check(_lib().nmn_engine_save_index(self._h, collection.encode(), str(path).encode()))
+
+    def load_index(self, path):
+        """-> the collection's name (lib.rs:3827-3866); max_index_file_bytes / max_index_entries apply."""
+        buf = C.create_string_buffer(4096)
+        _check(_lib().nmn_engine_load_index(self._h, str(path).encode(), buf, len(buf)))
+        return buf.value.decode()
+
+    def save_index_binary(self, collection, path):
+        """The snapshot with the vectors as flat shard sections (the device layout), lib.rs:3811-3817."""
+        _check(_lib().nmn_engine_save_index_binary(self._h, collection.encode(), str(path).encode()))
+
+    def load_index_binary(self, path):
+        buf = C.create_string_buffer(4096)
+        _check(_lib().nmn_engine_load_index_binary(self._h, str(path).encode(), buf, len(buf)))
+        return buf.value.decode()
+
+    def _take_strlist(self, h, st):
+        _check(st.value)
+        lib = _lib()
+        try:
+            return [lib.nmn_strlist_get(h, i).decode() for i in range(lib.nmn_strlist_len(h))]
+        finally:
+            lib.nmn_strlist_free(h)
+
+    def save_all_indices(self, directory):
+        st = C.c_int32()
+        h = _lib().nmn_engine_save_all_indices(self._h, str(directory).encode(), C.byref(st))
+        return self._take_strlist(h, st)
+
+    def load_all_indices(self, directory):
+        st = C.c_int32()
+        h = _lib().nmn_engine_load_all_indices(self._h, str(directory).encode(), C.byref(st))
+        return self._take_strlist(h, st)
+
+    def save_ivf_index(self, index, path):
+        """The (IVFIndex, key_mapping) pair with trained centroids and lists: restored without k-means."""
+        _check(_lib().nmn_engine_ivf_save(index._h, str(path).encode()))
+
+    def load_ivf_index(self, path):
+        h = vp()
+        _check(_lib().nmn_engine_ivf_load(self._h, str(path).encode(), C.byref(h)))
         index = IVFIndex(h)
         return index, index.keys
 

@@ -42,6 +42,27 @@ class GpuFlatIndex:
         self.capacity_rows = int(capacity_rows)
         self.row_base = int(row_base)
 
+    # -- persistence of the device layout ------------------------------------
+    def save(self, path):
+        """Rows (stride removed) + their magnitudes -> `path` (nmn_index_save)."""
+        _capi.check(self._lib.nmn_index_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, device=-1, capacity_rows=0, row_base=0, cand_cap=0, wide_rows=False, max_file_bytes=0, max_entries=0):
+        """nmn_index_load: a shard from a file written by `save`; the limits are the reference's max_index_file_bytes /
+        max_index_entries (0 = none).  The upload's magnitudes must match the stored ones bit for bit."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        desc = _capi.IndexDesc(dim=0, flags=1 if wide_rows else 0, capacity_rows=int(capacity_rows), row_base=int(row_base),
+                               device=int(device), cand_cap=int(cand_cap))
+        _capi.check(self._lib.nmn_index_load(str(path).encode(), C.byref(desc), int(max_file_bytes), int(max_entries),
+                                             C.byref(self._h)))
+        self.dim = int(self._lib.nmn_index_dim(self._h))
+        self.capacity_rows = max(int(capacity_rows), self.rows)
+        self.row_base = int(self._lib.nmn_index_row_base(self._h))
+        return self
+
     # -- lifecycle --------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

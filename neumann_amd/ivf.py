@@ -45,6 +45,24 @@ class GpuIvfFlat:
         self.nprobe = int(np.ceil(np.sqrt(np.float32(num_clusters)))) if nprobe is None else int(nprobe)
         return self
 
+    def save(self, path):
+        """Centroids, the list of every vector and the vectors in id order -> `path` (nmn_ivf_save)."""
+        _capi.check(self._lib.nmn_ivf_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, nprobe=None, capacity_rows=0, device=-1, max_file_bytes=0, max_entries=0):
+        """nmn_ivf_load: no k-means, no re-assignment — lists and centroids come back exactly as saved."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        desc = _capi.IndexDesc(dim=0, flags=0, capacity_rows=int(capacity_rows), row_base=0, device=int(device), cand_cap=0)
+        h = C.c_void_p()
+        _capi.check(self._lib.nmn_ivf_load(str(path).encode(), C.byref(desc), int(max_file_bytes), int(max_entries), C.byref(h)))
+        self._h = h
+        self.n_clusters = int(self._lib.nmn_ivf_clusters(h))
+        self.dim = int(self._lib.nmn_index_dim(self._lib.nmn_ivf_vectors(h)))
+        self.nprobe = int(np.ceil(np.sqrt(np.float32(self.n_clusters)))) if nprobe is None else int(nprobe)
+        return self
+
     def centroids(self):
         out = np.empty((self.n_clusters, self.dim), dtype=np.float32)
         _capi.check(self._lib.nmn_ivf_centroids(self._h, C.c_void_p(out.ctypes.data), out.size))
