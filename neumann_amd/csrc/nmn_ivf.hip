@@ -786,28 +786,8 @@ nmn_status persist_read_ivf(FILE* fp, const char* path, const PersistHeader& h, 
     nmn_ivf* ivf = nullptr;
     st = ivf_new(&d, cents.data(), n_clusters, &ivf);
     if (st != NMN_OK) return st;
-    // the vectors: stream the shard section into ivf->vectors (rows + integrity check of the magnitudes)
-    {
-        const size_t row_bytes = (size_t)h.dim * 4;
-        const uint64_t chunk_rows = std::max<uint64_t>(1, (32ull << 20) / row_bytes);
-        std::vector<float> buf((size_t)std::min<uint64_t>(chunk_rows, std::max<uint64_t>(h.rows, 1)) * h.dim);
-        for (uint64_t r = 0; r < h.rows && st == NMN_OK; r += chunk_rows) {
-            const uint64_t n = std::min(chunk_rows, h.rows - r);
-            if (fread(buf.data(), row_bytes, n, fp) != n) st = set_error(NMN_ERR_SERIALIZATION, "index file truncated (rows)");
-            else st = nmn_index_upload(ivf->vectors, buf.data(), r, n);
-        }
-        if (st == NMN_OK && h.rows) {
-            std::vector<float> want((size_t)h.rows), got((size_t)h.rows);
-            if (fread(want.data(), 4, h.rows, fp) != h.rows) st = set_error(NMN_ERR_SERIALIZATION, "index file truncated (magnitudes)");
-            if (st == NMN_OK) {
-                hipError_t e = hipSetDevice(ivf->device);
-                if (e == hipSuccess) e = hipMemcpy(got.data(), ivf->vectors->norms, (size_t)h.rows * 4, hipMemcpyDeviceToHost);
-                if (e != hipSuccess) st = set_error_hip(e, "reading the magnitudes back");
-                else if (memcmp(want.data(), got.data(), (size_t)h.rows * 4) != 0)
-                    st = set_error(NMN_ERR_SERIALIZATION, "index file corrupt: row magnitudes differ from the stored ones");
-            }
-        }
-    }
+    // the vectors: stream the shard section into ivf->vectors (checksum + integrity check of the magnitudes)
+    st = persist_read_rows_into(fp, hv, ivf->vectors);
     if (st == NMN_OK && h.rows) {
         hipError_t e = hipSetDevice(ivf->device);
         if (e == hipSuccess) e = hipMemcpy(ivf->assign, assign.data(), (size_t)h.rows * 4, hipMemcpyHostToDevice);

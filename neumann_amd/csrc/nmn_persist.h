@@ -32,6 +32,7 @@ nmn_status persist_check_file_size(const char* path, uint64_t max_file_bytes, ui
 nmn_status persist_check_entries(uint64_t entries, uint64_t max_entries);
 nmn_status persist_write_shard(nmn_index* idx, FILE* fp, const char* path);
 nmn_status persist_read_header(FILE* fp, const char* path, PersistHeader* h);
+nmn_status persist_read_rows_into(FILE* fp, const PersistHeader& h, nmn_index* idx);
 nmn_status persist_read_shard(FILE* fp, const char* path, const PersistHeader& h, const nmn_index_desc* overrides,
                               nmn_index** out);
 
