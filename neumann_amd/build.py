@@ -24,6 +24,7 @@ SOURCES = {
     "nmn_select.hip": [],
     "nmn_exact.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_synth.hip": ["-ffp-contract=off"],
+    "nmn_ingest.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_sortk.hip": [],
     "nmn_columns.hip": [],
     "nmn_ivf.hip": ["-ffp-contract=off"],

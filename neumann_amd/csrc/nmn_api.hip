@@ -470,6 +470,60 @@ extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
 static hipError_t half_scratch_get(nmn_index* idx, uint64_t rows, float** out);
 static void half_scratch_trim(nmn_index* idx);
 
+// The bf16 mirror of the corpus (nmn_index::half) and its bookkeeping.  Not enough HBM is not an error: the shard then
+// stays on the f32 sweep (half_failed).
+static nmn_status mirror_alloc(nmn_index* idx, hipStream_t stream) {
+    if (idx->half || idx->half_failed) return NMN_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half), (size_t)idx->cap_pad * idx->ld * 2);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        idx->half = nullptr;
+        idx->half_failed = true;
+        return NMN_OK;
+    }
+    idx->half_rows = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_err_bits), 8));
+    HIP_TRY(hipMemsetAsync(idx->half_err_bits, 0, 8, stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_stats), 8));
+    HIP_TRY(hipMemsetAsync(idx->half_stats, 0, 8, stream));
+    HIP_TRY(hipMemsetAsync(idx->half, 0, (size_t)idx->cap_pad * idx->ld * 2, stream));
+    return NMN_OK;
+}
+
+// What every writer of rows runs behind the copy: magnitudes in reference order, and the bf16 mirror of the same rows.
+// Rows in whole 32-float stages with no scalar tail take the ONE-PASS kernel (nmn_ingest.hip: one read of the f32 rows
+// feeds the magnitude chains, the bf16 pack and the error norms); a bulk write (>= 4096 rows) allocates the mirror right
+// away so that the first search finds it built.  Other shapes: norms_kernel now, the mirror lazily (search_enqueue).
+static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream) {
+    static const bool no_ingest = env_set("NMN_NO_INGEST");  // measurement knob: the three-pass path of round 1
+    if (ingest_supported(idx->ld, idx->dim) && !no_ingest) {
+        const bool want_mirror = !idx->mirror_off && !no_half() && !idx->half_failed;
+        if (want_mirror && !idx->half && n >= 4096 && row0 == 0) {
+            nmn_status st = mirror_alloc(idx, stream);
+            if (st != NMN_OK) return st;
+        }
+        const bool with_half = idx->half && row0 <= idx->half_rows;  // the mirror stays a prefix of the rows
+        HIP_TRY(launch_ingest(idx->corpus, idx->ld, row0, n, idx->norms, idx->max_norm_bits, with_half ? idx->half : nullptr,
+                              idx->half_err_bits, stream));
+        if (with_half) idx->half_rows = std::max(idx->half_rows, row0 + n);
+        return NMN_OK;
+    }
+    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
+    if (idx->half && row0 < idx->half_rows) {
+        // rows the mirror already holds are patched in place (re-deriving the mirror "from row0 on" made one overwritten
+        // row near the top cost a conversion of the whole shard at the next search); rows beyond it are converted lazily
+        const uint64_t cnt = std::min(row0 + n, idx->half_rows) - row0;
+        float* scratch = nullptr;
+        HIP_TRY(half_scratch_get(idx, cnt, &scratch));
+        HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row0, cnt, idx->norms, scratch, idx->half_err_bits, stream));
+        if (idx->half_scratch_cap > (1u << 20)) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            half_scratch_trim(idx);
+        }
+    }
+    return NMN_OK;
+}
+
 static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_host, uint64_t row0, uint64_t n,
                                 hipStream_t stream) {
     if (!idx || (!src && n)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
@@ -485,20 +539,9 @@ static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_ho
         HIP_TRY(hipMemcpy2DAsync(dst, (size_t)idx->ld * sizeof(float), src, (size_t)idx->dim * sizeof(float),
                                  (size_t)idx->dim * sizeof(float), n, kind, stream));
     }
-    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
+    nmn_status st = rows_written(idx, row0, n, stream);
+    if (st != NMN_OK) return st;
     idx->rows = std::max(idx->rows, row0 + n);
-    if (idx->half && row0 < idx->half_rows) {
-        // rows the mirror already holds are patched in place (re-deriving the mirror "from row0 on" made one overwritten
-        // row near the top cost a conversion of the whole shard at the next search); rows beyond it are converted lazily
-        const uint64_t cnt = std::min(row0 + n, idx->half_rows) - row0;
-        float* scratch = nullptr;
-        HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-        HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row0, cnt, idx->norms, scratch, idx->half_err_bits, stream));
-        if (idx->half_scratch_cap > (1u << 20)) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            half_scratch_trim(idx);
-        }
-    }
     return NMN_OK;
 }
 
@@ -683,20 +726,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         }
         if (use_half) {
             if (!idx->half) {
-                hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half), (size_t)idx->cap_pad * idx->ld * 2);
-                if (e != hipSuccess) {
-                    (void)hipGetLastError();
-                    idx->half = nullptr;
-                    idx->half_failed = true;  // not enough HBM for the mirror: f32 VALU sweeps serve everything
-                    use_half = false;
-                } else {
-                    idx->half_rows = 0;
-                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_err_bits), 8));
-                    HIP_TRY(hipMemsetAsync(idx->half_err_bits, 0, 8, stream));
-                    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_stats), 8));
-                    HIP_TRY(hipMemsetAsync(idx->half_stats, 0, 8, stream));
-                    HIP_TRY(hipMemsetAsync(idx->half, 0, (size_t)idx->cap_pad * idx->ld * 2, stream));
-                }
+                st = mirror_alloc(idx, stream);
+                if (st != NMN_OK) return st;
+                if (!idx->half) use_half = false;  // not enough HBM for the mirror: f32 VALU sweeps serve everything
             }
             if (use_half && idx->half_rows < n_rows) {
                 const uint64_t cnt = n_rows - idx->half_rows;
@@ -1644,10 +1676,11 @@ extern "C" nmn_status nmn_index_fill_synthetic(nmn_index* idx, uint64_t seed, ui
     IdleGuard idle(idx, lk);
     hipStream_t s = idx->host_stream;
     HIP_TRY(launch_synth_fill(idx->corpus, idx->ld, idx->dim, seed, idx->row_base + row0, row0, n, s));
-    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, s));
+    idx->half_rows = std::min(idx->half_rows, row0);  // whatever the mirror held from row0 on is stale
+    nmn_status st = rows_written(idx, row0, n, s);
+    if (st != NMN_OK) return st;
     HIP_TRY(hipStreamSynchronize(s));
     idx->rows = std::max(idx->rows, row0 + n);
-    idx->half_rows = std::min(idx->half_rows, row0);
     return NMN_OK;
 }
 
@@ -1660,14 +1693,8 @@ extern "C" nmn_status nmn_index_set_row(nmn_index* idx, uint64_t row, const floa
     hipStream_t s = idx->host_stream;
     HIP_TRY(hipMemcpyAsync(idx->corpus + row * (uint64_t)idx->ld, vec_host, (size_t)idx->dim * 4,
                            hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row, 1, idx->norms, idx->max_norm_bits, s));
-    if (idx->half && row < idx->half_rows) {
-        float* scratch = nullptr;
-        HIP_TRY(half_scratch_get(idx, 1, &scratch));
-        hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, row, 1, idx->norms, scratch, idx->half_err_bits, s);
-        if (ce == hipSuccess) ce = hipStreamSynchronize(s);
-        if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
-    }
+    nmn_status st = rows_written(idx, row, 1, s);
+    if (st != NMN_OK) return st;
     HIP_TRY(hipStreamSynchronize(s));
     return NMN_OK;
 }

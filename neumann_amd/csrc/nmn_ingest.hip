@@ -1,0 +1,239 @@
+// nmn_ingest.hip — ONE pass over freshly written f32 rows: their magnitudes in the reference's order, their bf16
+// mirror, and the mirror's rounding-error norms.  (Round 1 took three: norms_kernel read the rows 8 lanes per row, 4 bytes
+// per lane — 2.07 TB/s —, half_rows_kernel read them again to write the mirror, half_err_kernel folded the errors.)
+//
+// THIS TRANSLATION UNIT IS BUILT WITH -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt (build.py): the magnitude
+// is simd::magnitude (tensor_store/src/hnsw.rs:198-229) bit for bit — eight accumulators acc[l] = acc[l] + (v[8c+l]*v[8c+l])
+// over the chunks c in order, multiply and add rounded separately, the lanes summed left to right from -0.0, sqrt
+// correctly rounded.  (Only rows with dim % 8 == 0 come here: no scalar tail; a zero-padded chunk adds +0.0 exactly.)
+//
+// Shape of the work: the chain of accumulator lane l is sequential over the chunks of a row, so a row offers 8-fold
+// parallelism and no more.  Sixteen lanes per row (the sweep's load shape) would pass every partial sum from lane to lane
+// through DPP with one lane in eight doing useful work per step.  Instead a LANE OWNS A ROW — 8 independent chains, no
+// cross-lane traffic at all — and coalescing is restored by staging through LDS:
+//   * wave = 64 rows (a tile).  The tile streams through the wave's own LDS ring in stages of [64 rows][32 floats] = 8 KiB,
+//     filled by global_load_lds_dwordx4 (eight 1-KiB instructions, each 8 rows x 128 contiguous bytes = whole lines), 3 of 4
+//     stages in flight, counted s_waitcnt vmcnt — no workgroup barrier anywhere: the four waves of a workgroup never meet.
+//   * the LDS image is XOR-swizzled through the DMA source address (16-byte chunk ^= (row >> 1) & 7) so that the
+//     ds_read_b128 of 64 lanes, each at its own row, is conflict-free.
+//   * per stage and lane: 8 ds_read_b128, 32 mul + 32 add (the chains), 16 v_cvt_pk_bf16_f32, the error terms; the bf16
+//     halves of two stages (128 B per row = one line) go through a second swizzled LDS buffer and leave as 8 coalesced
+//     16-byte-per-lane stores of 8 rows x 128 B.
+//   * maxima (|v|, |e_r|, |e_r| / |v_r|) are kept per wave in registers across all its tiles: 3 atomics per wave per launch.
+// Traffic: rows * ld * 4 read + rows * ld * 2 written (+ 4 B/row) — 46.1 GB for 10M x 768; bound: HBM.
+#include <algorithm>
+
+#include "nmn_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace nmn {
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+constexpr int kStageFloats = 32;                 // floats of a row per stage (4 chunks of the reference's 8)
+constexpr int kStageBytes = 64 * kStageFloats * 4;  // 8 KiB
+constexpr int kRing = 4;                         // stages per wave (3 in flight)
+constexpr int kOutBytes = 64 * 128;              // bf16 of two stages: 128 B per row
+constexpr int kWaveLds = kRing * kStageBytes + kOutBytes;  // 40 KiB
+constexpr int kWaves = 4;                        // per workgroup: 160 KiB of LDS, one workgroup per CU
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// HALF: also write the bf16 mirror and fold its rounding errors
+template <bool HALF>
+__global__ void __launch_bounds__(kWaves * 64, 1) ingest_kernel(const float* __restrict__ corpus, uint32_t ld, uint64_t row0,
+                                                                uint64_t n, float* __restrict__ norms,
+                                                                uint32_t* __restrict__ max_norm_bits, float* __restrict__ half,
+                                                                uint32_t* __restrict__ err_bits) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* ring = lds_all + wave * (kWaveLds / 4);
+    float* obuf = ring + kRing * (kStageBytes / 4);
+    const uint64_t n_tiles = (n + 63) / 64;
+    const uint64_t gw = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
+    if (gw >= n_tiles) return;
+    const uint32_t KC = ld / kStageFloats;                        // stages per tile
+    const uint64_t my_tiles = (n_tiles - gw + n_waves - 1) / n_waves;
+    const uint64_t n_stage = my_tiles * KC;
+    const uint32_t swz = (lane >> 1) & 7u;                        // this lane's row swizzle (lane == row of the tile)
+
+    // DMA source offsets of the 8 pieces of a stage: piece p, lane i -> row 8p + i/8 of the tile, LDS chunk i%8, source
+    // chunk (i%8) ^ ((row >> 1) & 7).  Rows past the end are clamped to the last row (loaded, never stored).
+    const uint32_t pr = lane >> 3, pc = lane & 7u;
+    auto src_of = [&](uint64_t tile, uint32_t kc, uint32_t p) -> const char* {
+        const uint32_t r = 8u * p + pr;
+        uint64_t gi = tile * 64 + r;
+        if (gi >= n) gi = n - 1;
+        return reinterpret_cast<const char*>(corpus + (row0 + gi) * (uint64_t)ld + (uint64_t)kc * kStageFloats) +
+               ((pc ^ ((r >> 1) & 7u)) * 16u);
+    };
+    // the stage the DMA issues next: (tile, kc, ring slot), advanced incrementally (a 64-bit division per stage costs more
+    // than the stage's arithmetic)
+    uint64_t i_tile = gw;
+    uint32_t i_kc = 0, i_slot = 0;
+    auto issue = [&]() {
+        float* dst = ring + i_slot * (kStageBytes / 4);
+#pragma unroll
+        for (uint32_t p = 0; p < 8; p++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_of(i_tile, i_kc, p),
+                                             (__attribute__((address_space(3))) void*)(dst + p * 256u), 16, 0, 2);  // nt: read once
+        i_slot = (i_slot + 1u) & (kRing - 1u);
+        if (++i_kc == KC) {
+            i_kc = 0;
+            i_tile += n_waves;
+        }
+    };
+    static_assert((kRing & (kRing - 1)) == 0, "ring slots wrap with a mask");
+#pragma unroll
+    for (uint32_t s = 0; s < kRing - 1; s++)
+        if (s < n_stage) issue();
+
+    float acc[8];
+    float err2 = 0.f;
+    float mx_norm = 0.f, mx_err = 0.f, mx_rel = 0.f;
+    uint64_t tile = gw;
+    uint32_t kc = 0, slot = 0;
+    for (uint64_t s = 0; s < n_stage; s++) {
+        if (kc == 0) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) acc[l] = 0.0f;
+            err2 = 0.f;
+        }
+        // the oldest stage has landed once at most the younger ones (8 DMA each) are outstanding; bf16 stores in
+        // flight only make the wait conservative (stores and loads share vmcnt)
+        const uint64_t after = n_stage - 1 - s;
+        if (after >= kRing - 2) wait_vm<(kRing - 2) * 8>();
+        else if (after == 1) wait_vm<8>();
+        else wait_vm<0>();
+        asm volatile("" ::: "memory");
+        if (s + kRing - 1 < n_stage) issue();  // into the slot consumed (lgkmcnt(0) below) one iteration ago
+        const float* buf = ring + slot * (kStageBytes / 4) + lane * kStageFloats;
+        v4f x[8];
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) x[c] = *reinterpret_cast<const v4f*>(buf + ((c ^ swz) * 4u));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the reference's chains: chunk c8 = 4 kc + j holds x[2j] (lanes 0-3) and x[2j+1] (lanes 4-7)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = x[2 * j][e], b = x[2 * j + 1][e];
+                const float pa = a * a, pb = b * b;
+                acc[e] = acc[e] + pa;
+                acc[4 + e] = acc[4 + e] + pb;
+            }
+        }
+        if constexpr (HALF) {
+            // 32 floats -> 16 packed pairs = four 16-byte chunks of the mirror row; rounding error folded on the way
+            u4v pk[4];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const f2v lo = {x[c][0], x[c][1]}, hi = {x[c][2], x[c][3]};
+                const uint32_t p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf2v));
+                const uint32_t p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf2v));
+                const float e0 = x[c][0] - __uint_as_float(p0 << 16), e1 = x[c][1] - __uint_as_float(p0 & 0xFFFF0000u);
+                const float e2 = x[c][2] - __uint_as_float(p1 << 16), e3 = x[c][3] - __uint_as_float(p1 & 0xFFFF0000u);
+                err2 = err2 + e0 * e0;
+                err2 = err2 + e1 * e1;
+                err2 = err2 + e2 * e2;
+                err2 = err2 + e3 * e3;
+                pk[c >> 1][(c & 1) * 2] = p0;
+                pk[c >> 1][(c & 1) * 2 + 1] = p1;
+            }
+            // into the out buffer: row = lane, 16-byte chunk (kc & 1) * 4 + c of the 128-byte pair line, swizzled like the ring
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++)
+                *reinterpret_cast<u4v*>(obuf + lane * 32u + (((((kc & 1u) * 4u) + c) ^ swz) * 4u)) = pk[c];
+            const bool pair_done = (kc & 1u) == 1u || kc + 1 == KC;
+            if (pair_done) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint32_t valid_chunks = (kc & 1u) ? 8u : 4u;  // a row length of an odd number of stages ends on half a line
+                const uint32_t pair = kc >> 1;
+#pragma unroll
+                for (uint32_t p = 0; p < 8; p++) {
+                    const uint32_t r = 8u * p + pr;
+                    const u4v v = *reinterpret_cast<const u4v*>(obuf + r * 32u + ((pc ^ ((r >> 1) & 7u)) * 4u));
+                    const uint64_t gi = tile * 64 + r;
+                    if (gi < n && pc < valid_chunks)
+                        *reinterpret_cast<u4v*>(reinterpret_cast<char*>(half) + (row0 + gi) * (uint64_t)ld * 2ull + (uint64_t)pair * 128ull +
+                                                pc * 16u) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next pair overwrites the buffer
+            }
+        }
+        if (kc + 1 == KC) {
+            float r = -0.0f;
+#pragma unroll
+            for (int l = 0; l < 8; l++) r = r + acc[l];
+            const float mag = __builtin_sqrtf(r);
+            const uint64_t gi = tile * 64 + lane;
+            const bool live = gi < n;
+            if (live) norms[row0 + gi] = mag;
+            if (live && mag == mag) mx_norm = __builtin_fmaxf(mx_norm, mag);
+            if constexpr (HALF) {
+                const float e = __builtin_sqrtf(err2) * 1.0005f;  // (slack: the reference of this bound is a different summation order)
+                if (live && e == e && e > 0.f) {
+                    mx_err = __builtin_fmaxf(mx_err, e);
+                    if (mag > 0.f) {
+                        const float rel = e / mag * 1.0005f;
+                        if (rel == rel) mx_rel = __builtin_fmaxf(mx_rel, rel);
+                    }
+                }
+            }
+        }
+        slot = (slot + 1u) & (kRing - 1u);
+        if (++kc == KC) {
+            kc = 0;
+            tile += n_waves;
+        }
+    }
+    // non-negative floats: bit order == value order
+    mx_norm = wave_max(mx_norm);
+    if (lane == 0 && mx_norm > 0.f) atomicMax(max_norm_bits, __float_as_uint(mx_norm));
+    if constexpr (HALF) {
+        mx_err = wave_max(mx_err);
+        mx_rel = wave_max(mx_rel);
+        if (lane == 0 && mx_err > 0.f) atomicMax(err_bits, __float_as_uint(mx_err));
+        if (lane == 0 && mx_rel > 0.f) atomicMax(err_bits + 1, __float_as_uint(mx_rel));
+    }
+}
+
+}  // namespace
+
+// rows whose layout the one-pass kernel takes: whole reference chunks (no scalar tail) and whole 32-float stages
+bool ingest_supported(uint32_t ld, uint32_t dim) { return dim % 8u == 0 && ld % kStageFloats == 0 && ld >= (uint32_t)kStageFloats; }
+
+// magnitudes of rows [row0, row0 + n) (reference order) and, with `half`, their bf16 mirror rows + the mirror's error norms
+hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, uint32_t* max_norm_bits,
+                         float* half, uint32_t* err_bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t n_tiles = (n + 63) / 64;
+    // one workgroup per CU and a few more for the tail; every wave owns tiles gw, gw + n_waves, ...
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_tiles + kWaves - 1) / kWaves, 512);
+    const size_t lds = (size_t)kWaves * kWaveLds;
+    auto kern = half ? ingest_kernel<true> : ingest_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds, s, corpus, ld, row0, n, norms, max_norm_bits, half, err_bits);
+    return hipGetLastError();
+}
+
+}  // namespace nmn

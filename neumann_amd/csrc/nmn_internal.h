@@ -113,6 +113,11 @@ hipError_t launch_scan(const ScanParams& p, hipStream_t s);
 hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                             float* row_err2_scratch, uint32_t* err_bits, hipStream_t s);
 bool scan_half_supported(uint32_t ld, int metric);
+// one pass over freshly written rows (nmn_ingest.hip): magnitudes in reference order + (half != nullptr) their bf16 mirror
+// rows and the mirror's error norms folded into err_bits[0..1]
+bool ingest_supported(uint32_t ld, uint32_t dim);
+hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, uint32_t* max_norm_bits,
+                         float* half, uint32_t* err_bits, hipStream_t s);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);

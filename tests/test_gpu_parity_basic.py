@@ -78,3 +78,35 @@ def test_synth_matches_host():
         assert rows[0, 0] == 1005
         er, es = oc.search(host, q, 3, 0, row_base=1000)
         assert np.array_equal(rows[0], er) and np.all(scores[0] == es)
+
+
+@pytest.mark.parametrize("n,d", [(5000, 768), (4097, 128), (6000, 96), (4096, 32), (300, 1536), (70, 64)])
+def test_one_pass_ingest_magnitudes_and_mirror(n, d):
+    """Rows in whole 32-float stages take the one-pass ingest kernel (nmn_ingest.hip): magnitudes must equal
+    simd::magnitude bit for bit (cosine scores of EVERY row, which divide by them, equal the oracle's bits), and the bf16
+    mirror it writes in the same pass must serve exact searches — after a bulk upload (mirror built by the upload), an
+    append, an overwrite in place and a single-row patch."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(n * 31 + d)
+    A = (rng.standard_normal((n, d)) * rng.choice([1e-3, 1.0, 50.0], size=(n, 1))).astype(np.float32)
+    A[3] = 0.0
+    extra = rng.standard_normal((137, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n + 200) as idx:
+        idx.upload(A)
+        idx.upload(extra)                      # append: extends norms (and the mirror when the bulk upload built it)
+        A = np.concatenate([A, extra])
+        patch = rng.standard_normal((11, d)).astype(np.float32) * np.float32(3.0)
+        idx.upload(patch, row0=10)             # overwrite in place
+        A[10:21] = patch
+        idx.set_row(n // 2, q * np.float32(2.0))   # single-row patch: the query's direction becomes the best match
+        A[n // 2] = q * np.float32(2.0)
+        rows = np.arange(A.shape[0], dtype=np.uint64)
+        for metric in (0, 2):
+            got = idx.score_rows(q, rows, metric)[0]
+            exp = oc.scores_all(A, q, metric)
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), metric
+        for metric in METRICS:
+            _check(idx, A, q, 50, metric)
+        r, s, c = idx.search(q, 1, 0)
+        assert r[0, 0] == n // 2
