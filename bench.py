@@ -299,7 +299,8 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
     idx.set_timing(True)
     sweep_ms = []
     elem_bytes = 4
-    for i in range(4):
+    for i in range(6):
+        torch.cuda.synchronize()  # the sweep alone on the device: its HIP events must not span another step's kernels
         step(i)
         st = idx.last_stats(streams[i % 2])
         if st.scan_ms > 0:

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libneumann_gpu.so")
+# NEUMANN_GPU_LIB: an alternative build of the same library (A/B runs of kernel variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("NEUMANN_GPU_LIB") or os.path.join(_HERE, "lib", "libneumann_gpu.so")
 
 OK = 0
 ERR_NOT_FOUND = -1

@@ -391,6 +391,7 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
     auto cleanup = [&](nmn_status st) {
         if (idx->corpus) (void)hipFree(idx->corpus);
         if (idx->norms) (void)hipFree(idx->norms);
+        if (idx->inv_norms) (void)hipFree(idx->inv_norms);
         if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
         if (idx->host_stream) (void)hipStreamDestroy(idx->host_stream);
         delete idx;
@@ -402,12 +403,15 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
         return cleanup(fail_hip(e, "hipMalloc(corpus)"));
     if ((e = hipMalloc(reinterpret_cast<void**>(&idx->norms), idx->cap_pad * sizeof(float))) != hipSuccess)
         return cleanup(fail_hip(e, "hipMalloc(norms)"));
+    if ((e = hipMalloc(reinterpret_cast<void**>(&idx->inv_norms), idx->cap_pad * sizeof(float))) != hipSuccess)
+        return cleanup(fail_hip(e, "hipMalloc(inv_norms)"));
     if ((e = hipMalloc(reinterpret_cast<void**>(&idx->max_norm_bits), 4)) != hipSuccess)
         return cleanup(fail_hip(e, "hipMalloc(max_norm)"));
     if ((e = hipStreamCreateWithFlags(&idx->host_stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(fail_hip(e, "hipStreamCreate"));
     if ((e = hipMemsetAsync(idx->corpus, 0, corpus_bytes, idx->host_stream)) != hipSuccess ||
         (e = hipMemsetAsync(idx->norms, 0, idx->cap_pad * sizeof(float), idx->host_stream)) != hipSuccess ||
+        (e = hipMemsetAsync(idx->inv_norms, 0, idx->cap_pad * sizeof(float), idx->host_stream)) != hipSuccess ||
         (e = hipMemsetAsync(idx->max_norm_bits, 0, 4, idx->host_stream)) != hipSuccess ||
         (e = hipStreamSynchronize(idx->host_stream)) != hipSuccess)
         return cleanup(fail_hip(e, "memset"));
@@ -428,6 +432,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->half_stats) (void)hipFree(idx->half_stats);
     if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
     if (idx->norms) (void)hipFree(idx->norms);
+    if (idx->inv_norms) (void)hipFree(idx->inv_norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
     for (int i = 1; i < nmn_index::kHostSlots; i++)
         if (idx->host_slots[i]) (void)hipStreamDestroy(idx->host_slots[i]);
@@ -503,12 +508,12 @@ static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStr
             if (st != NMN_OK) return st;
         }
         const bool with_half = idx->half && row0 <= idx->half_rows;  // the mirror stays a prefix of the rows
-        HIP_TRY(launch_ingest(idx->corpus, idx->ld, row0, n, idx->norms, idx->max_norm_bits, with_half ? idx->half : nullptr,
+        HIP_TRY(launch_ingest(idx->corpus, idx->ld, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, with_half ? idx->half : nullptr,
                               idx->half_err_bits, stream));
         if (with_half) idx->half_rows = std::max(idx->half_rows, row0 + n);
         return NMN_OK;
     }
-    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->max_norm_bits, stream));
+    HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, stream));
     if (idx->half && row0 < idx->half_rows) {
         // rows the mirror already holds are patched in place (re-deriving the mirror "from row0 on" made one overwritten
         // row near the top cost a conversion of the whole shard at the next search); rows beyond it are converted lazily
@@ -771,6 +776,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.corpus = idx->corpus;
             sp.corpus_half = use_half ? idx->half : nullptr;
             sp.norms = idx->norms;
+            sp.inv_norms = idx->inv_norms;
             sp.qpad = w->qpad;
             sp.qinfo = w->qinfo;
             sp.mask = mask_dev;

@@ -165,7 +165,7 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ q, const 
 // ---- |v| for uploaded rows -------------------------------------------------------------------
 __global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ corpus, uint32_t ld, uint32_t dim,
                                                     uint64_t row0, uint64_t n, float* __restrict__ norms,
-                                                    uint32_t* __restrict__ max_norm_bits) {
+                                                    float* __restrict__ inv_norms, uint32_t* __restrict__ max_norm_bits) {
     const uint32_t l = threadIdx.x & 7u;
     const uint64_t i = (uint64_t)blockIdx.x * 32u + (threadIdx.x >> 3);
     const uint64_t row = row0 + (i < n ? i : n - 1);  // keep the whole 8-group converged for the shuffles
@@ -174,15 +174,16 @@ __global__ void __launch_bounds__(256) norms_kernel(const float* __restrict__ co
     const float mag = sqrt_rn(ss);
     if (i < n && l == 0) {
         norms[row] = mag;
+        inv_norms[row] = mag == 0.0f ? 0.0f : div_rn(1.0f, mag);  // approximate sweeps only: cosine = dot * (1/|q|) * (1/|v|)
         if (mag == mag) atomicMax(max_norm_bits, f2u(mag));  // mag >= 0: bit order == value order
     }
 }
 
 hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,
-                        uint32_t* max_norm_bits, hipStream_t s) {
+                        float* inv_norms, uint32_t* max_norm_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t blocks = (n + 31) / 32;
-    hipLaunchKernelGGL(norms_kernel, dim3((unsigned)blocks), dim3(256), 0, s, corpus, ld, dim, row0, n, norms,
+    hipLaunchKernelGGL(norms_kernel, dim3((unsigned)blocks), dim3(256), 0, s, corpus, ld, dim, row0, n, norms, inv_norms,
                        max_norm_bits);
     return hipGetLastError();
 }

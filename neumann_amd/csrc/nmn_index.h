@@ -121,6 +121,8 @@ struct nmn_index {
     float* half_scratch = nullptr;      // |e_r|^2 of the rows being converted; kept (hipMalloc / hipFree per store or per
     size_t half_scratch_cap = 0;        // search after a store would synchronise the whole device every time)
     float* norms = nullptr;
+    float* inv_norms = nullptr;         // 1 / |v| (0 for a zero row): what the batched cosine sweep multiplies by (one rcp per ROW at
+                                        // ingest instead of one per (row, query) in every sweep's epilogue)
     uint32_t* max_norm_bits = nullptr;
     hipEvent_t upload_ev = nullptr;     // recorded behind the latest nmn_index_upload_device (nmn_api.hip: upload_fence_*)
     uint64_t upload_seq = 0;

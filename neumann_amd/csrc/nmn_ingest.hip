@@ -59,7 +59,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // HALF: also write the bf16 mirror and fold its rounding errors
 template <bool HALF>
 __global__ void __launch_bounds__(kWaves * 64, 1) ingest_kernel(const float* __restrict__ corpus, uint32_t ld, uint64_t row0,
-                                                                uint64_t n, float* __restrict__ norms,
+                                                                uint64_t n, float* __restrict__ norms, float* __restrict__ inv_norms,
                                                                 uint32_t* __restrict__ max_norm_bits, float* __restrict__ half,
                                                                 uint32_t* __restrict__ err_bits) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(kWaves * 64, 1) ingest_kernel(const float* __r
             const float mag = __builtin_sqrtf(r);
             const uint64_t gi = tile * 64 + lane;
             const bool live = gi < n;
-            if (live) norms[row0 + gi] = mag;
+            if (live) {
+                norms[row0 + gi] = mag;
+                inv_norms[row0 + gi] = mag == 0.0f ? 0.0f : 1.0f / mag;  // for the batched cosine sweep's epilogue
+            }
             if (live && mag == mag) mx_norm = __builtin_fmaxf(mx_norm, mag);
             if constexpr (HALF) {
                 const float e = __builtin_sqrtf(err2) * 1.0005f;  // (slack: the reference of this bound is a different summation order)
@@ -222,8 +225,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) ingest_kernel(const float* __r
 bool ingest_supported(uint32_t ld, uint32_t dim) { return dim % 8u == 0 && ld % kStageFloats == 0 && ld >= (uint32_t)kStageFloats; }
 
 // magnitudes of rows [row0, row0 + n) (reference order) and, with `half`, their bf16 mirror rows + the mirror's error norms
-hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, uint32_t* max_norm_bits,
-                         float* half, uint32_t* err_bits, hipStream_t s) {
+hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms,
+                         uint32_t* max_norm_bits, float* half, uint32_t* err_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t n_tiles = (n + 63) / 64;
     // one workgroup per CU and a few more for the tail; every wave owns tiles gw, gw + n_waves, ...
@@ -232,7 +235,7 @@ hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64
     auto kern = half ? ingest_kernel<true> : ingest_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds, s, corpus, ld, row0, n, norms, max_norm_bits, half, err_bits);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds, s, corpus, ld, row0, n, norms, inv_norms, max_norm_bits, half, err_bits);
     return hipGetLastError();
 }
 

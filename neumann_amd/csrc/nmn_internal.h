@@ -85,6 +85,7 @@ struct ScanParams {
     const float* corpus_half;   // nullable: bf16 mirror (row stride ld/2 floats) the VALU sweep reads instead of `corpus`
     const QState* retry_state;  // nullable: sweep only the queries whose candidate list overflowed (f32 retry of a bf16 pass)
     const float* norms;      // [rows]
+    const float* inv_norms;  // [rows] 1 / |v|, 0 for a zero row (matrix-core cosine sweep)
     const float* qpad;       // [nq][ld] zero padded
     const QInfo* qinfo;      // [nq]
     const uint64_t* mask;    // nullable, ceil(rows/64) words
@@ -116,8 +117,8 @@ bool scan_half_supported(uint32_t ld, int metric);
 // one pass over freshly written rows (nmn_ingest.hip): magnitudes in reference order + (half != nullptr) their bf16 mirror
 // rows and the mirror's error norms folded into err_bits[0..1]
 bool ingest_supported(uint32_t ld, uint32_t dim);
-hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, uint32_t* max_norm_bits,
-                         float* half, uint32_t* err_bits, hipStream_t s);
+hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms,
+                         uint32_t* max_norm_bits, float* half, uint32_t* err_bits, hipStream_t s);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
@@ -197,7 +198,7 @@ hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_
 
 // exact (reference-order) kernels
 hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t row0, uint64_t n, float* norms,
-                        uint32_t* max_norm_bits, hipStream_t s);
+                        float* inv_norms, uint32_t* max_norm_bits, hipStream_t s);
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
                         hipStream_t s, const uint32_t* half_err_bits = nullptr);

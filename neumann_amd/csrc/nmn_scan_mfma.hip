@@ -71,7 +71,8 @@ __device__ __forceinline__ s8 to_bf16x8(const f4& a, const f4& b) {
     return __builtin_bit_cast(s8, h);
 }
 
-constexpr int kMaxRing = 8;      // stages of the deepest ring (norm slots are sized for it)
+constexpr int kNormSlots = 16;   // tiles whose row magnitudes live in LDS at once: the ring's tiles in flight (<= kMaxRing) plus the
+                                 // tile whose epilogue is deferred into the next tile's first stage
 
 // issue the LDS-DMA of one stage into LDS buffer `buf`.  `stage_base` = mirror + (tile*64*ld + kc*128) elements
 // (wave-uniform); `loff[pp]` = this lane's byte offset for piece pp, computed once per kernel.  A piece is one 1-KiB
@@ -90,6 +91,13 @@ __device__ __forceinline__ void stage_dma(const char* stage_base, const uint32_t
     }
 }
 
+template <int AUX, int PIECES>
+__device__ __forceinline__ void stage_dma_piece(const char* stage_base, const uint32_t (&loff)[PIECES], float* buf, uint32_t wave,
+                                                int pp) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stage_base + loff[pp]),
+                                     (__attribute__((address_space(3))) void*)(buf + (wave * PIECES + (uint32_t)pp) * 256u), 16, 0, AUX);
+}
+
 // |v| of the 64 rows of a tile, also by LDS-DMA (one dword per lane): the streaming loop then contains
 // no ordinary VGPR-destination load, so nothing makes the compiler drain the DMA queue with vmcnt(0).
 __device__ __forceinline__ void norms_dma(const float* __restrict__ norms, uint64_t tile, float* nbuf, uint32_t lane) {
@@ -97,20 +105,26 @@ __device__ __forceinline__ void norms_dma(const float* __restrict__ norms, uint6
                                      (__attribute__((address_space(3))) void*)nbuf, 4, 0, 0);
 }
 
-// wait until at most `stages_after` younger stages (PIECES DMA ops each) are still in flight.  vmcnt retires
-// in issue order on gfx9-class parts, so this guarantees the oldest stage has landed; the few extra
-// ops some waves carry (norm DMA, epilogue stores) only make the wait slightly conservative.
+// wait until at most `stages_after` younger stages (PIECES DMA ops each) are still in flight.  vmcnt retires in issue
+// order on gfx9-class parts (loads, LDS-DMA and stores alike), so this guarantees the oldest stage has landed; the few
+// extra ops some waves carry (norm DMA, epilogue stores) only make the wait slightly conservative.  (Counting those
+// extras exactly — a per-wave tally and a branch tree that picks the immediate — was measured: no gain, the
+// bookkeeping cost what the shorter waits saved.)
+template <int N>
+__device__ __forceinline__ void wait_vm_imm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 template <int PIECES>
 __device__ __forceinline__ void wait_stage(uint32_t stages_after) {
     static_assert(PIECES == 4 || PIECES == 8, "vmcnt immediates below");
     switch (stages_after * PIECES) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 0: wait_vm_imm<0>(); break;
+        case 4: wait_vm_imm<4>(); break;
+        case 8: wait_vm_imm<8>(); break;
+        case 12: wait_vm_imm<12>(); break;
+        case 16: wait_vm_imm<16>(); break;
+        case 20: wait_vm_imm<20>(); break;
+        default: wait_vm_imm<24>(); break;
     }
 }
 
@@ -139,8 +153,8 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;  // 1/(1+d), or -d (IVF list scans)
     constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || kL2;  // |v| of the tile's rows
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | norms
-    float* nrm = lds + kRingBytes / 4;                           // [kMaxRing tiles][64] row magnitudes (with one-stage
-                                                                 // tiles up to kRing tiles are in flight at once)
+    float* nrm = lds + kRingBytes / 4;                           // [kNormSlots tiles][64] row magnitudes — cosine: their INVERSES
+                                                                 // (ScanParams::inv_norms: one rcp per row at ingest, not 16 per lane here)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
@@ -215,17 +229,20 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         loff[pp] = r * ld * 2u + (((lane % LR) ^ (r & 15u)) * 16u);
     }
     const char* const mirror = reinterpret_cast<const char*>(p.corpus_half);
+    const float* const norm_src = METRIC == NMN_METRIC_COSINE ? p.inv_norms : p.norms;
     auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const char* {
         return mirror + ((uint64_t)tile_ * tstep * kTileRows * ld + kc_ * kStageElems) * 2ull;
     };
 
     // prologue: stages 0..kRing-2 in flight (stage s lives in ring slot s % kRing)
 #pragma unroll
-    for (uint32_t s0 = 0; s0 < kRing - 1; s0++) {
+    for (uint32_t s0 = 0; s0 < kRing; s0++) {
         if (s0 < n_stage) {
+            // (the magnitudes of stage kRing - 1's tile too: its pieces go out during the first iteration)
             if (kNeedNorms && wave == 0 && s0 % KC == 0)
-                norms_dma(p.norms, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kRing) * 64u, lane);
-            stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
+                norms_dma(norm_src, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kNormSlots) * 64u, lane);
+            if (s0 < kRing - 1)
+                stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         }
     }
 
@@ -235,6 +252,131 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
 #pragma unroll
     for (int ks = 0; ks < kSteps; ks++)
         off[ks] = n * kRowPitch + ((((kh * (uint32_t)kSteps + (uint32_t)ks) * 4u + g) ^ n) * 4u);
+
+    // ---- epilogue of one tile: scores, per-(query,tile) maximum, score writes — for the accumulators `facc` of tile `ftile`.
+    // (One wave per SIMD: nothing overlaps it, so it is kept short — see kLazy below.  Deferring it into the next tile's first
+    // stage was tried: its branches (partial tiles, score writes) cut that stage's basic block in two and cost the read / MFMA
+    // interleave more than the overlap returned.)
+    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile) __attribute__((always_inline)) {
+        constexpr int H = decltype(half_c)::value;
+        const uint32_t qn = qn_h[H];
+        const bool q_ok = q_ok_h[H];
+        const float qmag = qmag_h[H];
+        const uint32_t skip = skip_h[H];
+        f4 fin[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) fin[rb] = facc[rb][H];
+        // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
+        const uint64_t rtile = (uint64_t)ftile * tstep;  // real tile index (sampling pass: every tstep-th)
+        const uint64_t r0 = rtile * kTileRows;
+        const float* nslot = nrm + ((ftile - t0) % kNormSlots) * 64u;
+        uint64_t mword = ~0ull;
+        if constexpr (MASKED) {
+            // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
+            const uint64_t* mq = p.qmasks ? (q_ok ? p.qmasks[qn] : nullptr) : p.mask;
+            if (mq) mword = mq[rtile];
+        }
+        const uint64_t left = p.n_rows - r0;
+        if (left < 64) mword &= (1ull << left) - 1ull;
+        uint32_t tkey = kKeyMasked;
+        u4 bits[4];
+        const float inv_q = qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag);
+        const float qq = qmag * qmag;
+        (void)inv_q;
+        (void)qq;
+        // cosine / dot product with every row taking part (the common case): only the tile MAXIMUM is needed unless the tile
+        // can still hold a candidate (~2 % of the tiles), so the per-row work is one multiply by the row's inverse magnitude
+        // and a max; the query's 1/|q| (>= 0: monotone, rounding included) is applied once to the maximum, and the 16
+        // score words are formed only when they are written.
+        constexpr bool kLazy = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_DOT_PRODUCT;
+        const bool full = mword == ~0ull;
+        if (full) {
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                f4 sc = fin[rb];
+                if constexpr (METRIC == NMN_METRIC_COSINE) {
+                    // (a zero row has inverse magnitude 0: its score is 0 like cosine_similarity's; v_rcp at ingest: 1 ulp,
+                    // the margin has 1000x that slack)
+                    sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+                    fin[rb] = sc;
+                }
+                if constexpr (kL2) {
+                    const f4 vn = *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sc[e] = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (!kLazy) bits[rb][e] = f2u(sc[e]);
+                    m = __builtin_fmaxf(m, sc[e]);  // v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its key
+                }
+            }
+            if constexpr (METRIC == NMN_METRIC_COSINE) m = m * inv_q;
+            tkey = score_to_key(m);
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
+                f4 vn = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (kNeedNorms) vn = *reinterpret_cast<const f4*>(nslot + rr);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
+                    float sc = fin[rb][e];
+                    if constexpr (METRIC == NMN_METRIC_COSINE) sc = (sc * vn[e]) * inv_q;  // vn = 1 / |v| here
+                    if constexpr (kL2) sc = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc);
+                    bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
+                    if (valid) tkey = max(tkey, score_to_key(sc));
+                }
+            }
+        }
+        // tile maximum of query n: combine the four lane groups (v_permlane32_swap / v_permlane16_swap: no LDS round trip)
+        {
+            const auto r32 = __builtin_amdgcn_permlane32_swap(tkey, tkey, false, false);
+            tkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
+            const auto r16 = __builtin_amdgcn_permlane16_swap(tkey, tkey, false, false);
+            tkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
+        }
+        if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + ftile] = tkey;
+        wmax_h[H] = max(wmax_h[H], tkey);
+        // Scores are only worth their HBM write when the tile can still hold a candidate: with a
+        // per-query bound from the sampling pass ~2 % of the tiles qualify (64 queries x 10M rows would
+        // otherwise write 2.56 GB per sweep, measured at +1.45 ms on a 5.3 ms sweep).
+#ifdef NMN_MFMA_NO_SCORE_WRITES
+        if (false) {
+#else
+        if (q_ok && !sampling && tkey != kKeyMasked && tkey >= skip) {
+#endif
+            const uint64_t wr0 = r0;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                u4 w = bits[rb];
+                if constexpr (kLazy) {
+                    if (full) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) w[e] = f2u(METRIC == NMN_METRIC_COSINE ? fin[rb][e] * inv_q : fin[rb][e]);
+                    }
+                }
+                *reinterpret_cast<u4*>(p.scores + score_at(wr0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = w;
+            }
+        }
+    };
+    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile) __attribute__((always_inline)) {
+#ifdef NMN_MFMA_NO_EPILOGUE
+        {  // measurement only (-DNMN_MFMA_NO_EPILOGUE build): the sweep without its epilogue (answers are wrong)
+            float sink_v = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                for (int qg = 0; qg < kAccGroups; qg++) sink_v += facc[rb][qg][0] + facc[rb][qg][1] + facc[rb][qg][2] + facc[rb][qg][3];
+            if (sink_v == 1.2345e-30f) p.tmax[0] = 1u;
+            return;
+        }
+#endif
+        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile);
+        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile);
+    };
 
     uint32_t sidx = 0;  // running stage index of this workgroup
     for (uint32_t tile = t0; tile < t1; tile++) {
@@ -250,61 +392,85 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
             // younger stages stay in flight) and all waves met at the barrier.  WAR: a wave reaches this
             // barrier only after consuming (lgkmcnt) its reads of stage sidx-1, whose ring slot is the
             // one the DMA issued right below (stage sidx+kRing-1) overwrites.
-            wait_stage<kPieces>(min(n_stage - 1u - sidx, (uint32_t)(kRing - 2)));
+            wait_vm_imm<(kRing - 2) * kPieces>();  // (pieces are issued for every stage, real or dummy: always kRing - 2 younger stages)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            {
-                const uint32_t ns = sidx + (kRing - 1);
-                if (ns < n_stage) {
-                    const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
-                    if (kNeedNorms && wave == 0 && nkc == 0)
-                        norms_dma(p.norms, (uint64_t)nt * tstep, nrm + ((nt - t0) % kRing) * 64u, lane);
-                    stage_dma<AUX, kPieces>(stage_src(nt, nkc), loff, lds + (ns % kRing) * (kStageBytes / 4), wave);
-                }
-            }
-            // A fragments straight from the bf16 stage: chunk g of this wave's k-step = 8 consecutive elements of row n.
+            // The pieces of stage sidx + kRing - 1 go into the ring slot consumed one iteration ago.  They are NOT issued here in
+            // one burst: an LDS-DMA instruction holds the wave's issue port for 100-185 cycles when four waves fire eight each
+            // right behind the barrier (measured with s_memtime: 1150 of the ~2400 cycles of a stage, more than its MFMAs) but
+            // only ~25-60 in the shadow of running MFMAs — so they are spread over the stage's MFMA stream below, one per
+            // k-step.  And they are issued UNCONDITIONALLY: past the end of the workgroup's range every lane re-reads the first
+            // 16 bytes of the mirror into a slot nobody will read (one cache line per instruction), so that the stage body is
+            // one basic block — a branch around each piece would cut it into nine scheduling regions and with them the
+            // read / MFMA / DMA interleave that sched_group_barrier lays out below.
+            const uint32_t ns = sidx + (kRing - 1);
+            const bool issue = ns < n_stage;
+            const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
+            const char* const nsrc = issue ? stage_src(nt, nkc) : mirror;
+            const uint32_t lmask = issue ? 0xFFFFFFFFu : 0u;  // (scalar: the per-lane offsets are ANDed away in the tail)
+            float* const nbuf = lds + (ns % kRing) * (kStageBytes / 4);
+            // The stage body, in the order it is meant to issue (every __builtin_amdgcn_sched_barrier(0) is a fence the
+            // scheduler moves nothing across): the A-fragment reads of batch b + 1 go out BEFORE the MFMAs of batch b, so the
+            // LDS round trip of a batch hides behind a whole batch of MFMAs; each k-step's 4 * kBG MFMAs are followed by that
+            // k-step's DMA piece(s) of the stage ahead (see above).  A fragment = one ds_read_b128: chunk g of the k-step = 8
+            // consecutive bf16 of row n.  (sched_group_barrier pipelines could not place the LDS-DMA instructions — they are
+            // both VMEM and DS to the scheduler — and left them in one clump.)
+            constexpr int kKsPerBatch = (kBK * kBG * 4 >= 256) ? 1 : 2;  // k-steps whose fragments are read together (8 reads);
+                                                                         // 192+ VGPRs of stationary fragments: 4 reads at a time
+            static_assert(kSteps % kKsPerBatch == 0, "batches tile the stage");
+            constexpr int kNB = kSteps / kKsPerBatch;
             s8 a[kSteps][4];
+            auto read_batch = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ks = 0; ks < kSteps; ks++)
+                for (int ks = b * kKsPerBatch; ks < (b + 1) * kKsPerBatch; ks++)
 #pragma unroll
-                for (int rb = 0; rb < 4; rb++)
-                    a[ks][rb] = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kRowPitch + off[ks]));
+                    for (int rb = 0; rb < 4; rb++)
+                        a[ks][rb] = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kRowPitch + off[ks]));
+            };
+            static_assert(kPieces == kSteps || kHalfK, "one DMA piece per k-step of the stage");
+#ifdef NMN_MFMA_BURST_DMA  // A/B: all pieces in one burst behind the barrier (round 1's order)
 #pragma unroll
-            for (int ks = 0; ks < kSteps; ks++) {
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-                    for (int qg = 0; qg < kBG; qg++)
-                        acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
-            }
-#ifndef NMN_MFMA_NO_SCHED
-            // Left alone the scheduler emits read, wait lgkmcnt(0), MFMAs, read, ... (the 256 architectural VGPRs are
-            // full, and with LDS-DMA in flight every LDS wait the compiler inserts is a full drain): each LDS round
-            // trip is exposed and the matrix cores idle two cycles out of three.  Order the stage in batches of
-            // kBatch fragment reads: the reads of batch b+1 are issued in one go BEFORE the MFMAs of batch b, so the
-            // drain in front of batch b+1's MFMAs finds reads that are a whole batch of MFMAs old.
-            // (dot product, 128 queries of 1024-element rows: the ordered version spills DMA addresses inside the loop —
-            // a reload there is a vmcnt(0), which drains the whole DMA ring; left to the scheduler it does not)
-            if constexpr (!(METRIC == NMN_METRIC_DOT_PRODUCT && kBK * kBG * 4 == 256)) {
-                // (stationary fragments of 256+ VGPRs leave room for a quarter batch only: more spills in the loop)
-                constexpr int kWant = (kBK * kBG * 4 >= 256) ? NMN_MFMA_BATCH / 4 : NMN_MFMA_BATCH;
-                constexpr int kReads = kSteps * 4, kBatch = kReads < kWant ? kReads : kWant;
-                static_assert(kReads % kBatch == 0, "batches tile the stage");
-                __builtin_amdgcn_sched_group_barrier(0x100, kBatch, 0);
-#pragma unroll
-                for (int b = 1; b < kReads / kBatch; b++) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, kBatch, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, kBatch * kBG, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, kBatch * kBG, 0);
-            }
+            for (int pp = 0; pp < kPieces; pp++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
+                                                 (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
+            read_batch(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < kNB; b++) {
+                if (b + 1 < kNB) read_batch(b + 1);
+#pragma unroll
+                for (int ks = b * kKsPerBatch; ks < (b + 1) * kKsPerBatch; ks++) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                        for (int qg = 0; qg < kBG; qg++)
+                            acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
+                    // one piece of the stage ahead per k-step (K-halves: two, their waves multiply half the k-steps of a stage each)
+#ifndef NMN_MFMA_BURST_DMA
+#pragma unroll
+                    for (int pp = ks * (kPieces / kSteps); pp < (ks + 1) * (kPieces / kSteps); pp++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
+                                                         (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // row magnitudes of the tile whose first stage was just issued (its epilogue is >= kRing - 1 stages away); outside
+            // the stage's basic block.  One extra entry in wave 0's vmcnt queue per tile: its next waits are one piece conservative.
+            // (issued for the tile of stage ns + 1, i.e. BEFORE that stage's pieces go out in the next iteration: in-order vmcnt then
+            // lands it with them, and every wave passes a barrier behind wave 0's wait before the tile's epilogue reads it)
+            if (kNeedNorms && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) {
+                const uint32_t nt1 = t0 + (ns + 1u) / KC;
+                norms_dma(norm_src, (uint64_t)nt1 * tstep, nrm + ((nt1 - t0) % kNormSlots) * 64u, lane);
+            }
         }
         if constexpr (kHalfK) {
             // the two K-halves of a group meet: wave kh = 1 publishes, wave kh = 0 adds and finishes.  (The next
             // publication is a whole tile of stage barriers away: no second barrier needed.)
-            float* xch = nrm + kMaxRing * 64;  // [2 groups][64 lanes][4 row blocks] f4
+            float* xch = nrm + kNormSlots * 64;  // [2 groups][64 lanes][4 row blocks] f4
             if (kh == 1) {
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++)
@@ -319,98 +485,12 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                     acc[rb][0] += *reinterpret_cast<const f4*>(xch + ((grp * 64u + lane) * 4u + (uint32_t)rb) * 4u);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            finish_tile(acc, tile);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
+        } else {
+            finish_tile(acc, tile);
         }
-        // ---- the accumulators are the final dot products: scores, tile maxima, score writes per query group
-        auto finish_half = [&](auto half_c) __attribute__((always_inline)) {
-        constexpr int H = decltype(half_c)::value;
-        const uint32_t qn = qn_h[H];
-        const bool q_ok = q_ok_h[H];
-        const float qmag = qmag_h[H];
-        const uint32_t skip = skip_h[H];
-        f4 fin[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++) fin[rb] = acc[rb][H];
-        {
-            // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
-            const uint64_t rtile = (uint64_t)tile * tstep;  // real tile index (sampling pass: every tstep-th)
-            const uint64_t r0 = rtile * kTileRows;
-            uint64_t mword = ~0ull;
-            if constexpr (MASKED) {
-                // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
-                const uint64_t* mq = p.qmasks ? (q_ok ? p.qmasks[qn] : nullptr) : p.mask;
-                if (mq) mword = mq[rtile];
-            }
-            const uint64_t left = p.n_rows - r0;
-            if (left < 64) mword &= (1ull << left) - 1ull;
-            uint32_t tkey = kKeyMasked;
-            u4 bits[4];
-            const float inv_q = qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag);
-            const float qq = qmag * qmag;
-            (void)inv_q;
-            (void)qq;
-            if (mword == ~0ull) {
-                // every row of the tile takes part (the common case): the tile maximum is taken on the scores themselves
-                // (v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its true key) and converted once
-                float m = -__builtin_inff();
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    f4 sc = fin[rb];
-                    if constexpr (METRIC == NMN_METRIC_COSINE) {
-                        // approximate score: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the margin
-                        // has 1000x that slack.  A zero norm gives rcp = +inf: forced to 0 like cosine_similarity does.
-                        const f4 vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + (uint32_t)rb * 16u + g * 4u);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) sc[e] = vn[e] == 0.f ? 0.f : sc[e] * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
-                    }
-                    if constexpr (kL2) {
-                        const f4 vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + (uint32_t)rb * 16u + g * 4u);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) sc[e] = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc[e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        bits[rb][e] = f2u(sc[e]);
-                        m = __builtin_fmaxf(m, sc[e]);
-                    }
-                }
-                tkey = score_to_key(m);
-            } else {
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
-                    f4 vn = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (kNeedNorms)
-                        vn = *reinterpret_cast<const f4*>(nrm + ((tile - t0) % kRing) * 64u + rr);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
-                        float sc = fin[rb][e];
-                        if constexpr (METRIC == NMN_METRIC_COSINE)
-                            sc = vn[e] == 0.f ? 0.f : sc * (inv_q * __builtin_amdgcn_rcpf(vn[e]));
-                        if constexpr (kL2) sc = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc);
-                        bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
-                        if (valid) tkey = max(tkey, score_to_key(sc));
-                    }
-                }
-            }
-            // tile maximum of query n: combine the four lane groups
-            tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 16));
-            tkey = max(tkey, (uint32_t)__shfl_xor((int)tkey, 32));
-            if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + tile] = tkey;
-            wmax_h[H] = max(wmax_h[H], tkey);
-            // Scores are only worth their HBM write when the tile can still hold a candidate: with a
-            // per-query bound from the sampling pass ~2 % of the tiles qualify (64 queries x 10M rows would
-            // otherwise write 2.56 GB per sweep, measured at +1.45 ms on a 5.3 ms sweep).
-            if (q_ok && !sampling && tkey != kKeyMasked && tkey >= skip) {
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++)
-                    *reinterpret_cast<u4*>(p.scores + score_at(r0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = bits[rb];
-            }
-        }
-        };
-        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{});
-        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{});
     }
+    wait_vm_imm<0>();  // the dummy pieces of the tail must have landed before this workgroup's LDS is handed to the next one
     if (sampling) return;  // the sampling pass leaves only tmax
 #pragma unroll
     for (int h = 0; h < kHalves; h++)
@@ -428,7 +508,7 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
         pf.fold_ny = ny;
         grid = dim3(((blocks + 7u) / 8u) * 8u * ny, 1);
     }
-    const size_t lds = kRingBytes + kMaxRing * 64 * 4 + (QG == 2 ? 2 * 64 * 4 * 16 : 0);  // + the K-halves' exchange
+    const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG == 2 ? 2 * 64 * 4 * 16 : 0);  // + the K-halves' exchange
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
     auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

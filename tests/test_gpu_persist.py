@@ -106,7 +106,7 @@ def test_engine_binary_round_trip_rebuilds_the_mirror_at_once(tmp_path):
     e.create_collection("docs", VectorCollectionConfig().with_dimension(48))
     vecs = {f"d{i}": rng.standard_normal(48).astype(np.float32) for i in range(700)}
     for i, (k, v) in enumerate(vecs.items()):
-        e.store_in_collection("docs", k, v, {"bucket": i % 7, "tag": f"t{i % 3}"})
+        e.store_in_collection_with_metadata("docs", k, v, {"bucket": i % 7, "tag": f"t{i % 3}"})
     e.delete_from_collection("docs", "d13")
     vecs.pop("d13")
     q = rng.standard_normal(48).astype(np.float32)

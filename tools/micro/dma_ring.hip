@@ -33,7 +33,13 @@ __device__ __forceinline__ void wait_vm() {
 
 // STAGE bytes per stage, RING stages, WAVES per workgroup.  SEGB > 0: stage = [STAGE/SEGB rows][SEGB bytes] of rows with pitch
 // `pitch` (kc-th segment of each row); SEGB == 0: stage = STAGE contiguous bytes.
-template <int STAGE, int RING, int AUX, int SEGB, int WAVES>
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+// WORK: 0 = every wave reads 4 x 16 B per lane of the stage (the ring alone); 1 = every wave reads the WHOLE stage
+// (STAGE/1024 ds_read_b128 per wave: the query-split layout of nmn_scan_mfma.hip); 2 = + one v_mfma_f32_16x16x32_bf16 per read;
+// 3 = + a per-tile epilogue like the sweep's (16 rcp / max per lane every 3 stages, one 16-byte store per lane and tile)
+template <int STAGE, int RING, int AUX, int SEGB, int WAVES, int WORK = 0>
 __global__ void __launch_bounds__(WAVES * 64, 1) ring_kernel(const char* __restrict__ src, uint64_t wg_bytes, uint32_t pitch,
                                                              float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -73,6 +79,10 @@ __global__ void __launch_bounds__(WAVES * 64, 1) ring_kernel(const char* __restr
     for (uint32_t s = 0; s < RING - 1; s++)
         if (s < n_stage) issue(s);
     v4f acc = {0.f, 0.f, 0.f, 0.f};
+    v4f macc[4] = {acc, acc, acc, acc};
+    s8v bfrag[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) bfrag[i] = (s8v){(short)(lane + i), 1, 2, 3, 4, 5, 6, (short)i};
     for (uint32_t s = 0; s < n_stage; s++) {
         const uint32_t after = n_stage - 1u - s < (uint32_t)(RING - 2) ? n_stage - 1u - s : (uint32_t)(RING - 2);
         if (after == RING - 2) wait_vm<(RING - 2) * PIECES>();
@@ -80,16 +90,48 @@ __global__ void __launch_bounds__(WAVES * 64, 1) ring_kernel(const char* __restr
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + RING - 1 < n_stage) issue(s + RING - 1);
-        // consume: every wave reads a quarter of the stage (4 ds_read_b128)
         const float* buf = lds + (s % RING) * (STAGE / 4);
+        if constexpr (WORK == 0) {
+            // consume: every wave reads a quarter of the stage (4 ds_read_b128)
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc += *reinterpret_cast<const v4f*>(buf + ((wave * 4 + i) * 64u + lane) * 4u);
+            for (int i = 0; i < 4; i++) acc += *reinterpret_cast<const v4f*>(buf + ((wave * 4 + i) * 64u + lane) * 4u);
+        } else {
+            constexpr int NR = STAGE / 1024;
+            u4v a[NR];
+#pragma unroll
+            for (int i = 0; i < NR; i++) a[i] = *reinterpret_cast<const u4v*>(buf + ((uint32_t)i * 64u + (lane ^ (uint32_t)(i & 15))) * 4u);
+            if constexpr (WORK == 1) {
+#pragma unroll
+                for (int i = 0; i < NR; i++) acc[0] += __uint_as_float(a[i][0] ^ a[i][3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NR; i++)
+                    macc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s8v, a[i]), bfrag[i % 8], macc[i & 3], 0, 0, 0);
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (WORK == 3) {
+            if (s % 3 == 2) {  // "tile" epilogue
+                float m = -1e30f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float sc = macc[r][e] * __builtin_amdgcn_rcpf(1.0f + __builtin_fabsf(macc[r][e]));
+                        m = __builtin_fmaxf(m, sc);
+                        macc[r][e] = 0.f;
+                    }
+                m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+                if ((lane >> 4) == 0) sink[64 + ((blockIdx.x * WAVES + wave) * 16u + (lane & 15u))] = m;
+            }
+        }
     }
+    if constexpr (WORK >= 2) acc += macc[0] + macc[1] + macc[2] + macc[3];
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
 }
 
-template <int STAGE, int RING, int AUX, int SEGB, int WAVES>
+template <int STAGE, int RING, int AUX, int SEGB, int WAVES, int WORK = 0>
 static void run(const char* name, const char* src, uint64_t total_bytes, uint32_t pitch, uint32_t wgs, float* sink) {
     // whole tiles of 64 rows per workgroup
     const uint64_t tile_bytes = 64ull * pitch;
@@ -100,7 +142,7 @@ static void run(const char* name, const char* src, uint64_t total_bytes, uint32_
         printf("%-44s: skipped (workgroup range not a multiple of the stage)\n", name);
         return;
     }
-    auto k = ring_kernel<STAGE, RING, AUX, SEGB, WAVES>;
+    auto k = ring_kernel<STAGE, RING, AUX, SEGB, WAVES, WORK>;
     const size_t lds = (size_t)STAGE * RING;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         printf("%-44s: LDS %zu too large\n", name, lds);
@@ -125,6 +167,17 @@ static void run(const char* name, const char* src, uint64_t total_bytes, uint32_
     hipEventDestroy(b);
 }
 
+__global__ void fill_random(uint32_t* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = i * 0x9E3779B97F4A7C15ull + 0x1234567;
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 32;
+        // two bf16 values of magnitude ~1 with random mantissas and signs
+        p[i] = ((uint32_t)x & 0x807F807Fu) | 0x3F803F80u;
+    }
+}
+
 int main(int argc, char** argv) {
     const uint32_t pitch = argc > 1 ? (uint32_t)atoi(argv[1]) : 1536;  // bytes per mirror row (768 bf16)
     const uint64_t rows = 10000000ull / 64 * 64;
@@ -135,9 +188,23 @@ int main(int argc, char** argv) {
         printf("alloc failed\n");
         return 1;
     }
-    hipMemset(buf, 1, bytes);
+    if (argc > 3) hipMemset(buf, 1, bytes);  // constant data (lower power: clocks differ)
+    else hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(buf), (size_t)(bytes / 4));
     hipDeviceSynchronize();
     printf("mirror %.2f GB, row pitch %u B\n", bytes / 1e9, pitch);
+    if (argc > 2) {  // consumption models on the two layouts, 1024 workgroups
+        const uint32_t wgs = 1024;
+        run<32768, 4, 2, 512, 4, 0>("SEG  4x32K nt   ring alone", buf, bytes, pitch, wgs, sink);
+        run<32768, 4, 2, 512, 4, 1>("SEG  4x32K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
+        run<32768, 4, 2, 512, 4, 2>("SEG  4x32K nt   + reads + MFMA", buf, bytes, pitch, wgs, sink);
+        run<32768, 4, 2, 512, 4, 3>("SEG  4x32K nt   + reads + MFMA + epilogue", buf, bytes, pitch, wgs, sink);
+        run<24576, 6, 2, 0, 4, 1>("FULL 6x24K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
+        run<24576, 6, 2, 0, 4, 2>("FULL 6x24K nt   + reads + MFMA", buf, bytes, pitch, wgs, sink);
+        run<24576, 6, 2, 0, 4, 3>("FULL 6x24K nt   + reads + MFMA + epilogue", buf, bytes, pitch, wgs, sink);
+        run<16384, 8, 2, 256, 4, 2>("SEG  8x16K nt   + reads + MFMA", buf, bytes, pitch, wgs, sink);
+        run<32768, 4, 2, 512, 8, 2>("SEG  4x32K nt 8 waves + reads + MFMA (each wave whole stage)", buf, bytes, pitch, wgs, sink);
+        return 0;
+    }
     for (uint32_t wgs : {256u, 512u, 1024u, 2048u}) {
         run<32768, 4, 2, 512, 4>("SEG  64x512B  ring 4x32K nt (round 1)", buf, bytes, pitch, wgs, sink);
         run<32768, 4, 0, 512, 4>("SEG  64x512B  ring 4x32K default", buf, bytes, pitch, wgs, sink);
