@@ -142,13 +142,13 @@ __device__ __forceinline__ float l2_score(float qq, float vn, float dot) {
     return NEG ? -d : __builtin_amdgcn_rcpf(1.0f + d);
 }
 
-template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX>
-__global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 1) scan_mfma_kernel(ScanParams p) {
     constexpr int kStageElems = 128 * KS;                        // elements of a row per stage
     constexpr int kStageBytes = kTileRows * kStageElems * 2;     // 16 / 32 KiB of bf16
     constexpr int kRowPitch = kStageElems / 2;                   // LDS row pitch of a stage, in floats
     constexpr int kRing = kRingBytes / kStageBytes;              // 8 / 4 stages (all but one in flight)
-    constexpr int kPieces = 4 * KS;                              // 1-KiB DMA instructions per wave and stage
+    constexpr int kPieces = 16 * KS / WAVES;                     // 1-KiB DMA instructions per wave and stage (4 waves: 4 / 8, 8 waves: 2 / 4)
     constexpr uint32_t LR = 16 * KS;                             // lanes (16-B chunks) per row of a stage
     constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;  // 1/(1+d), or -d (IVF list scans)
     constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || kL2;  // |v| of the tile's rows
@@ -173,19 +173,22 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     // QG = 2 (rows of 2048 / 3072 / 4096 elements: half a group's B-fragments already take 128 / 192 / 256 VGPRs): the workgroup keeps 32
     // queries, and a group is shared by TWO waves that split the k-steps of every stage between them (kh = 0 / 1); their
     // partial sums meet once per tile through LDS and the kh = 0 wave finishes the group.
-    constexpr bool kHalfK = QG == 2;
-    const uint32_t grp = kHalfK ? (wave & 1u) : wave;  // the (first) query group this wave multiplies
-    const uint32_t kh = kHalfK ? (wave >> 1) : 0u;     // its half of the k-steps of a stage
+    // WAVES = 8 (two waves per SIMD, <= 256 registers each): the stalls of one wave — the barrier, the LDS round trips, the
+    // epilogue — are covered by its SIMD partner; one wave per SIMD left the sweep at the edge of being issue-bound, and its
+    // time moved 7 % from one box (clock) to the next.  64 queries: 4 groups x K-halves; 128 queries: 8 groups, whole K each.
+    constexpr bool kHalfK = QG * 2 == WAVES;
+    static_assert(kHalfK || QG % WAVES == 0, "query groups: one (or more) per wave, or one per wave PAIR");
+    const uint32_t grp = kHalfK ? (wave % (uint32_t)QG) : wave;  // the (first) query group this wave multiplies
+    const uint32_t kh = kHalfK ? (wave / (uint32_t)QG) : 0u;     // its half of the k-steps of a stage
 
     // ---- stationary operand: the wave's query groups x its k-steps of every stage -----------------
     constexpr int kSteps = kHalfK ? 2 * KS : 4 * KS;  // k-steps (32 elements) of a stage this wave multiplies
     constexpr int kBK = KC * kSteps;                  // ... of a row
-    constexpr int kBG = kHalfK ? 1 : QG / 4;          // query groups of this wave: groups wave, wave + 4, ...
+    constexpr int kBG = kHalfK ? 1 : QG / WAVES;      // query groups of this wave: groups wave, wave + WAVES, ...
     s8 bhi[kBK][kBG];
-    static_assert(QG == 2 || QG % 4 == 0, "query groups come in fours (one per wave), or two split over wave pairs");
 #pragma unroll
     for (int qg = 0; qg < kBG; qg++) {
-        const uint32_t qq = q0 + ((uint32_t)qg * 4u + grp) * 16u + n;
+        const uint32_t qq = q0 + ((uint32_t)qg * (uint32_t)WAVES + grp) * 16u + n;
         const bool ok = qq < p.nq;
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
 #pragma unroll
@@ -208,8 +211,8 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
     float qmag_h[kHalves];
 #pragma unroll
     for (int h = 0; h < kHalves; h++) {
-        qn_h[h] = q0 + ((uint32_t)h * 4u + grp) * 16u + n;
-        q_ok_h[h] = kh == 0 && (uint32_t)h * 4u + grp < (uint32_t)QG && qn_h[h] < p.nq;
+        qn_h[h] = q0 + ((uint32_t)h * (uint32_t)WAVES + grp) * 16u + n;
+        q_ok_h[h] = kh == 0 && (uint32_t)h * (uint32_t)WAVES + grp < (uint32_t)QG && qn_h[h] < p.nq;
         qmag_h[h] = q_ok_h[h] ? p.qinfo[qn_h[h]].qmag : 0.f;
         skip_h[h] = (q_ok_h[h] && p.skip_key) ? p.skip_key[qn_h[h]] : kKeyNaN;  // kKeyNaN: write every tile
         wmax_h[h] = kKeyMasked;
@@ -427,7 +430,6 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                     for (int rb = 0; rb < 4; rb++)
                         a[ks][rb] = __builtin_bit_cast(s8, *reinterpret_cast<const u4*>(buf + rb * 16 * kRowPitch + off[ks]));
             };
-            static_assert(kPieces == kSteps || kHalfK, "one DMA piece per k-step of the stage");
 #ifdef NMN_MFMA_BURST_DMA  // A/B: all pieces in one burst behind the barrier (round 1's order)
 #pragma unroll
             for (int pp = 0; pp < kPieces; pp++)
@@ -449,8 +451,9 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
                             acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
                     // one piece of the stage ahead per k-step (K-halves: two, their waves multiply half the k-steps of a stage each)
 #ifndef NMN_MFMA_BURST_DMA
+                    // (pieces ks * kPieces / kSteps .. (ks + 1) * kPieces / kSteps: two, one, or one every other k-step)
 #pragma unroll
-                    for (int pp = ks * (kPieces / kSteps); pp < (ks + 1) * (kPieces / kSteps); pp++)
+                    for (int pp = ks * kPieces / kSteps; pp < (ks + 1) * kPieces / kSteps; pp++)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
                                                          (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
 #endif
@@ -497,7 +500,7 @@ __global__ void __launch_bounds__(256, 1) scan_mfma_kernel(ScanParams p) {
         if (q_ok_h[h] && g == 0) p.wmax[(size_t)qn_h[h] * p.wmax_stride + bx] = wmax_h[h];
 }
 
-template <int KC, int KS, int QG, int METRIC, bool MASKED>
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     const uint32_t ny = (p.nq + QG * 16 - 1) / (QG * 16);
@@ -508,20 +511,20 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
         pf.fold_ny = ny;
         grid = dim3(((blocks + 7u) / 8u) * 8u * ny, 1);
     }
-    const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG == 2 ? 2 * 64 * 4 * 16 : 0);  // + the K-halves' exchange
+    const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0);  // + the K-halves' exchange
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
-    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2>;
+    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2, WAVES>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pf);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, pf);
     return hipGetLastError();
 }
 
-template <int KC, int KS, int QG, int METRIC>
+template <int KC, int KS, int QG, int METRIC, int WAVES = 4>
 static hipError_t launch_kc(const ScanParams& p, hipStream_t s) {
-    return (p.mask || p.qmasks) ? launch_one_mfma<KC, KS, QG, METRIC, true>(p, s)
-                                : launch_one_mfma<KC, KS, QG, METRIC, false>(p, s);
+    return (p.mask || p.qmasks) ? launch_one_mfma<KC, KS, QG, METRIC, true, WAVES>(p, s)
+                                : launch_one_mfma<KC, KS, QG, METRIC, false, WAVES>(p, s);
 }
 
 // row length / 128: rows that are a multiple of 256 elements stream in 32-KiB stages (KS = 2), the others in 16-KiB ones
@@ -531,6 +534,26 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
     // (the matrix cores are ~16 % busy at 64).  B-fragments: 192 VGPRs at 768, 256 / 320 at 1024 / 1280 — there the compiler
     // spills in the one-time fragment build, not in the loop (5M x 1024: two 64-query sweeps 3.43 ms, one of 128 2.18 ms).
     // 1536 would need 384 for the fragments alone.
+    // NMN_MFMA_WAVES=8 (measurement knob): 8-wave workgroups, two waves per SIMD at <= 256 registers each — 64 queries as 4
+    // groups x K-halves on wave pairs, 128 as 8 groups.  Built for 768-element rows only: same answers, and on 10M x 768 the
+    // same time as one wave per SIMD (2.59-2.63 vs 2.53-2.65 ms in one run): the sweep is not waiting on per-wave stalls.
+    static const bool waves8 = [] {
+        const char* e = getenv("NMN_MFMA_WAVES");
+        return e ? atoi(e) == 8 : false;
+    }();
+    if (waves8) {
+        if (p.nq > 64) {
+            switch (p.ld / kStageK) {
+                case 6: return launch_kc<3, 2, 8, METRIC, 8>(p, s);
+                default: break;
+            }
+        } else {
+            switch (p.ld / kStageK) {
+                case 6: return launch_kc<3, 2, 4, METRIC, 8>(p, s);
+                default: break;
+            }
+        }
+    }
     if (p.nq > 64) {
         switch (p.ld / kStageK) {
             case 1: return launch_kc<1, 1, 8, METRIC>(p, s);
