@@ -63,6 +63,7 @@ static bool no_mfma() { static const bool v = env_set("NMN_NO_MFMA"); return v; 
 static bool no_half() { static const bool v = env_set("NMN_NO_HALF"); return v; }
 static bool no_sample() { static const bool v = env_set("NMN_NO_SAMPLE"); return v; }
 static bool no_crowd() { static const bool v = env_set("NMN_NO_CROWD"); return v; }
+static bool no_grid_select() { static const bool v = env_set("NMN_NO_GRID_SELECT"); return v; }  // A/B: one-workgroup fallback select
 
 // ---- host slots ------------------------------------------------------------------------------------
 static bool coalesce_enabled() {
@@ -247,7 +248,8 @@ static void ws_release_core(Workspace* w) {
     void** ptrs[] = {(void**)&w->scores, (void**)&w->tmax, (void**)&w->wmax, (void**)&w->tsample, (void**)&w->skip_key,
                      (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
                      (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
-                     (void**)&w->crowd_rows, (void**)&w->crowd_scores};
+                     (void**)&w->crowd_rows, (void**)&w->crowd_scores, (void**)&w->fb_hist, (void**)&w->fb_list, (void**)&w->fb_count,
+                     (void**)&w->fb_sync};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -289,6 +291,11 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
         HIP_TRY(hipMemset(w->crowd_ctr, 0, 3 * nq * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_rows), (size_t)w->crowd_cap * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_scores), (size_t)w->crowd_cap * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_hist), (6 * 2048 + 2) * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_list), nq * (size_t)NMN_MAX_TOP_K * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_count), nq * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_sync), 8));
+        HIP_TRY(hipMemset(w->fb_sync, 0, 8));
     }
     for (auto& e : w->ev) HIP_TRY(hipEventCreate(&e));
     return NMN_OK;
@@ -908,8 +915,26 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             rp.cand_cap = w->cand_cap;
             rp.metric = (int)metric;
             HIP_TRY(launch_rescore(rp, stream));
+            if (crowd && w->fb_hist && k <= NMN_MAX_TOP_K && !no_grid_select()) {
+                // queries still flagged now hold the exact score of every row: select their top-k with the whole device
+                // (returns at once when none is flagged)
+                FallbackParams fb{};
+                fb.qstate = w->qstate;
+                fb.scores = w->scores;
+                fb.nql = nqc;
+                fb.nq = nqc;
+                fb.k = k;
+                fb.n_rows = n_rows;
+                fb.ghist = w->fb_hist;
+                fb.list = w->fb_list;
+                fb.list_count = w->fb_count;
+                fb.sync = w->fb_sync;
+                HIP_TRY(launch_fallback_select(fb, stream));
+            }
         }
         FinalParams fp{};
+        fp.fb_list = w->fb_list;
+        fp.fb_count = w->fb_count;
         fp.crowd_offset = w->crowd_ctr ? w->crowd_ctr + w->nq_cap : nullptr;
         fp.crowd_rows = w->crowd_rows;
         fp.crowd_scores = w->crowd_scores;

@@ -33,6 +33,11 @@ struct Workspace {
     uint32_t* crowd_rows = nullptr;
     float* crowd_scores = nullptr;
     uint32_t crowd_cap = 0;
+    // device-wide exact-fallback selection (FallbackParams): histograms + counters, per-query lists, grid-barrier counter
+    uint32_t* fb_hist = nullptr;
+    unsigned long long* fb_list = nullptr;
+    uint32_t* fb_count = nullptr;
+    unsigned long long* fb_sync = nullptr;
     uint64_t n_sample_cap = 0;
     uint64_t tmax_stride = 0;
     float* qpad = nullptr;

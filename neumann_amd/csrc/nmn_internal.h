@@ -173,7 +173,22 @@ struct CrowdParams {
 };
 hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s);  // count -> allocate slices -> fill
 
+// Device-wide exact-fallback selection (nmn_select.hip: fallback_select_kernel), shards of >= 2^18 rows
+struct FallbackParams {
+    QState* qstate;             // overflow == 1: exact scores of every row are in `scores`; set to 3 when the list is ready
+    const uint32_t* scores;     // score_at(row, q, nql), exact
+    uint32_t nql, nq, k;
+    uint64_t n_rows;
+    uint32_t* ghist;            // [6][2048] + 2 counters, scratch
+    unsigned long long* list;   // [nq][NMN_MAX_TOP_K] composites (score key << 32 | ~row) of the top-k
+    uint32_t* list_count;       // [nq]
+    unsigned long long* sync;   // grid-barrier counter: zero at allocation, never reset
+};
+hipError_t launch_fallback_select(const FallbackParams& p, hipStream_t s);
+
 struct FinalParams {
+    const unsigned long long* fb_list;  // nullable: lists of fallback_select_kernel (queries with overflow == 3)
+    const uint32_t* fb_count;
     const uint32_t* crowd_offset;  // nullable: slices of the crowd pool (queries with overflow == 2)
     const uint32_t* crowd_rows;
     const float* crowd_scores;

@@ -641,6 +641,139 @@ __device__ uint32_t crowd_select_into(const uint32_t* __restrict__ rows, const f
         k, list, hist, pick, s_misc);
 }
 
+// ---- exact-fallback selection on the WHOLE device (large shards) ----------------------------------------------------------
+// The same 64-bit radix select as exact_select_walk, by kFbGrid workgroups instead of one: a query whose neighbourhood
+// defeats every margin (all rows identical, a degenerate corpus) used to cost one compute unit seven walks over all its
+// exact scores — ~10 ms at 10M rows after the 7 ms exact scan.  Here every workgroup histograms its slice of the scores in
+// LDS, adds the non-empty bins to a global histogram, meets the others at a grid barrier, and then each workgroup picks the
+// digit for itself from the global histogram (identical arithmetic: no second barrier); at most six digits, then one pass
+// appends the composites >= the k-th to the query's list, which final_kernel sorts.  One launch per search on shards of
+// >= 2^18 rows, returning at once when no query is flagged; the grid (64 workgroups: a quarter of the compute units, so that launches of several streams fit side by side) is co-resident by
+// construction, the barrier is a monotonic counter that is never reset (a launch starts at the multiple of the grid size
+// the previous one left it at).
+constexpr uint32_t kFbGrid = 64;  // eight such launches (eight streams) stay co-resident: 1024 threads each, 2048 per CU
+
+__device__ __forceinline__ void fb_grid_barrier(unsigned long long* ctr, unsigned long long* target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // this workgroup's histogram adds / list appends are visible device-wide before it arrives
+        atomicAdd(ctr, 1ull);
+        *target += kFbGrid;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < *target) __builtin_amdgcn_s_sleep(4);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackParams p) {
+    __shared__ uint32_t hist[kBins];
+    __shared__ PickResult pick;
+    __shared__ uint32_t s_cnt;
+    __shared__ unsigned long long s_target;
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+    // anything to do?  (qstate was written by earlier kernels of this stream: every workgroup sees the same flags)
+    bool any = false;
+    for (uint32_t q = 0; q < p.nq; q++) any = any || p.qstate[q].overflow == 1u;
+    if (!any) return;
+    if (tid == 0) {
+        const unsigned long long now = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_target = now / kFbGrid * kFbGrid;  // fewer than kFbGrid arrivals can precede this read: the floor is the launch's base
+    }
+    __syncthreads();
+    const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
+    const uint64_t n_tiles = n_pad / 64, tiles_per = (n_tiles + kFbGrid - 1) / kFbGrid;
+    const uint64_t i0 = min((uint64_t)wg * tiles_per, n_tiles) * 64, i1 = min((uint64_t)(wg + 1) * tiles_per, n_tiles) * 64;
+    auto comp = [](uint64_t i, uint32_t key) -> unsigned long long {
+        return key == kKeyMasked ? 0ull : (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i));
+    };
+    const int shifts[6] = {53, 42, 32, 21, 10, 0};
+    const int widths[6] = {11, 11, 10, 11, 11, 10};
+    for (uint32_t q = 0; q < p.nq; q++) {
+        if (p.qstate[q].overflow != 1u) continue;
+        // zero the global histograms and counters of this query's run, then meet
+        for (uint32_t b = wg * kSelThreads + tid; b < 6u * kBins + 2u; b += kFbGrid * kSelThreads) p.ghist[b] = 0u;
+        fb_grid_barrier(p.sync, &s_target);
+        uint32_t* const g_rows = p.ghist + 6 * kBins;      // participating rows
+        uint32_t* const g_fill = p.ghist + 6 * kBins + 1;  // entries appended to the list
+        unsigned long long prefix = 0ull;
+        uint32_t need = 0, kk = 0;
+        bool empty = false;
+        for (int d = 0; d < 6; d++) {
+            const int nb = 1 << widths[d];
+            for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            const int hi_shift = shifts[d] + widths[d];
+            uint32_t loc = 0;
+            for (uint64_t i = i0 + 4ull * tid; i < i1; i += 4ull * kSelThreads) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.scores + score_at(i, q, p.nql));
+                const uint32_t kv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const unsigned long long c = comp(i + e, bits_to_key(kv[e]));
+                    if (c == 0ull) continue;
+                    loc++;
+                    if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) continue;
+                    atomicAdd(&hist[(uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1)], 1u);
+                }
+            }
+            if (d == 0 && loc) atomicAdd(&s_cnt, loc);
+            __syncthreads();
+            for (int b = tid; b < nb; b += kSelThreads)
+                if (hist[b]) atomicAdd(&p.ghist[d * kBins + b], hist[b]);
+            if (d == 0 && tid == 0 && s_cnt) atomicAdd(g_rows, s_cnt);
+            fb_grid_barrier(p.sync, &s_target);
+            // every workgroup picks the digit from the (now complete) global histogram
+            for (int b = tid; b < kBins; b += kSelThreads)
+                hist[b] = b < nb ? __hip_atomic_load(&p.ghist[d * kBins + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            __syncthreads();
+            if (d == 0) {
+                const uint32_t rows = __hip_atomic_load(g_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                kk = min(p.k, rows);
+                need = kk;
+                if (kk == 0) {
+                    empty = true;
+                    break;
+                }
+            }
+            pick_bin(hist, nb, need, &pick);
+            __syncthreads();
+            prefix |= (unsigned long long)pick.bin << shifts[d];
+            need -= pick.above;
+            const bool done = d == 2 && hist[pick.bin] == need;  // the score key is fixed and every row holding it is wanted
+            __syncthreads();
+            if (done) break;
+        }
+        if (!empty) {
+            // collect: composites >= prefix (exactly kk of them device-wide)
+            for (uint64_t i = i0 + 4ull * tid; i < ((i1 - i0 + 4ull * kSelThreads - 1) / (4ull * kSelThreads)) * (4ull * kSelThreads) + i0;
+                 i += 4ull * kSelThreads) {
+                uint4 v = make_uint4(kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits);
+                if (i < i1) v = *reinterpret_cast<const uint4*>(p.scores + score_at(i, q, p.nql));
+                const uint32_t kv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const unsigned long long c = comp(i + e, bits_to_key(kv[e]));
+                    const bool pred = c != 0ull && c >= prefix;
+                    const uint32_t pos = wave_append(pred, g_fill);
+                    if (pred && pos < NMN_MAX_TOP_K) p.list[(size_t)q * NMN_MAX_TOP_K + pos] = c;
+                }
+            }
+        }
+        fb_grid_barrier(p.sync, &s_target);  // the list is complete (and the histograms may be reused by the next query)
+        if (wg == 0 && tid == 0) {
+            const uint32_t got = empty ? 0u : __hip_atomic_load(g_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.list_count[q] = min(got, (uint32_t)NMN_MAX_TOP_K);
+            p.qstate[q].overflow = 3u;  // final_kernel: the list is ready
+        }
+    }
+}
+
+hipError_t launch_fallback_select(const FallbackParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(fallback_select_kernel, dim3(kFbGrid), dim3(kSelThreads), 0, s, p);
+    return hipGetLastError();
+}
+
 // ---- final sort: candidates by (exact score desc, row asc) -> top-k ---------------------------
 __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     __shared__ unsigned long long list[NMN_MAX_TOP_K];
@@ -654,6 +787,13 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     if (mode == 2) {
         const uint32_t off = p.crowd_offset[q];
         n = crowd_select_into(p.crowd_rows + off, p.crowd_scores + off, p.qstate[q].cand_count, p.k, list, hist, &pick, s_misc);
+    } else if (mode == 3) {  // exact fallback, selected by the device-wide radix select (fallback_select_kernel)
+        n = min(p.fb_count[q], (uint32_t)NMN_MAX_TOP_K);
+        for (uint32_t i = tid; i < n; i += kSelThreads) list[i] = p.fb_list[(size_t)q * NMN_MAX_TOP_K + i];
+        if (tid == 0) {
+            p.qstate[q].cand_count = n;
+            p.qstate[q].overflow = 1u;  // what the statistics report: this query took the exact fallback
+        }
     } else if (mode) {
         n = exact_select_into(p.scores, q, p.nql, p.n_rows, p.k, list, hist, &pick, s_misc);
         if (tid == 0) p.qstate[q].cand_count = n;

@@ -353,3 +353,33 @@ def test_crowd_of_duplicates_on_a_large_shard_is_resolved_from_the_crowd_list():
         for i in range(4):
             er, es = oc.search(A, Q[i], k, 0)
             assert np.array_equal(rows[i], er) and np.all(scores[i] == es), i
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_large_shard_exact_fallback_uses_the_device_wide_select(metric):
+    """Shards of >= 2^18 rows select the exact fallback's top-k with the whole device (fallback_select_kernel: per-workgroup
+    LDS histograms -> global histogram -> grid barrier, six radix digits at most): all rows identical (every row within any
+    margin: crowd path and f32 retry both give up), then a few hundred distinct values with thousands of exact copies each,
+    with a filter, with k up to NMN_MAX_TOP_K, and two flagged queries next to a normal one in one batch."""
+    from neumann_amd import GpuFlatIndex
+    n, d = 300_000, 32
+    rng = np.random.default_rng(31 + metric)
+    A = np.tile(np.linspace(-1, 1, d, dtype=np.float32), (n, 1))
+    q = np.linspace(1, 2, d, dtype=np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        st = check(idx, A, q, 10, metric)
+        assert st.fallback_queries == 1
+        rows, _, _ = idx.search(q, 4096, metric)
+        assert list(rows[0]) == list(range(4096))      # ties by ascending row id, k = NMN_MAX_TOP_K
+        keep = rng.random(n) < 0.01
+        check(idx, A, q, 50, metric, mask=oc.mask_from_bool(keep))
+    base = rng.standard_normal((200, d)).astype(np.float32)
+    A = base[rng.integers(0, 200, n)]                  # ~1500 exact copies of each of 200 vectors
+    Q = np.stack([base[3] + np.float32(0.01), base[7] * np.float32(2.0), rng.standard_normal(d).astype(np.float32)])
+    with GpuFlatIndex(d, n, cand_cap=64) as idx:
+        idx.upload(A)
+        rows, scores, counts, st = idx.search(Q, 300, metric, with_stats=True)   # (crowds of ~1500 copies: the crowd list takes them)
+        for qi in range(3):
+            er, es = oc.search(A, Q[qi], 300, metric, nthreads=8, partial=True, native=True)
+            assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es), qi
