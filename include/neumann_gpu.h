@@ -74,6 +74,11 @@ typedef struct nmn_index nmn_index; /* opaque: one row-range shard resident on o
  * 200 -> 256, 100 -> 128): batches of queries and concurrent callers then take the matrix-core sweep (up to 128 queries per
  * corpus read instead of 4) at the price of that much more HBM and single-query sweep time.  Results are the same. */
 #define NMN_INDEX_WIDE_ROWS 1u
+/* Shards of <= 65 536 rows (<= 64 MiB, dim <= 768) answer a single-query nmn_index_search (k <= 1024) with ONE kernel launch:
+ * exact reference-order scores of every row, selection and sort in that launch, the query in the kernel arguments and the
+ * result written straight into pinned host memory (neumann_amd/csrc/nmn_exact.hip: tiny_search_kernel).  With this flag
+ * such searches take the general pipeline (sweep, select, rescore, final) instead: same answers; for tests and A/B runs. */
+#define NMN_INDEX_NO_SINGLE_LAUNCH 2u
 
 typedef struct nmn_index_desc {
     uint32_t dim;            /* vector dimension d (>0) */

@@ -34,7 +34,7 @@ SOURCES = {
     "nmn_persist.hip": [],
     "nmn_engine.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["nmn_internal.h", "nmn_index.h", "nmn_persist.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
+HEADERS = ["nmn_internal.h", "nmn_index.h", "nmn_persist.h", "nmn_select_dev.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
            os.path.join("..", "..", "include", "neumann_engine.h")]
 
 

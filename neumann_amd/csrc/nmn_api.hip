@@ -63,6 +63,7 @@ static bool no_mfma() { static const bool v = env_set("NMN_NO_MFMA"); return v; 
 static bool no_half() { static const bool v = env_set("NMN_NO_HALF"); return v; }
 static bool no_sample() { static const bool v = env_set("NMN_NO_SAMPLE"); return v; }
 static bool no_crowd() { static const bool v = env_set("NMN_NO_CROWD"); return v; }
+static bool no_tiny() { static const bool v = env_set("NMN_NO_TINY"); return v; }  // A/B: small shards through the 5-launch pipeline
 static bool no_grid_select() { static const bool v = env_set("NMN_NO_GRID_SELECT"); return v; }  // A/B: one-workgroup fallback select
 
 // ---- host slots ------------------------------------------------------------------------------------
@@ -166,6 +167,9 @@ static void ws_free(Workspace* w) {
     if (w->h_qmasks) (void)hipFree(w->h_qmasks);
     for (void* p : {(void*)w->pred_block, (void*)w->pred_masks, (void*)w->pred_counts})
         if (p) (void)hipFree(p);
+    if (w->tiny_pool) (void)hipFree(w->tiny_pool);
+    if (w->tiny_ticket) (void)hipFree(w->tiny_ticket);
+    if (w->tiny_out) (void)hipHostFree(w->tiny_out);
     if (w->pin_pred) (void)hipHostFree(w->pin_pred);
     if (w->pin_in) (void)hipHostFree(w->pin_in);
     if (w->pin_out) (void)hipHostFree(w->pin_out);
@@ -361,7 +365,7 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
     if (!d || !out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (d->dim == 0) return fail_arg(NMN_ERR_EMPTY_VECTOR, "dim == 0");
-    if (d->flags & ~NMN_INDEX_WIDE_ROWS) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "unknown nmn_index_desc.flags bit");
+    if (d->flags & ~(NMN_INDEX_WIDE_ROWS | NMN_INDEX_NO_SINGLE_LAUNCH)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "unknown nmn_index_desc.flags bit");
     uint32_t ld = (d->dim + 7u) & ~7u;  // whole 16-byte chunks of the bf16 mirror too: every row length gets it
     {
         // a row length just short of a multiple of 128 (1000, 960, 1500, 3000, ...) is padded up to it when that costs at
@@ -395,6 +399,7 @@ extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out)
     idx->row_base = d->row_base;
     idx->device = dev;
     idx->cand_cap = d->cand_cap ? d->cand_cap : kDefaultCandCap;
+    idx->no_single_launch = (d->flags & NMN_INDEX_NO_SINGLE_LAUNCH) != 0;
     auto cleanup = [&](nmn_status st) {
         if (idx->corpus) (void)hipFree(idx->corpus);
         if (idx->norms) (void)hipFree(idx->norms);
@@ -1080,6 +1085,39 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     Workspace* w = nullptr;
     nmn_status st = ws_get(idx, s, nq, k, &w);
     if (st != NMN_OK) return st;
+    // ---- a small shard, one query: the whole search is ONE launch (tiny_search_kernel) — the query rides in the kernel
+    // arguments, the kernel writes the result into pinned host memory; no H2D, no D2H, none of the pipeline's buffers
+    if (n_reqs == 1 && nq == 1 && !first.pred_cols && (first.mask == nullptr || first.mask_on_device) &&
+        tiny_supported(idx->rows, idx->ld, idx->dim, k) && !no_tiny() && !idx->no_single_launch) {
+        constexpr size_t kTinyK = 1024, kOffScores = kTinyK * 8, kOffCount = kOffScores + kTinyK * 4;
+        if (!w->tiny_pool) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tiny_pool), 128 * 512 * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tiny_ticket), 4));
+            HIP_TRY(hipMemsetAsync(w->tiny_ticket, 0, 4, s));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->tiny_out), kOffCount + 16, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&w->tiny_out_dev), w->tiny_out, 0));
+        }
+        st = upload_fence_wait(idx, w, s);
+        if (st != NMN_OK) return st;
+        HIP_TRY(launch_tiny_search(idx->corpus, idx->norms, first.mask, idx->rows, idx->row_base, idx->ld, idx->dim, k, first.metric,
+                                   first.queries, w->tiny_pool, w->tiny_ticket, reinterpret_cast<uint64_t*>(w->tiny_out_dev),
+                                   reinterpret_cast<float*>(w->tiny_out_dev + kOffScores),
+                                   reinterpret_cast<uint32_t*>(w->tiny_out_dev + kOffCount), s));
+        const uint64_t rows_now = idx->rows;
+        lk.unlock();
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(first.out_rows, w->tiny_out, (size_t)k * 8);
+        memcpy(first.out_scores, w->tiny_out + kOffScores, (size_t)k * 4);
+        first.out_counts[0] = *reinterpret_cast<const uint32_t*>(w->tiny_out + kOffCount);
+        if (first.stats) {
+            memset(first.stats, 0, sizeof *first.stats);
+            first.stats->rows_scanned = rows_now;
+            first.stats->bytes_scanned = rows_now * (uint64_t)idx->dim * 4ull;  // exact scores straight from the f32 rows
+            first.stats->scan_ms = -1.f;
+            first.stats->total_ms = -1.f;
+        }
+        return NMN_OK;
+    }
     const size_t dim = idx->dim;
     const size_t qn = (size_t)nq * dim, on = (size_t)nq * k;
     const size_t words = (size_t)((idx->rows + 63) / 64);

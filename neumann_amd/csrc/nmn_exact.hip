@@ -15,8 +15,9 @@
 // dependent chain; the 8 partial sums are then added left to right by every thread of the group
 // (shuffles inside the 8-lane group), so no reassociation ever happens.
 #include <algorithm>
+#include <cstring>
 
-#include "nmn_internal.h"
+#include "nmn_select_dev.h"
 
 // Belt and braces: even if a build forgets -ffp-contract=off, nothing below may be contracted.
 #pragma clang fp contract(off)
@@ -412,6 +413,161 @@ hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s) {
     if (blocks > 2048) blocks = 2048;
     dim3 grid((unsigned)blocks, p.nq);
     hipLaunchKernelGGL(exact_scan_kernel, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- the whole SIMILAR TOP-K of a small shard in ONE launch ----------------------------------------------------------------
+// The sizes the reference itself publishes (1k-10k rows of 128 floats, vector_engine/benches/vector_engine_bench.rs:40-61;
+// lib.rs:4255-4276) are launch-bound on a GPU: the five launches of the pipeline, one H2D and one D2H cost 57 us at
+// 10k x 128 while the arithmetic is a microsecond.  Up to 65 536 rows and 64 MiB of corpus one kernel does everything, and
+// nothing else crosses PCIe as a separate operation: the query travels in the KERNEL ARGUMENTS (<= 768 floats), the result
+// is written by the kernel straight into pinned host memory mapped into the device.
+//   * every workgroup: |q| in reference order, the EXACT reference-order score of each of its rows (8 lanes per row as in
+//     exact_scan_kernel: at this size the exact pass is as cheap as an approximate one, so there is no margin machinery
+//     at all), its rows sorted in LDS, its best min(k, rows) composites to a pool;
+//   * the LAST workgroup to finish (ticket counter; release / acquire fences at agent scope) selects the top-k of the pool
+//     (in LDS when it fits, else the 64-bit radix select of the exact fallback) and emits it.
+struct TinyParams {
+    const float* corpus;
+    const float* norms;
+    const uint64_t* mask;  // nullable, DEVICE
+    unsigned long long* pool;  // [grid][kcap] composites (0 = no entry)
+    uint32_t* ticket;      // zero between launches (the last workgroup resets it)
+    uint64_t* out_rows;    // pinned host memory, mapped
+    float* out_scores;
+    uint32_t* out_count;
+    uint64_t n_rows, row_base;
+    uint32_t ld, dim, k, kcap, rows_per_wg;
+    int metric;
+    float q[kTinyMaxDim];
+};
+
+__global__ void __launch_bounds__(kSelThreads) tiny_search_kernel(TinyParams p) {
+    __shared__ unsigned long long list[NMN_MAX_TOP_K];
+    __shared__ uint32_t hist[kBins];
+    __shared__ PickResult pick;
+    __shared__ uint32_t s_misc[2];
+    __shared__ float qlds[kTinyMaxDim];
+    __shared__ float s_qmag;
+    __shared__ uint32_t s_ticket;
+    const uint32_t tid = threadIdx.x, l = tid & 7u, wg = blockIdx.x, G = gridDim.x;
+    for (uint32_t i = tid; i < kTinyMaxDim; i += kSelThreads) qlds[i] = i < p.dim ? p.q[i] : 0.0f;
+    __syncthreads();
+    if (tid < 8) {
+        const float ss = dot8_group<32>(qlds, qlds, p.dim, l);
+        if (tid == 0) s_qmag = sqrt_rn(ss);
+    }
+    __syncthreads();
+    const float qmag = s_qmag;
+    // exact score of this workgroup's rows -> composites in LDS (0 = row does not take part)
+    const uint64_t r0 = (uint64_t)wg * p.rows_per_wg;
+    const uint32_t R = (uint32_t)min((uint64_t)p.rows_per_wg, p.n_rows > r0 ? p.n_rows - r0 : 0ull);
+    uint32_t np2 = 1;
+    while (np2 < max(R, 1u)) np2 <<= 1;
+    for (uint32_t base = 0; base < np2; base += kSelThreads / 8) {
+        const uint32_t ri = base + (tid >> 3);
+        const uint64_t row = r0 + ri;
+        bool valid = ri < R;
+        if (valid && p.mask) valid = ((p.mask[row >> 6] >> (row & 63)) & 1ull) != 0;
+        unsigned long long c = 0ull;
+        if (valid) {  // (uniform per 8-lane group)
+            const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+            const float sc = exact_score(qlds, p.corpus + row * (uint64_t)p.ld, p.dim, qmag, vmag, p.metric, l);
+            c = ((unsigned long long)score_to_key(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+        }
+        if (l == 0 && ri < np2) list[ri] = c;
+    }
+    __syncthreads();
+    // this workgroup's rows in final order (score desc, row asc); its first kcap go to the pool
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (np2 >> 1); t += kSelThreads) {
+                const uint32_t lo = ((t / stride) * stride * 2u) + (t % stride), hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = list[lo], b = list[hi];
+                if ((a < b) == desc) {
+                    list[lo] = b;
+                    list[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < p.kcap; i += kSelThreads) p.pool[(size_t)wg * p.kcap + i] = i < np2 ? list[i] : 0ull;
+    // last workgroup standing merges (release: pool stores visible device-wide before the ticket; acquire before reading)
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        s_ticket = atomicAdd(p.ticket, 1u);
+    }
+    __syncthreads();
+    if (s_ticket != G - 1) return;
+    if (tid == 0) {
+        __threadfence();
+        *p.ticket = 0u;  // for the next launch on this workspace (stream order)
+    }
+    __syncthreads();
+    const uint32_t total = G * p.kcap;
+    if (total <= NMN_MAX_TOP_K) {
+        for (uint32_t i = tid; i < total; i += kSelThreads)
+            list[i] = __hip_atomic_load(&p.pool[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) s_misc[0] = 0;
+        __syncthreads();
+        uint32_t live = 0;
+        for (uint32_t i = tid; i < total; i += kSelThreads) live += list[i] != 0ull;
+        if (live) atomicAdd(&s_misc[0], live);
+        __syncthreads();
+        sort_and_emit(list, total, s_misc[0], p.k, p.row_base, p.out_rows, p.out_scores, p.out_count);  // (empty slots sort last)
+    } else {
+        const uint32_t n_round = (total + kSelThreads - 1) / kSelThreads * kSelThreads;
+        const uint32_t n = exact_select_walk(
+            [&](auto&& f) {
+                for (uint32_t e = tid; e < n_round; e += kSelThreads) {
+                    const unsigned long long c = e < total ? __hip_atomic_load(&p.pool[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    f((uint64_t)(0xFFFFFFFFu - (uint32_t)c), c ? (uint32_t)(c >> 32) : kKeyMasked);
+                }
+            },
+            p.k, list, hist, &pick, s_misc);
+        __syncthreads();
+        sort_and_emit(list, n, n, p.k, p.row_base, p.out_rows, p.out_scores, p.out_count);
+    }
+}
+
+bool tiny_supported(uint64_t n_rows, uint32_t ld, uint32_t dim, uint32_t k) {
+    return n_rows >= 1 && n_rows <= 65536 && dim <= (uint32_t)kTinyMaxDim && k <= 1024u && n_rows * (uint64_t)ld * 4ull <= (64ull << 20);
+}
+// rows per workgroup / grid for a shard of n_rows (the pool holds grid * kcap composites, kcap = min(k, rows per workgroup))
+void tiny_geometry(uint64_t n_rows, uint32_t k, uint32_t* grid, uint32_t* rows_per_wg, uint32_t* kcap) {
+    uint32_t g = (uint32_t)std::min<uint64_t>((n_rows + 255) / 256, 128);
+    g = std::max(g, 1u);
+    const uint32_t per = (uint32_t)((n_rows + g - 1) / g);
+    *grid = (uint32_t)((n_rows + per - 1) / per);
+    *rows_per_wg = per;
+    *kcap = std::min(k, per);
+}
+
+hipError_t launch_tiny_search(const float* corpus, const float* norms, const uint64_t* mask_dev, uint64_t n_rows, uint64_t row_base,
+                              uint32_t ld, uint32_t dim, uint32_t k, int metric, const float* query_host, unsigned long long* pool,
+                              uint32_t* ticket, uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s) {
+    TinyParams p{};
+    p.corpus = corpus;
+    p.norms = norms;
+    p.mask = mask_dev;
+    p.pool = pool;
+    p.ticket = ticket;
+    p.out_rows = out_rows;
+    p.out_scores = out_scores;
+    p.out_count = out_count;
+    p.n_rows = n_rows;
+    p.row_base = row_base;
+    p.ld = ld;
+    p.dim = dim;
+    p.k = k;
+    p.metric = metric;
+    uint32_t grid = 1;
+    tiny_geometry(n_rows, k, &grid, &p.rows_per_wg, &p.kcap);
+    memcpy(p.q, query_host, (size_t)dim * sizeof(float));
+    hipLaunchKernelGGL(tiny_search_kernel, dim3(grid), dim3(kSelThreads), 0, s, p);
     return hipGetLastError();
 }
 

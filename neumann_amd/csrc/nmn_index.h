@@ -62,6 +62,12 @@ struct Workspace {
     uint8_t* pin_pred = nullptr; size_t pin_pred_cap = 0;                // pinned host staging of pred_block
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
     uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
+    // single-launch search of a small shard (tiny_search_kernel): candidate pool, ticket, and the result block the kernel
+    // writes straight into pinned host memory ([rows 1024 x u64 | scores 1024 x f32 | count])
+    unsigned long long* tiny_pool = nullptr;
+    uint32_t* tiny_ticket = nullptr;
+    uint8_t* tiny_out = nullptr;        // pinned host
+    uint8_t* tiny_out_dev = nullptr;    // the same memory as the device sees it
     uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
     float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
     unsigned long long* h_counts2 = nullptr;
@@ -110,6 +116,7 @@ struct nmn_index {
     uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
     int device = 0;
     uint32_t cand_cap = kDefaultCandCap;
+    bool no_single_launch = false;  // NMN_INDEX_NO_SINGLE_LAUNCH
     float* corpus = nullptr;
     float* half = nullptr;       // bf16 mirror of `corpus` every approximate sweep reads (half the bytes); lazy
     uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current

@@ -262,6 +262,15 @@ hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s);
 hipError_t launch_count_cmp(const uint32_t* scores, uint64_t n_rows, float score, unsigned long long* out2,
                             hipStream_t s);
 
+// the whole search of a small shard in one launch (nmn_exact.hip: tiny_search_kernel); query in the kernel arguments, results
+// written by the kernel into (mapped, pinned) host memory
+constexpr int kTinyMaxDim = 768;
+bool tiny_supported(uint64_t n_rows, uint32_t ld, uint32_t dim, uint32_t k);
+void tiny_geometry(uint64_t n_rows, uint32_t k, uint32_t* grid, uint32_t* rows_per_wg, uint32_t* kcap);
+hipError_t launch_tiny_search(const float* corpus, const float* norms, const uint64_t* mask_dev, uint64_t n_rows, uint64_t row_base,
+                              uint32_t ld, uint32_t dim, uint32_t k, int metric, const float* query_host, unsigned long long* pool,
+                              uint32_t* ticket, uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s);
+
 // large-k path (nmn_sortk.hip): keys[] holds largek_sort_len(n_rows) u64 (next power of two >= max(n_rows, 4096));
 // score_bits[] are exact scores in plain row order (kScoreSentinelBits = row does not take part)
 uint64_t largek_sort_len(uint64_t n_rows);

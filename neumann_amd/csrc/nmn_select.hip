@@ -7,65 +7,9 @@
 // row id; NaN scores last.
 #include <algorithm>
 
-#include "nmn_internal.h"
+#include "nmn_select_dev.h"
 
 namespace nmn {
-
-constexpr int kSelThreads = 1024;
-constexpr int kBins = 2048;
-
-struct PickResult {
-    uint32_t bin;    // bin holding the kk-th largest key
-    uint32_t above;  // keys in bins strictly above it
-};
-
-// hist[0..nbins) filled (nbins = 1024 or 2048); find the bin containing the kk-th largest key
-// (1 <= kk <= total).  Block-wide: every thread owns nbins/1024 adjacent bins, suffix sums by wave
-// shuffles + one LDS hop across the 16 waves; exactly one thread sees the crossing and publishes it.
-// Callers __syncthreads() before reading *out.
-__device__ void pick_bin(const uint32_t* hist, int nbins, uint32_t kk, PickResult* out) {
-    __shared__ uint32_t wtot[kSelThreads / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int per = nbins / kSelThreads;  // 1 or 2
-    const uint32_t h0 = hist[tid * per];
-    const uint32_t h1 = per == 2 ? hist[tid * per + 1] : 0u;
-    const uint32_t s = h0 + h1;
-    uint32_t S = s;  // inclusive suffix sum inside the wave
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_down(S, off);
-        if (lane + off < 64) S += t;
-    }
-    if (lane == 0) wtot[wave] = S;
-    __syncthreads();
-    uint32_t above_waves = 0;
-    for (uint32_t w = wave + 1; w < kSelThreads / 64; w++) above_waves += wtot[w];
-    const uint32_t Sfx = S + above_waves;  // keys in bins >= first bin of this thread
-    const uint32_t above = Sfx - s;        // keys in bins above this thread's bins
-    if (Sfx >= kk && above < kk) {
-        if (per == 2 && above + h1 >= kk) {
-            out->bin = tid * per + 1;
-            out->above = above;
-        } else {
-            out->bin = tid * per;
-            out->above = above + h1;
-        }
-    }
-    __syncthreads();
-}
-
-// wave-aggregated append: returns the slot of this lane's element (or UINT32_MAX if !pred).
-// Must be called from wave-uniform control flow.
-__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0) return 0xFFFFFFFFu;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __builtin_ctzll(m);
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
-    base = __shfl(base, leader);
-    const uint32_t ofs = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-    return pred ? base + ofs : 0xFFFFFFFFu;
-}
 
 // collection threshold key from the radix lower bound T and the query's error margins
 __device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
@@ -562,63 +506,6 @@ __device__ __forceinline__ void walk_scores(const uint32_t* __restrict__ scores,
     }
 }
 
-// `walk(f)`: calls f(row, key) for every element, the same number of times on every lane (key == kKeyMasked: skip).
-template <class Walk>
-__device__ uint32_t exact_select_walk(Walk&& walk, uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
-                                      uint32_t* s_misc /* >= 2 words */) {
-    const uint32_t tid = threadIdx.x;
-    auto comp = [](uint64_t i, uint32_t key) -> unsigned long long {
-        return key == kKeyMasked ? 0ull : (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i));
-    };
-    // digit layout over the 64-bit composite, most significant first
-    const int shifts[6] = {53, 42, 32, 21, 10, 0};
-    const int widths[6] = {11, 11, 10, 11, 11, 10};
-    if (tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
-    unsigned long long prefix = 0ull;  // digits fixed so far (high bits)
-    uint32_t need = 0;                 // rank of the wanted composite among those matching the prefix
-    uint32_t kk = 0;
-    for (int d = 0; d < 6; d++) {
-        const int nb = 1 << widths[d];
-        for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-        __syncthreads();
-        const int hi_shift = shifts[d] + widths[d];
-        uint32_t loc = 0;
-        walk([&](uint64_t i, uint32_t key) {
-            const unsigned long long c = comp(i, key);
-            if (c == 0ull) return;
-            loc++;
-            if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) return;
-            atomicAdd(&hist[(uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1)], 1u);
-        });
-        if (d == 0) {  // the first walk also counts the participating rows
-            atomicAdd(&s_misc[0], loc);
-            __syncthreads();
-            kk = min(k, s_misc[0]);
-            if (kk == 0) return 0;
-            need = kk;
-        }
-        __syncthreads();
-        pick_bin(hist, nb, need, pick);
-        __syncthreads();
-        prefix |= (unsigned long long)pick->bin << shifts[d];
-        need -= pick->above;
-        // score key fixed and every row holding it is wanted: the row digits cannot change the cut
-        const bool done = d == 2 && hist[pick->bin] == need;
-        __syncthreads();
-        if (done) break;
-    }
-    // prefix is now the kk-th largest composite (or the score key of the cut with zero row digits, which
-    // admits the same set); collect everything >= it (exactly kk entries)
-    walk([&](uint64_t i, uint32_t key) {
-        const unsigned long long c = comp(i, key);
-        const bool pred = c != 0ull && c >= prefix;
-        const uint32_t pos = wave_append(pred, &s_misc[1]);
-        if (pred && pos < NMN_MAX_TOP_K) list[pos] = c;
-    });
-    __syncthreads();
-    return min(s_misc[1], (uint32_t)NMN_MAX_TOP_K);
-}
-
 // the exact scores of every row (exact fallback) ...
 __device__ uint32_t exact_select_into(const uint32_t* __restrict__ scores, uint32_t q, uint32_t nql, uint64_t n_rows,
                                       uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
@@ -805,39 +692,8 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
             list[i] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - row);
         }
     }
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t i = n + tid; i < np2; i += kSelThreads) list[i] = 0ull;
     __syncthreads();
-    // bitonic sort, descending
-    for (uint32_t size = 2; size <= np2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < (np2 >> 1); t += kSelThreads) {
-                const uint32_t lo = ((t / stride) * stride * 2u) + (t % stride);
-                const uint32_t hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = list[lo], b = list[hi];
-                if ((a < b) == desc) {
-                    list[lo] = b;
-                    list[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const uint32_t cnt = min(n, p.k);
-    for (uint32_t i = tid; i < p.k; i += kSelThreads) {
-        uint64_t row = UINT64_MAX;
-        float sc = u2f(0xFF800000u);  // -inf
-        if (i < cnt) {
-            const unsigned long long v = list[i];
-            row = p.row_base + (uint64_t)(0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull));
-            sc = key_to_score((uint32_t)(v >> 32));
-        }
-        p.out_rows[(size_t)q * p.k + i] = row;
-        p.out_scores[(size_t)q * p.k + i] = sc;
-    }
-    if (tid == 0) p.out_counts[q] = cnt;
+    sort_and_emit(list, n, n, p.k, p.row_base, p.out_rows + (size_t)q * p.k, p.out_scores + (size_t)q * p.k, p.out_counts + q);
 }
 
 hipError_t launch_final(const FinalParams& p, hipStream_t s) {

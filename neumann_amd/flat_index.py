@@ -30,12 +30,13 @@ def _ptr(a):
 
 
 class GpuFlatIndex:
-    def __init__(self, dim, capacity_rows, row_base=0, device=-1, cand_cap=0, wide_rows=False):
+    def __init__(self, dim, capacity_rows, row_base=0, device=-1, cand_cap=0, wide_rows=False, single_launch=True):
         # wide_rows: NMN_INDEX_WIDE_ROWS — rows padded up to the next multiple of 128 elements even at up to 1/2 more
         # bytes (300 -> 384), so query batches and concurrent callers take the matrix-core sweep
         self._lib = _capi.load()
         self._h = C.c_void_p()
-        desc = _capi.IndexDesc(dim=int(dim), flags=1 if wide_rows else 0, capacity_rows=int(capacity_rows),
+        # single_launch=False: NMN_INDEX_NO_SINGLE_LAUNCH — small shards go through the general pipeline too (tests, A/B)
+        desc = _capi.IndexDesc(dim=int(dim), flags=(1 if wide_rows else 0) | (0 if single_launch else 2), capacity_rows=int(capacity_rows),
                                row_base=int(row_base), device=int(device), cand_cap=int(cand_cap))
         _capi.check(self._lib.nmn_index_create(C.byref(desc), C.byref(self._h)))
         self.dim = int(dim)

@@ -31,7 +31,7 @@ def test_all_rows_identical_ties_by_row(metric):
     n, d = 5000, 24
     A = np.tile(np.linspace(-1, 1, d, dtype=np.float32), (n, 1))
     q = np.linspace(1, 2, d, dtype=np.float32)
-    with GpuFlatIndex(d, n) as idx:          # default cand_cap 4096 < 5000 tied rows -> exact fallback
+    with GpuFlatIndex(d, n, single_launch=False) as idx:   # (the pipeline) default cand_cap 4096 < 5000 tied rows -> exact fallback
         idx.upload(A)
         st = check(idx, A, q, 10, metric)
         assert st.fallback_queries == 1
@@ -47,7 +47,7 @@ def test_forced_fallback_small_cand_cap(metric):
     base = rng.standard_normal((30, d)).astype(np.float32)
     A = base[rng.integers(0, 30, n)]          # 30 distinct vectors, ~100 exact copies each
     q = rng.standard_normal(d).astype(np.float32)
-    with GpuFlatIndex(d, n, cand_cap=8) as idx:
+    with GpuFlatIndex(d, n, cand_cap=8, single_launch=False) as idx:
         idx.upload(A)
         st = check(idx, A, q, k, metric)
         assert st.fallback_queries == 1

@@ -21,15 +21,16 @@ def _check(idx, A, q, k, metric, mask=None, row_base=0):
     assert np.all(np.isneginf(scores[0, c:]))
 
 
+@pytest.mark.parametrize("single_launch", [True, False])  # small shards: the one-kernel search, and the general pipeline
 @pytest.mark.parametrize("metric", METRICS)
 @pytest.mark.parametrize("n,d,k", [(1000, 128, 5), (4096, 768, 100), (777, 36, 10), (100, 7, 3), (50, 2, 60),
                                    (20000, 64, 10), (3000, 1536, 100)])
-def test_search_matches_oracle(metric, n, d, k):
+def test_search_matches_oracle(metric, n, d, k, single_launch):
     from neumann_amd import GpuFlatIndex
     rng = np.random.default_rng(1234 + n + d)
     A = rng.standard_normal((n, d)).astype(np.float32)
     q = rng.standard_normal(d).astype(np.float32)
-    with GpuFlatIndex(d, n) as idx:
+    with GpuFlatIndex(d, n, single_launch=single_launch) as idx:
         idx.upload(A)
         assert idx.rows == n
         _check(idx, A, q, k, metric)
@@ -110,3 +111,42 @@ def test_one_pass_ingest_magnitudes_and_mirror(n, d):
             _check(idx, A, q, 50, metric)
         r, s, c = idx.search(q, 1, 0)
         assert r[0, 0] == n // 2
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d", [(1, 8), (63, 3), (64, 128), (65, 128), (255, 40), (1000, 128), (10_000, 128), (10_007, 768),
+                                 (65_536, 64), (40_000, 384)])
+def test_single_launch_search_of_small_shards(metric, n, d):
+    """Shards of <= 65 536 rows answer a lone query in ONE launch (tiny_search_kernel: exact scores of every row, per-workgroup
+    sort, the last workgroup merges; query in the kernel arguments, results written to pinned host memory).  Against the
+    oracle for k below / at / above the rows of a workgroup and of the shard, with ties (blocks of identical rows) and a
+    DEVICE bitmap; stats say which sweep ran (exact scores from the f32 rows: 4 bytes per element)."""
+    import torch
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(n * 7 + d + metric)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    if n >= 64:
+        A[n // 3:n // 3 + 20] = A[n // 3]       # 20 identical rows: equal scores come back in row order
+        A[5] = 0.0                                # a zero row
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n, row_base=10**10) as idx:
+        idx.upload(A)
+        for k in sorted({1, 5, 100, min(n, 300), 1000, 1024}):
+            rows, scores, counts, st = idx.search(q, k, metric, with_stats=True)
+            er, es = oc.search(A, q, k, metric, row_base=10**10)
+            c = er.size
+            assert counts[0] == c and np.array_equal(rows[0, :c], er) and np.all(scores[0, :c] == es), (k, c)
+            assert np.all(rows[0, c:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isneginf(scores[0, c:]))
+            assert st.bytes_scanned == n * d * 4 and st.fallback_queries == 0
+        # the same row twice as the query: cosine 1.0 first, ties by row
+        r, s_, c_ = idx.search(A[n // 3], 3, metric)
+        er, es = oc.search(A, A[n // 3], 3, metric, row_base=10**10)
+        assert np.array_equal(r[0, :er.size], er) and np.all(s_[0, :er.size] == es)
+        # device bitmap (what the predicate kernel / an IVF probe hands over)
+        for sel in (0.5, 0.02, 0.0):
+            keep = rng.random(n) < sel
+            m = oc.mask_from_bool(keep)
+            mt = torch.from_numpy(m.view(np.int64)).cuda()
+            rows, scores, counts = idx.search_dmask(q, 10, metric, mt.data_ptr())
+            er, es = oc.search(A, q, 10, metric, mask=m, row_base=10**10)
+            assert counts[0] == er.size and np.array_equal(rows[0, :er.size], er) and np.all(scores[0, :er.size] == es), sel
