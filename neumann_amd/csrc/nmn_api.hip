@@ -1096,16 +1096,34 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
             HIP_TRY(hipMemsetAsync(w->tiny_ticket, 0, 4, s));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->tiny_out), kOffCount + 16, hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&w->tiny_out_dev), w->tiny_out, 0));
+            memset(w->tiny_out, 0, kOffCount + 16);
         }
         st = upload_fence_wait(idx, w, s);
         if (st != NMN_OK) return st;
         HIP_TRY(launch_tiny_search(idx->corpus, idx->norms, first.mask, idx->rows, idx->row_base, idx->ld, idx->dim, k, first.metric,
                                    first.queries, w->tiny_pool, w->tiny_ticket, reinterpret_cast<uint64_t*>(w->tiny_out_dev),
                                    reinterpret_cast<float*>(w->tiny_out_dev + kOffScores),
-                                   reinterpret_cast<uint32_t*>(w->tiny_out_dev + kOffCount), s));
+                                   reinterpret_cast<uint32_t*>(w->tiny_out_dev + kOffCount),
+                                   reinterpret_cast<uint32_t*>(w->tiny_out_dev + kOffCount + 4), ++w->tiny_seq, s));
         const uint64_t rows_now = idx->rows;
+        const uint32_t want_seq = w->tiny_seq;
         lk.unlock();
-        HIP_TRY(hipStreamSynchronize(s));
+        // The kernel's last act is to echo the sequence number into the pinned block: spinning on that word returns a few
+        // microseconds before hipStreamSynchronize would (1000 x 128: 28 us per call with the runtime's wait).  A kernel
+        // that faults never writes it: after 2 ms the runtime's wait takes over and reports the error.
+        {
+            volatile const uint32_t* flag = reinterpret_cast<volatile const uint32_t*>(w->tiny_out + kOffCount + 4);
+            const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            uint32_t spins = 0;
+            while (*flag != want_seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > t_give_up) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         memcpy(first.out_rows, w->tiny_out, (size_t)k * 8);
         memcpy(first.out_scores, w->tiny_out + kOffScores, (size_t)k * 4);
         first.out_counts[0] = *reinterpret_cast<const uint32_t*>(w->tiny_out + kOffCount);

@@ -436,8 +436,9 @@ struct TinyParams {
     uint64_t* out_rows;    // pinned host memory, mapped
     float* out_scores;
     uint32_t* out_count;
+    uint32_t* out_seq;     // written LAST (system-scope release): the host polls it instead of synchronising the stream
     uint64_t n_rows, row_base;
-    uint32_t ld, dim, k, kcap, rows_per_wg;
+    uint32_t ld, dim, k, kcap, rows_per_wg, seq;
     int metric;
     float q[kTinyMaxDim];
 };
@@ -531,6 +532,12 @@ __global__ void __launch_bounds__(kSelThreads) tiny_search_kernel(TinyParams p) 
         __syncthreads();
         sort_and_emit(list, n, n, p.k, p.row_base, p.out_rows, p.out_scores, p.out_count);
     }
+    // publish: every result store of this workgroup is ordered before the sequence word the host is spinning on
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(p.out_seq, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 bool tiny_supported(uint64_t n_rows, uint32_t ld, uint32_t dim, uint32_t k) {
@@ -548,8 +555,11 @@ void tiny_geometry(uint64_t n_rows, uint32_t k, uint32_t* grid, uint32_t* rows_p
 
 hipError_t launch_tiny_search(const float* corpus, const float* norms, const uint64_t* mask_dev, uint64_t n_rows, uint64_t row_base,
                               uint32_t ld, uint32_t dim, uint32_t k, int metric, const float* query_host, unsigned long long* pool,
-                              uint32_t* ticket, uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s) {
+                              uint32_t* ticket, uint64_t* out_rows, float* out_scores, uint32_t* out_count, uint32_t* out_seq, uint32_t seq,
+                              hipStream_t s) {
     TinyParams p{};
+    p.out_seq = out_seq;
+    p.seq = seq;
     p.corpus = corpus;
     p.norms = norms;
     p.mask = mask_dev;

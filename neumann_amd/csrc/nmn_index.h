@@ -68,6 +68,7 @@ struct Workspace {
     uint32_t* tiny_ticket = nullptr;
     uint8_t* tiny_out = nullptr;        // pinned host
     uint8_t* tiny_out_dev = nullptr;    // the same memory as the device sees it
+    uint32_t tiny_seq = 0;              // sequence number of the last single-launch search (the kernel echoes it when done)
     uint64_t* h_rowlist = nullptr; size_t h_rowlist_cap = 0;
     float* h_scorelist = nullptr; size_t h_scorelist_cap = 0;
     unsigned long long* h_counts2 = nullptr;

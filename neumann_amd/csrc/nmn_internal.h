@@ -269,7 +269,8 @@ bool tiny_supported(uint64_t n_rows, uint32_t ld, uint32_t dim, uint32_t k);
 void tiny_geometry(uint64_t n_rows, uint32_t k, uint32_t* grid, uint32_t* rows_per_wg, uint32_t* kcap);
 hipError_t launch_tiny_search(const float* corpus, const float* norms, const uint64_t* mask_dev, uint64_t n_rows, uint64_t row_base,
                               uint32_t ld, uint32_t dim, uint32_t k, int metric, const float* query_host, unsigned long long* pool,
-                              uint32_t* ticket, uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s);
+                              uint32_t* ticket, uint64_t* out_rows, float* out_scores, uint32_t* out_count, uint32_t* out_seq, uint32_t seq,
+                              hipStream_t s);
 
 // large-k path (nmn_sortk.hip): keys[] holds largek_sort_len(n_rows) u64 (next power of two >= max(n_rows, 4096));
 // score_bits[] are exact scores in plain row order (kScoreSentinelBits = row does not take part)
