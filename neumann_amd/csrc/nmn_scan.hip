@@ -181,10 +181,19 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) wmax[q] = kKeyMasked;
 
+    uint64_t mcache = 0;
     for (uint32_t tile = t0; tile < t1; tile++) {
         const uint64_t r0 = (uint64_t)tile * kTileRows;
         uint64_t mword = ~0ull;
-        if constexpr (MASKED) mword = p.mask[tile];
+        if constexpr (MASKED) {
+            // the wave's bitmap words are fetched 64 tiles at a time (lane L keeps the word of tile base+L): a word per tile
+            // from memory put one more load latency on every tile's dependent chain (word -> row addresses -> rows)
+            const uint32_t rel = tile - t0;
+            if ((rel & 63u) == 0) mcache = tile + lane < t1 ? p.mask[tile + lane] : 0ull;
+            const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)(rel & 63u));
+            const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)(rel & 63u));
+            mword = ((uint64_t)hi << 32) | lo;
+        }
         {
             const uint64_t left = p.n_rows - r0;
             if (left < 64) mword &= (1ull << left) - 1ull;
@@ -199,16 +208,16 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
             if (cnt <= kCompactMaxRows) {  // wave-uniform
                 compacted = true;
                 float* stg = qs + (size_t)NQ * ld + (threadIdx.x >> 6) * (NQ * 64);  // this wave's [NQ][64] staging
+                // rank -> row table of the tile, built once: lane L, if its row takes part, writes its bit position at its rank
+                // (round 1 found each step's four rows with four ballots per step)
+                uint32_t* tab = reinterpret_cast<uint32_t*>(qs + (size_t)NQ * ld + 4 * (NQ * 64)) + (threadIdx.x >> 6) * 64;
                 const bool myset = ((mword >> lane) & 1ull) != 0;
                 const uint32_t myrank = (uint32_t)__builtin_popcountll(mword & ((1ull << lane) - 1ull));
-                for (uint32_t s0 = 0; s0 < cnt; s0 += 4) {
-                    uint32_t pos = 0;  // bit of the participating row of rank s0 + grp
-#pragma unroll
-                    for (uint32_t g2 = 0; g2 < 4; g2++) {
-                        const uint64_t b = __ballot(myset && myrank == s0 + g2);
-                        if (grp == g2) pos = b ? (uint32_t)__builtin_ctzll(b) : 0u;
-                    }
+                if (myset) tab[myrank] = lane;
+                __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order; this only pins the compiler)
+                for (uint32_t s0 = 0; s0 < cnt; s0 += 4u) {
                     const bool active = s0 + grp < cnt;
+                    const uint32_t pos = active ? tab[s0 + grp] : 0u;
                     const v4f* rowp = reinterpret_cast<const v4f*>(mat + (r0 + pos) * (uint64_t)mat_ld);
                     float acc[NQ];
                     row_partial<METRIC, NQ, CH, FULL, NT, HALF>(rowp, active, j, chunks, ld4, qs4, acc);
@@ -289,8 +298,8 @@ template <int METRIC, bool MASKED, int NQ, int CH, bool FULL, bool NT, bool HALF
 static hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
-    // queries, plus (masked kernels) one [NQ][64] staging array per wave for the compacted tiles
-    const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) : 0);
+    // queries, plus (masked kernels) one [NQ][64] staging array and one 64-entry rank -> row table per wave for the compacted tiles
+    const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) : 0);  // + rank tables
     auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT, HALF>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
