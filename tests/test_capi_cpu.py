@@ -28,6 +28,29 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_capi.SIGNATURES), set(names) ^ set(_capi.SIGNATURES)
 
 
+def test_rust_ffi_file_is_current_and_complete():
+    """integration/rust/ffi.rs (the `mod ffi` of INTEGRATION.md §2) is generated from the header: it must be what the
+    generator emits today and name every exported function exactly once; the safe wrappers only call what it declares."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ffi = open(os.path.join(ROOT, "integration", "rust", "ffi.rs")).read()
+    fns = re.findall(r"pub fn (nmn_[a-z0-9_]+)\(", ffi)
+    assert sorted(fns) == _declared("neumann_gpu.h")
+    assert len(fns) == len(set(fns))
+    wrappers = open(os.path.join(ROOT, "integration", "rust", "gpu_index.rs")).read()
+    used = set(re.findall(r"ffi::(nmn_[a-z0-9_]+)\s*\(", wrappers))
+    assert used and used <= set(fns), used - set(fns)
+    for const in re.findall(r"ffi::(NMN_[A-Z0-9_]+)", wrappers):
+        assert re.search(rf"pub const {const}:", ffi), const
+    # struct layouts: same field order as the C structs ctypes uses
+    for cname, ctype in (("nmn_index_desc", _capi.IndexDesc), ("nmn_sharded_desc", _capi.ShardedDesc),
+                         ("nmn_search_stats", _capi.SearchStats)):
+        body = re.search(rf"pub struct {cname} \{{(.*?)\}}", ffi, flags=re.S).group(1)
+        assert re.findall(r"pub (\w+):", body) == [f[0] for f in ctype._fields_], cname
+
+
 def test_engine_header_symbols_exported():
     path = os.path.join(ROOT, "include", "neumann_engine.h")
     if not os.path.exists(path):
