@@ -48,7 +48,16 @@ typedef struct nmn_engine_config {
     uint32_t cand_cap;           /* 0 = default (new knob, additive) */
     int64_t max_index_file_bytes; /* lib.rs:644, 660: 100 MiB; < 0 = None; 0 is a ConfigurationError (lib.rs:740-746) */
     int64_t max_index_entries;    /* lib.rs:646, 661: 1 000 000; < 0 = None; 0 is a ConfigurationError (lib.rs:747-753) */
+    /* GPUs of this node the engine spreads every collection over (new knob, additive).  0: `device` alone.  1: devices[0]
+     * alone.  >= 2: each mirror is ONE nmn_sharded index (include/neumann_gpu.h) whose equal row ranges sit on
+     * devices[0..n_devices): a search runs on all of them at once, the per-GPU top-k blocks are gathered (RCCL all-gather
+     * over xGMI, or peer copies when an ordinal repeats) and merged on devices[0] with ResultMerger::merge_top_k's rule
+     * (query_router/src/distributed.rs:413-433).  Results are the single-GPU results.  Metadata columns, IVF indexes and
+     * the compute_similarity slot stay on devices[0]; a predicate's bitmap is evaluated there and sliced per shard. */
+    uint32_t n_devices;
+    int32_t devices[16]; /* NMN_ENGINE_MAX_DEVICES */
 } nmn_engine_config;
+#define NMN_ENGINE_MAX_DEVICES 16u
 
 /* ScalarValue / FilterValue payload (tensor_store ScalarValue; lib.rs:342-353). */
 #define NMN_VAL_NULL 0

@@ -29,6 +29,7 @@
 
 #include <dirent.h>
 #include <sys/stat.h>
+#include <hip/hip_runtime_api.h>  // hipMemcpy of a selection bitmap / the magnitudes (no kernels in this file)
 
 #include "../../include/neumann_engine.h"
 
@@ -229,7 +230,13 @@ struct FieldColumn {
 };
 
 struct Mirror {
-    nmn_index* idx = nullptr;
+    nmn_index* idx = nullptr;    // one GPU (nmn_engine_config.n_devices <= 1)
+    nmn_sharded* sh = nullptr;   // several: the rows split into equal ranges over config.devices[] (include/neumann_gpu.h)
+    bool has_rows() const { return idx || sh; }
+    uint64_t rows() const { return idx ? nmn_index_rows(idx) : sh ? nmn_sharded_rows(sh) : 0; }
+    nmn_status upload(const float* rows_host, uint64_t row0, uint64_t n) {
+        return idx ? nmn_index_upload(idx, rows_host, row0, n) : nmn_sharded_upload(sh, rows_host, row0, n);
+    }
     std::vector<uint32_t> row_to_slot;
     std::vector<uint64_t> live;  // bit r of word r/64: row r takes part
     uint64_t cap = 0, n_dead = 0;
@@ -249,6 +256,7 @@ struct Mirror {
     ~Mirror() {
         drop_columns();
         if (idx) nmn_index_destroy(idx);
+        if (sh) nmn_sharded_destroy(sh);
     }
 };
 
@@ -388,7 +396,7 @@ struct ReadLock {
 Mirror* mirror_of(Collection* c, uint64_t dim) {
     auto it = c->mirrors.find(dim);
     if (it == c->mirrors.end()) return nullptr;
-    if (!it->second->idx) {  // built when no row of this dimension existed: nothing to patch, rebuild lazily
+    if (!it->second->has_rows()) {  // built when no row of this dimension existed: nothing to patch, rebuild lazily
         c->mirrors.erase(it);
         return nullptr;
     }
@@ -573,7 +581,7 @@ nmn_status delete_from(Collection* c, const std::string& key, const std::string&
 // A row that died meanwhile still gets a vector (appends must stay contiguous; the live bitmap keeps it out of every
 // scan).  On a device error the mirror is dropped and rebuilt by the caller's get_mirror.
 bool mirror_flush(Collection* c, Mirror* m, uint64_t dim) {
-    if (m->dirty.empty() || !m->idx) {
+    if (m->dirty.empty() || !m->has_rows()) {
         m->dirty.clear();
         return true;
     }
@@ -592,7 +600,7 @@ bool mirror_flush(Collection* c, Mirror* m, uint64_t dim) {
             if (ent.live && ent.mrow == (int64_t)row && ent.vec.size() == dim)
                 memcpy(buf.data() + (r - i) * dim, ent.vec.data(), dim * sizeof(float));
         }
-        if (nmn_index_upload(m->idx, buf.data(), m->dirty[i], j - i) != NMN_OK) return false;
+        if (m->upload(buf.data(), m->dirty[i], j - i) != NMN_OK) return false;
         i = j;
     }
     m->dirty.clear();
@@ -645,7 +653,25 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
         d.row_base = 0;
         d.device = e->cfg.device;
         d.cand_cap = e->cfg.cand_cap;
-        nmn_status st = nmn_index_create(&d, &m->idx);
+        nmn_status st;
+        if (e->cfg.n_devices >= 2) {
+            // one logical index over the configured GPUs: equal contiguous row ranges, every search on all of them at once,
+            // per-shard top-k gathered (RCCL over xGMI / peer copies) and merged on devices[0] (nmn_sharded.hip).  The
+            // metadata columns of the collection stay on devices[0]; a predicate's bitmap is sliced per shard by the search.
+            nmn_sharded_desc sd{};
+            sd.dim = d.dim;
+            sd.flags = d.flags;
+            sd.capacity_rows = m->cap;
+            sd.row_base = 0;
+            sd.n_shards = e->cfg.n_devices;
+            sd.gather = NMN_GATHER_AUTO;
+            sd.devices = e->cfg.devices;
+            sd.cand_cap = e->cfg.cand_cap;
+            m->device = e->cfg.devices[0];
+            st = nmn_sharded_create(&sd, &m->sh);
+        } else {
+            st = nmn_index_create(&d, &m->idx);
+        }
         if (st != NMN_OK) return err_gpu(st);
         m->row_to_slot.reserve(n);
         // stage in chunks so the host copy stays small next to the store itself
@@ -656,7 +682,7 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
         auto flush = [&]() -> nmn_status {
             if (buf.empty()) return NMN_OK;
             const uint64_t cnt = buf.size() / dim;
-            nmn_status s2 = nmn_index_upload(m->idx, buf.data(), row0, cnt);
+            nmn_status s2 = m->upload(buf.data(), row0, cnt);
             row0 += cnt;
             buf.clear();
             return s2;
@@ -693,8 +719,8 @@ struct DeviceSelection {
 
 nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, int32_t metric,
                     const DeviceSelection* selected, nmn_results* res) {
-    if (!m->idx) return NMN_OK;  // no rows of this dimension
-    const uint64_t rows = nmn_index_rows(m->idx);
+    if (!m->has_rows()) return NMN_OK;  // no rows of this dimension
+    const uint64_t rows = m->rows();
     const uint64_t taking_part = selected ? selected->count : rows - std::min<uint64_t>(m->n_dead, rows);
     uint64_t k = std::min<uint64_t>(top_k, taking_part);
     if (k == 0) return NMN_OK;
@@ -702,7 +728,20 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
     std::vector<float> out_scores(k);
     uint32_t count = 0;
     nmn_status st;
-    if (selected) {
+    if (m->sh) {
+        // several GPUs: the bitmap travels as a host bitmap over global rows (the search slices it per shard); a
+        // predicate's selection is read back from devices[0] first (rows / 8 bytes)
+        std::vector<uint64_t> sel_host;
+        const uint64_t* mask = m->n_dead ? m->live.data() : nullptr;
+        if (selected) {
+            sel_host.resize((size_t)((rows + 63) / 64));
+            if (hipMemcpy(sel_host.data(), selected->mask_dev, sel_host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(NMN_ERR_STORAGE, "Storage error: reading the selection bitmap back");
+            mask = sel_host.data();
+        }
+        st = nmn_sharded_search(m->sh, q, 1, (uint32_t)k, (nmn_metric)metric, mask, out_rows.data(), out_scores.data(), &count,
+                                nullptr);
+    } else if (selected) {
         st = nmn_index_search_dmask_hint(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, selected->mask_dev, selected->count,
                                          out_rows.data(), out_scores.data(), &count, nullptr);
     } else {
@@ -921,12 +960,12 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
         auto it = c->mirrors.find(dim);
         if (it == c->mirrors.end()) return kRetryExclusive;
         m = it->second.get();
-        if (!m->dirty.empty() || (m->idx && !m->cols)) return kRetryExclusive;
+        if (!m->dirty.empty() || (m->has_rows() && !m->cols)) return kRetryExclusive;
     } else {
         nmn_status st = get_mirror(e, c, dim, &m);
         if (st != NMN_OK) return st;
     }
-    if (!m->idx) return NMN_OK;
+    if (!m->has_rows()) return NMN_OK;
     nmn_status st = shared ? NMN_OK : columns_build(e, c, m);
     if (st != NMN_OK) return st;
     Program p;
@@ -935,14 +974,15 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
     // predicate and search in one call (nmn_index_search_pred): concurrent filtered searches then wait for ONE batch —
     // their predicates are evaluated together on the batch's stream, right before the sweep that serves them all
     if (dl.expired()) return err_timeout(op, dl.ms);  // lib.rs:2005-2010
-    const uint64_t rows = nmn_index_rows(m->idx);
+    const uint64_t rows = m->rows();
     const uint64_t k = std::min<uint64_t>(std::min<uint64_t>(top_k, rows), NMN_MAX_TOP_K);
     if (k == 0 || rows != m->row_to_slot.size()) {
         if (k == 0) return NMN_OK;
         return fail(NMN_ERR_STORAGE, "mirror and metadata columns disagree on the row count");
     }
-    if (top_k > NMN_MAX_TOP_K) {
-        // beyond the candidate pipeline: evaluate, then the large-k path over the bitmap (the two-step form)
+    if (top_k > NMN_MAX_TOP_K || m->sh) {
+        // beyond the candidate pipeline: evaluate, then the large-k path over the bitmap (the two-step form); also the
+        // form of a mirror that spans several GPUs (evaluate on devices[0], search every shard under its slice)
         DeviceSelection sel{nullptr, 0};
         uint32_t slot = 0;
         st = nmn_columns_eval_acquire(m->cols, p.ops.data(), (uint32_t)p.ops.size(), p.consts.data(), p.consts.size(),
@@ -975,7 +1015,7 @@ nmn_status pre_filter_search(nmn_engine* e, Collection* c, const float* q, uint6
 nmn_status prepare_filtered(nmn_engine* e, Collection* c, uint64_t dim) {
     Mirror* m = nullptr;
     nmn_status st = get_mirror(e, c, dim, &m);
-    if (st != NMN_OK || !m->idx) return st;
+    if (st != NMN_OK || !m->has_rows()) return st;
     return columns_build(e, c, m);
 }
 
@@ -1009,6 +1049,8 @@ void nmn_engine_config_default(nmn_engine_config* c) {  // lib.rs:648-664
     c->cand_cap = 0;
     c->max_index_file_bytes = 100ll * 1024 * 1024;  // lib.rs:660
     c->max_index_entries = 1000000;                 // lib.rs:661
+    c->n_devices = 0;
+    for (uint32_t i = 0; i < NMN_ENGINE_MAX_DEVICES; i++) c->devices[i] = -1;
 }
 
 void nmn_filtered_config_default(nmn_filtered_config* c) {  // lib.rs:412-420
@@ -1043,6 +1085,13 @@ nmn_status nmn_engine_create(const nmn_engine_config* config, nmn_engine** out) 
         delete e;
         return fail(NMN_ERR_CONFIGURATION, "Configuration error: max_index_entries must be greater than 0");
     }
+    if (e->cfg.n_devices > NMN_ENGINE_MAX_DEVICES) {
+        delete e;
+        return fail(NMN_ERR_CONFIGURATION, "Configuration error: n_devices exceeds NMN_ENGINE_MAX_DEVICES");
+    }
+    // devices[]: one entry = that GPU; two or more = every mirror is one index over all of them; the collection-level
+    // device objects that are not sharded (metadata columns, IVF indexes, the compute_similarity slot) live on devices[0]
+    if (e->cfg.n_devices >= 1) e->cfg.device = e->cfg.devices[0];
     *out = e;
     return NMN_OK;
 }
@@ -2696,12 +2745,19 @@ nmn_status nmn_engine_load_index_binary(nmn_engine* e, const char* path, char* n
         Mirror* m = nullptr;
         st = get_mirror(e, c, kv.first, &m);
         if (st != NMN_OK) return st;
-        if (!m || !m->idx) continue;
-        const uint64_t n_rows = nmn_index_rows(m->idx);
+        if (!m || !m->has_rows()) continue;
+        const uint64_t n_rows = m->rows();
         std::vector<float> dev((size_t)n_rows);
-        // (device pointer of the magnitudes through the public accessor; one D2H)
-        if (n_rows && hipMemcpy(dev.data(), nmn_index_norms_device(m->idx), (size_t)n_rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(NMN_ERR_STORAGE, "Storage error: reading the magnitudes back");
+        // (device pointer of the magnitudes through the public accessor; one D2H per shard)
+        const uint32_t n_sh = m->sh ? nmn_sharded_shards(m->sh) : 1u;
+        for (uint32_t g = 0; g < n_sh; g++) {
+            const nmn_index* part = m->sh ? nmn_sharded_shard(m->sh, g) : m->idx;
+            const uint64_t cnt = nmn_index_rows(part), base = nmn_index_row_base(part);
+            if (cnt == 0) continue;
+            if (base + cnt > n_rows) return fail(NMN_ERR_STORAGE, "Storage error: shard rows beyond the mirror");
+            if (hipMemcpy(dev.data() + base, nmn_index_norms_device(part), (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(NMN_ERR_STORAGE, "Storage error: reading the magnitudes back");
+        }
         const std::vector<float>& want = stored_norms[kv.first];
         for (size_t r = 0; r < kv.second.size(); r++) {
             auto it = c->by_key.find(d.entries[kv.second[r]].key);

@@ -25,7 +25,8 @@ class _EngineConfig(C.Structure):
                 ("parallel_threshold", C.c_uint64), ("default_metric", C.c_int32),
                 ("max_dimension", C.c_uint64), ("max_keys_per_scan", C.c_uint64),
                 ("search_timeout_ms", C.c_int64), ("device", C.c_int32), ("cand_cap", C.c_uint32),
-                ("max_index_file_bytes", C.c_int64), ("max_index_entries", C.c_int64)]
+                ("max_index_file_bytes", C.c_int64), ("max_index_entries", C.c_int64),
+                ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16)]
 
 
 class _Value(C.Structure):
@@ -234,6 +235,7 @@ class VectorEngineConfig:
     cand_cap: int = 0
     max_index_file_bytes: int = 100 * 1024 * 1024   # lib.rs:660; None = no limit
     max_index_entries: int = 1_000_000              # lib.rs:661; None = no limit
+    devices: tuple = ()   # GPU ordinals; two or more = every collection is one index sharded over them (nmn_sharded_*)
 
 
 @dataclass
@@ -453,6 +455,12 @@ class VectorEngine:
             cfg.cand_cap = config.cand_cap
             cfg.max_index_file_bytes = -1 if config.max_index_file_bytes is None else int(config.max_index_file_bytes)
             cfg.max_index_entries = -1 if config.max_index_entries is None else int(config.max_index_entries)
+            devs = tuple(config.devices or ())
+            if len(devs) > 16:
+                raise VectorError(_capi.ERR_CONFIGURATION, "Configuration error: n_devices exceeds NMN_ENGINE_MAX_DEVICES")
+            cfg.n_devices = len(devs)
+            for i, d in enumerate(devs):
+                cfg.devices[i] = int(d)
         self._h = vp()
         _check(lib.nmn_engine_create(C.byref(cfg), C.byref(self._h)))
 

@@ -206,3 +206,9 @@ def test_load_overwrites_existing_keys_and_float_round_trip(tmp_path):
     e2.load_index(path)
     assert e2.count() == 2
     assert np.array_equal(e2.get_embedding("a").view(np.uint32), v.view(np.uint32))
+
+
+def test_engine_rejects_more_devices_than_it_can_hold():
+    with pytest.raises(VectorError) as ei:
+        VectorEngine(VectorEngineConfig(devices=(0,) * 17))
+    assert ei.value.kind == "ConfigurationError"
