@@ -463,8 +463,10 @@ __global__ void __launch_bounds__(kSelThreads) tiny_search_kernel(TinyParams p) 
     // exact score of this workgroup's rows -> composites in LDS (0 = row does not take part)
     const uint64_t r0 = (uint64_t)wg * p.rows_per_wg;
     const uint32_t R = (uint32_t)min((uint64_t)p.rows_per_wg, p.n_rows > r0 ? p.n_rows - r0 : 0ull);
+    const bool small_k = p.k <= 64u;  // (kernel-argument uniform; kcap <= k) the wave-level top-64 network serves this launch
     uint32_t np2 = 1;
     while (np2 < max(R, 1u)) np2 <<= 1;
+    if (small_k) np2 = max((R + 63u) & ~63u, 64u);  // here: the slots scored (whole waves' worth; not a power of two)
     for (uint32_t base = 0; base < np2; base += kSelThreads / 8) {
         const uint32_t ri = base + (tid >> 3);
         const uint64_t row = r0 + ri;
@@ -480,6 +482,10 @@ __global__ void __launch_bounds__(kSelThreads) tiny_search_kernel(TinyParams p) 
     }
     __syncthreads();
     // this workgroup's rows in final order (score desc, row asc); its first kcap go to the pool
+    if (small_k) {
+        const unsigned long long v = wg_top64(list, np2 >> 6);
+        if (tid < p.kcap) p.pool[(size_t)wg * p.kcap + tid] = v;
+    } else {
     for (uint32_t size = 2; size <= np2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             for (uint32_t t = tid; t < (np2 >> 1); t += kSelThreads) {
@@ -495,6 +501,7 @@ __global__ void __launch_bounds__(kSelThreads) tiny_search_kernel(TinyParams p) 
         }
     }
     for (uint32_t i = tid; i < p.kcap; i += kSelThreads) p.pool[(size_t)wg * p.kcap + i] = i < np2 ? list[i] : 0ull;
+    }
     // last workgroup standing merges (release: pool stores visible device-wide before the ticket; acquire before reading)
     __syncthreads();
     if (tid == 0) {
@@ -509,7 +516,13 @@ __global__ void __launch_bounds__(kSelThreads) tiny_search_kernel(TinyParams p) 
     }
     __syncthreads();
     const uint32_t total = G * p.kcap;
-    if (total <= NMN_MAX_TOP_K) {
+    if (small_k && total <= kSelThreads) {
+        const uint32_t n64 = (total + 63u) >> 6;
+        if (tid < n64 * 64u) list[tid] = tid < total ? __hip_atomic_load(&p.pool[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        __syncthreads();
+        const unsigned long long v = wg_top64(list, n64);
+        emit_top64(v, p.k, p.row_base, p.out_rows, p.out_scores, p.out_count);
+    } else if (total <= NMN_MAX_TOP_K) {
         for (uint32_t i = tid; i < total; i += kSelThreads)
             list[i] = __hip_atomic_load(&p.pool[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) s_misc[0] = 0;
@@ -545,7 +558,9 @@ bool tiny_supported(uint64_t n_rows, uint32_t ld, uint32_t dim, uint32_t k) {
 }
 // rows per workgroup / grid for a shard of n_rows (the pool holds grid * kcap composites, kcap = min(k, rows per workgroup))
 void tiny_geometry(uint64_t n_rows, uint32_t k, uint32_t* grid, uint32_t* rows_per_wg, uint32_t* kcap) {
-    uint32_t g = (uint32_t)std::min<uint64_t>((n_rows + 255) / 256, 128);
+    // 128 rows per workgroup = one scoring pass of its 1024 threads (8 lanes per row), up to 128 workgroups; beyond 16k rows
+    // the workgroups take more passes
+    uint32_t g = (uint32_t)std::min<uint64_t>((n_rows + 127) / 128, 128);
     g = std::max(g, 1u);
     const uint32_t per = (uint32_t)((n_rows + g - 1) / g);
     *grid = (uint32_t)((n_rows + per - 1) / per);

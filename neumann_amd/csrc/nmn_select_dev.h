@@ -160,4 +160,64 @@ static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint3
     if (tid == 0) *out_count = cnt;
 }
 
+// ---- wave-level sorting (no barriers): one composite per lane ---------------------------------------------------------------
+static __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// the wave's 64 values in descending order (lane i = rank i): bitonic network over lane exchanges
+static __device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned long long o = shfl_xor_u64(v, (int)stride);
+            const bool keep_max = ((lane & stride) == 0) == ((lane & size) == 0);
+            v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
+// a bitonic sequence across the lanes -> descending order
+static __device__ __forceinline__ unsigned long long wave_merge_desc(unsigned long long v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t stride = 32; stride > 0; stride >>= 1) {
+        const unsigned long long o = shfl_xor_u64(v, (int)stride);
+        v = ((lane & stride) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+    }
+    return v;
+}
+// The 64 largest of list[0 .. n64 * 64) (n64 <= waves of the workgroup; empty slots 0), descending, in WAVE 0 (lane i = rank
+// i); every thread of the workgroup calls.  Each wave sorts its 64 in registers, then a tree of merges that keep the top 64
+// of two sorted runs (max of A[i] and B[63 - i] is a bitonic sequence of exactly those): one LDS exchange and two barriers
+// per level instead of the (log n)^2 / 2 barrier steps of a workgroup-wide bitonic sort.  `list` is overwritten.
+static __device__ unsigned long long wg_top64(unsigned long long* list, uint32_t n64) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    unsigned long long v = wave < n64 ? list[tid] : 0ull;
+    if (wave < n64) v = wave_sort_desc(v, lane);
+    for (uint32_t s = 1; s < n64; s <<= 1) {
+        __syncthreads();  // every wave holds its run in registers: the slots may be overwritten
+        if (wave < n64) list[tid] = v;
+        __syncthreads();
+        if (wave < n64 && (wave % (2u * s)) == 0 && wave + s < n64) {
+            const unsigned long long o = list[(wave + s) * 64u + (63u - lane)];
+            v = wave_merge_desc(v > o ? v : o, lane);
+        }
+    }
+    return v;
+}
+// wave 0 emits its lanes' composites (descending; 0 = none) as the first k results, padded like sort_and_emit
+static __device__ __forceinline__ void emit_top64(unsigned long long v, uint32_t k, uint64_t row_base, uint64_t* out_rows,
+                                                  float* out_scores, uint32_t* out_count) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x >= 64) return;
+    const bool live = v != 0ull && lane < k;
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(live));
+    if (lane < k) {
+        out_rows[lane] = live ? row_base + (uint64_t)(0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull)) : UINT64_MAX;
+        out_scores[lane] = live ? key_to_score((uint32_t)(v >> 32)) : u2f(0xFF800000u);
+    }
+    if (lane == 0) *out_count = cnt;
+}
+
 }  // namespace nmn

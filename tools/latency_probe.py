@@ -2,12 +2,13 @@
 
   python tools/latency_probe.py [rows:dim:k ...]      default: 10000:128:5 100000:768:100 1000000:768:100 10000000:768:100
 """
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neumann_amd import GpuFlatIndex, synth_rows  # noqa: E402
 
 cases = sys.argv[1:] or ["10000:128:5", "100000:768:100", "1000000:768:100", "10000000:768:100"]
