@@ -861,6 +861,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.skip_key = sp.skip_key;
             sel.k_extra = nullptr;
             sel.retry = 0;
+            sel.retry_follows = f32_retry ? 1 : 0;
             sel.half_stats = f32_retry ? idx->half_stats : nullptr;
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
@@ -895,6 +896,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 SelectParams sel2 = sel;
                 sel2.qinfo = w->qinfo_f32;
                 sel2.retry = 1;
+                sel2.retry_follows = 0;
                 HIP_TRY(launch_select(sel2, stream));
             }
 

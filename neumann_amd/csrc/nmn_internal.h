@@ -145,6 +145,7 @@ struct SelectParams {
     const uint32_t* k_extra;   // nullable: added to k for the threshold rank (rows forced to +inf, f64 similarity)
     int retry;                 // 1: second selection after the f32 retry sweep — only queries flagged `overflow` take part
     uint32_t* half_stats;      // nullable [2]: queries selected on the bf16 mirror / of those, queries that needed the retry
+    int retry_follows;         // 1: an f32 retry sweep follows this selection (it may flag a query as not worth retrying)
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);

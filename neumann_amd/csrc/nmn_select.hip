@@ -159,7 +159,11 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t nql = p.nql;
-    if (p.retry && p.qstate[q].overflow != 1) return;  // block-uniform: this query's first selection stood (or its crowd list did)
+    if (p.retry && p.qstate[q].overflow != 1) {  // block-uniform: this query's first selection stood (or its crowd list did)
+        // ... or it was found hopeless for the retry (below): the retry sweep skipped it, from here on it is an ordinary overflow
+        if (tid == 0 && p.qstate[q].overflow == 4u) p.qstate[q].overflow = 1u;
+        return;
+    }
     if (p.half_stats && tid == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
     auto score_bits = [&](uint64_t row) -> uint32_t { return p.scores[score_at(row, q, nql)]; };
     const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
@@ -343,13 +347,39 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         }
     }
     __syncthreads();
+    const uint32_t c = s_w[2];
+    const bool over = c > p.cand_cap || nB_raw > kListCap;  // > 4096 passing tiles means > 4096 candidates
+    // An overflow on the bf16 mirror is normally answered by the f32 retry sweep (a narrower margin).  Not when more than
+    // kListCap TILES hold a row with the very same top key: approximate scores that agree bit for bit in thousands of tiles
+    // belong to copies of one row, and copies tie in f32 as well — the retry would read the whole corpus to overflow again
+    // (10M identical rows: 5.1 ms of 14).  Such a query is flagged 4: the retry sweep and the crowd kernels skip it, the
+    // retry's selection turns it back into 1, the exact fallback answers it.
+    bool hopeless = false;
+    if (over && p.retry_follows) {  // (block-uniform)
+        __syncthreads();
+        if (tid == 0) { s_w[0] = 0; s_w[3] = 0; }
+        __syncthreads();
+        uint32_t top = 0;
+        for (uint32_t i = tid; i < W; i += kSelThreads)
+            if (wk[i] != kKeyMasked) top = max(top, wk[i]);
+        atomicMax(&s_w[3], top);
+        __syncthreads();
+        top = s_w[3];
+        uint32_t ties = 0;
+        const uint32_t slots = W * tpw;
+        for (uint32_t e = tid; e < slots; e += kSelThreads) {
+            const uint32_t i = e / tpw, t = e;  // (tile t belongs to wave t / tpw)
+            if (wk[i] == top && t < n_tiles && tmax[t] == top) ties++;
+        }
+        if (ties) atomicAdd(&s_w[0], ties);
+        __syncthreads();
+        hopeless = s_w[0] > kListCap;
+    }
     if (tid == 0) {
-        const uint32_t c = s_w[2];
-        const bool over = c > p.cand_cap || nB_raw > kListCap;  // > 4096 passing tiles means > 4096 candidates
         QState st;
         st.n_valid = vw;
         st.thr_key = Tc;
-        st.overflow = over ? 1u : 0u;
+        st.overflow = over ? (hopeless ? 4u : 1u) : 0u;
         st.cand_count = over ? 0u : c;
         p.qstate[q] = st;
     }
