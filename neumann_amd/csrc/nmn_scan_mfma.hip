@@ -49,7 +49,13 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 constexpr int kStageK = 128;     // granularity of the row length this kernel accepts (elements)
 // A stage is [64 rows][128*KS bf16] (KS = 1 or 2 k-steps per wave and stage): 16 KiB or 32 KiB.  Rows whose length is a
 // multiple of 256 use KS = 2: half as many stage hand-overs (a counted wait and a workgroup barrier each) per byte.
-constexpr int kRingBytes = 128 * 1024;  // LDS given to the DMA ring: 8 stages of 16 KiB or 4 of 32 KiB
+#ifndef NMN_MFMA_RING_KB   // measurement builds (tools/build_variant.sh): 64 + NMN_MFMA_OCC=2 puts two workgroups on a CU, 144 = 9 x 16 KiB
+#define NMN_MFMA_RING_KB 128
+#endif
+#ifndef NMN_MFMA_OCC
+#define NMN_MFMA_OCC 1
+#endif
+constexpr int kRingBytes = NMN_MFMA_RING_KB * 1024;  // LDS given to the DMA ring: 8 stages of 16 KiB or 4 of 32 KiB
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -143,7 +149,7 @@ __device__ __forceinline__ float l2_score(float qq, float vn, float dot) {
 }
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 1) scan_mfma_kernel(ScanParams p) {
+__global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(ScanParams p) {
     constexpr int kStageElems = 128 * KS;                        // elements of a row per stage
     constexpr int kStageBytes = kTileRows * kStageElems * 2;     // 16 / 32 KiB of bf16
     constexpr int kRowPitch = kStageElems / 2;                   // LDS row pitch of a stage, in floats
@@ -573,7 +579,11 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
         case 3: return launch_kc<3, 1, 4, METRIC>(p, s);   // 384
         case 4: return launch_kc<2, 2, 4, METRIC>(p, s);   // 512
         case 5: return launch_kc<5, 1, 4, METRIC>(p, s);   // 640
+#ifdef NMN_MFMA_768_KS1
+        case 6: return launch_kc<6, 1, 4, METRIC>(p, s);   // 768 in 16-KiB stages (measurement build)
+#else
         case 6: return launch_kc<3, 2, 4, METRIC>(p, s);   // 768
+#endif
         case 8: return launch_kc<4, 2, 4, METRIC>(p, s);   // 1024
         case 10: return launch_kc<5, 2, 4, METRIC>(p, s);  // 1280
         case 12: return launch_kc<6, 2, 4, METRIC>(p, s);  // 1536
