@@ -582,7 +582,11 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 #ifdef NMN_MFMA_768_KS1
         case 6: return launch_kc<6, 1, 4, METRIC>(p, s);   // 768 in 16-KiB stages (measurement build)
 #else
+#ifdef NMN_MFMA_768_KS1
+        case 6: return launch_kc<6, 1, 4, METRIC>(p, s);   // 768 in 16-KiB stages (measurement build)
+#else
         case 6: return launch_kc<3, 2, 4, METRIC>(p, s);   // 768
+#endif
 #endif
         case 8: return launch_kc<4, 2, 4, METRIC>(p, s);   // 1024
         case 10: return launch_kc<5, 2, 4, METRIC>(p, s);  // 1280
