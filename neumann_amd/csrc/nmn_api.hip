@@ -838,7 +838,35 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 HIP_TRY(launch_sample_bound(w->tsample, w->n_sample_cap, n_sample, w->qinfo, nqc, k, w->skip_key, stream));
                 sp.skip_key = w->skip_key;
             }
-            HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : launch_scan(sp, stream));
+            // More than 64 queries per pass: the score stores of the sweep are what its epilogue costs (a written tile is four
+            // store instructions per query group with one query's lanes active, each holding the wave's issue slot behind the
+            // DMA pieces: 0.24 of 2.98 ms at 128 queries, nothing at 64).  The sampled bound sits at about rank 32 k (every 32nd
+            // tile); the tile maxima of the sweep's own first quarter give one at about rank 4 k.  So the sweep runs as two
+            // launches over workgroup ranges with that refinement in between: ~8x fewer written tiles in the last three quarters
+            // for one more launch (measured: DESIGN.md 3.2).  NMN_NO_REFINE=1: one launch (A/B).
+            static const bool no_refine = getenv("NMN_NO_REFINE") != nullptr;
+            const uint32_t mfma_blocks = use_mfma ? (n_tiles + sp.tiles_per_wave - 1) / sp.tiles_per_wave : 0;
+            // the first launch is ONE round of workgroups (one per CU: the sweep's 1024 workgroups are four rounds, and a launch
+            // that ends with a nearly empty round pays for a whole one: 248 + 774 workgroups measured +0.4 ms)
+            static const uint32_t n_cu = [] {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                return (uint32_t)n;
+            }();
+            const uint32_t first_blocks = mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
+            if (use_mfma && sample && nqc > 64 && !no_refine && first_blocks >= 64 && (uint64_t)first_blocks * sp.tiles_per_wave >= 4ull * k) {
+                ScanParams sa = sp;
+                sa.bx_base = 0;
+                sa.bx_count = first_blocks;
+                HIP_TRY(launch_scan_mfma(sa, stream));
+                HIP_TRY(launch_sample_bound(w->tmax, w->tmax_stride, first_blocks * sp.tiles_per_wave, w->qinfo, nqc, k, w->skip_key, stream, 1));
+                ScanParams sb = sp;
+                sb.bx_base = first_blocks;
+                sb.bx_count = 0;
+                HIP_TRY(launch_scan_mfma(sb, stream));
+            } else {
+                HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : launch_scan(sp, stream));
+            }
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
 
             SelectParams sel{};

@@ -106,6 +106,7 @@ struct ScanParams {
     uint32_t n_tiles;
     uint32_t nq;
     uint32_t tiles_per_wave;
+    uint32_t bx_base, bx_count;  // MFMA sweep: this launch covers workgroups [bx_base, bx_base + bx_count) (0 = to the end)
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
@@ -150,8 +151,9 @@ struct SelectParams {
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);
 // per query: skip_key[q] = margin_key(k-th largest of the sampled tile maxima) (kKeyNaN if fewer than k are valid)
+// (combine_max: keep the larger of the bound already in skip_key and the new one)
 hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uint32_t n_sample, const QInfo* qinfo,
-                               uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s);
+                               uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s, int combine_max = 0);
 
 // Crowd path: a query with more than cand_cap rows within the margin of its k-th score (masses of duplicates,
 // near-duplicates) does not fall back to the exact scan of the whole shard at once: the rows with approximate key >=

@@ -32,6 +32,7 @@
 // Euclidean batches ride the same sweep: |q - v|^2 = |q|^2 + |v|^2 - 2 q.v from the dot product and the stored row
 // magnitudes.  The expansion cancels for near neighbours, so its error is bounded in SQUARED-distance space
 // (qprep_kernel: QInfo.pad < 0, applied by margin_key) and every candidate is re-scored exactly as always.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -175,6 +176,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         by = r_ / 8u;
         bx = grp_ * 8u + (r_ % 8u);
     }
+    // a launch may cover only the workgroups [bx_base, bx_base + bx_count) of the sweep (nmn_api.hip: the bound that gates the
+    // score stores is tightened between two such launches); workgroup ids keep their meaning for `wmax` and the selection
+    if (p.bx_count && bx >= p.bx_count) return;  // (padding of the folded grid)
+    bx += p.bx_base;
     const uint32_t q0 = by * (uint32_t)(QG * 16);
     // QG = 2 (rows of 2048 / 3072 / 4096 elements: half a group's B-fragments already take 128 / 192 / 256 VGPRs): the workgroup keeps 32
     // queries, and a group is shared by TWO waves that split the k-steps of every stage between them (kh = 0 / 1); their
@@ -508,9 +513,12 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
-    const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    const uint32_t blocks_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    if (p.bx_base >= blocks_all) return hipSuccess;
+    const uint32_t blocks = p.bx_count ? std::min(p.bx_count, blocks_all - p.bx_base) : blocks_all - p.bx_base;
     const uint32_t ny = (p.nq + QG * 16 - 1) / (QG * 16);
     ScanParams pf = p;
+    pf.bx_count = blocks;
     dim3 grid(blocks, ny);
     static const bool no_fold = getenv("NMN_MFMA_NO_FOLD") != nullptr;
     if (ny > 1 && !no_fold) {  // folded 1-D grid (see the kernel): tile ranges padded to a multiple of 8

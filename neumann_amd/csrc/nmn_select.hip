@@ -123,7 +123,7 @@ __device__ uint32_t count_valid(KeyAt key_at, uint32_t n, uint32_t* s_word) {
 __global__ void __launch_bounds__(kSelThreads) sample_bound_kernel(const uint32_t* __restrict__ tmax_sample,
                                                                    uint64_t stride, uint32_t n_sample,
                                                                    const QInfo* __restrict__ qinfo, uint32_t k,
-                                                                   uint32_t* __restrict__ skip_key) {
+                                                                   uint32_t* __restrict__ skip_key, int combine_max) {
     __shared__ uint32_t hist[kBins];
     __shared__ PickResult pick;
     __shared__ uint32_t s_cnt;
@@ -133,13 +133,14 @@ __global__ void __launch_bounds__(kSelThreads) sample_bound_kernel(const uint32_
     const uint32_t valid = count_valid(key_at, n_sample, &s_cnt);
     uint32_t skip = kKeyNaN;
     if (valid >= k) skip = margin_key(radix2(key_at, n_sample, k, hist, &pick), qinfo[q]);
-    if (threadIdx.x == 0) skip_key[q] = skip;
+    // combine_max: a second, tighter bound from tile maxima of the main sweep itself never loosens the one already there
+    if (threadIdx.x == 0) skip_key[q] = combine_max ? max(skip_key[q], skip) : skip;
 }
 
 hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uint32_t n_sample, const QInfo* qinfo,
-                               uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s) {
+                               uint32_t nq, uint32_t k, uint32_t* skip_key, hipStream_t s, int combine_max) {
     hipLaunchKernelGGL(sample_bound_kernel, dim3(nq), dim3(kSelThreads), 0, s, tmax_sample, stride, n_sample, qinfo, k,
-                       skip_key);
+                       skip_key, combine_max);
     return hipGetLastError();
 }
 
