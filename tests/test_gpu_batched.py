@@ -157,3 +157,30 @@ def test_mfma_sampling_pass_large_shard():
         for qi in range(6):
             er, es = oc.search(A, Q[qi], k, 0, mask=mask, nthreads=8, partial=True, native=True)
             assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es)
+
+
+def test_more_than_64_queries_on_a_large_shard_two_launch_sweep():
+    """More than 64 queries on a shard with a sampling pass: the main sweep runs as two launches over workgroup ranges and
+    the score-store bound is tightened from the first round's own tile maxima in between (nmn_api.hip).  Whatever the bound
+    suppresses must never be a candidate: oracle on the full 2.2M x 128 corpus, all three metrics, with and without a mask."""
+    from neumann_amd import GpuFlatIndex
+    n, d, nq, k = 2_200_000, 128, 96, 25
+    A = oc.synth(777, 0, n, d, nthreads=8)
+    Q = oc.synth(778, 0, nq, d)
+    Q[5] = A[2_000_001]          # a query whose best match sits in the LAST quarter of the shard (the second launch)
+    Q[6] = A[17]                 # ... and one in the first
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(777, n)
+        for metric in (0, 1, 2):
+            rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
+            assert st.fallback_queries == 0
+            for qi in list(range(0, nq, 9)) + [5, 6]:
+                er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
+                assert counts[qi] == k and np.array_equal(rows[qi], er) and np.all(scores[qi] == es), (metric, qi)
+        assert rows[5][0] == 2_000_001 or scores[5][0] >= scores[5][1]
+        keep = np.random.default_rng(3).random(n) < 0.3
+        mask = oc.mask_from_bool(keep)
+        rows, scores, counts = idx.search(Q, k, 0, mask=mask)
+        for qi in (0, 5, 6, 50, 95):
+            er, es = oc.search(A, Q[qi], k, 0, mask=mask, nthreads=8, partial=True, native=True)
+            assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es), qi
