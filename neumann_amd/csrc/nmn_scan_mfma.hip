@@ -292,20 +292,37 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         }
         const uint64_t left = p.n_rows - r0;
         if (left < 64) mword &= (1ull << left) - 1ull;
-        uint32_t tkey = kKeyMasked;
-        u4 bits[4];
         const float inv_q = qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag);
         const float qq = qmag * qmag;
         (void)inv_q;
         (void)qq;
-        // cosine / dot product with every row taking part (the common case): only the tile MAXIMUM is needed unless the tile
-        // can still hold a candidate (~2 % of the tiles), so the per-row work is one multiply by the row's inverse magnitude
-        // and a max; the query's 1/|q| (>= 0: monotone, rounding included) is applied once to the maximum, and the 16
-        // score words are formed only when they are written.
+        // what follows a tile's key: the maximum over the four lane groups of a query (v_permlane32_swap / v_permlane16_swap: no
+        // LDS round trip), the tile and workgroup maxima, and whether this lane's query writes the tile's scores.  Scores are
+        // only worth their HBM write when the tile can still hold a candidate: with a per-query bound from the sampling pass
+        // ~2 % of the tiles qualify (64 queries x 10M rows would otherwise write 2.56 GB per sweep, +1.45 ms on a 5.3 ms sweep).
+        auto publish = [&](uint32_t tkey) __attribute__((always_inline)) -> bool {
+            const auto r32 = __builtin_amdgcn_permlane32_swap(tkey, tkey, false, false);
+            tkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
+            const auto r16 = __builtin_amdgcn_permlane16_swap(tkey, tkey, false, false);
+            tkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
+            if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + ftile] = tkey;
+            wmax_h[H] = max(wmax_h[H], tkey);
+#ifdef NMN_MFMA_NO_SCORE_WRITES
+            return false;
+#else
+            return q_ok && !sampling && tkey != kKeyMasked && tkey >= skip;
+#endif
+        };
+        // The two cases are two complete code paths (key, publish, stores): merged behind one `publish` the compiler carried
+        // the score words of the rare path through the common one — 16 registers zeroed per tile, and earlier the scaled
+        // products parked in AGPRs and fetched back (32 moves) for the one tile in thirty that writes.
+        // Cosine / dot product with every row taking part (the common case): only the tile MAXIMUM is needed, so the per-row
+        // work is one multiply by the row's inverse magnitude and a max; the query's 1/|q| (>= 0: monotone, rounding included)
+        // is applied once to the maximum, and the 16 score words are formed — multiplying again — only where they are written.
         constexpr bool kLazy = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_DOT_PRODUCT;
-        const bool full = mword == ~0ull;
-        if (full) {
+        if (mword == ~0ull) {
             float m = -__builtin_inff();
+            u4 bits[4];
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
                 f4 sc = fin[rb];
@@ -313,7 +330,6 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                     // (a zero row has inverse magnitude 0: its score is 0 like cosine_similarity's; v_rcp at ingest: 1 ulp,
                     // the margin has 1000x that slack)
                     sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
-                    fin[rb] = sc;
                 }
                 if constexpr (kL2) {
                     const f4 vn = *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
@@ -327,8 +343,24 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 }
             }
             if constexpr (METRIC == NMN_METRIC_COSINE) m = m * inv_q;
-            tkey = score_to_key(m);
+            if (publish(score_to_key(m))) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    u4 w;
+                    if constexpr (kLazy) {
+                        f4 sc = fin[rb];
+                        if constexpr (METRIC == NMN_METRIC_COSINE) sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) w[e] = f2u(METRIC == NMN_METRIC_COSINE ? sc[e] * inv_q : sc[e]);
+                    } else {
+                        w = bits[rb];
+                    }
+                    *reinterpret_cast<u4*>(p.scores + score_at(r0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = w;
+                }
+            }
         } else {
+            uint32_t tkey = kKeyMasked;
+            u4 bits[4];
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
                 const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
@@ -344,35 +376,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                     if (valid) tkey = max(tkey, score_to_key(sc));
                 }
             }
-        }
-        // tile maximum of query n: combine the four lane groups (v_permlane32_swap / v_permlane16_swap: no LDS round trip)
-        {
-            const auto r32 = __builtin_amdgcn_permlane32_swap(tkey, tkey, false, false);
-            tkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
-            const auto r16 = __builtin_amdgcn_permlane16_swap(tkey, tkey, false, false);
-            tkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
-        }
-        if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + ftile] = tkey;
-        wmax_h[H] = max(wmax_h[H], tkey);
-        // Scores are only worth their HBM write when the tile can still hold a candidate: with a
-        // per-query bound from the sampling pass ~2 % of the tiles qualify (64 queries x 10M rows would
-        // otherwise write 2.56 GB per sweep, measured at +1.45 ms on a 5.3 ms sweep).
-#ifdef NMN_MFMA_NO_SCORE_WRITES
-        if (false) {
-#else
-        if (q_ok && !sampling && tkey != kKeyMasked && tkey >= skip) {
-#endif
-            const uint64_t wr0 = r0;
+            if (publish(tkey)) {
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++) {
-                u4 w = bits[rb];
-                if constexpr (kLazy) {
-                    if (full) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) w[e] = f2u(METRIC == NMN_METRIC_COSINE ? fin[rb][e] * inv_q : fin[rb][e]);
-                    }
-                }
-                *reinterpret_cast<u4*>(p.scores + score_at(wr0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = w;
+                for (int rb = 0; rb < 4; rb++)
+                    *reinterpret_cast<u4*>(p.scores + score_at(r0 + (uint32_t)rb * 16u + g * 4u, qn, p.nql)) = bits[rb];
             }
         }
     };
