@@ -21,5 +21,9 @@ python $R/tools/prof_summary.py $DB "bench.py --batched 128 --steps 10 (nq=1 loo
 rm -rf $O/trace
 cd $R
 { echo "# matrix-core sweep across row lengths, final tree (tools/mfma_shapes.sh; sweep_ms includes the sampling pass)"; NQ=64 bash tools/mfma_shapes.sh; NQ=128 bash tools/mfma_shapes.sh; } > $O/mfma_shapes.txt 2>&1
-{ python tools/mfma_loop.py --nq 64; python tools/mfma_loop.py --nq 128; python tools/mfma_loop.py --nq 64; python tools/mfma_loop.py --nq 128; } > $O/mfma_loop.txt 2>&1
-tail -3 $O/gpu_suite.log; cat $O/smoke.log | tail -1; head -c 1500 $O/bench_default.json; echo; head -12 $O/timeline_mirror.txt; cat $O/mfma_shapes.txt $O/mfma_loop.txt
+{ python tools/mfma_loop.py --nq 64 --realloc 4; python tools/mfma_loop.py --nq 128 --realloc 4; python tools/mfma_loop.py --nq 64 --realloc 4; python tools/mfma_loop.py --nq 128 --realloc 4; } > $O/mfma_loop.txt 2>&1
+timeout 300 python tools/latency_probe.py 1000:128:5 10000:128:5 10000:768:10 65536:128:5 100000:768:100 1000000:768:100 10000000:768:100 > $O/latency.txt 2>&1
+timeout 300 python tools/fallback_probe.py > $O/fallback.txt 2>/dev/null
+NMN_NO_GRID_SELECT=1 timeout 300 python tools/fallback_probe.py >> $O/fallback.txt 2>/dev/null
+bash tools/mask_ab.sh default > $O/masks.txt 2>&1
+tail -3 $O/gpu_suite.log; cat $O/smoke.log | tail -1; head -c 1500 $O/bench_default.json; echo; head -12 $O/timeline_mirror.txt; cat $O/mfma_shapes.txt $O/mfma_loop.txt $O/latency.txt $O/fallback.txt $O/masks.txt
