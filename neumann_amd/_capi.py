@@ -159,6 +159,7 @@ SIGNATURES = {
     "nmn_sharded_set_timing": (C.c_int32, [vp, C.c_int32]),
     "nmn_sharded_set_mirror": (C.c_int32, [vp, C.c_int32]),
     "nmn_sharded_last_gather_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
+    "nmn_sharded_coalesce_stats": (C.c_int32, [vp, vp, vp]),
     "nmn_index_search_dmask": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, vp, vp, vp,
                                            C.POINTER(SearchStats)]),
     "nmn_index_search_dmask_hint": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_int32, vp, C.c_uint64, vp, vp, vp,

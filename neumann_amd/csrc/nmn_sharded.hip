@@ -18,7 +18,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -103,7 +105,36 @@ struct ShardLane {  // what one shard needs for one search in flight
     uint64_t* mask = nullptr;      size_t mask_cap = 0;     // device, this shard's slice of the selection bitmap
 };
 
+// A caller of the handle while it is busy.  Callers that arrive during a search wait in `waiting`; when the running one ends,
+// the oldest waiter is woken to lead and takes every waiting search of the same metric (no bitmap) along as ONE query
+// batch — the request coalescing of nmn_index_search (nmn_api.hip), one level up: a second QUERY in a sweep of all the
+// shards is nearly free, a second SWEEP costs a whole one.  Writers (upload, fill) queue as `solo` and run alone, in turn.
+struct ShardedReq {
+    const float* queries = nullptr;
+    uint32_t nq = 0, k = 0;
+    nmn_metric metric = NMN_METRIC_COSINE;
+    const uint64_t* mask = nullptr;
+    uint64_t* out_rows = nullptr;
+    float* out_scores = nullptr;
+    uint32_t* out_counts = nullptr;
+    nmn_search_stats* stats = nullptr;
+    bool solo = false;
+    // filled by the leader of the batch this request rode in
+    nmn_status status = NMN_OK;
+    std::string err;
+    bool done = false, lead = false;
+    std::condition_variable cv;
+};
+constexpr uint32_t kShardedBatchQueries = 128;  // one pass of the matrix-core sweep
+
 struct nmn_sharded {
+    std::deque<ShardedReq*> waiting;
+    bool busy = false;
+    uint64_t merged_batches = 0, merged_calls = 0;  // batches that carried >= 2 calls / calls in them
+    std::vector<float> cat_q;                        // a merged batch: the callers' queries back to back
+    std::vector<uint64_t> cat_rows;
+    std::vector<float> cat_scores;
+    std::vector<uint32_t> cat_counts;
     uint32_t dim = 0, n_shards = 0;
     uint64_t cap = 0, per = 0;  // total capacity, rows per shard (= ceil(cap / n_shards); the last one may hold fewer)
     uint32_t gather = NMN_GATHER_PEER;
@@ -120,7 +151,7 @@ struct nmn_sharded {
     float last_gather_ms = -1.f;
     hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;  // around the collective + merge on the merging device (when timed)
     bool timing = false;
-    std::mutex mu;  // one search (or upload) at a time per handle: the shards' own coalescers are not involved here
+    std::mutex mu;  // guards `busy` / `waiting`; the lanes belong to whoever holds `busy` (one batch or one writer at a time)
 };
 
 template <typename T>
@@ -311,9 +342,39 @@ static nmn_status for_each_part(nmn_sharded* s, uint64_t row0, uint64_t n, F&& f
     return NMN_OK;
 }
 
+// Take the handle for a writer or a lone search: returns with s->busy held by the caller (mu NOT held).
+static void sharded_acquire_solo(nmn_sharded* s) {
+    ShardedReq me;
+    me.solo = true;
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (!s->busy) {
+        s->busy = true;
+        return;
+    }
+    s->waiting.push_back(&me);
+    me.cv.wait(lk, [&] { return me.lead; });
+}
+// Hand the handle to the oldest waiter (it leads the next batch), or mark it idle.
+static void sharded_release(nmn_sharded* s) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->waiting.empty()) {
+        ShardedReq* nx = s->waiting.front();
+        s->waiting.pop_front();
+        nx->lead = true;
+        nx->cv.notify_one();  // busy stays set: ownership passes
+    } else {
+        s->busy = false;
+    }
+}
+struct SoloGuard {
+    nmn_sharded* s;
+    explicit SoloGuard(nmn_sharded* s_) : s(s_) { sharded_acquire_solo(s); }
+    ~SoloGuard() { sharded_release(s); }
+};
+
 extern "C" nmn_status nmn_sharded_upload(nmn_sharded* s, const float* rows_host, uint64_t row0, uint64_t n) {
     if (!s || (!rows_host && n)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> g(s->mu);
+    SoloGuard turn(s);
     return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t src0, uint64_t cnt) {
         return nmn_index_upload(s->shard[sh], rows_host + src0 * (uint64_t)s->dim, local0, cnt);
     });
@@ -321,7 +382,7 @@ extern "C" nmn_status nmn_sharded_upload(nmn_sharded* s, const float* rows_host,
 
 extern "C" nmn_status nmn_sharded_fill_synthetic(nmn_sharded* s, uint64_t seed, uint64_t row0, uint64_t n) {
     if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
-    std::lock_guard<std::mutex> g(s->mu);
+    SoloGuard turn(s);
     return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t, uint64_t cnt) {
         return nmn_index_fill_synthetic(s->shard[sh], seed, local0, cnt);  // value(seed, row_base + row, col): global ids
     });
@@ -340,15 +401,10 @@ static void bitmap_slice(const uint64_t* src, uint64_t b0, uint64_t nbits, uint6
     if (nbits & 63) dst[words - 1] &= (~0ull) >> (64 - (nbits & 63));
 }
 
-extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
-                                         const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
-                                         nmn_search_stats* stats) {
-    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
-    if (k == 0) return set_error(NMN_ERR_INVALID_TOP_K, "k == 0");
-    if (nq == 0 || nq > NMN_MAX_QUERIES) return set_error(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
-    if (!queries || !out_rows || !out_scores || !out_counts) return set_error(NMN_ERR_INVALID_ARGUMENT, "null buffer");
-    if ((int)metric < 0 || (int)metric > 3) return set_error(NMN_ERR_INVALID_ARGUMENT, "bad metric");
-    std::lock_guard<std::mutex> guard(s->mu);
+// one query batch over every shard: the caller holds s->busy
+static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                              const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                              nmn_search_stats* stats) {
     const uint32_t G = s->n_shards;
     const PackLayout pl = pack_layout(nq, k);
     const size_t qbytes = (size_t)nq * s->dim * sizeof(float);
@@ -465,6 +521,118 @@ extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, u
             stats->total_ms = std::max(stats->total_ms, one.total_ms);
         }
     }
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                                         const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                         nmn_search_stats* stats) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    if (k == 0) return set_error(NMN_ERR_INVALID_TOP_K, "k == 0");
+    if (nq == 0 || nq > NMN_MAX_QUERIES) return set_error(NMN_ERR_INVALID_ARGUMENT, "nq out of range");
+    if (!queries || !out_rows || !out_scores || !out_counts) return set_error(NMN_ERR_INVALID_ARGUMENT, "null buffer");
+    if ((int)metric < 0 || (int)metric > 3) return set_error(NMN_ERR_INVALID_ARGUMENT, "bad metric");
+    ShardedReq me;
+    me.queries = queries;
+    me.nq = nq;
+    me.k = k;
+    me.metric = metric;
+    me.mask = mask;
+    me.out_rows = out_rows;
+    me.out_scores = out_scores;
+    me.out_counts = out_counts;
+    me.stats = stats;
+    std::vector<ShardedReq*> batch{&me};
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (s->busy) {
+            s->waiting.push_back(&me);
+            me.cv.wait(lk, [&] { return me.done || me.lead; });
+            if (me.done) {  // rode in somebody's batch
+                if (me.status != NMN_OK) return set_error(me.status, me.err.c_str());
+                return NMN_OK;
+            }
+        } else {
+            s->busy = true;
+        }
+        // I lead: every waiting search that can share my sweeps comes along (same metric, no bitmap, up to one pass of queries)
+        if (!me.mask) {
+            uint32_t total = me.nq;
+            for (auto it = s->waiting.begin(); it != s->waiting.end();) {
+                ShardedReq* r = *it;
+                if (!r->solo && !r->mask && r->metric == me.metric && total + r->nq <= kShardedBatchQueries) {
+                    total += r->nq;
+                    batch.push_back(r);
+                    it = s->waiting.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+    }
+    nmn_status st;
+    if (batch.size() == 1) {
+        st = sharded_run(s, queries, nq, k, metric, mask, out_rows, out_scores, out_counts, stats);
+    } else {
+        uint32_t total = 0, kmax = 0;
+        for (ShardedReq* r : batch) {
+            total += r->nq;
+            kmax = std::max(kmax, r->k);
+        }
+        s->cat_q.resize((size_t)total * s->dim);
+        s->cat_rows.resize((size_t)total * kmax);
+        s->cat_scores.resize((size_t)total * kmax);
+        s->cat_counts.resize(total);
+        size_t q0 = 0;
+        for (ShardedReq* r : batch) {
+            memcpy(s->cat_q.data() + q0 * s->dim, r->queries, (size_t)r->nq * s->dim * sizeof(float));
+            q0 += r->nq;
+        }
+        nmn_search_stats bst{};
+        st = sharded_run(s, s->cat_q.data(), total, kmax, metric, nullptr, s->cat_rows.data(), s->cat_scores.data(),
+                         s->cat_counts.data(), &bst);
+        const std::string err = st != NMN_OK ? std::string(nmn_last_error()) : std::string();
+        // every caller gets the first k_i entries of its queries' lists: the same total order, so what it gets alone
+        q0 = 0;
+        for (ShardedReq* r : batch) {
+            if (st == NMN_OK) {
+                for (uint32_t q = 0; q < r->nq; q++) {
+                    const size_t src = (q0 + q) * (size_t)kmax, dst = (size_t)q * r->k;
+                    const uint32_t cnt = std::min(s->cat_counts[q0 + q], r->k);
+                    memcpy(r->out_rows + dst, s->cat_rows.data() + src, (size_t)r->k * 8);
+                    memcpy(r->out_scores + dst, s->cat_scores.data() + src, (size_t)r->k * 4);
+                    for (uint32_t i = cnt; i < r->k; i++) {  // (entries past the list's end: the padding of a lone call)
+                        r->out_rows[dst + i] = UINT64_MAX;
+                        uint32_t ninf = 0xFF800000u;
+                        memcpy(&r->out_scores[dst + i], &ninf, 4);
+                    }
+                    r->out_counts[q] = cnt;
+                }
+                if (r->stats) *r->stats = bst;
+            }
+            q0 += r->nq;
+        }
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->merged_batches++;
+        s->merged_calls += batch.size();
+        for (ShardedReq* r : batch) {
+            if (r == &me) continue;
+            r->status = st;
+            r->err = err;
+            r->done = true;
+            r->cv.notify_one();
+        }
+        if (st != NMN_OK) set_error(st, err.c_str());
+    }
+    sharded_release(s);
+    return st;
+}
+
+extern "C" nmn_status nmn_sharded_coalesce_stats(nmn_sharded* s, uint64_t* batches, uint64_t* calls) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (batches) *batches = s->merged_batches;
+    if (calls) *calls = s->merged_calls;
     return NMN_OK;
 }
 

@@ -112,6 +112,14 @@ class GpuShardedIndex:
         _capi.check(self._lib.nmn_sharded_last_gather_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def coalesce_stats(self):
+        """(sweeps that carried two or more concurrent calls, calls in them)"""
+        import ctypes as C
+        from . import _capi
+        b, c = C.c_uint64(), C.c_uint64()
+        _capi.check(self._lib.nmn_sharded_coalesce_stats(self._h, C.byref(b), C.byref(c)))
+        return int(b.value), int(c.value)
+
     def search(self, queries, k, metric=0, mask=None, with_stats=False):
         """As GpuFlatIndex.search: (rows u64 [nq,k], scores f32 [nq,k], counts u32 [nq]); `mask` covers the GLOBAL rows."""
         import ctypes as C

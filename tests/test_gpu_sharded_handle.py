@@ -154,3 +154,61 @@ def test_one_shard_per_device_over_rccl():
             for qi in range(4):
                 er, es = oc.search(A, Q[qi], k, metric, nthreads=16, partial=True, native=True)
                 assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es)
+
+
+def test_concurrent_callers_of_the_handle_share_sweeps():
+    """Many threads searching one nmn_sharded handle: calls that arrive while a search runs leave together as one query
+    batch (nmn_sharded_coalesce_stats), writers run alone in between, and every caller gets bit for bit what a lone call
+    returns — different k per caller, a masked caller among them (never merged), an upload in the middle."""
+    import threading
+    from neumann_amd import GpuShardedIndex
+    n, d = 300_000, 64
+    A = oc.synth(91, 0, n, d, nthreads=8)
+    Q = oc.synth(92, 0, 48, d)
+    keep = np.random.default_rng(4).random(n) < 0.4
+    mask = oc.mask_from_bool(keep)
+    with GpuShardedIndex(d, n + 1000, 3, devices=[0, 0, 0]) as s:
+        s.upload(A)
+        ks = [5 + (t % 4) * 20 for t in range(48)]
+        lone = [s.search(Q[t], ks[t], t % 3) for t in range(48)]
+        lone_masked = s.search(Q[0], 10, 0, mask=mask)
+        errors, lock = [], threading.Lock()
+        start = threading.Barrier(25)
+
+        def caller(t):
+            try:
+                start.wait()
+                for rep in range(6):
+                    qi = (t * 2 + rep) % 48
+                    r, sc, c = s.search(Q[qi], ks[qi], qi % 3)
+                    er, es, ec = lone[qi]
+                    assert np.array_equal(r, er) and np.array_equal(sc.view(np.uint32), es.view(np.uint32)) and np.array_equal(c, ec), (t, rep)
+            except Exception as e:  # noqa: BLE001
+                with lock:
+                    errors.append(repr(e))
+
+        def masked_caller():
+            try:
+                start.wait()
+                for rep in range(4):
+                    r, sc, c = s.search(Q[0], 10, 0, mask=mask)
+                    assert np.array_equal(r, lone_masked[0]) and np.array_equal(sc.view(np.uint32), lone_masked[1].view(np.uint32))
+            except Exception as e:  # noqa: BLE001
+                with lock:
+                    errors.append(repr(e))
+
+        threads = [threading.Thread(target=caller, args=(t,)) for t in range(24)] + [threading.Thread(target=masked_caller)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors[:3]
+        batches, calls = s.coalesce_stats()
+        assert batches >= 1 and calls >= 2 * batches, (batches, calls)
+        # a writer between searches: appended rows are found afterwards, by every later caller
+        extra = oc.synth(93, 0, 500, d)
+        s.upload(extra, row0=n)
+        A2 = np.concatenate([A, extra])
+        r, sc, c = s.search(extra[7], 3, 0)
+        er, es = oc.search(A2, extra[7], 3, 0, nthreads=8, partial=True, native=True)
+        assert np.array_equal(r[0], er) and np.all(sc[0] == es)

@@ -49,7 +49,30 @@ def main():
             for _ in range(5):
                 s.search(Q, a.k, 0)
             b64 = (time.perf_counter() - t0) / 5 * 1e3
-            print(json.dumps({"shards_on_device_0": shards, "gather": label, "rows": a.rows, "dim": a.dim, "k": a.k,
+            # concurrent single-query callers of the handle (Python threads: ctypes releases the GIL for the call)
+            import threading
+            conc = {}
+            for T in (1, 16, 64):
+                stop = time.perf_counter() + 1.5
+                done = [0] * T
+
+                def work(t):
+                    i = t
+                    while time.perf_counter() < stop:
+                        s.search(Q[i % 64], a.k, 0)
+                        i += 1
+                        done[t] += 1
+                b0, c0 = s.coalesce_stats()
+                t0 = time.perf_counter()
+                th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                el = time.perf_counter() - t0
+                b1, c1 = s.coalesce_stats()
+                conc[f"threads_{T}"] = {"qps": round(sum(done) / el), "merged_batches": b1 - b0, "calls_in_them": c1 - c0}
+            print(json.dumps({"shards_on_device_0": shards, "gather": label, "concurrent_callers": conc, "rows": a.rows, "dim": a.dim, "k": a.k,
                               "nq1_ms_median": round(float(np.median(lat)), 3), "gather_plus_merge_ms_median": round(float(np.median(g)), 4),
                               "nq64_ms": round(b64, 3), "identical_to_unsharded": True}))
 
