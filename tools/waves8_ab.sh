@@ -1,0 +1,16 @@
+cd ${GRAFT_REPO_ROOT:-$PWD}
+for round in $(seq 1 ${ROUNDS:-3}); do
+  for mode in w4 w8; do
+    if [ $mode = w8 ]; then export NMN_MFMA_WAVES=8; else unset NMN_MFMA_WAVES; fi
+    python tools/mfma_loop.py --nq $NQ --reps 16 --realloc 4 --tag $mode 2>/dev/null
+  done
+done | python -c "
+import sys, re, collections
+d = collections.defaultdict(list)
+for ln in sys.stdin:
+    m = re.match(r'\s*(\S+) wgs.*? (\d+x\d+) nq=(\d+).*med (\d+\.\d+)', ln)
+    if m: d[(m.group(3), m.group(1))].append(float(m.group(4)))
+for k, v in sorted(d.items()):
+    v.sort()
+    print('nq=%-4s %-4s n=%d  min %.3f  median %.3f  max %.3f' % (k[0], k[1], len(v), v[0], v[len(v)//2], v[-1]))
+"
