@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // k-step.  And they are issued UNCONDITIONALLY: past the end of the workgroup's range every lane re-reads the first
             // 16 bytes of the mirror into a slot nobody will read (one cache line per instruction), so that the stage body is
             // one basic block — a branch around each piece would cut it into nine scheduling regions and with them the
-            // read / MFMA / DMA interleave that sched_group_barrier lays out below.
+            // read / MFMA / DMA interleave laid out below.
             const uint32_t ns = sidx + (kRing - 1);
             const bool issue = ns < n_stage;
             const uint32_t nt = t0 + ns / KC, nkc = ns % KC;

@@ -48,7 +48,10 @@ def main():
                                    "hbm_bytes_per_launch": rd + wr,
                                    "correction": "FETCH_SIZE*1024*2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE*1024; "
                                                  "max over the launches of the template (= the full sweeps)"})
-            print(f"# {rf[0][:70]}: HBM traffic per full sweep: read {rd / 1e9:.3f} GB (corrected) + write {wr / 1e9:.3f} GB")
+            print(f"# {rf[0][:70]}: HBM traffic of the LARGEST launch of this template: read {rd / 1e9:.3f} GB (corrected) + write {wr / 1e9:.3f} GB")
+            # (a query batch of more than 64 queries is a sampling pass + TWO launches of the main sweep, of up to 64 one + one:
+            #  the per-batch figure is the sum over the template's launches divided by the batches)
+            print(f"#   sum over its {rf[1]} launches: read {rf[2] * rf[1] * 1024 * 2 / 1e9:.3f} GB + write {(rw[2] * rw[1] if rw else 0.0) * 1024 / 1e9:.3f} GB")
     if fill_w:
         out["write_calibration_synth_fill_bytes"] = fill_w[2] * 1024
     json.dump(out, open(out_json, "w"), indent=1)
