@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -131,6 +132,9 @@ struct nmn_sharded {
     std::deque<ShardedReq*> waiting;
     bool busy = false;
     uint64_t merged_batches = 0, merged_calls = 0;  // batches that carried >= 2 calls / calls in them
+    std::condition_variable arrive_cv;               // a caller queued up (the leader may be waiting for the cohort to return)
+    uint32_t last_batch_calls = 1;                   // calls the previous batch carried
+    double last_batch_us = 0.0;                      // ... and how long it ran
     std::vector<float> cat_q;                        // a merged batch: the callers' queries back to back
     std::vector<uint64_t> cat_rows;
     std::vector<float> cat_scores;
@@ -547,6 +551,7 @@ extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, u
         std::unique_lock<std::mutex> lk(s->mu);
         if (s->busy) {
             s->waiting.push_back(&me);
+            s->arrive_cv.notify_one();
             me.cv.wait(lk, [&] { return me.done || me.lead; });
             if (me.done) {  // rode in somebody's batch
                 if (me.status != NMN_OK) return set_error(me.status, me.err.c_str());
@@ -555,7 +560,15 @@ extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, u
         } else {
             s->busy = true;
         }
-        // I lead: every waiting search that can share my sweeps comes along (same metric, no bitmap, up to one pass of queries)
+        // I lead.  The callers of the batch that just ended are on their way back (their results are being copied out): a
+        // leader that finds fewer waiters than that batch carried waits a moment for them — 8 % of the batch's time, 30-200 us —
+        // instead of sweeping for half of the cohort now and the other half next (64 threads: 41 calls per batch without).
+        if (!me.mask && s->last_batch_calls > 1 && s->waiting.size() + 1 < s->last_batch_calls) {
+            const double us = std::min(200.0, std::max(30.0, 0.08 * s->last_batch_us));
+            const uint32_t want = s->last_batch_calls;
+            s->arrive_cv.wait_for(lk, std::chrono::microseconds((long)us), [&] { return s->waiting.size() + 1 >= want; });
+        }
+        // every waiting search that can share my sweeps comes along (same metric, no bitmap, up to one pass of queries)
         if (!me.mask) {
             uint32_t total = me.nq;
             for (auto it = s->waiting.begin(); it != s->waiting.end();) {
@@ -571,6 +584,7 @@ extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, u
         }
     }
     nmn_status st;
+    const auto t_batch = std::chrono::steady_clock::now();
     if (batch.size() == 1) {
         st = sharded_run(s, queries, nq, k, metric, mask, out_rows, out_scores, out_counts, stats);
     } else {
@@ -623,6 +637,11 @@ extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, u
             r->cv.notify_one();
         }
         if (st != NMN_OK) set_error(st, err.c_str());
+    }
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->last_batch_calls = (uint32_t)batch.size();
+        s->last_batch_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_batch).count();
     }
     sharded_release(s);
     return st;
