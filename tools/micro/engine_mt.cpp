@@ -19,6 +19,13 @@ int main(int argc, char** argv) {
     const int per = argc > 4 ? atoi(argv[4]) : 200;
     nmn_engine_config cfg;
     nmn_engine_config_default(&cfg);
+    // ENGINE_MT_DEVICES="0,1,2,3": every collection mirror is one nmn_sharded index over these GPUs (an ordinal may repeat)
+    if (const char* e = getenv("ENGINE_MT_DEVICES"))
+        for (const char* p = e; *p && cfg.n_devices < NMN_ENGINE_MAX_DEVICES;) {
+            cfg.devices[cfg.n_devices++] = atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
     const int filtered = getenv("ENGINE_MT_FILTER") ? atoi(getenv("ENGINE_MT_FILTER")) : 0;
     nmn_engine* e = nullptr;
     if (nmn_engine_create(&cfg, &e) != 0) { printf("create failed: %s\n", nmn_engine_last_error()); return 1; }
