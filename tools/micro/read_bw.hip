@@ -48,6 +48,31 @@ __global__ __launch_bounds__(256) void read_rows_kernel(const v4f* __restrict__ 
 }
 
 
+// the masked sweep's pattern without its bitmap and arithmetic: a sorted list of SELECTED rows (a fraction s of all rows, chosen
+// by a hash), each wave walks a contiguous piece of the list, 4 rows per step, 16 lanes per 3 KiB row: what scattered 3 KiB
+// rows can stream at.  (selectivity 1.0 = read_rows_kernel through an index list.)
+template <int CH, bool NT>
+__global__ __launch_bounds__(256) void read_listed_rows_kernel(const v4f* __restrict__ src, const uint32_t* __restrict__ list,
+                                                               size_t n_list, uint32_t ld4, float* __restrict__ sink) {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, grp = lane >> 4;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t per = (n_list + n_waves - 1) / n_waves;
+    const size_t i0 = wave * per, i1 = i0 + per < n_list ? i0 + per : n_list;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = i0 + grp; i < i1; i += 4) {
+        const v4f* rowp = src + (size_t)list[i] * ld4;
+        for (uint32_t c0 = 0; c0 < ld4; c0 += 16u * CH) {
+            v4f x[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) x[c] = NT ? __builtin_nontemporal_load(rowp + c0 + c * 16 + j) : rowp[c0 + c * 16 + j];
+#pragma unroll
+            for (int c = 0; c < CH; c++) acc += x[c];
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
+}
+
 // the access pattern of an MFMA sweep that loads A-fragments straight into registers: workgroup = 4 waves,
 // wave w owns the 128-byte k-step w of every 512-byte stage of a row; lane (n = lane & 15, g = lane >> 4) reads
 // 16 B at row n of a 16-row block, offset g*16 (hi half) and 64 + g*16 (lo half): 16 rows x 64 B per instruction.
@@ -121,6 +146,27 @@ int main(int argc, char** argv) {
 #define RUNR(CH, NT) { float ms = time_ms([&] { hipLaunchKernelGGL((read_rows_kernel<CH, NT>), dim3(blocks), dim3(256), 0, 0, src, n_rows, 192u, sink); }, 5); \
                        printf("row-major    waves/CU %2d  CH %2d  %s : %7.3f ms  %6.0f GB/s\n", waves_per_cu, CH, NT ? "nt " : "def", ms, bytes / ms / 1e6); }
         RUNR(12, true) RUNR(12, false) RUNR(6, true)
+    }
+    for (double sel : {1.0, 0.5, 0.25, 0.1, 0.05, 0.01}) {
+        std::vector<uint32_t> h;
+        h.reserve((size_t)(n_rows * sel * 1.05) + 16);
+        for (size_t r = 0; r < n_rows; r++) {
+            uint64_t x = (r + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+            x ^= x >> 31;
+            x *= 0x94D049BB133111EBull;
+            x ^= x >> 29;
+            if ((double)(x >> 11) * (1.0 / 9007199254740992.0) < sel) h.push_back((uint32_t)r);
+        }
+        uint32_t* dl;
+        CK(hipMalloc((void**)&dl, h.size() * 4 + 16));
+        CK(hipMemcpy(dl, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        for (int waves_per_cu : {16, 32}) {
+            const int blocks = 256 * waves_per_cu / 4;
+#define RUNL(CH, NT) { const size_t nl = h.size(); float ms = time_ms([&] { hipLaunchKernelGGL((read_listed_rows_kernel<CH, NT>), dim3(blocks), dim3(256), 0, 0, src, dl, nl, 192u, sink); }, 5); \
+                       printf("listed rows  selectivity %.2f  waves/CU %2d  CH %2d  %s : %7.3f ms  %6.0f GB/s of the rows read\n", sel, waves_per_cu, CH, NT ? "nt " : "def", ms, (double)nl * 3072 / ms / 1e6); }
+            RUNL(12, true) RUNL(12, false) RUNL(6, true)
+        }
+        CK(hipFree(dl));
     }
     const uint32_t n_tiles = (uint32_t)(n_rows / 64);
     for (int wgs : {256, 512, 1024, 2048}) {
