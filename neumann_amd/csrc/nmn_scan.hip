@@ -198,6 +198,15 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
             const uint64_t left = p.n_rows - r0;
             if (left < 64) mword &= (1ull << left) - 1ull;
         }
+        if constexpr (MASKED) {
+            // a tile the bitmap excludes entirely (half of the tiles at selectivity 0.01): its maximum says "nobody takes part",
+            // which is all anybody reads of it — selection, crowd list and certificate gate every read of scores[] by the
+            // tile maximum, the exact fallback rewrites the scores of the whole shard itself.  No sentinel store, no epilogue.
+            if (mword == 0ull) {  // (wave-uniform)
+                if (lane < (uint32_t)NQ && q0 + lane < p.nq) p.tmax[(uint64_t)(q0 + lane) * p.tmax_stride + tile] = kKeyMasked;
+                continue;
+            }
+        }
         float mydot[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
