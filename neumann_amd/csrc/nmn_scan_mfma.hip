@@ -534,7 +534,10 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     }
     const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0);  // + the K-halves' exchange
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
-    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, 2, WAVES>;
+#ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
+#define NMN_MFMA_AUX 2
+#endif
+    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, NMN_MFMA_AUX, WAVES>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
