@@ -173,8 +173,14 @@ __global__ void __launch_bounds__(kWaves * 64, 1) ingest_kernel(const float* __r
                     const u4v v = *reinterpret_cast<const u4v*>(obuf + r * 32u + ((pc ^ ((r >> 1) & 7u)) * 4u));
                     const uint64_t gi = tile * 64 + r;
                     if (gi < n && pc < valid_chunks)
+#ifdef NMN_INGEST_PLAIN_STORES  // A/B build
                         *reinterpret_cast<u4v*>(reinterpret_cast<char*>(half) + (row0 + gi) * (uint64_t)ld * 2ull + (uint64_t)pair * 128ull +
                                                 pc * 16u) = v;
+#else
+                        // (non-temporal: the mirror is written once and not read by this kernel)
+                        __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(reinterpret_cast<char*>(half) + (row0 + gi) * (uint64_t)ld * 2ull +
+                                                                              (uint64_t)pair * 128ull + pc * 16u));
+#endif
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next pair overwrites the buffer
             }
