@@ -825,11 +825,17 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // Batched sweep on a large shard: a sampling pass over every 32nd tile (tile maxima only) bounds
             // the k-th best score of each query from below, so the main sweep writes scores only for the few
             // tiles that can still hold a candidate.
-            const uint32_t n_sample = (n_tiles + kSampleStep - 1) / kSampleStep;
+            // (NMN_SAMPLE_STEP = 64 / 128: a coarser sample for the A/B — never finer than kSampleStep, which sizes the buffers)
+            static const uint32_t sample_step = [] {
+                const char* e = getenv("NMN_SAMPLE_STEP");
+                const long v = e ? atol(e) : 0;
+                return (v == 64 || v == 128 || v == 256) ? (uint32_t)v : kSampleStep;
+            }();
+            const uint32_t n_sample = (n_tiles + sample_step - 1) / sample_step;
             const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
             if (sample) {
                 ScanParams ss = sp;
-                ss.tile_step = kSampleStep;
+                ss.tile_step = sample_step;
                 ss.n_tiles = n_sample;
                 ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
                 ss.tmax = w->tsample;
@@ -854,7 +860,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 return (uint32_t)n;
             }();
             const uint32_t first_blocks = mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
-            if (use_mfma && sample && nqc > 64 && !no_refine && first_blocks >= 64 && (uint64_t)first_blocks * sp.tiles_per_wave >= 4ull * k) {
+            static const uint32_t refine_min_nq = [] {  // (A/B knob: NMN_REFINE_MIN_NQ)
+                const char* e = getenv("NMN_REFINE_MIN_NQ");
+                return e ? (uint32_t)atol(e) : 65u;
+            }();
+            if (use_mfma && sample && nqc >= refine_min_nq && !no_refine && first_blocks >= 64 && (uint64_t)first_blocks * sp.tiles_per_wave >= 4ull * k) {
                 ScanParams sa = sp;
                 sa.bx_base = 0;
                 sa.bx_count = first_blocks;
