@@ -271,6 +271,8 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     // (One wave per SIMD: nothing overlaps it, so it is kept short — see kLazy below.  Deferring it into the next tile's first
     // stage was tried: its branches (partial tiles, score writes) cut that stage's basic block in two and cost the read / MFMA
     // interleave more than the overlap returned.)
+    // tile maxima of the current group of four tiles (see publish): [wave][query group of the wave][16 queries][4 tiles] in LDS
+    uint32_t* const tk_pend = reinterpret_cast<uint32_t*>(nrm + kNormSlots * 64 + (kHalfK ? QG * 64 * 16 : 0));
     auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile) __attribute__((always_inline)) {
         constexpr int H = decltype(half_c)::value;
         const uint32_t qn = qn_h[H];
@@ -305,7 +307,35 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             tkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
             const auto r16 = __builtin_amdgcn_permlane16_swap(tkey, tkey, false, false);
             tkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
+            // Tile maxima leave in groups of four tiles (one 16-byte store per query instead of four 4-byte ones): a store costs the
+            // wave its issue slot for 100+ cycles behind the DMA pieces whatever it carries, and this one is paid on EVERY tile.
+            // Tiles at the ragged ends of the workgroup's range (and everything when the rows of tmax are not 16-byte aligned)
+            // go out one by one.
+#ifdef NMN_MFMA_TMAX_SINGLE  // A/B build: one store per tile
             if (q_ok && g == 0) p.tmax[(uint64_t)qn * p.tmax_stride + ftile] = tkey;
+#else
+            {
+                // (the four keys of a group wait in LDS, one 16-byte slot per query: registers are what the 128-query kernel has none of)
+                const uint32_t slot = ftile & 3u;  // (wave-uniform)
+                uint32_t* mine = tk_pend + (((uint32_t)wave * (uint32_t)kHalves + (uint32_t)H) * 16u + n) * 4u;
+                if (g == 0) mine[slot] = tkey;
+                if (slot == 3u || ftile + 1u == t1) {
+                    const uint32_t g0 = ftile & ~3u, first = max(g0, t0);
+                    if (q_ok && g == 0) {
+                        uint32_t* dst = p.tmax + (uint64_t)qn * p.tmax_stride + g0;
+                        const u4 v = *reinterpret_cast<const u4*>(mine);
+                        if (first == g0 && slot == 3u && (p.tmax_stride & 3ull) == 0ull) {
+                            *reinterpret_cast<u4*>(dst) = v;
+                        } else {
+                            if (first <= g0 + 0u) dst[0] = v[0];
+                            if (first <= g0 + 1u && slot >= 1u) dst[1] = v[1];
+                            if (first <= g0 + 2u && slot >= 2u) dst[2] = v[2];
+                            if (first <= g0 + 3u && slot >= 3u) dst[3] = v[3];
+                        }
+                    }
+                }
+            }
+#endif
             wmax_h[H] = max(wmax_h[H], tkey);
 #ifdef NMN_MFMA_NO_SCORE_WRITES
             return false;
@@ -532,7 +562,8 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
         pf.fold_ny = ny;
         grid = dim3(((blocks + 7u) / 8u) * 8u * ny, 1);
     }
-    const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0);  // + the K-halves' exchange
+    const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0) +  // + the K-halves' exchange
+                       (size_t)WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 16;                       // + pending tile maxima
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
 #ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
 #define NMN_MFMA_AUX 2
