@@ -616,7 +616,11 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
             case 3: return launch_kc<3, 1, 8, METRIC>(p, s);
             case 4: return launch_kc<2, 2, 8, METRIC>(p, s);
             case 5: return launch_kc<5, 1, 8, METRIC>(p, s);
+#ifdef NMN_MFMA_768_KS1
+            case 6: return launch_kc<6, 1, 8, METRIC>(p, s);  // 16-KiB stages (measurement build)
+#else
             case 6: return launch_kc<3, 2, 8, METRIC>(p, s);
+#endif
             case 8: return launch_kc<4, 2, 8, METRIC>(p, s);
             case 10: return launch_kc<5, 2, 8, METRIC>(p, s);
             default: break;
