@@ -959,7 +959,16 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             rp.nq = nqc;
             rp.cand_cap = w->cand_cap;
             rp.metric = (int)metric;
+            // the exact score of EVERY row for flagged queries: a lane per row streaming through LDS (nmn_ingest.hip) instead of the
+            // eight-lanes-per-row form of rescore_kernel's fallback duty — Euclidean's sequential sum 11 -> 4.7 ms per 10M x 768,
+            // dot / cosine 5.2 -> 4.7 (NMN_NO_EXACT_ROWS=1: the old form, for the A/B)
+            static const bool no_exact_rows = getenv("NMN_NO_EXACT_ROWS") != nullptr;
+            const bool exact_rows = !no_exact_rows && n_rows >= (1u << 18) && exact_rows_supported(idx->ld, idx->dim, (int)metric);  // (small shards: not worth a launch)
+            rp.skip_fallback = exact_rows ? 1 : 0;
             HIP_TRY(launch_rescore(rp, stream));
+            if (exact_rows)  // (returns at once unless a query of the pass is flagged)
+                HIP_TRY(launch_exact_rows(idx->corpus, idx->norms, idx->ld, n_rows, w->qpad, w->qinfo, w->qstate, 1, mask_dev,
+                                          qmasks_dev ? qmasks_dev + qa : nullptr, w->scores, nqc, nqc, (int)metric, stream));
             if (crowd && w->fb_hist && k <= NMN_MAX_TOP_K && !no_grid_select()) {
                 // queries still flagged now hold the exact score of every row: select their top-k with the whole device
                 // (returns at once when none is flagged)

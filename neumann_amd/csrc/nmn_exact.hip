@@ -317,6 +317,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreParams p) {
         return;
     }
     if (p.qstate[q].overflow) {
+        if (p.skip_fallback) return;  // (exact_rows_kernel, a lane per row, serves this pass: nmn_ingest.hip)
         const uint64_t* mask = p.qmasks ? p.qmasks[q] : p.mask;
         const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
         for (uint64_t base = (uint64_t)blockIdx.x * 32u; base < n_pad; base += (uint64_t)gridDim.x * 32u) {
@@ -409,6 +410,11 @@ __global__ void __launch_bounds__(256) exact_scan_kernel(ExactScanParams p) {
 
 hipError_t launch_exact_scan(const ExactScanParams& p, hipStream_t s) {
     if (p.n_rows == 0) return hipSuccess;
+    // large shards of whole-stage rows: a lane per row streaming through LDS (nmn_ingest.hip), same scores bit for bit
+    static const bool no_exact_rows = getenv("NMN_NO_EXACT_ROWS") != nullptr;
+    if (!no_exact_rows && p.n_rows >= (1u << 16) && exact_rows_supported(p.ld, p.dim, p.metric))
+        return launch_exact_rows(p.corpus, p.norms, p.ld, p.n_rows, p.qpad, p.qinfo, p.qstate, 2, p.mask, nullptr, p.scores, p.nql, p.nq,
+                                 p.metric, s);
     uint64_t blocks = (p.n_rows + 31) / 32;
     if (blocks > 2048) blocks = 2048;
     dim3 grid((unsigned)blocks, p.nq);

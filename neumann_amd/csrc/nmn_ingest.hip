@@ -225,6 +225,202 @@ __global__ void __launch_bounds__(kWaves * 64, 1) ingest_kernel(const float* __r
     }
 }
 
+// ---- exact score of EVERY row for flagged queries, a lane per row -------------------------------------------------------------
+// Euclidean (lib.rs:2249-2253) is ONE strictly sequential sum over the elements of a row, s = ((((-0.0 + d0*d0) + d1*d1) + ...),
+// d = q - v, multiply and add rounded separately: a row offers no parallelism at all, and the eight-lanes-per-row form of
+// nmn_exact.hip (euclid_sumsq_seq: products by eight lanes, the sum pulled through shuffles in element order) runs at one add
+// per lane group and shuffle — 11 ms per 10M x 768 sweep, 85 ms at 1536: the cliff behind every Euclidean exact fallback and
+// k > 4096 search.  Dot product / cosine (hnsw.rs:168-193) are eight chains per row, which the same form serves at 5.9 TB/s.
+// Here a LANE OWNS A ROW and walks it in element order from the LDS ring the ingest kernel streams through
+// (global_load_lds_dwordx4, swizzled, three stages in flight per wave), the query broadcast from LDS: 64 independent rows per
+// wave, 6.5 TB/s.  Zero padding of row and query adds +0.0 terms, which leave every sum as it is.  Scores go out exactly as
+// rescore_kernel's fallback duty / exact_scan_kernel write them: f32 bits at score_at(row, q, nql), the sentinel for rows the
+// bitmap excludes or past the end.
+struct ExactRowsParams {
+    const float* corpus;
+    const float* norms;             // cosine
+    const float* qpad;              // [nq][ld]
+    const QInfo* qinfo;             // cosine: |q|
+    const QState* qstate;           // nullable: only flagged queries are computed
+    int flagged;                    // 1: overflow == 1 (the pipeline's fallback duty); 2: overflow != 0 (exact_scan_kernel's rule)
+    const uint64_t* mask;           // nullable
+    const uint64_t* const* qmasks;  // nullable [nq]
+    uint32_t* scores;
+    uint64_t n_rows;
+    uint32_t ld, nql, nq;
+    int metric;
+};
+
+// FAM 0: Euclidean family (one sequential sum); FAM 1: dot product / cosine (eight strided accumulators)
+template <int FAM>
+__global__ void __launch_bounds__(kWaves * 64, 1) exact_rows_kernel(ExactRowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const uint32_t q = blockIdx.y;
+    if (p.qstate) {  // (block-uniform)
+        const uint32_t o = p.qstate[q].overflow;
+        if (p.flagged == 1 ? o != 1u : o == 0u) return;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int kRingLds = kRing * kStageBytes;  // 32 KiB per wave
+    float* ring = lds_all + wave * (kRingLds / 4);
+    float* qlds = lds_all + kWaves * (kRingLds / 4);  // [ld] the query, shared by the four waves
+    const uint32_t ld = p.ld;
+    for (uint32_t i = threadIdx.x; i < ld; i += kWaves * 64) qlds[i] = p.qpad[(size_t)q * ld + i];
+    __syncthreads();
+    const uint64_t n = p.n_rows, n_tiles = (n + 63) / 64;
+    const uint64_t gw = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
+    if (gw >= n_tiles) return;
+    const uint32_t KC = ld / kStageFloats;
+    const uint64_t my_tiles = (n_tiles - gw + n_waves - 1) / n_waves;
+    const uint64_t n_stage = my_tiles * KC;
+    const uint32_t swz = (lane >> 1) & 7u;
+    const uint32_t pr = lane >> 3, pc = lane & 7u;
+    auto src_of = [&](uint64_t tile, uint32_t kc, uint32_t piece) -> const char* {
+        const uint32_t r = 8u * piece + pr;
+        uint64_t gi = tile * 64 + r;
+        if (gi >= n) gi = n - 1;  // (loaded, never scored)
+        return reinterpret_cast<const char*>(p.corpus + gi * (uint64_t)ld + (uint64_t)kc * kStageFloats) + ((pc ^ ((r >> 1) & 7u)) * 16u);
+    };
+    uint64_t i_tile = gw;
+    uint32_t i_kc = 0, i_slot = 0;
+    auto issue = [&]() {
+        float* dst = ring + i_slot * (kStageBytes / 4);
+#pragma unroll
+        for (uint32_t piece = 0; piece < 8; piece++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_of(i_tile, i_kc, piece),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 256u), 16, 0, 2);
+        i_slot = (i_slot + 1u) & (kRing - 1u);
+        if (++i_kc == KC) {
+            i_kc = 0;
+            i_tile += n_waves;
+        }
+    };
+#pragma unroll
+    for (uint32_t st = 0; st < kRing - 1; st++)
+        if (st < n_stage) issue();
+
+    const uint64_t* mask = p.qmasks ? p.qmasks[q] : p.mask;
+    const float qmag = (FAM == 1 && p.metric == NMN_METRIC_COSINE) ? p.qinfo[q].qmag : 0.0f;
+    float sum = -0.0f;
+    float acc[8];
+    uint64_t tile = gw;
+    uint32_t kc = 0, slot = 0;
+    for (uint64_t st = 0; st < n_stage; st++) {
+        if (kc == 0) {
+            sum = -0.0f;
+#pragma unroll
+            for (int l = 0; l < 8; l++) acc[l] = 0.0f;
+        }
+        const uint64_t after = n_stage - 1 - st;
+        if (after >= kRing - 2) wait_vm<(kRing - 2) * 8>();
+        else if (after == 1) wait_vm<8>();
+        else wait_vm<0>();
+        asm volatile("" ::: "memory");
+        if (st + kRing - 1 < n_stage) issue();
+        const float* buf = ring + slot * (kStageBytes / 4) + lane * kStageFloats;
+        const float* qc = qlds + kc * kStageFloats;
+        v4f x[8], y[8];
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) {
+            x[c] = *reinterpret_cast<const v4f*>(buf + ((c ^ swz) * 4u));
+            y[c] = *reinterpret_cast<const v4f*>(qc + c * 4u);  // (every lane the same address: a broadcast)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (FAM == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float d = y[c][e] - x[c][e];
+                    const float pr2 = d * d;
+                    sum = sum + pr2;
+                }
+        } else {
+            // the reference's chains: chunk 4 kc + j holds x[2j] (accumulators 0-3) and x[2j+1] (accumulators 4-7)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float pa = y[2 * j][e] * x[2 * j][e], pb = y[2 * j + 1][e] * x[2 * j + 1][e];
+                    acc[e] = acc[e] + pa;
+                    acc[4 + e] = acc[4 + e] + pb;
+                }
+        }
+        if (kc + 1 == KC) {
+            const uint64_t row = tile * 64 + lane;
+            bool valid = row < n;
+            if (valid && mask) valid = ((mask[row >> 6] >> (row & 63)) & 1ull) != 0;
+            float sc;
+            if constexpr (FAM == 0) {
+                if (p.metric == kMetricNegL2Sq) sc = -sum;
+                else {
+                    const float dist = __builtin_sqrtf(sum);
+                    sc = p.metric == kMetricNegL2 ? -dist : 1.0f / (1.0f + dist);
+                }
+            } else {
+                float r = -0.0f;
+#pragma unroll
+                for (int l = 0; l < 8; l++) r = r + acc[l];
+                sc = r;
+                if (p.metric == NMN_METRIC_COSINE) {
+                    const float vmag = valid ? p.norms[row] : 1.0f;
+                    sc = (qmag == 0.0f || vmag == 0.0f) ? 0.0f : r / (qmag * vmag);  // lib.rs:2257-2266: one mul, one div, in that order
+                }
+            }
+            // (the score matrix is padded to whole tiles: rows past the end get the sentinel like excluded ones)
+            p.scores[score_at(row, q, p.nql)] = valid ? __float_as_uint(sc) : kScoreSentinelBits;
+        }
+        slot = (slot + 1u) & (kRing - 1u);
+        if (++kc == KC) {
+            kc = 0;
+            tile += n_waves;
+        }
+    }
+}
+
+}  // namespace
+
+// what the lane-per-row kernel takes: Euclidean family with rows of whole 32-float stages; dot product / cosine in addition with
+// whole reference chunks (dim % 8 == 0: no scalar tail); the query fits LDS next to the rings
+bool exact_rows_supported(uint32_t ld, uint32_t dim, int metric) {
+    const bool l2 = metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2 || metric == kMetricNegL2Sq;
+    const bool dot = metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT;
+    return (l2 || (dot && dim % 8u == 0)) && dim >= 1 && ld % kStageFloats == 0 && ld >= (uint32_t)kStageFloats && ld <= 8192u;
+}
+
+// exact scores of every row for the flagged queries (all `nq` when qstate is null) -> scores[]
+hipError_t launch_exact_rows(const float* corpus, const float* norms, uint32_t ld, uint64_t n_rows, const float* qpad, const QInfo* qinfo,
+                             const QState* qstate, int flagged, const uint64_t* mask, const uint64_t* const* qmasks, uint32_t* scores,
+                             uint32_t nql, uint32_t nq, int metric, hipStream_t s) {
+    if (n_rows == 0 || nq == 0) return hipSuccess;
+    ExactRowsParams p{};
+    p.corpus = corpus;
+    p.norms = norms;
+    p.qpad = qpad;
+    p.qinfo = qinfo;
+    p.qstate = qstate;
+    p.flagged = flagged;
+    p.mask = mask;
+    p.qmasks = qmasks;
+    p.scores = scores;
+    p.n_rows = n_rows;
+    p.ld = ld;
+    p.nql = nql;
+    p.nq = nq;
+    p.metric = metric;
+    const uint64_t n_tiles = (n_rows + 63) / 64;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_tiles + kWaves - 1) / kWaves, 512);
+    const size_t lds = (size_t)kWaves * kRing * kStageBytes + (size_t)ld * 4;
+    const bool l2 = metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2 || metric == kMetricNegL2Sq;
+    auto kern = l2 ? exact_rows_kernel<0> : exact_rows_kernel<1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(kWaves * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 // rows whose layout the one-pass kernel takes: whole reference chunks (no scalar tail) and whole 32-float stages

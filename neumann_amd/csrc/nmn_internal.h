@@ -118,6 +118,12 @@ bool scan_half_supported(uint32_t ld, int metric);
 // one pass over freshly written rows (nmn_ingest.hip): magnitudes in reference order + (half != nullptr) their bf16 mirror
 // rows and the mirror's error norms folded into err_bits[0..1]
 bool ingest_supported(uint32_t ld, uint32_t dim);
+// exact scores of every row for flagged queries, a lane per row (nmn_ingest.hip): rows of whole 32-float stages
+// flagged: 1 = queries with qstate.overflow == 1, 2 = overflow != 0 (null qstate: every query)
+bool exact_rows_supported(uint32_t ld, uint32_t dim, int metric);
+hipError_t launch_exact_rows(const float* corpus, const float* norms, uint32_t ld, uint64_t n_rows, const float* qpad, const QInfo* qinfo,
+                             const QState* qstate, int flagged, const uint64_t* mask, const uint64_t* const* qmasks, uint32_t* scores,
+                             uint32_t nql, uint32_t nq, int metric, hipStream_t s);
 hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms,
                          uint32_t* max_norm_bits, float* half, uint32_t* err_bits, hipStream_t s);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
@@ -242,6 +248,7 @@ struct RescoreParams {
     uint32_t nql;
     uint32_t ld, dim, nq, cand_cap;
     int metric;
+    int skip_fallback;  // 1: the exact-fallback duty is served by another launch (launch_exact_l2_rows)
 };
 hipError_t launch_rescore(const RescoreParams& p, hipStream_t s);
 // exact score of explicit (query,row) pairs: out[q][i] = score(q, rows[i])
