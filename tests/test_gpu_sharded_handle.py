@@ -197,12 +197,16 @@ def test_concurrent_callers_of_the_handle_share_sweeps():
                 with lock:
                     errors.append(repr(e))
 
-        threads = [threading.Thread(target=caller, args=(t,)) for t in range(24)] + [threading.Thread(target=masked_caller)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        assert not errors, errors[:3]
+        for attempt in range(5):   # whether calls meet is timing: hammer again if none did
+            threads = [threading.Thread(target=caller, args=(t,)) for t in range(24)] + [threading.Thread(target=masked_caller)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            assert not errors, errors[:3]
+            if s.coalesce_stats()[0] >= 1:
+                break
+            start.reset()
         batches, calls = s.coalesce_stats()
         assert batches >= 1 and calls >= 2 * batches, (batches, calls)
         # a writer between searches: appended rows are found afterwards, by every later caller
