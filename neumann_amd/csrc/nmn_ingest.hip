@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) exact_rows_kernel(ExactRowsPar
 bool exact_rows_supported(uint32_t ld, uint32_t dim, int metric) {
     const bool l2 = metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2 || metric == kMetricNegL2Sq;
     const bool dot = metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT;
-    return (l2 || (dot && dim % 8u == 0)) && dim >= 1 && ld % kStageFloats == 0 && ld >= (uint32_t)kStageFloats && ld <= 8192u;
+    return (l2 || (dot && dim % 8u == 0)) && dim >= 1 && ld % kStageFloats == 0 && ld >= (uint32_t)kStageFloats && ld <= 6144u;  // 128 KiB of rings + the query <= 152 KiB of LDS
 }
 
 // exact scores of every row for the flagged queries (all `nq` when qstate is null) -> scores[]

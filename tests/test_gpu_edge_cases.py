@@ -250,6 +250,38 @@ def test_large_k_matches_oracle(n, d):
             assert np.array_equal(rows[0, :er.size], er) and np.all(scores[0, :er.size] == es)
 
 
+@pytest.mark.parametrize("n,d", [(70_000, 1536), (66_000, 4096), (131_072 + 5, 96), (70_000, 40)])
+def test_exact_scores_of_every_row_by_the_lane_per_row_kernel(n, d):
+    """Shards of >= 2^16 rows whose rows are whole 32-float stages compute the exact score of every row (k > 4096, the exact
+    fallback, the certificate) with exact_rows_kernel: a lane per row, the reference's chains in registers (one sequential sum
+    for Euclidean, eight strided accumulators for dot / cosine).  Bit-equal to the oracle for every metric, with a bitmap, with
+    duplicates, a zero row, a partial last tile; rows of 40 floats (not whole stages) keep the eight-lanes-per-row form."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(n + d)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[10] = A[3]
+    A[n - 1] = A[3]
+    A[7] = 0.0
+    Q = rng.standard_normal((2, d)).astype(np.float32)
+    keep = rng.random(n) < 0.3
+    mask = oc.mask_from_bool(keep)
+    k = 5000
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for metric in (0, 1, 2):
+            rows, scores, counts = idx.search(Q, k, metric)
+            for qi in range(2):
+                er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
+                assert counts[qi] == k and np.array_equal(rows[qi], er) and np.all(scores[qi] == es), (metric, qi)
+            rows, scores, counts = idx.search(Q[0], k, metric, mask=mask)
+            er, es = oc.search(A, Q[0], k, metric, mask=mask, nthreads=8, partial=True, native=True)
+            assert counts[0] == er.size and np.array_equal(rows[0, :er.size], er) and np.all(scores[0, :er.size] == es), metric
+            # the certificate's counts come from the same kernel: rows scoring above / at the k-th
+            gt, eq = idx.count_exact(Q[0], float(es[-1]), metric, mask=mask)
+            s_all = oc.scores_all(A, Q[0], metric)
+            assert gt == int(np.sum(s_all[keep] > es[-1])) and eq == int(np.sum(s_all[keep] == es[-1])), metric
+
+
 def test_large_k_multi_query_and_special_values():
     from neumann_amd import GpuFlatIndex
     rng = np.random.default_rng(404)
