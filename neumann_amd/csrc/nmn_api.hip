@@ -1136,17 +1136,34 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     if (st != NMN_OK) return st;
     // ---- a small shard, one query: the whole search is ONE launch (tiny_search_kernel) — the query rides in the kernel
     // arguments, the kernel writes the result into pinned host memory; no H2D, no D2H, none of the pipeline's buffers
-    if (n_reqs == 1 && nq == 1 && !first.pred_cols && (first.mask == nullptr || first.mask_on_device) &&
-        tiny_supported(idx->rows, idx->ld, idx->dim, k) && !no_tiny() && !idx->no_single_launch) {
-        constexpr size_t kTinyK = 1024, kOffScores = kTinyK * 8, kOffCount = kOffScores + kTinyK * 4;
-        if (!w->tiny_pool) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tiny_pool), 128 * 512 * sizeof(unsigned long long)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tiny_ticket), 4));
-            HIP_TRY(hipMemsetAsync(w->tiny_ticket, 0, 4, s));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->tiny_out), kOffCount + 16, hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&w->tiny_out_dev), w->tiny_out, 0));
-            memset(w->tiny_out, 0, kOffCount + 16);
+    constexpr size_t kTinyK = 1024, kOffScores = kTinyK * 8, kOffCount = kOffScores + kTinyK * 4;
+    bool tiny = n_reqs == 1 && nq == 1 && !first.pred_cols && (first.mask == nullptr || first.mask_on_device) &&
+                tiny_supported(idx->rows, idx->ld, idx->dim, k) && !no_tiny() && !idx->no_single_launch;
+    if (tiny && !w->tiny_pool) {
+        // its three buffers appear together or not at all (a workspace with the pool but no ticket would pass this test next
+        // time and launch with null pointers); if one cannot be had the search simply takes the general pipeline
+        unsigned long long* pool = nullptr;
+        uint32_t* ticket = nullptr;
+        uint8_t *out = nullptr, *out_dev = nullptr;
+        bool ok = hipMalloc(reinterpret_cast<void**>(&pool), 128 * 512 * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&ticket), 4) == hipSuccess && hipMemsetAsync(ticket, 0, 4, s) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void**>(&out), kOffCount + 16, hipHostMallocMapped) == hipSuccess &&
+                  hipHostGetDevicePointer(reinterpret_cast<void**>(&out_dev), out, 0) == hipSuccess;
+        if (ok) {
+            memset(out, 0, kOffCount + 16);
+            w->tiny_pool = pool;
+            w->tiny_ticket = ticket;
+            w->tiny_out = out;
+            w->tiny_out_dev = out_dev;
+        } else {
+            (void)hipGetLastError();
+            if (out) (void)hipHostFree(out);
+            if (ticket) (void)hipFree(ticket);
+            if (pool) (void)hipFree(pool);
+            tiny = false;
         }
+    }
+    if (tiny) {
         st = upload_fence_wait(idx, w, s);
         if (st != NMN_OK) return st;
         HIP_TRY(launch_tiny_search(idx->corpus, idx->norms, first.mask, idx->rows, idx->row_base, idx->ld, idx->dim, k, first.metric,
