@@ -167,6 +167,16 @@ nmn_status persist_read_header(FILE* fp, const char* path, PersistHeader* h) {
     if (memcmp(h->magic, kMagic, 8) != 0) return set_error(NMN_ERR_SERIALIZATION, "not a neumann_gpu index file (bad magic)");
     if (h->version != 1) return set_error(NMN_ERR_SERIALIZATION, "unsupported index file version");
     (void)path;
+    // a header is only believed as far as the file can back it: the payload it announces must exist (a hostile header
+    // must not size an allocation), and rows x dim must not wrap
+    if (h->dim != 0 && h->rows > (UINT64_MAX / 8ull) / h->dim) return set_error(NMN_ERR_SERIALIZATION, "index file header is inconsistent");
+    const long here = ftell(fp);
+    if (here >= 0 && fseek(fp, 0, SEEK_END) == 0) {
+        const long end = ftell(fp);
+        if (fseek(fp, here, SEEK_SET) != 0) return set_error(NMN_ERR_IO, "IO error: cannot seek in the index file");
+        if (end >= here && h->payload_bytes > (uint64_t)(end - here))
+            return set_error(NMN_ERR_SERIALIZATION, "index file truncated (payload shorter than its header says)");
+    }
     return NMN_OK;
 }
 

@@ -66,6 +66,19 @@ def test_index_load_limits_and_corruption(tmp_path):
     with pytest.raises(NeumannGpuError) as e:
         GpuFlatIndex.load(tmp_path / "short")
     assert e.value.status == _capi.ERR_SERIALIZATION
+    # a header that announces far more than the file holds (rows x dim near 2^64) must not size an allocation
+    hostile = bytearray(raw)
+    hostile[24:32] = (2**61).to_bytes(8, "little")       # PersistHeader.rows
+    (tmp_path / "hostile").write_bytes(hostile)
+    with pytest.raises(NeumannGpuError) as e:
+        GpuFlatIndex.load(tmp_path / "hostile")
+    assert e.value.status == _capi.ERR_SERIALIZATION
+    hostile[24:32] = (10**9).to_bytes(8, "little")
+    hostile[40:48] = (10**9 * 33 * 4).to_bytes(8, "little")   # ... and a payload_bytes to match
+    (tmp_path / "hostile2").write_bytes(hostile)
+    with pytest.raises(NeumannGpuError) as e:
+        GpuFlatIndex.load(tmp_path / "hostile2")
+    assert e.value.status == _capi.ERR_SERIALIZATION
     (tmp_path / "junk").write_bytes(b"\xff" * 100)
     with pytest.raises(NeumannGpuError) as e:
         GpuFlatIndex.load(tmp_path / "junk")
