@@ -767,6 +767,15 @@ nmn_status persist_read_ivf(FILE* fp, const char* path, const PersistHeader& h, 
     if (h.kind != kPersistIvf || h.dim == 0 || h.aux == 0 || h.aux > 0xFFFFFFFFull)
         return set_error(NMN_ERR_SERIALIZATION, "not an IVF index file");
     const uint32_t n_clusters = (uint32_t)h.aux;
+    {   // what the header announces must be in the file before anything is sized by it
+        const long here = ftell(fp);
+        long end = -1;
+        if (here >= 0 && fseek(fp, 0, SEEK_END) == 0) end = ftell(fp);
+        if (here < 0 || end < here || fseek(fp, here, SEEK_SET) != 0) return set_error(NMN_ERR_IO, "IO error: cannot seek in the index file");
+        const uint64_t left = (uint64_t)(end - here);
+        if ((uint64_t)n_clusters * h.dim > left / 4ull || h.rows > left / 4ull)
+            return set_error(NMN_ERR_SERIALIZATION, "index file truncated (centroids / lists)");
+    }
     std::vector<float> cents((size_t)n_clusters * h.dim);
     std::vector<uint32_t> assign((size_t)h.rows);
     if (fread(cents.data(), 4, cents.size(), fp) != cents.size() || (h.rows && fread(assign.data(), 4, h.rows, fp) != h.rows))
