@@ -2697,7 +2697,7 @@ nmn_status nmn_engine_load_index_binary(nmn_engine* e, const char* path, char* n
     if (nmn::persist_read_header(fp, path, &h) != NMN_OK || h.kind != nmn::kPersistEngine) return err_serialization("not a neumann_gpu collection file");
     st = check_entry_limit(e, h.rows);
     if (st != NMN_OK) return st;
-    if (h.aux > (1ull << 40)) return err_serialization("text block too large");
+    if (h.aux > (1ull << 40) || h.aux > nmn::persist_bytes_left(fp)) return err_serialization("file truncated (text block)");
     std::string text((size_t)h.aux, '\0');
     if (h.aux && fread(&text[0], 1, (size_t)h.aux, fp) != h.aux) return err_serialization("file truncated (text block)");
     JVal root;
@@ -2875,7 +2875,7 @@ nmn_status nmn_engine_ivf_load(nmn_engine* e, const char* path, nmn_engine_ivf**
         return err_serialization("not a neumann_gpu IVF index file");
     st = check_entry_limit(e, h.rows);
     if (st != NMN_OK) return st;
-    if (h.aux > (1ull << 40)) return err_serialization("text block too large");
+    if (h.aux > (1ull << 40) || h.aux > nmn::persist_bytes_left(fp)) return err_serialization("file truncated (text block)");
     std::string text((size_t)h.aux, '\0');
     if (h.aux && fread(&text[0], 1, (size_t)h.aux, fp) != h.aux) return err_serialization("file truncated (text block)");
     JVal root;

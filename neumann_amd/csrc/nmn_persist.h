@@ -28,6 +28,8 @@ struct PersistHeader {  // 64 bytes, little endian
 static_assert(sizeof(PersistHeader) == 64, "PersistHeader is part of the file format");
 
 nmn_status persist_io_error(const char* what, const char* path);
+// bytes between the file position and the end of the file (UINT64_MAX if it cannot be told): what a header may announce
+uint64_t persist_bytes_left(FILE* fp);
 nmn_status persist_check_file_size(const char* path, uint64_t max_file_bytes, uint64_t* size_out);
 nmn_status persist_check_entries(uint64_t entries, uint64_t max_entries);
 nmn_status persist_write_shard(nmn_index* idx, FILE* fp, const char* path);

@@ -162,6 +162,14 @@ nmn_status persist_write_shard(nmn_index* idx, FILE* fp, const char* path) {
     return st;
 }
 
+uint64_t persist_bytes_left(FILE* fp) {
+    const long here = ftell(fp);
+    if (here < 0 || fseek(fp, 0, SEEK_END) != 0) return UINT64_MAX;
+    const long end = ftell(fp);
+    if (fseek(fp, here, SEEK_SET) != 0 || end < here) return UINT64_MAX;
+    return (uint64_t)(end - here);
+}
+
 nmn_status persist_read_header(FILE* fp, const char* path, PersistHeader* h) {
     if (fread(h, sizeof *h, 1, fp) != 1) return set_error(NMN_ERR_SERIALIZATION, "index file truncated (header)");
     if (memcmp(h->magic, kMagic, 8) != 0) return set_error(NMN_ERR_SERIALIZATION, "not a neumann_gpu index file (bad magic)");
