@@ -568,12 +568,13 @@ extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, u
             const uint32_t want = s->last_batch_calls;
             s->arrive_cv.wait_for(lk, std::chrono::microseconds((long)us), [&] { return s->waiting.size() + 1 >= want; });
         }
-        // every waiting search that can share my sweeps comes along (same metric, no bitmap, up to one pass of queries)
-        if (!me.mask) {
+        // every waiting search that can share my sweeps comes along (same metric, no bitmap, up to one pass of queries; k within
+        // the candidate-list path, which also bounds the merged result block: 128 x NMN_MAX_TOP_K entries)
+        if (!me.mask && me.k <= NMN_MAX_TOP_K) {
             uint32_t total = me.nq;
             for (auto it = s->waiting.begin(); it != s->waiting.end();) {
                 ShardedReq* r = *it;
-                if (!r->solo && !r->mask && r->metric == me.metric && total + r->nq <= kShardedBatchQueries) {
+                if (!r->solo && !r->mask && r->metric == me.metric && r->k <= NMN_MAX_TOP_K && total + r->nq <= kShardedBatchQueries) {
                     total += r->nq;
                     batch.push_back(r);
                     it = s->waiting.erase(it);

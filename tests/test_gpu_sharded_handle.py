@@ -159,7 +159,7 @@ def test_one_shard_per_device_over_rccl():
 def test_concurrent_callers_of_the_handle_share_sweeps():
     """Many threads searching one nmn_sharded handle: calls that arrive while a search runs leave together as one query
     batch (nmn_sharded_coalesce_stats), writers run alone in between, and every caller gets bit for bit what a lone call
-    returns — different k per caller, a masked caller among them (never merged), an upload in the middle."""
+    returns — different k per caller, a masked caller and a k = 5000 caller among them (never merged), an upload in the middle."""
     import threading
     from neumann_amd import GpuShardedIndex
     n, d = 300_000, 64
@@ -172,8 +172,9 @@ def test_concurrent_callers_of_the_handle_share_sweeps():
         ks = [5 + (t % 4) * 20 for t in range(48)]
         lone = [s.search(Q[t], ks[t], t % 3) for t in range(48)]
         lone_masked = s.search(Q[0], 10, 0, mask=mask)
+        lone_large = s.search(Q[1], 5000, 0)   # k > NMN_MAX_TOP_K: the large-k path, never merged with other callers
         errors, lock = [], threading.Lock()
-        start = threading.Barrier(25)
+        start = threading.Barrier(26)
 
         def caller(t):
             try:
@@ -197,8 +198,20 @@ def test_concurrent_callers_of_the_handle_share_sweeps():
                 with lock:
                     errors.append(repr(e))
 
+        def large_k_caller():
+            try:
+                start.wait()
+                for rep in range(3):
+                    r, sc, c = s.search(Q[1], 5000, 0)
+                    assert np.array_equal(r, lone_large[0]) and np.array_equal(sc.view(np.uint32), lone_large[1].view(np.uint32))
+                    assert np.array_equal(c, lone_large[2])
+            except Exception as e:  # noqa: BLE001
+                with lock:
+                    errors.append(repr(e))
+
         for attempt in range(5):   # whether calls meet is timing: hammer again if none did
-            threads = [threading.Thread(target=caller, args=(t,)) for t in range(24)] + [threading.Thread(target=masked_caller)]
+            threads = [threading.Thread(target=caller, args=(t,)) for t in range(24)] + [threading.Thread(target=masked_caller),
+                                                                                         threading.Thread(target=large_k_caller)]
             for th in threads:
                 th.start()
             for th in threads:
