@@ -283,7 +283,7 @@ nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled);  /* nmn_inde
 nmn_status nmn_sharded_last_gather_ms(const nmn_sharded* s, float* ms);
 /* Concurrent callers: the handle may be searched from any number of threads (the reference shares one Arc<VectorEngine>,
  * query_router/src/lib.rs:710).  A search that arrives while another runs waits; when the running one ends the oldest
- * waiter leads the next sweep and takes every waiting search of the same metric (and no bitmap) along as ONE query batch
+ * waiter leads the next sweep and takes every waiting search of the same metric (no bitmap, k <= NMN_MAX_TOP_K) along as ONE query batch
  * — up to 128 queries, k = the largest asked for; each caller receives the first k entries of its own queries' lists,
  * i.e. exactly what it gets alone.  Uploads run alone, in arrival order.  batches / calls: sweeps that carried two or
  * more calls, and the calls in them. */
