@@ -63,9 +63,8 @@ __device__ uint32_t radix2(KeyAt key_at, uint32_t n, uint32_t kk, uint32_t* hist
 #pragma unroll
             for (int u = 0; u < V; u++) {
                 const uint32_t key = kv[u];
-                if (key == kKeyMasked) continue;
-                if (pass == 0) atomicAdd(&hist[key >> 21], 1u);
-                else if ((key >> 21) == b1) atomicAdd(&hist[(key >> 10) & 2047u], 1u);
+                const bool in = key != kKeyMasked && (pass == 0 || (key >> 21) == b1);
+                hist_add_wave(hist, in, pass == 0 ? key >> 21 : (key >> 10) & 2047u);  // (keys of one query crowd into few bins)
             }
         }
         __syncthreads();
@@ -210,10 +209,11 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             }
 #pragma unroll
             for (int u = 0; u < V; u++) {
-                if (tk[u] != kKeyMasked && tk[u] >= Twm) {
-                    const uint32_t pos = atomicAdd(&s_w[1], 1u);
-                    if (pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
-                }
+                // (appends are counted per wave, one LDS atomic for all its lanes: on a degenerate shard every element passes,
+                // and 64 lanes adding to one LDS word serialize)
+                const bool pr = tk[u] != kKeyMasked && tk[u] >= Twm;
+                const uint32_t pos = wave_append(pr, &s_w[1]);
+                if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
             }
         }
     }
@@ -247,10 +247,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 #pragma unroll
             for (int u = 0; u < V; u++) {
                 const uint32_t key = bits_to_key(kb[u]);
-                if (key != kKeyMasked && key >= T2m) {
-                    const uint32_t pos = atomicAdd(&s_w[2], 1u);
-                    if (pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | rr[u];
-                }
+                const bool pr = key != kKeyMasked && key >= T2m;
+                const uint32_t pos = wave_append(pr, &s_w[2]);
+                if (pr && pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | rr[u];
             }
         }
         __syncthreads();
@@ -261,10 +260,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             Tc = max(margin_key(T3, qi), skip);  // >= T2m: every row that can matter is in LR
             for (uint32_t e = tid; e < cr; e += kSelThreads) {
                 const unsigned long long ent = LR[e];
-                if ((uint32_t)(ent >> 32) >= Tc) {
-                    const uint32_t pos = atomicAdd(&s_w[3], 1u);
-                    if (pos < p.cand_cap) out[pos] = (uint32_t)(ent & 0xFFFFFFFFull);
-                }
+                const bool pr = (uint32_t)(ent >> 32) >= Tc;
+                const uint32_t pos = wave_append(pr, &s_w[3]);
+                if (pr && pos < p.cand_cap) out[pos] = (uint32_t)(ent & 0xFFFFFFFFull);
             }
             __syncthreads();
             if (tid == 0) {
@@ -317,10 +315,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             }
 #pragma unroll
             for (int u = 0; u < V; u++) {
-                if (tk[u] != kKeyMasked && tk[u] >= Tc) {
-                    const uint32_t pos = atomicAdd(&s_w[1], 1u);
-                    if (pos < kListCap) lb[pos] = tt[u];
-                }
+                const bool pr = tk[u] != kKeyMasked && tk[u] >= Tc;
+                const uint32_t pos = wave_append(pr, &s_w[1]);
+                if (pr && pos < kListCap) lb[pos] = tt[u];
             }
         }
     }
@@ -340,10 +337,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             for (int u = 0; u < V; u++) {
                 const uint32_t e = e0 + (uint32_t)u * kSelThreads;
                 const uint32_t key = bits_to_key(kb[u]);
-                if (e < tot && key != kKeyMasked && key >= Tc) {
-                    const uint32_t pos = atomicAdd(&s_w[2], 1u);
-                    if (pos < p.cand_cap) out[pos] = lb[e >> 6] * kTileRows + (e & 63u);
-                }
+                const bool pr = e < tot && key != kKeyMasked && key >= Tc;
+                const uint32_t pos = wave_append(pr, &s_w[2]);
+                if (pr && pos < p.cand_cap) out[pos] = lb[e >> 6] * kTileRows + (e & 63u);
             }
         }
     }
@@ -629,10 +625,10 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const unsigned long long c = comp(i + e, bits_to_key(kv[e]));
-                    if (c == 0ull) continue;
-                    loc++;
-                    if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) continue;
-                    atomicAdd(&hist[(uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1)], 1u);
+                    if (c != 0ull) loc++;
+                    const bool in = c != 0ull && !(hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift));
+                    const uint32_t bin = (uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1);
+                    hist_add_wave(hist, in, bin);  // (one LDS atomic for all the lanes that share a bin: nmn_select_dev.h)
                 }
             }
             if (d == 0 && loc) atomicAdd(&s_cnt, loc);

@@ -62,6 +62,21 @@ static __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* coun
     return pred ? base + ofs : 0xFFFFFFFFu;
 }
 
+// One histogram count per lane with `in`, by a whole wave.  The selections that histogram composites serve degenerate inputs —
+// at worst every row holds the same score, and then every lane of every wave adds to the SAME bin: 64 serialized LDS atomics
+// per wave and element (65 us per digit at 10M rows on 64 workgroups).  So the lanes that share the first active lane's bin
+// are counted with one ballot and added once; the others (none in the degenerate case, most on ordinary data) add for
+// themselves.  Callable from divergent code: only active lanes take part.
+static __device__ __forceinline__ void hist_add_wave(uint32_t* hist, bool in, uint32_t bin) {
+    const unsigned long long act = __ballot(in);
+    if (act == 0ull) return;
+    const int lead = __builtin_ctzll(act);
+    const uint32_t b0 = (uint32_t)__shfl((int)bin, lead);
+    const unsigned long long same = __ballot(in && bin == b0);
+    if ((int)(threadIdx.x & 63u) == lead) atomicAdd(&hist[b0], (uint32_t)__builtin_popcountll(same));
+    else if (in && bin != b0) atomicAdd(&hist[bin], 1u);
+}
+
 // `walk(f)`: calls f(row, key) for every element, the same number of times on every lane (key == kKeyMasked: skip).
 template <class Walk>
 static __device__ uint32_t exact_select_walk(Walk&& walk, uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
@@ -85,10 +100,9 @@ static __device__ uint32_t exact_select_walk(Walk&& walk, uint32_t k, unsigned l
         uint32_t loc = 0;
         walk([&](uint64_t i, uint32_t key) {
             const unsigned long long c = comp(i, key);
-            if (c == 0ull) return;
-            loc++;
-            if (hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift)) return;
-            atomicAdd(&hist[(uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1)], 1u);
+            if (c != 0ull) loc++;
+            const bool in = c != 0ull && !(hi_shift < 64 && (c >> hi_shift) != (prefix >> hi_shift));
+            hist_add_wave(hist, in, (uint32_t)(c >> shifts[d]) & (uint32_t)(nb - 1));
         });
         if (d == 0) {  // the first walk also counts the participating rows
             atomicAdd(&s_misc[0], loc);
