@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r02z
 mkdir -p $O
 cd $R
-( time timeout 1500 python -m pytest tests -x -q -m gpu ) > $O/gpu_suite.log 2>&1
+[ -n "$SKIP_SUITE" ] || ( time timeout 1500 python -m pytest tests -x -q -m gpu ) > $O/gpu_suite.log 2>&1   # SKIP_SUITE=1 / SKIP_SHAPES=1: artifacts refreshed elsewhere
 ( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -20,8 +20,8 @@ DB=$(find $O/trace -name "*.db" | head -1)
 python $R/tools/prof_summary.py $DB "bench.py --batched 128 --steps 10 (nq=1 loop, then 128-query batches)" > $O/kernel_trace_batched128.txt 2>&1
 rm -rf $O/trace
 cd $R
-{ echo "# matrix-core sweep across row lengths, final tree (tools/mfma_shapes.sh; sweep_ms includes the sampling pass)"; NQ=64 bash tools/mfma_shapes.sh; NQ=128 bash tools/mfma_shapes.sh; } > $O/mfma_shapes.txt 2>&1
-{ python tools/mfma_loop.py --nq 64 --realloc 4; python tools/mfma_loop.py --nq 128 --realloc 4; python tools/mfma_loop.py --nq 64 --realloc 4; python tools/mfma_loop.py --nq 128 --realloc 4; } > $O/mfma_loop.txt 2>&1
+[ -n "$SKIP_SHAPES" ] || { echo "# matrix-core sweep across row lengths, final tree (tools/mfma_shapes.sh; sweep_ms includes the sampling pass)"; NQ=64 bash tools/mfma_shapes.sh; NQ=128 bash tools/mfma_shapes.sh; } > $O/mfma_shapes.txt 2>&1
+[ -n "$SKIP_SHAPES" ] || { python tools/mfma_loop.py --nq 64 --realloc 4; python tools/mfma_loop.py --nq 128 --realloc 4; python tools/mfma_loop.py --nq 64 --realloc 4; python tools/mfma_loop.py --nq 128 --realloc 4; } > $O/mfma_loop.txt 2>&1
 timeout 300 python tools/latency_probe.py 1000:128:5 10000:128:5 10000:768:10 65536:128:5 100000:768:100 1000000:768:100 10000000:768:100 > $O/latency.txt 2>&1
 timeout 300 python tools/fallback_probe.py > $O/fallback.txt 2>/dev/null
 NMN_NO_GRID_SELECT=1 timeout 300 python tools/fallback_probe.py >> $O/fallback.txt 2>/dev/null
