@@ -261,7 +261,9 @@ typedef struct nmn_sharded_desc {
 nmn_status nmn_sharded_create(const nmn_sharded_desc* desc, nmn_sharded** out);
 nmn_status nmn_sharded_destroy(nmn_sharded* s);
 /* nmn_index_upload over the GLOBAL row numbering: rows [row0, row0+n) (HOST, row-major n x dim) go to the shards whose
- * ranges they fall into.  Rows must arrive in global order (each shard, like nmn_index_upload, takes no gaps). */
+ * ranges they fall into.  Rows must arrive in global order (row0 <= nmn_sharded_rows: a gap is refused before any shard is
+ * touched).  With shards on several devices the parts are copied side by side, one host thread per shard (the same threads
+ * enqueue every shard's search pipeline at once; environment NMN_SHARDED_CREW=1|0 forces them on / off). */
 nmn_status nmn_sharded_upload(nmn_sharded* s, const float* rows_host, uint64_t row0, uint64_t n);
 /* nmn_index_fill_synthetic over the global numbering: the shards together hold exactly the unsharded corpus. */
 nmn_status nmn_sharded_fill_synthetic(nmn_sharded* s, uint64_t seed, uint64_t row0, uint64_t n);

@@ -20,11 +20,15 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nmn_index.h"
@@ -128,6 +132,23 @@ struct ShardedReq {
 };
 constexpr uint32_t kShardedBatchQueries = 128;  // one pass of the matrix-core sweep
 
+// One host thread per shard.  A search enqueues a dozen launches per shard; issued from ONE thread the shards of a node start
+// one after the other (8 shards: the last begins ~0.4 ms after the first, longer than the sweep of a 1.25M-row shard), and a
+// host upload that spans shards would cross one PCIe link at a time.  The crew runs `job(g)` for every shard at once and
+// returns when all have finished ENQUEUEING (the streams carry on); errors come back with their text (the last-error string
+// is thread-local).  Used when the shards sit on several devices (crew_start).
+struct ShardCrew {
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    uint64_t seq = 0;
+    uint32_t pending = 0;
+    bool quit = false;
+    const std::function<nmn_status(uint32_t)>* job = nullptr;
+    std::vector<nmn_status> st;
+    std::vector<std::string> err;
+    std::vector<std::thread> th;
+};
+
 struct nmn_sharded {
     std::deque<ShardedReq*> waiting;
     bool busy = false;
@@ -155,6 +176,7 @@ struct nmn_sharded {
     float last_gather_ms = -1.f;
     hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;  // around the collective + merge on the merging device (when timed)
     bool timing = false;
+    std::unique_ptr<ShardCrew> crew;  // null: the shards share one device (crew_start)
     std::mutex mu;  // guards `busy` / `waiting`; the lanes belong to whoever holds `busy` (one batch or one writer at a time)
 };
 
@@ -184,8 +206,78 @@ static void shard_bounds(const nmn_sharded* s, uint32_t g, uint64_t total, uint6
     *r1 = std::min<uint64_t>(*r0 + s->per, total);
 }
 
+static void crew_worker(nmn_sharded* s, uint32_t g) {
+    ShardCrew& c = *s->crew;
+    (void)hipSetDevice(s->device[g]);
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<nmn_status(uint32_t)>* job;
+        {
+            std::unique_lock<std::mutex> lk(c.m);
+            c.cv_go.wait(lk, [&] { return c.quit || c.seq != seen; });
+            if (c.quit) return;
+            seen = c.seq;
+            job = c.job;
+        }
+        const nmn_status st = (*job)(g);
+        std::string why;
+        if (st != NMN_OK) why = nmn_last_error();
+        std::lock_guard<std::mutex> lk(c.m);
+        c.st[g] = st;
+        c.err[g] = std::move(why);
+        if (--c.pending == 0) c.cv_done.notify_one();
+    }
+}
+static void crew_start(nmn_sharded* s) {
+    // Worth it where the shards sit on different GPUs.  Logical shards of ONE device gain nothing from parallel enqueueing (the
+    // device serializes them anyway) and pay the hand-over: 8 shards on one MI355X, one caller, 0.94 -> 1.03 ms per search.
+    // NMN_SHARDED_CREW=1 / 0 forces it on / off (tests run the crew on the one-GPU box that way).
+    bool several_devices = false;
+    for (int d : s->device) several_devices = several_devices || d != s->device[0];
+    const char* force = getenv("NMN_SHARDED_CREW");
+    if (s->n_shards < 2 || !(force ? atoi(force) != 0 : several_devices)) return;
+    s->crew.reset(new ShardCrew());
+    s->crew->st.assign(s->n_shards, NMN_OK);
+    s->crew->err.resize(s->n_shards);
+    for (uint32_t g = 0; g < s->n_shards; g++) s->crew->th.emplace_back(crew_worker, s, g);
+}
+static void crew_stop(nmn_sharded* s) {
+    if (!s->crew) return;
+    {
+        std::lock_guard<std::mutex> lk(s->crew->m);
+        s->crew->quit = true;
+    }
+    s->crew->cv_go.notify_all();
+    for (std::thread& t : s->crew->th)
+        if (t.joinable()) t.join();
+    s->crew.reset();
+}
+// job(g) for every shard (side by side when there is a crew); the first failure in shard order is reported.  The caller holds
+// s->busy, so one call is in here at a time.
+static nmn_status for_each_shard(nmn_sharded* s, const std::function<nmn_status(uint32_t)>& job) {
+    if (!s->crew) {
+        for (uint32_t g = 0; g < s->n_shards; g++) {
+            const nmn_status st = job(g);
+            if (st != NMN_OK) return st;
+        }
+        return NMN_OK;
+    }
+    ShardCrew& c = *s->crew;
+    std::unique_lock<std::mutex> lk(c.m);
+    c.job = &job;
+    c.pending = s->n_shards;
+    c.seq++;
+    c.cv_go.notify_all();
+    c.cv_done.wait(lk, [&] { return c.pending == 0; });
+    c.job = nullptr;
+    for (uint32_t g = 0; g < s->n_shards; g++)
+        if (c.st[g] != NMN_OK) return set_error(c.st[g], c.err[g].c_str());
+    return NMN_OK;
+}
+
 extern "C" nmn_status nmn_sharded_destroy(nmn_sharded* s) {
     if (!s) return NMN_OK;
+    crew_stop(s);
     for (uint32_t g = 0; g < s->lane.size(); g++) {
         (void)hipSetDevice(s->device[g]);
         ShardLane& l = s->lane[g];
@@ -304,6 +396,7 @@ extern "C" nmn_status nmn_sharded_create(const nmn_sharded_desc* d, nmn_sharded*
     (void)hipSetDevice(s->device[0]);
     (void)hipEventCreate(&s->ev_g0);
     (void)hipEventCreate(&s->ev_g1);
+    crew_start(s);
     *out = s;
     return NMN_OK;
 }
@@ -330,20 +423,22 @@ extern "C" nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled) {
     return NMN_OK;
 }
 
-// rows [row0, row0+n) of the GLOBAL numbering: each shard gets the part that falls into its range.  Like nmn_index_upload
-// rows must arrive without gaps, i.e. in global order (a shard fills up before the next one starts).
+// rows [row0, row0+n) of the GLOBAL numbering: each shard gets the part that falls into its range, all parts at once (a host
+// upload then crosses every GPU's PCIe link at the same time).  Like nmn_index_upload rows must arrive without gaps, i.e. in
+// global order (a shard fills up before the next one starts) — checked here, before any shard is touched.
 template <typename F>
 static nmn_status for_each_part(nmn_sharded* s, uint64_t row0, uint64_t n, F&& f) {
     if (n > s->cap || row0 > s->cap - n) return set_error(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
-    for (uint32_t g = 0; g < s->n_shards && n; g++) {
+    if (row0 > nmn_sharded_rows(s)) return set_error(NMN_ERR_INVALID_ARGUMENT, "row0 leaves a gap (row0 > rows)");
+    if (n == 0) return NMN_OK;
+    const std::function<nmn_status(uint32_t)> job = [&](uint32_t g) -> nmn_status {
         uint64_t r0, r1;
         shard_bounds(s, g, s->cap, &r0, &r1);
         const uint64_t a = std::max(row0, r0), b = std::min(row0 + n, r1);
-        if (a >= b) continue;
-        nmn_status st = f(g, a - r0, a - row0, b - a);
-        if (st != NMN_OK) return st;
-    }
-    return NMN_OK;
+        if (a >= b) return NMN_OK;
+        return f(g, a - r0, a - row0, b - a);
+    };
+    return for_each_shard(s, job);
 }
 
 // Take the handle for a writer or a lone search: returns with s->busy held by the caller (mu NOT held).
@@ -434,7 +529,7 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
         for (uint32_t g = 0; g < G; g++)
             if (rows_of[g]) bitmap_slice(mask, base_of[g], rows_of[g], pin_mask + mask_off[g]);
     // ---- every shard: H2D of the queries (and its bitmap slice), the single-shard pipeline, into its packed block --------
-    for (uint32_t g = 0; g < G; g++) {
+    const std::function<nmn_status(uint32_t)> enqueue = [&](uint32_t g) -> nmn_status {
         ShardLane& l = s->lane[g];
         S_TRY(hipSetDevice(s->device[g]));
         S_TRY(grow_dev(&l.queries, &l.queries_cap, (size_t)nq * s->dim));
@@ -452,6 +547,10 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
         nmn_status st = index_search_device(s->shard[g], l.queries, nq, k, (int)metric, mask_dev,
                                             reinterpret_cast<uint64_t*>(l.block), reinterpret_cast<float*>(l.block + pl.off_scores),
                                             reinterpret_cast<uint32_t*>(l.block + pl.off_counts), l.stream);
+        return st;
+    };
+    {
+        const nmn_status st = for_each_shard(s, enqueue);
         if (st != NMN_OK) return st;
     }
     // ---- the collective: every packed block to the merging device (RCCL: to every device) ---------------------------------

@@ -53,12 +53,21 @@ def test_one_shard_through_rccl_matches_oracle():
         _check(sh, A, Q, k, 0, mask=oc.mask_from_bool(keep), row_base=500)
 
 
+def per_gap(n, n_shards):
+    """first row of the second shard: an upload there while the first shard is empty leaves a gap"""
+    return -(-n // n_shards)
+
+
+@pytest.mark.parametrize("crew", [False, True])
 @pytest.mark.parametrize("n_shards", [2, 3, 8])
-def test_logical_shards_on_one_device_match_oracle(n_shards):
+def test_logical_shards_on_one_device_match_oracle(n_shards, crew, monkeypatch):
     """S shards on device 0 (peer-copy gather): uploads that straddle shard boundaries, shard ranges that are not multiples
-    of 64 (the global bitmap is re-sliced bit by bit), duplicates across shards (ties by global row id)."""
+    of 64 (the global bitmap is re-sliced bit by bit), duplicates across shards (ties by global row id).  crew: the handle
+    drives every shard from a host thread of its own (what it does when the shards sit on different GPUs; forced here)."""
     from neumann_amd import GpuShardedIndex
+    from neumann_amd._capi import NeumannGpuError
     from neumann_amd._capi import GATHER_PEER
+    monkeypatch.setenv("NMN_SHARDED_CREW", "1" if crew else "0")
     n, d, k = 10007, 96, 64
     rng = np.random.default_rng(77 + n_shards)
     A = rng.standard_normal((n, d)).astype(np.float32)
@@ -67,6 +76,9 @@ def test_logical_shards_on_one_device_match_oracle(n_shards):
     Q = np.stack([A[17] + np.float32(1e-3) * rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)])
     with GpuShardedIndex(d, n, n_shards, devices=[0] * n_shards, gather=GATHER_PEER) as sh:
         assert sh.gather_mode == GATHER_PEER
+        with pytest.raises(NeumannGpuError):   # a gap in the global numbering is refused before any shard is touched
+            sh.upload(A[:10], row0=per_gap(n, n_shards))
+        assert sh.rows == 0
         for a, b in ((0, 3000), (3000, 3001), (3001, n)):   # pieces that cross shard boundaries
             sh.upload(A[a:b], row0=a)
         per = -(-n // n_shards)
