@@ -644,7 +644,7 @@ static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* quer
             if (w->timed && first) HIP_TRY(hipEventRecord(w->ev[2], stream));
             const size_t o = (size_t)(qa + q);
             HIP_TRY(launch_largek(w->scores, n_rows, w->lk_keys, k, idx->row_base, out_rows + o * k, out_scores + o * k,
-                                  out_counts + o, stream));
+                                  out_counts + o, stream, w->fb_hist, w->fb_sync));
         }
     }
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[3], stream));

@@ -192,6 +192,8 @@ struct FallbackParams {
     unsigned long long* list;   // [nq][NMN_MAX_TOP_K] composites (score key << 32 | ~row) of the top-k
     uint32_t* list_count;       // [nq]
     unsigned long long* sync;   // grid-barrier counter: zero at allocation, never reset
+    uint32_t list_cap;          // entries per query in `list` (0: NMN_MAX_TOP_K)
+    int all;                    // 1: every query is selected and qstate is not touched (the large-k path: nq = 1, k <= list_cap)
 };
 hipError_t launch_fallback_select(const FallbackParams& p, hipStream_t s);
 
@@ -286,7 +288,8 @@ hipError_t launch_tiny_search(const float* corpus, const float* norms, const uin
 // score_bits[] are exact scores in plain row order (kScoreSentinelBits = row does not take part)
 uint64_t largek_sort_len(uint64_t n_rows);
 hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* keys, uint32_t k, uint64_t row_base,
-                         uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s);
+                         uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s,
+                         uint32_t* sel_hist = nullptr, unsigned long long* sel_sync = nullptr);
 
 // k-means training of an IVF index (nmn_kmeans.hip)
 hipError_t launch_kmeans_update(const float* corpus, uint32_t ld, uint32_t dim, const uint32_t* members,

@@ -586,8 +586,8 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
     __shared__ unsigned long long s_target;
     const uint32_t tid = threadIdx.x, wg = blockIdx.x;
     // anything to do?  (qstate was written by earlier kernels of this stream: every workgroup sees the same flags)
-    bool any = false;
-    for (uint32_t q = 0; q < p.nq; q++) any = any || p.qstate[q].overflow == 1u;
+    bool any = p.all != 0;
+    for (uint32_t q = 0; q < p.nq && !any; q++) any = p.qstate[q].overflow == 1u;
     if (!any) return;
     if (tid == 0) {
         const unsigned long long now = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -602,8 +602,9 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
     };
     const int shifts[6] = {53, 42, 32, 21, 10, 0};
     const int widths[6] = {11, 11, 10, 11, 11, 10};
+    const uint32_t list_cap = p.list_cap ? p.list_cap : (uint32_t)NMN_MAX_TOP_K;
     for (uint32_t q = 0; q < p.nq; q++) {
-        if (p.qstate[q].overflow != 1u) continue;
+        if (!p.all && p.qstate[q].overflow != 1u) continue;
         // zero the global histograms and counters of this query's run, then meet
         for (uint32_t b = wg * kSelThreads + tid; b < 6u * kBins + 2u; b += kFbGrid * kSelThreads) p.ghist[b] = 0u;
         fb_grid_barrier(p.sync, &s_target);
@@ -670,15 +671,15 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
                     const unsigned long long c = comp(i + e, bits_to_key(kv[e]));
                     const bool pred = c != 0ull && c >= prefix;
                     const uint32_t pos = wave_append(pred, g_fill);
-                    if (pred && pos < NMN_MAX_TOP_K) p.list[(size_t)q * NMN_MAX_TOP_K + pos] = c;
+                    if (pred && pos < list_cap) p.list[(size_t)q * list_cap + pos] = c;
                 }
             }
         }
         fb_grid_barrier(p.sync, &s_target);  // the list is complete (and the histograms may be reused by the next query)
         if (wg == 0 && tid == 0) {
             const uint32_t got = empty ? 0u : __hip_atomic_load(g_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p.list_count[q] = min(got, (uint32_t)NMN_MAX_TOP_K);
-            p.qstate[q].overflow = 3u;  // final_kernel: the list is ready
+            p.list_count[q] = min(got, list_cap);
+            if (!p.all) p.qstate[q].overflow = 3u;  // final_kernel: the list is ready
         }
     }
 }

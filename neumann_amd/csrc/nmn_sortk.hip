@@ -134,11 +134,8 @@ uint64_t largek_sort_len(uint64_t n_rows) {
     return n;
 }
 
-hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* keys, uint32_t k, uint64_t row_base,
-                         uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s) {
-    const uint64_t n = largek_sort_len(n_rows);
-    const uint32_t grid_stream = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 32ull);
-    hipLaunchKernelGGL(largek_keys_kernel, dim3(grid_stream), dim3(256), 0, s, score_bits, n_rows, n, keys);
+// the bitonic sort of keys[0 .. n) (n a power of two >= kSortTile), descending
+static void sort_keys(uint64_t* keys, uint64_t n, hipStream_t s) {
     const uint32_t tiles = (uint32_t)(n / kSortTile);
     hipLaunchKernelGGL(bitonic_tile_sort_kernel, dim3(tiles), dim3(kSortThreads), 0, s, keys);
     const uint32_t grid_pairs = (uint32_t)std::min<uint64_t>((n / 2 + 255) / 256, 256ull * 32ull);
@@ -147,6 +144,42 @@ hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* 
             hipLaunchKernelGGL(bitonic_stride_kernel, dim3(grid_pairs), dim3(256), 0, s, keys, n / 2, j, stage);
         hipLaunchKernelGGL(bitonic_tile_merge_kernel, dim3(tiles), dim3(kSortThreads), 0, s, keys, stage);
     }
+}
+
+// sel_hist / sel_sync (the scratch of fallback_select_kernel, both or neither): when k is a small part of the shard the k
+// best composites are first SELECTED — the device-wide radix select of the exact fallback finds the k-th largest composite
+// and appends everything >= it, in any order, to keys[0 .. k) — and only those are sorted: 10M rows, k = 10 000 sorts 2^14
+// keys instead of 2^24 (91 passes over 128 MiB).  The selected set is exactly the first k of the full order (composites are
+// unique), so the output is the same bit for bit.
+hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* keys, uint32_t k, uint64_t row_base,
+                         uint64_t* out_rows, float* out_scores, uint32_t* out_count, hipStream_t s, uint32_t* sel_hist,
+                         unsigned long long* sel_sync) {
+    uint64_t n = largek_sort_len(n_rows);
+    uint64_t n_sel = kSortTile;
+    while (n_sel < (uint64_t)k) n_sel <<= 1;
+    if (sel_hist && sel_sync && n_rows >= (1u << 18) && n_sel * 4 <= n) {
+        hipError_t e = hipMemsetAsync(keys, 0, n_sel * sizeof(uint64_t), s);  // unused slots sort last (and mark the count)
+        if (e != hipSuccess) return e;
+        FallbackParams fb{};
+        fb.all = 1;
+        fb.scores = score_bits;  // plain row order: score_at(row, 0, 1) == row
+        fb.nql = 1;
+        fb.nq = 1;
+        fb.k = k;
+        fb.n_rows = n_rows;
+        fb.ghist = sel_hist;
+        fb.list = reinterpret_cast<unsigned long long*>(keys);
+        fb.list_cap = (uint32_t)n_sel;
+        fb.list_count = out_count;  // (overwritten by the emit kernel with the same value)
+        fb.sync = sel_sync;
+        e = launch_fallback_select(fb, s);
+        if (e != hipSuccess) return e;
+        n = n_sel;
+    } else {
+        const uint32_t grid_stream = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 32ull);
+        hipLaunchKernelGGL(largek_keys_kernel, dim3(grid_stream), dim3(256), 0, s, score_bits, n_rows, n, keys);
+    }
+    sort_keys(keys, n, s);
     const uint32_t grid_emit = (uint32_t)std::min<uint64_t>(((uint64_t)k + 255) / 256, 4096ull);
     hipLaunchKernelGGL(largek_emit_kernel, dim3(grid_emit), dim3(256), 0, s, keys, n, k, row_base, out_rows, out_scores,
                        out_count);

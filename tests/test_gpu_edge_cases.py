@@ -282,6 +282,39 @@ def test_exact_scores_of_every_row_by_the_lane_per_row_kernel(n, d):
             assert gt == int(np.sum(s_all[keep] > es[-1])) and eq == int(np.sum(s_all[keep] == es[-1])), metric
 
 
+def test_large_k_selected_before_it_is_sorted():
+    """k > NMN_MAX_TOP_K on a shard of >= 2^18 rows: while k is a small part of the shard the device-wide radix select picks
+    the k best composites and only those are sorted (nmn_sortk.hip); a k too large for that keeps the full sort.  Same lists
+    bit for bit: duplicates straddling the cut (ties by row id), a filter that leaves fewer than k rows, NaN / inf scores."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(515)
+    n, d = 300_000, 32
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[1000:9000] = A[17]            # 8000 equal scores: the k-th sits inside the run for k = 5000 when q is near A[17]
+    A[5, 0] = np.inf
+    A[6, 1] = np.nan
+    Q = np.stack([A[17] + np.float32(1e-3) * rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)])
+    few = np.zeros(n, bool)
+    few[rng.choice(n, 4500, replace=False)] = True      # fewer rows than k = 5000
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for k in (5000, 70_000, 200_000):               # select + sort of 8192 / 131072 keys; full sort of 2^19
+            for metric in (0, 1, 2):
+                rows, scores, counts = idx.search(Q, k, metric)
+                for qi in range(2):
+                    er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
+                    assert counts[qi] == er.size == k
+                    assert np.array_equal(rows[qi], er), (k, metric, qi)
+                    assert np.array_equal(scores[qi].view(np.uint32), es.view(np.uint32)), (k, metric, qi)
+        for sel, keep in ((0.3, rng.random(n) < 0.3), (0.015, few)):
+            mask = oc.mask_from_bool(keep)
+            rows, scores, counts = idx.search(Q[0], 5000, 0, mask=mask)
+            er, es = oc.search(A, Q[0], 5000, 0, mask=mask, nthreads=8, partial=True, native=True)
+            assert counts[0] == er.size == min(5000, int(keep.sum()))
+            assert np.array_equal(rows[0, :er.size], er) and np.array_equal(scores[0, :er.size].view(np.uint32), es.view(np.uint32)), sel
+            assert np.all(rows[0, er.size:] == np.uint64(2**64 - 1))
+
+
 def test_large_k_multi_query_and_special_values():
     from neumann_amd import GpuFlatIndex
     rng = np.random.default_rng(404)
