@@ -146,7 +146,7 @@ const float* nmn_index_norms_device(const nmn_index* idx);
  * `search_in_collection` scoring + full sort + truncate (vector_engine/src/lib.rs:1950-2101,
  * 1585-1689) and, with `mask`, the survivor scan of `search_with_pre_filter` (lib.rs:3514-3557).
  *
- *   queries  nq x dim f32, HOST.          k  >= 1 (k > NMN_MAX_TOP_K: large-k path, one full sort per query)
+ *   queries  nq x dim f32, HOST.          k  >= 1 (k > NMN_MAX_TOP_K: large-k path, exact scores + select/sort per query)
  *   mask     nullable HOST bitmap, ceil(rows/64) u64 words, bit i of word i/64 (LSB first) = row i
  *            takes part (layout of relational_engine's selection bitmaps, simd.rs:6-311).
  *   out_rows   nq x k  global row ids (row_base + local row), best first; unused slots = UINT64_MAX
