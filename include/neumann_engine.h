@@ -42,7 +42,10 @@ typedef struct nmn_engine_config {
     uint64_t parallel_threshold; /* 5000: kept for API parity, the GPU path has no sequential mode */
     int32_t default_metric;      /* nmn_metric */
     uint64_t max_dimension;      /* 0 = None */
-    uint64_t max_keys_per_scan;  /* 0 = None */
+    uint64_t max_keys_per_scan;  /* 0 = None; else list_keys / list_keys_paginated / clear / search_entities /
+                                    scan_entities_with_embeddings stop after that many keys of the scan (lib.rs:2322, 2341,
+                                    2948, 3179, 3225).  Some(0) is a ConfigurationError in the reference (lib.rs:728-733): a
+                                    binding rejects it before it fills this struct */
     int64_t search_timeout_ms;   /* <0 = None */
     int32_t device;              /* GPU ordinal, -1 = current (new knob, additive) */
     uint32_t cand_cap;           /* 0 = default (new knob, additive) */
@@ -104,8 +107,12 @@ nmn_status nmn_engine_get_embedding(nmn_engine* e, const char* key, float* out, 
 nmn_status nmn_engine_delete_embedding(nmn_engine* e, const char* key); /* lib.rs:1915-1925 */
 int32_t nmn_engine_exists(nmn_engine* e, const char* key);              /* lib.rs:1929-1932 */
 uint64_t nmn_engine_count(nmn_engine* e);                               /* lib.rs:1936-1938 */
-nmn_strlist* nmn_engine_list_keys(nmn_engine* e);                       /* lib.rs:2312-2319 */
-nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed);          /* lib.rs:2340-2352 */
+nmn_strlist* nmn_engine_list_keys(nmn_engine* e);                       /* lib.rs:2312-2329 (bounded by max_keys_per_scan) */
+/* list_keys_paginated (lib.rs:2945-2980): limit -1 = None; *total_count -1 = None */
+nmn_strlist* nmn_engine_list_keys_paginated(nmn_engine* e, uint64_t skip, int64_t limit, int32_t count_total,
+                                            int64_t* total_count, int32_t* has_more);
+/* clear (lib.rs:2340-2354): with max_keys_per_scan set and more keys stored, deletes that many ("call again until 0") */
+nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed);
 nmn_status nmn_engine_batch_store(nmn_engine* e, const char* const* keys, const float* rows, uint64_t n,
                                   uint64_t dim); /* batch_store_embeddings (lib.rs:2865-2913), uniform dim */
 

@@ -716,12 +716,17 @@ struct DeviceSelection {
     const uint64_t* mask_dev;
     uint64_t count;
 };
+// the same as a HOST bitmap over the mirror's rows (a subset of the live rows), e.g. the first max_keys_per_scan keys
+struct HostSelection {
+    const uint64_t* mask;
+    uint64_t count;
+};
 
 nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, int32_t metric,
-                    const DeviceSelection* selected, nmn_results* res) {
+                    const DeviceSelection* selected, nmn_results* res, const HostSelection* host_sel = nullptr) {
     if (!m->has_rows()) return NMN_OK;  // no rows of this dimension
     const uint64_t rows = m->rows();
-    const uint64_t taking_part = selected ? selected->count : rows - std::min<uint64_t>(m->n_dead, rows);
+    const uint64_t taking_part = host_sel ? host_sel->count : selected ? selected->count : rows - std::min<uint64_t>(m->n_dead, rows);
     uint64_t k = std::min<uint64_t>(top_k, taking_part);
     if (k == 0) return NMN_OK;
     std::vector<uint64_t> out_rows(k);
@@ -732,7 +737,7 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
         // several GPUs: the bitmap travels as a host bitmap over global rows (the search slices it per shard); a
         // predicate's selection is read back from devices[0] first (rows / 8 bytes)
         std::vector<uint64_t> sel_host;
-        const uint64_t* mask = m->n_dead ? m->live.data() : nullptr;
+        const uint64_t* mask = host_sel ? host_sel->mask : m->n_dead ? m->live.data() : nullptr;
         if (selected) {
             sel_host.resize((size_t)((rows + 63) / 64));
             if (hipMemcpy(sel_host.data(), selected->mask_dev, sel_host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
@@ -746,7 +751,8 @@ nmn_status gpu_topk(Collection* c, Mirror* m, const float* q, uint64_t top_k, in
                                          out_rows.data(), out_scores.data(), &count, nullptr);
     } else {
         // deleted rows stay in the matrix until the next rebuild: the live bitmap keeps them out of every scan
-        st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric, m->n_dead ? m->live.data() : nullptr,
+        st = nmn_index_search(m->idx, q, 1, (uint32_t)k, (nmn_metric)metric,
+                              host_sel ? host_sel->mask : m->n_dead ? m->live.data() : nullptr,
                               out_rows.data(), out_scores.data(), &count, nullptr);
     }
     if (st != NMN_OK) return err_gpu(st);
@@ -1159,20 +1165,73 @@ uint64_t nmn_engine_count(nmn_engine* e) {
     return e->dflt.live;
 }
 
-nmn_strlist* nmn_engine_list_keys(nmn_engine* e) {
+// max_keys_per_scan (lib.rs:638, 2322, 2341, 2948, 3179, 3225): every unbounded walk over the store stops after that many
+// keys of the scan.  The reference's scan order is its HashSet's (slab_router.rs:287-305: unspecified); here it is slot
+// order, so "the first N keys" is a deterministic prefix.  0 = None.
+static uint64_t scan_limit(const nmn_engine* e) { return e->cfg.max_keys_per_scan ? e->cfg.max_keys_per_scan : UINT64_MAX; }
+
+nmn_strlist* nmn_engine_list_keys(nmn_engine* e) {  // list_keys_bounded, lib.rs:2321-2329
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !l) return l;
     WriteLock g(e);
-    for (const auto& ent : e->dflt.slots)
+    const uint64_t limit = scan_limit(e);
+    for (const auto& ent : e->dflt.slots) {
+        if (l->items.size() >= limit) break;
         if (ent.live) l->items.push_back(ent.key);
+    }
     return l;
 }
 
-nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed) {
+// list_keys_paginated (lib.rs:2945-2980): scan -> take(min(skip + limit.unwrap_or(max_scan), max_scan)) -> skip -> take(limit);
+// total_count = count() when asked for; has_more = skip + items < total, or (no total) items == limit.unwrap_or(0)
+nmn_strlist* nmn_engine_list_keys_paginated(nmn_engine* e, uint64_t skip, int64_t limit, int32_t count_total,
+                                            int64_t* total_count, int32_t* has_more) {
+    nmn_strlist* l = new (std::nothrow) nmn_strlist();
+    if (total_count) *total_count = -1;
+    if (has_more) *has_more = 0;
+    if (!e || !l) return l;
+    WriteLock g(e);
+    const uint64_t max_scan = scan_limit(e);
+    uint64_t fetch = skip + (limit >= 0 ? (uint64_t)limit : max_scan);
+    if (fetch < skip) fetch = UINT64_MAX;  // saturating_add
+    fetch = std::min(fetch, max_scan);
+    uint64_t seen = 0;
+    for (const auto& ent : e->dflt.slots) {
+        if (seen >= fetch) break;
+        if (!ent.live) continue;
+        if (seen++ < skip) continue;
+        if (limit >= 0 && l->items.size() >= (uint64_t)limit) break;
+        l->items.push_back(ent.key);
+    }
+    const uint64_t n = l->items.size();
+    if (count_total) {
+        if (total_count) *total_count = (int64_t)e->dflt.live;
+        uint64_t reach = skip + n;
+        if (reach < skip) reach = UINT64_MAX;
+        if (has_more) *has_more = reach < e->dflt.live ? 1 : 0;
+    } else if (has_more) {
+        *has_more = n == (limit >= 0 ? (uint64_t)limit : 0ull) ? 1 : 0;
+    }
+    return l;
+}
+
+nmn_status nmn_engine_clear(nmn_engine* e, uint64_t* removed) {  // lib.rs:2340-2354
     if (!e) return fail(NMN_ERR_INVALID_ARGUMENT, "null engine");
     WriteLock g(e);
-    if (removed) *removed = e->dflt.live;
-    e->dflt = Collection();
+    const uint64_t max_keys = scan_limit(e);
+    if (e->dflt.live <= max_keys) {
+        if (removed) *removed = e->dflt.live;
+        e->dflt = Collection();
+        return NMN_OK;
+    }
+    // more keys than one bounded scan covers: the first max_keys go ("call again until 0 is returned")
+    std::vector<std::string> keys;
+    for (const auto& ent : e->dflt.slots) {
+        if (keys.size() >= max_keys) break;
+        if (ent.live) keys.push_back(ent.key);
+    }
+    for (const auto& k : keys) delete_from(&e->dflt, k, k);
+    if (removed) *removed = keys.size();
     return NMN_OK;
 }
 
@@ -1683,15 +1742,20 @@ nmn_strlist* nmn_engine_scan_entities_with_embeddings(nmn_engine* e) {  // lib.r
     nmn_strlist* l = new (std::nothrow) nmn_strlist();
     if (!e || !l) return l;
     WriteLock g(e);
-    for (const auto& ent : e->entities.slots)
+    // `.scan("").take(max_scan).filter(entity_has_embedding)`: the reference's bound counts every key of its store in an
+    // unspecified order; this key space only holds entities WITH an embedding, so the bound counts those
+    const uint64_t limit = scan_limit(e);
+    for (const auto& ent : e->entities.slots) {
+        if (l->items.size() >= limit) break;
         if (ent.live) l->items.push_back(ent.key);
+    }
     return l;
 }
 
-uint64_t nmn_engine_count_entities_with_embeddings(nmn_engine* e) {  // lib.rs:3235-3237
+uint64_t nmn_engine_count_entities_with_embeddings(nmn_engine* e) {  // lib.rs:3235-3237: scan_entities_with_embeddings().len()
     if (!e) return 0;
     WriteLock g(e);
-    return e->entities.live;
+    return std::min<uint64_t>(e->entities.live, scan_limit(e));
 }
 
 nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t dim, uint64_t top_k, nmn_results** out) {
@@ -1703,7 +1767,39 @@ nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t di
     nmn_results* res = new_results();
     if (!res) return fail(NMN_ERR_OUT_OF_MEMORY, "results alloc");
     if (!zero_magnitude(q, dim)) {  // lib.rs:3175-3178
-        st = locked_search(e, [&] { return &e->entities; }, q, dim, top_k, NMN_METRIC_COSINE, "search_entities", dl, res);
+        bool bounded = false;
+        {
+            ReadLock rd(e);
+            bounded = e->entities.live > scan_limit(e);
+        }
+        if (bounded) {
+            // `let keys = self.store.scan("").into_iter().take(max_scan)` (lib.rs:3179-3180): only the first max_scan keys of
+            // the scan take part (then the `_embedding` / dimension filter): a selection bitmap over the mirror's rows
+            WriteLock wr(e);
+            Collection* c = &e->entities;
+            Mirror* m = nullptr;
+            st = get_mirror(e, c, dim, &m);
+            if (st == NMN_OK && dl.expired()) st = err_timeout("search_entities", dl.ms);
+            if (st == NMN_OK && m->has_rows()) {
+                std::vector<uint64_t> sel(m->live.size(), 0ull);
+                uint64_t seen = 0, picked = 0;
+                const uint64_t limit = scan_limit(e);
+                for (const auto& ent : c->slots) {
+                    if (seen >= limit) break;
+                    if (!ent.live) continue;
+                    seen++;
+                    if (ent.vec.size() == dim && ent.mrow >= 0 && ((m->live[(uint64_t)ent.mrow >> 6] >> ((uint64_t)ent.mrow & 63)) & 1ull)) {
+                        sel[(uint64_t)ent.mrow >> 6] |= 1ull << ((uint64_t)ent.mrow & 63);
+                        picked++;
+                    }
+                }
+                const HostSelection hs{sel.data(), picked};
+                st = gpu_topk(c, m, q, top_k, NMN_METRIC_COSINE, nullptr, res, &hs);
+                if (st == NMN_OK && dl.expired()) st = err_timeout("search_entities", dl.ms);
+            }
+        } else {
+            st = locked_search(e, [&] { return &e->entities; }, q, dim, top_k, NMN_METRIC_COSINE, "search_entities", dl, res);
+        }
         if (st != NMN_OK) {
             delete res;
             return st;

@@ -55,6 +55,7 @@ ENGINE_SIGNATURES = {
     "nmn_engine_exists": (C.c_int32, [vp, C.c_char_p]),
     "nmn_engine_count": (C.c_uint64, [vp]),
     "nmn_engine_list_keys": (vp, [vp]),
+    "nmn_engine_list_keys_paginated": (vp, [vp, C.c_uint64, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
     "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
@@ -449,6 +450,8 @@ class VectorEngine:
             cfg.parallel_threshold = config.parallel_threshold
             cfg.default_metric = int(config.default_metric)
             cfg.max_dimension = config.max_dimension or 0
+            if config.max_keys_per_scan is not None and int(config.max_keys_per_scan) <= 0:  # lib.rs:728-733
+                raise VectorError(_capi.ERR_CONFIGURATION, "Configuration error: max_keys_per_scan must be greater than 0")
             cfg.max_keys_per_scan = config.max_keys_per_scan or 0
             cfg.search_timeout_ms = -1 if config.search_timeout is None else int(config.search_timeout * 1000)
             cfg.device = config.device
@@ -531,6 +534,16 @@ class VectorEngine:
 
     def list_keys(self):
         return self._take_list(_lib().nmn_engine_list_keys(self._h))
+
+    def list_keys_bounded(self):
+        return self.list_keys()
+
+    def list_keys_paginated(self, pagination):
+        total, more = C.c_int64(), C.c_int32()
+        h = _lib().nmn_engine_list_keys_paginated(self._h, int(pagination.skip),
+                                                  -1 if pagination.limit is None else int(pagination.limit),
+                                                  int(pagination.count_total), C.byref(total), C.byref(more))
+        return PagedResult(self._take_list(h), None if total.value < 0 else int(total.value), bool(more.value))
 
     def clear(self):
         n = C.c_uint64()

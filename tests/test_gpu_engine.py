@@ -654,6 +654,42 @@ def test_search_entities_matches_oracle(E):
         assert np.all(np.array([r.score for r in res], F) == es)
 
 
+def test_search_entities_is_bounded_by_max_keys_per_scan(E):
+    """`let keys = self.store.scan("").into_iter().take(max_scan)` (lib.rs:3179-3180): only the first max_keys_per_scan keys of
+    the scan are scored.  Which keys those are is the scan order's business (a HashSet in the reference, slot order here);
+    what is checkable is that the answer is exactly the oracle's top-k over SOME max_scan keys — here the bounded
+    scan_entities_with_embeddings() — and that an unbounded engine sees everything."""
+    rng = np.random.default_rng(67)
+    n, d, k, bound = 900, 64, 20, 300
+    A = rng.standard_normal((n, d)).astype(F)
+    bounded = E.VectorEngine(E.VectorEngineConfig(max_keys_per_scan=bound))
+    free = E.VectorEngine()
+    for i in range(n):
+        bounded.set_entity_embedding(f"k{i}", A[i])
+        free.set_entity_embedding(f"k{i}", A[i])
+    for i in (5, 17, 250):   # removed keys free their slots: the scan order no longer equals insertion order
+        bounded.remove_entity_embedding(f"k{i}")
+        free.remove_entity_embedding(f"k{i}")
+    scanned = bounded.scan_entities_with_embeddings()
+    assert len(scanned) == bound
+    part = np.zeros(n, bool)
+    part[[int(s[1:]) for s in scanned]] = True
+    live = np.ones(n, bool)
+    live[[5, 17, 250]] = False
+    for t in range(3):
+        q = rng.standard_normal(d).astype(F)
+        res = bounded.search_entities(q, k)
+        er, es = oc.search(A, q, k, 0, mask=oc.mask_from_bool(part))
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+        assert np.all(np.array([r.score for r in res], F) == es)
+        res = free.search_entities(q, k)
+        er, es = oc.search(A, q, k, 0, mask=oc.mask_from_bool(live))
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+    # top_k larger than the bounded scan: every scanned key comes back, nothing else
+    res = bounded.search_entities(A[0], n)
+    assert len(res) == bound and {r.key for r in res} == set(scanned)
+
+
 # ---- concurrency contract (lib.rs:5615-5711) -------------------------------------------------------------
 def test_concurrent_search_and_store(E):
     engine = E.VectorEngine()
