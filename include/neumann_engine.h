@@ -52,7 +52,8 @@ typedef struct nmn_engine_config {
     int64_t max_index_file_bytes; /* lib.rs:644, 660: 100 MiB; < 0 = None; 0 is a ConfigurationError (lib.rs:740-746) */
     int64_t max_index_entries;    /* lib.rs:646, 661: 1 000 000; < 0 = None; 0 is a ConfigurationError (lib.rs:747-753) */
     /* GPUs of this node the engine spreads every collection over (new knob, additive).  0: `device` alone.  1: devices[0]
-     * alone.  >= 2: each mirror is ONE nmn_sharded index (include/neumann_gpu.h) whose equal row ranges sit on
+     * alone.  >= 2: each mirror is ONE nmn_sharded index (include/neumann_gpu.h, NMN_SHARDED_LAYOUT_CYCLIC: 64-row blocks dealt
+     * round-robin, so the rows held — not the capacity — are spread evenly and stay so under appends) whose shards sit on
      * devices[0..n_devices): a search runs on all of them at once, the per-GPU top-k blocks are gathered (RCCL all-gather
      * over xGMI, or peer copies when an ordinal repeats) and merged on devices[0] with ResultMerger::merge_top_k's rule
      * (query_router/src/distributed.rs:413-433).  Results are the single-GPU results.  Metadata columns, IVF indexes and
@@ -274,6 +275,8 @@ uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f);
 /* Mirror bookkeeping (for the cache-protocol tests, lib.rs:9686-9944): number of GPU mirror builds
  * so far and whether a mirror is currently cached for `coll` (NULL = default collection). */
 uint64_t nmn_engine_mirror_builds(nmn_engine* e);
+/* rows the GPU mirror of (default collection, dim) holds on each GPU: out[0 .. min(cap, shards)); returns the shard count */
+uint32_t nmn_engine_mirror_shard_rows(nmn_engine* e, uint64_t dim, uint64_t* out, uint32_t cap);
 /* Pre-filter predicates evaluated by the GPU predicate kernel over the metadata columns, and how many
  * times a column set was (re)built from the store (instrumentation of SURVEY.md §8f-2). */
 uint64_t nmn_engine_device_filter_evals(nmn_engine* e);

@@ -244,6 +244,14 @@ typedef struct nmn_sharded nmn_sharded;
 #define NMN_GATHER_AUTO 0u /* RCCL when the shards' devices are distinct (and there are >= 2), else peer copies */
 #define NMN_GATHER_RCCL 1u /* ncclAllGather, one communicator rank per shard; needs distinct devices (1 shard is legal) */
 #define NMN_GATHER_PEER 2u /* hipMemcpyPeerAsync of every block into the merging device's gather buffer */
+/* How the global rows map to the shards.  RANGES (default): shard g holds [g*ceil(N/G), (g+1)*ceil(N/G)) of
+ * the CAPACITY — the layout of a corpus loaded once (bench.py, config 4).  CYCLIC: 64-row blocks (one scan tile, one bitmap
+ * word) are dealt round-robin, block b -> shard b % G, so the rows HELD are spread evenly however few of the capacity's rows
+ * exist and wherever appends land — what a store that grows and shrinks needs (the engine's mirrors: with RANGES the n live
+ * rows of a mirror with 50 % spare capacity filled shard 0, then shard 1, ... and left the last GPUs idle).  Same API, same
+ * answers: row ids in and out are the global ones. */
+#define NMN_SHARDED_LAYOUT_RANGES 0u
+#define NMN_SHARDED_LAYOUT_CYCLIC 1u
 
 typedef struct nmn_sharded_desc {
     uint32_t dim;            /* vector dimension d (>0) */
@@ -255,7 +263,7 @@ typedef struct nmn_sharded_desc {
     const int32_t* devices;  /* [n_shards] HIP device ordinal of each shard (repeats = logical shards on one GPU);
                                 NULL = round-robin over the node's devices */
     uint32_t cand_cap;       /* as nmn_index_desc.cand_cap */
-    uint32_t reserved;       /* 0 */
+    uint32_t layout;         /* NMN_SHARDED_LAYOUT_*; 0 = contiguous row ranges */
 } nmn_sharded_desc;
 
 nmn_status nmn_sharded_create(const nmn_sharded_desc* desc, nmn_sharded** out);
@@ -278,6 +286,14 @@ uint64_t nmn_sharded_rows(const nmn_sharded* s);               /* rows held, all
 nmn_index* nmn_sharded_shard(nmn_sharded* s, uint32_t g);      /* the shard's own handle (owned by s) */
 int32_t nmn_sharded_device(const nmn_sharded* s, uint32_t g);  /* HIP device of shard g */
 uint32_t nmn_sharded_gather_mode(const nmn_sharded* s);        /* NMN_GATHER_RCCL or NMN_GATHER_PEER: what create chose */
+uint32_t nmn_sharded_layout(const nmn_sharded* s);             /* NMN_SHARDED_LAYOUT_* in effect (1 shard: RANGES) */
+/* nmn_sharded_create on >= 2 shards ends with a SELF-TEST of the collective a search will use: every shard puts its rank
+ * into its result block, the blocks travel through the very gather code path (grouped ncclAllGather on the communicators of
+ * ncclCommInitAll, or the peer copies), and the merging device — with RCCL every device — must hold ranks 0..G-1 in order.
+ * A failure is NMN_ERR_STORAGE with the reason in nmn_last_error(), at create time instead of inside the first search.
+ * nmn_sharded_rccl_ranks: communicator ranks that took part in that all-gather (ncclCommCount of the handle's communicators,
+ * cross-checked against the gathered ranks); 0 when the gather is peer copies. */
+uint32_t nmn_sharded_rccl_ranks(const nmn_sharded* s);
 nmn_status nmn_sharded_set_timing(nmn_sharded* s, int32_t enabled);  /* hipEvent timing of the shards' sweeps and of gather+merge */
 nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled);  /* nmn_index_set_mirror on every shard */
 /* hipEvent span of the last search's collective + merge on the merging device (ms; -1 when not timed).  It starts when

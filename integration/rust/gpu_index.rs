@@ -169,7 +169,7 @@ impl GpuShardedIndex {
             gather: ffi::NMN_GATHER_AUTO,
             devices: devices.as_ptr(),
             cand_cap: 0,
-            reserved: 0,
+            layout: ffi::NMN_SHARDED_LAYOUT_RANGES,
         };
         let mut raw = std::ptr::null_mut();
         check(unsafe { ffi::nmn_sharded_create(&desc, &mut raw) }, dim, dim)?;

@@ -51,7 +51,7 @@ class ShardedDesc(C.Structure):
     """nmn_sharded_desc: one corpus row-range sharded over several devices of ONE process."""
     _fields_ = [("dim", C.c_uint32), ("flags", C.c_uint32), ("capacity_rows", C.c_uint64), ("row_base", C.c_uint64),
                 ("n_shards", C.c_uint32), ("gather", C.c_uint32), ("devices", C.POINTER(C.c_int32)),
-                ("cand_cap", C.c_uint32), ("reserved", C.c_uint32)]
+                ("cand_cap", C.c_uint32), ("layout", C.c_uint32)]
 
 
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
@@ -156,6 +156,8 @@ SIGNATURES = {
     "nmn_sharded_shard": (vp, [vp, C.c_uint32]),
     "nmn_sharded_device": (C.c_int32, [vp, C.c_uint32]),
     "nmn_sharded_gather_mode": (C.c_uint32, [vp]),
+    "nmn_sharded_layout": (C.c_uint32, [vp]),
+    "nmn_sharded_rccl_ranks": (C.c_uint32, [vp]),
     "nmn_sharded_set_timing": (C.c_int32, [vp, C.c_int32]),
     "nmn_sharded_set_mirror": (C.c_int32, [vp, C.c_int32]),
     "nmn_sharded_last_gather_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),

@@ -298,8 +298,8 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_hist), (6 * 2048 + 2) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_list), nq * (size_t)NMN_MAX_TOP_K * 8));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_count), nq * 4));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_sync), 8));
-        HIP_TRY(hipMemset(w->fb_sync, 0, 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_sync), 16));  // arrival counter + abort flag
+        HIP_TRY(hipMemset(w->fb_sync, 0, 16));
     }
     for (auto& e : w->ev) HIP_TRY(hipEventCreate(&e));
     return NMN_OK;
@@ -901,6 +901,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.retry = 0;
             sel.retry_follows = f32_retry ? 1 : 0;
             sel.half_stats = f32_retry ? idx->half_stats : nullptr;
+            sel.fb_sync_reset = w->fb_sync;  // (nullable) zeroed for the device-wide fallback selection further down this stream
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
                 sel.k_extra = w->k_extra;
@@ -935,6 +936,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel2.qinfo = w->qinfo_f32;
                 sel2.retry = 1;
                 sel2.retry_follows = 0;
+                sel2.fb_sync_reset = nullptr;
                 HIP_TRY(launch_select(sel2, stream));
             }
 

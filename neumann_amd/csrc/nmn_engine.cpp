@@ -655,7 +655,7 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
         d.cand_cap = e->cfg.cand_cap;
         nmn_status st;
         if (e->cfg.n_devices >= 2) {
-            // one logical index over the configured GPUs: equal contiguous row ranges, every search on all of them at once,
+            // one logical index over the configured GPUs: the rows dealt evenly over them, every search on all of them at once,
             // per-shard top-k gathered (RCCL over xGMI / peer copies) and merged on devices[0] (nmn_sharded.hip).  The
             // metadata columns of the collection stay on devices[0]; a predicate's bitmap is sliced per shard by the search.
             nmn_sharded_desc sd{};
@@ -667,6 +667,9 @@ nmn_status get_mirror(nmn_engine* e, Collection* c, uint64_t dim, Mirror** out) 
             sd.gather = NMN_GATHER_AUTO;
             sd.devices = e->cfg.devices;
             sd.cand_cap = e->cfg.cand_cap;
+            // 64-row blocks dealt round-robin: the rows HELD (n of the n + 50 % capacity) and every later append are spread
+            // evenly over the GPUs; contiguous ranges of the capacity would fill GPU 0, then GPU 1, ... and leave the last idle
+            sd.layout = NMN_SHARDED_LAYOUT_CYCLIC;
             m->device = e->cfg.devices[0];
             st = nmn_sharded_create(&sd, &m->sh);
         } else {
@@ -2198,6 +2201,24 @@ uint64_t nmn_engine_mirror_builds(nmn_engine* e) {
     if (!e) return 0;
     WriteLock g(e);
     return e->mirror_builds;
+}
+
+// rows the mirror of (default collection, dim) holds on each of its GPUs: out[0 .. min(cap, shards)); returns the number of
+// shards (1 for a single-GPU mirror, 0 when no mirror of that dimension exists)
+uint32_t nmn_engine_mirror_shard_rows(nmn_engine* e, uint64_t dim, uint64_t* out, uint32_t cap) {
+    if (!e) return 0;
+    WriteLock g(e);
+    auto it = e->dflt.mirrors.find(dim);
+    if (it == e->dflt.mirrors.end() || !it->second->has_rows()) return 0;
+    Mirror* m = it->second.get();
+    mirror_flush(&e->dflt, m, dim);
+    if (m->idx) {
+        if (out && cap) out[0] = nmn_index_rows(m->idx);
+        return 1;
+    }
+    const uint32_t G = nmn_sharded_shards(m->sh);
+    for (uint32_t i = 0; i < G && i < cap && out; i++) out[i] = nmn_index_rows(nmn_sharded_shard(m->sh, i));
+    return G;
 }
 
 int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll) {

@@ -153,6 +153,7 @@ struct SelectParams {
     int retry;                 // 1: second selection after the f32 retry sweep — only queries flagged `overflow` take part
     uint32_t* half_stats;      // nullable [2]: queries selected on the bf16 mirror / of those, queries that needed the retry
     int retry_follows;         // 1: an f32 retry sweep follows this selection (it may flag a query as not worth retrying)
+    unsigned long long* fb_sync_reset;  // nullable [2]: counters of the fallback_select launch that follows, zeroed here
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);
@@ -191,7 +192,8 @@ struct FallbackParams {
     uint32_t* ghist;            // [6][2048] + 2 counters, scratch
     unsigned long long* list;   // [nq][NMN_MAX_TOP_K] composites (score key << 32 | ~row) of the top-k
     uint32_t* list_count;       // [nq]
-    unsigned long long* sync;   // grid-barrier counter: zero at allocation, never reset
+    unsigned long long* sync;   // [2] grid-barrier arrival counter + abort flag, both zeroed before every launch
+    unsigned long long timeout_ticks;  // patience of a barrier wait in 100 MHz wall-clock ticks (0: default, ~100 ms)
     uint32_t list_cap;          // entries per query in `list` (0: NMN_MAX_TOP_K)
     int all;                    // 1: every query is selected and qstate is not touched (the large-k path: nq = 1, k <= list_cap)
 };

@@ -785,7 +785,11 @@ nmn_status persist_read_ivf(FILE* fp, const char* path, const PersistHeader& h, 
     PersistHeader hv{};
     nmn_status st = persist_read_header(fp, path, &hv);
     if (st != NMN_OK) return st;
-    if (hv.kind != kPersistFlat || hv.dim != h.dim || hv.rows != h.rows) return set_error(NMN_ERR_SERIALIZATION, "index file header is inconsistent");
+    // (the section must announce exactly the payload its shape implies — persist_read_header has checked that many bytes are
+    //  in the file — before anything is allocated by that shape: payload_bytes = 0 would pass the size check with any rows)
+    if (hv.kind != kPersistFlat || hv.dim != h.dim || hv.rows != h.rows ||
+        hv.payload_bytes != hv.rows * (uint64_t)hv.dim * 4ull + hv.rows * 4ull)
+        return set_error(NMN_ERR_SERIALIZATION, "index file header is inconsistent");
     nmn_index_desc d{};
     d.dim = h.dim;
     d.flags = overrides ? overrides->flags : 0;

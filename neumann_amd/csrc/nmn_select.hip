@@ -165,6 +165,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         return;
     }
     if (p.half_stats && tid == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
+    if (p.fb_sync_reset && q == 0 && tid == 0) {  // arrival counter + abort flag of the fallback_select launch that follows on this stream
+        p.fb_sync_reset[0] = 0ull;
+        p.fb_sync_reset[1] = 0ull;
+    }
     auto score_bits = [&](uint64_t row) -> uint32_t { return p.scores[score_at(row, q, nql)]; };
     const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
     const uint32_t* wmax = p.wmax + (uint64_t)q * p.wmax_stride;
@@ -567,16 +571,40 @@ __device__ uint32_t crowd_select_into(const uint32_t* __restrict__ rows, const f
 // the previous one left it at).
 constexpr uint32_t kFbGrid = 64;  // eight such launches (eight streams) stay co-resident: 1024 threads each, 2048 per CU
 
-__device__ __forceinline__ void fb_grid_barrier(unsigned long long* ctr, unsigned long long* target) {
+// The grid barrier.  sync[0] counts arrivals and is ZEROED before every launch (by select_kernel, which precedes this
+// kernel on the same stream, or by a memset on the large-k path), sync[1] is the launch's abort flag.  Nothing but an
+// idle device guarantees that the 64 workgroups are resident together: up to NMN_MAX_SHARDS logical shards, each with a
+// stream of its own, may flag a query at the same moment, and partially resident grids that wait for each other would
+// hang the device.  So the wait is BOUNDED (FallbackParams::timeout_ticks of the 100 MHz wall clock, ~100 ms): the
+// first workgroup to run out of patience raises the abort flag, every workgroup leaves at its next look, the queries
+// not finished keep overflow == 1 and final_kernel selects them with one workgroup (slower, same answer).  The large-k
+// path, which has no such second line, launches this kernel cooperatively (co-residency guaranteed by the runtime).
+__device__ __forceinline__ bool fb_grid_barrier(unsigned long long* sync, unsigned long long* target, unsigned long long timeout,
+                                                uint32_t* s_abort) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();  // this workgroup's histogram adds / list appends are visible device-wide before it arrives
-        atomicAdd(ctr, 1ull);
+        atomicAdd(sync, 1ull);
         *target += kFbGrid;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < *target) __builtin_amdgcn_s_sleep(4);
+        const unsigned long long t0 = wall_clock64();
+        uint32_t bad = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < *target) {
+            if (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+                bad = 1;
+                break;
+            }
+            if (wall_clock64() - t0 > timeout) {
+                __hip_atomic_store(sync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *s_abort = bad;
         __threadfence();
     }
     __syncthreads();
+    return *s_abort == 0;
 }
 
 __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackParams p) {
@@ -584,16 +612,18 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
     __shared__ PickResult pick;
     __shared__ uint32_t s_cnt;
     __shared__ unsigned long long s_target;
+    __shared__ uint32_t s_abort;
     const uint32_t tid = threadIdx.x, wg = blockIdx.x;
     // anything to do?  (qstate was written by earlier kernels of this stream: every workgroup sees the same flags)
     bool any = p.all != 0;
     for (uint32_t q = 0; q < p.nq && !any; q++) any = p.qstate[q].overflow == 1u;
     if (!any) return;
     if (tid == 0) {
-        const unsigned long long now = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_target = now / kFbGrid * kFbGrid;  // fewer than kFbGrid arrivals can precede this read: the floor is the launch's base
+        s_target = 0ull;  // the counter was zeroed before this launch
+        s_abort = 0u;
     }
     __syncthreads();
+    const unsigned long long patience = p.timeout_ticks ? p.timeout_ticks : 10000000ull;  // 100 ms of the 100 MHz wall clock
     const uint64_t n_pad = (p.n_rows + 63) & ~63ull;
     const uint64_t n_tiles = n_pad / 64, tiles_per = (n_tiles + kFbGrid - 1) / kFbGrid;
     const uint64_t i0 = min((uint64_t)wg * tiles_per, n_tiles) * 64, i1 = min((uint64_t)(wg + 1) * tiles_per, n_tiles) * 64;
@@ -607,7 +637,7 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
         if (!p.all && p.qstate[q].overflow != 1u) continue;
         // zero the global histograms and counters of this query's run, then meet
         for (uint32_t b = wg * kSelThreads + tid; b < 6u * kBins + 2u; b += kFbGrid * kSelThreads) p.ghist[b] = 0u;
-        fb_grid_barrier(p.sync, &s_target);
+        if (!fb_grid_barrier(p.sync, &s_target, patience, &s_abort)) return;
         uint32_t* const g_rows = p.ghist + 6 * kBins;      // participating rows
         uint32_t* const g_fill = p.ghist + 6 * kBins + 1;  // entries appended to the list
         unsigned long long prefix = 0ull;
@@ -637,7 +667,7 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
             for (int b = tid; b < nb; b += kSelThreads)
                 if (hist[b]) atomicAdd(&p.ghist[d * kBins + b], hist[b]);
             if (d == 0 && tid == 0 && s_cnt) atomicAdd(g_rows, s_cnt);
-            fb_grid_barrier(p.sync, &s_target);
+            if (!fb_grid_barrier(p.sync, &s_target, patience, &s_abort)) return;
             // every workgroup picks the digit from the (now complete) global histogram
             for (int b = tid; b < kBins; b += kSelThreads)
                 hist[b] = b < nb ? __hip_atomic_load(&p.ghist[d * kBins + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -675,7 +705,8 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
                 }
             }
         }
-        fb_grid_barrier(p.sync, &s_target);  // the list is complete (and the histograms may be reused by the next query)
+        // the list is complete (and the histograms may be reused by the next query)
+        if (!fb_grid_barrier(p.sync, &s_target, patience, &s_abort)) return;
         if (wg == 0 && tid == 0) {
             const uint32_t got = empty ? 0u : __hip_atomic_load(g_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             p.list_count[q] = min(got, list_cap);
@@ -684,7 +715,27 @@ __global__ void __launch_bounds__(kSelThreads) fallback_select_kernel(FallbackPa
     }
 }
 
-hipError_t launch_fallback_select(const FallbackParams& p, hipStream_t s) {
+static unsigned long long fb_timeout_ticks() {  // NMN_FB_TIMEOUT_TICKS: the test of the abort path sets it to 1
+    static const unsigned long long v = [] {
+        const char* e = getenv("NMN_FB_TIMEOUT_TICKS");
+        const long long x = e ? atoll(e) : 0;
+        return (unsigned long long)(x > 0 ? x : 0);
+    }();
+    return v;
+}
+
+hipError_t launch_fallback_select(const FallbackParams& p_in, hipStream_t s) {
+    FallbackParams p = p_in;
+    if (!p.timeout_ticks) p.timeout_ticks = fb_timeout_ticks();
+    if (p.all) {
+        // no second line behind this selection (the caller sorts what it selected): the counters are zeroed here and the
+        // grid is launched cooperatively — resident together or not at all (an error the caller answers with the full sort)
+        hipError_t e = hipMemsetAsync(p.sync, 0, 16, s);
+        if (e != hipSuccess) return e;
+        p.timeout_ticks = ~0ull >> 1;
+        void* args[] = {&p};
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fallback_select_kernel), dim3(kFbGrid), dim3(kSelThreads), args, 0, s);
+    }
     hipLaunchKernelGGL(fallback_select_kernel, dim3(kFbGrid), dim3(kSelThreads), 0, s, p);
     return hipGetLastError();
 }

@@ -55,6 +55,8 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
     std::string why;
 };
@@ -78,6 +80,8 @@ Rccl& rccl() {
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
         r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd;
         if (!r.ok) r.why = "librccl lacks ncclCommInitAll / ncclAllGather / ncclGroupStart";
     });
@@ -87,6 +91,16 @@ nmn_status fail_nccl(ncclResult_t e, const char* what) {
     Rccl& r = rccl();
     std::string m = std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error") + " (" + std::to_string(e) + ")";
     return set_error(NMN_ERR_STORAGE, m.c_str());
+}
+
+// Every nmn_sharded handle owns communicators of its own over (possibly) the same devices, and an engine keeps one handle
+// per mirror: two searches on two mirrors would issue grouped all-gathers on different communicators from different host
+// threads with nothing ordering them across the devices — RCCL documents that as a potential deadlock (the devices may start
+// the two collectives in opposite orders).  One process-wide lock is held from ncclGroupStart until every rank's stream has
+// drained the collective: collectives of different handles never interleave.  (Their sweeps, enqueued before, still overlap.)
+std::mutex& collective_mutex() {
+    static std::mutex m;
+    return m;
 }
 
 struct PackLayout {
@@ -162,6 +176,9 @@ struct nmn_sharded {
     std::vector<uint32_t> cat_counts;
     uint32_t dim = 0, n_shards = 0;
     uint64_t cap = 0, per = 0;  // total capacity, rows per shard (= ceil(cap / n_shards); the last one may hold fewer)
+    uint64_t row_base = 0;      // global id of row 0 (cyclic layout: added when the shards' local ids are mapped back)
+    bool cyclic = false;        // NMN_SHARDED_LAYOUT_CYCLIC: 64-row blocks dealt round-robin (block b -> shard b % G, local block b / G)
+    uint32_t rccl_ranks = 0;    // communicator ranks the create-time self-test saw answer (0: peer-copy gather)
     uint32_t gather = NMN_GATHER_PEER;
     std::vector<nmn_index*> shard;
     std::vector<int> device;
@@ -275,6 +292,148 @@ static nmn_status for_each_shard(nmn_sharded* s, const std::function<nmn_status(
     return NMN_OK;
 }
 
+// ---- the collective ----------------------------------------------------------------------------------------------------
+// lane[g].block (`bytes` each) of every shard -> lane[0].gathered[g * bytes ...] (RCCL: -> every lane's `gathered`).  Enqueued
+// on the lanes' streams behind whatever produced the blocks; on return the merging stream (lane 0) is ordered behind all of
+// them.  RCCL: the caller holds collective_mutex() until every lane's stream has drained.
+static nmn_status sharded_gather(nmn_sharded* s, size_t bytes) {
+    const uint32_t G = s->n_shards;
+    ShardLane& root = s->lane[0];
+    if (s->gather == NMN_GATHER_RCCL) {
+        Rccl& r = rccl();
+        ncclResult_t e = r.GroupStart();
+        if (e != 0) return fail_nccl(e, "ncclGroupStart");
+        for (uint32_t g = 0; g < G && e == 0; g++) {
+            // (grouped calls may be issued from one thread for all the devices it drives; RCCL sets the device itself)
+            e = r.AllGather(s->lane[g].block, s->lane[g].gathered, bytes, kNcclChar, s->comm[g], s->lane[g].stream);
+        }
+        ncclResult_t e2 = r.GroupEnd();
+        if (e != 0) return fail_nccl(e, "ncclAllGather");
+        if (e2 != 0) return fail_nccl(e2, "ncclGroupEnd");
+        return NMN_OK;
+    }
+    for (uint32_t g = 0; g < G; g++) {
+        ShardLane& l = s->lane[g];
+        S_TRY(hipSetDevice(s->device[g]));
+        // enqueued on the PRODUCING shard's stream (right behind its pipeline); the merging stream waits for the event
+        if (s->device[g] == s->device[0])
+            S_TRY(hipMemcpyAsync(root.gathered + (size_t)g * bytes, l.block, bytes, hipMemcpyDeviceToDevice, l.stream));
+        else
+            S_TRY(hipMemcpyPeerAsync(root.gathered + (size_t)g * bytes, s->device[0], l.block, s->device[g], bytes, l.stream));
+        if (g != 0) S_TRY(hipEventRecord(l.done, l.stream));
+    }
+    S_TRY(hipSetDevice(s->device[0]));
+    for (uint32_t g = 1; g < G; g++) S_TRY(hipStreamWaitEvent(root.stream, s->lane[g].done, 0));
+    return NMN_OK;
+}
+
+// wait for every lane's stream (after a failure: nothing may still be reading the staging buffers the next call rewrites)
+static void sharded_drain(nmn_sharded* s) {
+    for (uint32_t g = 0; g < s->lane.size(); g++) {
+        if (!s->lane[g].stream) continue;
+        (void)hipSetDevice(s->device[g]);
+        (void)hipStreamSynchronize(s->lane[g].stream);
+    }
+    (void)hipGetLastError();
+    if (!s->device.empty()) (void)hipSetDevice(s->device[0]);
+}
+
+// create-time self-test: ranks through the collective.  Shard g's block = 4 words {magic, g, G, ~g}; after the gather the
+// merging device — with RCCL every device — must hold them in rank order.
+static nmn_status sharded_selftest(nmn_sharded* s) {
+    const uint32_t G = s->n_shards;
+    constexpr size_t kBytes = 16;
+    constexpr uint32_t kMagic = 0x4E4D4E53u;  // "NMNS"
+    std::unique_lock<std::mutex> coll(collective_mutex(), std::defer_lock);
+    if (s->gather == NMN_GATHER_RCCL) coll.lock();
+    nmn_status st = NMN_OK;
+    for (uint32_t g = 0; g < G && st == NMN_OK; g++) {
+        ShardLane& l = s->lane[g];
+        const uint32_t words[4] = {kMagic, g, G, ~g};
+        hipError_t e = hipSetDevice(s->device[g]);
+        if (e == hipSuccess) e = grow_dev(&l.block, &l.block_cap, kBytes);
+        if (e == hipSuccess && (s->gather == NMN_GATHER_RCCL || g == 0)) e = grow_dev(&l.gathered, &l.gathered_cap, kBytes * G);
+        if (e == hipSuccess && l.gathered) e = hipMemsetAsync(l.gathered, 0, kBytes * G, l.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(l.block, words, kBytes, hipMemcpyHostToDevice, l.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(l.stream);  // (`words` is a stack buffer)
+        if (e != hipSuccess) st = set_error_hip(e, "self-test: staging a shard's rank");
+    }
+    if (st == NMN_OK) st = sharded_gather(s, kBytes);
+    std::vector<uint32_t> got((size_t)4 * G);
+    const uint32_t readers = s->gather == NMN_GATHER_RCCL ? G : 1u;
+    for (uint32_t r = 0; r < readers && st == NMN_OK; r++) {
+        ShardLane& l = s->lane[r];
+        hipError_t e = hipSetDevice(s->device[r]);
+        if (e == hipSuccess) e = hipMemcpyAsync(got.data(), l.gathered, kBytes * G, hipMemcpyDeviceToHost, l.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(l.stream);
+        if (e != hipSuccess) {
+            st = set_error_hip(e, "self-test: reading the gathered ranks back");
+            break;
+        }
+        for (uint32_t g = 0; g < G; g++) {
+            const uint32_t* w = got.data() + (size_t)4 * g;
+            if (w[0] != kMagic || w[1] != g || w[2] != G || w[3] != ~g) {
+                const std::string m = std::string("Storage error: multi-GPU self-test failed: device ") + std::to_string(s->device[r]) +
+                                      " does not hold the block of shard " + std::to_string(g) + " (device " + std::to_string(s->device[g]) +
+                                      ") after the " + (s->gather == NMN_GATHER_RCCL ? "RCCL all-gather" : "peer-copy gather");
+                st = set_error(NMN_ERR_STORAGE, m.c_str());
+                break;
+            }
+        }
+    }
+    if (st != NMN_OK) {
+        const std::string why = nmn_last_error();
+        sharded_drain(s);
+        return set_error(st == NMN_ERR_STORAGE ? st : NMN_ERR_STORAGE, why.c_str());
+    }
+    sharded_drain(s);
+    if (s->gather == NMN_GATHER_RCCL) {
+        // ranks that answered = G (checked above on every device); the communicators must agree
+        Rccl& r = rccl();
+        uint32_t ranks = G;
+        for (uint32_t g = 0; g < G && r.CommCount; g++) {
+            int cnt = 0, me = -1;
+            if (r.CommCount(s->comm[g], &cnt) != 0 || (uint32_t)cnt != G) ranks = 0;
+            if (r.CommUserRank && (r.CommUserRank(s->comm[g], &me) != 0 || (uint32_t)me != g)) ranks = 0;
+        }
+        if (ranks != G) return set_error(NMN_ERR_STORAGE, "Storage error: multi-GPU self-test failed: ncclCommCount / ncclCommUserRank disagree with the shard list");
+        s->rccl_ranks = G;
+    }
+    return NMN_OK;
+}
+
+// cyclic layout: a shard's pipeline reports LOCAL rows (its row_base is 0); global = base + ((local / 64) * G + g) * 64 + local % 64
+__global__ void __launch_bounds__(256) cyclic_remap_kernel(uint64_t* __restrict__ rows, uint32_t n, uint32_t g, uint32_t G, uint64_t base) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = rows[i];
+    if (r != UINT64_MAX) rows[i] = base + (((r >> 6) * G + g) << 6) + (r & 63ull);
+}
+
+// rows [row0, row0 + n) of the global numbering that fall to shard g under the cyclic layout: ONE run of local rows
+// [*local0, *local0 + *cnt) (only the first block of the run can start inside a block, only the last can end inside one)
+static void cyclic_part(const nmn_sharded* s, uint32_t g, uint64_t row0, uint64_t n, uint64_t* local0, uint64_t* cnt) {
+    const uint64_t G = s->n_shards;
+    *local0 = 0;
+    *cnt = 0;
+    if (n == 0) return;
+    const uint64_t b0 = row0 >> 6, bl = (row0 + n - 1) >> 6;
+    const uint64_t bf = b0 + ((g + G - b0 % G) % G);  // first block >= b0 that belongs to shard g
+    if (bf > bl) return;
+    *local0 = (bf / G) * 64 + (bf == b0 ? (row0 & 63) : 0);
+    for (uint64_t b = bf; b <= bl; b += G) *cnt += std::min(row0 + n, (b + 1) * 64) - std::max(row0, b * 64);
+}
+// the same rows, copied out of the caller's contiguous buffer src[(row - row0) * dim ...] into one contiguous run
+static void cyclic_pack(const nmn_sharded* s, uint32_t g, const float* src, uint64_t row0, uint64_t n, float* dst) {
+    const uint64_t G = s->n_shards;
+    const uint64_t b0 = row0 >> 6, bl = (row0 + n - 1) >> 6;
+    for (uint64_t b = b0 + ((g + G - b0 % G) % G); b <= bl; b += G) {
+        const uint64_t a = std::max(row0, b * 64), e = std::min(row0 + n, (b + 1) * 64);
+        memcpy(dst, src + (a - row0) * (uint64_t)s->dim, (size_t)(e - a) * s->dim * sizeof(float));
+        dst += (e - a) * (uint64_t)s->dim;
+    }
+}
+
 extern "C" nmn_status nmn_sharded_destroy(nmn_sharded* s) {
     if (!s) return NMN_OK;
     crew_stop(s);
@@ -315,10 +474,20 @@ extern "C" nmn_status nmn_sharded_create(const nmn_sharded_desc* d, nmn_sharded*
     }
     nmn_sharded* s = new (std::nothrow) nmn_sharded();
     if (!s) return set_error(NMN_ERR_OUT_OF_MEMORY, "sharded alloc");
+    if (d->layout > NMN_SHARDED_LAYOUT_CYCLIC) {
+        delete s;
+        return set_error(NMN_ERR_INVALID_ARGUMENT, "unknown nmn_sharded_desc.layout");
+    }
     s->dim = d->dim;
     s->n_shards = d->n_shards;
     s->cap = d->capacity_rows;
+    s->row_base = d->row_base;
+    s->cyclic = d->layout == NMN_SHARDED_LAYOUT_CYCLIC && d->n_shards > 1;
     s->per = (d->capacity_rows + d->n_shards - 1) / d->n_shards;  // shard g owns [g*ceil(N/G), ...)
+    if (s->cyclic) {  // whole 64-row blocks per shard: block b of the global numbering is local block b / G of shard b % G
+        const uint64_t blocks = (d->capacity_rows + 63) / 64;
+        s->per = (blocks + d->n_shards - 1) / d->n_shards * 64;
+    }
     bool distinct = true;
     for (uint32_t g = 0; g < d->n_shards; g++) {
         int dev = d->devices ? d->devices[g] : (int)(g % (uint32_t)ndev);  // no list: round-robin over the node's GPUs
@@ -348,8 +517,8 @@ extern "C" nmn_status nmn_sharded_create(const nmn_sharded_desc* d, nmn_sharded*
         id.flags = d->flags;
         uint64_t r0, r1;
         shard_bounds(s, g, s->cap, &r0, &r1);
-        id.capacity_rows = r1 - r0;
-        id.row_base = d->row_base + r0;
+        id.capacity_rows = s->cyclic ? s->per : r1 - r0;
+        id.row_base = s->cyclic ? 0 : d->row_base + r0;  // (cyclic: local ids are mapped to global ones after the shard's search)
         id.device = s->device[g];
         id.cand_cap = d->cand_cap;
         nmn_index* idx = nullptr;
@@ -397,6 +566,16 @@ extern "C" nmn_status nmn_sharded_create(const nmn_sharded_desc* d, nmn_sharded*
     (void)hipEventCreate(&s->ev_g0);
     (void)hipEventCreate(&s->ev_g1);
     crew_start(s);
+    if (s->n_shards >= 2) {
+        // first contact with the other devices happens HERE, not in somebody's search: every shard sends its rank through the
+        // very collective a search uses and the merging device (RCCL: every device) must see all of them
+        const nmn_status st = sharded_selftest(s);
+        if (st != NMN_OK) {
+            const std::string why = nmn_last_error();
+            nmn_sharded_destroy(s);
+            return set_error(st, why.c_str());
+        }
+    }
     *out = s;
     return NMN_OK;
 }
@@ -411,17 +590,8 @@ extern "C" uint64_t nmn_sharded_rows(const nmn_sharded* s) {
         for (nmn_index* i : s->shard) n += nmn_index_rows(i);
     return n;
 }
-extern "C" nmn_status nmn_sharded_set_timing(nmn_sharded* s, int32_t enabled) {
-    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
-    s->timing = enabled != 0;
-    for (nmn_index* i : s->shard) (void)nmn_index_set_timing(i, enabled);
-    return NMN_OK;
-}
-extern "C" nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled) {
-    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
-    for (nmn_index* i : s->shard) (void)nmn_index_set_mirror(i, enabled);
-    return NMN_OK;
-}
+extern "C" uint32_t nmn_sharded_rccl_ranks(const nmn_sharded* s) { return s ? s->rccl_ranks : 0; }
+extern "C" uint32_t nmn_sharded_layout(const nmn_sharded* s) { return (s && s->cyclic) ? NMN_SHARDED_LAYOUT_CYCLIC : NMN_SHARDED_LAYOUT_RANGES; }
 
 // rows [row0, row0+n) of the GLOBAL numbering: each shard gets the part that falls into its range, all parts at once (a host
 // upload then crosses every GPU's PCIe link at the same time).  Like nmn_index_upload rows must arrive without gaps, i.e. in
@@ -471,17 +641,66 @@ struct SoloGuard {
     ~SoloGuard() { sharded_release(s); }
 };
 
+// (the switches change what a running search reads: they take a turn like a writer)
+extern "C" nmn_status nmn_sharded_set_timing(nmn_sharded* s, int32_t enabled) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    SoloGuard turn(s);
+    s->timing = enabled != 0;
+    for (nmn_index* i : s->shard) (void)nmn_index_set_timing(i, enabled);
+    return NMN_OK;
+}
+extern "C" nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled) {
+    if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    SoloGuard turn(s);
+    for (nmn_index* i : s->shard) (void)nmn_index_set_mirror(i, enabled);
+    return NMN_OK;
+}
+
+// the caller holds the handle's turn
+static nmn_status sharded_upload_turn(nmn_sharded* s, const float* rows_host, uint64_t row0, uint64_t n) {
+    if (!s->cyclic)
+        return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t src0, uint64_t cnt) {
+            return nmn_index_upload(s->shard[sh], rows_host + src0 * (uint64_t)s->dim, local0, cnt);
+        });
+    // cyclic: every shard gets ONE run of local rows, gathered block by block out of the caller's buffer (by the shard's
+    // crew thread when there is one: the packing and the PCIe copies of the shards run side by side)
+    if (n > s->cap || row0 > s->cap - n) return set_error(NMN_ERR_CAPACITY, "row0 + n > capacity_rows");
+    if (row0 > nmn_sharded_rows(s)) return set_error(NMN_ERR_INVALID_ARGUMENT, "row0 leaves a gap (row0 > rows)");
+    if (n == 0) return NMN_OK;
+    const std::function<nmn_status(uint32_t)> job = [&](uint32_t g) -> nmn_status {
+        uint64_t local0, cnt;
+        cyclic_part(s, g, row0, n, &local0, &cnt);
+        if (cnt == 0) return NMN_OK;
+        std::vector<float> run((size_t)cnt * s->dim);
+        cyclic_pack(s, g, rows_host, row0, n, run.data());
+        return nmn_index_upload(s->shard[g], run.data(), local0, cnt);
+    };
+    return for_each_shard(s, job);
+}
+
 extern "C" nmn_status nmn_sharded_upload(nmn_sharded* s, const float* rows_host, uint64_t row0, uint64_t n) {
     if (!s || (!rows_host && n)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
     SoloGuard turn(s);
-    return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t src0, uint64_t cnt) {
-        return nmn_index_upload(s->shard[sh], rows_host + src0 * (uint64_t)s->dim, local0, cnt);
-    });
+    return sharded_upload_turn(s, rows_host, row0, n);
 }
 
 extern "C" nmn_status nmn_sharded_fill_synthetic(nmn_sharded* s, uint64_t seed, uint64_t row0, uint64_t n) {
     if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
     SoloGuard turn(s);
+    if (s->cyclic) {
+        // the device generator numbers a shard's rows row_base + local; under the cyclic layout the rows come from the host
+        // generator instead (bit-identical values), a chunk at a time
+        const uint64_t chunk = std::max<uint64_t>(64, ((64ull << 20) / ((uint64_t)s->dim * 4)) & ~63ull);
+        std::vector<float> buf;
+        for (uint64_t a = 0; a < n; a += chunk) {
+            const uint64_t c = std::min(chunk, n - a);
+            buf.resize((size_t)c * s->dim);
+            nmn_status st = nmn_synth_fill_host(buf.data(), seed, s->row_base + row0 + a, c, s->dim);
+            if (st == NMN_OK) st = sharded_upload_turn(s, buf.data(), row0 + a, c);
+            if (st != NMN_OK) return st;
+        }
+        return NMN_OK;
+    }
     return for_each_part(s, row0, n, [&](uint32_t sh, uint64_t local0, uint64_t, uint64_t cnt) {
         return nmn_index_fill_synthetic(s->shard[sh], seed, local0, cnt);  // value(seed, row_base + row, col): global ids
     });
@@ -501,7 +720,7 @@ static void bitmap_slice(const uint64_t* src, uint64_t b0, uint64_t nbits, uint6
 }
 
 // one query batch over every shard: the caller holds s->busy
-static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+static nmn_status sharded_run_body(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
                               const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
                               nmn_search_stats* stats) {
     const uint32_t G = s->n_shards;
@@ -526,8 +745,15 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
     memcpy(s->pin_in, queries, qbytes);
     uint64_t* pin_mask = reinterpret_cast<uint64_t*>(s->pin_in + ((qbytes + 15) & ~(size_t)15));
     if (mask)
-        for (uint32_t g = 0; g < G; g++)
-            if (rows_of[g]) bitmap_slice(mask, base_of[g], rows_of[g], pin_mask + mask_off[g]);
+        for (uint32_t g = 0; g < G; g++) {
+            if (!rows_of[g]) continue;
+            if (s->cyclic) {  // local word i of shard g is global word i * G + g (a block is one bitmap word)
+                const size_t words = (size_t)((rows_of[g] + 63) / 64);
+                for (size_t i = 0; i < words; i++) pin_mask[mask_off[g] + i] = mask[i * G + g];
+            } else {
+                bitmap_slice(mask, base_of[g], rows_of[g], pin_mask + mask_off[g]);
+            }
+        }
     // ---- every shard: H2D of the queries (and its bitmap slice), the single-shard pipeline, into its packed block --------
     const std::function<nmn_status(uint32_t)> enqueue = [&](uint32_t g) -> nmn_status {
         ShardLane& l = s->lane[g];
@@ -547,6 +773,12 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
         nmn_status st = index_search_device(s->shard[g], l.queries, nq, k, (int)metric, mask_dev,
                                             reinterpret_cast<uint64_t*>(l.block), reinterpret_cast<float*>(l.block + pl.off_scores),
                                             reinterpret_cast<uint32_t*>(l.block + pl.off_counts), l.stream);
+        if (st == NMN_OK && s->cyclic) {
+            const uint32_t cnt = nq * k;
+            hipLaunchKernelGGL(cyclic_remap_kernel, dim3((cnt + 255) / 256), dim3(256), 0, l.stream, reinterpret_cast<uint64_t*>(l.block), cnt,
+                               g, G, s->row_base);
+            S_TRY(hipGetLastError());
+        }
         return st;
     };
     {
@@ -559,30 +791,12 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
         S_TRY(hipSetDevice(s->device[0]));
         S_TRY(hipEventRecord(s->ev_g0, root.stream));
     }
-    if (s->gather == NMN_GATHER_RCCL) {
-        Rccl& r = rccl();
-        ncclResult_t e = r.GroupStart();
-        if (e != 0) return fail_nccl(e, "ncclGroupStart");
-        for (uint32_t g = 0; g < G && e == 0; g++) {
-            // (grouped calls may be issued from one thread for all the devices it drives; RCCL sets the device itself)
-            e = r.AllGather(s->lane[g].block, s->lane[g].gathered, pl.size, kNcclChar, s->comm[g], s->lane[g].stream);
-        }
-        ncclResult_t e2 = r.GroupEnd();
-        if (e != 0) return fail_nccl(e, "ncclAllGather");
-        if (e2 != 0) return fail_nccl(e2, "ncclGroupEnd");
-    } else {
-        for (uint32_t g = 0; g < G; g++) {
-            ShardLane& l = s->lane[g];
-            S_TRY(hipSetDevice(s->device[g]));
-            // enqueued on the PRODUCING shard's stream (right behind its pipeline); the merging stream waits for the event
-            if (s->device[g] == s->device[0])
-                S_TRY(hipMemcpyAsync(root.gathered + (size_t)g * pl.size, l.block, pl.size, hipMemcpyDeviceToDevice, l.stream));
-            else
-                S_TRY(hipMemcpyPeerAsync(root.gathered + (size_t)g * pl.size, s->device[0], l.block, s->device[g], pl.size, l.stream));
-            if (g != 0) S_TRY(hipEventRecord(l.done, l.stream));
-        }
-        S_TRY(hipSetDevice(s->device[0]));
-        for (uint32_t g = 1; g < G; g++) S_TRY(hipStreamWaitEvent(root.stream, s->lane[g].done, 0));
+    // (RCCL: collectives of different handles must not interleave across the devices — held until every rank has drained)
+    std::unique_lock<std::mutex> coll(collective_mutex(), std::defer_lock);
+    if (s->gather == NMN_GATHER_RCCL) coll.lock();
+    {
+        const nmn_status st = sharded_gather(s, pl.size);
+        if (st != NMN_OK) return st;
     }
     // ---- merge_top_k on the merging device, one D2H ---------------------------------------------------------------------
     S_TRY(hipSetDevice(s->device[0]));
@@ -599,6 +813,7 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
             S_TRY(hipSetDevice(s->device[g]));
             S_TRY(hipStreamSynchronize(s->lane[g].stream));
         }
+    if (coll.owns_lock()) coll.unlock();
     memcpy(out_rows, s->pin_out, (size_t)nq * k * 8);
     memcpy(out_scores, s->pin_out + pl.off_scores, (size_t)nq * k * 4);
     memcpy(out_counts, s->pin_out + pl.off_counts, (size_t)nq * 4);
@@ -606,7 +821,10 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
     if (s->timing) {
         float ms = -1.f;
         (void)hipSetDevice(s->device[0]);
-        if (hipEventElapsedTime(&ms, s->ev_g0, s->ev_g1) == hipSuccess) s->last_gather_ms = ms;
+        if (hipEventElapsedTime(&ms, s->ev_g0, s->ev_g1) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->last_gather_ms = ms;
+        }
         (void)hipGetLastError();
     }
     if (stats) {
@@ -625,6 +843,20 @@ static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq,
         }
     }
     return NMN_OK;
+}
+
+static nmn_status sharded_run(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
+                              const uint64_t* mask, uint64_t* out_rows, float* out_scores, uint32_t* out_counts,
+                              nmn_search_stats* stats) {
+    const nmn_status st = sharded_run_body(s, queries, nq, k, metric, mask, out_rows, out_scores, out_counts, stats);
+    if (st != NMN_OK) {
+        // some lanes may still be running what was enqueued before the failure: nothing of it may outlive this call (the
+        // pinned staging and the lanes' device buffers are rewritten by the next one)
+        const std::string why = nmn_last_error();
+        sharded_drain(s);
+        return set_error(st, why.c_str());
+    }
+    return st;
 }
 
 extern "C" nmn_status nmn_sharded_search(nmn_sharded* s, const float* queries, uint32_t nq, uint32_t k, nmn_metric metric,
@@ -757,6 +989,7 @@ extern "C" nmn_status nmn_sharded_coalesce_stats(nmn_sharded* s, uint64_t* batch
 
 extern "C" nmn_status nmn_sharded_last_gather_ms(const nmn_sharded* s, float* ms) {
     if (!s || !ms) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(const_cast<nmn_sharded*>(s)->mu);
     *ms = s->last_gather_ms;
     return NMN_OK;
 }

@@ -157,6 +157,7 @@ hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* 
     uint64_t n = largek_sort_len(n_rows);
     uint64_t n_sel = kSortTile;
     while (n_sel < (uint64_t)k) n_sel <<= 1;
+    bool selected = false;
     if (sel_hist && sel_sync && n_rows >= (1u << 18) && n_sel * 4 <= n) {
         hipError_t e = hipMemsetAsync(keys, 0, n_sel * sizeof(uint64_t), s);  // unused slots sort last (and mark the count)
         if (e != hipSuccess) return e;
@@ -172,10 +173,16 @@ hipError_t launch_largek(const uint32_t* score_bits, uint64_t n_rows, uint64_t* 
         fb.list_cap = (uint32_t)n_sel;
         fb.list_count = out_count;  // (overwritten by the emit kernel with the same value)
         fb.sync = sel_sync;
+        // (a cooperative launch: the grid is resident together or the launch is refused — then the full sort answers)
         e = launch_fallback_select(fb, s);
-        if (e != hipSuccess) return e;
-        n = n_sel;
-    } else {
+        if (e == hipSuccess) {
+            n = n_sel;
+            selected = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (!selected) {
         const uint32_t grid_stream = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 32ull);
         hipLaunchKernelGGL(largek_keys_kernel, dim3(grid_stream), dim3(256), 0, s, score_bits, n_rows, n, keys);
     }

@@ -135,6 +135,7 @@ ENGINE_SIGNATURES = {
     "nmn_filter_free": (None, [vp]),
     "nmn_engine_count_matching": (C.c_uint64, [vp, vp]),
     "nmn_engine_mirror_builds": (C.c_uint64, [vp]),
+    "nmn_engine_mirror_shard_rows": (C.c_uint32, [vp, C.c_uint64, vp, C.c_uint32]),
     "nmn_engine_device_filter_evals": (C.c_uint64, [vp]),
     "nmn_engine_column_builds": (C.c_uint64, [vp]),
     "nmn_engine_mirror_cached": (C.c_int32, [vp, C.c_char_p]),
@@ -849,6 +850,11 @@ class VectorEngine:
         return self._take_results(h)
 
     # -- mirror bookkeeping (cache protocol tests) ------------------------------------------------
+    def mirror_shard_rows(self, dim):
+        out = (C.c_uint64 * 64)()
+        n = int(_lib().nmn_engine_mirror_shard_rows(self._h, int(dim), out, 64))
+        return [int(out[i]) for i in range(min(n, 64))]
+
     def mirror_builds(self):
         return int(_lib().nmn_engine_mirror_builds(self._h))
 

@@ -34,7 +34,8 @@ class GpuShardedIndex:
     gathers the per-shard top-k blocks with one RCCL all-gather (distinct devices) or peer copies (logical shards on one
     device) and merges them on shard 0's device — `ResultMerger::merge_top_k` (distributed.rs:413-433)."""
 
-    def __init__(self, dim, capacity_rows, n_shards, devices=None, row_base=0, gather=0, cand_cap=0, wide_rows=False):
+    def __init__(self, dim, capacity_rows, n_shards, devices=None, row_base=0, gather=0, cand_cap=0, wide_rows=False,
+                 cyclic=False):
         import ctypes as C
         from . import _capi
         self._lib = _capi.load()
@@ -46,7 +47,7 @@ class GpuShardedIndex:
             devs = (C.c_int32 * n_shards)(*[int(d) for d in devices])
         desc = _capi.ShardedDesc(dim=self.dim, flags=1 if wide_rows else 0, capacity_rows=self.capacity_rows,
                                  row_base=self.row_base, n_shards=self.n_shards, gather=int(gather),
-                                 devices=devs, cand_cap=int(cand_cap), reserved=0)
+                                 devices=devs, cand_cap=int(cand_cap), layout=1 if cyclic else 0)
         _capi.check(self._lib.nmn_sharded_create(C.byref(desc), C.byref(self._h)))
 
     def close(self):
@@ -70,6 +71,15 @@ class GpuShardedIndex:
     @property
     def rows(self):
         return int(self._lib.nmn_sharded_rows(self._h))
+
+    @property
+    def rccl_ranks(self):
+        """communicator ranks the create-time self-test saw answer the all-gather (0: peer-copy gather)"""
+        return int(self._lib.nmn_sharded_rccl_ranks(self._h))
+
+    @property
+    def layout(self):
+        return int(self._lib.nmn_sharded_layout(self._h))
 
     @property
     def gather_mode(self):

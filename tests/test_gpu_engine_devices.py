@@ -138,3 +138,29 @@ def test_sharded_engine_snapshot_round_trip(E, tmp_path):
     _, fresh = engines(E, 2)
     assert fresh.load_index_binary(path) == "docs"
     same(before, fresh.search_in_collection("docs", q, 15))
+
+
+def test_engine_mirror_is_spread_evenly_over_the_devices(E):
+    """get_mirror gives a mirror 50 % spare capacity; the rows HELD must still be dealt evenly (contiguous ranges
+    of the capacity put 75 % / 25 % on two GPUs and left the fourth of four empty), and stay so under appends."""
+    rng = np.random.default_rng(11)
+    n, d = 9000, 48
+    A = rng.standard_normal((n, d)).astype(F)
+    for G in (2, 4):
+        eng = E.VectorEngine(E.VectorEngineConfig(devices=(0,) * G))
+        eng.batch_store_embeddings([f"k{i}" for i in range(n)], A)
+        q = rng.standard_normal(d).astype(F)
+        res = eng.search_similar(q, 25)   # builds the mirror
+        er, es = oc.search(A, q, 25, 0)
+        assert [r.key for r in res] == [f"k{i}" for i in er]
+        rows = eng.mirror_shard_rows(d)
+        assert len(rows) == G and sum(rows) == n and max(rows) - min(rows) <= 64, rows
+        extra = rng.standard_normal((1000, d)).astype(F)
+        for i in range(1000):
+            eng.store_embedding(f"x{i}", extra[i])
+        res = eng.search_similar(q, 25)
+        er, es = oc.search(np.concatenate([A, extra]), q, 25, 0)
+        assert [r.key for r in res] == [f"k{i}" if i < n else f"x{i - n}" for i in er]
+        rows = eng.mirror_shard_rows(d)
+        assert sum(rows) == n + 1000 and max(rows) - min(rows) <= 64, rows
+        assert eng.mirror_builds() == 1

@@ -89,6 +89,7 @@ def test_index_load_limits_and_corruption(tmp_path):
 
 
 def test_ivf_save_load_restores_lists_without_retraining(tmp_path):
+    from neumann_amd import _capi
     from neumann_amd.ivf import GpuIvfFlat
     path = tmp_path / "ivf.nmnidx"
     rng = np.random.default_rng(3)
@@ -107,6 +108,17 @@ def test_ivf_save_load_restores_lists_without_retraining(tmp_path):
             i2, d2, c2 = ivf.search(Q, 20, nprobe=p)
             assert np.array_equal(i2, ids) and np.array_equal(d2.view(np.uint32), dist.view(np.uint32)) and np.array_equal(c2, cnt)
         assert ivf.add(V[:3] * np.float32(1.5)).size == 3  # the restored index accepts new vectors
+    # a crafted file: the embedded vector section announces no payload (payload_bytes = 0 passes the "is it in the file"
+    # check with any row count) — refused as inconsistent before anything is allocated by its shape
+    raw = bytearray(path.read_bytes())
+    second = 64 + C * d * 4 + n * 4          # ivf header | centroids | lists | flat-section header
+    assert raw[second:second + 6] == b"NMNIDX"
+    raw[second + 40:second + 48] = (0).to_bytes(8, "little")   # PersistHeader::payload_bytes
+    bad = tmp_path / "crafted.nmnidx"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(_capi.NeumannGpuError) as e:
+        GpuIvfFlat.load(bad)
+    assert e.value.status == _capi.ERR_SERIALIZATION
 
 
 def test_engine_binary_round_trip_rebuilds_the_mirror_at_once(tmp_path):

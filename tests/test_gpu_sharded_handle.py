@@ -241,3 +241,69 @@ def test_concurrent_callers_of_the_handle_share_sweeps():
         r, sc, c = s.search(extra[7], 3, 0)
         er, es = oc.search(A2, extra[7], 3, 0, nthreads=8, partial=True, native=True)
         assert np.array_equal(r[0], er) and np.all(sc[0] == es)
+
+
+# ---- cyclic layout + create-time self-test (round 3) --------------------------------------------------------------------
+@pytest.mark.parametrize("crew", [False, True])
+@pytest.mark.parametrize("n_shards", [2, 3, 5])
+def test_cyclic_layout_matches_oracle_and_is_balanced(n_shards, crew, monkeypatch):
+    """NMN_SHARDED_LAYOUT_CYCLIC: 64-row blocks dealt round-robin.  Global row ids in and out, uploads in pieces that start
+    and end inside blocks, a capacity far above the rows held (what an engine mirror looks like): every shard holds its
+    share of the rows HELD, and every answer is the unsharded one (duplicates across shards tie by GLOBAL row id)."""
+    from neumann_amd import GpuShardedIndex
+    from neumann_amd._capi import NeumannGpuError
+    monkeypatch.setenv("NMN_SHARDED_CREW", "1" if crew else "0")
+    n, d, k, cap, base = 10007, 96, 64, 25000, 1000
+    rng = np.random.default_rng(177 + n_shards)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[5000:5040] = A[17]
+    A[n - 1] = A[17]
+    Q = np.stack([A[17] + np.float32(1e-3) * rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)])
+    with GpuShardedIndex(d, cap, n_shards, devices=[0] * n_shards, row_base=base, cyclic=True) as sh:
+        assert sh.layout == 1
+        with pytest.raises(NeumannGpuError):
+            sh.upload(A[:10], row0=64)     # a gap in the global numbering
+        assert sh.rows == 0
+        for a, b in ((0, 3000), (3000, 3001), (3001, 3070), (3070, n)):
+            sh.upload(A[a:b], row0=a)
+        assert sh.rows == n
+        blocks = -(-n // 64)
+        held = [sh.shard_rows(g) for g in range(n_shards)]
+        expect = [sum(min(64, n - b * 64) for b in range(g, blocks, n_shards)) for g in range(n_shards)]
+        assert held == expect and max(held) - min(held) <= 64
+        for metric in (0, 1, 2):
+            _check(sh, A, Q, k, metric, row_base=base)
+        for sel in (0.5, 0.02, 0.0):
+            keep = rng.random(n) < sel
+            _check(sh, A, Q, k, 0, mask=oc.mask_from_bool(keep), row_base=base)
+        _check(sh, A, Q, 5000, 1, row_base=base)            # large-k path per shard, ids remapped all the same
+        A[4000:4100] = rng.standard_normal((100, d)).astype(np.float32)
+        sh.upload(A[4000:4100], row0=4000)                  # overwrite in place, across blocks
+        _check(sh, A, Q, k, 0, row_base=base)
+        B = rng.standard_normal((300, d)).astype(np.float32)
+        sh.upload(B, row0=n)                                # append
+        _check(sh, np.concatenate([A, B]), Q, k, 2, row_base=base)
+
+
+def test_cyclic_fill_synthetic_equals_the_unsharded_corpus():
+    from neumann_amd import GpuShardedIndex
+    n, d, k = 20000, 128, 30
+    A = oc.synth(71, 300, n, d)
+    Q = oc.synth(72, 0, 2, d)
+    with GpuShardedIndex(d, n + 5000, 4, devices=[0] * 4, row_base=300, cyclic=True) as sh:
+        sh.fill_synthetic(71, n)
+        for metric in (0, 1, 2):
+            _check(sh, A, Q, k, metric, row_base=300)
+
+
+def test_create_runs_the_collective_selftest():
+    """>= 2 shards: create ends with every shard's rank travelling through the gather a search uses.  One device: peer
+    copies (rccl_ranks == 0); with >= 2 GPUs the RCCL all-gather over distinct devices (rccl_ranks == shards)."""
+    from neumann_amd import GpuShardedIndex
+    from neumann_amd._capi import GATHER_PEER, GATHER_RCCL
+    with GpuShardedIndex(64, 1000, 4, devices=[0] * 4) as sh:
+        assert sh.gather_mode == GATHER_PEER and sh.rccl_ranks == 0
+    g = _n_gpus()
+    if g >= 2:
+        with GpuShardedIndex(64, 1000, g, devices=list(range(g))) as sh:
+            assert sh.gather_mode == GATHER_RCCL and sh.rccl_ranks == g
