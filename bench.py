@@ -4,36 +4,46 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json `metric`): 10M x 768 f32 cosine brute-force TOP-100.  One "step" = one pass
-of the hot path over one batch of `--nq` synthetic queries (default 1: the HBM-bound single-query
-scan the roofline target is quoted on).  The corpus and the queries are resident in HBM before the
-timed region.  With N > 1 the 10M-row corpus is row-range sharded over the N GPUs (one process per
-GPU); every step each rank scans its shard, the per-shard top-k blocks are all-gathered over RCCL
-and merged on-device (strong scaling: total work per query is fixed).  `--scaling weak` instead
-keeps 10M rows PER GPU (config 4: 80M rows on 8 GPUs).
+Workload (BASELINE.json `metric`): 10M x 768 f32 cosine brute-force TOP-100.  One "step" = one pass of the hot path over
+one batch of `--nq` synthetic queries (default 1: the HBM-bound single-query scan the roofline target is quoted on).  The
+corpus and the queries are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel of the headline configuration (scan_kernel over the shard's bf16 mirror: 2 bytes per corpus
-                element; the exact f32 rescore keeps the answer bit-equal).  `achieved` / `frac` count the bytes that kernel is
-                asked to read (rows*dim*2, `pricing` says so, `bytes_per_corpus_element` = 2); SURVEY.md §8(d) prices a query
-                at rows*dim*4 (the f32 corpus): `achieved_priced_as_survey_8d` / `frac_priced_as_survey_8d` give the same
-                kernel time under that pricing (an EFFECTIVE rate; it exceeds the HBM peak because half the bytes are moved)
-  roofline_f32_corpus  (default single-GPU run) the same index, same queries, same 2-stream loop with
-                nmn_index_set_mirror(0): the sweep of the row-major f32 corpus §8(d) describes, priced at rows*dim*4 —
-                queries/s, HIP-event kernel average, achieved GB/s, frac of 8 TB/s, exactness certificate
-  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded
-                row sample of the same workload, extrapolated linearly to the full row count
-  parity        the GPU result of the last timed query checked against the oracle / exact certificate
-  batched       (default single-GPU run) config 3: 64 queries per step on the MFMA sweep, same resident corpus
-  concurrent_callers  (default single-GPU run) 64 native host threads, each a loop of single-query nmn_index_search calls on
-                the same resident corpus: the C ABI merges callers that arrive while the shard is busy into one batch
-  other_configs (default single-GPU run) config 2 (1M x 768) and config 5 (10M x 1536 L2 TOP-1000, mask 1.0 / 0.5 /
-                0.1), each as a child run of this script with its own corpus, each with its exactness certificate
+N > 1: ONE PROCESS PER GPU.  `python bench.py --gpus N` with no launcher around it starts the N ranks ITSELF (rank r on
+device r, rendezvous on 127.0.0.1) and refuses to run when fewer than N devices are visible; under torch.distributed.run it
+uses the ranks it is given and refuses a WORLD_SIZE that is not N.  The corpus is row-range sharded (rank g owns
+[g*ceil(T/N), ...)); every step each rank scans its shard, the packed per-shard top-k blocks are all-gathered over RCCL and
+merged on-device.  `--scaling weak` (default; BASELINE config 4) keeps `--rows` rows PER GPU — 80M x 768 on 8 GPUs;
+`--scaling strong` splits `--rows` rows over the GPUs.  At N = 1 the two are the same run.
+
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   median over `--rebuilds` index rebuilds (each: W warmup steps, then EXACTLY K timed steps between a
+                barrier + synchronize on both sides, max over ranks); `rebuilds` lists every draw — where the driver puts a
+                15 GB buffer moves a single draw by several per cent
+  dtype         what the sweep computes in.  The approximate sweep of 1-2 queries reads the shard's 8-BIT mirror (int8 codes,
+                one scale per row, int32 accumulation); every candidate it selects is re-scored from the f32 corpus in the
+                reference's f32 operation order, so the answer is the reference's bit for bit (`parity`)
+  roofline      the dominant kernel of the timed loop.  `achieved` / `frac` count the bytes that kernel is asked to read
+                (rows x dim x bytes_per_corpus_element, `pricing` says so); right beside them `achieved_priced_as_survey_8d` /
+                `frac_priced_as_survey_8d` give the same kernel time priced as SURVEY.md §8(d) writes it (rows x dim x 4: an
+                EFFECTIVE rate that exceeds the HBM peak because fewer bytes move).  `avg_kernel_ms` is the HIP-event average
+                of that kernel in `kernel_timing_loop` (steps enqueued one at a time, nothing else on the device: the clean
+                kernel duration); the timed loop keeps two steps in flight on two streams, where sweeps overlap
+  roofline_f32_corpus / roofline_bf16_mirror  (default single-GPU run) the same index, queries, streams, steps with
+                nmn_index_set_mirror(0) / (2): the sweep of the row-major f32 corpus exactly as §8(d) prices it, and the
+                2-byte mirror the 8-bit one replaced; same answer required
+  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded row sample
+  parity        size-independent exactness certificate of the last timed result (see certificate())
+  batched, concurrent_callers, other_configs, next_rows   further legs of the default single-GPU run (config 3; 64 / 128
+                host threads; configs 2 and 5; SURVEY §8(f): filtered SIMILAR end to end, IVF probe, upload, index load)
+  multi_gpu     (N > 1) rccl_ranks (ranks seen by a real all-gather of rank ids), rows_per_gpu[], gather_plus_merge_ms, and
+                `one_process_handle`: the same GPUs driven by ONE process through the C ABI's nmn_sharded handle
 """
 import argparse
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,6 +56,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/
 SEED_CORPUS = 0x5EED0003
 SEED_QUERY = 0x5EED0002
 METRICS = {"cosine": 0, "euclidean": 1, "dot": 2}
+SWEEP = {1: ("i8", "8-bit mirror (int8 codes, one f32 scale per row), int32 accumulate", "rows*dim*1, the 8-bit mirror"),
+         2: ("bf16", "bf16 mirror of the corpus, f32 accumulate", "rows*dim*2, the bf16 mirror"),
+         4: ("f32", "f32 corpus", "SURVEY §8(d): rows*dim*4, the f32 corpus")}
 
 
 def parse():
@@ -53,39 +66,93 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (strong) / rows per GPU (weak)")
+    ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per GPU (weak) / in total (strong)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--nq", type=int, default=1, help="queries per step")
     ap.add_argument("--metric", default="cosine", choices=sorted(METRICS))
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="weak (default, BASELINE config 4): --rows rows PER GPU; strong: --rows rows split over the GPUs")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are pipelined over (each stream runs whole steps in order; with 2 "
                          "the select/rescore/gather tail of one query overlaps the next query's scan)")
+    ap.add_argument("--rebuilds", type=int, default=3,
+                    help="index builds the timed loop is repeated over; value = the median (buffer placement moves one draw by several %%)")
     ap.add_argument("--mask", type=float, default=1.0,
                     help="selectivity of a synthetic WHERE-predicate bitmap (config 5); 1.0 = no mask")
+    ap.add_argument("--mirror", type=int, default=1, choices=[0, 1, 2],
+                    help="nmn_index_set_mirror: 1 = smallest mirror that serves the call (default), 2 = bf16 only, 0 = f32 corpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--callers", type=int, default=64, help="host threads of the concurrent-callers leg (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra legs of the default single-GPU run: BASELINE.json's other single-GPU "
-                         "configurations (config 2: 1M x 768 cosine TOP-100; config 5: 10M x 1536 L2 TOP-1000 with mask "
-                         "1.0 / 0.5 / 0.1) measured as child runs of this script and reported under \"other_configs\"")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+                         "configurations (config 2, config 5 with mask 1.0 / 0.5 / 0.1) and the SURVEY §8(f) legs")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (then it comes from profiles/pmc_traffic.json)")
-    ap.add_argument("--no-f32-leg", action="store_true",
-                    help="skip the roofline_f32_corpus leg (the same loop with the bf16 mirror switched off)")
+    ap.add_argument("--no-mirror-legs", "--no-f32-leg", dest="no_mirror_legs", action="store_true",
+                    help="skip the roofline_f32_corpus / roofline_bf16_mirror legs")
     ap.add_argument("--always-gather", action="store_true",
-                    help="run the RCCL all-gather + device merge even with one rank (measures what the N>1 step adds "
-                         "on a 1-GPU box; the group has one member)")
+                    help="run the all-gather + device merge even with one rank (what the N>1 step adds, on a 1-GPU box)")
     ap.add_argument("--batched", type=int, default=64,
-                    help="also measure config 3 (this many queries per step on the MFMA sweep) after the main "
-                         "measurement and report it under \"batched\" (single-GPU runs only; 0 = skip)")
+                    help="also measure config 3 (this many queries per step on the MFMA sweep) and report it under \"batched\" "
+                         "(single-GPU runs only; 0 = skip)")
+    ap.add_argument("--no-handle-leg", action="store_true", help="N > 1: skip the one-process nmn_sharded leg")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--next-rows-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--handle-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
+def _synth(seed, row0, n, dim):
+    from neumann_amd import synth_rows
+    return synth_rows(seed, row0, n, dim)
+
+
+def _visible_devices():
+    import ctypes as C
+    from neumann_amd import _capi
+    n = C.c_int32(0)
+    _capi.load().nmn_device_count(C.byref(n))
+    return int(n.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process becomes the launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    n = args.gpus
+    visible = _visible_devices()
+    pinned = os.environ.get("NMN_BENCH_DEVICE")  # debugging aid: every rank on ONE device (needs NMN_BENCH_BACKEND=gloo)
+    if pinned is None and visible < n:
+        print(f"[bench] --gpus {n} but only {visible} HIP device(s) are visible: refusing to measure fewer GPUs than asked for",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+        rc = rc or p.returncode
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return rc or 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args, metric, total_rows, device):
     """Time the CPU oracle on a bounded row sample (and, as the checker, compare the GPU path with it
     on that same sample); returns the cpu_baseline object."""
@@ -127,12 +194,19 @@ def cpu_baseline(args, metric, total_rows, device):
     }
 
 
+def _child_json(cmd, timeout):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        raise RuntimeError(f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+    return json.loads(lines[-1])
+
+
 def other_configs():
     """BASELINE.json configs 2 and 5 as child runs (each needs its own resident corpus: 3 GB and 61 GB)."""
-    import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--batched", "0", "--callers", "0",
-            "--no-f32-leg", "--no-live-pmc", "--warmup", "3"]
-    runs = [("config2_1Mx768_cosine_top100", ["--rows", "1000000", "--steps", "200"]),
+            "--no-mirror-legs", "--no-live-pmc", "--warmup", "3", "--rebuilds", "1"]
+    runs = [("config2_1Mx768_cosine_top100", ["--rows", "1000000", "--steps", "200", "--rebuilds", "3"]),
             ("config5_10Mx1536_l2_top1000_mask1.0", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12"]),
             ("config5_10Mx1536_l2_top1000_mask0.5", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12",
                                                      "--mask", "0.5"]),
@@ -141,12 +215,12 @@ def other_configs():
     out = {}
     for name, extra in runs:
         try:
-            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=240)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            d = json.loads(line[-1])
+            d = _child_json(base + extra, 240)
             out[name] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
-                         "ms_per_step": d["ms_per_step"], "roofline_frac": d["roofline"]["frac"],
-                         "achieved_GBps": d["roofline"]["achieved"], "kernel": d["roofline"]["kernel"],
+                         "ms_per_step": d["ms_per_step"], "sweep": d["dtype"], "roofline_frac": d["roofline"]["frac"],
+                         "achieved_GBps": d["roofline"]["achieved"], "bytes_per_corpus_element": d["roofline"]["bytes_per_corpus_element"],
+                         "frac_priced_as_survey_8d": d["roofline"]["frac_priced_as_survey_8d"], "kernel": d["roofline"]["kernel"],
+                         "candidates_rescored": d["roofline"].get("candidates_rescored"),
                          "exact_topk_certified": d["parity"]["exact_topk_certified"] if d["parity"] else None}
         except Exception as e:  # a child failing must not take the headline line down with it
             out[name] = {"error": f"{type(e).__name__}: {e}"}
@@ -155,7 +229,7 @@ def other_configs():
 
 def pmc_traffic(rows_per_gpu, args, elem_bytes=4):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if this
-    exact workload was profiled; bench.py cannot collect PMC counters itself (they need a rocprofv3 wrapper)."""
+    exact workload was profiled (the fallback where rocprofv3 cannot be run around a child)."""
     try:
         ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
     except (OSError, ValueError, KeyError):
@@ -168,16 +242,15 @@ def pmc_traffic(rows_per_gpu, args, elem_bytes=4):
 
 
 def live_pmc(args):
-    """HBM bytes per launch of the two nq=1 sweeps, measured NOW: two child runs of this script under
+    """HBM bytes per launch of the nq=1 sweeps, measured NOW: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes, no other trace
     domain — MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"), each a handful of sweeps of the same synthetic shard over
-    the bf16 mirror and over the f32 corpus.  Corrections as that guide prescribes: both counters are KiB; on gfx950
-    FETCH_SIZE reports half the bytes of a 16-B-per-lane streaming read, so read bytes = FETCH_SIZE * 1024 * 2.
-    Returns {"mirror": {...}, "f32": {...}} or None when rocprofv3 is not usable here."""
+    the 8-bit mirror, the bf16 mirror and the f32 corpus.  Corrections as that guide prescribes: both counters are KiB; on
+    gfx950 FETCH_SIZE reports half the bytes of a 16-B-per-lane streaming read, so read bytes = FETCH_SIZE * 1024 * 2.
+    Returns {"i8": {...}, "bf16": {...}, "f32": {...}} or None when rocprofv3 is not usable here."""
     import glob
     import shutil
     import sqlite3
-    import subprocess
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
@@ -197,14 +270,17 @@ def live_pmc(args):
                 return None
             db = sqlite3.connect(dbs[0])
             rows = list(db.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)))
-            for half, tag in ((True, "mirror"), (False, "f32")):
-                # scan_kernel<METRIC, MASKED, NQ, CHUNKS, .., .., HALF>: the sweeps proper are the launches within 2x of the
-                # largest (the f32 retry launches of a mirror pass share the f32 template and return at once)
-                want = "true" if half else "false"
-                v = [val for name, val in rows
-                     if (m := re.search(r"scan_kernel<[^>]*?(true|false)>", name)) and m.group(1) == want]
+            for tag in ("i8", "bf16", "f32"):
+                # scan_kernel<METRIC, MASKED, NQ, CHUNKS, .., .., HALF> / scan_i8_kernel<...>: the sweeps proper are the launches
+                # within 2x of the largest (the f32 retry launches of a mirror pass share the f32 template and return at once)
+                if tag == "i8":
+                    v = [val for name, val in rows if "scan_i8_kernel" in name]
+                else:
+                    want = "true" if tag == "bf16" else "false"
+                    v = [val for name, val in rows
+                         if "scan_i8" not in name and (m := re.search(r"scan_kernel<[^>]*?(true|false)>", name)) and m.group(1) == want]
                 if not v:
-                    return None
+                    continue
                 big = [x for x in v if x * 2 >= max(v)]
                 per.setdefault(tag, {})[counter] = (float(np.mean(big)), len(big))
     except (subprocess.TimeoutExpired, OSError, sqlite3.Error):
@@ -213,6 +289,8 @@ def live_pmc(args):
         shutil.rmtree(tmp, ignore_errors=True)
     res = {}
     for tag, d in per.items():
+        if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+            continue
         rd = d["FETCH_SIZE"][0] * 1024 * 2
         wr = d["WRITE_SIZE"][0] * 1024
         res[tag] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr,
@@ -220,11 +298,11 @@ def live_pmc(args):
                     "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace and --pmc WRITE_SIZE "
                               "--kernel-trace (separate passes) around child runs of bench.py --pmc-child; "
                               "FETCH_SIZE*1024*2 (gfx950 correction, MI355X_MICROARCH.md), WRITE_SIZE*1024"}
-    return res
+    return res or None
 
 
 def pmc_child(args):
-    """What live_pmc() profiles: a few nq=1 sweeps over the bf16 mirror, then over the f32 corpus; no output."""
+    """What live_pmc() profiles: a few nq=1 sweeps over the 8-bit mirror, the bf16 mirror, the f32 corpus; no output."""
     import torch
     from neumann_amd import GpuFlatIndex
     dev = torch.device("cuda", 0)
@@ -232,39 +310,45 @@ def pmc_child(args):
     idx = GpuFlatIndex(args.dim, args.rows, device=0)
     idx.fill_synthetic(SEED_CORPUS, args.rows)
     q = torch.from_numpy(_synth(SEED_QUERY, 0, 4, args.dim)).to(dev)
-    for mirror in (True, False):
-        idx.set_mirror(mirror)
+    for mode in (1, 2, 0):
+        idx.set_mirror(mode)
         for i in range(8):
             idx.search_device(q[i % 4:i % 4 + 1], args.k, METRICS[args.metric])
         torch.cuda.synchronize()
     idx.close()
 
 
-def certificate(idx, q_host, metric, rows, scores, counts, world, dev, mask_host=None):
+def certificate(idx, q_host, metric, rows, scores, counts, world, dev, mask_host=None, reduce=None):
     """Size-independent proof that (rows, scores) is the exact top-k of the whole sharded corpus, using
     only the product's exact (reference-order) kernels, which tests/ pin bit-for-bit to the oracle:
       1. every returned score equals the exact score of its row (owner shard recomputes it);
       2. the list is ordered (score desc, row asc);
       3. #rows anywhere with exact score > s_k  ==  #returned scores > s_k, and the returned ties at
-         s_k do not exceed the corpus-wide number of rows scoring exactly s_k."""
-    import torch
-    import torch.distributed as dist
+         s_k do not exceed the corpus-wide number of rows scoring exactly s_k.
+    `idx` may be a list of shards held by this process (the one-process handle)."""
+    shards = idx if isinstance(idx, (list, tuple)) else [idx]
     cnt = int(counts[0])
     r = rows[0, :cnt].astype(np.uint64)
     s = scores[0, :cnt]
-    base, n_local = idx.row_base, idx.rows
-    mine = (r >= base) & (r < base + n_local)
-    ok_scores = True
-    if mine.any():
-        ex = idx.score_rows(q_host, (r[mine] - np.uint64(base)), metric)[0]
-        ok_scores = bool(np.all(ex == s[mine]))
-    ordered = bool(np.all((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (r[:-1] < r[1:])))) if cnt > 1 else True
     sk = float(s[-1]) if cnt else float("inf")
-    gt, eq = idx.count_exact(q_host, sk, metric, mask=mask_host) if cnt else (0, 0)
-    agg = torch.tensor([gt, eq, 0 if ok_scores else 1], dtype=torch.int64, device=dev)
+    gt = eq = bad = 0
+    for sh in shards:
+        base, n_local = sh.row_base, sh.rows
+        mine = (r >= base) & (r < base + n_local)
+        if mine.any():
+            ex = sh.score_rows(q_host, (r[mine] - np.uint64(base)), metric)[0]
+            bad += 0 if bool(np.all(ex == s[mine])) else 1
+        if cnt:
+            g, e = sh.count_exact(q_host, sk, metric, mask=mask_host)
+            gt += g
+            eq += e
+    ordered = bool(np.all((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (r[:-1] < r[1:])))) if cnt > 1 else True
     if world > 1:
+        import torch
+        import torch.distributed as dist
+        agg = torch.tensor([gt, eq, bad], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(agg)
-    gt, eq, bad = (int(x) for x in agg.tolist())
+        gt, eq, bad = (int(x) for x in agg.tolist())
     n_gt_ret = int(np.sum(s > np.float32(sk)))
     n_eq_ret = int(np.sum(s == np.float32(sk)))
     exact = bad == 0 and ordered and gt == n_gt_ret and n_eq_ret <= eq and (cnt == 0 or n_eq_ret >= 1)
@@ -272,9 +356,9 @@ def certificate(idx, q_host, metric, rows, scores, counts, world, dev, mask_host
             "rows_above_kth": gt, "rows_equal_kth": eq, "returned": cnt, "recall_at_k": 1.0 if exact else None}
 
 
-def measure_batched(args, idx, dev, metric, total_rows, torch):
-    """Config 3 on the same resident corpus: nq queries per step through the MFMA sweep (one corpus sweep per 64
-    queries), two steps in flight; the last batch is certified query by query with the exact kernels."""
+def measure_batched(args, idx, dev, metric, total_rows, torch, certify=True):
+    """Config 3 on the resident corpus: nq queries per step through the MFMA sweep (one corpus sweep per 64 queries), two
+    steps in flight; the last batch is certified query by query with the exact kernels."""
     from neumann_amd.sharded import ShardedSearcher
     nq = args.batched
     q_host = np.stack([_synth(SEED_QUERY + 1, s * nq, nq, args.dim) for s in range(4)])
@@ -310,49 +394,209 @@ def measure_batched(args, idx, dev, metric, total_rows, torch):
     idx.set_timing(False)
     torch.cuda.synchronize()
     qh = q_host[(steps - 1) % 4]
-    ok = True
-    if not args.no_parity:
+    ok = None
+    if certify and not args.no_parity:
+        ok = True
         for qi in (0, nq // 2, nq - 1):  # three of the batch's queries: the exact certificate is a full pass each
-            c = certificate(idx, qh[qi], metric, rows.view(np.uint64)[qi:qi + 1], scores[qi:qi + 1], counts[qi:qi + 1],
-                            1, dev)
+            c = certificate(idx, qh[qi], metric, rows.view(np.uint64)[qi:qi + 1], scores[qi:qi + 1], counts[qi:qi + 1], 1, dev)
             ok = ok and c["exact_topk_certified"]
-    # stationary queries of one matrix-core sweep (launch_metric in nmn_scan_mfma.hip): 128 when the pass holds more
-    # than 64 queries and the rows are <= 768 elements long, else 64
-    per_sweep = 128 if ((args.dim // 128 <= 6 or args.dim // 128 in (8, 10)) and nq > 64) else 32 if args.dim // 128 in (16, 24, 32) else 64
-    sweeps = (nq + per_sweep - 1) // per_sweep
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
-    # ONE launch carries every query block; the workgroups that stream the same tiles for different blocks sit on the
-    # same XCD (ids 8 apart) and share its L2, so the algorithmic HBM bytes are one corpus read per launch.  The bytes
-    # the workgroups REQUEST (query blocks x corpus) are reported beside it.
-    gbps = idx.rows * args.dim * elem_bytes / (sweep * 1e-3) / 1e9
-    return {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
-            "value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "sweep_ms_incl_sampling_pass": sweep, "query_blocks_per_launch": sweeps,
-            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbps / HBM_PEAK_GBS, "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)",
-                         "bytes_per_corpus_element": elem_bytes, "requested_GBs_all_query_blocks": gbps * sweeps},
-            "exact_topk_certified_3_of_batch": bool(ok) if not args.no_parity else None}
+    return {"value": nq * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "sweep_ms": sweep,
+            "elem_bytes": elem_bytes, "certified": ok}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY §8(f) rows, driver-visible: filtered SIMILAR end to end, IVF probe, upload, index-file load (child process)
+# ---------------------------------------------------------------------------------------------------------------------
+def next_rows_child(args):
+    import tempfile
+    import torch
+    from neumann_amd import GpuFlatIndex
+    from neumann_amd import columns as g
+    from neumann_amd.ivf import GpuIvfFlat
+    torch.cuda.set_device(0)
+    out = {}
+    metric = METRICS[args.metric]
+    n, d, k = args.rows, args.dim, args.k
+    # ---- (f2) filtered SIMILAR at selectivity 0.1 through the C ABI: predicate program -> bitmap -> masked sweep -> top-k ----
+    try:
+        with GpuFlatIndex(d, n, device=0) as idx, g.GpuColumns(n) as cols:
+            idx.fill_synthetic(SEED_CORPUS, n)
+            col = cols.add_column()
+            bucket = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) >> np.uint64(7)) % np.uint64(10)
+            cols.write(col, 0, np.full(n, g.CELL_INT, np.uint8), bucket)
+            cols.write_valid(0, np.full((n + 63) // 64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+            prog = [(g.PRED_CMP, g.CMP_EQ, g.CELL_INT, col, 3, 0)]
+            Q = _synth(SEED_QUERY + 7, 0, 8, d)
+            rows, scores, counts, selected = idx.search_pred(cols, prog, [], Q[0], k, metric)
+            _, _, _, st = idx.search(Q[0], k, metric, with_stats=True)
+            eb = int(st.bytes_scanned // max(1, st.rows_scanned * d))
+            reps = 40
+            t0 = time.perf_counter()
+            for i in range(reps):
+                rows, scores, counts, selected = idx.search_pred(cols, prog, [], Q[i % 8], k, metric)
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            keep = bucket == 3
+            words = (n + 63) // 64
+            padded = np.zeros(words * 64, dtype=bool)
+            padded[:n] = keep
+            mask = np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words)
+            cert = certificate(idx, Q[(reps - 1) % 8], metric, rows, scores, counts, 1, None, mask)
+            alg = selected * d * eb + n * 9 + n // 8  # kept rows of the sweep + (kind u8, payload u64) per row + the bitmap
+            out["filtered_similar_sel0.1"] = {
+                "what": f"nmn_index_search_pred (host buffers: query H2D, predicate kernel over {n} rows, masked sweep, select, "
+                        f"rescore, result D2H) — search_with_pre_filter end to end (lib.rs:3514-3557), WHERE bucket = 3 of 10",
+                "rows": n, "selected": int(selected), "selectivity": selected / n, "ms_per_query_wall": ms, "value": 1e3 / ms,
+                "unit": "queries/s", "bytes_per_corpus_element": eb, "algorithmic_bytes": alg,
+                "roofline": {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "note": "wall time of the whole call, PCIe and launches included"},
+                "exact_topk_certified": cert["exact_topk_certified"]}
+    except Exception as e:
+        out["filtered_similar_sel0.1"] = {"error": f"{type(e).__name__}: {e}"}
+    # ---- (f1) upload and (f4) index-file load, GB/s end to end ----
+    try:
+        un = 500_000
+        A = np.empty((un, d), dtype=np.float32)
+        A[:] = (np.arange(d, dtype=np.float32) % 7 - 3.0)[None, :]
+        A += (np.arange(un, dtype=np.float32) % 1013 * np.float32(1e-3))[:, None]
+        with GpuFlatIndex(d, un, device=0) as idx:
+            idx.upload(A[:1000])  # warm (allocations, first-touch)
+            t0 = time.perf_counter()
+            idx.upload(A, row0=0)
+            dt = time.perf_counter() - t0
+            out["upload_host_rows"] = {"what": "nmn_index_upload: pageable host rows -> HBM + magnitudes in reference order + bf16 mirror (one ingest kernel)",
+                                       "rows": un, "bytes": A.nbytes, "seconds": dt, "value": A.nbytes / dt / 1e9, "unit": "GB/s",
+                                       "bound": "PCIe (the copy); the ingest kernel behind it is HBM-bound"}
+            path = os.path.join(tempfile.mkdtemp(prefix="nmn_bench_", dir="/tmp"), "shard.nmnidx")
+            idx.save(path)
+            fbytes = os.path.getsize(path)
+        t0 = time.perf_counter()
+        idx2 = GpuFlatIndex.load(path, device=0)
+        dt = time.perf_counter() - t0
+        ok = idx2.rows == un
+        idx2.close()
+        os.remove(path)
+        out["index_file_load"] = {"what": "nmn_index_load: sequential read through pinned chunks, H2D, magnitudes recomputed and compared bit for bit, checksum",
+                                  "rows": un, "file_bytes": fbytes, "seconds": dt, "value": fbytes / dt / 1e9, "unit": "GB/s",
+                                  "rows_restored": bool(ok), "bound": "file system / PCIe"}
+    except Exception as e:
+        out["upload_and_load"] = {"error": f"{type(e).__name__}: {e}"}
+    # ---- (f4) IVF-Flat probe: 2M x 768, 256 lists, nprobe 8 ----
+    try:
+        rn, C_, nprobe, tn = 2_000_000, 256, 8, 200_000
+        rng = np.random.default_rng(5)
+        centers = rng.standard_normal((C_, d)).astype(np.float32) * np.float32(2.0)
+        pool = rng.standard_normal((8192, d)).astype(np.float32)
+
+        def rows_of(a, b):
+            i = np.arange(a, b, dtype=np.int64)
+            return centers[(i * 2654435761 >> 9) % C_] + pool[(i * 40503 + 17) % 8192]
+
+        t0 = time.perf_counter()
+        ivf = GpuIvfFlat.build(rows_of(0, tn), C_, nprobe=nprobe, max_iterations=3, seed=42, init_method="kmeans++", capacity_rows=rn)
+        t_train = time.perf_counter() - t0
+        with ivf:
+            t0 = time.perf_counter()
+            for a in range(tn, rn, 300_000):
+                ivf.add(rows_of(a, min(a + 300_000, rn)))
+            t_add = time.perf_counter() - t0
+            Q = rows_of(12345, 12345 + 32) + np.float32(0.05)
+            ivf.search(Q[0], k)
+            reps = 64
+            t0 = time.perf_counter()
+            for i in range(reps):
+                ids, dist, cnt = ivf.search(Q[i % 32], k)
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            sizes = ivf.cluster_sizes()
+            ex_ids, ex_dist, _ = ivf.search(Q[(reps - 1) % 32], k, nprobe=C_)  # every list: the exhaustive answer
+            recall = len(set(ids[0].tolist()) & set(ex_ids[0].tolist())) / float(k)
+            probed = float(np.sort(sizes)[::-1][:nprobe].sum())  # upper bound on the rows one probe scans
+            out["ivf_probe"] = {"what": "nmn_ivf_search (tensor_store/src/ivf.rs:325-406): rank 256 centroids, scan the 8 nearest lists, top-k",
+                                "rows": rn, "dim": d, "clusters": C_, "nprobe": nprobe, "k": k, "ms_per_query_wall": ms, "value": 1e3 / ms,
+                                "unit": "queries/s", "train_seconds": t_train, "add_rows_per_s": (rn - tn) / t_add,
+                                "list_size_min_mean_max": [int(sizes.min()), float(sizes.mean()), int(sizes.max())],
+                                "rows_in_8_largest_lists": probed, "recall_vs_exhaustive_probe_one_query": recall,
+                                "note": "the probe is launch-bound at this size (list scan ~50 us of the call); IVF itself is approximate in the reference too"}
+    except Exception as e:
+        out["ivf_probe"] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N GPUs driven by ONE process through the C ABI (nmn_sharded): what a Rust host holding one Arc<VectorEngine> binds
+# ---------------------------------------------------------------------------------------------------------------------
+def handle_child(args):
+    from neumann_amd import GpuShardedIndex
+    n = args.gpus
+    pinned = os.environ.get("NMN_BENCH_DEVICE")
+    devices = [int(pinned)] * n if pinned is not None else list(range(n))
+    per_gpu = min(args.rows, 2_000_000)
+    total = per_gpu * n
+    metric = METRICS[args.metric]
+    out = {"what": "nmn_sharded_*: ONE process, one shard per GPU, queries replicated, per-shard pipelines on per-device streams "
+                   "(one host thread per shard), one grouped ncclAllGather of the packed top-k blocks, merge on device 0",
+           "devices": devices, "rows_total": total}
+    with GpuShardedIndex(args.dim, total, n, devices=devices) as sh:  # create ends with the collective's self-test
+        sh.fill_synthetic(SEED_CORPUS, total)
+        out["rccl_ranks"] = sh.rccl_ranks
+        out["gather"] = {1: "rccl all-gather", 2: "peer copies"}.get(sh.gather_mode, str(sh.gather_mode))
+        out["rows_per_gpu"] = [sh.shard_rows(g) for g in range(n)]
+        Q = _synth(SEED_QUERY + 11, 0, 8, args.dim)
+        sh.set_timing(True)
+        for i in range(3):
+            sh.search(Q[i], args.k, metric)
+        reps = 30
+        gm = []
+        t0 = time.perf_counter()
+        for i in range(reps):
+            rows, scores, counts = sh.search(Q[i % 8], args.k, metric)
+            gm.append(sh.last_gather_ms())
+        dt = (time.perf_counter() - t0) / reps
+        cert = certificate([sh.shard(g) for g in range(n)], Q[(reps - 1) % 8], metric, rows, scores, counts, 1, None)
+        out.update({"value": 1.0 / dt, "unit": "queries/s (host-buffer API: query H2D and result D2H inside every call)",
+                    "ms_per_query_wall": dt * 1e3, "gather_plus_merge_ms": float(np.median(gm)),
+                    "exact_topk_certified": cert["exact_topk_certified"]})
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    if args.next_rows_child:
+        return next_rows_child(args)
+    if args.handle_child:
+        return handle_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a number "
+                  f"for a GPU count that was not asked for", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # NMN_BENCH_DEVICE pins every rank to one device: lets the N>1 code path run on a 1-GPU box where the
-    # collective library tolerates several ranks per GPU (debugging aid, never used by the driver)
-    dev_index = int(os.environ.get("NMN_BENCH_DEVICE", local_rank))
+    # NMN_BENCH_DEVICE pins every rank to one device: lets the N>1 code path run on a 1-GPU box with NMN_BENCH_BACKEND=gloo
+    # (RCCL refuses two ranks on one device); a debugging aid, never used by the driver
+    pinned = os.environ.get("NMN_BENCH_DEVICE")
+    dev_index = int(pinned) if pinned is not None else local_rank
+    if dev_index >= torch.cuda.device_count():
+        print(f"[bench] rank {rank}: device {dev_index} does not exist ({torch.cuda.device_count()} visible); --gpus {args.gpus} "
+              f"needs one device per rank", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = None
+    rccl_ranks = 0
     if world > 1 or args.always_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29571")
@@ -361,34 +605,30 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        # a REAL all-gather of rank ids before anything is measured: every rank must see 0..world-1 in order
+        me = torch.tensor([rank], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        got = [torch.empty_like(me) for _ in range(world)]
+        dist.all_gather(got, me)
+        seen = [int(t.item()) for t in got]
+        if seen != list(range(world)):
+            print(f"[bench] rank {rank}: the all-gather of rank ids returned {seen}", file=sys.stderr)
+            sys.exit(3)
+        rccl_ranks = dist.get_world_size()
 
     from neumann_amd import GpuFlatIndex
     from neumann_amd.sharded import ShardedSearcher, shard_range
 
     metric = METRICS[args.metric]
-    if args.scaling == "weak":
-        total_rows = args.rows * world
-    else:
-        total_rows = args.rows
+    total_rows = args.rows * world if args.scaling == "weak" else args.rows
     r0, r1 = shard_range(total_rows, world, rank)
     local_rows = r1 - r0
-
-    idx = GpuFlatIndex(args.dim, local_rows, row_base=r0, device=dev_index)
-    t_fill = time.perf_counter()
-    idx.fill_synthetic(SEED_CORPUS, local_rows)
-    torch.cuda.synchronize()
-    t_fill = time.perf_counter() - t_fill
+    rows_per_gpu = [shard_range(total_rows, world, g)[1] - shard_range(total_rows, world, g)[0] for g in range(world)]
 
     n_query_sets = 16
     q_host = np.stack([_synth(SEED_QUERY, s * args.nq, args.nq, args.dim) for s in range(n_query_sets)])
     q_dev = torch.from_numpy(q_host).to(dev)  # [sets, nq, dim] resident in HBM
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    searchers = [ShardedSearcher(idx, world_size=world, rank=rank, k=args.k, nq=args.nq, device=dev,
-                                 always_gather=args.always_gather)
-                 for _ in range(n_streams)]  # one set of result buffers (and one library workspace) per stream
     mask_host = mask_dev = None
     kept_rows = local_rows
     if args.mask < 1.0:
@@ -401,18 +641,34 @@ def main():
         mask_host = np.packbits(padded.reshape(words, 64), axis=1, bitorder="little").view(np.uint64).reshape(words)
         mask_dev = torch.from_numpy(mask_host.view(np.int64)).to(dev)
 
-    def step(i):
-        with torch.cuda.stream(streams[i % n_streams]):
-            return searchers[i % n_streams].search_device(q_dev[i % n_query_sets], metric, mask_t=mask_dev)
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run():
-        """W untimed steps, K timed steps between fences (max over ranks), then the dominant kernel's HIP-event average
-        over up to 30 more steps.  Returns (elapsed_s, last result, scan_ms list, total_ms list, bytes per element)."""
+    state = {}
+
+    def build_index():
+        if state.get("idx") is not None:
+            state["idx"].close()
+        idx = GpuFlatIndex(args.dim, local_rows, row_base=r0, device=dev_index)
+        t = time.perf_counter()
+        idx.fill_synthetic(SEED_CORPUS, local_rows)
+        torch.cuda.synchronize()
+        state["fill_s"] = time.perf_counter() - t
+        idx.set_mirror(args.mirror)
+        state["idx"] = idx
+        # one set of result buffers (and one library workspace) per stream
+        state["searchers"] = [ShardedSearcher(idx, world_size=world, rank=rank, k=args.k, nq=args.nq, device=dev,
+                                              always_gather=args.always_gather) for _ in range(n_streams)]
+        return idx
+
+    def step(i):
+        with torch.cuda.stream(streams[i % n_streams]):
+            return state["searchers"][i % n_streams].search_device(q_dev[i % n_query_sets], metric, mask_t=mask_dev)
+
+    def timed_loop():
+        """W untimed steps, EXACTLY K timed steps between fences; the elapsed time is the max over ranks."""
         for i in range(args.warmup):
             step(i)
         fence()
@@ -422,90 +678,154 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        last = tuple(t.cpu().numpy().copy() for t in out)  # result of the last timed step
-        # dominant-kernel timing: HIP events on the launch stream, recorded inside the library
+        return elapsed, tuple(t.cpu().numpy().copy() for t in out)  # result of the last timed step
+
+    def kernel_timing_loop():
+        """The dominant kernel's duration: HIP events the library records on the launch stream, steps enqueued and waited for
+        one at a time (its events must not span another step's kernels).  Also the whole pipeline's span in that loop."""
+        idx = state["idx"]
         idx.set_timing(True)
-        scan_ms, total_ms = [], []
-        eb = 4  # bytes per corpus element the dominant kernel reads: 4 (f32 corpus) or 2 (its bf16 mirror)
+        scan_ms, total_ms, cands = [], [], []
+        eb = 4
         for i in range(min(max(args.steps, 5), 30)):
+            torch.cuda.synchronize()
             step(i)
             st = idx.last_stats(streams[i % n_streams])
             if st.scan_ms > 0:
                 scan_ms.append(st.scan_ms)
                 total_ms.append(st.total_ms)
+                cands.append(st.candidates_rescored)
             if st.rows_scanned:
                 eb = int(st.bytes_scanned // (st.rows_scanned * args.dim))
         idx.set_timing(False)
         fence()
-        return elapsed, last, scan_ms, total_ms, eb
+        return scan_ms, total_ms, eb, cands
 
-    elapsed, last_out, scan_ms, total_ms, elem_bytes = timed_run()
+    default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
+                        args.metric == "cosine" and args.mask >= 1.0 and args.mirror == 1)
+    extras = world == 1 and not args.always_gather
+
+    # ---- the headline: median over index rebuilds --------------------------------------------------------------------
+    draws, batched_draws = [], []
+    last_out = None
+    for b in range(max(1, args.rebuilds)):
+        build_index()
+        elapsed, last_out = timed_loop()
+        draws.append(elapsed)
+        if extras and args.batched > 0 and args.nq == 1 and args.mask >= 1.0 and args.mirror == 1:
+            batched_draws.append(measure_batched(args, state["idx"], dev, metric, total_rows, torch,
+                                                 certify=(b == max(1, args.rebuilds) - 1)))
+    idx = state["idx"]
+    elapsed = float(np.median(draws))
     ms_per_step = elapsed / args.steps * 1e3
     value = args.nq * args.steps / elapsed
+    scan_ms, total_ms, elem_bytes, cands = kernel_timing_loop()
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
-    # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3
-    # queries at dim >= 768, else >= 5; cosine/dot), else 4 (VALU) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
+    # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3 queries at dim >= 768, else >= 5), else 4 (VALU; 2 on
+    # the 8-bit mirror) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
     ld128 = (args.dim + 127) // 128 * 128  # nmn_index_create pads rows just short of a supported multiple of 128 up to it
     while ld128 <= 4096 and not (ld128 // 128 <= 6 or ld128 // 128 in (8, 10, 12, 16, 24, 32)):
         ld128 += 128
     kc = ld128 // 128 if (ld128 <= 4096 and (ld128 - args.dim) * 8 <= args.dim) else 0
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and kc and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
-            and args.k <= 4096)
-    # the matrix-core sweep is ONE launch whatever the number of query blocks (they share the tiles through the XCD's L2);
-    # VALU sweeps are one launch per 4 queries
+            and args.k <= 4096 and args.mirror != 0)
     passes = 1 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
-    alg_bytes = (kept_rows * args.dim * elem_bytes + (local_rows // 8 if mask_dev is not None else 0)) * passes  # excluded rows are never read
-    achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
 
-    # ---- read ceiling of this device: the scan's access pattern with the arithmetic removed (rank 0 reports) ----
+    def alg_bytes_for(eb):  # excluded rows are never read
+        return (kept_rows * args.dim * eb + (local_rows // 8 if mask_dev is not None else 0)) * passes
+
+    alg_bytes = alg_bytes_for(elem_bytes)
+    achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
+    kernel_name = ("nmn::exact_scan_kernel" if args.k > 4096 else "nmn::scan_mfma_kernel" if mfma else
+                   "nmn::scan_i8_kernel" if elem_bytes == 1 else "nmn::scan_kernel")
+
+    # ---- read ceiling of this device: the scan's access pattern with the arithmetic removed ----
     read_ceiling = idx.read_probe(3) if local_rows else None
 
-    # ---- parity of the last result ----------------------------------------------------------------
+    # ---- parity of the last result ----
     parity = None
+    q_last = q_host[(args.steps - 1) % n_query_sets][0]
     if not args.no_parity:
         o_rows, o_scores, o_counts = last_out
-        parity = certificate(idx, q_host[(args.steps - 1) % n_query_sets][0], metric,
-                             o_rows.view(np.uint64), o_scores, o_counts, world, dev, mask_host)
+        parity = certificate(idx, q_last, metric, o_rows.view(np.uint64), o_scores, o_counts, world, dev, mask_host)
 
-    # ---- the sweep SURVEY §8(d) prices: the row-major f32 corpus itself, same index / queries / loop ----
-    f32_leg = None
-    if world == 1 and elem_bytes == 2 and not args.no_f32_leg and args.k <= 4096 and args.nq == 1:
-        idx.set_mirror(False)
-        e2, out2, scan2, total2, eb2 = timed_run()
-        idx.set_mirror(True)
-        k_ms = float(np.mean(scan2)) if scan2 else float("nan")
-        bytes4 = (kept_rows * args.dim * 4 + (local_rows // 8 if mask_dev is not None else 0)) * passes
-        ach = bytes4 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
-        cert2 = None
-        if not args.no_parity:
-            cert2 = certificate(idx, q_host[(args.steps - 1) % n_query_sets][0], metric, out2[0].view(np.uint64), out2[1],
-                                out2[2], world, dev, mask_host)
-        same = bool(np.array_equal(out2[0], last_out[0]) and np.array_equal(out2[1].view(np.uint32), last_out[1].view(np.uint32)))
-        f32_leg = {"what": "nmn_index_set_mirror(0): scan_kernel streams the row-major f32 corpus (SURVEY §8(d): rows*dim*4 "
-                           "bytes per query); same index, queries, streams, steps and warmup as the headline loop",
-                   "value": args.nq * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
-                   "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS if scan2 else None,
-                   "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes4, "bytes_per_corpus_element": eb2,
-                   "pricing": "SURVEY §8(d): rows*dim*4",
-                   "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
-                   "traffic": pmc_traffic(local_rows, args, 4)[0], "traffic_source": pmc_traffic(local_rows, args, 4)[1],
-                   "exact_topk_certified": cert2["exact_topk_certified"] if cert2 else None,
-                   "same_answer_as_mirror_sweep": same}
+    # ---- N > 1: what the collective step costs, measured on its own ----
+    multi = None
+    if world > 1 or args.always_gather:
+        s0 = state["searchers"][0]
+        gm = []
+        for i in range(12):
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(streams[0]):
+                e0.record()
+                s0.gather_merge()
+                e1.record()
+            torch.cuda.synchronize()
+            gm.append(e0.elapsed_time(e1))
+        multi = {"rccl_ranks": rccl_ranks if backend == "nccl" else 0, "ranks": rccl_ranks,
+                 "collective_backend": "nccl (RCCL over xGMI)" if backend == "nccl" else backend,
+                 "rank_id_all_gather": "ranks 0..N-1 seen in order on every rank before the measurement",
+                 "rows_per_gpu": rows_per_gpu, "gather_plus_merge_ms": float(np.median(gm[2:])),
+                 "gather_bytes_per_rank": int(state["searchers"][0]._bufs["size"]), "host": "one process per GPU (torch.distributed)"}
+
+    # ---- the sweeps this one replaced, on the same index / queries / loop: the f32 corpus (§8(d)'s pricing), the bf16 mirror ----
+    legs = {}
+    if extras and elem_bytes < 4 and not args.no_mirror_legs and args.k <= 4096 and args.nq == 1 and args.mirror == 1:
+        for mode, name in ((0, "roofline_f32_corpus"), (2, "roofline_bf16_mirror")):
+            if mode == 2 and elem_bytes == 2:
+                continue  # the headline already is the bf16 mirror
+            idx.set_mirror(mode)
+            e2, out2 = timed_loop()
+            scan2, total2, eb2, c2 = kernel_timing_loop()
+            idx.set_mirror(args.mirror)
+            k_ms = float(np.mean(scan2)) if scan2 else float("nan")
+            b2 = alg_bytes_for(eb2)
+            ach = b2 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
+            cert2 = None
+            if not args.no_parity:
+                cert2 = certificate(idx, q_last, metric, out2[0].view(np.uint64), out2[1], out2[2], world, dev, mask_host)
+            same = bool(np.array_equal(out2[0], last_out[0]) and np.array_equal(out2[1].view(np.uint32), last_out[1].view(np.uint32)))
+            legs[name] = {"what": f"nmn_index_set_mirror({mode}): scan_kernel streams the " + SWEEP[eb2][1] +
+                                  "; same index, queries, streams, steps and warmup as the headline loop",
+                          "value": args.nq * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
+                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS if scan2 else None,
+                          "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": b2, "bytes_per_corpus_element": eb2,
+                          "pricing": SWEEP[eb2][2],
+                          "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
+                          "candidates_rescored": int(np.median(c2)) if c2 else None,
+                          "traffic": pmc_traffic(local_rows, args, eb2)[0], "traffic_source": pmc_traffic(local_rows, args, eb2)[1],
+                          "exact_topk_certified": cert2["exact_topk_certified"] if cert2 else None,
+                          "same_answer_as_headline_sweep": same}
 
     batched = None
-    if world == 1 and args.batched > 0 and args.nq == 1 and args.mask >= 1.0:
-        batched = measure_batched(args, idx, dev, metric, total_rows, torch)
+    if batched_draws:
+        vals = [b["value"] for b in batched_draws]
+        sw = [b["sweep_ms"] for b in batched_draws]
+        eb3 = batched_draws[-1]["elem_bytes"]
+        nq = args.batched
+        per_sweep = 128 if ((args.dim // 128 <= 6 or args.dim // 128 in (8, 10)) and nq > 64) else 32 if args.dim // 128 in (16, 24, 32) else 64
+        sweep_med = float(np.median(sw))
+        gbps = idx.rows * args.dim * eb3 / (sweep_med * 1e-3) / 1e9
+        batched = {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
+                   "value": float(np.median(vals)), "unit": "queries/s", "rebuilds": vals,
+                   "ms_per_step": float(np.median([b["ms_per_step"] for b in batched_draws])), "steps": batched_draws[-1]["steps"],
+                   "sweep_ms_incl_sampling_pass": sweep_med, "sweep_ms_rebuilds": sw, "query_blocks_per_launch": (nq + per_sweep - 1) // per_sweep,
+                   "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)", "bytes_per_corpus_element": eb3,
+                                "frac_priced_as_survey_8d": gbps * 4 / eb3 / HBM_PEAK_GBS},
+                   "exact_topk_certified_3_of_batch": batched_draws[-1]["certified"]}
 
     # Single-query calls from many host threads at once (the reference's Arc<VectorEngine> under concurrent clients):
     # the C ABI merges callers that arrive while the shard is busy into one query batch.  Native threads, 1 second.
     callers = None
-    if world == 1 and args.callers > 0 and args.nq == 1 and args.mask >= 1.0 and args.k <= 4096:
+    if extras and args.callers > 0 and args.nq == 1 and args.mask >= 1.0 and args.k <= 4096 and args.mirror == 1:
         cq = _synth(SEED_QUERY + 2, 0, args.callers, args.dim)
         r = idx.callers_probe(cq, args.k, metric, seconds=1.0)
         callers = {"workload": f"{args.callers} host threads, each nmn_index_search(nq=1, k={args.k}) in a loop, "
@@ -513,84 +833,100 @@ def main():
                    "value": r["calls_per_s"], "unit": "queries/s", "threads": args.callers,
                    "sweeps_carrying_2_or_more_calls": r["merged_batches"], "calls_in_them": r["merged_calls"],
                    "answers_differing_from_a_lone_call": r["mismatches"]}
-        # twice the threads: one sweep carries up to 128 callers
-        cq2 = _synth(SEED_QUERY + 3, 0, 2 * args.callers, args.dim)
+        cq2 = _synth(SEED_QUERY + 3, 0, 2 * args.callers, args.dim)  # twice the threads: one sweep carries up to 128 callers
         r2 = idx.callers_probe(cq2, args.k, metric, seconds=1.0)
         callers["with_twice_the_threads"] = {"threads": 2 * args.callers, "value": r2["calls_per_s"], "unit": "queries/s",
                                              "answers_differing_from_a_lone_call": r2["mismatches"]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, metric, total_rows, local_rank)
+        cpu = cpu_baseline(args, metric, total_rows, dev_index)
 
     traffic, traffic_src = pmc_traffic(local_rows, args, elem_bytes)
-    others = None
-    default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
-                        args.metric == "cosine" and args.mask >= 1.0)
+    traffic_rw = None
     # HBM traffic of the dominant kernel from PMC counters collected in THIS run (the committed profiles/pmc_traffic.json
     # figure above is the fallback where rocprofv3 is not usable)
-    if rank == 0 and world == 1 and default_workload and not args.no_live_pmc and not args.always_gather:
+    if rank == 0 and extras and default_workload and not args.no_live_pmc:
         live = live_pmc(args)
         if live:
-            key = "mirror" if elem_bytes == 2 else "f32"
-            traffic, traffic_src = live[key]["hbm_bytes_per_launch"], live[key]["source"]
-            if f32_leg is not None:
-                f32_leg["traffic"], f32_leg["traffic_source"] = live["f32"]["hbm_bytes_per_launch"], live["f32"]["source"]
-                f32_leg["traffic_read_write"] = [live["f32"]["read_bytes_corrected"], live["f32"]["write_bytes"]]
-            traffic_rw = [live[key]["read_bytes_corrected"], live[key]["write_bytes"]]
-        else:
-            traffic_rw = None
-    else:
-        traffic_rw = None
-    if world == 1 and default_workload and not args.no_other_configs and not args.always_gather:
-        idx.close()  # the children need the HBM (config 5 alone is 61 GB + workspace)
+            key = SWEEP[elem_bytes][0]
+            if key in live:
+                traffic, traffic_src = live[key]["hbm_bytes_per_launch"], live[key]["source"]
+                traffic_rw = [live[key]["read_bytes_corrected"], live[key]["write_bytes"]]
+            for name, key2 in (("roofline_f32_corpus", "f32"), ("roofline_bf16_mirror", "bf16")):
+                if name in legs and key2 in live:
+                    legs[name]["traffic"], legs[name]["traffic_source"] = live[key2]["hbm_bytes_per_launch"], live[key2]["source"]
+                    legs[name]["traffic_read_write"] = [live[key2]["read_bytes_corrected"], live[key2]["write_bytes"]]
+    fill_s = state["fill_s"]
+    idx.close()  # the children (and the one-process handle) need the HBM
+    state["idx"] = None
+    others = next_rows = None
+    if extras and default_workload and not args.no_other_configs:
         others = other_configs()
+        try:
+            next_rows = _child_json([sys.executable, os.path.abspath(__file__), "--next-rows-child"], 240)
+        except Exception as e:
+            next_rows = {"error": f"{type(e).__name__}: {e}"}
+    if world > 1 or args.always_gather:
+        dist.barrier()  # every rank is done with its collectives before any of them tears the group down
+        dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.no_handle_leg and multi is not None:
+        # the same GPUs, ONE process, through the C ABI's nmn_sharded handle (its create runs the rank all-gather self-test)
+        try:
+            time.sleep(1.0)  # the other ranks are exiting and returning their HBM
+            multi["one_process_handle"] = _child_json(
+                [sys.executable, os.path.abspath(__file__), "--handle-child", "--gpus", str(world), "--rows", str(args.rows),
+                 "--dim", str(args.dim), "--k", str(args.k), "--metric", args.metric], 240)
+        except Exception as e:
+            multi["one_process_handle"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
+        sweep_key, sweep_txt, pricing = SWEEP[elem_bytes]
         line = {
             "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": f"{sweep_key} sweep + f32 exact rescore (results bit-equal to the f32 reference path)" if sweep_key != "f32" else "f32",
+            "data": "synthetic",
+            "rebuilds": {"n": len(draws), "queries_per_s": [args.nq * args.steps / e for e in draws],
+                         "spread": (max(draws) - min(draws)) / elapsed if len(draws) > 1 else 0.0,
+                         "value_is": "the median draw; every draw is W warmup + exactly K timed steps on a freshly built index"},
             "config": {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={args.nq}/step"
                                    + (f", WHERE mask selectivity {args.mask}" if args.mask < 1.0 else ""),
                        "rows_total": total_rows, "rows_per_gpu": local_rows, "dim": args.dim, "k": args.k,
                        "nq": args.nq, "streams": n_streams,
-                       "approximate_sweep": ("bf16 mirror of the corpus, f32 accumulate" if elem_bytes == 2 else "f32 corpus")
-                                            + "; every candidate re-scored from the f32 corpus in the reference's order",
+                       "approximate_sweep": sweep_txt + "; every candidate re-scored from the f32 corpus in the reference's order",
                        "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if scan_ms else None, "traffic": traffic,
-                         "traffic_source": traffic_src, "traffic_read_write": traffic_rw,
-                         "kernel": ("nmn::exact_scan_kernel" if args.k > 4096 else
-                                    "nmn::scan_mfma_kernel" if mfma else "nmn::scan_kernel"), "avg_kernel_ms": scan_avg,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_corpus_element": elem_bytes,
-                         "pricing": ("bytes the kernel is asked to read: rows*dim*2, the bf16 mirror" if elem_bytes == 2
-                                     else "SURVEY §8(d): rows*dim*4, the f32 corpus"),
+                         "frac": achieved / HBM_PEAK_GBS if scan_ms else None,
                          # the same kernel time priced as SURVEY §8(d) writes it (N*d*4 per query): an EFFECTIVE rate
                          "achieved_priced_as_survey_8d": achieved * 4 / elem_bytes if scan_ms else None,
                          "frac_priced_as_survey_8d": achieved * 4 / elem_bytes / HBM_PEAK_GBS if scan_ms else None,
-                         "pipeline_ms_per_query_batch": float(np.mean(total_ms)) if total_ms else None,
+                         "pricing": "bytes the kernel is asked to read: " + pricing,
+                         "bytes_per_corpus_element": elem_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_read_write": traffic_rw,
+                         "kernel": kernel_name, "avg_kernel_ms": scan_avg,
+                         "avg_kernel_ms_from": "kernel_timing_loop: hipEvents around the kernel, one step on the device at a time",
+                         "kernel_timing_loop": {"ms_per_step": float(np.mean(total_ms)) if total_ms else None,
+                                                "queries_per_s": (args.nq * 1e3 / float(np.mean(total_ms))) if total_ms else None,
+                                                "note": "same loop as avg_kernel_ms: kernel <= step here; the timed loop overlaps two steps"},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "candidates_rescored": int(np.median(cands)) if cands else None,
                          # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
                          "measured_read_ceiling": read_ceiling,
                          "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None},
-            "roofline_f32_corpus": f32_leg,
+            "roofline_f32_corpus": legs.get("roofline_f32_corpus"),
+            "roofline_bf16_mirror": legs.get("roofline_bf16_mirror"),
             "cpu_baseline": cpu,
             "parity": parity,
+            "multi_gpu": multi,
             "batched": batched,
             "concurrent_callers": callers,
             "other_configs": others,
-            "fill_s": t_fill,
+            "next_rows": next_rows,
+            "fill_s": fill_s,
         }
         print(json.dumps(line), flush=True)
-    if world > 1 or args.always_gather:
-        dist.barrier()  # every rank is done with its collectives before any of them tears the group down
-        dist.destroy_process_group()
-
-
-def _synth(seed, row0, n, dim):
-    from neumann_amd import synth_rows
-    return synth_rows(seed, row0, n, dim)
 
 
 if __name__ == "__main__":

@@ -92,7 +92,7 @@ typedef struct nmn_index_desc {
 /* Timing / accounting of the most recent search on a workspace (nullable everywhere). */
 typedef struct nmn_search_stats {
     uint64_t rows_scanned;        /* rows whose vectors were read (mask-excluded rows are not) */
-    uint64_t bytes_scanned;       /* algorithmic bytes of the scan: rows_scanned * dim * (4: f32 corpus, 2: bf16 mirror) */
+    uint64_t bytes_scanned;       /* algorithmic bytes of the scan: rows_scanned * dim * (4: f32 corpus, 2: bf16 mirror, 1: 8-bit mirror) */
     uint32_t candidates_rescored; /* max over queries of rows re-scored in reference order */
     uint32_t fallback_queries;    /* queries that took the exact-fallback path */
     float scan_ms;                /* hipEvent span of the scan kernel(s); -1 if not timed */
@@ -169,10 +169,15 @@ nmn_status nmn_index_search_device(nmn_index* idx, const float* queries_dev, uin
 
 /* Stats of the last search enqueued on `stream` (synchronises that stream). */
 nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_search_stats* stats);
-/* Which matrix the approximate sweep streams.  enabled != 0 (default): the shard's bf16 mirror (2 bytes per corpus
- * element; built on first use).  enabled == 0: the row-major f32 corpus itself — the sweep SURVEY.md §8(d) prices at
- * rows * dim * 4 bytes per query (bench.py's `roofline_f32_corpus` leg); query batches then run as VALU sweeps of 4.
- * Results are identical either way (every candidate is re-scored from the f32 corpus in the reference's order). */
+/* Which matrix the approximate sweep streams.  enabled == 1 (default): the smallest mirror that serves the call — the shard's
+ * 8-BIT mirror (int8 codes with a scale per row, 1 byte per corpus element; sweeps of 1-2 queries over rows of whole
+ * 256-element groups: 256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096) or else its bf16 mirror (2 bytes per element; every
+ * row length, and every query batch on the matrix cores); both are built on first use and carry their MEASURED rounding
+ * error into the candidate margin, and a shard whose 8-bit margin keeps overflowing the candidate lists returns to the bf16
+ * mirror by itself.  enabled == 2: the bf16 mirror only.  enabled == 0: the row-major f32 corpus itself — the sweep
+ * SURVEY.md §8(d) prices at rows * dim * 4 bytes per query (bench.py's `roofline_f32_corpus` leg); query batches then run as
+ * VALU sweeps of 4.  Results are identical in every mode (every candidate is re-scored from the f32 corpus in the
+ * reference's order). */
 nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled);
 /* Turn hipEvent timing of the scan kernel on/off for `*_device` searches (default off). */
 nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled);
@@ -287,6 +292,8 @@ nmn_index* nmn_sharded_shard(nmn_sharded* s, uint32_t g);      /* the shard's ow
 int32_t nmn_sharded_device(const nmn_sharded* s, uint32_t g);  /* HIP device of shard g */
 uint32_t nmn_sharded_gather_mode(const nmn_sharded* s);        /* NMN_GATHER_RCCL or NMN_GATHER_PEER: what create chose */
 uint32_t nmn_sharded_layout(const nmn_sharded* s);             /* NMN_SHARDED_LAYOUT_* in effect (1 shard: RANGES) */
+/* global id (row_base included) of local row `local_row` of shard g under the handle's layout; UINT64_MAX for a bad shard */
+uint64_t nmn_sharded_global_row(const nmn_sharded* s, uint32_t g, uint64_t local_row);
 /* nmn_sharded_create on >= 2 shards ends with a SELF-TEST of the collective a search will use: every shard puts its rank
  * into its result block, the blocks travel through the very gather code path (grouped ncclAllGather on the communicators of
  * ncclCommInitAll, or the peer copies), and the merging device — with RCCL every device — must hold ranks 0..G-1 in order.

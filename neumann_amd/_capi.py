@@ -157,6 +157,7 @@ SIGNATURES = {
     "nmn_sharded_device": (C.c_int32, [vp, C.c_uint32]),
     "nmn_sharded_gather_mode": (C.c_uint32, [vp]),
     "nmn_sharded_layout": (C.c_uint32, [vp]),
+    "nmn_sharded_global_row": (C.c_uint64, [vp, C.c_uint32, C.c_uint64]),
     "nmn_sharded_rccl_ranks": (C.c_uint32, [vp]),
     "nmn_sharded_set_timing": (C.c_int32, [vp, C.c_int32]),
     "nmn_sharded_set_mirror": (C.c_int32, [vp, C.c_int32]),

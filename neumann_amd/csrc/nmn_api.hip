@@ -61,6 +61,15 @@ static bool env_set(const char* name) {
 }
 static bool no_mfma() { static const bool v = env_set("NMN_NO_MFMA"); return v; }
 static bool no_half() { static const bool v = env_set("NMN_NO_HALF"); return v; }
+static bool no_i8() { static const bool v = env_set("NMN_NO_I8"); return v; }  // A/B: never the 8-bit mirror
+static uint64_t i8_min_rows() {  // shards below this stay on the bf16 mirror (the build and its HBM are not worth it)
+    static const uint64_t v = [] {
+        const char* e = getenv("NMN_I8_MIN_ROWS");
+        const long long x = e ? atoll(e) : 4096;
+        return (uint64_t)(x > 0 ? x : 0);
+    }();
+    return v;
+}
 static bool no_sample() { static const bool v = env_set("NMN_NO_SAMPLE"); return v; }
 static bool no_crowd() { static const bool v = env_set("NMN_NO_CROWD"); return v; }
 static bool no_tiny() { static const bool v = env_set("NMN_NO_TINY"); return v; }  // A/B: small shards through the 5-launch pipeline
@@ -158,7 +167,7 @@ struct IdleGuard {
 
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->crowd_ctr, w->crowd_rows, w->crowd_scores, w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qinfo, w->qinfo_f32, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
+    void* ptrs[] = {w->crowd_ctr, w->crowd_rows, w->crowd_scores, w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qi8, w->qinfo, w->qinfo_f32, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
                     w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
                     w->h_counts2, w->lk_keys};
     for (void* p : ptrs)
@@ -250,7 +259,7 @@ constexpr uint64_t kCrowdPool = 8ull << 20;
 // Frees what ws_alloc allocates (and only that), leaving the workspace as ws_get made it.
 static void ws_release_core(Workspace* w) {
     void** ptrs[] = {(void**)&w->scores, (void**)&w->tmax, (void**)&w->wmax, (void**)&w->tsample, (void**)&w->skip_key,
-                     (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
+                     (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qi8, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
                      (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
                      (void**)&w->crowd_rows, (void**)&w->crowd_scores, (void**)&w->fb_hist, (void**)&w->fb_list, (void**)&w->fb_count,
                      (void**)&w->fb_sync};
@@ -280,6 +289,7 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->skip_key), nq * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->k_extra), 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qpad), nq * w->ld * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qi8), nq * w->ld * 2));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo), nq * sizeof(QInfo)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qinfo_f32), nq * sizeof(QInfo)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
@@ -442,6 +452,8 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->half_scratch) (void)hipFree(idx->half_scratch);
     if (idx->half_stats) (void)hipFree(idx->half_stats);
+    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_err_bits, (void*)idx->q8_stats})
+        if (p) (void)hipFree(p);
     if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->inv_norms) (void)hipFree(idx->inv_norms);
@@ -475,6 +487,7 @@ extern "C" nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
     idx->mirror_off = enabled == 0;
+    idx->i8_off = enabled == 2;
     return NMN_OK;
 }
 
@@ -507,6 +520,42 @@ static nmn_status mirror_alloc(nmn_index* idx, hipStream_t stream) {
     return NMN_OK;
 }
 
+// The 8-bit mirror (nmn_index::q8).  Not enough HBM is not an error: the shard stays on the bf16 mirror (q8_failed).
+static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
+    if (idx->q8 || idx->q8_failed) return NMN_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->q8), (size_t)idx->cap_pad * idx->ld);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_scale), (size_t)idx->cap_pad * 4);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (idx->q8) (void)hipFree(idx->q8);
+        idx->q8 = nullptr;
+        idx->q8_failed = true;
+        return NMN_OK;
+    }
+    idx->q8_rows = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_err_bits), 8));
+    HIP_TRY(hipMemsetAsync(idx->q8_err_bits, 0, 8, stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_stats), 8));
+    HIP_TRY(hipMemsetAsync(idx->q8_stats, 0, 8, stream));
+    HIP_TRY(hipMemsetAsync(idx->q8, 0, (size_t)idx->cap_pad * idx->ld, stream));
+    HIP_TRY(hipMemsetAsync(idx->q8_scale, 0, (size_t)idx->cap_pad * 4, stream));
+    return NMN_OK;
+}
+
+// rows the 8-bit mirror already holds were overwritten: re-quantize them in place (rows beyond it are converted lazily)
+static nmn_status q8_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream) {
+    if (!idx->q8 || row0 >= idx->q8_rows) return NMN_OK;
+    const uint64_t cnt = std::min(row0 + n, idx->q8_rows) - row0;
+    float* scratch = nullptr;
+    HIP_TRY(half_scratch_get(idx, cnt, &scratch));
+    HIP_TRY(launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->ld, row0, cnt, idx->norms, scratch, idx->q8_err_bits, stream));
+    if (idx->half_scratch_cap > (1u << 20)) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        half_scratch_trim(idx);
+    }
+    return NMN_OK;
+}
+
 // What every writer of rows runs behind the copy: magnitudes in reference order, and the bf16 mirror of the same rows.
 // Rows in whole 32-float stages with no scalar tail take the ONE-PASS kernel (nmn_ingest.hip: one read of the f32 rows
 // feeds the magnitude chains, the bf16 pack and the error norms); a bulk write (>= 4096 rows) allocates the mirror right
@@ -523,7 +572,7 @@ static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStr
         HIP_TRY(launch_ingest(idx->corpus, idx->ld, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, with_half ? idx->half : nullptr,
                               idx->half_err_bits, stream));
         if (with_half) idx->half_rows = std::max(idx->half_rows, row0 + n);
-        return NMN_OK;
+        return q8_patch(idx, row0, n, stream);
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, stream));
     if (idx->half && row0 < idx->half_rows) {
@@ -538,7 +587,7 @@ static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStr
             half_scratch_trim(idx);
         }
     }
-    return NMN_OK;
+    return q8_patch(idx, row0, n, stream);
 }
 
 static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_host, uint64_t row0, uint64_t n,
@@ -762,6 +811,42 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }
         }
         const bool use_mfma = mfma_shape && use_half;  // the matrix-core sweep has no f32 variant
+        // 1-2 queries on rows of whole 256-element groups: the 8-BIT mirror (one byte per element, nmn_scan_i8.hip), with its own
+        // measured margin and its own on/off switch; built on first use, extended when rows were uploaded since
+        bool use_i8 = use_half && !use_mfma && nqc <= 2 && !qmasks_dev && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() &&
+                      !idx->q8_failed && scan_i8_supported(idx->ld, idx->dim, (int)metric) && idx->q8_calls >= idx->q8_off_until;
+        if (!use_mfma && idx->q8_stats && use_half && nqc <= 2 && (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {
+            uint32_t now[2] = {0, 0};
+            if (hipMemcpy(now, idx->q8_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                const uint32_t total = now[0] - idx->q8_seen[0], retried = now[1] - idx->q8_seen[1];
+                idx->q8_seen[0] = now[0];
+                idx->q8_seen[1] = now[1];
+                if (total >= 64 && retried * 2 > total) {
+                    idx->q8_off_until = idx->q8_calls + 8192;
+                    use_i8 = false;
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (use_i8) {
+            if (!idx->q8) {
+                st = q8_alloc(idx, stream);
+                if (st != NMN_OK) return st;
+                if (!idx->q8) use_i8 = false;  // not enough HBM: the bf16 mirror serves
+            }
+            if (use_i8 && idx->q8_rows < n_rows) {
+                const uint64_t cnt = n_rows - idx->q8_rows;
+                float* scratch = nullptr;
+                HIP_TRY(half_scratch_get(idx, cnt, &scratch));
+                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
+                                               idx->q8_err_bits, stream);
+                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // (as for the bf16 mirror: other streams may rely on it from now on)
+                half_scratch_trim(idx);
+                if (ce != hipSuccess) return fail_hip(ce, "8-bit mirror");
+                idx->q8_rows = n_rows;
+            }
+        }
         if (qmasks_host && !use_mfma) {
             // per-query bitmaps need the matrix-core sweep: this pass runs query by query instead
             for (uint32_t i = 0; i < nqc; i++) {
@@ -773,20 +858,24 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             w->last_nq = nq;
             continue;
         }
-        w->last_elem_bytes = use_half ? 2u : 4u;
-        // A bf16 pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
+        w->last_elem_bytes = use_i8 ? 1u : use_half ? 2u : 4u;
+        // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
         const bool f32_retry = use_half && !use_mfma && n_rows >= (1u << 18);
         if (f32_retry)
             HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric, idx->max_norm_bits,
                                  w->qpad, w->qinfo_f32, w->qstate, 0, stream));
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
-                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate, (use_mfma ? 1 : 0) | (use_half ? 2 : 0), stream,
-                             use_half ? idx->half_err_bits : nullptr));
+                             idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
+                             use_i8 ? (1 | 2 | 4) : ((use_mfma ? 1 : 0) | (use_half ? 2 : 0)), stream,
+                             use_i8 ? idx->q8_err_bits : use_half ? idx->half_err_bits : nullptr, use_i8 ? w->qi8 : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
             sp.corpus_half = use_half ? idx->half : nullptr;
+            sp.corpus_i8 = use_i8 ? idx->q8 : nullptr;
+            sp.i8_scale = idx->q8_scale;
+            sp.qi8 = w->qi8;
             sp.norms = idx->norms;
             sp.inv_norms = idx->inv_norms;
             sp.qpad = w->qpad;
@@ -875,7 +964,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sb.bx_count = 0;
                 HIP_TRY(launch_scan_mfma(sb, stream));
             } else {
-                HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : launch_scan(sp, stream));
+                HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));
             }
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
 
@@ -900,7 +989,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.k_extra = nullptr;
             sel.retry = 0;
             sel.retry_follows = f32_retry ? 1 : 0;
-            sel.half_stats = f32_retry ? idx->half_stats : nullptr;
+            sel.half_stats = f32_retry ? (use_i8 ? idx->q8_stats : idx->half_stats) : nullptr;
             sel.fb_sync_reset = w->fb_sync;  // (nullable) zeroed for the device-wide fallback selection further down this stream
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));

@@ -2867,13 +2867,19 @@ nmn_status nmn_engine_load_index_binary(nmn_engine* e, const char* path, char* n
         std::vector<float> dev((size_t)n_rows);
         // (device pointer of the magnitudes through the public accessor; one D2H per shard)
         const uint32_t n_sh = m->sh ? nmn_sharded_shards(m->sh) : 1u;
+        std::vector<float> part_norms;
         for (uint32_t g = 0; g < n_sh; g++) {
             const nmn_index* part = m->sh ? nmn_sharded_shard(m->sh, g) : m->idx;
-            const uint64_t cnt = nmn_index_rows(part), base = nmn_index_row_base(part);
+            const uint64_t cnt = nmn_index_rows(part);
             if (cnt == 0) continue;
-            if (base + cnt > n_rows) return fail(NMN_ERR_STORAGE, "Storage error: shard rows beyond the mirror");
-            if (hipMemcpy(dev.data() + base, nmn_index_norms_device(part), (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            part_norms.resize((size_t)cnt);
+            if (hipMemcpy(part_norms.data(), nmn_index_norms_device(part), (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess)
                 return fail(NMN_ERR_STORAGE, "Storage error: reading the magnitudes back");
+            for (uint64_t l = 0; l < cnt; l++) {  // the shard's local rows back to mirror rows (ranges or 64-row blocks dealt round-robin)
+                const uint64_t row = m->sh ? nmn_sharded_global_row(m->sh, g, l) : l;
+                if (row >= n_rows) return fail(NMN_ERR_STORAGE, "Storage error: shard rows beyond the mirror");
+                dev[(size_t)row] = part_norms[(size_t)l];
+            }
         }
         const std::vector<float>& want = stored_norms[kv.first];
         for (size_t r = 0; r < kv.second.size(); r++) {

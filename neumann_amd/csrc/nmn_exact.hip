@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                                                    int metric, const uint32_t* __restrict__ max_norm_bits,
                                                    float* __restrict__ qpad, QInfo* __restrict__ qinfo,
                                                    QState* __restrict__ qstate, int mfma_pass,
-                                                   const uint32_t* __restrict__ half_err_bits) {
+                                                   const uint32_t* __restrict__ half_err_bits, uint32_t* __restrict__ qi8) {
     const uint32_t q = blockIdx.x;
     const float* src = queries + (size_t)q * dim;
     float* dst = qpad + (size_t)q * ld;
@@ -204,7 +204,41 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
     const float ss = dot8_group<32>(src, src, dim, threadIdx.x & 7u);
     // MFMA sweep: the stationary copy of this query is bf16 — its rounding error |q - bf16(q)| goes into the margin
     float qerr2 = 0.0f;
-    if (mfma_pass & 1) {
+    float qscale = 0.0f;
+    if ((mfma_pass & 4) && qi8) {
+        // 8-bit sweep (nmn_scan_i8.hip): q = s_q (h + l / 256) + e_q with int8 vectors h, l; the planes go to qi8[q][2][ld]
+        // (zero beyond dim), |e_q| into the margin exactly like the bf16 rounding of the matrix-core sweep's queries
+        float mx = 0.0f;
+        bool bad = false;
+        for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+            const float ax = __builtin_fabsf(src[i]);
+            bad = bad || !(ax <= 3.0e38f);
+            mx = __builtin_fmaxf(mx, ax);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, off));
+            bad = bad || (__shfl_xor((int)bad, off) != 0);
+        }
+        qscale = (bad || mx == 0.0f) ? 0.0f : mx / 127.0f;
+        const float inv = qscale > 0.0f ? 127.0f / mx : 0.0f;
+        int8_t* hp = reinterpret_cast<int8_t*>(qi8) + (size_t)q * 2u * ld;
+        int8_t* lp = hp + ld;
+        for (uint32_t i = threadIdx.x; i < ld; i += 64) {
+            float h = 0.0f, l = 0.0f;
+            if (i < dim && qscale > 0.0f) {
+                const float t = src[i] * inv;
+                h = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(t), -127.0f), 127.0f);
+                l = __builtin_fminf(__builtin_fmaxf(__builtin_rintf((t - h) * 256.0f), -127.0f), 127.0f);
+                const float e = src[i] - qscale * (h + l * 0.00390625f);
+                qerr2 = qerr2 + e * e;
+            } else if (i < dim) {
+                qerr2 = bad ? __builtin_inff() : qerr2;  // a non-finite query: infinite margin, the exact paths answer
+            }
+            hp[i] = (int8_t)(int)h;
+            lp[i] = (int8_t)(int)l;
+        }
+        for (int off = 32; off > 0; off >>= 1) qerr2 = qerr2 + __shfl_down(qerr2, off);
+    } else if (mfma_pass & 1) {
         for (uint32_t i = threadIdx.x; i < dim; i += 64) {
             const float x = src[i];
             const uint32_t b = f2u(x);
@@ -221,6 +255,8 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         QInfo qi;
         qi.qmag = qmag;
         qi.pad = 0.f;
+        qi.qscale = qscale;
+        qi.rsv[0] = qi.rsv[1] = qi.rsv[2] = 0.f;
         // What the approximate sweep adds on top of f32 summation error, relative to |q||v|.  The margin is applied ONCE
         // below the k-th approximate score and must cover the error twice (k rows with approx >= T have exact >= T - e, so
         // the exact k-th is >= T - e, and a row with exact >= T - e has approx >= T - 2e).
@@ -285,9 +321,9 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
 
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
-                        hipStream_t s, const uint32_t* half_err_bits) {
+                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8) {
     hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), 0, s, queries, dim, ld, metric, max_norm_bits, qpad,
-                       qinfo, qstate, mfma_pass, half_err_bits);
+                       qinfo, qstate, mfma_pass, half_err_bits, qi8);
     return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@ struct Workspace {
     uint64_t n_sample_cap = 0;
     uint64_t tmax_stride = 0;
     float* qpad = nullptr;
+    uint32_t* qi8 = nullptr;       // [nq][2][ld / 4]: int8 h / l planes of the queries (8-bit sweep, nmn_scan_i8.hip)
     QInfo* qinfo = nullptr;
     QInfo* qinfo_f32 = nullptr;    // margins of the f32 sweep, for the retry after an overflowing bf16 pass
     QState* qstate = nullptr;
@@ -80,7 +81,7 @@ struct Workspace {
     bool allocated = false;  // every buffer of ws_alloc exists (set last; a partial allocation is rolled back)
     uint32_t last_nq = 0;
     uint64_t last_rows_scanned = 0;
-    uint32_t last_elem_bytes = 4;  // bytes per corpus element the last sweep read (2 on the bf16 mirror)
+    uint32_t last_elem_bytes = 4;  // bytes per corpus element the last sweep read (2 on the bf16 mirror, 1 on the 8-bit one)
     bool last_masked = false;
 };
 
@@ -123,6 +124,19 @@ struct nmn_index {
     uint64_t half_rows = 0;      // rows [0, half_rows) of `half` are current
     bool half_failed = false;    // allocation failed once: stay on the f32 sweep
     bool mirror_off = false;     // nmn_index_set_mirror(idx, 0): every sweep reads the f32 corpus (SURVEY §8(d)'s bytes)
+    bool i8_off = false;         // nmn_index_set_mirror(idx, 2): the bf16 mirror only, never the 8-bit one
+    // The 8-bit mirror (nmn_scan_i8.hip): int8 codes + a scale per row, what sweeps of 1-2 queries read where the row
+    // length allows it (whole 256-element groups).  Built on first use, extended / patched like `half`.  Its own on/off
+    // switch (q8_*; same rule as the bf16 mirror's): a shard whose measured 8-bit margin keeps overflowing the candidate
+    // lists goes back to the bf16 mirror for the next 8192 searches.
+    int8_t* q8 = nullptr;
+    float* q8_scale = nullptr;
+    uint32_t* q8_err_bits = nullptr;    // device [2]: max_r |e_r|, max_r |e_r| / |v_r|
+    uint32_t* q8_stats = nullptr;       // device [2]: queries selected on the 8-bit mirror / of those, retried in f32
+    uint64_t q8_rows = 0;
+    bool q8_failed = false;
+    uint32_t q8_seen[2] = {0, 0};
+    uint64_t q8_calls = 0, q8_off_until = 0;
     // Mirror on/off switch: data whose rounding margin keeps overflowing the candidate capacity (a row of enormous norm
     // under a Euclidean metric, ...) pays a bf16 pass AND an f32 retry per query.  select_kernel counts both in
     // half_stats; every 256th search the host reads them and, if more than half of the recent queries were retried, leaves

@@ -34,7 +34,9 @@ struct QInfo {
     float margin_abs;  // candidates: approx >= tau - margin_abs - |tau|*margin_rel
     float margin_rel;
     float pad;         // Euclidean score over the bf16 mirror: > 0 two-sided absolute error of the distance (VALU sweep);
-                       // < 0 minus the two-sided absolute error of the SQUARED distance (matrix-core sweep); else 0
+                       // < 0 minus the two-sided absolute error of the SQUARED distance (matrix-core / 8-bit sweep); else 0
+    float qscale;      // 8-bit sweep: s_q of the query's split q = s_q (h + l / 256) + e_q (nmn_scan_i8.hip); else 0
+    float rsv[3];
 };
 
 // Per-query selection state shared by select / fallback / rescore / final.
@@ -83,6 +85,9 @@ __host__ __device__ inline uint64_t score_at(uint64_t row, uint32_t q, uint32_t 
 struct ScanParams {
     const float* corpus;     // [rows][ld]
     const float* corpus_half;   // nullable: bf16 mirror (row stride ld/2 floats) the VALU sweep reads instead of `corpus`
+    const int8_t* corpus_i8;    // 8-bit sweep (nmn_scan_i8.hip): int8 codes, row stride ld bytes
+    const float* i8_scale;      // ... [rows] per-row scale s_r
+    const uint32_t* qi8;        // ... [nq][2][ld / 4]: the h plane and the l plane of every query (int8, zero padded)
     const QState* retry_state;  // nullable: sweep only the queries whose candidate list overflowed (f32 retry of a bf16 pass)
     const float* norms;      // [rows]
     const float* inv_norms;  // [rows] 1 / |v|, 0 for a zero row (matrix-core cosine sweep)
@@ -115,6 +120,12 @@ hipError_t launch_scan(const ScanParams& p, hipStream_t s);
 hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                             float* row_err2_scratch, uint32_t* err_bits, hipStream_t s);
 bool scan_half_supported(uint32_t ld, int metric);
+// the 8-bit mirror (nmn_scan_i8.hip): 1-2 queries per sweep over int8 codes with a per-row scale
+bool scan_i8_supported(uint32_t ld, uint32_t dim, int metric);
+hipError_t launch_scan_i8(const ScanParams& p, hipStream_t s);
+// quantizes rows [row0, row0+n) into q8 / scale and folds their error norms into err_bits[0..1] (row_err2_scratch: n floats)
+hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+                          float* row_err2_scratch, uint32_t* err_bits, hipStream_t s);
 // one pass over freshly written rows (nmn_ingest.hip): magnitudes in reference order + (half != nullptr) their bf16 mirror
 // rows and the mirror's error norms folded into err_bits[0..1]
 bool ingest_supported(uint32_t ld, uint32_t dim);
@@ -229,9 +240,10 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
                         float* inv_norms, uint32_t* max_norm_bits, hipStream_t s);
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
-                        hipStream_t s, const uint32_t* half_err_bits = nullptr);
-// approx_pass bits: 1 = queries rounded to bf16 (MFMA sweep), 2 = the sweep reads the bf16 mirror of the corpus
-// (half_err_bits = the mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep
+                        hipStream_t s, const uint32_t* half_err_bits = nullptr, uint32_t* qi8 = nullptr);
+// approx_pass bits: 1 = the sweep's copy of the query is rounded (bf16 on the MFMA sweep; with bit 4 the int8 split
+// q = s_q (h + l / 256), written to qi8[q][2][ld] and QInfo.qscale), 2 = the sweep reads a mirror of the corpus
+// (half_err_bits = that mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep
 struct RescoreParams {
     const float* corpus;
     const float* norms;

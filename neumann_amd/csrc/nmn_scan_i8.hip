@@ -1,0 +1,432 @@
+// nmn_scan_i8.hip — the single-query sweep over the shard's 8-BIT mirror: one byte per corpus element instead of the two of
+// the bf16 mirror (nmn_scan.hip) or the four of the f32 corpus.  The sweep is HBM-bound and runs at ~0.95 of what a plain
+// read of the same buffer achieves, so the only lever left on queries/s is the number of bytes a query has to move.
+//
+// Still the reference's answer, bit for bit: the sweep only has to be APPROXIMATELY right.  What it replaces is the per-key
+// loop of vector_engine/src/lib.rs:2115-2228; the scores it produces select candidates, every candidate is re-scored from
+// the f32 corpus in the reference's operation order (nmn_exact.hip; tensor_store/src/hnsw.rs:168-229, lib.rs:2231-2266),
+// and the candidate margin carries the MEASURED error of this representation:
+//   row r is stored as  v_r = s_r * c_r + e_r,  c_r in [-127, 127]^d (int8),  s_r = max_i |v_r[i]| / 127  (f32, per row),
+//   ||e_r|| and ||e_r|| / ||v_r|| are measured while the mirror is written and their maxima kept (q8_err_bits);
+//   the query is split  q = s_q * (h + l / 256) + e_q  with h, l int8 vectors (||e_q|| / ||q|| ~ 3e-5, measured per query),
+//   so the sweep's dot product  s_q s_r (h.c + (l.c) / 256)  is EXACT integer arithmetic (v_dot4_i32_i8: four multiply-adds
+//   per instruction, int32 accumulators) and differs from q.v by at most ||q|| ||v_r|| (rho_q (1 + rho_v) + rho_v).
+// For N(0,1)-like rows of 768 elements rho_v is about 0.009 (bf16 mirror: 0.0015): ~1 000 candidates instead of ~270 at
+// 10M rows, k = 100 — still one rescore launch.  A corpus whose rows are dominated by a few large elements gets a large
+// measured rho_v, overflows the candidate lists, and the shard goes back to the bf16 mirror by itself (nmn_api.hip).
+// Euclidean scores use ||q - v||^2 = ||q||^2 + ||v||^2 - 2 q.v with the stored reference-order magnitudes, margin in squared-
+// distance space exactly as on the matrix-core sweep (qprep_kernel: QInfo.pad < 0).
+//
+// Mapping: the one of scan_kernel — a wave owns whole 64-row tiles, 16 steps x 4 rows, each 16-lane DPP row reads ONE corpus
+// row with 16-byte non-temporal loads (lane j takes chunks j, j + 16, ...; a chunk is 16 elements), row_ror reductions, lane
+// L finishes tile row (L & 15) * 4 + (L >> 4).  Rows of up to 1536 elements keep the query's h / l planes in REGISTERS
+// (8 VGPRs per chunk and lane: 24 at 768, 48 at 1536): no LDS traffic at all in the loop.  Algorithmic bytes per row:
+// dim (+ 4 B scale, 4 B magnitude read, 4 B score written); per launch rows * dim = 7.68 GB at 10M x 768.
+#include <algorithm>
+
+#include "nmn_internal.h"
+
+namespace nmn {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float row16_sum(float v) {  // all-reduce over a 16-lane DPP row (row_ror 8, 4, 2, 1)
+    v += dpp_f<0x128>(v);
+    v += dpp_f<0x124>(v);
+    v += dpp_f<0x122>(v);
+    v += dpp_f<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_u<0x128>(v));
+    v = max(v, dpp_u<0x124>(v));
+    v = max(v, dpp_u<0x122>(v));
+    v = max(v, dpp_u<0x121>(v));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// 16 int8 of a row against 16 int8 of the query's h plane and of its l plane: 8 x v_dot4_i32_i8
+__device__ __forceinline__ void dot16(const v4i x, const v4i qh, const v4i ql, int& hi, int& lo) {
+    hi = __builtin_amdgcn_sdot4(x.x, qh.x, hi, false);
+    lo = __builtin_amdgcn_sdot4(x.x, ql.x, lo, false);
+    hi = __builtin_amdgcn_sdot4(x.y, qh.y, hi, false);
+    lo = __builtin_amdgcn_sdot4(x.y, ql.y, lo, false);
+    hi = __builtin_amdgcn_sdot4(x.z, qh.z, hi, false);
+    lo = __builtin_amdgcn_sdot4(x.z, ql.z, lo, false);
+    hi = __builtin_amdgcn_sdot4(x.w, qh.w, hi, false);
+    lo = __builtin_amdgcn_sdot4(x.w, ql.w, lo, false);
+}
+
+// this lane's share of ONE row against NQ queries: h.c and l.c folded into one float per query, h.c + (l.c) / 256 (both
+// partial sums are far below 2^24: exact conversions, one rounding of 2^-24 relative in the addition)
+// QREG: the query planes of this lane's chunks live in qh / ql; else they are read from the LDS image qs4
+// (query q: h plane at [q * 2 * chunks, +chunks), l plane behind it)
+template <int NQ, int CH, bool SINGLE, bool QREG>
+__device__ __forceinline__ void row_partial_i8(const v4i* __restrict__ rowp, bool active, uint32_t j, uint32_t chunks,
+                                               const v4i* __restrict__ qs4, const v4i (&qh)[QREG ? CH : 1],
+                                               const v4i (&ql)[QREG ? CH : 1], float (&acc)[NQ]) {
+    int hi[NQ], lo[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) hi[q] = lo[q] = 0;
+    if constexpr (SINGLE) {
+        v4i x[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            if (active) x[c] = __builtin_nontemporal_load(rowp + (uint32_t)c * 16u + j);
+            else x[c] = (v4i){0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                if constexpr (QREG) {
+                    dot16(x[c], qh[c], ql[c], hi[q], lo[q]);
+                } else {
+                    const uint32_t col = (uint32_t)c * 16u + j;
+                    dot16(x[c], qs4[(uint32_t)q * 2u * chunks + col], qs4[(uint32_t)q * 2u * chunks + chunks + col], hi[q], lo[q]);
+                }
+            }
+        }
+    } else {
+        for (uint32_t c0 = 0; c0 < chunks; c0 += 16u * CH) {
+            v4i x[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                if (active) x[c] = __builtin_nontemporal_load(rowp + c0 + (uint32_t)c * 16u + j);
+                else x[c] = (v4i){0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const uint32_t col = c0 + (uint32_t)c * 16u + j;
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    dot16(x[c], qs4[(uint32_t)q * 2u * chunks + col], qs4[(uint32_t)q * 2u * chunks + chunks + col], hi[q], lo[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = (float)hi[q] + (float)lo[q] * 0.00390625f;
+}
+
+// Euclidean score from the dot product (as the matrix-core sweep, nmn_scan_mfma.hip: l2_score)
+__device__ __forceinline__ float l2_from_dot(float qq, float vn, float dot, bool neg) {
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, __builtin_fmaf(vn, vn, qq)), 0.0f);
+    const float d = __builtin_amdgcn_sqrtf(d2);
+    return neg ? -d : __builtin_amdgcn_rcpf(1.0f + d);
+}
+
+constexpr uint32_t kCompactMaxRows = 40;  // tiles with at most this many participating rows run compacted steps (nmn_scan.hip)
+
+// METRIC: cosine / Euclidean (also the IVF list scan's -d) / dot.  MASKED: predicate bitmap.  NQ: 1 or 2 queries per sweep.
+// CH: 16-byte loads per lane and row step; SINGLE: the row is exactly 16 * CH chunks (no column loop).
+template <int METRIC, bool MASKED, int NQ, int CH, bool SINGLE>
+__global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) int qsi[];  // [NQ][2][chunks] x 16 B: h plane, l plane of every query
+    constexpr bool QREG = SINGLE && NQ == 1;
+    const uint32_t ld = p.ld, chunks = ld >> 4;
+    const uint32_t q0 = blockIdx.y * NQ;
+    {
+        v4i* qs4w = reinterpret_cast<v4i*>(qsi);
+        const uint32_t per_q = 2u * chunks;
+        for (uint32_t i = threadIdx.x; i < NQ * per_q; i += 256) {
+            const uint32_t q = i / per_q, c = i - q * per_q;
+            v4i v = {0, 0, 0, 0};
+            if (q0 + q < p.nq) v = reinterpret_cast<const v4i*>(p.qi8 + (size_t)(q0 + q) * (ld >> 1))[c];
+            qs4w[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t j = lane & 15u, grp = lane >> 4;
+    const uint32_t t0 = wave * p.tiles_per_wave;
+    if (t0 >= p.n_tiles) return;
+    const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+    const v4i* qs4 = reinterpret_cast<const v4i*>(qsi);
+    const int8_t* const mat = p.corpus_i8;
+
+    v4i qh[QREG ? CH : 1], ql[QREG ? CH : 1];
+    if constexpr (QREG) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            qh[c] = qs4[(uint32_t)c * 16u + j];
+            ql[c] = qs4[chunks + (uint32_t)c * 16u + j];
+        }
+    } else {
+        qh[0] = ql[0] = (v4i){0, 0, 0, 0};
+    }
+
+    float qmag[NQ], qsc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        qmag[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qmag : 0.f;
+        qsc[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qscale : 0.f;
+    }
+    const bool neg = p.metric == kMetricNegL2;
+
+    uint32_t wmax[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) wmax[q] = kKeyMasked;
+
+    uint64_t mcache = 0;
+    for (uint32_t tile = t0; tile < t1; tile++) {
+        const uint64_t r0 = (uint64_t)tile * kTileRows;
+        uint64_t mword = ~0ull;
+        if constexpr (MASKED) {  // the wave's bitmap words, 64 tiles at a time (as scan_kernel)
+            const uint32_t rel = tile - t0;
+            if ((rel & 63u) == 0) mcache = tile + lane < t1 ? p.mask[tile + lane] : 0ull;
+            const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)(rel & 63u));
+            const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)(rel & 63u));
+            mword = ((uint64_t)hi << 32) | lo;
+        }
+        {
+            const uint64_t left = p.n_rows - r0;
+            if (left < 64) mword &= (1ull << left) - 1ull;
+        }
+        if constexpr (MASKED) {
+            if (mword == 0ull) {  // nobody of this tile takes part: its maximum says so, which is all anybody reads of it
+                if (lane < (uint32_t)NQ && q0 + lane < p.nq) p.tmax[(uint64_t)(q0 + lane) * p.tmax_stride + tile] = kKeyMasked;
+                continue;
+            }
+        }
+        float mydot[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
+
+        bool compacted = false;
+        if constexpr (MASKED) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(mword);
+            if (cnt <= kCompactMaxRows) {  // wave-uniform: sparse tile, every step reads 4 participating rows
+                compacted = true;
+                float* stg = reinterpret_cast<float*>(qsi + (size_t)NQ * (ld >> 1)) + (threadIdx.x >> 6) * (NQ * 64);
+                uint32_t* tab = reinterpret_cast<uint32_t*>(qsi + (size_t)NQ * (ld >> 1) + 4 * (NQ * 64)) + (threadIdx.x >> 6) * 64;
+                const bool myset = ((mword >> lane) & 1ull) != 0;
+                const uint32_t myrank = (uint32_t)__builtin_popcountll(mword & ((1ull << lane) - 1ull));
+                if (myset) tab[myrank] = lane;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t s0 = 0; s0 < cnt; s0 += 4u) {
+                    const bool active = s0 + grp < cnt;
+                    const uint32_t pos = active ? tab[s0 + grp] : 0u;
+                    const v4i* rowp = reinterpret_cast<const v4i*>(mat + (r0 + pos) * (uint64_t)ld);
+                    float acc[NQ];
+                    row_partial_i8<NQ, CH, SINGLE, QREG>(rowp, active, j, chunks, qs4, qh, ql, acc);
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const float t = row16_sum(acc[q]);
+                        if (j == 0 && active) stg[q * 64 + (int)pos] = t;
+                    }
+                }
+                const uint32_t bit = j * 4u + grp;
+                if ((mword >> bit) & 1ull) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) mydot[q] = stg[q * 64 + (int)bit];
+                }
+            }
+        }
+        if (!compacted) {
+            constexpr int kSteps = CH <= 3 ? 4 : 2;  // row steps whose loads are in flight together (>= 6 x 16 B per lane)
+#pragma unroll kSteps
+            for (uint32_t s = 0; s < 16; s++) {
+                if constexpr (MASKED) {
+                    if (((mword >> (s * 4)) & 0xFull) == 0) continue;  // wave-uniform: 4 rows all excluded
+                }
+                const uint32_t rbit = s * 4 + grp;
+                const bool active = MASKED ? ((mword >> rbit) & 1ull) != 0 : true;
+                const v4i* rowp = reinterpret_cast<const v4i*>(mat + (r0 + rbit) * (uint64_t)ld);
+                float acc[NQ];
+                row_partial_i8<NQ, CH, SINGLE, QREG>(rowp, active, j, chunks, qs4, qh, ql, acc);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const float t = row16_sum(acc[q]);
+                    if (j == s) mydot[q] = t;
+                }
+            }
+        }
+
+        // lane L finishes tile row (L & 15) * 4 + (L >> 4)
+        const uint32_t mybit = j * 4u + grp;
+        const bool valid = ((mword >> mybit) & 1ull) != 0;
+        const uint64_t myrow = r0 + mybit;
+        const float sr = valid ? p.i8_scale[myrow] : 0.f;
+        float vn = 1.f;
+        if constexpr (METRIC != NMN_METRIC_DOT_PRODUCT) vn = valid ? p.norms[myrow] : 1.f;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (q0 + q >= p.nq) break;
+            const float dot = mydot[q] * (qsc[q] * sr);
+            float sc;
+            if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
+            else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_from_dot(qmag[q] * qmag[q], vn, dot, neg);
+            else sc = dot;
+            const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
+            p.scores[score_at(myrow, q0 + q, p.nql)] = valid ? f2u(sc) : kScoreSentinelBits;
+            const uint32_t m = wave_max_u32(key);
+            if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tile] = m;
+            wmax[q] = max(wmax[q], m);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            if (q0 + q < p.nq) p.wmax[(size_t)(q0 + q) * p.wmax_stride + wave] = wmax[q];
+    }
+}
+
+template <int METRIC, bool MASKED, int NQ, int CH, bool SINGLE>
+hipError_t launch_one(const ScanParams& p, hipStream_t s) {
+    const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
+    // query planes (2 bytes per element), plus (masked) the per-wave staging arrays and rank tables of the compacted tiles
+    const size_t lds = (size_t)NQ * p.ld * 2 + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) : 0);
+    auto kern = scan_i8_kernel<METRIC, MASKED, NQ, CH, SINGLE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int METRIC, bool MASKED, int NQ>
+hipError_t launch_layout(const ScanParams& p, hipStream_t s) {
+    switch (p.ld >> 8) {  // chunks / 16 = 256-element groups per row
+        case 1: return launch_one<METRIC, MASKED, NQ, 1, true>(p, s);
+        case 2: return launch_one<METRIC, MASKED, NQ, 2, true>(p, s);
+        case 3: return launch_one<METRIC, MASKED, NQ, 3, true>(p, s);
+        case 4: return launch_one<METRIC, MASKED, NQ, 4, true>(p, s);
+        case 5: return launch_one<METRIC, MASKED, NQ, 5, true>(p, s);
+        case 6: return launch_one<METRIC, MASKED, NQ, 6, true>(p, s);
+        default: break;
+    }
+    if ((p.ld >> 8) % 6 == 0) return launch_one<METRIC, MASKED, NQ, 6, false>(p, s);
+    if ((p.ld >> 8) % 4 == 0) return launch_one<METRIC, MASKED, NQ, 4, false>(p, s);
+    return launch_one<METRIC, MASKED, NQ, 1, false>(p, s);
+}
+
+template <int METRIC>
+hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
+    if (p.mask) return p.nq >= 2 ? launch_layout<METRIC, true, 2>(p, s) : launch_layout<METRIC, true, 1>(p, s);
+    return p.nq >= 2 ? launch_layout<METRIC, false, 2>(p, s) : launch_layout<METRIC, false, 1>(p, s);
+}
+
+// ---- writing the mirror -----------------------------------------------------------------------------------------------
+// `lpr` lanes (a power of two <= 64) share one row: pass 1 finds max |v| (the row's scale), pass 2 re-reads the row (it is
+// in L2), rounds v / s to the nearest integer in [-127, 127], accumulates |v - s c|^2 and stores 8 codes per 8 elements.
+// A row with a non-finite element gets scale 0 / codes 0 and an infinite error norm: its shard's margin becomes useless,
+// every query overflows into the f32 retry and the shard leaves the mirror alone (nmn_api.hip) — never a wrong answer.
+__global__ void __launch_bounds__(256) q8_rows_kernel(const float* __restrict__ corpus, int8_t* __restrict__ q8, float* __restrict__ scale,
+                                                      uint32_t ld, uint64_t row0, uint64_t n, float* __restrict__ row_err2, uint32_t lpr) {
+    const uint32_t per_row = ld >> 3;  // 8-element groups per row
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & (lpr - 1u), slot = lane / lpr, rows_per_wave = 64u / lpr;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t rb = wave * rows_per_wave; rb < n; rb += n_waves * rows_per_wave) {
+        const uint64_t ri = rb + slot;
+        const bool live = ri < n;
+        const uint64_t r = row0 + (live ? ri : 0);
+        float mx = 0.f;
+        bool bad = false;
+        for (uint32_t g = sub; live && g < per_row; g += lpr) {
+            const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
+            const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const float ax = __builtin_fabsf(x[t]);
+                bad = bad || !(ax <= 3.0e38f);  // inf or NaN
+                mx = __builtin_fmaxf(mx, ax);
+            }
+        }
+        for (uint32_t off = lpr >> 1; off > 0; off >>= 1) {
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, (int)off));
+            bad = bad || (__shfl_xor((int)bad, (int)off) != 0);
+        }
+        const float s = (bad || mx == 0.f) ? 0.f : mx / 127.0f;
+        const float inv = s > 0.f ? 127.0f / mx : 0.f;
+        float err2 = 0.f;
+        for (uint32_t g = sub; live && g < per_row; g += lpr) {
+            const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
+            const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                float c = __builtin_rintf(x[t] * inv);
+                c = __builtin_fminf(__builtin_fmaxf(c, -127.0f), 127.0f);
+                if (!(c == c)) c = 0.f;
+                const float e = x[t] - s * c;
+                err2 = __builtin_fmaf(e, e, err2);
+                pk[t >> 2] |= ((uint32_t)(int)c & 0xFFu) << (8 * (t & 3));
+            }
+            *reinterpret_cast<uint2*>(q8 + r * (uint64_t)ld + g * 8u) = make_uint2(pk[0], pk[1]);
+        }
+        for (uint32_t off = lpr >> 1; off > 0; off >>= 1) err2 += __shfl_xor(err2, (int)off);
+        if (live && sub == 0) {
+            scale[r] = s;
+            row_err2[ri] = bad ? __builtin_inff() : err2;
+        }
+    }
+}
+
+// err_bits[0] = max_r |e_r|, err_bits[1] = max_r |e_r| / |v_r| (with slack for the order of the f32 sums that produced them)
+__global__ void __launch_bounds__(256) q8_err_kernel(const float* __restrict__ row_err2, const float* __restrict__ norms, uint64_t row0,
+                                                     uint64_t n, uint32_t* __restrict__ err_bits) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float e = __builtin_sqrtf(row_err2[i]) * 1.0005f;
+        const float vn = norms[row0 + i];
+        if (e > 0.f) {  // (+inf included; e >= 0: bit order == value order)
+            atomicMax(err_bits, __float_as_uint(e));
+            if (vn > 0.f || !(vn == vn)) {
+                float rel = e / vn * 1.0005f;
+                if (!(rel == rel)) rel = __builtin_inff();  // a non-finite row (inf / inf): no margin vouches for it
+                atomicMax(err_bits + 1, __float_as_uint(rel));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool scan_i8_supported(uint32_t ld, uint32_t dim, int metric) {
+    (void)dim;
+    // rows of whole 256-element groups (one 16-byte chunk per lane of a 16-lane row group), up to the 4096 of the widest sweep
+    if (ld == 0 || ld % 256u != 0 || ld > 4096u) return false;
+    return metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2;
+}
+
+hipError_t launch_scan_i8(const ScanParams& p, hipStream_t s) {
+    switch (p.metric) {
+        case NMN_METRIC_COSINE: return launch_metric<NMN_METRIC_COSINE>(p, s);
+        case NMN_METRIC_EUCLIDEAN:
+        case kMetricNegL2: return launch_metric<NMN_METRIC_EUCLIDEAN>(p, s);
+        default: return launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+    }
+}
+
+hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+                          float* row_err2_scratch, uint32_t* err_bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t lpr = 1;
+    while (lpr < 64u && lpr < (ld >> 3)) lpr <<= 1;
+    hipLaunchKernelGGL(q8_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, q8, scale, ld, row0, n, row_err2_scratch, lpr);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(q8_err_kernel, dim3(blocks), dim3(256), 0, s, row_err2_scratch, norms, row0, n, err_bits);
+    return hipGetLastError();
+}
+
+}  // namespace nmn

@@ -590,6 +590,11 @@ extern "C" uint64_t nmn_sharded_rows(const nmn_sharded* s) {
         for (nmn_index* i : s->shard) n += nmn_index_rows(i);
     return n;
 }
+extern "C" uint64_t nmn_sharded_global_row(const nmn_sharded* s, uint32_t g, uint64_t local_row) {
+    if (!s || g >= s->n_shards) return UINT64_MAX;
+    if (s->cyclic) return s->row_base + (((local_row >> 6) * s->n_shards + g) << 6) + (local_row & 63ull);
+    return nmn_index_row_base(s->shard[g]) + local_row;
+}
 extern "C" uint32_t nmn_sharded_rccl_ranks(const nmn_sharded* s) { return s ? s->rccl_ranks : 0; }
 extern "C" uint32_t nmn_sharded_layout(const nmn_sharded* s) { return (s && s->cyclic) ? NMN_SHARDED_LAYOUT_CYCLIC : NMN_SHARDED_LAYOUT_RANGES; }
 

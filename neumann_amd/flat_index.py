@@ -64,8 +64,23 @@ class GpuFlatIndex:
         self.row_base = int(self._lib.nmn_index_row_base(self._h))
         return self
 
+    @classmethod
+    def _view(cls, handle, owner):
+        """A non-owning face of a shard some other object owns (nmn_sharded_shard): close() leaves the handle alone."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        self._h = C.c_void_p(handle)
+        self._owner = owner
+        self.dim = int(self._lib.nmn_index_dim(self._h))
+        self.capacity_rows = self.rows
+        self.row_base = int(self._lib.nmn_index_row_base(self._h))
+        return self
+
     # -- lifecycle --------------------------------------------------------------------------
     def close(self):
+        if getattr(self, "_owner", None) is not None:
+            self._h = C.c_void_p()
+            return
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.nmn_index_destroy(self._h)
             self._h = C.c_void_p()
@@ -215,8 +230,10 @@ class GpuFlatIndex:
         return rows, scores, counts
 
     def set_mirror(self, enabled):
-        """False: approximate sweeps read the f32 corpus (rows*dim*4 bytes per query) instead of its bf16 mirror."""
-        _capi.check(self._lib.nmn_index_set_mirror(self._h, 1 if enabled else 0))
+        """What approximate sweeps read.  True / 1 (default): the smallest mirror that serves the shape — the 8-bit mirror for
+        1-2 queries over rows of whole 256-element groups, else the bf16 mirror.  2: the bf16 mirror only.  False / 0: the
+        f32 corpus itself (rows*dim*4 bytes per query, SURVEY §8(d)'s pricing).  Results are identical in every mode."""
+        _capi.check(self._lib.nmn_index_set_mirror(self._h, int(enabled)))
 
     def set_timing(self, enabled):
         _capi.check(self._lib.nmn_index_set_timing(self._h, 1 if enabled else 0))

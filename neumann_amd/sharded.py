@@ -92,6 +92,14 @@ class GpuShardedIndex:
     def shard_rows(self, shard):
         return int(self._lib.nmn_index_rows(self._lib.nmn_sharded_shard(self._h, int(shard))))
 
+    def shard(self, g):
+        """Shard g as a GpuFlatIndex VIEW (the handle stays owned by this object): its exact helpers (score_rows,
+        count_exact) serve certificates over a sharded corpus."""
+        return flat_index.GpuFlatIndex._view(self._lib.nmn_sharded_shard(self._h, int(g)), self)
+
+    def global_row(self, shard, local_row):
+        return int(self._lib.nmn_sharded_global_row(self._h, int(shard), int(local_row)))
+
     def upload(self, rows, row0=None):
         import ctypes as C
         from . import _capi
@@ -207,8 +215,23 @@ class ShardedSearcher:
                                  out=(b["rows"], b["scores"], b["counts"]))
         if self.world_size == 1 and not self.always_gather:
             return b["rows"], b["scores"], b["counts"]
+        return self.gather_merge()
+
+    def gather_merge(self):
+        """The collective step on its own: all-gather of this rank's packed block (whatever the last search left in it),
+        then the device merge.  RCCL (backend "nccl") moves the device buffers directly; under "gloo" — the control-flow
+        check of the N > 1 path with every rank on ONE GPU, where RCCL refuses to run — the blocks are staged through the host."""
+        import torch
         import torch.distributed as dist
-        dist.all_gather_into_tensor(b["gathered"], b["block"], group=self.group)
+        b = self._bufs
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(b["gathered"], b["block"], group=self.group)
+        else:
+            torch.cuda.current_stream().synchronize()
+            mine = b["block"].cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(parts, mine, group=self.group)
+            b["gathered"].copy_(torch.cat(parts), non_blocking=False)
         return flat_index.merge_topk_device_packed(b["gathered"], self.world_size, self.nq, self.k, out=b["out"])
 
     # ---- host path (gloo tests, router-side merge) -----------------------------------------------

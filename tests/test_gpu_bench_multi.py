@@ -1,0 +1,49 @@
+"""bench.py's N > 1 path end to end on ONE GPU: plain `python bench.py --gpus 2` — no torchrun — must start
+two ranks itself, shard the corpus by row range, all-gather rank ids and top-k blocks, merge, certify, and say n_gpus == 2.
+RCCL refuses two ranks on one device, so the ranks are pinned to device 0 and the collective runs over gloo (staged through
+the host): the launcher, the rendezvous, the sharding, the packed gather + device merge and the certificate are the real
+ones; the xGMI transport is the driver's 8-GPU run.  The one-process handle leg runs too (logical shards on device 0)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plain_bench_gpus_2_starts_two_ranks_and_certifies():
+    env = dict(os.environ, NMN_BENCH_DEVICE="0", NMN_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--rows", "300000", "--rebuilds", "2"], capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6 and d["warmup"] == 2
+    assert d["config"]["rows_total"] == 600000 and d["config"]["rows_per_gpu"] == 300000
+    m = d["multi_gpu"]
+    assert m["ranks"] == 2 and m["rows_per_gpu"] == [300000, 300000] and m["gather_plus_merge_ms"] > 0
+    assert m["rccl_ranks"] == 0 and m["collective_backend"] == "gloo"   # (2 under RCCL: one rank per device)
+    assert d["parity"]["exact_topk_certified"] is True and d["parity"]["returned"] == 100
+    assert len(d["rebuilds"]["queries_per_s"]) == 2 and d["value"] > 0
+    h = m["one_process_handle"]
+    assert "error" not in h, h
+    assert h["rows_per_gpu"] == [300000, 300000] and h["exact_topk_certified"] is True and h["gather"] == "peer copies"
+
+
+def test_strong_scaling_splits_the_rows():
+    env = dict(os.environ, NMN_BENCH_DEVICE="0", NMN_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1",
+                        "--rows", "200000", "--rebuilds", "1", "--scaling", "strong", "--no-handle-leg"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["rows_total"] == 200000
+    assert d["multi_gpu"]["rows_per_gpu"] == [66667, 66667, 66666] and d["parity"]["exact_topk_certified"] is True

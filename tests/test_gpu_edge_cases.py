@@ -1,6 +1,7 @@
 """GPU edge cases of the SIMILAR TOP-K path through the C ABI: ties, duplicates, the exact-fallback
 path, n<k, empty shards, k=NMN_MAX_TOP_K, multi-query batches, tile-threshold mode, error codes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -448,3 +449,36 @@ def test_large_shard_exact_fallback_uses_the_device_wide_select(metric):
         for qi in range(3):
             er, es = oc.search(A, Q[qi], 300, metric, nthreads=8, partial=True, native=True)
             assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es), qi
+
+
+def test_device_wide_select_gives_up_its_barrier_instead_of_hanging():
+    """fallback_select_kernel's grid barrier is a bounded wait (nothing but an idle device guarantees that the 64
+    workgroups of several concurrent launches are all resident).  With NMN_FB_TIMEOUT_TICKS=1 every barrier wait that is not
+    satisfied at its first look runs out of patience: the launch raises its abort flag, the flagged query keeps
+    overflow == 1 and final_kernel selects it with one workgroup — the same answer, and the next search (counters zeroed
+    by select_kernel) is not disturbed by the aborted one.  Runs in a child process: the knob is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from oracle import oracle_c as oc
+from neumann_amd import GpuFlatIndex
+n, d = 300_000, 32
+A = np.tile(np.linspace(-1, 1, d, dtype=np.float32), (n, 1))
+q = np.linspace(1, 2, d, dtype=np.float32)
+with GpuFlatIndex(d, n) as idx:
+    idx.upload(A)
+    for rep in range(3):
+        for metric in (0, 1, 2):
+            rows, scores, counts, st = idx.search(q, 10, metric, with_stats=True)
+            er, es = oc.search(A, q, 10, metric, nthreads=8, partial=True, native=True)
+            assert st.fallback_queries == 1
+            assert np.array_equal(rows[0], er) and np.all(scores[0] == es), (rep, metric)
+    rows, _, _ = idx.search(q, 6000, 0)    # large-k path: cooperative launch (or the full sort), same list
+    assert list(rows[0]) == list(range(6000))
+print("ok")
+'''
+    env = dict(os.environ, NMN_FB_TIMEOUT_TICKS="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

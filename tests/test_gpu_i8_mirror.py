@@ -1,0 +1,189 @@
+"""The 8-bit mirror (neumann_amd/csrc/nmn_scan_i8.hip): sweeps of 1-2 queries read int8 codes with a scale per row — one
+byte per corpus element — and the answer must still be the reference's, bit for bit: rows identical to the oracle's
+(vector_engine/src/lib.rs:1950-2101 restated in oracle/nmn_oracle.c), scores equal as u32 bits.  What makes that true is
+the measured quantization error in the candidate margin plus the exact rescore; what these tests attack is exactly that:
+every supported row length and metric, bitmaps dense and sparse, near-ties and duplicates around the cut, rows the
+quantization serves badly (one huge element: the margin becomes useless and the sweep must notice), non-finite rows,
+overwrites and appends after the mirror exists."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def check(idx, A, Q, k, metric, mask=None, expect_bytes=None):
+    Q = np.atleast_2d(Q)
+    rows, scores, counts, stats = idx.search(Q, k, metric, mask=mask, with_stats=True)
+    for qi in range(Q.shape[0]):
+        er, es = oc.search(A, Q[qi], k, metric, mask=mask, nthreads=8, partial=True, native=True)
+        c = er.size
+        assert counts[qi] == c, (qi, counts[qi], c)
+        assert np.array_equal(rows[qi, :c], er), (metric, qi, rows[qi, :8], er[:8])
+        assert np.array_equal(scores[qi, :c].view(np.uint32), es.view(np.uint32)), (metric, qi)
+        assert np.all(rows[qi, c:] == U64_MAX) and np.all(np.isneginf(scores[qi, c:]))
+    if expect_bytes is not None:
+        assert stats.bytes_scanned == stats.rows_scanned * A.shape[1] * expect_bytes, (stats.bytes_scanned, stats.rows_scanned)
+    return stats
+
+
+@pytest.mark.parametrize("d", [256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096])
+def test_every_supported_row_length_matches_the_oracle(d):
+    from neumann_amd import GpuFlatIndex
+    n = 70_000 if d <= 1536 else 20_000
+    A = oc.synth(0x18 + d, 0, n, d, nthreads=8)
+    Q = oc.synth(0x19 + d, 0, 2, d)
+    with GpuFlatIndex(d, n, single_launch=False) as idx:
+        idx.upload(A)
+        for metric in (0, 1, 2):
+            check(idx, A, Q[0], 100, metric, expect_bytes=1)       # one query
+            check(idx, A, Q, 37, metric, expect_bytes=1)           # two per sweep
+        keep = np.random.default_rng(d).random(n) < 0.5
+        check(idx, A, Q[0], 100, 0, mask=oc.mask_from_bool(keep), expect_bytes=1)
+        keep = np.random.default_rng(d + 1).random(n) < 0.04       # sparse tiles: compacted steps
+        check(idx, A, Q, 50, 1, mask=oc.mask_from_bool(keep), expect_bytes=1)
+
+
+def test_mirror_modes_read_1_2_and_4_bytes_per_element_and_agree():
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 150_000, 768, 100
+    A = oc.synth(0x21, 0, n, d, nthreads=8)
+    q = oc.synth(0x22, 0, 1, d)[0]
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(0x21, n)
+        got = {}
+        for mode, nbytes in ((1, 1), (2, 2), (0, 4), (1, 1)):
+            idx.set_mirror(mode)
+            st = check(idx, A, q, k, 0, expect_bytes=nbytes)
+            got[mode] = idx.search(q, k, 0)
+        for mode in (2, 0):
+            assert np.array_equal(got[mode][0], got[1][0]) and np.array_equal(got[mode][1].view(np.uint32), got[1][1].view(np.uint32))
+        # a 3-query batch is the matrix-core sweep's (bf16 mirror), a row length outside the 256-element groups the bf16 VALU sweep's
+        idx.set_mirror(1)
+        Q3 = oc.synth(0x23, 0, 3, d)
+        check(idx, A, Q3, k, 0, expect_bytes=2)
+    with GpuFlatIndex(320, 80_000, single_launch=False) as idx:
+        B = oc.synth(0x24, 0, 80_000, 320, nthreads=8)
+        idx.upload(B)
+        check(idx, B, oc.synth(0x25, 0, 1, 320)[0], 10, 0, expect_bytes=2)
+
+
+def test_planted_near_ties_and_duplicates_around_the_cut():
+    """rows within a few ulps of each other around rank k, and exact copies straddling it: the order must be the oracle's
+    (score descending, row ascending) although the 8-bit sweep cannot tell any of them apart"""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 120_000, 768, 64
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    near = np.flatnonzero(rng.random(n) < 0.001)[:90]
+    for t, r in enumerate(near):                       # 90 rows close to the query, differing in the last bits
+        A[r] = q * np.float32(1.0 + 1e-7 * (t % 5)) + np.float32(1e-4) * rng.standard_normal(d).astype(np.float32) * np.float32(t % 3 == 0)
+    A[near[10]] = A[near[3]]
+    A[near[40]] = A[near[3]]                           # exact copies: ties by row id
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for metric in (0, 1, 2):
+            for kk in (k, 89, 90, 91, 500):
+                check(idx, A, q, kk, metric, expect_bytes=1)
+
+
+def test_rows_the_quantization_serves_badly():
+    """Every row carries one element 1000x the others: the per-row scale is set by it, the other 255 elements round to 0 or
+    +-1 and the measured relative error is several per cent — the margin admits ~10 000 rows, far beyond cand_cap.  The
+    crowd list takes them (a crowd, not a useless margin: well under an eighth of the shard); the answer is the oracle's."""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 300_000, 256, 20
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[np.arange(n), rng.integers(0, d, n)] *= np.float32(1000.0)
+    Q = rng.standard_normal((6, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for i in range(6):
+            for metric in (0, 1, 2):
+                check(idx, A, Q[i], k, metric)
+
+
+def test_the_8_bit_mirror_switches_itself_off_when_its_margin_is_useless():
+    """All rows point the same way (a common vector plus 5 % noise): cosine scores differ in the third decimal.  The bf16
+    mirror's measured error (~0.0015) still separates them; the 8-bit mirror's (~0.01) puts EVERY row within the margin —
+    not a crowd but a useless margin: each query is re-swept in f32 (and is still exact).  After enough of those the shard
+    leaves the 8-bit mirror alone: its sweeps read 2 bytes per element again."""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 300_000, 256, 20
+    rng = np.random.default_rng(10)
+    c = rng.standard_normal(d).astype(np.float32)
+    A = (c[None, :] + np.float32(0.05) * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    Q = rng.standard_normal((6, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        st = check(idx, A, Q[0], k, 0, expect_bytes=1)
+        for i in range(6):
+            check(idx, A, Q[i], k, 0)
+            check(idx, A, Q[i], k, 2)
+        for i in range(300):                           # the switch looks at its counters every 256th call
+            idx.search(Q[i % 6], k, 0)
+        st = check(idx, A, Q[0], k, 0)
+        assert st.bytes_scanned == st.rows_scanned * d * 2, "the shard should have left the 8-bit mirror alone by now"
+
+
+def test_non_finite_rows_and_queries():
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 90_000, 512, 30
+    rng = np.random.default_rng(13)
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    A[1234, 7] = np.inf
+    A[40_000, 100] = -np.inf
+    q = np.abs(rng.standard_normal(d)).astype(np.float32)
+    with GpuFlatIndex(d, n, single_launch=False) as idx:
+        idx.upload(A)
+        rows, scores, counts = idx.search(q, k, 2)     # dot product: row 1234 scores +inf and must come first
+        er, es = oc.search(A, q, k, 2)
+        assert np.array_equal(rows[0], er) and np.array_equal(scores[0].view(np.uint32), es.view(np.uint32))
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    with GpuFlatIndex(d, n, single_launch=False) as idx:
+        idx.upload(A)
+        qbad = q.copy()
+        qbad[3] = np.inf
+        rows, scores, counts = idx.search(qbad, k, 1)  # Euclidean: every distance is inf, score 0 — ties by row id
+        er, es = oc.search(A, qbad, k, 1)
+        assert np.array_equal(rows[0], er) and np.array_equal(scores[0].view(np.uint32), es.view(np.uint32))
+        check(idx, A, q, k, 0, expect_bytes=1)
+
+
+def test_overwrites_and_appends_after_the_mirror_exists():
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 100_000, 768, 40
+    rng = np.random.default_rng(21)
+    A = rng.standard_normal((n + 5000, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    with GpuFlatIndex(d, n + 5000, single_launch=False) as idx:
+        idx.upload(A[:n])
+        check(idx, A[:n], q, k, 0, expect_bytes=1)                 # builds the 8-bit mirror
+        A[777] = q * np.float32(3.0)                               # set_row: a new best row
+        idx.set_row(777, A[777])
+        A[5000:5200] = rng.standard_normal((200, d)).astype(np.float32) + q * np.float32(0.5)
+        idx.upload(A[5000:5200], row0=5000)                        # overwrite a run of rows
+        for metric in (0, 1, 2):
+            check(idx, A[:n], q, k, metric, expect_bytes=1)
+        A[n:n + 5000] = rng.standard_normal((5000, d)).astype(np.float32) + q * np.float32(0.2)
+        idx.upload(A[n:n + 5000], row0=n)                          # append: the mirror is extended at the next search
+        for metric in (0, 1, 2):
+            check(idx, A, q, k, metric, expect_bytes=1)
+
+
+def test_k_1000_euclidean_with_masks_like_config_5():
+    """config 5's shape at 1/50 scale: 1536-element rows, L2, TOP-1000, bitmaps of selectivity 1.0 / 0.5 / 0.1"""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 200_000, 1536, 1000
+    A = oc.synth(0x5EED0005, 0, n, d, nthreads=8)
+    q = oc.synth(0x5EED0002, 0, 1, d)[0]
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(0x5EED0005, n)
+        check(idx, A, q, k, 1, expect_bytes=1)
+        for sel in (0.5, 0.1, 0.01):
+            keep = np.random.default_rng(int(sel * 100)).random(n) < sel
+            check(idx, A, q, k, 1, mask=oc.mask_from_bool(keep), expect_bytes=1)
