@@ -452,7 +452,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->half_scratch) (void)hipFree(idx->half_scratch);
     if (idx->half_stats) (void)hipFree(idx->half_stats);
-    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_err_bits, (void*)idx->q8_stats})
+    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_vv, (void*)idx->q8_err_bits, (void*)idx->q8_stats})
         if (p) (void)hipFree(p);
     if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
     if (idx->norms) (void)hipFree(idx->norms);
@@ -525,10 +525,13 @@ static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
     if (idx->q8 || idx->q8_failed) return NMN_OK;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->q8), (size_t)idx->cap_pad * idx->ld);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_scale), (size_t)idx->cap_pad * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_vv), (size_t)idx->cap_pad * 4);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (idx->q8) (void)hipFree(idx->q8);
+        if (idx->q8_scale) (void)hipFree(idx->q8_scale);
         idx->q8 = nullptr;
+        idx->q8_scale = nullptr;
         idx->q8_failed = true;
         return NMN_OK;
     }
@@ -539,6 +542,7 @@ static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(idx->q8_stats, 0, 8, stream));
     HIP_TRY(hipMemsetAsync(idx->q8, 0, (size_t)idx->cap_pad * idx->ld, stream));
     HIP_TRY(hipMemsetAsync(idx->q8_scale, 0, (size_t)idx->cap_pad * 4, stream));
+    HIP_TRY(hipMemsetAsync(idx->q8_vv, 0, (size_t)idx->cap_pad * 4, stream));
     return NMN_OK;
 }
 
@@ -548,7 +552,7 @@ static nmn_status q8_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_
     const uint64_t cnt = std::min(row0 + n, idx->q8_rows) - row0;
     float* scratch = nullptr;
     HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-    HIP_TRY(launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->ld, row0, cnt, idx->norms, scratch, idx->q8_err_bits, stream));
+    HIP_TRY(launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->ld, row0, cnt, idx->norms, scratch, idx->q8_err_bits, stream));
     if (idx->half_scratch_cap > (1u << 20)) {
         HIP_TRY(hipStreamSynchronize(stream));
         half_scratch_trim(idx);
@@ -839,7 +843,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 const uint64_t cnt = n_rows - idx->q8_rows;
                 float* scratch = nullptr;
                 HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
+                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
                                                idx->q8_err_bits, stream);
                 if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // (as for the bf16 mirror: other streams may rely on it from now on)
                 half_scratch_trim(idx);
@@ -875,6 +879,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.corpus_half = use_half ? idx->half : nullptr;
             sp.corpus_i8 = use_i8 ? idx->q8 : nullptr;
             sp.i8_scale = idx->q8_scale;
+            sp.i8_vv = idx->q8_vv;
             sp.qi8 = w->qi8;
             sp.norms = idx->norms;
             sp.inv_norms = idx->inv_norms;

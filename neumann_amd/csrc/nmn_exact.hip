@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
     const float ss = dot8_group<32>(src, src, dim, threadIdx.x & 7u);
     // MFMA sweep: the stationary copy of this query is bf16 — its rounding error |q - bf16(q)| goes into the margin
     float qerr2 = 0.0f;
-    float qscale = 0.0f;
+    float qscale = 0.0f, qq8 = 0.0f;
     if ((mfma_pass & 4) && qi8) {
         // 8-bit sweep (nmn_scan_i8.hip): q = s_q (h + l / 256) + e_q with int8 vectors h, l; the planes go to qi8[q][2][ld]
         // (zero beyond dim), |e_q| into the margin exactly like the bf16 rounding of the matrix-core sweep's queries
@@ -229,15 +229,20 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                 const float t = src[i] * inv;
                 h = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(t), -127.0f), 127.0f);
                 l = __builtin_fminf(__builtin_fmaxf(__builtin_rintf((t - h) * 256.0f), -127.0f), 127.0f);
-                const float e = src[i] - qscale * (h + l * 0.00390625f);
+                const float qt = qscale * (h + l * 0.00390625f);
+                const float e = src[i] - qt;
                 qerr2 = qerr2 + e * e;
+                qq8 = qq8 + qt * qt;
             } else if (i < dim) {
                 qerr2 = bad ? __builtin_inff() : qerr2;  // a non-finite query: infinite margin, the exact paths answer
             }
             hp[i] = (int8_t)(int)h;
             lp[i] = (int8_t)(int)l;
         }
-        for (int off = 32; off > 0; off >>= 1) qerr2 = qerr2 + __shfl_down(qerr2, off);
+        for (int off = 32; off > 0; off >>= 1) {
+            qerr2 = qerr2 + __shfl_down(qerr2, off);
+            qq8 = qq8 + __shfl_down(qq8, off);
+        }
     } else if (mfma_pass & 1) {
         for (uint32_t i = threadIdx.x; i < dim; i += 64) {
             const float x = src[i];
@@ -256,7 +261,9 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         qi.qmag = qmag;
         qi.pad = 0.f;
         qi.qscale = qscale;
-        qi.rsv[0] = qi.rsv[1] = qi.rsv[2] = 0.f;
+        qi.qq8 = qq8;
+        qi.pad_sq = 0.f;
+        qi.neg_d = 0.f;
         // What the approximate sweep adds on top of f32 summation error, relative to |q||v|.  The margin is applied ONCE
         // below the k-th approximate score and must cover the error twice (k rows with approx >= T have exact >= T - e, so
         // the exact k-th is >= T - e, and a row with exact >= T - e has approx >= T - 2e).
@@ -284,7 +291,21 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         } else {
             qi.margin_abs = 0.0f;
             qi.margin_rel = 4.0f * (dd + 8.0f) * u;
-            if ((mfma_pass & 1) && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) {
+            if ((mfma_pass & 4) && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) {
+                // 8-bit sweep: d~ = |q~ - v~| computed from the stored representations themselves, so |d~ - d| <= |e_q| + |e_r|
+                // (triangle inequality): an ABSOLUTE error of the DISTANCE, twice as always -> pad.  What the f32 evaluation of
+                // |q~|^2 + |v~|^2 - 2 q~.v~ adds (|q~|^2 summed by 64 lanes: (d/64 + 8) u; |v~|^2 = s^2 * an exact integer: 3 u; the
+                // dot product s_q s_r (h.c + l.c / 256): 4 u; the two additions: 2 u of the larger operand) is bounded in
+                // squared-distance space, also twice -> pad_sq; V~ <= V + E.
+                const float V = u2f(*max_norm_bits);
+                const float E = half_err_bits ? u2f(half_err_bits[0]) : 3.95e-03f * V;
+                const float eq = __builtin_sqrtf(qerr2) * 1.0005f;
+                const float Vt = V + E, qt = qmag + eq;
+                qi.pad = 2.0f * 1.001f * (E + eq);
+                qi.pad_sq = 2.0f * ((dd * 0.015625f + 16.0f) * u) * (qt + Vt) * (qt + Vt);
+                qi.margin_rel = 16.0f * u;  // v_sqrt, v_rcp and the arithmetic of margin_key itself
+                qi.neg_d = metric == kMetricNegL2 ? 1.0f : 0.0f;
+            } else if ((mfma_pass & 1) && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) {
                 // Matrix-core sweep: d~^2 = |q|^2 + |v|^2 - 2 q~.v~ with bf16 q~ = q + e_q, v~ = v + e_r.  Absolute
                 // error of d~^2 (A):
                 //   2 |q~.v~ - q.v|  <= 2 (|q||e_r| + |e_q||v| + |e_q||e_r|) <= 2 |q| (E + rho_q (V + E))

@@ -36,7 +36,9 @@ struct QInfo {
     float pad;         // Euclidean score over the bf16 mirror: > 0 two-sided absolute error of the distance (VALU sweep);
                        // < 0 minus the two-sided absolute error of the SQUARED distance (matrix-core / 8-bit sweep); else 0
     float qscale;      // 8-bit sweep: s_q of the query's split q = s_q (h + l / 256) + e_q (nmn_scan_i8.hip); else 0
-    float rsv[3];
+    float qq8;         // 8-bit sweep: |q~|^2 of the split query q~ = s_q (h + l / 256) (the Euclidean estimator |q~ - v~|^2)
+    float pad_sq;      // > 0 (8-bit Euclidean sweep): two-sided absolute error of the SQUARED distance ON TOP OF `pad` (distance space)
+    float neg_d;       // 1: the score pad_sq applies to is -d (IVF list scan), else 1 / (1 + d)
 };
 
 // Per-query selection state shared by select / fallback / rescore / final.
@@ -87,6 +89,7 @@ struct ScanParams {
     const float* corpus_half;   // nullable: bf16 mirror (row stride ld/2 floats) the VALU sweep reads instead of `corpus`
     const int8_t* corpus_i8;    // 8-bit sweep (nmn_scan_i8.hip): int8 codes, row stride ld bytes
     const float* i8_scale;      // ... [rows] per-row scale s_r
+    const float* i8_vv;         // ... [rows] |s_r c_r|^2: the squared magnitude of the row AS STORED (Euclidean estimator)
     const uint32_t* qi8;        // ... [nq][2][ld / 4]: the h plane and the l plane of every query (int8, zero padded)
     const QState* retry_state;  // nullable: sweep only the queries whose candidate list overflowed (f32 retry of a bf16 pass)
     const float* norms;      // [rows]
@@ -124,7 +127,7 @@ bool scan_half_supported(uint32_t ld, int metric);
 bool scan_i8_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_i8(const ScanParams& p, hipStream_t s);
 // quantizes rows [row0, row0+n) into q8 / scale and folds their error norms into err_bits[0..1] (row_err2_scratch: n floats)
-hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, float* vv, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                           float* row_err2_scratch, uint32_t* err_bits, hipStream_t s);
 // one pass over freshly written rows (nmn_ingest.hip): magnitudes in reference order + (half != nullptr) their bf16 mirror
 // rows and the mirror's error norms folded into err_bits[0..1]

@@ -14,8 +14,11 @@
 // For N(0,1)-like rows of 768 elements rho_v is about 0.009 (bf16 mirror: 0.0015): ~1 000 candidates instead of ~270 at
 // 10M rows, k = 100 — still one rescore launch.  A corpus whose rows are dominated by a few large elements gets a large
 // measured rho_v, overflows the candidate lists, and the shard goes back to the bf16 mirror by itself (nmn_api.hip).
-// Euclidean scores use ||q - v||^2 = ||q||^2 + ||v||^2 - 2 q.v with the stored reference-order magnitudes, margin in squared-
-// distance space exactly as on the matrix-core sweep (qprep_kernel: QInfo.pad < 0).
+// Euclidean scores: the sweep computes the distance between the STORED representations exactly,
+// ||q~ - v~||^2 = ||q~||^2 + ||v~||^2 - 2 q~.v~ (||v~||^2 = s_r^2 c_r.c_r kept per row, ||q~||^2 per query), so by the triangle
+// inequality the DISTANCE is off by at most ||e_q|| + ||e_r|| — an absolute error in distance space (QInfo.pad), which stays
+// small for near neighbours where a bound on q.e_r (2 ||q|| ||e_r|| on the squared distance) would swamp them; the f32
+// roundings of the three-term expression are bounded in squared-distance space on top of it (QInfo.pad_sq).
 //
 // Mapping: the one of scan_kernel — a wave owns whole 64-row tiles, 16 steps x 4 rows, each 16-lane DPP row reads ONE corpus
 // row with 16-byte non-temporal loads (lane j takes chunks j, j + 16, ...; a chunk is 16 elements), row_ror reductions, lane
@@ -121,9 +124,9 @@ __device__ __forceinline__ void row_partial_i8(const v4i* __restrict__ rowp, boo
     for (int q = 0; q < NQ; q++) acc[q] = (float)hi[q] + (float)lo[q] * 0.00390625f;
 }
 
-// Euclidean score from the dot product (as the matrix-core sweep, nmn_scan_mfma.hip: l2_score)
-__device__ __forceinline__ float l2_from_dot(float qq, float vn, float dot, bool neg) {
-    const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, __builtin_fmaf(vn, vn, qq)), 0.0f);
+// Euclidean score from |q~|^2, |v~|^2 and q~.v~
+__device__ __forceinline__ float l2_from_dot(float qq, float vv, float dot, bool neg) {
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, qq + vv), 0.0f);
     const float d = __builtin_amdgcn_sqrtf(d2);
     return neg ? -d : __builtin_amdgcn_rcpf(1.0f + d);
 }
@@ -170,11 +173,12 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
         qh[0] = ql[0] = (v4i){0, 0, 0, 0};
     }
 
-    float qmag[NQ], qsc[NQ];
+    float qmag[NQ], qsc[NQ], qq8[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         qmag[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qmag : 0.f;
         qsc[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qscale : 0.f;
+        qq8[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qq8 : 0.f;
     }
     const bool neg = p.metric == kMetricNegL2;
 
@@ -262,15 +266,16 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
         const bool valid = ((mword >> mybit) & 1ull) != 0;
         const uint64_t myrow = r0 + mybit;
         const float sr = valid ? p.i8_scale[myrow] : 0.f;
-        float vn = 1.f;
-        if constexpr (METRIC != NMN_METRIC_DOT_PRODUCT) vn = valid ? p.norms[myrow] : 1.f;
+        float vn = 1.f;  // cosine: |v| in reference order; Euclidean: |v~|^2 of the row as stored
+        if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? p.norms[myrow] : 1.f;
+        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn = valid ? p.i8_vv[myrow] : 0.f;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             if (q0 + q >= p.nq) break;
             const float dot = mydot[q] * (qsc[q] * sr);
             float sc;
             if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
-            else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_from_dot(qmag[q] * qmag[q], vn, dot, neg);
+            else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_from_dot(qq8[q], vn, dot, neg);
             else sc = dot;
             const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
             p.scores[score_at(myrow, q0 + q, p.nql)] = valid ? f2u(sc) : kScoreSentinelBits;
@@ -329,7 +334,8 @@ hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 // A row with a non-finite element gets scale 0 / codes 0 and an infinite error norm: its shard's margin becomes useless,
 // every query overflows into the f32 retry and the shard leaves the mirror alone (nmn_api.hip) — never a wrong answer.
 __global__ void __launch_bounds__(256) q8_rows_kernel(const float* __restrict__ corpus, int8_t* __restrict__ q8, float* __restrict__ scale,
-                                                      uint32_t ld, uint64_t row0, uint64_t n, float* __restrict__ row_err2, uint32_t lpr) {
+                                                      float* __restrict__ vv, uint32_t ld, uint64_t row0, uint64_t n,
+                                                      float* __restrict__ row_err2, uint32_t lpr) {
     const uint32_t per_row = ld >> 3;  // 8-element groups per row
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & (lpr - 1u), slot = lane / lpr, rows_per_wave = 64u / lpr;
@@ -359,6 +365,7 @@ __global__ void __launch_bounds__(256) q8_rows_kernel(const float* __restrict__ 
         const float s = (bad || mx == 0.f) ? 0.f : mx / 127.0f;
         const float inv = s > 0.f ? 127.0f / mx : 0.f;
         float err2 = 0.f;
+        int cc = 0;  // c.c of this lane's codes: an exact integer (<= 4096 * 127^2 over the whole row)
         for (uint32_t g = sub; live && g < per_row; g += lpr) {
             const v4f a = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u);
             const v4f b = *reinterpret_cast<const v4f*>(corpus + r * ld + g * 8u + 4u);
@@ -371,13 +378,18 @@ __global__ void __launch_bounds__(256) q8_rows_kernel(const float* __restrict__ 
                 if (!(c == c)) c = 0.f;
                 const float e = x[t] - s * c;
                 err2 = __builtin_fmaf(e, e, err2);
+                cc += (int)c * (int)c;
                 pk[t >> 2] |= ((uint32_t)(int)c & 0xFFu) << (8 * (t & 3));
             }
             *reinterpret_cast<uint2*>(q8 + r * (uint64_t)ld + g * 8u) = make_uint2(pk[0], pk[1]);
         }
-        for (uint32_t off = lpr >> 1; off > 0; off >>= 1) err2 += __shfl_xor(err2, (int)off);
+        for (uint32_t off = lpr >> 1; off > 0; off >>= 1) {
+            err2 += __shfl_xor(err2, (int)off);
+            cc += __shfl_xor(cc, (int)off);
+        }
         if (live && sub == 0) {
             scale[r] = s;
+            vv[r] = (s * s) * (float)cc;
             row_err2[ri] = bad ? __builtin_inff() : err2;
         }
     }
@@ -418,12 +430,12 @@ hipError_t launch_scan_i8(const ScanParams& p, hipStream_t s) {
     }
 }
 
-hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, float* vv, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                           float* row_err2_scratch, uint32_t* err_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t lpr = 1;
     while (lpr < 64u && lpr < (ld >> 3)) lpr <<= 1;
-    hipLaunchKernelGGL(q8_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, q8, scale, ld, row0, n, row_err2_scratch, lpr);
+    hipLaunchKernelGGL(q8_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, q8, scale, vv, ld, row0, n, row_err2_scratch, lpr);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(q8_err_kernel, dim3(blocks), dim3(256), 0, s, row_err2_scratch, norms, row0, n, err_bits);
     return hipGetLastError();

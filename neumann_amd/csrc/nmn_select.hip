@@ -16,12 +16,31 @@ __device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
     uint32_t Tc = kKeyNaN;
     if (T > kKeyNegInf) {
         float tau = key_to_score(T);
+        float m_abs = qi.margin_abs;
+        if (qi.pad_sq > 0.0f) {
+            // 8-bit Euclidean sweep: the distance may be off by qi.pad AND, on top, its square by qi.pad_sq (both two-sided):
+            // the threshold distance d grows to sqrt((d + pad)^2 + pad_sq); the score is 1 / (1 + d), or -d (IVF list scan)
+            if (qi.neg_d != 0.0f) {
+                const float d = fmaxf(-tau, 0.0f) + qi.pad;
+                tau = -sqrtf(d * d + qi.pad_sq);
+            } else if (tau > 0.0f) {
+                const float d = fmaxf(1.0f / tau - 1.0f, 0.0f) + qi.pad;
+                tau = 1.0f / (1.0f + sqrtf(d * d + qi.pad_sq));
+            }
+            const float thr = tau - fabsf(tau) * qi.margin_rel;
+            uint32_t Tq = kKeyNaN;
+            if (thr == thr) {
+                Tq = score_to_key(thr);
+                if (Tq > T) Tq = T;
+                if (Tq < kKeyNaN) Tq = kKeyNaN;
+            }
+            return Tq;
+        }
         // Euclidean score 1/(1+d) swept over the bf16 mirror: the distance may be off by up to qi.pad (two-sided), i.e.
         // the threshold distance 1/tau - 1 grows by qi.pad
         if (qi.pad > 0.0f && tau > 0.0f) tau = tau / (1.0f + qi.pad * tau);
         // ... swept by the matrix cores (|q|^2 + |v|^2 - 2 q.v): the SQUARED distance may be off by up to -qi.pad
         // (two-sided), i.e. the threshold distance d = 1/tau - 1 grows to sqrt(d^2 - qi.pad)
-        float m_abs = qi.margin_abs;
         if (qi.pad < 0.0f && qi.margin_abs < 0.0f) {  // ... with the score -d of the IVF list scan (flag: margin_abs < 0)
             const float d = fmaxf(-tau, 0.0f);
             tau = -sqrtf(d * d - qi.pad);
