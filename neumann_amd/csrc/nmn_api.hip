@@ -62,6 +62,7 @@ static bool env_set(const char* name) {
 static bool no_mfma() { static const bool v = env_set("NMN_NO_MFMA"); return v; }
 static bool no_half() { static const bool v = env_set("NMN_NO_HALF"); return v; }
 static bool no_i8() { static const bool v = env_set("NMN_NO_I8"); return v; }  // A/B: never the 8-bit mirror
+static bool no_i8_mfma() { static const bool v = env_set("NMN_NO_I8_MFMA"); return v; }  // A/B: batches stay on the bf16 mirror
 static uint64_t i8_min_rows() {  // shards below this stay on the bf16 mirror (the build and its HBM are not worth it)
     static const uint64_t v = [] {
         const char* e = getenv("NMN_I8_MIN_ROWS");
@@ -452,7 +453,7 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->half_scratch) (void)hipFree(idx->half_scratch);
     if (idx->half_stats) (void)hipFree(idx->half_stats);
-    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_vv, (void*)idx->q8_err_bits, (void*)idx->q8_stats})
+    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_vv, (void*)idx->q8_cos, (void*)idx->q8_err_bits, (void*)idx->q8_stats})
         if (p) (void)hipFree(p);
     if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
     if (idx->norms) (void)hipFree(idx->norms);
@@ -526,12 +527,15 @@ static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->q8), (size_t)idx->cap_pad * idx->ld);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_scale), (size_t)idx->cap_pad * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_vv), (size_t)idx->cap_pad * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_cos), (size_t)idx->cap_pad * 4);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (idx->q8) (void)hipFree(idx->q8);
         if (idx->q8_scale) (void)hipFree(idx->q8_scale);
+        if (idx->q8_vv) (void)hipFree(idx->q8_vv);
         idx->q8 = nullptr;
         idx->q8_scale = nullptr;
+        idx->q8_vv = nullptr;
         idx->q8_failed = true;
         return NMN_OK;
     }
@@ -543,6 +547,7 @@ static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(idx->q8, 0, (size_t)idx->cap_pad * idx->ld, stream));
     HIP_TRY(hipMemsetAsync(idx->q8_scale, 0, (size_t)idx->cap_pad * 4, stream));
     HIP_TRY(hipMemsetAsync(idx->q8_vv, 0, (size_t)idx->cap_pad * 4, stream));
+    HIP_TRY(hipMemsetAsync(idx->q8_cos, 0, (size_t)idx->cap_pad * 4, stream));
     return NMN_OK;
 }
 
@@ -552,7 +557,7 @@ static nmn_status q8_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_
     const uint64_t cnt = std::min(row0 + n, idx->q8_rows) - row0;
     float* scratch = nullptr;
     HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-    HIP_TRY(launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->ld, row0, cnt, idx->norms, scratch, idx->q8_err_bits, stream));
+    HIP_TRY(launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->q8_cos, idx->ld, row0, cnt, idx->norms, scratch, idx->q8_err_bits, stream));
     if (idx->half_scratch_cap > (1u << 20)) {
         HIP_TRY(hipStreamSynchronize(stream));
         half_scratch_trim(idx);
@@ -817,9 +822,14 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         const bool use_mfma = mfma_shape && use_half;  // the matrix-core sweep has no f32 variant
         // 1-2 queries on rows of whole 256-element groups: the 8-BIT mirror (one byte per element, nmn_scan_i8.hip), with its own
         // measured margin and its own on/off switch; built on first use, extended when rows were uploaded since
-        bool use_i8 = use_half && !use_mfma && nqc <= 2 && !qmasks_dev && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() &&
-                      !idx->q8_failed && scan_i8_supported(idx->ld, idx->dim, (int)metric) && idx->q8_calls >= idx->q8_off_until;
-        if (!use_mfma && idx->q8_stats && use_half && nqc <= 2 && (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {
+        // ... and unmasked batches on rows of 256 .. 1536 elements take the matrix-core sweep over the same 8-bit mirror
+        const bool i8_ok = use_half && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() && !idx->q8_failed &&
+                           idx->q8_calls >= idx->q8_off_until;
+        const bool i8_valu = i8_ok && !use_mfma && nqc <= 2 && !qmasks_dev && scan_i8_supported(idx->ld, idx->dim, (int)metric);
+        const bool i8_mfma = i8_ok && use_mfma && !mask_dev && !qmasks_dev && !no_i8_mfma() && scan_mfma_i8_supported(idx->ld, idx->dim, (int)metric);
+        bool use_i8 = i8_valu || i8_mfma;
+        if (use_half && (i8_valu || i8_mfma || (idx->q8_stats && idx->q8_calls < idx->q8_off_until)) && idx->q8_stats &&
+            (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {
             uint32_t now[2] = {0, 0};
             if (hipMemcpy(now, idx->q8_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
                 const uint32_t total = now[0] - idx->q8_seen[0], retried = now[1] - idx->q8_seen[1];
@@ -843,7 +853,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 const uint64_t cnt = n_rows - idx->q8_rows;
                 float* scratch = nullptr;
                 HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
+                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->q8_cos, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
                                                idx->q8_err_bits, stream);
                 if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // (as for the bf16 mirror: other streams may rely on it from now on)
                 half_scratch_trim(idx);
@@ -880,6 +890,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.corpus_i8 = use_i8 ? idx->q8 : nullptr;
             sp.i8_scale = idx->q8_scale;
             sp.i8_vv = idx->q8_vv;
+            sp.i8_cos = idx->q8_cos;
             sp.qi8 = w->qi8;
             sp.norms = idx->norms;
             sp.inv_norms = idx->inv_norms;
@@ -969,7 +980,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sb.bx_count = 0;
                 HIP_TRY(launch_scan_mfma(sb, stream));
             } else {
-                HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));
+                HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
             }
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
 
@@ -994,7 +1005,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.k_extra = nullptr;
             sel.retry = 0;
             sel.retry_follows = f32_retry ? 1 : 0;
-            sel.half_stats = f32_retry ? (use_i8 ? idx->q8_stats : idx->half_stats) : nullptr;
+            sel.half_stats = f32_retry ? (use_i8 ? idx->q8_stats : idx->half_stats) : (use_i8 && use_mfma) ? idx->q8_stats : nullptr;
+            sel.count_overflows = (use_i8 && use_mfma) ? 1 : 0;
             sel.fb_sync_reset = w->fb_sync;  // (nullable) zeroed for the device-wide fallback selection further down this stream
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));

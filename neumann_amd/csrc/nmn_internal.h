@@ -90,6 +90,7 @@ struct ScanParams {
     const int8_t* corpus_i8;    // 8-bit sweep (nmn_scan_i8.hip): int8 codes, row stride ld bytes
     const float* i8_scale;      // ... [rows] per-row scale s_r
     const float* i8_vv;         // ... [rows] |s_r c_r|^2: the squared magnitude of the row AS STORED (Euclidean estimator)
+    const float* i8_cos;        // ... [rows] s_r / |v_r| (0 for a zero row): the cosine factor of the matrix-core 8-bit sweep
     const uint32_t* qi8;        // ... [nq][2][ld / 4]: the h plane and the l plane of every query (int8, zero padded)
     const QState* retry_state;  // nullable: sweep only the queries whose candidate list overflowed (f32 retry of a bf16 pass)
     const float* norms;      // [rows]
@@ -127,7 +128,7 @@ bool scan_half_supported(uint32_t ld, int metric);
 bool scan_i8_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_i8(const ScanParams& p, hipStream_t s);
 // quantizes rows [row0, row0+n) into q8 / scale and folds their error norms into err_bits[0..1] (row_err2_scratch: n floats)
-hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, float* vv, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, float* vv, float* cosf, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                           float* row_err2_scratch, uint32_t* err_bits, hipStream_t s);
 // one pass over freshly written rows (nmn_ingest.hip): magnitudes in reference order + (half != nullptr) their bf16 mirror
 // rows and the mirror's error norms folded into err_bits[0..1]
@@ -144,6 +145,8 @@ hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, 
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
+// ... over the 8-bit mirror (p.corpus_i8 set: launch_scan_mfma dispatches on it): unmasked batches, rows of 256 .. 1536 elements
+bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric);
 
 struct SelectParams {
     const uint32_t* scores;  // score_at(row, q, nql)
@@ -168,6 +171,8 @@ struct SelectParams {
     uint32_t* half_stats;      // nullable [2]: queries selected on the bf16 mirror / of those, queries that needed the retry
     int retry_follows;         // 1: an f32 retry sweep follows this selection (it may flag a query as not worth retrying)
     unsigned long long* fb_sync_reset;  // nullable [2]: counters of the fallback_select launch that follows, zeroed here
+    int count_overflows;       // 1: half_stats[1] counts the queries whose candidate list overflowed in THIS selection (batched 8-bit
+                               // sweeps have no f32 retry whose selections could be counted)
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);

@@ -124,6 +124,35 @@ __device__ __forceinline__ void row_partial_i8(const v4i* __restrict__ rowp, boo
     for (int q = 0; q < NQ; q++) acc[q] = (float)hi[q] + (float)lo[q] * 0.00390625f;
 }
 
+// the two halves of row_partial_i8 for rows of exactly 16 * CH chunks, so that the loads of the NEXT steps can be issued before
+// the products of the current ones (the pipelined loop of scan_i8_kernel)
+template <int CH>
+__device__ __forceinline__ void load_row(const v4i* __restrict__ rowp, uint32_t j, v4i (&x)[CH]) {
+#pragma unroll
+    for (int c = 0; c < CH; c++) x[c] = __builtin_nontemporal_load(rowp + (uint32_t)c * 16u + j);
+}
+template <int NQ, int CH, bool QREG>
+__device__ __forceinline__ void dot_row(const v4i (&x)[CH], uint32_t j, uint32_t chunks, const v4i* __restrict__ qs4,
+                                        const v4i (&qh)[QREG ? CH : 1], const v4i (&ql)[QREG ? CH : 1], float (&acc)[NQ]) {
+    int hi[NQ], lo[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) hi[q] = lo[q] = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if constexpr (QREG) {
+                dot16(x[c], qh[c], ql[c], hi[q], lo[q]);
+            } else {
+                const uint32_t col = (uint32_t)c * 16u + j;
+                dot16(x[c], qs4[(uint32_t)q * 2u * chunks + col], qs4[(uint32_t)q * 2u * chunks + chunks + col], hi[q], lo[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = (float)hi[q] + (float)lo[q] * 0.00390625f;
+}
+
 // Euclidean score from |q~|^2, |v~|^2 and q~.v~
 __device__ __forceinline__ float l2_from_dot(float qq, float vv, float dot, bool neg) {
     const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, qq + vv), 0.0f);
@@ -186,6 +215,104 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) wmax[q] = kKeyMasked;
 
+#ifndef NMN_I8_NO_PIPE
+    // Unmasked sweeps over rows of one chunk group: the loads run ONE BATCH AHEAD of the products.  A batch is kB row steps
+    // (4 rows each, CH 16-byte loads per lane and step); while batch b is multiplied the loads of batch b + 1 — the next
+    // tile's first batch at the end of a tile — are already in flight, so the wave never drains its queue between batches
+    // (the plain loop below ends every batch at vmcnt(0): 0.79 of the HBM peak at 10M x 768 against 0.8x for this form).
+    if constexpr (!MASKED && SINGLE) {
+#ifdef NMN_I8_KB  // measurement builds (tools/build_variant.sh): steps per batch for every row length
+        constexpr int kB = NMN_I8_KB;
+#else
+        constexpr int kB = CH <= 2 ? 4 : CH <= 4 ? 2 : 1;   // steps per batch: 4-6 loads per lane in each of the two buffers
+#endif
+        constexpr int kNB = 16 / kB;                        // batches per tile (even)
+        v4i xa[kB][CH], xb[kB][CH];
+        auto issue = [&](v4i (&x)[kB][CH], uint32_t tile_, int b) __attribute__((always_inline)) {
+            const uint64_t r0_ = (uint64_t)tile_ * kTileRows;
+#pragma unroll
+            for (int s = 0; s < kB; s++) {
+                // (rows past the end of the shard: the last tile's padding rows exist in the mirror — cap_pad rows, zeroed)
+                const v4i* rowp = reinterpret_cast<const v4i*>(mat + (r0_ + (uint32_t)(b * kB + s) * 4u + grp) * (uint64_t)ld);
+                load_row<CH>(rowp, j, x[s]);
+            }
+        };
+        float mydot[NQ];
+        auto multiply = [&](const v4i (&x)[kB][CH], int b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < kB; s++) {
+                float acc[NQ];
+                dot_row<NQ, CH, QREG>(x[s], j, chunks, qs4, qh, ql, acc);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const float t = row16_sum(acc[q]);
+                    if (j == (uint32_t)(b * kB + s)) mydot[q] = t;
+                }
+            }
+        };
+        issue(xa, t0, 0);
+        const uint32_t mybit = j * 4u + grp;
+        for (uint32_t tile = t0; tile < t1; tile++) {
+            // this lane's row of the tile: its scale (and magnitude) are requested BEFORE the tile's rows — the queue retires in
+            // order, so they are there long before the epilogue asks, and the epilogue's wait does not drain the rows in flight
+            const uint64_t r0 = (uint64_t)tile * kTileRows;
+            const uint64_t myrow = r0 + mybit;
+            const bool valid = myrow < p.n_rows;
+            const uint64_t srow = valid ? myrow : 0;  // (padding rows of the last tile: any valid address)
+            const float sr_raw = p.i8_scale[srow];
+            float vn_raw = 1.f;
+            if constexpr (METRIC == NMN_METRIC_COSINE) vn_raw = p.norms[srow];
+            if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn_raw = p.i8_vv[srow];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
+            // (the tile after the last re-reads the last tile's first batch: issued unconditionally, so that the compiler can
+            //  count the queue — a branch around the prefetch made it end every tile at vmcnt(0))
+            const uint32_t next_tile = min(tile + 1u, t1 - 1u);
+#pragma unroll
+            for (int b = 0; b < kNB; b += 2) {
+                // (the fences keep a batch's loads together and ahead of the other buffer's products: left alone the scheduler
+                //  strings them out one load per eight products with four in flight)
+                issue(xb, tile, b + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(xa, b);
+                __builtin_amdgcn_sched_barrier(0);
+                if (b + 2 < kNB) issue(xa, tile, b + 2);
+                else issue(xa, next_tile, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(xb, b + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float sr = valid ? sr_raw : 0.f;
+            float vn = 1.f;
+            if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? vn_raw : 1.f;
+            if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn = valid ? vn_raw : 0.f;
+            // (the arithmetic runs for every query slot, only the stores are guarded: uses of sr / vn inside a conditional block
+            //  let the compiler sink their loads down here, behind all the rows of the tile)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const bool q_ok = q0 + q < p.nq;
+                const float dot = mydot[q] * (qsc[q] * sr);
+                float sc;
+                if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
+                else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_from_dot(qq8[q], vn, dot, neg);
+                else sc = dot;
+                const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
+                const uint32_t m = wave_max_u32(key);
+                if (q_ok) {
+                    p.scores[score_at(myrow, q0 + q, p.nql)] = valid ? f2u(sc) : kScoreSentinelBits;
+                    if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tile] = m;
+                    wmax[q] = max(wmax[q], m);
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (q0 + q < p.nq) p.wmax[(size_t)(q0 + q) * p.wmax_stride + wave] = wmax[q];
+        }
+        return;
+    }
+#endif
     uint64_t mcache = 0;
     for (uint32_t tile = t0; tile < t1; tile++) {
         const uint64_t r0 = (uint64_t)tile * kTileRows;
@@ -334,8 +461,8 @@ hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 // A row with a non-finite element gets scale 0 / codes 0 and an infinite error norm: its shard's margin becomes useless,
 // every query overflows into the f32 retry and the shard leaves the mirror alone (nmn_api.hip) — never a wrong answer.
 __global__ void __launch_bounds__(256) q8_rows_kernel(const float* __restrict__ corpus, int8_t* __restrict__ q8, float* __restrict__ scale,
-                                                      float* __restrict__ vv, uint32_t ld, uint64_t row0, uint64_t n,
-                                                      float* __restrict__ row_err2, uint32_t lpr) {
+                                                      float* __restrict__ vv, float* __restrict__ cosf, const float* __restrict__ norms,
+                                                      uint32_t ld, uint64_t row0, uint64_t n, float* __restrict__ row_err2, uint32_t lpr) {
     const uint32_t per_row = ld >> 3;  // 8-element groups per row
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & (lpr - 1u), slot = lane / lpr, rows_per_wave = 64u / lpr;
@@ -390,6 +517,8 @@ __global__ void __launch_bounds__(256) q8_rows_kernel(const float* __restrict__ 
         if (live && sub == 0) {
             scale[r] = s;
             vv[r] = (s * s) * (float)cc;
+            const float vn = norms[r];
+            cosf[r] = (vn > 0.f && vn <= 3.0e38f) ? s / vn : 0.f;  // cosine factor of the batched sweep (a zero row scores 0)
             row_err2[ri] = bad ? __builtin_inff() : err2;
         }
     }
@@ -430,12 +559,12 @@ hipError_t launch_scan_i8(const ScanParams& p, hipStream_t s) {
     }
 }
 
-hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, float* vv, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
+hipError_t launch_q8_rows(const float* corpus, int8_t* q8, float* scale, float* vv, float* cosf, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
                           float* row_err2_scratch, uint32_t* err_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t lpr = 1;
     while (lpr < 64u && lpr < (ld >> 3)) lpr <<= 1;
-    hipLaunchKernelGGL(q8_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, q8, scale, vv, ld, row0, n, row_err2_scratch, lpr);
+    hipLaunchKernelGGL(q8_rows_kernel, dim3(256 * 16), dim3(256), 0, s, corpus, q8, scale, vv, cosf, norms, ld, row0, n, row_err2_scratch, lpr);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(q8_err_kernel, dim3(blocks), dim3(256), 0, s, row_err2_scratch, norms, row0, n, err_bits);
     return hipGetLastError();

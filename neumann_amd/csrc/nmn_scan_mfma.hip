@@ -149,23 +149,41 @@ __device__ __forceinline__ float l2_score(float qq, float vn, float dot) {
     return NEG ? -d : __builtin_amdgcn_rcpf(1.0f + d);
 }
 
-template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES>
+// I8: the sweep streams the shard's 8-BIT mirror (nmn_scan_i8.hip: int8 codes, one scale per row) instead of the bf16 one — the
+// same bytes-per-stage geometry (a stage is [64 rows][256 * KS bytes], a k-step 64 bytes of a row = one 16-byte fragment per
+// lane), half the bytes per element.  The stationary queries are the int8 planes h, l of q = s_q (h + l / 256) + e_q (qprep):
+// two v_mfma_i32_16x16x64_i8 per fragment into two int32 accumulator sets, exact integer arithmetic; the epilogue forms
+// (h.c + l.c / 256) * s_q * s_r and the score from it.  Margins: qprep_kernel, approx_pass 1 | 2 | 4.
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <bool NEG>
+__device__ __forceinline__ float l2_score_i8(float qq8, float vv, float dot) {  // |q~ - v~|^2 = |q~|^2 + |v~|^2 - 2 q~.v~
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, qq8 + vv), 0.0f);
+    const float d = __builtin_amdgcn_sqrtf(d2);
+    return NEG ? -d : __builtin_amdgcn_rcpf(1.0f + d);
+}
+
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES, bool I8 = false>
 __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(ScanParams p) {
-    constexpr int kStageElems = 128 * KS;                        // elements of a row per stage
+    constexpr int kStageElems = 128 * KS;                        // elements of a row per stage (I8: 256 * KS, the same BYTES)
     constexpr int kStageBytes = kTileRows * kStageElems * 2;     // 16 / 32 KiB of bf16
     constexpr int kRowPitch = kStageElems / 2;                   // LDS row pitch of a stage, in floats
     constexpr int kRing = kRingBytes / kStageBytes;              // 8 / 4 stages (all but one in flight)
     constexpr int kPieces = 16 * KS / WAVES;                     // 1-KiB DMA instructions per wave and stage (4 waves: 4 / 8, 8 waves: 2 / 4)
     constexpr uint32_t LR = 16 * KS;                             // lanes (16-B chunks) per row of a stage
     constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;  // 1/(1+d), or -d (IVF list scans)
-    constexpr bool kNeedNorms = METRIC == NMN_METRIC_COSINE || kL2;  // |v| of the tile's rows
+    constexpr bool kNeedNorms = I8 || METRIC == NMN_METRIC_COSINE || kL2;  // |v| of the tile's rows (I8: their scales, always)
+    // the score is the accumulator times a per-row factor (from LDS) times a per-query factor: cosine, and the 8-bit dot product
+    constexpr bool kScaled = METRIC == NMN_METRIC_COSINE || (I8 && METRIC == NMN_METRIC_DOT_PRODUCT);
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | norms
     float* nrm = lds + kRingBytes / 4;                           // [kNormSlots tiles][64] row magnitudes — cosine: their INVERSES
                                                                  // (ScanParams::inv_norms: one rcp per row at ingest, not 16 per lane here)
+    // (I8, Euclidean) |v~|^2 of the tiles' rows, behind the pending tile maxima (see tk_pend)
+    float* const nrm2 = nrm + kNormSlots * 64 + (QG * 2 == WAVES ? QG * 64 * 16 : 0) + WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 4;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
     const uint32_t ld = p.ld;
+    const uint32_t row_bytes = I8 ? ld : ld * 2u;  // bytes of one row of the streamed mirror
     // Workgroup -> (tile range bx, query block by).  With several query blocks the grid is 1-D and folded so that the
     // workgroups that stream the SAME tiles for different query blocks get ids 8 apart: same XCD (ids go round the 8 XCDs),
     // dispatched together — the second reader of a tile then finds it in that XCD's L2 / the infinity cache instead of
@@ -197,11 +215,30 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     constexpr int kBK = KC * kSteps;                  // ... of a row
     constexpr int kBG = kHalfK ? 1 : QG / WAVES;      // query groups of this wave: groups wave, wave + WAVES, ...
     s8 bhi[kBK][kBG];
+    s8 blo[I8 ? kBK : 1][kBG];  // (I8) the l plane of the query split
 #pragma unroll
     for (int qg = 0; qg < kBG; qg++) {
         const uint32_t qq = q0 + ((uint32_t)qg * (uint32_t)WAVES + grp) * 16u + n;
         const bool ok = qq < p.nq;
         const float* qv = p.qpad + (size_t)(ok ? qq : q0) * ld;
+        if constexpr (I8) {
+            // qi8[q][2][ld] int8: the 16 bytes of k-step kc this lane's group multiplies, from the h plane and from the l plane
+            const char* qb = reinterpret_cast<const char*>(p.qi8) + (size_t)(ok ? qq : q0) * 2u * ld;
+#pragma unroll
+            for (int kc = 0; kc < kBK; kc++) {
+                const uint32_t k0b = ((uint32_t)(kc / kSteps) * (4u * KS) + kh * (uint32_t)kSteps + (uint32_t)(kc % kSteps)) * 64u + g * 16u;
+                u4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    h = *reinterpret_cast<const u4*>(qb + k0b);
+                    l = *reinterpret_cast<const u4*>(qb + ld + k0b);
+                }
+                bhi[kc][qg] = __builtin_bit_cast(s8, h);
+                blo[kc][qg] = __builtin_bit_cast(s8, l);
+            }
+            continue;
+        } else {
+            blo[0][qg] = (s8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
 #pragma unroll
         for (int kc = 0; kc < kBK; kc++) {
             // k-step kc of this wave = k-step kh*kSteps + kc % kSteps of stage kc / kSteps
@@ -220,11 +257,14 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     uint32_t qn_h[kHalves], skip_h[kHalves], wmax_h[kHalves];
     bool q_ok_h[kHalves];
     float qmag_h[kHalves];
+    float qsc_h[kHalves], qq8_h[kHalves];  // (I8) s_q and |q~|^2 of the query split
 #pragma unroll
     for (int h = 0; h < kHalves; h++) {
         qn_h[h] = q0 + ((uint32_t)h * (uint32_t)WAVES + grp) * 16u + n;
         q_ok_h[h] = kh == 0 && (uint32_t)h * (uint32_t)WAVES + grp < (uint32_t)QG && qn_h[h] < p.nq;
         qmag_h[h] = q_ok_h[h] ? p.qinfo[qn_h[h]].qmag : 0.f;
+        qsc_h[h] = (I8 && q_ok_h[h]) ? p.qinfo[qn_h[h]].qscale : 0.f;
+        qq8_h[h] = (I8 && q_ok_h[h]) ? p.qinfo[qn_h[h]].qq8 : 0.f;
         skip_h[h] = (q_ok_h[h] && p.skip_key) ? p.skip_key[qn_h[h]] : kKeyNaN;  // kKeyNaN: write every tile
         wmax_h[h] = kKeyMasked;
     }
@@ -240,12 +280,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 #pragma unroll
     for (int pp = 0; pp < kPieces; pp++) {
         const uint32_t r = (64u / LR) * (wave * kPieces + (uint32_t)pp) + lane / LR;
-        loff[pp] = r * ld * 2u + (((lane % LR) ^ (r & 15u)) * 16u);
+        loff[pp] = r * row_bytes + (((lane % LR) ^ (r & 15u)) * 16u);
     }
-    const char* const mirror = reinterpret_cast<const char*>(p.corpus_half);
-    const float* const norm_src = METRIC == NMN_METRIC_COSINE ? p.inv_norms : p.norms;
+    const char* const mirror = I8 ? reinterpret_cast<const char*>(p.corpus_i8) : reinterpret_cast<const char*>(p.corpus_half);
+    // per-row factor of the epilogue: 1 / |v| (cosine) or |v| (Euclidean); I8: s_r / |v| (cosine) or s_r (dot, Euclidean), and
+    // for Euclidean a second array, |v~|^2 of the row as stored
+    const float* const norm_src = I8 ? (METRIC == NMN_METRIC_COSINE ? p.i8_cos : p.i8_scale)
+                                     : (METRIC == NMN_METRIC_COSINE ? p.inv_norms : p.norms);
     auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const char* {
-        return mirror + ((uint64_t)tile_ * tstep * kTileRows * ld + kc_ * kStageElems) * 2ull;
+        return mirror + (uint64_t)tile_ * tstep * kTileRows * row_bytes + (uint64_t)kc_ * (kStageElems * 2u);
     };
 
     // prologue: stages 0..kRing-2 in flight (stage s lives in ring slot s % kRing)
@@ -254,7 +297,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         if (s0 < n_stage) {
             // (the magnitudes of stage kRing - 1's tile too: its pieces go out during the first iteration)
             if (kNeedNorms && wave == 0 && s0 % KC == 0)
+            {
                 norms_dma(norm_src, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kNormSlots) * 64u, lane);
+                if constexpr (I8 && kL2) norms_dma(p.i8_vv, (uint64_t)(t0 + s0 / KC) * tstep, nrm2 + ((s0 / KC) % kNormSlots) * 64u, lane);
+            }
             if (s0 < kRing - 1)
                 stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         }
@@ -286,6 +332,8 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         const uint64_t rtile = (uint64_t)ftile * tstep;  // real tile index (sampling pass: every tstep-th)
         const uint64_t r0 = rtile * kTileRows;
         const float* nslot = nrm + ((ftile - t0) % kNormSlots) * 64u;
+        const float* nslot2 = nrm2 + ((ftile - t0) % kNormSlots) * 64u;  // (I8, Euclidean)
+        (void)nslot2;
         uint64_t mword = ~0ull;
         if constexpr (MASKED) {
             // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
@@ -294,8 +342,11 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         }
         const uint64_t left = p.n_rows - r0;
         if (left < 64) mword &= (1ull << left) - 1ull;
-        const float inv_q = qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag);
-        const float qq = qmag * qmag;
+        // per-query factor: 1 / |q| (cosine); I8: s_q / |q| (cosine), s_q (dot product; also what scales the Euclidean dot)
+        const float qsc = qsc_h[H];
+        const float inv_q = I8 ? (METRIC == NMN_METRIC_COSINE ? (qmag == 0.f ? 0.f : qsc * __builtin_amdgcn_rcpf(qmag)) : qsc)
+                               : (qmag == 0.f ? 0.f : __builtin_amdgcn_rcpf(qmag));
+        const float qq = I8 ? qq8_h[H] : qmag * qmag;
         (void)inv_q;
         (void)qq;
         // what follows a tile's key: the maximum over the four lane groups of a query (v_permlane32_swap / v_permlane16_swap: no
@@ -350,21 +401,28 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         // work is one multiply by the row's inverse magnitude and a max; the query's 1/|q| (>= 0: monotone, rounding included)
         // is applied once to the maximum, and the 16 score words are formed — multiplying again — only where they are written.
         constexpr bool kLazy = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_DOT_PRODUCT;
+        // Euclidean score of one row from its accumulator
+        auto l2_of = [&](float acc_v, float vn_v, float vv_v) __attribute__((always_inline)) -> float {
+            if constexpr (I8) return l2_score_i8<METRIC == kMetricNegL2>(qq, vv_v, acc_v * (inv_q * vn_v));  // vn_v = s_r here
+            else return l2_score<METRIC == kMetricNegL2>(qq, vn_v, acc_v);
+        };
         if (mword == ~0ull) {
             float m = -__builtin_inff();
             u4 bits[4];
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
                 f4 sc = fin[rb];
-                if constexpr (METRIC == NMN_METRIC_COSINE) {
+                if constexpr (kScaled) {
                     // (a zero row has inverse magnitude 0: its score is 0 like cosine_similarity's; v_rcp at ingest: 1 ulp,
                     // the margin has 1000x that slack)
                     sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
                 }
                 if constexpr (kL2) {
                     const f4 vn = *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+                    f4 vv = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (I8) vv = *reinterpret_cast<const f4*>(nslot2 + (uint32_t)rb * 16u + g * 4u);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) sc[e] = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc[e]);
+                    for (int e = 0; e < 4; e++) sc[e] = l2_of(sc[e], vn[e], vv[e]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -372,16 +430,16 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                     m = __builtin_fmaxf(m, sc[e]);  // v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its key
                 }
             }
-            if constexpr (METRIC == NMN_METRIC_COSINE) m = m * inv_q;
+            if constexpr (kScaled) m = m * inv_q;
             if (publish(score_to_key(m))) {
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++) {
                     u4 w;
                     if constexpr (kLazy) {
                         f4 sc = fin[rb];
-                        if constexpr (METRIC == NMN_METRIC_COSINE) sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+                        if constexpr (kScaled) sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) w[e] = f2u(METRIC == NMN_METRIC_COSINE ? sc[e] * inv_q : sc[e]);
+                        for (int e = 0; e < 4; e++) w[e] = f2u(kScaled ? sc[e] * inv_q : sc[e]);
                     } else {
                         w = bits[rb];
                     }
@@ -394,14 +452,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
                 const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
-                f4 vn = {1.f, 1.f, 1.f, 1.f};
+                f4 vn = {1.f, 1.f, 1.f, 1.f}, vv = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (kNeedNorms) vn = *reinterpret_cast<const f4*>(nslot + rr);
+                if constexpr (I8 && kL2) vv = *reinterpret_cast<const f4*>(nslot2 + rr);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const bool valid = ((mword >> (rr + (uint32_t)e)) & 1ull) != 0;
                     float sc = fin[rb][e];
-                    if constexpr (METRIC == NMN_METRIC_COSINE) sc = (sc * vn[e]) * inv_q;  // vn = 1 / |v| here
-                    if constexpr (kL2) sc = l2_score<METRIC == kMetricNegL2>(qq, vn[e], sc);
+                    if constexpr (kScaled) sc = (sc * vn[e]) * inv_q;  // vn = 1 / |v| here (I8: s_r / |v|, or s_r)
+                    if constexpr (kL2) sc = l2_of(sc, vn[e], vv[e]);
                     bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
                     if (valid) tkey = max(tkey, score_to_key(sc));
                 }
@@ -432,10 +491,17 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     uint32_t sidx = 0;  // running stage index of this workgroup
     for (uint32_t tile = t0; tile < t1; tile++) {
         f4 acc[4][kAccGroups];  // [row block][query group of this wave]
+        v4i ach[I8 ? 4 : 1][kAccGroups], acl[I8 ? 4 : 1][kAccGroups];  // (I8) int32 sums of the h plane / the l plane
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-            for (int qg = 0; qg < kAccGroups; qg++) acc[rb][qg] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int qg = 0; qg < kAccGroups; qg++) {
+                acc[rb][qg] = (f4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (I8) {
+                    ach[rb][qg] = (v4i){0, 0, 0, 0};
+                    acl[rb][qg] = (v4i){0, 0, 0, 0};
+                }
+            }
 #pragma unroll
         for (int kc = 0; kc < KC; kc++, sidx++) {
             const float* buf = lds + (sidx % kRing) * (kStageBytes / 4);
@@ -466,7 +532,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // k-step's DMA piece(s) of the stage ahead (see above).  A fragment = one ds_read_b128: chunk g of the k-step = 8
             // consecutive bf16 of row n.  (sched_group_barrier pipelines could not place the LDS-DMA instructions — they are
             // both VMEM and DS to the scheduler — and left them in one clump.)
-            constexpr int kKsPerBatch = (kBK * kBG * 4 >= 256) ? 1 : 2;  // k-steps whose fragments are read together (8 reads);
+            constexpr int kKsPerBatch = (kBK * kBG * (I8 ? 8 : 4) >= (I8 ? 192 : 256)) ? 1 : 2;  // k-steps whose fragments are read together (8 reads);
                                                                          // 192+ VGPRs of stationary fragments: 4 reads at a time
             static_assert(kSteps % kKsPerBatch == 0, "batches tile the stage");
             constexpr int kNB = kSteps / kKsPerBatch;
@@ -495,8 +561,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 #pragma unroll
                     for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-                        for (int qg = 0; qg < kBG; qg++)
-                            acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
+                        for (int qg = 0; qg < kBG; qg++) {
+                            if constexpr (I8) {
+                                const v4i av = __builtin_bit_cast(v4i, a[ks][rb]);
+                                ach[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, bhi[kc * kSteps + ks][qg]), ach[rb][qg], 0, 0, 0);
+                                acl[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, blo[kc * kSteps + ks][qg]), acl[rb][qg], 0, 0, 0);
+                            } else {
+                                acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
+                            }
+                        }
                     // one piece of the stage ahead per k-step (K-halves: two, their waves multiply half the k-steps of a stage each)
 #ifndef NMN_MFMA_BURST_DMA
                     // (pieces ks * kPieces / kSteps .. (ks + 1) * kPieces / kSteps: two, one, or one every other k-step)
@@ -516,7 +589,18 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             if (kNeedNorms && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) {
                 const uint32_t nt1 = t0 + (ns + 1u) / KC;
                 norms_dma(norm_src, (uint64_t)nt1 * tstep, nrm + ((nt1 - t0) % kNormSlots) * 64u, lane);
+                if constexpr (I8 && kL2) norms_dma(p.i8_vv, (uint64_t)nt1 * tstep, nrm2 + ((nt1 - t0) % kNormSlots) * 64u, lane);
             }
+        }
+        if constexpr (I8) {
+            // h.c + (l.c) / 256: both sums are exact integers well below 2^24 * 256 (rows of <= 1536 elements: |h.c| <= 1536 * 127^2
+            // = 2.5e7 — converted with one rounding of 2^-24 relative, far inside the margin's f32 slack)
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                for (int qg = 0; qg < kAccGroups; qg++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[rb][qg][e] = (float)ach[rb][qg][e] + (float)acl[rb][qg][e] * 0.00390625f;
         }
         if constexpr (kHalfK) {
             // the two K-halves of a group meet: wave kh = 1 publishes, wave kh = 0 adds and finishes.  (The next
@@ -548,7 +632,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         if (q_ok_h[h] && g == 0) p.wmax[(size_t)qn_h[h] * p.wmax_stride + bx] = wmax_h[h];
 }
 
-template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES>
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES, bool I8 = false>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     if (p.bx_base >= blocks_all) return hipSuccess;
@@ -563,12 +647,13 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
         grid = dim3(((blocks + 7u) / 8u) * 8u * ny, 1);
     }
     const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0) +  // + the K-halves' exchange
-                       (size_t)WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 16;                       // + pending tile maxima
+                       (size_t)WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 16 +                      // + pending tile maxima
+                       (I8 ? kNormSlots * 64 * 4 : 0);                                                     // + (8-bit, Euclidean) |v~|^2 of the tiles' rows
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
 #ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
 #define NMN_MFMA_AUX 2
 #endif
-    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, NMN_MFMA_AUX, WAVES>;
+    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, NMN_MFMA_AUX, WAVES, I8>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -652,6 +737,26 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
     }
 }
 
+// The 8-bit mirror on the matrix cores: 64 stationary queries per workgroup (more queries: several query blocks of one
+// launch, folded onto one XCD like the long rows of the bf16 sweep), rows of whole 256-element groups up to 1536, no bitmap.
+template <int METRIC>
+static hipError_t launch_metric_i8(const ScanParams& p, hipStream_t s) {
+    switch (p.ld / 256u) {  // = row bytes / 256: the unit the bf16 launcher calls ld / kStageK
+        case 1: return launch_one_mfma<1, 1, 4, METRIC, false, 4, true>(p, s);   // 256
+        case 2: return launch_one_mfma<1, 2, 4, METRIC, false, 4, true>(p, s);   // 512
+        case 3: return launch_one_mfma<3, 1, 4, METRIC, false, 4, true>(p, s);   // 768
+        case 4: return launch_one_mfma<2, 2, 4, METRIC, false, 4, true>(p, s);   // 1024
+        case 5: return launch_one_mfma<5, 1, 4, METRIC, false, 4, true>(p, s);   // 1280
+        case 6: return launch_one_mfma<3, 2, 4, METRIC, false, 4, true>(p, s);   // 1536
+        default: return hipErrorInvalidValue;
+    }
+}
+bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric) {
+    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2))
+        return false;
+    return dim <= ld && ld % 256u == 0 && ld >= 256u && ld <= 1536u;
+}
+
 // Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768, or 1024 / 1280 /
 // 1536 with 64 stationary queries per workgroup (their bf16 B-fragments take up to 192 VGPRs at 1536), or 2048 / 3072 / 4096 with 32.
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
@@ -665,6 +770,15 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
+    if (p.corpus_i8) {  // the 8-bit mirror (never with a bitmap: the caller keeps masked batches on the bf16 mirror)
+        if (p.mask || p.qmasks) return hipErrorInvalidValue;
+        switch (p.metric) {
+            case NMN_METRIC_COSINE: return launch_metric_i8<NMN_METRIC_COSINE>(p, s);
+            case NMN_METRIC_EUCLIDEAN: return launch_metric_i8<NMN_METRIC_EUCLIDEAN>(p, s);
+            case kMetricNegL2: return launch_metric_i8<kMetricNegL2>(p, s);
+            default: return launch_metric_i8<NMN_METRIC_DOT_PRODUCT>(p, s);
+        }
+    }
     switch (p.metric) {
         case NMN_METRIC_COSINE: return launch_metric<NMN_METRIC_COSINE>(p, s);
         case NMN_METRIC_EUCLIDEAN: return launch_metric<NMN_METRIC_EUCLIDEAN>(p, s);

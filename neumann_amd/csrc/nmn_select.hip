@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                 st.overflow = c > p.cand_cap ? 1u : 0u;
                 st.cand_count = c > p.cand_cap ? 0u : c;
                 p.qstate[q] = st;
+                if (p.count_overflows && p.half_stats && st.overflow) atomicAdd(p.half_stats + 1, 1u);
             }
             done = true;
         }
@@ -402,6 +403,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         st.overflow = over ? (hopeless ? 4u : 1u) : 0u;
         st.cand_count = over ? 0u : c;
         p.qstate[q] = st;
+        if (p.count_overflows && p.half_stats && over) atomicAdd(p.half_stats + 1, 1u);
     }
 }
 

@@ -60,9 +60,14 @@ def test_mirror_modes_read_1_2_and_4_bytes_per_element_and_agree():
             got[mode] = idx.search(q, k, 0)
         for mode in (2, 0):
             assert np.array_equal(got[mode][0], got[1][0]) and np.array_equal(got[mode][1].view(np.uint32), got[1][1].view(np.uint32))
-        # a 3-query batch is the matrix-core sweep's (bf16 mirror), a row length outside the 256-element groups the bf16 VALU sweep's
+        # a 3-query batch is the matrix-core sweep's — over the 8-bit mirror too; with a bitmap it stays on the bf16 mirror;
+        # a row length outside the 256-element groups is the bf16 VALU sweep's
         idx.set_mirror(1)
         Q3 = oc.synth(0x23, 0, 3, d)
+        check(idx, A, Q3, k, 0, expect_bytes=1)
+        keep = np.random.default_rng(3).random(n) < 0.5
+        check(idx, A, Q3, k, 0, mask=oc.mask_from_bool(keep), expect_bytes=2)
+        idx.set_mirror(2)
         check(idx, A, Q3, k, 0, expect_bytes=2)
     with GpuFlatIndex(320, 80_000, single_launch=False) as idx:
         B = oc.synth(0x24, 0, 80_000, 320, nthreads=8)
@@ -187,3 +192,46 @@ def test_k_1000_euclidean_with_masks_like_config_5():
         for sel in (0.5, 0.1, 0.01):
             keep = np.random.default_rng(int(sel * 100)).random(n) < sel
             check(idx, A, q, k, 1, mask=oc.mask_from_bool(keep), expect_bytes=1)
+
+
+@pytest.mark.parametrize("d", [256, 512, 768, 1024, 1280, 1536])
+def test_batches_on_the_matrix_cores_over_the_8_bit_mirror(d):
+    """3 .. 128 queries per sweep: v_mfma_i32_16x16x64_i8 over the int8 codes, the queries as two int8 planes.  Every metric,
+    batch sizes on both sides of the 64-query block (two query blocks folded into one launch), k up to 1000."""
+    from neumann_amd import GpuFlatIndex
+    n = 150_000 if d <= 768 else 80_000
+    A = oc.synth(0x31 + d, 0, n, d, nthreads=8)
+    Q = oc.synth(0x32 + d, 0, 100, d)
+    Q[5] = A[777] * np.float32(1.5)                 # a query proportional to a stored row
+    Q[6] = A[778] + np.float32(1e-3)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(0x31 + d, n)
+        for metric in (0, 1, 2):
+            check(idx, A, Q[:5 if d < 768 else 3], 50, metric, expect_bytes=1)
+            check(idx, A, Q[:64], 100, metric, expect_bytes=1)
+        check(idx, A, Q, 100, 0, expect_bytes=1)    # 100 queries: two blocks of 64 in one launch
+        check(idx, A, Q[:17], 1000, 1, expect_bytes=1)
+
+
+def test_large_shard_batch_with_sampling_pass_and_planted_ties():
+    """1.2M rows: the sampling pass and the score-write suppression are active (n_sample >= 1024 tiles); near-duplicates of the
+    queries planted around the cut; cosine and Euclidean."""
+    from neumann_amd import GpuFlatIndex
+    n, d, k, nq = 1_200_000, 768, 100, 64
+    A = oc.synth(0x41, 0, n, d, nthreads=8)
+    Q = oc.synth(0x42, 0, nq, d)
+    rng = np.random.default_rng(4)
+    plant = rng.choice(n, 64, replace=False)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(0x41, n)
+        for t, r in enumerate(plant):
+            A[r] = Q[t % 8] * np.float32(1.0 + 1e-6 * t) + np.float32(2e-4) * rng.standard_normal(d).astype(np.float32)
+            idx.set_row(int(r), A[r])
+        A[plant[9]] = A[plant[1]]
+        idx.set_row(int(plant[9]), A[plant[9]])
+        for metric in (0, 1):
+            rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
+            assert st.bytes_scanned == st.rows_scanned * d
+            for qi in (0, 1, 7, 8, 33, 63):
+                er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
+                assert np.array_equal(rows[qi], er) and np.array_equal(scores[qi].view(np.uint32), es.view(np.uint32)), (metric, qi)

@@ -90,6 +90,8 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 150000 and d["scaling"] == "strong"
+    # (under a launcher bench.py uses the ranks it is given; weak scaling is the default: --rows rows PER GPU, BASELINE config 4)
+    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 300000 and d["config"]["rows_total"] == 600000 and d["scaling"] == "weak"
     assert d["parity"]["exact_topk_certified"] and d["parity"]["returned"] == 100
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["multi_gpu"]["ranks"] == 2 and d["multi_gpu"]["rows_per_gpu"] == [300000, 300000]
