@@ -10,4 +10,4 @@ from .flat_index import (DistanceMetric, GpuFlatIndex, merge_topk_device, merge_
 
 from .sharded import GpuShardedIndex  # noqa: F401,E402
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

@@ -370,7 +370,7 @@ extern "C" const char* nmn_status_str(nmn_status s) {
 }
 
 extern "C" const char* nmn_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* nmn_version(void) { return "0.2.0"; }
+extern "C" const char* nmn_version(void) { return "0.3.0"; }
 
 extern "C" nmn_status nmn_index_create(const nmn_index_desc* d, nmn_index** out) {
     if (!d || !out) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");

@@ -741,6 +741,11 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 // launch, folded onto one XCD like the long rows of the bf16 sweep), rows of whole 256-element groups up to 1536, no bitmap.
 template <int METRIC>
 static hipError_t launch_metric_i8(const ScanParams& p, hipStream_t s) {
+    static const bool waves8 = [] {  // measurement knob (NMN_MFMA_WAVES=8): two waves per SIMD, query groups on wave pairs that split K
+        const char* e = getenv("NMN_MFMA_WAVES");
+        return e ? atoi(e) == 8 : false;
+    }();
+    if (waves8 && p.ld == 768u) return launch_one_mfma<3, 1, 4, METRIC, false, 8, true>(p, s);
     switch (p.ld / 256u) {  // = row bytes / 256: the unit the bf16 launcher calls ld / kStageK
         case 1: return launch_one_mfma<1, 1, 4, METRIC, false, 4, true>(p, s);   // 256
         case 2: return launch_one_mfma<1, 2, 4, METRIC, false, 4, true>(p, s);   // 512
