@@ -453,7 +453,8 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
     if (idx->half_err_bits) (void)hipFree(idx->half_err_bits);
     if (idx->half_scratch) (void)hipFree(idx->half_scratch);
     if (idx->half_stats) (void)hipFree(idx->half_stats);
-    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_vv, (void*)idx->q8_cos, (void*)idx->q8_err_bits, (void*)idx->q8_stats})
+    for (void* p : {(void*)idx->q8, (void*)idx->q8_scale, (void*)idx->q8_vv, (void*)idx->q8_cos, (void*)idx->q8_err_bits, (void*)idx->q8_stats,
+                    (void*)idx->q8_l2_hint})
         if (p) (void)hipFree(p);
     if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
     if (idx->norms) (void)hipFree(idx->norms);
@@ -542,6 +543,8 @@ static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
     idx->q8_rows = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_err_bits), 8));
     HIP_TRY(hipMemsetAsync(idx->q8_err_bits, 0, 8, stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_l2_hint), 4));
+    HIP_TRY(hipMemsetAsync(idx->q8_l2_hint, 0, 4, stream));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_stats), 8));
     HIP_TRY(hipMemsetAsync(idx->q8_stats, 0, 8, stream));
     HIP_TRY(hipMemsetAsync(idx->q8, 0, (size_t)idx->cap_pad * idx->ld, stream));
@@ -881,8 +884,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                                  w->qpad, w->qinfo_f32, w->qstate, 0, stream));
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
-                             use_i8 ? (1 | 2 | 4) : ((use_mfma ? 1 : 0) | (use_half ? 2 : 0)), stream,
-                             use_i8 ? idx->q8_err_bits : use_half ? idx->half_err_bits : nullptr, use_i8 ? w->qi8 : nullptr));
+                             use_i8 ? (1 | 2 | 4 | (use_mfma ? 0 : 8)) : ((use_mfma ? 1 : 0) | (use_half ? 2 : 0)), stream,
+                             use_i8 ? idx->q8_err_bits : use_half ? idx->half_err_bits : nullptr, use_i8 ? w->qi8 : nullptr,
+                             (use_i8 && !use_mfma) ? idx->q8_l2_hint : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
@@ -1007,6 +1011,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.retry_follows = f32_retry ? 1 : 0;
             sel.half_stats = f32_retry ? (use_i8 ? idx->q8_stats : idx->half_stats) : (use_i8 && use_mfma) ? idx->q8_stats : nullptr;
             sel.count_overflows = (use_i8 && use_mfma) ? 1 : 0;
+            sel.l2_hint = (use_i8 && !use_mfma && metric == NMN_METRIC_EUCLIDEAN) ? idx->q8_l2_hint : nullptr;
             sel.fb_sync_reset = w->fb_sync;  // (nullable) zeroed for the device-wide fallback selection further down this stream
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
@@ -1043,6 +1048,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel2.retry = 1;
                 sel2.retry_follows = 0;
                 sel2.fb_sync_reset = nullptr;
+                sel2.l2_hint = nullptr;
                 HIP_TRY(launch_select(sel2, stream));
             }
 

@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                                                    int metric, const uint32_t* __restrict__ max_norm_bits,
                                                    float* __restrict__ qpad, QInfo* __restrict__ qinfo,
                                                    QState* __restrict__ qstate, int mfma_pass,
-                                                   const uint32_t* __restrict__ half_err_bits, uint32_t* __restrict__ qi8) {
+                                                   const uint32_t* __restrict__ half_err_bits, uint32_t* __restrict__ qi8,
+                                                   const float* __restrict__ l2_hint) {
     const uint32_t q = blockIdx.x;
     const float* src = queries + (size_t)q * dim;
     float* dst = qpad + (size_t)q * ld;
@@ -291,7 +292,17 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         } else {
             qi.margin_abs = 0.0f;
             qi.margin_rel = 4.0f * (dd + 8.0f) * u;
-            if ((mfma_pass & 4) && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) {
+            // Which Euclidean estimator the 8-bit sweep of 1-2 queries uses.  A: |q~ - v~| between the stored representations, off by
+            // <= |e_q| + |e_r| in DISTANCE space (below).  B: |q|^2 + |v|^2 - 2 q~.v~ with the exact magnitudes, off by <= 2 |q| E in
+            // SQUARED-distance space (the matrix-core branch further down).  Around the threshold distance d_T, B's slack is worth
+            // |q| E / d_T of distance against A's E: B is tighter exactly when d_T > |q| — uncorrelated rows (d ~ sqrt(2) |q|), where it
+            // keeps 10M x 1536 TOP-1000 under a 0.1 bitmap at ~6 000 candidates instead of ~10 000 (past the selection's compact lists:
+            // 0.39 ms of select_kernel) — and far looser for the near neighbours of clustered data.  Both are rigorous; the choice only
+            // moves the candidate count, so it is made from the shard's PREVIOUS Euclidean selection (select_kernel leaves its
+            // threshold distance in *l2_hint; 0 until one has run: estimator A).
+            const bool est_b = (mfma_pass & 8) && l2_hint && *l2_hint > qmag && metric == NMN_METRIC_EUCLIDEAN;
+            if (est_b) qi.qq8 = -1.0f;
+            if ((mfma_pass & 4) && !est_b && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) {
                 // 8-bit sweep: d~ = |q~ - v~| computed from the stored representations themselves, so |d~ - d| <= |e_q| + |e_r|
                 // (triangle inequality): an ABSOLUTE error of the DISTANCE, twice as always -> pad.  What the f32 evaluation of
                 // |q~|^2 + |v~|^2 - 2 q~.v~ adds (|q~|^2 summed by 64 lanes: (d/64 + 8) u; |v~|^2 = s^2 * an exact integer: 3 u; the
@@ -342,9 +353,9 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
 
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
-                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8) {
+                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8, const float* l2_hint) {
     hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), 0, s, queries, dim, ld, metric, max_norm_bits, qpad,
-                       qinfo, qstate, mfma_pass, half_err_bits, qi8);
+                       qinfo, qstate, mfma_pass, half_err_bits, qi8, l2_hint);
     return hipGetLastError();
 }
 

@@ -133,6 +133,7 @@ struct nmn_index {
     float* q8_scale = nullptr;
     float* q8_vv = nullptr;             // |s_r c_r|^2 per row (the Euclidean estimator of the 8-bit sweep)
     float* q8_cos = nullptr;            // s_r / |v_r| per row (cosine factor of the batched 8-bit sweep)
+    float* q8_l2_hint = nullptr;        // device [1]: threshold distance of the last Euclidean selection on the 8-bit mirror (qprep's estimator choice)
     uint32_t* q8_err_bits = nullptr;    // device [2]: max_r |e_r|, max_r |e_r| / |v_r|
     uint32_t* q8_stats = nullptr;       // device [2]: queries selected on the 8-bit mirror / of those, retried in f32
     uint64_t q8_rows = 0;

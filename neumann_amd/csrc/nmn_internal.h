@@ -36,7 +36,8 @@ struct QInfo {
     float pad;         // Euclidean score over the bf16 mirror: > 0 two-sided absolute error of the distance (VALU sweep);
                        // < 0 minus the two-sided absolute error of the SQUARED distance (matrix-core / 8-bit sweep); else 0
     float qscale;      // 8-bit sweep: s_q of the query's split q = s_q (h + l / 256) + e_q (nmn_scan_i8.hip); else 0
-    float qq8;         // 8-bit sweep: |q~|^2 of the split query q~ = s_q (h + l / 256) (the Euclidean estimator |q~ - v~|^2)
+    float qq8;         // 8-bit sweep: |q~|^2 of the split query q~ = s_q (h + l / 256) (the Euclidean estimator |q~ - v~|^2);
+                       // < 0: this query uses the OTHER estimator, |q|^2 + |v|^2 - 2 q~.v~ with the exact magnitudes
     float pad_sq;      // > 0 (8-bit Euclidean sweep): two-sided absolute error of the SQUARED distance ON TOP OF `pad` (distance space)
     float neg_d;       // 1: the score pad_sq applies to is -d (IVF list scan), else 1 / (1 + d)
 };
@@ -171,6 +172,7 @@ struct SelectParams {
     uint32_t* half_stats;      // nullable [2]: queries selected on the bf16 mirror / of those, queries that needed the retry
     int retry_follows;         // 1: an f32 retry sweep follows this selection (it may flag a query as not worth retrying)
     unsigned long long* fb_sync_reset;  // nullable [2]: counters of the fallback_select launch that follows, zeroed here
+    float* l2_hint;            // nullable: query 0's threshold distance is left here (feeds qprep's choice of the 8-bit Euclidean estimator)
     int count_overflows;       // 1: half_stats[1] counts the queries whose candidate list overflowed in THIS selection (batched 8-bit
                                // sweeps have no f32 retry whose selections could be counted)
 };
@@ -248,10 +250,13 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
                         float* inv_norms, uint32_t* max_norm_bits, hipStream_t s);
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
-                        hipStream_t s, const uint32_t* half_err_bits = nullptr, uint32_t* qi8 = nullptr);
+                        hipStream_t s, const uint32_t* half_err_bits = nullptr, uint32_t* qi8 = nullptr,
+                        const float* l2_hint = nullptr);
 // approx_pass bits: 1 = the sweep's copy of the query is rounded (bf16 on the MFMA sweep; with bit 4 the int8 split
 // q = s_q (h + l / 256), written to qi8[q][2][ld] and QInfo.qscale), 2 = the sweep reads a mirror of the corpus
-// (half_err_bits = that mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep
+// (half_err_bits = that mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep;
+// 8 (with 4, Euclidean, the 1-2 query sweep): the estimator may be chosen per query from *l2_hint, the threshold distance of
+// the shard's previous Euclidean selection (nmn_scan_i8.hip: "which Euclidean estimator")
 struct RescoreParams {
     const float* corpus;
     const float* norms;

@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
         qq8[q] = (q0 + q < p.nq) ? p.qinfo[q0 + q].qq8 : 0.f;
     }
     const bool neg = p.metric == kMetricNegL2;
+    bool any_est_b = false;  // some query of this block measures |q|^2 + |v|^2 - 2 q~.v~ (qprep_kernel: "which Euclidean estimator")
+#pragma unroll
+    for (int q = 0; q < NQ; q++) any_est_b = any_est_b || qq8[q] < 0.f;
 
     uint32_t wmax[NQ];
 #pragma unroll
@@ -263,6 +266,11 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
             float vn_raw = 1.f;
             if constexpr (METRIC == NMN_METRIC_COSINE) vn_raw = p.norms[srow];
             if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn_raw = p.i8_vv[srow];
+            float vb = 0.f;  // (Euclidean, estimator B of some query: the row's exact magnitude)
+            if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                if (any_est_b) vb = p.norms[srow];  // (wave-uniform)
+            }
+            (void)vb;
 #pragma unroll
             for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
             // (the tile after the last re-reads the last tile's first batch: issued unconditionally, so that the compiler can
@@ -294,7 +302,7 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                 const float dot = mydot[q] * (qsc[q] * sr);
                 float sc;
                 if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
-                else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_from_dot(qq8[q], vn, dot, neg);
+                else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = qq8[q] < 0.f ? l2_from_dot(qmag[q] * qmag[q], vb * vb, dot, neg) : l2_from_dot(qq8[q], vn, dot, neg);
                 else sc = dot;
                 const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
                 const uint32_t m = wave_max_u32(key);
@@ -334,6 +342,23 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                 continue;
             }
         }
+        // lane L finishes tile row (L & 15) * 4 + (L >> 4).  Its scale (and magnitude) are requested HERE, before the tile's rows:
+        // a sparse tile is a chain of dependent memory round trips per wave (bitmap -> rows -> these factors -> store), and
+        // at selectivity 0.1 a tile is two row steps — the factors' trip alone was a third of the chain.
+        const uint32_t mybit = j * 4u + grp;
+        const bool valid = ((mword >> mybit) & 1ull) != 0;
+        const uint64_t myrow = r0 + mybit;
+        const uint64_t srow = valid ? myrow : r0;  // (rows that do not take part: any valid address of the tile)
+        const float sr_raw = p.i8_scale[srow];
+        float vn_raw = 1.f;  // cosine: |v| in reference order; Euclidean: |v~|^2 of the row as stored
+        if constexpr (METRIC == NMN_METRIC_COSINE) vn_raw = p.norms[srow];
+        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn_raw = p.i8_vv[srow];
+        float vb = 0.f;  // (Euclidean, estimator B of some query: the row's exact magnitude)
+        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+            if (any_est_b) vb = p.norms[srow];  // (wave-uniform)
+        }
+        (void)vb;
+
         float mydot[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) mydot[q] = 0.f;
@@ -349,6 +374,8 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                 const uint32_t myrank = (uint32_t)__builtin_popcountll(mword & ((1ull << lane) - 1ull));
                 if (myset) tab[myrank] = lane;
                 __builtin_amdgcn_wave_barrier();
+                // (two steps' loads in flight together — 8 rows per trip — was built and measured: 140 VGPRs, three waves per SIMD
+                //  instead of five, every selectivity 5-20 % slower; the sparse sweep lives on occupancy)
                 for (uint32_t s0 = 0; s0 < cnt; s0 += 4u) {
                     const bool active = s0 + grp < cnt;
                     const uint32_t pos = active ? tab[s0 + grp] : 0u;
@@ -361,10 +388,9 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                         if (j == 0 && active) stg[q * 64 + (int)pos] = t;
                     }
                 }
-                const uint32_t bit = j * 4u + grp;
-                if ((mword >> bit) & 1ull) {
+                if (valid) {
 #pragma unroll
-                    for (int q = 0; q < NQ; q++) mydot[q] = stg[q * 64 + (int)bit];
+                    for (int q = 0; q < NQ; q++) mydot[q] = stg[q * 64 + (int)mybit];
                 }
             }
         }
@@ -388,27 +414,26 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
             }
         }
 
-        // lane L finishes tile row (L & 15) * 4 + (L >> 4)
-        const uint32_t mybit = j * 4u + grp;
-        const bool valid = ((mword >> mybit) & 1ull) != 0;
-        const uint64_t myrow = r0 + mybit;
-        const float sr = valid ? p.i8_scale[myrow] : 0.f;
-        float vn = 1.f;  // cosine: |v| in reference order; Euclidean: |v~|^2 of the row as stored
-        if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? p.norms[myrow] : 1.f;
-        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn = valid ? p.i8_vv[myrow] : 0.f;
+        const float sr = valid ? sr_raw : 0.f;
+        float vn = 1.f;
+        if constexpr (METRIC == NMN_METRIC_COSINE) vn = valid ? vn_raw : 1.f;
+        if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vn = valid ? vn_raw : 0.f;
+        // (the arithmetic runs for every query slot, only the stores are guarded: see the pipelined loop above)
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            if (q0 + q >= p.nq) break;
+            const bool q_ok = q0 + q < p.nq;
             const float dot = mydot[q] * (qsc[q] * sr);
             float sc;
             if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
-            else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = l2_from_dot(qq8[q], vn, dot, neg);
+            else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = qq8[q] < 0.f ? l2_from_dot(qmag[q] * qmag[q], vb * vb, dot, neg) : l2_from_dot(qq8[q], vn, dot, neg);
             else sc = dot;
             const uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
-            p.scores[score_at(myrow, q0 + q, p.nql)] = valid ? f2u(sc) : kScoreSentinelBits;
             const uint32_t m = wave_max_u32(key);
-            if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tile] = m;
-            wmax[q] = max(wmax[q], m);
+            if (q_ok) {
+                p.scores[score_at(myrow, q0 + q, p.nql)] = valid ? f2u(sc) : kScoreSentinelBits;
+                if (lane == 0) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tile] = m;
+                wmax[q] = max(wmax[q], m);
+            }
         }
     }
     if (lane == 0) {

@@ -297,6 +297,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                 st.cand_count = c > p.cand_cap ? 0u : c;
                 p.qstate[q] = st;
                 if (p.count_overflows && p.half_stats && st.overflow) atomicAdd(p.half_stats + 1, 1u);
+                if (p.l2_hint && q == 0) {  // the threshold DISTANCE of this selection (score 1 / (1 + d)): qprep's estimator choice
+                    const float tau = key_to_score(Tc);
+                    *p.l2_hint = (tau > 0.0f && tau <= 1.0f) ? 1.0f / tau - 1.0f : 0.0f;
+                }
             }
             done = true;
         }
@@ -404,6 +408,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         st.cand_count = over ? 0u : c;
         p.qstate[q] = st;
         if (p.count_overflows && p.half_stats && over) atomicAdd(p.half_stats + 1, 1u);
+        if (p.l2_hint && q == 0) {
+            const float tau = key_to_score(Tc);
+            *p.l2_hint = (tau > 0.0f && tau <= 1.0f) ? 1.0f / tau - 1.0f : 0.0f;
+        }
     }
 }
 

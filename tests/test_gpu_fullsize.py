@@ -89,8 +89,9 @@ def corpus_10Mx768():
 
 
 def test_config3_10Mx768_cosine_top100_batch64(corpus_10Mx768):
-    """BASELINE config 3: 64 queries per call — one matrix-core sweep of the bf16 mirror, every candidate re-scored from
-    the f32 corpus.  All 64 lists are compared with the oracle."""
+    """BASELINE config 3: 64 queries per call — one matrix-core sweep of the 8-bit mirror (and, for the record, of the bf16
+    mirror it replaced: nmn_index_set_mirror(2)), every candidate re-scored from the f32 corpus.  All 64 lists of both sweeps
+    are compared with the oracle."""
     from neumann_amd import GpuFlatIndex
     A = corpus_10Mx768
     n, d = A.shape
@@ -99,14 +100,22 @@ def test_config3_10Mx768_cosine_top100_batch64(corpus_10Mx768):
     with GpuFlatIndex(d, n) as idx:
         idx.fill_synthetic(0x5EED0003, n)
         rows, scores, counts, st = idx.search(Q, k, 0, with_stats=True)
-        assert st.bytes_scanned == n * d * 2, "a 64-query batch sweeps the bf16 mirror"
+        assert st.bytes_scanned == n * d, "a 64-query batch sweeps the 8-bit mirror"
+        idx.set_mirror(2)
+        rows2, scores2, counts2, st2 = idx.search(Q, k, 0, with_stats=True)
+        assert st2.bytes_scanned == n * d * 2, "nmn_index_set_mirror(2): the bf16 mirror"
+        assert np.array_equal(rows2, rows) and np.array_equal(scores2.view(np.uint32), scores.view(np.uint32)) and np.array_equal(counts2, counts)
         for qi in range(nq):
             er, es = _oracle(A, Q[qi], k, 0, literal=qi in (0, 63))
             _check_query(rows, scores, counts, qi, er, es)
-        # the headline configuration on the same corpus: one query per call (VALU sweep), f32 sweep included
-        for qi in (0, 63):
-            r1, s1, c1 = idx.search(Q[qi], k, 0)
-            assert np.array_equal(r1[0], rows[qi]) and np.array_equal(s1[0].view(np.uint32), scores[qi].view(np.uint32))
+        # the headline configuration on the same corpus: one query per call — over the 8-bit mirror (the default), the bf16 mirror
+        # and the f32 corpus
+        for mode, nbytes in ((1, 1), (2, 2), (0, 4)):
+            idx.set_mirror(mode)
+            for qi in (0, 63):
+                r1, s1, c1, st1 = idx.search(Q[qi], k, 0, with_stats=True)
+                assert st1.bytes_scanned == n * d * nbytes
+                assert np.array_equal(r1[0], rows[qi]) and np.array_equal(s1[0].view(np.uint32), scores[qi].view(np.uint32))
 
 
 def test_config4_shape_eight_shards_of_10Mx768_merge_to_unsharded(corpus_10Mx768):

@@ -235,3 +235,32 @@ def test_large_shard_batch_with_sampling_pass_and_planted_ties():
             for qi in (0, 1, 7, 8, 33, 63):
                 er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
                 assert np.array_equal(rows[qi], er) and np.array_equal(scores[qi].view(np.uint32), es.view(np.uint32)), (metric, qi)
+
+
+def test_euclidean_estimator_follows_the_data():
+    """qprep picks the 8-bit sweep's Euclidean estimator per query from the shard's previous threshold distance: between the
+    stored representations (error bounded in distance space: tight for near neighbours) or |q|^2 + |v|^2 - 2 q~.v~ with exact
+    magnitudes (bounded in squared-distance space: tighter when the k-th neighbour is farther than |q|, i.e. on uncorrelated
+    rows).  Either way the answer is the oracle's; on uncorrelated rows the second query must need fewer candidates than
+    the first (which had no history), on clustered rows the choice must not cost exactness."""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 300_000, 768, 200
+    A = oc.synth(0x51, 0, n, d, nthreads=8)
+    Q = oc.synth(0x52, 0, 4, d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(0x51, n)
+        c = [check(idx, A, Q[i], k, 1, expect_bytes=1).candidates_rescored for i in range(4)]
+        assert c[1] < c[0] and c[2] < c[0] and c[3] < c[0], c
+        keep = np.random.default_rng(2).random(n) < 0.2
+        check(idx, A, Q[0], k, 1, mask=oc.mask_from_bool(keep), expect_bytes=1)
+        check(idx, A, Q[:2], k, 1, expect_bytes=1)      # two queries per sweep
+    rng = np.random.default_rng(8)
+    centres = (rng.standard_normal((64, d)) * 3.0).astype(np.float32)
+    B = (centres[rng.integers(0, 64, n)] + np.float32(0.05) * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(B)
+        for i in range(4):
+            q = centres[i] + np.float32(0.02) * rng.standard_normal(d).astype(np.float32)
+            check(idx, B, q, k, 1, expect_bytes=1)
+        check(idx, B, Q[0], k, 1, expect_bytes=1)       # a far query after near ones, and back
+        check(idx, B, centres[9], k, 1, expect_bytes=1)

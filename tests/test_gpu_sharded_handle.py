@@ -116,7 +116,7 @@ def test_batched_queries_and_stats():
         sh.fill_synthetic(41, n)
         sh.set_timing(True)
         rows, scores, counts, st = sh.search(Q, k, 0, with_stats=True)
-        assert st.rows_scanned == n and st.bytes_scanned == n * d * 2 and st.scan_ms > 0
+        assert st.rows_scanned == n and st.bytes_scanned == n * d and st.scan_ms > 0   # (every shard's batch sweeps its 8-bit mirror)
         assert sh.last_gather_ms() >= 0
         for qi in (0, 31, 63):
             er, es = oc.search(A, Q[qi], k, 0, nthreads=8, partial=True, native=True)
