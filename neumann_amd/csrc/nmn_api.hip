@@ -302,8 +302,8 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
         // (never more than the pass can use: a crowd is at most an eighth of the shard per query)
         w->crowd_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(kCrowdPool, (uint64_t)nq << 17),
                                                     std::max<uint64_t>(idx->cap_pad, (uint64_t)nq * (idx->cap_pad / 8)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_ctr), 3 * nq * 4));
-        HIP_TRY(hipMemset(w->crowd_ctr, 0, 3 * nq * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_ctr), (3 + (size_t)kCrowdMaxGrid) * nq * 4));  // count | offset | fill | per-workgroup counts
+        HIP_TRY(hipMemset(w->crowd_ctr, 0, (3 + (size_t)kCrowdMaxGrid) * nq * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_rows), (size_t)w->crowd_cap * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->crowd_scores), (size_t)w->crowd_cap * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->fb_hist), (6 * 2048 + 2) * 4));
@@ -1017,8 +1017,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
                 sel.k_extra = w->k_extra;
             }
-            HIP_TRY(launch_select(sel, stream));
             const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && !no_crowd();
+            sel.crowd_follows = crowd ? 1 : 0;
+            HIP_TRY(launch_select(sel, stream));
             if (crowd) {  // three launches that return at once unless a candidate list overflowed
                 CrowdParams cp{};
                 cp.qstate = w->qstate;
@@ -1032,6 +1033,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 cp.count = w->crowd_ctr;
                 cp.offset = w->crowd_ctr + w->nq_cap;
                 cp.fill = w->crowd_ctr + 2 * (size_t)w->nq_cap;
+                cp.wg_count = w->crowd_ctr + 3 * (size_t)w->nq_cap;
                 cp.pool_rows = w->crowd_rows;
                 cp.pool_scores = w->crowd_scores;
                 cp.pool_cap = w->crowd_cap;
@@ -1049,6 +1051,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel2.retry_follows = 0;
                 sel2.fb_sync_reset = nullptr;
                 sel2.l2_hint = nullptr;
+                sel2.crowd_follows = 0;
                 HIP_TRY(launch_select(sel2, stream));
             }
 

@@ -172,6 +172,7 @@ struct SelectParams {
     uint32_t* half_stats;      // nullable [2]: queries selected on the bf16 mirror / of those, queries that needed the retry
     int retry_follows;         // 1: an f32 retry sweep follows this selection (it may flag a query as not worth retrying)
     unsigned long long* fb_sync_reset;  // nullable [2]: counters of the fallback_select launch that follows, zeroed here
+    int crowd_follows;         // 1: the crowd kernels run behind this selection (it may hand a query with many tiles over to them early)
     float* l2_hint;            // nullable: query 0's threshold distance is left here (feeds qprep's choice of the 8-bit Euclidean estimator)
     int count_overflows;       // 1: half_stats[1] counts the queries whose candidate list overflowed in THIS selection (batched 8-bit
                                // sweeps have no f32 retry whose selections could be counted)
@@ -197,11 +198,13 @@ struct CrowdParams {
     uint64_t n_rows;
     uint32_t* count;           // [nq] rows found (zeroed between searches by the alloc kernel)
     uint32_t* offset;          // [nq] slice start in the pool
-    uint32_t* fill;            // [nq] append cursor
+    uint32_t* fill;            // [nq] append cursor (unused since the per-workgroup slice parts: kept zeroed)
+    uint32_t* wg_count;        // [nq][kCrowdMaxGrid] rows found per workgroup of the count launch = where each workgroup's part of the slice starts
     uint32_t* pool_rows;       // [pool_cap]
     float* pool_scores;        // [pool_cap] exact scores (crowd_rescore)
     uint32_t pool_cap;
 };
+constexpr uint32_t kCrowdMaxGrid = 512;  // workgroups per query of the count / fill launches
 hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s);  // count -> allocate slices -> fill
 
 // Device-wide exact-fallback selection (nmn_select.hip: fallback_select_kernel), shards of >= 2^18 rows
