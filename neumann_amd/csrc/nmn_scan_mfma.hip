@@ -565,7 +565,9 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                             if constexpr (I8) {
                                 const v4i av = __builtin_bit_cast(v4i, a[ks][rb]);
                                 ach[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, bhi[kc * kSteps + ks][qg]), ach[rb][qg], 0, 0, 0);
+#ifndef NMN_MFMA_I8_NO_LO  // (measurement build: the sweep without the l plane's products — wrong answers, timing only)
                                 acl[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, blo[kc * kSteps + ks][qg]), acl[rb][qg], 0, 0, 0);
+#endif
                             } else {
                                 acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
                             }
