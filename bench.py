@@ -488,9 +488,11 @@ def next_rows_child(args):
         centers = rng.standard_normal((C_, d)).astype(np.float32) * np.float32(2.0)
         pool = rng.standard_normal((8192, d)).astype(np.float32)
 
-        def rows_of(a, b):
-            i = np.arange(a, b, dtype=np.int64)
-            return centers[(i * 2654435761 >> 9) % C_] + pool[(i * 40503 + 17) % 8192]
+        def rows_of(a, b):  # cluster centre + a noise vector from a pool + a per-row nudge (no two rows identical: exact ties make a
+            i = np.arange(a, b, dtype=np.int64)  # probe re-fetch its list until the run of equal distances ends)
+            r = centers[(i * 2654435761 >> 9) % C_] + pool[(i * 40503 + 17) % 8192]
+            r[:, 0] += ((i % 100003) * np.float32(1e-5)).astype(np.float32)
+            return r
 
         t0 = time.perf_counter()
         ivf = GpuIvfFlat.build(rows_of(0, tn), C_, nprobe=nprobe, max_iterations=3, seed=42, init_method="kmeans++", capacity_rows=rn)

@@ -475,6 +475,12 @@ nmn_status nmn_ivf_cluster_sizes(nmn_ivf* ivf, uint64_t* out_sizes /* [n_cluster
  *   out_counts nq = min(k, vectors in the probed lists).  Synchronous. */
 nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_t nq, uint32_t k, uint32_t nprobe,
                           uint64_t* out_ids, float* out_distances, uint32_t* out_counts, nmn_search_stats* stats);
+/* Vectors (ids [0, n)) the LIST-MAJOR copy covers: the reference keeps a Vec of entries per list (ivf.rs:160-175), and so
+ * does the device — a second copy of the vectors ordered by list, over which a probe reads contiguous row ranges and no
+ * per-row array; laid out after nmn_ivf_build / nmn_ivf_load and again whenever the vectors added since make up an eighth of
+ * it (those are scanned through a bitmap over the id-ordered rows meanwhile).  0: no copy (fewer than 4096 vectors, or no
+ * HBM for it) — every probe goes through the bitmap.  Results are the same either way. */
+uint64_t nmn_ivf_list_major_rows(const nmn_ivf* ivf);
 /* The flat index holding the vectors (exhaustive search over the same rows, stats, ...). */
 nmn_index* nmn_ivf_vectors(nmn_ivf* ivf);
 

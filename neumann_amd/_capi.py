@@ -138,6 +138,7 @@ SIGNATURES = {
     "nmn_ivf_centroids": (C.c_int32, [vp, vp, C.c_uint64]),
     "nmn_ivf_add": (C.c_int32, [vp, vp, C.c_uint64, vp]),
     "nmn_ivf_len": (C.c_uint64, [vp]),
+    "nmn_ivf_list_major_rows": (C.c_uint64, [vp]),
     "nmn_ivf_clusters": (C.c_uint32, [vp]),
     "nmn_ivf_cluster_sizes": (C.c_int32, [vp, vp]),
     "nmn_ivf_search": (C.c_int32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(SearchStats)]),

@@ -928,6 +928,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }();
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
             sp.metric = (int)metric;
+            sp.strided = (!use_mfma && mask_dev) ? 1u : 0u;  // masked VALU sweeps: a wave takes every W-th tile (runs of selected rows spread over all waves)
             sp.tile_step = 1;
             sp.skip_key = nullptr;
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));
@@ -999,6 +1000,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.tmax_stride = w->tmax_stride;
             sel.wmax_stride = kMaxScanWaves;
             sel.tiles_per_wave = sp.tiles_per_wave;
+            sel.strided = sp.strided;
             sel.n_waves = (n_tiles + sp.tiles_per_wave - 1) / sp.tiles_per_wave;
             sel.qinfo = w->qinfo;
             sel.qstate = w->qstate;

@@ -116,6 +116,9 @@ struct ScanParams {
     uint32_t n_tiles;
     uint32_t nq;
     uint32_t tiles_per_wave;
+    uint32_t strided;        // VALU sweeps: 0 = wave w owns the tiles [w * tiles_per_wave, ...) (a contiguous range); 1 = the tiles
+                             // w, w + W, w + 2W, ... (W = scan waves): what masked sweeps use — a selection that is a few RUNS of rows
+                             // (an IVF list in the list-major copy, a WHERE over a time range) would otherwise land on a few waves
     uint32_t bx_base, bx_count;  // MFMA sweep: this launch covers workgroups [bx_base, bx_base + bx_count) (0 = to the end)
     int metric;
 };
@@ -157,6 +160,7 @@ struct SelectParams {
     uint64_t wmax_stride;
     uint32_t n_waves;        // scan waves that own tiles (<= kMaxScanWaves)
     uint32_t tiles_per_wave;
+    uint32_t strided;        // as ScanParams::strided: tile j of wave w is j * n_waves + w instead of w * tiles_per_wave + j
     const QInfo* qinfo;
     QState* qstate;
     uint32_t* cand_rows;     // [nq][cand_cap]

@@ -130,18 +130,60 @@ __global__ __launch_bounds__(1024) void ivf_rank_kernel(const uint32_t* __restri
     if (tid == 0) *probe_count = total;
 }
 
+// rows [row_lo, n_rows) whose list is probed (the rows below row_lo are served by the list-major copy)
 __global__ __launch_bounds__(256) void ivf_mask_kernel(const uint32_t* __restrict__ assign,
-                                                       const uint32_t* __restrict__ probe_rank, uint64_t n_rows,
+                                                       const uint32_t* __restrict__ probe_rank, uint64_t n_rows, uint64_t row_lo,
                                                        uint64_t* __restrict__ mask) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t n_words = (n_rows + 63) >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t w = wave; w < n_words; w += n_waves) {
+        uint64_t word = 0ull;
+        if (((w + 1) << 6) > row_lo) {  // (wave-uniform: words entirely below row_lo read nothing)
+            const uint64_t row = (w << 6) + lane;
+            const bool in = row >= row_lo && row < n_rows && probe_rank[assign[row]] != kNoRank;
+            word = __ballot(in);
+        }
+        if (lane == 0) mask[w] = word;
+    }
+}
+
+// The same selection over the LIST-MAJOR copy: its rows [list_off[c], list_off[c + 1]) are list c, so a probed list is a run of
+// set bits and the list scan streams contiguous rows.  No per-row array is read: a lane finds its row's list by bisecting the
+// (n_clusters + 1)-entry offset table.
+__global__ __launch_bounds__(256) void ivf_range_mask_kernel(const uint32_t* __restrict__ list_off, uint32_t n_clusters,
+                                                             const uint32_t* __restrict__ probe_rank, uint64_t n_rows,
+                                                             uint64_t* __restrict__ mask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_words = (n_rows + 63) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t w = wave; w < n_words; w += n_waves) {
         const uint64_t row = (w << 6) + lane;
-        const bool in = row < n_rows && probe_rank[assign[row]] != kNoRank;
+        bool in = false;
+        if (row < n_rows) {
+            uint32_t lo = 0, hi = n_clusters;  // the list c with list_off[c] <= row < list_off[c + 1]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (list_off[mid] <= (uint32_t)row) lo = mid;
+                else hi = mid;
+            }
+            in = probe_rank[lo] != kNoRank;
+        }
         const uint64_t word = __ballot(in);
         if (lane == 0) mask[w] = word;
+    }
+}
+
+// dst[i][0 .. dim) = src[perm[pos0 + i]][0 .. dim): rows of the id-ordered corpus (stride ld) gathered into a tight block
+__global__ __launch_bounds__(256) void ivf_gather_kernel(const float* __restrict__ src, uint32_t ld, uint32_t dim,
+                                                         const uint32_t* __restrict__ perm, uint64_t pos0, uint32_t cnt,
+                                                         float* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        const float* row = src + (uint64_t)perm[pos0 + i] * ld;
+        float* out = dst + (uint64_t)i * dim;
+        for (uint32_t c = threadIdx.x; c < dim; c += 256) out[c] = row[c];
     }
 }
 
@@ -153,6 +195,17 @@ struct nmn_ivf {
     uint32_t n_clusters = 0, dim = 0;
     int device = 0;
     uint64_t cap = 0;
+    // The same vectors a second time in LIST-MAJOR order (the reference's IVFStorage::Flat keeps a Vec per list, ivf.rs:160-175):
+    // the rows of list 0, then list 1, ..., ids ascending inside a list.  A probe over it reads contiguous row ranges instead of
+    // a bitmap's worth of scattered rows, and no per-row side array at all.  Rebuilt (ivf_relayout) after a build / load and
+    // when the vectors added since make up an eighth of it; those younger vectors are scanned in `vectors` through the bitmap.
+    nmn_index* cvec = nullptr;
+    uint64_t c_rows = 0;                 // ids [0, c_rows) are in cvec
+    std::vector<uint32_t> perm_host;     // cvec row -> id
+    std::vector<uint32_t> list_off_host; // [n_clusters + 1] first cvec row of every list
+    uint32_t* list_off = nullptr;        // device copy
+    bool cvec_failed = false;            // no HBM for the copy: probes stay on the bitmap over `vectors`
+    uint32_t flags = 0, cand_cap = 0;    // of the nmn_index_desc the index was created with
     uint32_t* assign = nullptr;          // device [cap]
     std::vector<uint32_t> assign_host;   // same, for cluster_sizes and the tie order of equal distances
     std::vector<float> centroids_host;   // trained centroids (nmn_ivf_build), row-major n_clusters x dim
@@ -184,6 +237,7 @@ struct nmn_ivf {
         uint32_t* probe_count = nullptr;
         uint32_t* probe_rank = nullptr;
         uint64_t* mask = nullptr;
+        uint64_t* mask_c = nullptr;      // selection over the list-major copy
         float* qraw = nullptr;
         float* qpad = nullptr;
         QInfo* qinfo = nullptr;
@@ -212,7 +266,7 @@ extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
     for (void* p : {(void*)ivf->assign, (void*)ivf->cscores, (void*)ivf->ckeys, (void*)ivf->probe_rows,
                     (void*)ivf->probe_scores, (void*)ivf->probe_count, (void*)ivf->probe_rank, (void*)ivf->mask,
                     (void*)ivf->qraw, (void*)ivf->qpad, (void*)ivf->qinfo, (void*)ivf->qstate, (void*)ivf->assign_tmp,
-                    })
+                    (void*)ivf->list_off})
         if (p) (void)hipFree(p);
     for (auto& sl : ivf->slots) {
         if (sl->stream) {
@@ -220,12 +274,13 @@ extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
             (void)hipStreamDestroy(sl->stream);
         }
         for (void* p : {(void*)sl->cscores, (void*)sl->ckeys, (void*)sl->probe_rows, (void*)sl->probe_scores,
-                        (void*)sl->probe_count, (void*)sl->probe_rank, (void*)sl->mask, (void*)sl->qraw, (void*)sl->qpad,
+                        (void*)sl->probe_count, (void*)sl->probe_rank, (void*)sl->mask, (void*)sl->mask_c, (void*)sl->qraw, (void*)sl->qpad,
                         (void*)sl->qinfo, (void*)sl->qstate})
             if (p) (void)hipFree(p);
         if (sl->pin) (void)hipHostFree(sl->pin);
     }
     if (ivf->stream) (void)hipStreamDestroy(ivf->stream);
+    if (ivf->cvec) nmn_index_destroy(ivf->cvec);
     if (ivf->vectors) nmn_index_destroy(ivf->vectors);
     if (ivf->centroids) nmn_index_destroy(ivf->centroids);
     delete ivf;
@@ -255,6 +310,8 @@ static nmn_status ivf_new(const nmn_index_desc* desc, const float* centroids, ui
         if (st != NMN_OK) return bail(st);
     }
     ivf->n_clusters = n_clusters;
+    ivf->flags = desc->flags;
+    ivf->cand_cap = desc->cand_cap;
     ivf->dim = desc->dim;
     ivf->device = ivf->vectors->device;
     ivf->cap = ivf->vectors->cap;
@@ -351,6 +408,74 @@ static nmn_status assign_rows(nmn_ivf* ivf, uint64_t row0, uint64_t n) {
     return NMN_OK;
 }
 
+// (Re)build the list-major copy from the id-ordered vectors and their list assignments.  Caller holds ivf->rw exclusively.
+// A stable counting sort of the assignments gives the permutation; the rows are gathered on the device 128 Ki rows at a time
+// and go through the ordinary device upload (magnitudes, mirrors).  Not enough HBM for the copy is not an error.
+static nmn_status ivf_relayout(nmn_ivf* ivf) {
+    static const bool disabled = getenv("NMN_IVF_NO_LIST_MAJOR") != nullptr;  // A/B: every probe through the bitmap over `vectors`
+    const uint64_t n = ivf->vectors->rows;
+    if (disabled || ivf->cvec_failed || n < 4096 || ivf->assign_host.size() < n) return NMN_OK;
+    IVF_TRY(hipSetDevice(ivf->device));
+    if (!ivf->cvec) {
+        nmn_index_desc d{};
+        d.dim = ivf->dim;
+        d.flags = ivf->flags;
+        d.capacity_rows = ivf->cap;
+        d.row_base = 0;
+        d.device = ivf->device;
+        d.cand_cap = ivf->cand_cap;
+        if (nmn_index_create(&d, &ivf->cvec) != NMN_OK || ivf->cvec->ld != ivf->vectors->ld) {
+            if (ivf->cvec) nmn_index_destroy(ivf->cvec);
+            ivf->cvec = nullptr;
+            ivf->cvec_failed = true;
+            ivf->c_rows = 0;
+            return NMN_OK;
+        }
+    }
+    const uint32_t C = ivf->n_clusters;
+    ivf->list_off_host.assign((size_t)C + 1, 0u);
+    for (uint64_t r = 0; r < n; r++) ivf->list_off_host[ivf->assign_host[r] + 1]++;
+    for (uint32_t c = 0; c < C; c++) ivf->list_off_host[c + 1] += ivf->list_off_host[c];
+    ivf->perm_host.resize(n);
+    {
+        std::vector<uint32_t> cur(ivf->list_off_host.begin(), ivf->list_off_host.end() - 1);
+        for (uint64_t r = 0; r < n; r++) ivf->perm_host[cur[ivf->assign_host[r]]++] = (uint32_t)r;  // ids ascending inside a list
+    }
+    constexpr uint64_t kChunk = 128 * 1024;
+    uint32_t* perm_dev = nullptr;
+    float* tmp = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&perm_dev), n * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tmp), std::min(kChunk, n) * (uint64_t)ivf->dim * 4);
+    if (e == hipSuccess && !ivf->list_off) e = hipMalloc(reinterpret_cast<void**>(&ivf->list_off), ((size_t)C + 1) * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(perm_dev, ivf->perm_host.data(), n * 4, hipMemcpyHostToDevice, ivf->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ivf->list_off, ivf->list_off_host.data(), ((size_t)C + 1) * 4, hipMemcpyHostToDevice, ivf->stream);
+    nmn_status st = NMN_OK;
+    for (uint64_t pos0 = 0; pos0 < n && e == hipSuccess && st == NMN_OK; pos0 += kChunk) {
+        const uint32_t cnt = (uint32_t)std::min(kChunk, n - pos0);
+        hipLaunchKernelGGL(ivf_gather_kernel, dim3(std::min<uint32_t>(cnt, 4096)), dim3(256), 0, ivf->stream, ivf->vectors->corpus,
+                           ivf->vectors->ld, ivf->dim, perm_dev, pos0, cnt, tmp);
+        e = hipGetLastError();
+        if (e == hipSuccess) st = nmn_index_upload_device(ivf->cvec, tmp, pos0, cnt, ivf->stream);
+        if (e == hipSuccess && st == NMN_OK) e = hipStreamSynchronize(ivf->stream);  // (`tmp` is reused by the next chunk)
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ivf->stream);
+    if (perm_dev) (void)hipFree(perm_dev);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess || st != NMN_OK) {
+        // (out of memory half way, ...): drop the copy, keep serving from the bitmap over `vectors`
+        (void)hipGetLastError();
+        nmn_index_destroy(ivf->cvec);
+        ivf->cvec = nullptr;
+        ivf->cvec_failed = true;
+        ivf->c_rows = 0;
+        return NMN_OK;
+    }
+    ivf->c_rows = n;
+    return NMN_OK;
+}
+
+extern "C" uint64_t nmn_ivf_list_major_rows(const nmn_ivf* ivf) { return ivf ? ivf->c_rows : 0; }
+
 extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t n, uint32_t* clusters_out) {
     if (!ivf || (n && !rows_host)) return set_error(NMN_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return NMN_OK;
@@ -363,6 +488,10 @@ extern "C" nmn_status nmn_ivf_add(nmn_ivf* ivf, const float* rows_host, uint64_t
     st = assign_rows(ivf, row0, n);
     if (st != NMN_OK) return st;
     if (clusters_out) memcpy(clusters_out, ivf->assign_host.data() + row0, n * 4);
+    // the vectors added since the list-major copy was laid out are scanned through the bitmap; once they are an eighth of it
+    // (or there is no copy yet and the index is worth one) it is laid out afresh
+    const uint64_t rows = row0 + n, young = rows - ivf->c_rows;
+    if (young >= std::max<uint64_t>(4096, ivf->c_rows / 8)) return ivf_relayout(ivf);
     return NMN_OK;
 }
 
@@ -530,6 +659,8 @@ extern "C" nmn_status nmn_ivf_build(const nmn_index_desc* desc, const float* row
     st = assign_rows(ivf, 0, n);
     if (st != NMN_OK) return bail(st);
     ivf->centroids_host = cents;
+    st = ivf_relayout(ivf);
+    if (st != NMN_OK) return bail(st);
     *out = ivf;
     return NMN_OK;
 }
@@ -576,6 +707,7 @@ static nmn_status probe_slot_acquire(nmn_ivf* ivf, nmn_ivf::ProbeSlot** out) {
     alloc(reinterpret_cast<void**>(&sl->probe_count), 8);
     alloc(reinterpret_cast<void**>(&sl->probe_rank), (size_t)ivf->n_clusters * 4);
     alloc(reinterpret_cast<void**>(&sl->mask), ((ivf->cap + 63) / 64 + 1) * 8);
+    alloc(reinterpret_cast<void**>(&sl->mask_c), ((ivf->cap + 63) / 64 + 1) * 8);
     alloc(reinterpret_cast<void**>(&sl->qraw), (size_t)ivf->dim * 4);
     alloc(reinterpret_cast<void**>(&sl->qpad), (size_t)ld * 4);
     alloc(reinterpret_cast<void**>(&sl->qinfo), sizeof(QInfo));
@@ -587,7 +719,7 @@ static nmn_status probe_slot_acquire(nmn_ivf* ivf, nmn_ivf::ProbeSlot** out) {
     if (e != hipSuccess) {
         if (sl->stream) (void)hipStreamDestroy(sl->stream);
         for (void* p : {(void*)sl->cscores, (void*)sl->ckeys, (void*)sl->probe_rows, (void*)sl->probe_scores,
-                        (void*)sl->probe_count, (void*)sl->probe_rank, (void*)sl->mask, (void*)sl->qraw, (void*)sl->qpad,
+                        (void*)sl->probe_count, (void*)sl->probe_rank, (void*)sl->mask, (void*)sl->mask_c, (void*)sl->qraw, (void*)sl->qpad,
                         (void*)sl->qinfo, (void*)sl->qstate})
             if (p) (void)hipFree(p);
         if (sl->pin) (void)hipHostFree(sl->pin);
@@ -672,29 +804,75 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
             hipLaunchKernelGGL(ivf_probe_rank_kernel, dim3((np + 255) / 256), dim3(256), 0, s, sl->probe_rows, sl->probe_count,
                                sl->probe_rank);
         }
-        const uint64_t n_words = (n_rows + 63) / 64;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
-        hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, sl->probe_rank, n_rows, sl->mask);
+        // the selection: over the list-major copy its ids [0, c_rows) — probed lists are runs of rows there — and, for the
+        // vectors added since it was laid out, the bitmap over the id-ordered rows
+        const uint64_t c_rows = ivf->cvec ? std::min(ivf->c_rows, n_rows) : 0;
+        if (c_rows) {
+            const uint64_t cw = (c_rows + 63) / 64;
+            hipLaunchKernelGGL(ivf_range_mask_kernel, dim3((uint32_t)std::min<uint64_t>((cw + 3) / 4, 4096)), dim3(256), 0, s, ivf->list_off,
+                               ivf->n_clusters, sl->probe_rank, c_rows, sl->mask_c);
+        }
+        if (c_rows < n_rows) {
+            const uint64_t n_words = (n_rows + 63) / 64;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
+            hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, sl->probe_rank, n_rows, c_rows, sl->mask);
+        }
         IVF_TRY(hipGetLastError());
         IVF_TRY(hipMemcpyAsync(probe_host, sl->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost, s));
         IVF_TRY(hipStreamSynchronize(s));
         // rows in the probed lists: the selectivity hint of the list scan (how the flat index's coalescer decides what may
         // run side by side) and the most the scan can return
-        uint64_t probed_rows = 0;
+        uint64_t probed_rows = 0, probed_c = 0;
         for (uint32_t i = 0; i < np; i++)
-            if (probe_host[i] < ivf->list_sizes.size()) probed_rows += ivf->list_sizes[probe_host[i]];
+            if (probe_host[i] < ivf->list_sizes.size()) {
+                probed_rows += ivf->list_sizes[probe_host[i]];
+                if (c_rows) probed_c += ivf->list_off_host[probe_host[i] + 1] - ivf->list_off_host[probe_host[i]];
+            }
         if (ivf->list_sizes_rows != n_rows) probed_rows = UINT64_MAX;  // sizes not current (never after add / build)
+        const uint64_t probed_t = (probed_rows == UINT64_MAX) ? UINT64_MAX : probed_rows - std::min(probed_rows, probed_c);
         // 2. masked scan ranking by distance (negated so that nearest = largest).  One result more than asked for: the scan
         //    breaks equal distances by id, the reference by candidate order, so a run of equal distances that straddles
         //    the cut must be seen whole before it is reordered and cut.
         uint64_t kk = std::min<uint64_t>((uint64_t)k + 1, std::max<uint64_t>(n_rows, 1));
         uint32_t cnt = 0;
+        std::vector<uint64_t> part_ids;
+        std::vector<float> part_dist;
         for (;;) {
             tmp_ids.assign(kk, UINT64_MAX);
             tmp_dist.assign(kk, 0.f);
-            st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, sl->mask, true, tmp_ids.data(),
-                                     tmp_dist.data(), &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_rows);
-            if (st != NMN_OK) return st;
+            if (c_rows) {  // the list-major copy: results are ITS rows, mapped back to ids
+                st = index_search_hostio(ivf->cvec, qh, 1, (uint32_t)kk, kMetricNegL2, sl->mask_c, true, tmp_ids.data(), tmp_dist.data(),
+                                         &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_c);
+                if (st != NMN_OK) return st;
+                for (uint32_t i = 0; i < cnt; i++) tmp_ids[i] = ivf->vectors->row_base + ivf->perm_host[tmp_ids[i]];
+            }
+            if (c_rows < n_rows) {  // the younger vectors, in id order
+                uint32_t cnt_t = 0;
+                part_ids.assign(kk, UINT64_MAX);
+                part_dist.assign(kk, 0.f);
+                st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, sl->mask, true, part_ids.data(), part_dist.data(),
+                                         &cnt_t, (stats && q + 1 == nq && !c_rows) ? stats : nullptr, probed_t);
+                if (st != NMN_OK) return st;
+                if (!c_rows) {
+                    tmp_ids.swap(part_ids);
+                    tmp_dist.swap(part_dist);
+                    cnt = cnt_t;
+                } else if (cnt_t) {
+                    // merge the two lists (each best first: score = -distance descending, ties by id) and keep kk
+                    std::vector<uint64_t> mi(kk, UINT64_MAX);
+                    std::vector<float> md(kk, 0.f);
+                    uint32_t a = 0, b = 0, o = 0;
+                    while (o < kk && (a < cnt || b < cnt_t)) {
+                        const bool take_a = b >= cnt_t || (a < cnt && (tmp_dist[a] > part_dist[b] || (tmp_dist[a] == part_dist[b] && tmp_ids[a] < part_ids[b])));
+                        if (take_a) { mi[o] = tmp_ids[a]; md[o] = tmp_dist[a]; a++; }
+                        else { mi[o] = part_ids[b]; md[o] = part_dist[b]; b++; }
+                        o++;
+                    }
+                    tmp_ids.swap(mi);
+                    tmp_dist.swap(md);
+                    cnt = o;
+                }
+            }
             const bool cut_inside_run = cnt > k && tmp_dist[k] == tmp_dist[k - 1];
             // the run is seen whole as soon as it ENDS inside the fetched list (its last fetched entry differs from the
             // k-th); only a run that reaches the end of a full list may continue beyond it
@@ -816,6 +994,11 @@ nmn_status persist_read_ivf(FILE* fp, const char* path, const PersistHeader& h, 
     ivf->list_sizes.assign(n_clusters, 0);
     for (uint32_t a : ivf->assign_host) ivf->list_sizes[a]++;
     ivf->list_sizes_rows = h.rows;
+    st = ivf_relayout(ivf);  // (the file holds the vectors in id order; the list-major copy is derived like after a build)
+    if (st != NMN_OK) {
+        nmn_ivf_destroy(ivf);
+        return st;
+    }
     *out = ivf;
     return NMN_OK;
 }

@@ -168,9 +168,11 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t j = lane & 15u, grp = lane >> 4;
-    const uint32_t t0 = wave * p.tiles_per_wave;
-    if (t0 >= p.n_tiles) return;
-    const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+    // the wave's tiles: a contiguous range, or (p.strided: masked sweeps) every W-th tile starting at its own number
+    const uint32_t n_waves_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    const bool strided = MASKED && p.strided != 0;
+    if (wave >= n_waves_all) return;
+    auto tile_at = [&](uint32_t jt) -> uint32_t { return strided ? jt * n_waves_all + wave : wave * p.tiles_per_wave + jt; };
     const v4f* qs4 = reinterpret_cast<const v4f*>(qs);
 
     float qmag[NQ];
@@ -182,14 +184,18 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
     for (int q = 0; q < NQ; q++) wmax[q] = kKeyMasked;
 
     uint64_t mcache = 0;
-    for (uint32_t tile = t0; tile < t1; tile++) {
+    for (uint32_t rel = 0; rel < p.tiles_per_wave; rel++) {
+        const uint32_t tile = tile_at(rel);
+        if (tile >= p.n_tiles) break;
         const uint64_t r0 = (uint64_t)tile * kTileRows;
         uint64_t mword = ~0ull;
         if constexpr (MASKED) {
-            // the wave's bitmap words are fetched 64 tiles at a time (lane L keeps the word of tile base+L): a word per tile
+            // the wave's bitmap words are fetched 64 tiles at a time (lane L keeps the word of its tile rel + L): a word per tile
             // from memory put one more load latency on every tile's dependent chain (word -> row addresses -> rows)
-            const uint32_t rel = tile - t0;
-            if ((rel & 63u) == 0) mcache = tile + lane < t1 ? p.mask[tile + lane] : 0ull;
+            if ((rel & 63u) == 0) {
+                const uint32_t tl = tile_at(rel + lane);
+                mcache = (rel + lane < p.tiles_per_wave && tl < p.n_tiles) ? p.mask[tl] : 0ull;
+            }
             const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)(rel & 63u));
             const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)(rel & 63u));
             mword = ((uint64_t)hi << 32) | lo;

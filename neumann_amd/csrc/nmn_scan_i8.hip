@@ -185,9 +185,13 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t j = lane & 15u, grp = lane >> 4;
+    // the wave's tiles: a contiguous range [t0, t1), or (p.strided: masked sweeps) every W-th tile starting at its own number
+    const uint32_t n_waves_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    const bool strided = MASKED && p.strided != 0;
+    if (wave >= n_waves_all) return;
     const uint32_t t0 = wave * p.tiles_per_wave;
-    if (t0 >= p.n_tiles) return;
     const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+    auto tile_at = [&](uint32_t jt) -> uint32_t { return strided ? jt * n_waves_all + wave : t0 + jt; };
     const v4i* qs4 = reinterpret_cast<const v4i*>(qsi);
     const int8_t* const mat = p.corpus_i8;
 
@@ -322,12 +326,16 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
     }
 #endif
     uint64_t mcache = 0;
-    for (uint32_t tile = t0; tile < t1; tile++) {
+    for (uint32_t rel = 0; rel < p.tiles_per_wave; rel++) {
+        const uint32_t tile = tile_at(rel);
+        if (tile >= p.n_tiles) break;
         const uint64_t r0 = (uint64_t)tile * kTileRows;
         uint64_t mword = ~0ull;
         if constexpr (MASKED) {  // the wave's bitmap words, 64 tiles at a time (as scan_kernel)
-            const uint32_t rel = tile - t0;
-            if ((rel & 63u) == 0) mcache = tile + lane < t1 ? p.mask[tile + lane] : 0ull;
+            if ((rel & 63u) == 0) {
+                const uint32_t tl = tile_at(rel + lane);
+                mcache = (rel + lane < p.tiles_per_wave && tl < p.n_tiles) ? p.mask[tl] : 0ull;
+            }
             const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)(rel & 63u));
             const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)(rel & 63u));
             mword = ((uint64_t)hi << 32) | lo;

@@ -193,6 +193,8 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t* tmax = p.tmax + (uint64_t)q * p.tmax_stride;
     const uint32_t* wmax = p.wmax + (uint64_t)q * p.wmax_stride;
     const uint32_t W = p.n_waves, tpw = p.tiles_per_wave, n_tiles = p.n_tiles;
+    const bool strided = p.strided != 0;
+    auto tile_of = [&](uint32_t w, uint32_t j) -> uint32_t { return strided ? j * W + w : w * tpw + j; };  // tile j of scan wave w
     const QInfo qi = p.qinfo[q];
     uint32_t* out = p.cand_rows + (size_t)q * p.cand_cap;
     // rank of the threshold: k, plus (f64 artifact similarity only) the rows whose approximate score is forced to
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 #pragma unroll
             for (int u = 0; u < V; u++) {
                 const uint32_t e = e0 + (uint32_t)u * kSelThreads;
-                tt[u] = e < slots ? la[e / tpw] * tpw + e % tpw : 0xFFFFFFFFu;
+                tt[u] = e < slots ? tile_of(la[e / tpw], e % tpw) : 0xFFFFFFFFu;
                 tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
             }
 #pragma unroll
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         __syncthreads();
         const uint32_t slots = s_w[1] * tpw;
         auto tile_key = [&](uint32_t e) -> uint32_t {
-            const uint32_t t = la[e / tpw] * tpw + e % tpw;
+            const uint32_t t = tile_of(la[e / tpw], e % tpw);
             const uint32_t key = t < n_tiles ? tmax[t] : kKeyMasked;
             return key >= Twm ? key : kKeyMasked;
         };
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 #pragma unroll
             for (int u = 0; u < V; u++) {
                 const uint32_t e = e0 + (uint32_t)u * kSelThreads;
-                tt[u] = e < slots ? la[e / tpw] * tpw + e % tpw : 0xFFFFFFFFu;
+                tt[u] = e < slots ? tile_of(la[e / tpw], e % tpw) : 0xFFFFFFFFu;
                 tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
             }
 #pragma unroll
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         uint32_t ties = 0;
         const uint32_t slots = W * tpw;
         for (uint32_t e = tid; e < slots; e += kSelThreads) {
-            const uint32_t i = e / tpw, t = e;  // (tile t belongs to wave t / tpw)
+            const uint32_t i = e / tpw, t = tile_of(i, e % tpw);
             if (wk[i] == top && t < n_tiles && tmax[t] == top) ties++;
         }
         if (ties) atomicAdd(&s_w[0], ties);

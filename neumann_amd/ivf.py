@@ -85,6 +85,11 @@ class GpuIvfFlat:
         except Exception:
             pass
 
+    @property
+    def list_major_rows(self):
+        """vectors covered by the list-major copy (0: every probe goes through the bitmap over the id-ordered rows)"""
+        return int(self._lib.nmn_ivf_list_major_rows(self._h))
+
     def __len__(self):
         return int(self._lib.nmn_ivf_len(self._h))
 

@@ -17,12 +17,12 @@ def create_test_vectors(n, dim):  # ivf.rs:569-577
 FAST = dict(max_iterations=2, convergence_threshold=1.0, seed=42, init_method="random")  # ivf.rs:589-596
 
 
-def build_pair(vectors, num_clusters, nprobe=None, kmeans=None, train=None):
+def build_pair(vectors, num_clusters, nprobe=None, kmeans=None, train=None, spare=64):
     """Oracle index trained on `train` (default: the vectors) and a GPU index created from ITS centroids."""
     from neumann_amd.ivf import GpuIvfFlat
     orc = io.IVFFlat(num_clusters, nprobe=nprobe, kmeans=io.KMeansConfig(**(kmeans or FAST)))
     orc.train(vectors if train is None else train)
-    gpu = GpuIvfFlat(orc.centroids, capacity_rows=len(vectors) + 64, nprobe=orc.nprobe)
+    gpu = GpuIvfFlat(orc.centroids, capacity_rows=len(vectors) + spare, nprobe=orc.nprobe)
     return orc, gpu
 
 
@@ -252,3 +252,73 @@ def test_concurrent_probes_equal_sequential_probes(d):
         for j in range(64):
             for a, b in zip(want[j], got[j]):
                 assert np.array_equal(np.asarray(a), np.asarray(b)), j
+
+
+# ---- the list-major copy (round 3) ---------------------------------------------------------------------------------------
+def test_list_major_copy_matches_oracle_through_adds_and_relayouts():
+    """>= 4096 vectors: probes read a second copy of the vectors ordered by list (contiguous ranges) and map its rows back to
+    ids; vectors added since it was laid out are scanned through the bitmap and merged; a new layout happens when they make
+    up an eighth.  Ids, order (probe order of the list, then id, for equal distances) and distances must be the oracle's at
+    every stage — duplicates inside and across the two parts included."""
+    rng = np.random.default_rng(91)
+    n0, d, c = 6000, 64, 24
+    centres = rng.standard_normal((c, d)).astype(F) * F(2.0)
+    def rows(m):
+        return (centres[rng.integers(0, c, m)] + F(0.4) * rng.standard_normal((m, d)).astype(F)).astype(F)
+    V = rows(n0)
+    V[77] = V[5]
+    V[4000] = V[5]
+    orc, gpu = build_pair(V, c, nprobe=5, kmeans=dict(max_iterations=4, convergence_threshold=1e-4, seed=3, init_method="kmeans++"),
+                          train=V[:1500], spare=5000)
+    with gpu:
+        assert gpu.list_major_rows == 0
+        gpu.add(V)
+        for v in V:
+            orc.add(v)
+        assert gpu.list_major_rows == n0                      # laid out by the add that crossed 4096 vectors
+        Q = [V[5], V[123], rows(1)[0], centres[3]]
+        for q in Q:
+            for nprobe in (1, 5, c):
+                check_same(orc, gpu, q, 25, nprobe)
+        young = rows(300)
+        young[7] = V[5]                                        # a copy of an old vector among the young ones: a tie across the parts
+        gpu.add(young)
+        for v in young:
+            orc.add(v)
+        assert gpu.list_major_rows == n0 and len(gpu) == n0 + 300   # not yet an eighth: two-part probes
+        for q in Q + [young[7], young[100]]:
+            for nprobe in (1, 5, c):
+                check_same(orc, gpu, q, 25, nprobe)
+            check_same(orc, gpu, q, 700, 5)                    # k beyond most lists
+        more = rows(3900)
+        gpu.add(more)
+        for v in more:
+            orc.add(v)
+        assert gpu.list_major_rows == n0 + 4200                # 4200 young vectors (>= 4096 and >= an eighth of 6000): laid out afresh
+        for q in Q + [more[3]]:
+            check_same(orc, gpu, q, 25, 5)
+
+
+def test_list_major_copy_after_build_and_after_load(tmp_path):
+    from neumann_amd.ivf import GpuIvfFlat
+    rng = np.random.default_rng(92)
+    n, d, c = 9000, 128, 32
+    V = (rng.standard_normal((c, d))[rng.integers(0, c, n)] * 2.0 + 0.5 * rng.standard_normal((n, d))).astype(F)
+    Q = V[:3] + F(0.01)
+    with GpuIvfFlat.build(V, c, max_iterations=5, seed=7) as ivf:
+        assert ivf.list_major_rows == n
+        want = [ivf.search(Q, 30, nprobe=p) for p in (1, 6, c)]
+        ex = ivf.search(Q, 30, nprobe=c)
+        path = tmp_path / "i.nmnidx"
+        ivf.save(path)
+    with GpuIvfFlat.load(path) as ivf:
+        assert ivf.list_major_rows == n
+        for p, (ids, dist, cnt) in zip((1, 6, c), want):
+            i2, d2, c2 = ivf.search(Q, 30, nprobe=p)
+            assert np.array_equal(i2, ids) and np.array_equal(d2.view(np.uint32), dist.view(np.uint32)) and np.array_equal(c2, cnt)
+    # probing every list is the exhaustive Euclidean search: same ids as the flat index over the same rows
+    from neumann_amd import GpuFlatIndex
+    with GpuFlatIndex(d, n, single_launch=False) as flat:
+        flat.upload(V)
+        rows, scores, counts = flat.search(Q, 30, 1)
+        assert np.array_equal(rows, ex[0])
