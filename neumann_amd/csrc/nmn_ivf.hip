@@ -79,16 +79,21 @@ __global__ void ivf_probe_rank_kernel(const uint64_t* __restrict__ probe_rows, c
 // probe order and probe_rank[cluster] = its rank or kNoRank.  Replaces five launches (keys, 4096-key tile sort, emit,
 // memset, rank scatter: ~50 us of a 370 us probe) by one.
 constexpr uint32_t kRankMax = 4096;
-__global__ __launch_bounds__(1024) void ivf_rank_kernel(const uint32_t* __restrict__ cscores, uint32_t n_clusters,
+// Query blockIdx.x of a chunk of nql queries (their scores interleaved tile-major: score_at): outputs at probe_rows + q * n_clusters,
+// probe_rank + q * n_clusters, probe_count + q.
+__global__ __launch_bounds__(1024) void ivf_rank_kernel(const uint32_t* __restrict__ cscores, uint32_t nql, uint32_t n_clusters,
                                                         uint32_t np2, uint32_t np, uint64_t* __restrict__ probe_rows,
                                                         uint32_t* __restrict__ probe_count,
                                                         uint32_t* __restrict__ probe_rank) {
     __shared__ uint64_t t[kRankMax];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+    probe_rows += (size_t)qi * n_clusters;
+    probe_rank += (size_t)qi * n_clusters;
+    probe_count += qi;
     for (uint32_t i = tid; i < np2; i += 1024) {
         uint64_t key = 0;
         if (i < n_clusters) {
-            const uint32_t sk = bits_to_key(cscores[i]);  // one query per pass: tile-major layout == plain order
+            const uint32_t sk = bits_to_key(cscores[score_at(i, qi, nql)]);
             if (sk != kKeyMasked) key = ((uint64_t)sk << 32) | (uint32_t)~i;
         }
         t[i] = key;
@@ -131,9 +136,12 @@ __global__ __launch_bounds__(1024) void ivf_rank_kernel(const uint32_t* __restri
 }
 
 // rows [row_lo, n_rows) whose list is probed (the rows below row_lo are served by the list-major copy)
+// (query blockIdx.y of a chunk: its ranks at probe_rank + y * n_clusters, its bitmap at mask + y * mask_stride)
 __global__ __launch_bounds__(256) void ivf_mask_kernel(const uint32_t* __restrict__ assign,
-                                                       const uint32_t* __restrict__ probe_rank, uint64_t n_rows, uint64_t row_lo,
-                                                       uint64_t* __restrict__ mask) {
+                                                       const uint32_t* __restrict__ probe_rank, uint32_t n_clusters, uint64_t n_rows,
+                                                       uint64_t row_lo, uint64_t* __restrict__ mask, uint64_t mask_stride) {
+    probe_rank += (size_t)blockIdx.y * n_clusters;
+    mask += (size_t)blockIdx.y * mask_stride;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t n_words = (n_rows + 63) >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -154,7 +162,9 @@ __global__ __launch_bounds__(256) void ivf_mask_kernel(const uint32_t* __restric
 // (n_clusters + 1)-entry offset table.
 __global__ __launch_bounds__(256) void ivf_range_mask_kernel(const uint32_t* __restrict__ list_off, uint32_t n_clusters,
                                                              const uint32_t* __restrict__ probe_rank, uint64_t n_rows,
-                                                             uint64_t* __restrict__ mask) {
+                                                             uint64_t* __restrict__ mask, uint64_t mask_stride) {
+    probe_rank += (size_t)blockIdx.y * n_clusters;
+    mask += (size_t)blockIdx.y * mask_stride;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t n_words = (n_rows + 63) >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -242,7 +252,8 @@ struct nmn_ivf {
         float* qpad = nullptr;
         QInfo* qinfo = nullptr;
         QState* qstate = nullptr;
-        uint8_t* pin = nullptr;          // pinned: [query dim x 4 | probe rows n_clusters x 8]
+        uint8_t* pin = nullptr;          // pinned: [queries nb x dim x 4 | probe rows nb x n_clusters x 8]
+        uint32_t nb = 1;                 // queries of one chunk the buffers above are sized for (probe_slot_grow)
         bool busy = false;
     };
     std::vector<std::unique_ptr<ProbeSlot>> slots;
@@ -730,6 +741,44 @@ static nmn_status probe_slot_acquire(nmn_ivf* ivf, nmn_ivf::ProbeSlot** out) {
     ivf->slots.push_back(std::move(sl));
     return NMN_OK;
 }
+// Size a slot's per-query buffers for chunks of `nb` queries (many queries of one nmn_ivf_search call share the centroid
+// sweep, the ranking launch, the bitmap launches and ONE round trip to the host).  Only grows.
+static nmn_status probe_slot_grow(nmn_ivf* ivf, nmn_ivf::ProbeSlot* sl, uint32_t nb) {
+    if (nb <= sl->nb) return NMN_OK;
+    IVF_TRY(hipStreamSynchronize(sl->stream));
+    const size_t c_pad = ivf->centroids->cap_pad, C = ivf->n_clusters, words = (ivf->cap + 63) / 64 + 1;
+    const uint32_t ld = ivf->vectors->ld;
+    hipError_t e = hipSuccess;
+    auto regrow = [&](void** p, size_t bytes) {
+        if (e != hipSuccess) return;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        e = hipMalloc(p, std::max<size_t>(bytes, 64));
+    };
+    regrow(reinterpret_cast<void**>(&sl->cscores), c_pad * nb * 4);
+    regrow(reinterpret_cast<void**>(&sl->probe_rows), C * nb * 8);
+    regrow(reinterpret_cast<void**>(&sl->probe_count), (size_t)nb * 8);
+    regrow(reinterpret_cast<void**>(&sl->probe_rank), C * nb * 4);
+    regrow(reinterpret_cast<void**>(&sl->mask), words * nb * 8);
+    regrow(reinterpret_cast<void**>(&sl->mask_c), words * nb * 8);
+    regrow(reinterpret_cast<void**>(&sl->qraw), (size_t)ivf->dim * nb * 4);
+    regrow(reinterpret_cast<void**>(&sl->qpad), (size_t)ld * nb * 4);
+    regrow(reinterpret_cast<void**>(&sl->qinfo), sizeof(QInfo) * nb);
+    regrow(reinterpret_cast<void**>(&sl->qstate), sizeof(QState) * nb);
+    if (e == hipSuccess) e = hipMemsetAsync(sl->qinfo, 0, sizeof(QInfo) * nb, sl->stream);
+    if (e == hipSuccess) {
+        if (sl->pin) (void)hipHostFree(sl->pin);
+        sl->pin = nullptr;
+        e = hipHostMalloc(reinterpret_cast<void**>(&sl->pin), ((size_t)ivf->dim * 4 * nb + 15 & ~(size_t)15) + C * 8 * nb + 16, hipHostMallocDefault);
+    }
+    if (e != hipSuccess) {
+        sl->nb = 0;  // (buffers in an unknown state: the next call grows them again from scratch)
+        return set_error_hip(e, "IVF probe slot (chunk buffers)");
+    }
+    sl->nb = nb;
+    return NMN_OK;
+}
+
 static void probe_slot_release(nmn_ivf* ivf, nmn_ivf::ProbeSlot* sl) {
     {
         std::lock_guard<std::mutex> g(ivf->slot_mu);
@@ -761,8 +810,18 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
         ~Release() { probe_slot_release(ivf, sl); }
     } release{ivf, sl};
     hipStream_t s = sl->stream;
+    // Queries are served in chunks of up to kProbeChunk: ONE copy of the chunk's queries, one exact sweep of all of them
+    // over the centroids, one ranking launch (a workgroup per query), one launch per bitmap kind (a grid row per query) and
+    // one copy of the probe orders back — a single round trip to the host for the whole chunk where every query used to pay
+    // its own; the list scans then follow query by query (each its own bitmap and, with k + 1, its own tie handling).
+    constexpr uint32_t kProbeChunk = 16;
+    const uint32_t chunk = (ivf->n_clusters <= kRankMax) ? std::min<uint32_t>(nq, kProbeChunk) : 1u;  // (> 4096 lists: the large-k sort, one query at a time)
+    st = probe_slot_grow(ivf, sl, chunk);
+    if (st != NMN_OK) return st;
+    const size_t mask_words = (ivf->cap + 63) / 64 + 1;
     float* pin_q = reinterpret_cast<float*>(sl->pin);
-    uint64_t* probe_host = reinterpret_cast<uint64_t*>(sl->pin + (((size_t)ivf->dim * 4 + 15) & ~(size_t)15));
+    uint64_t* probe_host_all = reinterpret_cast<uint64_t*>(sl->pin + (((size_t)ivf->dim * 4 * sl->nb + 15) & ~(size_t)15));
+    const uint64_t c_rows = ivf->cvec ? std::min(ivf->c_rows, n_rows) : 0;  // ids the list-major copy covers
     for (uint32_t q = 0; q < nq; q++) {
         uint64_t* o_ids = out_ids + (size_t)q * k;
         float* o_dist = out_distances + (size_t)q * k;
@@ -771,55 +830,60 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
         out_counts[q] = 0;
         if (n_rows == 0 || np == 0) continue;
         const float* qh = queries + (size_t)q * ivf->dim;
-        // 1. rank the centroids by squared distance (ascending; ties by index), keep the first nprobe, turn `assign`
-        //    into the selection bitmap — all on this slot's stream, one wait
-        memcpy(pin_q, qh, (size_t)ivf->dim * 4);
-        IVF_TRY(hipMemcpyAsync(sl->qraw, pin_q, (size_t)ivf->dim * 4, hipMemcpyHostToDevice, s));
-        IVF_TRY(launch_qprep(sl->qraw, 1, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits, sl->qpad,
-                             sl->qinfo, sl->qstate, 0, s));
-        {
-            ExactScanParams ep{};
-            ep.corpus = ivf->centroids->corpus;
-            ep.norms = ivf->centroids->norms;
-            ep.qpad = sl->qpad;
-            ep.qinfo = sl->qinfo;
-            ep.scores = sl->cscores;
-            ep.n_rows = ivf->n_clusters;
-            ep.nql = 1;
-            ep.ld = ivf->centroids->ld;
-            ep.dim = ivf->dim;
-            ep.nq = 1;
-            ep.metric = kMetricNegL2Sq;
-            IVF_TRY(launch_exact_scan(ep, s));
+        const uint32_t qc = q % chunk;  // position in its chunk
+        if (qc == 0) {
+            // 1. (whole chunk) rank the centroids by squared distance (ascending; ties by index), keep the first nprobe, turn the
+            //    list assignments into selection bitmaps — all on this slot's stream, one wait
+            const uint32_t nb = std::min<uint32_t>(chunk, nq - q);
+            memcpy(pin_q, qh, (size_t)ivf->dim * 4 * nb);
+            IVF_TRY(hipMemcpyAsync(sl->qraw, pin_q, (size_t)ivf->dim * 4 * nb, hipMemcpyHostToDevice, s));
+            IVF_TRY(launch_qprep(sl->qraw, nb, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits, sl->qpad,
+                                 sl->qinfo, sl->qstate, 0, s));
+            {
+                ExactScanParams ep{};
+                ep.corpus = ivf->centroids->corpus;
+                ep.norms = ivf->centroids->norms;
+                ep.qpad = sl->qpad;
+                ep.qinfo = sl->qinfo;
+                ep.scores = sl->cscores;
+                ep.n_rows = ivf->n_clusters;
+                ep.nql = nb;
+                ep.ld = ivf->centroids->ld;
+                ep.dim = ivf->dim;
+                ep.nq = nb;
+                ep.metric = kMetricNegL2Sq;
+                IVF_TRY(launch_exact_scan(ep, s));
+            }
+            if (ivf->n_clusters <= kRankMax) {
+                uint32_t np2 = 2;
+                while (np2 < ivf->n_clusters) np2 <<= 1;
+                hipLaunchKernelGGL(ivf_rank_kernel, dim3(nb), dim3(1024), 0, s, sl->cscores, nb, ivf->n_clusters, np2, np, sl->probe_rows,
+                                   sl->probe_count, sl->probe_rank);
+            } else {
+                IVF_TRY(launch_largek(sl->cscores, ivf->n_clusters, sl->ckeys, np, 0, sl->probe_rows, sl->probe_scores,
+                                      sl->probe_count, s));
+                IVF_TRY(hipMemsetAsync(sl->probe_rank, 0xFF, (size_t)ivf->n_clusters * 4, s));
+                hipLaunchKernelGGL(ivf_probe_rank_kernel, dim3((np + 255) / 256), dim3(256), 0, s, sl->probe_rows, sl->probe_count,
+                                   sl->probe_rank);
+            }
+            if (c_rows) {
+                const uint64_t cw = (c_rows + 63) / 64;
+                hipLaunchKernelGGL(ivf_range_mask_kernel, dim3((uint32_t)std::min<uint64_t>((cw + 3) / 4, 4096), nb), dim3(256), 0, s,
+                                   ivf->list_off, ivf->n_clusters, sl->probe_rank, c_rows, sl->mask_c, (uint64_t)mask_words);
+            }
+            if (c_rows < n_rows) {
+                const uint64_t n_words = (n_rows + 63) / 64;
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
+                hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks, nb), dim3(256), 0, s, ivf->assign, sl->probe_rank, ivf->n_clusters, n_rows,
+                                   c_rows, sl->mask, (uint64_t)mask_words);
+            }
+            IVF_TRY(hipGetLastError());
+            IVF_TRY(hipMemcpyAsync(probe_host_all, sl->probe_rows, (size_t)nb * ivf->n_clusters * 8, hipMemcpyDeviceToHost, s));
+            IVF_TRY(hipStreamSynchronize(s));
         }
-        if (ivf->n_clusters <= kRankMax) {
-            uint32_t np2 = 2;
-            while (np2 < ivf->n_clusters) np2 <<= 1;
-            hipLaunchKernelGGL(ivf_rank_kernel, dim3(1), dim3(1024), 0, s, sl->cscores, ivf->n_clusters, np2, np, sl->probe_rows,
-                               sl->probe_count, sl->probe_rank);
-        } else {
-            IVF_TRY(launch_largek(sl->cscores, ivf->n_clusters, sl->ckeys, np, 0, sl->probe_rows, sl->probe_scores,
-                                  sl->probe_count, s));
-            IVF_TRY(hipMemsetAsync(sl->probe_rank, 0xFF, (size_t)ivf->n_clusters * 4, s));
-            hipLaunchKernelGGL(ivf_probe_rank_kernel, dim3((np + 255) / 256), dim3(256), 0, s, sl->probe_rows, sl->probe_count,
-                               sl->probe_rank);
-        }
-        // the selection: over the list-major copy its ids [0, c_rows) — probed lists are runs of rows there — and, for the
-        // vectors added since it was laid out, the bitmap over the id-ordered rows
-        const uint64_t c_rows = ivf->cvec ? std::min(ivf->c_rows, n_rows) : 0;
-        if (c_rows) {
-            const uint64_t cw = (c_rows + 63) / 64;
-            hipLaunchKernelGGL(ivf_range_mask_kernel, dim3((uint32_t)std::min<uint64_t>((cw + 3) / 4, 4096)), dim3(256), 0, s, ivf->list_off,
-                               ivf->n_clusters, sl->probe_rank, c_rows, sl->mask_c);
-        }
-        if (c_rows < n_rows) {
-            const uint64_t n_words = (n_rows + 63) / 64;
-            const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_words + 3) / 4, 4096);
-            hipLaunchKernelGGL(ivf_mask_kernel, dim3(blocks), dim3(256), 0, s, ivf->assign, sl->probe_rank, n_rows, c_rows, sl->mask);
-        }
-        IVF_TRY(hipGetLastError());
-        IVF_TRY(hipMemcpyAsync(probe_host, sl->probe_rows, (size_t)np * 8, hipMemcpyDeviceToHost, s));
-        IVF_TRY(hipStreamSynchronize(s));
+        const uint64_t* probe_host = probe_host_all + (size_t)qc * ivf->n_clusters;
+        const uint64_t* mask_q = sl->mask + (size_t)qc * mask_words;
+        const uint64_t* mask_cq = sl->mask_c + (size_t)qc * mask_words;
         // rows in the probed lists: the selectivity hint of the list scan (how the flat index's coalescer decides what may
         // run side by side) and the most the scan can return
         uint64_t probed_rows = 0, probed_c = 0;
@@ -841,7 +905,7 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
             tmp_ids.assign(kk, UINT64_MAX);
             tmp_dist.assign(kk, 0.f);
             if (c_rows) {  // the list-major copy: results are ITS rows, mapped back to ids
-                st = index_search_hostio(ivf->cvec, qh, 1, (uint32_t)kk, kMetricNegL2, sl->mask_c, true, tmp_ids.data(), tmp_dist.data(),
+                st = index_search_hostio(ivf->cvec, qh, 1, (uint32_t)kk, kMetricNegL2, mask_cq, true, tmp_ids.data(), tmp_dist.data(),
                                          &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_c);
                 if (st != NMN_OK) return st;
                 for (uint32_t i = 0; i < cnt; i++) tmp_ids[i] = ivf->vectors->row_base + ivf->perm_host[tmp_ids[i]];
@@ -850,7 +914,7 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
                 uint32_t cnt_t = 0;
                 part_ids.assign(kk, UINT64_MAX);
                 part_dist.assign(kk, 0.f);
-                st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, sl->mask, true, part_ids.data(), part_dist.data(),
+                st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, mask_q, true, part_ids.data(), part_dist.data(),
                                          &cnt_t, (stats && q + 1 == nq && !c_rows) ? stats : nullptr, probed_t);
                 if (st != NMN_OK) return st;
                 if (!c_rows) {

@@ -254,6 +254,38 @@ def test_concurrent_probes_equal_sequential_probes(d):
                 assert np.array_equal(np.asarray(a), np.asarray(b)), j
 
 
+@pytest.mark.parametrize("n,d,c,nprobe,young", [(9000, 48, 24, 5, 0), (12_000, 128, 40, 7, 3000)])
+def test_many_queries_per_call_share_the_centroid_phase(n, d, c, nprobe, young):
+    """One call with many queries (chunks of 16 share the centroid sweep, the ranking launch, the bitmap launches and one
+    round trip) answers exactly what one call per query answers and what the oracle answers — across a ragged last chunk,
+    growth of a probe slot that first served a single query, ties, and rows younger than the list-major copy."""
+    rng = np.random.default_rng(77)
+    X = (rng.standard_normal((n, d)) + 3.0 * rng.standard_normal((c, d))[rng.integers(0, c, n)]).astype(F)
+    X[500:520] = X[499]
+    orc, gpu = build_pair(X[: n - young], c, nprobe=nprobe, spare=young + 64)
+    with gpu:
+        gpu.add(X[: n - young])
+        for v in X[: n - young]:
+            orc.add(v)
+        if young:                                        # list-major copy covers the first part only
+            gpu.add(X[n - young:])
+            for v in X[n - young:]:
+                orc.add(v)
+        Q = rng.standard_normal((41, d)).astype(F) + X[rng.integers(0, n, 41)]
+        Q[3] = X[499]
+        one = gpu.search(Q[0], 9)                        # a slot sized for one query exists before the batched call
+        for k, npb in ((9, None), (1, 2), (300, c)):
+            ids, dist, counts = gpu.search(Q, k, npb)
+            assert ids.shape == (41, k)
+            for j in range(41):
+                a = gpu.search(Q[j], k, npb)
+                assert np.array_equal(a[0][0], ids[j]) and np.array_equal(a[1][0], dist[j]) and a[2][0] == counts[j], (k, j)
+                eids, ed = orc.search(Q[j], k, npb)
+                assert counts[j] == len(eids) and ids[j, :len(eids)].tolist() == eids, (k, j)
+                assert np.array_equal(dist[j, :len(eids)], ed)
+        assert np.array_equal(one[0][0], gpu.search(Q[:17], 9)[0][0])
+
+
 # ---- the list-major copy (round 3) ---------------------------------------------------------------------------------------
 def test_list_major_copy_matches_oracle_through_adds_and_relayouts():
     """>= 4096 vectors: probes read a second copy of the vectors ordered by list (contiguous ranges) and map its rows back to
