@@ -36,7 +36,8 @@ for k, v in agg.items():
     big = [x for x in v if x * 4 >= max(v)]   # the main sweeps (the sampling pass reads 1/32 of the mirror)
     small = [x for x in v if x * 4 < max(v)]
     scale = 1024 * (2 if c == "FETCH_SIZE" else 1)   # KiB; gfx950: FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads
-    print(f"{c}: {k}: main sweeps {len(big)} x {sum(big)/len(big)*scale/1e9:.4f} GB; sampling passes {len(small)} x {(sum(small)/max(1,len(small)))*scale/1e9:.4f} GB  (algorithmic: 7.68 GB per sweep of the 8-bit mirror)")
+    nb = max(1, len(small))   # one sampling pass per query batch; the main sweep of a batch is TWO launches (bound refinement)
+    print(f"{c}: {k}: per batch of 64 queries: main sweep {sum(big)/nb*scale/1e9:.4f} GB in {len(big)//nb} launches; sampling pass {(sum(small)/nb)*scale/1e9:.4f} GB  ({nb} batches; algorithmic: 7.68 GB per sweep of the 8-bit mirror)")
 PY
   rm -rf $O/pmc_$c
 done
