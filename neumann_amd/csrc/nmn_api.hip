@@ -929,6 +929,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
             sp.metric = (int)metric;
             sp.strided = (!use_mfma && mask_dev) ? 1u : 0u;  // masked VALU sweeps: a wave takes every W-th tile (runs of selected rows spread over all waves)
+            static const bool no_walk = getenv("NMN_NO_WALK") != nullptr;  // (A/B switch of the survivor walk)
+            sp.walk = (sp.strided && !no_walk) ? 1u : 0u;
             sp.tile_step = 1;
             sp.skip_key = nullptr;
             if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));

@@ -119,6 +119,8 @@ struct ScanParams {
     uint32_t strided;        // VALU sweeps: 0 = wave w owns the tiles [w * tiles_per_wave, ...) (a contiguous range); 1 = the tiles
                              // w, w + W, w + 2W, ... (W = scan waves): what masked sweeps use — a selection that is a few RUNS of rows
                              // (an IVF list in the list-major copy, a WHERE over a time range) would otherwise land on a few waves
+    uint32_t walk;           // masked 8-bit VALU sweep: 1 = the survivor walk (participating rows of up to 64 tiles listed and read four
+                             // per step across tile borders, nmn_scan_i8.hip); 0 = tile by tile
     uint32_t bx_base, bx_count;  // MFMA sweep: this launch covers workgroups [bx_base, bx_base + bx_count) (0 = to the end)
     int metric;
 };

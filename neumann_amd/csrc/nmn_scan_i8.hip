@@ -161,13 +161,32 @@ __device__ __forceinline__ float l2_from_dot(float qq, float vv, float dot, bool
 }
 
 constexpr uint32_t kCompactMaxRows = 40;  // tiles with at most this many participating rows run compacted steps (nmn_scan.hip)
+// The survivor walk of masked sweeps: a wave lists the participating rows of up to 64 of its tiles at once (at most kWalkRows,
+// so 8 full tiles always fit) and reads them four per step, every step full and independent of the tile borders.
+#ifndef NMN_I8_WALK_ROWS
+#define NMN_I8_WALK_ROWS 512
+#endif
+constexpr uint32_t kWalkRows = NMN_I8_WALK_ROWS;
+#ifndef NMN_I8_MASKED_QREG_CH   // masked sweeps keep the query planes in registers up to this many chunk groups (else they are read from LDS)
+#define NMN_I8_MASKED_QREG_CH 6
+#endif
+#ifndef NMN_I8_WALK_DENSE
+#define NMN_I8_WALK_DENSE 20u
+#endif
+#ifndef NMN_I8_WALK_PIPE_CH
+#define NMN_I8_WALK_PIPE_CH 3
+#endif
+template <int N>
+__device__ __forceinline__ float row_share(float v) {  // lane N of the caller's 16-lane DPP row, to all of its lanes
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xF, 0xF, false));
+}
 
 // METRIC: cosine / Euclidean (also the IVF list scan's -d) / dot.  MASKED: predicate bitmap.  NQ: 1 or 2 queries per sweep.
 // CH: 16-byte loads per lane and row step; SINGLE: the row is exactly 16 * CH chunks (no column loop).
 template <int METRIC, bool MASKED, int NQ, int CH, bool SINGLE>
 __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) int qsi[];  // [NQ][2][chunks] x 16 B: h plane, l plane of every query
-    constexpr bool QREG = SINGLE && NQ == 1;
+    constexpr bool QREG = SINGLE && NQ == 1 && (!MASKED || CH <= NMN_I8_MASKED_QREG_CH);
     const uint32_t ld = p.ld, chunks = ld >> 4;
     const uint32_t q0 = blockIdx.y * NQ;
     {
@@ -326,6 +345,7 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
     }
 #endif
     uint64_t mcache = 0;
+    const bool walk = MASKED && p.walk != 0;
     for (uint32_t rel = 0; rel < p.tiles_per_wave; rel++) {
         const uint32_t tile = tile_at(rel);
         if (tile >= p.n_tiles) break;
@@ -334,7 +354,167 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
         if constexpr (MASKED) {  // the wave's bitmap words, 64 tiles at a time (as scan_kernel)
             if ((rel & 63u) == 0) {
                 const uint32_t tl = tile_at(rel + lane);
-                mcache = (rel + lane < p.tiles_per_wave && tl < p.n_tiles) ? p.mask[tl] : 0ull;
+                const bool tl_ok = rel + lane < p.tiles_per_wave && tl < p.n_tiles;
+                mcache = tl_ok ? p.mask[tl] : 0ull;  // (requesting the first 64 words before the query is staged: measured, slower at 1536)
+                if (tl_ok) {
+                    const uint64_t left = p.n_rows - (uint64_t)tl * kTileRows;
+                    if (left < 64) mcache &= (1ull << left) - 1ull;
+                }
+                bool walk_here = walk;
+                if (walk && CH <= NMN_I8_WALK_PIPE_CH) {
+                    // short rows: a step is few loads under a fixed cost per row (list entry, factors, score); from ~20 participating
+                    // rows per tile on the tile-by-tile steps are cheaper (measured at 768: selectivity 0.5 0.72 vs 0.75 of peak)
+                    uint32_t tot = (uint32_t)__builtin_popcountll(mcache);
+#pragma unroll
+                    for (uint32_t d = 1; d < 64; d <<= 1) tot += (uint32_t)__shfl_xor((int)tot, d);
+                    walk_here = tot <= NMN_I8_WALK_DENSE * min(64u, p.tiles_per_wave - rel);
+                }
+                if (walk_here) {
+                    // ---- the survivor walk: these (up to) 64 tiles at once --------------------------------------------------
+                    // A sparse tile alone is a chain of dependent round trips (bitmap -> rows -> store) that keeps one row step
+                    // of a wave in flight; at selectivity 0.01 the sweep spent 40 of its 66 us waiting on ~18 such chains per
+                    // wave.  Here lane L owns tile rel + L: a prefix sum of the popcounts places every participating row of
+                    // the sub-range in ONE list (tile << 6 | bit), the rows are read four per step straight down the list
+                    // (loads of step s + 1 in flight under the products of step s), each row's score is parked in LDS, and
+                    // the tiles' 256-byte score blocks, maxima and the wave maximum are written at the end.
+                    uint16_t* wtab = reinterpret_cast<uint16_t*>(qsi + (size_t)NQ * (ld >> 1) + 4 * (NQ * 64) + 4 * 64) + (threadIdx.x >> 6) * kWalkRows;
+                    uint32_t* wsc = reinterpret_cast<uint32_t*>(qsi + (size_t)NQ * (ld >> 1) + 4 * (NQ * 64) + 4 * 64 + 4 * (kWalkRows / 2)) +
+                                    (threadIdx.x >> 6) * (NQ * kWalkRows);
+                    const uint32_t n_here = min(64u, p.tiles_per_wave - rel);
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mcache);
+                    uint32_t incl = cnt;
+#pragma unroll
+                    for (uint32_t d = 1; d < 64; d <<= 1) {
+                        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+                        if (lane >= d) incl += t;
+                    }
+                    const float* fptr = p.i8_scale;  // lane j of a 16-lane row fetches: 0 the row's scale, 1 its magnitude / |v~|^2, 2 |v| (estimator B)
+                    if constexpr (METRIC == NMN_METRIC_COSINE) fptr = j == 1 ? p.norms : fptr;
+                    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) fptr = j == 1 ? p.i8_vv : (j == 2 ? p.norms : fptr);
+                    const bool f_lane = j == 0 || (METRIC == NMN_METRIC_COSINE && j == 1) ||
+                                        (METRIC == NMN_METRIC_EUCLIDEAN && (j == 1 || (j == 2 && any_est_b)));
+                    uint32_t base_lane = 0, base_cnt = 0;
+                    while (base_lane < n_here) {
+                        const uint64_t fit = __ballot(lane >= base_lane && lane < n_here && incl - base_cnt <= kWalkRows);
+                        const uint32_t end_lane = base_lane + (uint32_t)__builtin_popcountll(fit);  // (>= base_lane + 8 or n_here)
+                        const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(end_lane - 1)) - base_cnt;
+                        const bool mine = lane >= base_lane && lane < end_lane;
+                        const uint32_t off = incl - cnt - base_cnt;
+                        if (mine) {
+                            uint64_t w = mcache;
+                            uint32_t o = off;
+                            while (w) {
+                                wtab[o++] = (uint16_t)((lane << 6) | (uint32_t)__builtin_ctzll(w));
+                                w &= w - 1;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        // one step: entry -> row address -> loads
+                        auto entry_of = [&](uint32_t s0) -> uint32_t { return s0 + grp < S ? (uint32_t)wtab[s0 + grp] : 0xFFFFu; };
+                        auto row_of = [&](uint32_t e) -> uint64_t { return (uint64_t)tile_at(rel + (e >> 6)) * kTileRows + (e & 63u); };
+                        auto finish = [&](uint32_t s0, uint32_t e, const float (&acc)[NQ], float f) {
+                            const bool active = e != 0xFFFFu;
+                            const float sr = row_share<0>(f);
+                            float vn = 1.f, vb = 0.f;
+                            if constexpr (METRIC != NMN_METRIC_DOT_PRODUCT) vn = row_share<1>(f);
+                            if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vb = row_share<2>(f);
+                            (void)vb;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) {
+                                const float dot = row16_sum(acc[q]) * (qsc[q] * sr);
+                                float sc;
+                                if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
+                                else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = qq8[q] < 0.f ? l2_from_dot(qmag[q] * qmag[q], vb * vb, dot, neg) : l2_from_dot(qq8[q], vn, dot, neg);
+                                else sc = dot;
+                                if (j == 0 && active) wsc[q * kWalkRows + s0 + grp] = f2u(sc);
+                            }
+                        };
+                        if constexpr (SINGLE && CH <= NMN_I8_WALK_PIPE_CH) {  // (longer rows: a step is >= 4 KiB in flight per wave as it is,
+                            v4i xa[CH], xb[CH];                                //  and the second buffer would cost a wave per SIMD)
+                            float fa = 0.f, fb = 0.f;
+                            uint32_t ea = entry_of(0), eb = 0xFFFFu;
+                            auto issue = [&](uint32_t e, v4i (&x)[CH], float& f) {
+                                if (e != 0xFFFFu) {
+                                    const uint64_t row = row_of(e);
+                                    load_row<CH>(reinterpret_cast<const v4i*>(mat + row * (uint64_t)ld), j, x);
+                                    f = f_lane ? fptr[row] : 0.f;
+                                } else {
+#pragma unroll
+                                    for (int c = 0; c < CH; c++) x[c] = (v4i){0, 0, 0, 0};
+                                    f = 0.f;
+                                }
+                            };
+                            issue(ea, xa, fa);
+                            for (uint32_t s0 = 0; s0 < S; s0 += 8u) {
+                                eb = entry_of(s0 + 4u);
+                                issue(eb, xb, fb);
+                                __builtin_amdgcn_sched_barrier(0);
+                                {
+                                    float acc[NQ];
+                                    dot_row<NQ, CH, QREG>(xa, j, chunks, qs4, qh, ql, acc);
+                                    finish(s0, ea, acc, fa);
+                                }
+                                ea = entry_of(s0 + 8u);
+                                issue(ea, xa, fa);
+                                __builtin_amdgcn_sched_barrier(0);
+                                {
+                                    float acc[NQ];
+                                    dot_row<NQ, CH, QREG>(xb, j, chunks, qs4, qh, ql, acc);
+                                    finish(s0 + 4u, eb, acc, fb);
+                                }
+                            }
+                        } else {
+                            for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
+                                const uint32_t e = entry_of(s0);
+                                const bool active = e != 0xFFFFu;
+                                const uint64_t row = active ? row_of(e) : 0ull;
+                                const float f = (active && f_lane) ? fptr[row] : 0.f;
+                                float acc[NQ];
+                                row_partial_i8<NQ, CH, SINGLE, QREG>(reinterpret_cast<const v4i*>(mat + row * (uint64_t)ld), active, j, chunks, qs4, qh, ql, acc);
+                                finish(s0, e, acc, f);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        // the tiles' score blocks (non-participating rows: the sentinel), tile by tile
+                        for (uint32_t tl2 = base_lane; tl2 < end_lane; tl2++) {
+                            const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)tl2);
+                            const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)tl2);
+                            const uint64_t w = ((uint64_t)whi << 32) | wlo;
+                            if (w == 0ull) continue;  // (its maximum says so below; nobody reads the scores of such a tile)
+                            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)tl2);
+                            const bool set = ((w >> lane) & 1ull) != 0;
+                            const uint32_t rank = (uint32_t)__builtin_popcountll(w & ((1ull << lane) - 1ull));
+                            const uint64_t row = (uint64_t)tile_at(rel + tl2) * kTileRows + lane;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) {
+                                const uint32_t bits = set ? wsc[q * kWalkRows + o + rank] : kScoreSentinelBits;
+                                if (q0 + q < p.nq) p.scores[score_at(row, q0 + q, p.nql)] = bits;
+                            }
+                        }
+                        // tile maxima: lane L walks its own tile's entries
+                        uint32_t m[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) m[q] = kKeyMasked;
+                        if (mine) {
+                            for (uint32_t i = 0; i < cnt; i++) {
+#pragma unroll
+                                for (int q = 0; q < NQ; q++) m[q] = max(m[q], score_to_key(u2f(wsc[q * kWalkRows + off + i])));
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            if (q0 + q < p.nq) {
+                                if (mine && tl_ok) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tl] = m[q];
+                                wmax[q] = max(wmax[q], wave_max_u32(m[q]));
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        base_lane = end_lane;
+                        base_cnt += S;
+                    }
+                    rel += 63u;  // (the loop's own increment completes the 64)
+                    continue;
+                }
             }
             const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)(rel & 63u));
             const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)(rel & 63u));
@@ -456,7 +636,10 @@ hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
     // query planes (2 bytes per element), plus (masked) the per-wave staging arrays and rank tables of the compacted tiles
-    const size_t lds = (size_t)NQ * p.ld * 2 + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) : 0);
+    // and (survivor walk) a row list of kWalkRows 16-bit entries and kWalkRows parked scores per query, per wave
+    const size_t lds = (size_t)NQ * p.ld * 2 + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) +
+                                                             4 * kWalkRows * sizeof(uint16_t) + 4 * NQ * kWalkRows * sizeof(uint32_t)
+                                                       : 0);
     auto kern = scan_i8_kernel<METRIC, MASKED, NQ, CH, SINGLE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

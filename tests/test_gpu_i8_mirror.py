@@ -264,3 +264,70 @@ def test_euclidean_estimator_follows_the_data():
             check(idx, B, q, k, 1, expect_bytes=1)
         check(idx, B, Q[0], k, 1, expect_bytes=1)       # a far query after near ones, and back
         check(idx, B, centres[9], k, 1, expect_bytes=1)
+
+
+# ---- the survivor walk of masked sweeps (round 3) -----------------------------------------------------------------------
+_WALK_CHILD = r'''
+import sys, numpy as np
+from oracle import oracle_c as oc
+from neumann_amd import GpuFlatIndex
+n, d = int(sys.argv[1]), int(sys.argv[2])
+A = oc.synth(0x51 + d, 0, n, d, nthreads=8)
+A[1000:1040] = A[999]                                   # copies inside and across tiles
+Q = oc.synth(0x52 + d, 0, 2, d)
+Q[1] = A[999] * np.float32(1.25)
+rng = np.random.default_rng(d)
+tiles = (n + 63) // 64
+masks = {}
+masks["random 0.3"] = rng.random(n) < 0.3
+masks["random 0.02"] = rng.random(n) < 0.02
+masks["random 0.002"] = rng.random(n) < 0.002
+runs = np.zeros(tiles * 64, bool).reshape(tiles, 64)
+runs[(np.arange(tiles) % 40) < 10] = True              # ten full tiles, thirty empty ones
+masks["runs of full tiles"] = runs.reshape(-1)[:n].copy()
+masks["all"] = np.ones(n, bool)
+tail = np.zeros(n, bool); tail[-37:] = True; tail[5] = True
+masks["tail rows and one more"] = tail
+mixed = rng.random(n) < 0.01
+mixed[: n // 3] = rng.random(n // 3) < 0.9             # a third nearly full, the rest sparse
+masks["dense third, sparse rest"] = mixed
+masks["none"] = np.zeros(n, bool)
+U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+with GpuFlatIndex(d, n, single_launch=False) as idx:
+    idx.upload(A)
+    for name, keep in masks.items():
+        m = oc.mask_from_bool(keep)
+        for metric, k, QQ in ((0, 100, Q[:1]), (1, 40, Q), (2, 7, Q[1:])):
+            rows, scores, counts, stats = idx.search(QQ, k, metric, mask=m, with_stats=True)
+            assert stats.bytes_scanned == stats.rows_scanned * d, (name, "not the 8-bit sweep")
+            for qi in range(QQ.shape[0]):
+                er, es = oc.search(A, QQ[qi], k, metric, mask=m, nthreads=8, partial=True, native=True)
+                c = er.size
+                assert counts[qi] == c, (name, metric, qi, counts[qi], c)
+                assert np.array_equal(rows[qi, :c], er), (name, metric, qi, rows[qi, :8], er[:8])
+                assert np.array_equal(scores[qi, :c].view(np.uint32), es.view(np.uint32)), (name, metric, qi)
+                assert np.all(rows[qi, c:] == U64_MAX)
+print("WALK-OK")
+'''
+
+
+@pytest.mark.parametrize("n,d,waves", [(300_000, 256, "256"), (300_000, 1536, "256"), (200_000, 2048, "256"), (1_200_000, 256, "256"),
+                                        (300_000, 768, ""), (300_000, 768, "nowalk")])
+def test_survivor_walk_of_masked_sweeps_matches_the_oracle(n, d, waves):
+    """The masked 8-bit sweep lists the participating rows of up to 64 tiles of a wave and reads them four per step across
+    tile borders (nmn_scan_i8.hip).  With NMN_SCAN_WAVES=256 a wave owns 19-74 tiles, so the lists are cut into sub-ranges
+    of at most 512 rows and a wave walks more than one 64-tile range — the paths a 300k-row shard under the default 4096
+    waves (2 tiles per wave) never reaches.  Masks: random dense / sparse / very sparse, runs of full and empty tiles,
+    everything, nothing, the ragged tail, a dense third; rows and score bits must be the oracle's."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if waves == "nowalk":
+        env["NMN_NO_WALK"] = "1"
+    elif waves:
+        env["NMN_SCAN_WAVES"] = waves
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", _WALK_CHILD, str(n), str(d)], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "WALK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
