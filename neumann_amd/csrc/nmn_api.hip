@@ -879,14 +879,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
         const bool f32_retry = use_half && !use_mfma && n_rows >= (1u << 18);
-        if (f32_retry)
-            HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric, idx->max_norm_bits,
-                                 w->qpad, w->qinfo_f32, w->qstate, 0, stream));
+        // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
                              use_i8 ? (1 | 2 | 4 | (use_mfma ? 0 : 8)) : ((use_mfma ? 1 : 0) | (use_half ? 2 : 0)), stream,
                              use_i8 ? idx->q8_err_bits : use_half ? idx->half_err_bits : nullptr, use_i8 ? w->qi8 : nullptr,
-                             (use_i8 && !use_mfma) ? idx->q8_l2_hint : nullptr));
+                             (use_i8 && !use_mfma) ? idx->q8_l2_hint : nullptr, f32_retry ? w->qinfo_f32 : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
@@ -1027,6 +1025,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }
             const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && !no_crowd();
             sel.crowd_follows = crowd ? 1 : 0;
+            sel.crowd_count_reset = crowd ? w->crowd_ctr : nullptr;
             HIP_TRY(launch_select(sel, stream));
             if (crowd) {  // three launches that return at once unless a candidate list overflowed
                 CrowdParams cp{};
@@ -1060,6 +1059,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel2.fb_sync_reset = nullptr;
                 sel2.l2_hint = nullptr;
                 sel2.crowd_follows = 0;
+                sel2.crowd_count_reset = nullptr;
                 HIP_TRY(launch_select(sel2, stream));
             }
 

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                                                    float* __restrict__ qpad, QInfo* __restrict__ qinfo,
                                                    QState* __restrict__ qstate, int mfma_pass,
                                                    const uint32_t* __restrict__ half_err_bits, uint32_t* __restrict__ qi8,
-                                                   const float* __restrict__ l2_hint) {
+                                                   const float* __restrict__ l2_hint, QInfo* __restrict__ qinfo_plain) {
     const uint32_t q = blockIdx.x;
     const float* src = queries + (size_t)q * dim;
     float* dst = qpad + (size_t)q * ld;
@@ -342,6 +342,28 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
             }
         }
         qinfo[q] = qi;
+        if (qinfo_plain) {
+            // the same query for a sweep over the f32 corpus itself (the retry of a mirror pass whose margin overflowed): what
+            // this kernel writes with mfma_pass == 0 — f32 summation error only — in the same launch
+            QInfo qp;
+            qp.qmag = qmag;
+            qp.pad = 0.f;
+            qp.qscale = 0.f;
+            qp.qq8 = 0.f;
+            qp.pad_sq = 0.f;
+            qp.neg_d = 0.f;
+            if (metric == NMN_METRIC_COSINE || metric == NMN_METRIC_SPARSE_COSINE_F64) {
+                qp.margin_abs = 3.0f * (dd + 10.0f) * u;
+                qp.margin_rel = 0.0f;
+            } else if (metric == NMN_METRIC_DOT_PRODUCT) {
+                qp.margin_abs = (3.0f * (dd + 10.0f) * u) * qmag * u2f(*max_norm_bits);
+                qp.margin_rel = 8.0f * u;
+            } else {
+                qp.margin_abs = 0.0f;
+                qp.margin_rel = 4.0f * (dd + 8.0f) * u;
+            }
+            qinfo_plain[q] = qp;
+        }
         QState st;
         st.cand_count = 0;
         st.overflow = 0;
@@ -353,9 +375,9 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
 
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
-                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8, const float* l2_hint) {
+                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8, const float* l2_hint, QInfo* qinfo_plain) {
     hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), 0, s, queries, dim, ld, metric, max_norm_bits, qpad,
-                       qinfo, qstate, mfma_pass, half_err_bits, qi8, l2_hint);
+                       qinfo, qstate, mfma_pass, half_err_bits, qi8, l2_hint, qinfo_plain);
     return hipGetLastError();
 }
 

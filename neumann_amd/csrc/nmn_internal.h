@@ -178,6 +178,7 @@ struct SelectParams {
     uint32_t* half_stats;      // nullable [2]: queries selected on the bf16 mirror / of those, queries that needed the retry
     int retry_follows;         // 1: an f32 retry sweep follows this selection (it may flag a query as not worth retrying)
     unsigned long long* fb_sync_reset;  // nullable [2]: counters of the fallback_select launch that follows, zeroed here
+    uint32_t* crowd_count_reset;  // nullable [nq]: the crowd kernels' row totals, zeroed here (they follow on this stream)
     int crowd_follows;         // 1: the crowd kernels run behind this selection (it may hand a query with many tiles over to them early)
     float* l2_hint;            // nullable: query 0's threshold distance is left here (feeds qprep's choice of the 8-bit Euclidean estimator)
     int count_overflows;       // 1: half_stats[1] counts the queries whose candidate list overflowed in THIS selection (batched 8-bit
@@ -211,7 +212,7 @@ struct CrowdParams {
     uint32_t pool_cap;
 };
 constexpr uint32_t kCrowdMaxGrid = 512;  // workgroups per query of the count / fill launches
-hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s);  // count -> allocate slices -> fill
+hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s);  // count -> fill (every workgroup allocates the slices for itself)
 
 // Device-wide exact-fallback selection (nmn_select.hip: fallback_select_kernel), shards of >= 2^18 rows
 struct FallbackParams {
@@ -260,7 +261,7 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
                         hipStream_t s, const uint32_t* half_err_bits = nullptr, uint32_t* qi8 = nullptr,
-                        const float* l2_hint = nullptr);
+                        const float* l2_hint = nullptr, QInfo* qinfo_plain = nullptr);  // qinfo_plain: also the approx_pass == 0 record (f32 retry)
 // approx_pass bits: 1 = the sweep's copy of the query is rounded (bf16 on the MFMA sweep; with bit 4 the int8 split
 // q = s_q (h + l / 256), written to qi8[q][2][ld] and QInfo.qscale), 2 = the sweep reads a mirror of the corpus
 // (half_err_bits = that mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep;

@@ -59,6 +59,9 @@ __device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
     return Tc;
 }
 
+#ifndef NMN_SELECT_VR
+#define NMN_SELECT_VR 16
+#endif
 constexpr uint32_t kListCap = 4096;  // LDS work lists (waves, tiles); both bounded by kMaxScanWaves / cand_cap
 
 // Two 11-bit radix digits over n gathered keys (key_at(e) == 0: does not take part): returns T, the
@@ -185,6 +188,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         return;
     }
     if (p.half_stats && tid == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
+    if (p.crowd_count_reset && tid == 0) p.crowd_count_reset[q] = 0u;  // the crowd kernels behind this selection count from zero
     if (p.fb_sync_reset && q == 0 && tid == 0) {  // arrival counter + abort flag of the fallback_select launch that follows on this stream
         p.fb_sync_reset[0] = 0ull;
         p.fb_sync_reset[1] = 0ull;
@@ -281,10 +285,13 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         // ---- level R: compact (key,row) of rows >= T2m in tiles >= T2m (la is dead: LR may be written)
         __syncthreads();
         const uint32_t tot = ct * kTileRows;
-        for (uint32_t e0 = tid; e0 < tot; e0 += kSelThreads * V) {
-            uint32_t kb[V], rr[V];
+        // (this gather is the longest chain of the kernel: ct x 64 scores through ONE workgroup, a memory round trip per batch of
+        //  loads — under the 8-bit margin ct is ~700 at 1M rows, k = 100: 16 loads per thread in flight instead of 8)
+        constexpr int VR = NMN_SELECT_VR;
+        for (uint32_t e0 = tid; e0 < tot; e0 += kSelThreads * VR) {
+            uint32_t kb[VR], rr[VR];
 #pragma unroll
-            for (int u = 0; u < V; u++) {
+            for (int u = 0; u < VR; u++) {
                 const uint32_t e = e0 + (uint32_t)u * kSelThreads;
                 kb[u] = kScoreSentinelBits;
                 rr[u] = 0;
@@ -297,7 +304,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < V; u++) {
+            for (int u = 0; u < VR; u++) {
                 const uint32_t key = bits_to_key(kb[u]);
                 const bool pr = key != kKeyMasked && key >= T2m;
                 const uint32_t pos = wave_append(pr, &s_w[2]);
@@ -500,67 +507,73 @@ __global__ __launch_bounds__(256) void crowd_count_kernel(CrowdParams p) {
     }
 }
 
-// slices of the pool, first come first served in query order; resets the counters for the next search
-__global__ __launch_bounds__(256) void crowd_alloc_kernel(CrowdParams p) {  // one workgroup, nq <= 256
-    __shared__ uint32_t s_cnt[256], s_off[256];
-    const uint32_t q = threadIdx.x;
-    uint32_t c = 0;
-    if (q < p.nq) {  // loads and resets in parallel; only the slice cursor is sequential
-        c = p.count[q];
-        p.count[q] = 0;
-        p.fill[q] = 0;
-        if (p.qstate[q].overflow != 1) c = 0;
-        // a threshold that lets more than an eighth of the shard through is not a crowd around the query but a useless
-        // margin (one row of enormous norm under a Euclidean metric): that is the f32 retry's case
-        if ((uint64_t)c * 8u > p.n_rows) c = 0;
-    }
-    s_cnt[threadIdx.x] = c;
-    s_off[threadIdx.x] = 0xFFFFFFFFu;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t cursor = 0;
-        for (uint32_t i = 0; i < p.nq && i < 256u; i++) {
-            const uint32_t ci = s_cnt[i];
-            if (ci != 0 && ci <= p.pool_cap - cursor) {
-                s_off[i] = cursor;
-                cursor += ci;
-            }
-        }
-    }
-    __syncthreads();
-    if (q < p.nq && s_off[q] != 0xFFFFFFFFu) {
-        p.offset[q] = s_off[q];
-        p.qstate[q].overflow = 2;
-        p.qstate[q].cand_count = c;
-    }
-}
-
 // Every workgroup writes its rows into ITS part of the query's slice: the parts' starts are the prefix sums of the counts
 // crowd_count_kernel left per workgroup (same grid, same walk, hence the same rows).  One append cursor per QUERY in global
 // memory — one atomic per hot tile, all on one address — made this kernel 115 us at 10 000 tiles, ten times the count.
+// The slices of the pool (first come first served in query order) are worked out HERE, by every workgroup for itself from the
+// read-only totals — the one-workgroup launch that used to sit between count and fill is gone, and with it 4.4 us of every
+// search (a dependent launch costs that much even when it returns at once).  select_kernel zeroes the totals.
 __global__ __launch_bounds__(256) void crowd_fill_kernel(CrowdParams p) {
     const uint32_t q = blockIdx.y;
-    const QState st = p.qstate[q];
-    if (st.overflow != 2) return;
-    __shared__ uint32_t s_part[256], s_cur;
+    {
+        const uint32_t ov = p.qstate[q].overflow;
+        if (ov != 1 && ov != 2) return;  // (2: workgroup 0 of this query has already published the decision made below)
+    }
+    __shared__ uint32_t s_part[256], s_cur, s_off, s_total;
+    {
+        uint32_t c = 0;
+        if (threadIdx.x <= q) {  // nq <= 256
+            c = p.count[threadIdx.x];
+            const uint32_t o = p.qstate[threadIdx.x].overflow;
+            if (o != 1 && o != 2) c = 0;
+            // a threshold that lets more than an eighth of the shard through is not a crowd around the query but a useless
+            // margin (one row of enormous norm under a Euclidean metric): that is the f32 retry's case
+            if ((uint64_t)c * 8u > p.n_rows) c = 0;
+        }
+        s_part[threadIdx.x] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cursor = 0, off = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i <= q && i < 256u; i++) {
+                const uint32_t ci = s_part[i];
+                if (ci != 0 && ci <= p.pool_cap - cursor) {
+                    if (i == q) off = cursor;
+                    cursor += ci;
+                }
+            }
+            s_off = off;
+            s_total = s_part[q < 256u ? q : 255u];
+        }
+        __syncthreads();
+    }
+    const uint32_t off = s_off, total = s_total;
+    if (off == 0xFFFFFFFFu) return;  // no slice: the query stays an ordinary overflow (f32 retry / exact fallback)
+    __syncthreads();
     {
         const uint32_t* wc = p.wg_count + (size_t)q * gridDim.x;
         uint32_t acc = 0;
         for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) acc += wc[i];
         s_part[threadIdx.x] = acc;
         __syncthreads();
-        for (uint32_t off = 128; off > 0; off >>= 1) {
-            if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+        for (uint32_t o2 = 128; o2 > 0; o2 >>= 1) {
+            if (threadIdx.x < o2) s_part[threadIdx.x] += s_part[threadIdx.x + o2];
             __syncthreads();
         }
         if (threadIdx.x == 0) s_cur = s_part[0];
         __syncthreads();
     }
-    uint32_t* dst = p.pool_rows + p.offset[q];
-    crowd_walk(p, q, st.thr_key, [&](uint64_t row, bool pred) {
+    uint32_t* dst = p.pool_rows + off;
+    const uint32_t thr = p.qstate[q].thr_key;
+    crowd_walk(p, q, thr, [&](uint64_t row, bool pred) {
         const uint32_t pos = wave_append(pred, &s_cur);  // (LDS: the workgroup's four waves)
-        if (pred && pos < st.cand_count) dst[pos] = (uint32_t)row;
+        if (pred && pos < total) dst[pos] = (uint32_t)row;
     });
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // what rescore / final read
+        p.offset[q] = off;
+        p.qstate[q].cand_count = total;
+        __threadfence();
+        p.qstate[q].overflow = 2;
+    }
 }
 
 hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s) {
@@ -568,7 +581,6 @@ hipError_t launch_crowd_collect(const CrowdParams& p, hipStream_t s) {
     const uint32_t gx_cap = std::max<uint32_t>(8, std::min<uint32_t>(kCrowdMaxGrid, 4096 / std::max<uint32_t>(p.nq, 1)));
     const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((p.n_tiles + 64 * 4 - 1) / (64 * 4), gx_cap));
     hipLaunchKernelGGL(crowd_count_kernel, dim3(gx, p.nq), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(crowd_alloc_kernel, dim3(1), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_fill_kernel, dim3(gx, p.nq), dim3(256), 0, s, p);
     return hipGetLastError();
 }
