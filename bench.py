@@ -515,6 +515,12 @@ def next_rows_child(args):
                 bi, bd, bc = ivf.search(Q, k)
             ms_b = (time.perf_counter() - t0) / (4 * 32) * 1e3
             same = bool(np.array_equal(bi[(reps - 1) % 32], ids[0]) and np.array_equal(bd[(reps - 1) % 32], dist[0]))
+            Q128 = rows_of(54321, 54321 + 128) + np.float32(0.05)   # 128 per call: two chunks of 64, each ONE batched pass per part
+            ivf.search(Q128, k)
+            t0 = time.perf_counter()
+            for i in range(3):
+                ivf.search(Q128, k)
+            ms_b128 = (time.perf_counter() - t0) / (3 * 128) * 1e3
             sizes = ivf.cluster_sizes()
             ex_ids, ex_dist, _ = ivf.search(Q[(reps - 1) % 32], k, nprobe=C_)  # every list: the exhaustive answer
             recall = len(set(ids[0].tolist()) & set(ex_ids[0].tolist())) / float(k)
@@ -522,10 +528,11 @@ def next_rows_child(args):
             out["ivf_probe"] = {"what": "nmn_ivf_search (tensor_store/src/ivf.rs:325-406): rank 256 centroids, scan the 8 nearest lists, top-k",
                                 "rows": rn, "dim": d, "clusters": C_, "nprobe": nprobe, "k": k, "ms_per_query_wall": ms, "value": 1e3 / ms,
                                 "unit": "queries/s", "ms_per_query_wall_32_per_call": ms_b, "value_32_per_call": 1e3 / ms_b,
+                                "ms_per_query_wall_128_per_call": ms_b128, "value_128_per_call": 1e3 / ms_b128,
                                 "batched_call_equals_single_calls": same, "list_major_rows": int(ivf.list_major_rows), "train_seconds": t_train, "add_rows_per_s": (rn - tn) / t_add,
                                 "list_size_min_mean_max": [int(sizes.min()), float(sizes.mean()), int(sizes.max())],
                                 "rows_in_8_largest_lists": probed, "recall_vs_exhaustive_probe_one_query": recall,
-                                "note": "the probe is launch-bound at this size (list scan ~50 us of the call); IVF itself is approximate in the reference too"}
+                                "note": "a single-query call is launch-bound at this size (list scan ~50 us of the call); with many queries per call the centroid phase is shared and the list scans of a chunk run as one batched sweep with a bitmap per query; IVF itself is approximate in the reference too"}
     except Exception as e:
         out["ivf_probe"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)

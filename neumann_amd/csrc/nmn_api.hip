@@ -1495,7 +1495,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     return NMN_OK;
 }
 
-static nmn_status host_submit(nmn_index* idx, HostReq& me);
+static nmn_status host_submit(nmn_index* idx, HostReq& me, HostReq* const* extras = nullptr, size_t n_extras = 0);
 
 nmn_status nmn::index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
                                     const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
@@ -1553,8 +1553,43 @@ extern "C" nmn_status nmn_index_search_pred(nmn_index* idx, nmn_columns* cols, c
     return host_submit(idx, me);
 }
 
+uint32_t nmn::index_hostio_many_capacity(const nmn_index* idx, int metric, uint32_t k) {
+    if (!idx || k > NMN_MAX_TOP_K || !coalesce_enabled()) return 0;
+    const uint32_t cap = batch_queries(idx, metric);
+    return cap > 4 ? cap : 0;  // (4: the VALU sweep, one bitmap for all its queries)
+}
+
+nmn_status nmn::index_search_hostio_many(nmn_index* idx, const HostSearchSpec* specs, uint32_t n, uint32_t k, int metric,
+                                         nmn_search_stats* stats) {
+    if (!idx || !specs || n == 0) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    if (n > index_hostio_many_capacity(idx, metric, k)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "more searches than one batch carries");
+    HIP_TRY(hipSetDevice(idx->device));
+    std::vector<HostReq> reqs(n);
+    std::vector<HostReq*> extras;
+    for (uint32_t i = 0; i < n; i++) {
+        HostReq& r = reqs[i];
+        nmn_status st = check_search_args(idx, specs[i].query, 1, k, metric == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : (nmn_metric)metric,
+                                          specs[i].out_rows, specs[i].out_scores, specs[i].out_count);
+        if (st != NMN_OK) return st;
+        r.queries = specs[i].query;
+        r.nq = 1;
+        r.k = k;
+        r.metric = metric;
+        r.mask = specs[i].mask;
+        r.mask_on_device = true;
+        r.mask_rows = specs[i].mask ? specs[i].mask_rows : UINT64_MAX;
+        r.out_rows = specs[i].out_rows;
+        r.out_scores = specs[i].out_scores;
+        r.out_counts = specs[i].out_count;
+        r.stats = i + 1 == n ? stats : nullptr;
+        r.local = i != 0;
+        if (i) extras.push_back(&r);
+    }
+    return host_submit(idx, reqs[0], extras.data(), extras.size());
+}
+
 // queue / lead / ride: the coalescer proper
-static nmn_status host_submit(nmn_index* idx, HostReq& me) {
+static nmn_status host_submit(nmn_index* idx, HostReq& me, HostReq* const* extras, size_t n_extras) {
     const uint32_t nq = me.nq;
     const int metric = me.metric;
     nmn_status st = NMN_OK;
@@ -1579,7 +1614,9 @@ static nmn_status host_submit(nmn_index* idx, HostReq& me) {
     }
     // lead a batch: this request plus every queued one that can share its sweep
     std::vector<HostReq*> batch{&me};
-    if (mergeable(idx, me)) {
+    if (n_extras) {  // the caller's own batch: nobody else rides in it
+        batch.insert(batch.end(), extras, extras + n_extras);
+    } else if (mergeable(idx, me)) {
         const uint32_t limit = batch_queries(idx, metric);
         const uint32_t gather_us = gather_window_us(idx);
         if (gather_us && idx->last_batch_requests > 1) {
@@ -1640,7 +1677,7 @@ static nmn_status host_submit(nmn_index* idx, HostReq& me) {
     const std::string err = st == NMN_OK ? std::string() : std::string(nmn_last_error());
     // wake the riders first (their results are in place), then pass the slot on
     for (HostReq* r : batch) {
-        if (r == &me) continue;
+        if (r == &me || r->local) continue;
         std::lock_guard<std::mutex> g(r->m);
         r->st = st;
         r->err = err;

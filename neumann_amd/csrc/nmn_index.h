@@ -111,6 +111,7 @@ struct HostReq {
     std::mutex m;
     std::condition_variable cv;
     bool done = false, lead = false;  // guarded by m
+    bool local = false;  // rides in the batch of the request that brought it along (index_search_hostio_many): nobody waits on it
 };
 
 struct nmn_index {
@@ -204,6 +205,21 @@ int columns_device(const nmn_columns* c);
 nmn_status index_search_hostio(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k, int metric,
                                const uint64_t* mask, bool mask_on_device, uint64_t* out_rows, float* out_scores,
                                uint32_t* out_counts, nmn_search_stats* stats, uint64_t mask_rows = UINT64_MAX);
+
+// Several single-query searches of ONE caller as one batch (each with its own device bitmap): what the coalescer does for
+// concurrent callers, for a caller that has all its queries at hand (the list scans of an IVF chunk).  n <= the value
+// index_hostio_many_capacity returns (0: this shard's batches cannot carry a bitmap per query — search them one by one).
+struct HostSearchSpec {
+    const float* query;      // host, dim floats
+    const uint64_t* mask;    // device bitmap (nullable)
+    uint64_t mask_rows;      // rows it selects (UINT64_MAX: unknown)
+    uint64_t* out_rows;      // host [k]
+    float* out_scores;       // host [k]
+    uint32_t* out_count;     // host
+};
+uint32_t index_hostio_many_capacity(const nmn_index* idx, int metric, uint32_t k);
+nmn_status index_search_hostio_many(nmn_index* idx, const HostSearchSpec* specs, uint32_t n, uint32_t k, int metric,
+                                    nmn_search_stats* stats);
 
 // nmn_index_search_device with the internal metrics allowed (everything in device memory, asynchronous)
 nmn_status index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric,

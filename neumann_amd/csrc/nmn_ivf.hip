@@ -814,14 +814,63 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
     // over the centroids, one ranking launch (a workgroup per query), one launch per bitmap kind (a grid row per query) and
     // one copy of the probe orders back — a single round trip to the host for the whole chunk where every query used to pay
     // its own; the list scans then follow query by query (each its own bitmap and, with k + 1, its own tie handling).
-    constexpr uint32_t kProbeChunk = 16;
+    // (chunk: up to 64 queries, fewer when their bitmaps — two per query — would take more than 256 MiB)
+    const size_t mask_words = (ivf->cap + 63) / 64 + 1;
+    const uint32_t kProbeChunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(64, ((size_t)256 << 20) / (mask_words * 16)));
     const uint32_t chunk = (ivf->n_clusters <= kRankMax) ? std::min<uint32_t>(nq, kProbeChunk) : 1u;  // (> 4096 lists: the large-k sort, one query at a time)
     st = probe_slot_grow(ivf, sl, chunk);
     if (st != NMN_OK) return st;
-    const size_t mask_words = (ivf->cap + 63) / 64 + 1;
     float* pin_q = reinterpret_cast<float*>(sl->pin);
     uint64_t* probe_host_all = reinterpret_cast<uint64_t*>(sl->pin + (((size_t)ivf->dim * 4 * sl->nb + 15) & ~(size_t)15));
     const uint64_t c_rows = ivf->cvec ? std::min(ivf->c_rows, n_rows) : 0;  // ids the list-major copy covers
+    // The list scans of a chunk as ONE batch per part (list-major copy / younger vectors): the flat index's batched sweep reads a
+    // bitmap per query, so sixteen probes cost one pass over the vectors instead of sixteen launch-bound searches — whenever that
+    // pass is the cheaper way (the coalescer's own estimate: a search alone costs max(100 us, its share of a sweep)).
+    const uint64_t kk1 = std::min<uint64_t>((uint64_t)k + 1, std::max<uint64_t>(n_rows, 1));
+    std::vector<uint64_t> bc_ids, bt_ids, hint_c, hint_t;
+    std::vector<float> bc_dist, bt_dist;
+    std::vector<uint32_t> bc_cnt, bt_cnt;
+    bool batched_c = false, batched_t = false;
+    auto probed_of = [&](const uint64_t* probe_host, uint64_t* pc, uint64_t* pt) {
+        uint64_t probed_rows = 0, probed_c = 0;
+        for (uint32_t i = 0; i < np; i++)
+            if (probe_host[i] < ivf->list_sizes.size()) {
+                probed_rows += ivf->list_sizes[probe_host[i]];
+                if (c_rows) probed_c += ivf->list_off_host[probe_host[i] + 1] - ivf->list_off_host[probe_host[i]];
+            }
+        if (ivf->list_sizes_rows != n_rows) probed_rows = UINT64_MAX;  // sizes not current (never after add / build)
+        *pc = probed_c;
+        *pt = (probed_rows == UINT64_MAX) ? UINT64_MAX : probed_rows - std::min(probed_rows, probed_c);
+    };
+    auto scan_many = [&](nmn_index* ix, const uint64_t* masks, const std::vector<uint64_t>& hints, const float* q0, uint32_t nb,
+                         std::vector<uint64_t>& ids, std::vector<float>& dist, std::vector<uint32_t>& cnt, bool* done,
+                         nmn_search_stats* stats_out) -> nmn_status {
+        *done = false;
+        static const bool no_many = getenv("NMN_IVF_NO_BATCHED_SCANS") != nullptr;  // (A/B switch)
+        if (no_many || nb < 2 || kk1 > NMN_MAX_TOP_K || nb > index_hostio_many_capacity(ix, kMetricNegL2, (uint32_t)kk1)) return NMN_OK;
+        const double sweep_us = (double)ix->rows * ix->ld * 2.0 / 5.5e6, fixed_us = 100.0;
+        double separately = 0.0;
+        for (uint32_t i = 0; i < nb; i++) {
+            const double sel = hints[i] == UINT64_MAX ? 1.0 : (double)hints[i] / (double)std::max<uint64_t>(ix->rows, 1);
+            separately += std::max(fixed_us, sel * sweep_us);
+        }
+        if (separately < 1.1 * sweep_us + fixed_us) return NMN_OK;
+        ids.assign((size_t)nb * kk1, UINT64_MAX);
+        dist.assign((size_t)nb * kk1, 0.f);
+        cnt.assign(nb, 0);
+        std::vector<HostSearchSpec> specs(nb);
+        for (uint32_t i = 0; i < nb; i++) {
+            specs[i].query = q0 + (size_t)i * ivf->dim;
+            specs[i].mask = masks + (size_t)i * mask_words;
+            specs[i].mask_rows = hints[i];
+            specs[i].out_rows = ids.data() + (size_t)i * kk1;
+            specs[i].out_scores = dist.data() + (size_t)i * kk1;
+            specs[i].out_count = cnt.data() + i;
+        }
+        nmn_status st2 = index_search_hostio_many(ix, specs.data(), nb, (uint32_t)kk1, kMetricNegL2, stats_out);
+        if (st2 == NMN_OK) *done = true;
+        return st2;
+    };
     for (uint32_t q = 0; q < nq; q++) {
         uint64_t* o_ids = out_ids + (size_t)q * k;
         float* o_dist = out_distances + (size_t)q * k;
@@ -880,43 +929,64 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
             IVF_TRY(hipGetLastError());
             IVF_TRY(hipMemcpyAsync(probe_host_all, sl->probe_rows, (size_t)nb * ivf->n_clusters * 8, hipMemcpyDeviceToHost, s));
             IVF_TRY(hipStreamSynchronize(s));
+            // 2a. the chunk's list scans, batched where that pays (results at k + 1, picked up query by query below)
+            hint_c.assign(nb, 0);
+            hint_t.assign(nb, 0);
+            for (uint32_t i = 0; i < nb; i++) probed_of(probe_host_all + (size_t)i * ivf->n_clusters, &hint_c[i], &hint_t[i]);
+            batched_c = batched_t = false;
+            if (c_rows) {
+                st = scan_many(ivf->cvec, sl->mask_c, hint_c, qh, nb, bc_ids, bc_dist, bc_cnt, &batched_c, (stats && q + nb == nq) ? stats : nullptr);
+                if (st != NMN_OK) return st;
+            }
+            if (c_rows < n_rows) {
+                st = scan_many(ivf->vectors, sl->mask, hint_t, qh, nb, bt_ids, bt_dist, bt_cnt, &batched_t,
+                               (stats && q + nb == nq && !c_rows) ? stats : nullptr);
+                if (st != NMN_OK) return st;
+            }
         }
         const uint64_t* probe_host = probe_host_all + (size_t)qc * ivf->n_clusters;
         const uint64_t* mask_q = sl->mask + (size_t)qc * mask_words;
         const uint64_t* mask_cq = sl->mask_c + (size_t)qc * mask_words;
         // rows in the probed lists: the selectivity hint of the list scan (how the flat index's coalescer decides what may
         // run side by side) and the most the scan can return
-        uint64_t probed_rows = 0, probed_c = 0;
-        for (uint32_t i = 0; i < np; i++)
-            if (probe_host[i] < ivf->list_sizes.size()) {
-                probed_rows += ivf->list_sizes[probe_host[i]];
-                if (c_rows) probed_c += ivf->list_off_host[probe_host[i] + 1] - ivf->list_off_host[probe_host[i]];
-            }
-        if (ivf->list_sizes_rows != n_rows) probed_rows = UINT64_MAX;  // sizes not current (never after add / build)
-        const uint64_t probed_t = (probed_rows == UINT64_MAX) ? UINT64_MAX : probed_rows - std::min(probed_rows, probed_c);
+        uint64_t probed_c = 0, probed_t = 0;
+        probed_of(probe_host, &probed_c, &probed_t);
         // 2. masked scan ranking by distance (negated so that nearest = largest).  One result more than asked for: the scan
         //    breaks equal distances by id, the reference by candidate order, so a run of equal distances that straddles
         //    the cut must be seen whole before it is reordered and cut.
-        uint64_t kk = std::min<uint64_t>((uint64_t)k + 1, std::max<uint64_t>(n_rows, 1));
+        uint64_t kk = kk1;
         uint32_t cnt = 0;
         std::vector<uint64_t> part_ids;
         std::vector<float> part_dist;
         for (;;) {
+            const bool first = kk == kk1;  // (the batched scans of 2a answer the first round; an extension searches alone)
             tmp_ids.assign(kk, UINT64_MAX);
             tmp_dist.assign(kk, 0.f);
             if (c_rows) {  // the list-major copy: results are ITS rows, mapped back to ids
-                st = index_search_hostio(ivf->cvec, qh, 1, (uint32_t)kk, kMetricNegL2, mask_cq, true, tmp_ids.data(), tmp_dist.data(),
-                                         &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_c);
-                if (st != NMN_OK) return st;
+                if (first && batched_c) {
+                    cnt = bc_cnt[qc];
+                    std::copy(bc_ids.begin() + (size_t)qc * kk1, bc_ids.begin() + (size_t)(qc + 1) * kk1, tmp_ids.begin());
+                    std::copy(bc_dist.begin() + (size_t)qc * kk1, bc_dist.begin() + (size_t)(qc + 1) * kk1, tmp_dist.begin());
+                } else {
+                    st = index_search_hostio(ivf->cvec, qh, 1, (uint32_t)kk, kMetricNegL2, mask_cq, true, tmp_ids.data(), tmp_dist.data(),
+                                             &cnt, (stats && q + 1 == nq) ? stats : nullptr, probed_c);
+                    if (st != NMN_OK) return st;
+                }
                 for (uint32_t i = 0; i < cnt; i++) tmp_ids[i] = ivf->vectors->row_base + ivf->perm_host[tmp_ids[i]];
             }
             if (c_rows < n_rows) {  // the younger vectors, in id order
                 uint32_t cnt_t = 0;
                 part_ids.assign(kk, UINT64_MAX);
                 part_dist.assign(kk, 0.f);
-                st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, mask_q, true, part_ids.data(), part_dist.data(),
-                                         &cnt_t, (stats && q + 1 == nq && !c_rows) ? stats : nullptr, probed_t);
-                if (st != NMN_OK) return st;
+                if (first && batched_t) {
+                    cnt_t = bt_cnt[qc];
+                    std::copy(bt_ids.begin() + (size_t)qc * kk1, bt_ids.begin() + (size_t)(qc + 1) * kk1, part_ids.begin());
+                    std::copy(bt_dist.begin() + (size_t)qc * kk1, bt_dist.begin() + (size_t)(qc + 1) * kk1, part_dist.begin());
+                } else {
+                    st = index_search_hostio(ivf->vectors, qh, 1, (uint32_t)kk, kMetricNegL2, mask_q, true, part_ids.data(), part_dist.data(),
+                                             &cnt_t, (stats && q + 1 == nq && !c_rows) ? stats : nullptr, probed_t);
+                    if (st != NMN_OK) return st;
+                }
                 if (!c_rows) {
                     tmp_ids.swap(part_ids);
                     tmp_dist.swap(part_dist);

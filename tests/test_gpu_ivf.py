@@ -284,6 +284,9 @@ def test_many_queries_per_call_share_the_centroid_phase(n, d, c, nprobe, young):
                 assert counts[j] == len(eids) and ids[j, :len(eids)].tolist() == eids, (k, j)
                 assert np.array_equal(dist[j, :len(eids)], ed)
         assert np.array_equal(one[0][0], gpu.search(Q[:17], 9)[0][0])
+        # two queries: below what one pass over the vectors is worth — the list scans run one by one; 41: as one batch per part
+        two = gpu.search(Q[:2], 9)
+        assert np.array_equal(two[0], gpu.search(Q, 9)[0][:2]) and np.array_equal(two[1], gpu.search(Q, 9)[1][:2])
 
 
 # ---- the list-major copy (round 3) ---------------------------------------------------------------------------------------
