@@ -829,7 +829,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         const bool i8_ok = use_half && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() && !idx->q8_failed &&
                            idx->q8_calls >= idx->q8_off_until;
         const bool i8_valu = i8_ok && !use_mfma && nqc <= 2 && !qmasks_dev && scan_i8_supported(idx->ld, idx->dim, (int)metric);
-        const bool i8_mfma = i8_ok && use_mfma && !mask_dev && !qmasks_dev && !no_i8_mfma() && scan_mfma_i8_supported(idx->ld, idx->dim, (int)metric);
+        static const bool no_i8_masked_mfma = getenv("NMN_NO_I8_MASKED_MFMA") != nullptr;  // (A/B: bitmap batches on the bf16 mirror, as until round 3)
+        const bool i8_mfma = i8_ok && use_mfma && !((mask_dev || qmasks_dev) && no_i8_masked_mfma) && !no_i8_mfma() &&
+                             scan_mfma_i8_supported(idx->ld, idx->dim, (int)metric);
         bool use_i8 = i8_valu || i8_mfma;
         if (use_half && (i8_valu || i8_mfma || (idx->q8_stats && idx->q8_calls < idx->q8_off_until)) && idx->q8_stats &&
             (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {

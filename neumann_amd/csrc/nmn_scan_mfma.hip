@@ -314,6 +314,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             }
             if (s0 < kRing - 1)
                 stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
+        } else if (s0 < kRing - 1) {
+            // A range shorter than the ring (a small shard: one tile per workgroup is KC stages, the ring of 16-KiB stages holds
+            // eight): the loop's counted wait — "at most kRing - 2 younger stages in flight" — only says that stage sidx has landed
+            // if kRing - 1 stages WERE issued here.  The missing ones go out as the same dummy pieces the loop issues past the end
+            // of the range (every lane re-reads the first 16 bytes of the mirror into a slot nobody reads).  Without them the wait
+            // returned at once and the first stage was read on the strength of whatever else had drained the queue by then —
+            // found when the 8-bit sweep got its bitmap variant (20 000 x 768, 64 queries: rows missing from 47 answers).
+            const uint32_t zero[kPieces] = {};
+            stage_dma<AUX, kPieces>(mirror, zero, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         }
     }
 
@@ -783,21 +792,27 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 }
 
 // The 8-bit mirror on the matrix cores: 64 stationary queries per workgroup (more queries: several query blocks of one
-// launch, folded onto one XCD like the long rows of the bf16 sweep), rows of whole 256-element groups up to 1536, no bitmap.
+// launch, folded onto one XCD like the long rows of the bf16 sweep), rows of whole 256-element groups up to 1536; with one bitmap
+// for the batch or one per query (the epilogue's business: the sweep reads every row either way).
+template <int KC, int KS, int METRIC>
+static hipError_t launch_kc_i8(const ScanParams& p, hipStream_t s) {
+    return (p.mask || p.qmasks) ? launch_one_mfma<KC, KS, 4, METRIC, true, 4, true>(p, s)
+                                : launch_one_mfma<KC, KS, 4, METRIC, false, 4, true>(p, s);
+}
 template <int METRIC>
 static hipError_t launch_metric_i8(const ScanParams& p, hipStream_t s) {
     static const bool waves8 = [] {  // measurement knob (NMN_MFMA_WAVES=8): two waves per SIMD, query groups on wave pairs that split K
         const char* e = getenv("NMN_MFMA_WAVES");
         return e ? atoi(e) == 8 : false;
     }();
-    if (waves8 && p.ld == 768u) return launch_one_mfma<3, 1, 4, METRIC, false, 8, true>(p, s);
+    if (waves8 && p.ld == 768u && !p.mask && !p.qmasks) return launch_one_mfma<3, 1, 4, METRIC, false, 8, true>(p, s);
     switch (p.ld / 256u) {  // = row bytes / 256: the unit the bf16 launcher calls ld / kStageK
-        case 1: return launch_one_mfma<1, 1, 4, METRIC, false, 4, true>(p, s);   // 256
-        case 2: return launch_one_mfma<1, 2, 4, METRIC, false, 4, true>(p, s);   // 512
-        case 3: return launch_one_mfma<3, 1, 4, METRIC, false, 4, true>(p, s);   // 768
-        case 4: return launch_one_mfma<2, 2, 4, METRIC, false, 4, true>(p, s);   // 1024
-        case 5: return launch_one_mfma<5, 1, 4, METRIC, false, 4, true>(p, s);   // 1280
-        case 6: return launch_one_mfma<3, 2, 4, METRIC, false, 4, true>(p, s);   // 1536
+        case 1: return launch_kc_i8<1, 1, METRIC>(p, s);   // 256
+        case 2: return launch_kc_i8<1, 2, METRIC>(p, s);   // 512
+        case 3: return launch_kc_i8<3, 1, METRIC>(p, s);   // 768
+        case 4: return launch_kc_i8<2, 2, METRIC>(p, s);   // 1024
+        case 5: return launch_kc_i8<5, 1, METRIC>(p, s);   // 1280
+        case 6: return launch_kc_i8<3, 2, METRIC>(p, s);   // 1536
         default: return hipErrorInvalidValue;
     }
 }
@@ -820,8 +835,7 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
 
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
-    if (p.corpus_i8) {  // the 8-bit mirror (never with a bitmap: the caller keeps masked batches on the bf16 mirror)
-        if (p.mask || p.qmasks) return hipErrorInvalidValue;
+    if (p.corpus_i8) {  // the 8-bit mirror
         switch (p.metric) {
             case NMN_METRIC_COSINE: return launch_metric_i8<NMN_METRIC_COSINE>(p, s);
             case NMN_METRIC_EUCLIDEAN: return launch_metric_i8<NMN_METRIC_EUCLIDEAN>(p, s);

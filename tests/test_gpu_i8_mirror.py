@@ -60,13 +60,15 @@ def test_mirror_modes_read_1_2_and_4_bytes_per_element_and_agree():
             got[mode] = idx.search(q, k, 0)
         for mode in (2, 0):
             assert np.array_equal(got[mode][0], got[1][0]) and np.array_equal(got[mode][1].view(np.uint32), got[1][1].view(np.uint32))
-        # a 3-query batch is the matrix-core sweep's — over the 8-bit mirror too; with a bitmap it stays on the bf16 mirror;
+        # a 3-query batch is the matrix-core sweep's — over the 8-bit mirror too, with or without a bitmap (round 3);
         # a row length outside the 256-element groups is the bf16 VALU sweep's
         idx.set_mirror(1)
         Q3 = oc.synth(0x23, 0, 3, d)
         check(idx, A, Q3, k, 0, expect_bytes=1)
         keep = np.random.default_rng(3).random(n) < 0.5
-        check(idx, A, Q3, k, 0, mask=oc.mask_from_bool(keep), expect_bytes=2)
+        check(idx, A, Q3, k, 0, mask=oc.mask_from_bool(keep), expect_bytes=1)
+        for metric in (1, 2):
+            check(idx, A, Q3, 17, metric, mask=oc.mask_from_bool(keep), expect_bytes=1)
         idx.set_mirror(2)
         check(idx, A, Q3, k, 0, expect_bytes=2)
     with GpuFlatIndex(320, 80_000, single_launch=False) as idx:
@@ -331,3 +333,20 @@ def test_survivor_walk_of_masked_sweeps_matches_the_oracle(n, d, waves):
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", _WALK_CHILD, str(n), str(d)], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "WALK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("d", [256, 768, 1280])   # 16-KiB stages: a tile is 1 / 3 / 5 stages of a ring of eight
+def test_bitmap_batches_on_a_small_shard_one_tile_per_workgroup(d):
+    """64-query batches under a bitmap on the 8-bit mirror where a workgroup's range (one tile) is shorter than the DMA ring:
+    the ring's prologue must still put kRing - 1 stages in flight, or the loop's counted wait says nothing about stage 0
+    (round 3: 47 of 64 answers lost a row at 20 000 x 768 under a Euclidean metric until the prologue issued its dummies)."""
+    from neumann_amd import GpuFlatIndex
+    n, nq = 20_000, 64
+    A = oc.synth(0x61 + d, 0, n, d, nthreads=8)
+    Q = oc.synth(0x62 + d, 0, nq, d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        for sel in (1.0, 0.9, 0.3):
+            keep = np.random.default_rng(d).random(n) < sel
+            for metric, k in ((1, 100), (0, 17), (2, 40)):
+                check(idx, A, Q, k, metric, mask=oc.mask_from_bool(keep), expect_bytes=1)
