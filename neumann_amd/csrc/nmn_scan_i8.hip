@@ -104,16 +104,17 @@ __device__ __forceinline__ void row_partial_i8(const v4i* __restrict__ rowp, boo
             }
         }
     } else {
+        // (rows of an odd number of 128-element halves — 384, 640, 896 ... — end in a chunk group only lanes 0-7 have a part of)
         for (uint32_t c0 = 0; c0 < chunks; c0 += 16u * CH) {
             v4i x[CH];
 #pragma unroll
             for (int c = 0; c < CH; c++) {
-                if (active) x[c] = __builtin_nontemporal_load(rowp + c0 + (uint32_t)c * 16u + j);
+                if (active && c0 + (uint32_t)c * 16u + j < chunks) x[c] = __builtin_nontemporal_load(rowp + c0 + (uint32_t)c * 16u + j);
                 else x[c] = (v4i){0, 0, 0, 0};
             }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
-                const uint32_t col = c0 + (uint32_t)c * 16u + j;
+                const uint32_t col = min(c0 + (uint32_t)c * 16u + j, chunks - 1u);  // (beyond the row: x is zero, any query chunk will do)
 #pragma unroll
                 for (int q = 0; q < NQ; q++)
                     dot16(x[c], qs4[(uint32_t)q * 2u * chunks + col], qs4[(uint32_t)q * 2u * chunks + chunks + col], hi[q], lo[q]);
@@ -651,6 +652,16 @@ hipError_t launch_one(const ScanParams& p, hipStream_t s) {
 
 template <int METRIC, bool MASKED, int NQ>
 hipError_t launch_layout(const ScanParams& p, hipStream_t s) {
+    if (p.ld & 255u) {  // 384, 640, 896 ...: the generic loop with a guarded last group — up to 1408 in ONE pass of ceil(chunks / 16) loads per lane
+        switch ((p.ld + 255u) >> 8) {
+            case 2: return launch_one<METRIC, MASKED, NQ, 2, false>(p, s);
+            case 3: return launch_one<METRIC, MASKED, NQ, 3, false>(p, s);
+            case 4: return launch_one<METRIC, MASKED, NQ, 4, false>(p, s);
+            case 5: return launch_one<METRIC, MASKED, NQ, 5, false>(p, s);
+            case 6: return launch_one<METRIC, MASKED, NQ, 6, false>(p, s);
+            default: return launch_one<METRIC, MASKED, NQ, 1, false>(p, s);
+        }
+    }
     switch (p.ld >> 8) {  // chunks / 16 = 256-element groups per row
         case 1: return launch_one<METRIC, MASKED, NQ, 1, true>(p, s);
         case 2: return launch_one<METRIC, MASKED, NQ, 2, true>(p, s);
@@ -761,8 +772,12 @@ __global__ void __launch_bounds__(256) q8_err_kernel(const float* __restrict__ r
 
 bool scan_i8_supported(uint32_t ld, uint32_t dim, int metric) {
     (void)dim;
-    // rows of whole 256-element groups (one 16-byte chunk per lane of a 16-lane row group), up to the 4096 of the widest sweep
-    if (ld == 0 || ld % 256u != 0 || ld > 4096u) return false;
+    // rows of whole 256-element groups (one 16-byte chunk per lane of a 16-lane row group), up to the 4096 of the widest sweep;
+    // also rows of an odd number of 128-element halves (half of the last group's lanes idle: 384 reads 1.5 load
+    // slots per row for 384 bytes — still fewer bytes than the 768 of the bf16 mirror)
+    static const uint32_t min_odd = [] { const char* e = getenv("NMN_I8_MIN_ODD_LD"); return e ? (uint32_t)atol(e) : 128u; }();
+    if (ld == 0 || ld % 128u != 0 || ld > 4096u) return false;
+    if (ld % 256u != 0 && ld < min_odd) return false;
     return metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2;
 }
 

@@ -231,7 +231,7 @@ class GpuFlatIndex:
 
     def set_mirror(self, enabled):
         """What approximate sweeps read.  True / 1 (default): the smallest mirror that serves the shape — the 8-bit mirror for
-        1-2 queries over rows of whole 256-element groups, else the bf16 mirror.  2: the bf16 mirror only.  False / 0: the
+        1-2 queries over rows whose stride is a multiple of 128 elements (batches: of 256, up to 1536), else the bf16 mirror.  2: the bf16 mirror only.  False / 0: the
         f32 corpus itself (rows*dim*4 bytes per query, SURVEY §8(d)'s pricing).  Results are identical in every mode."""
         _capi.check(self._lib.nmn_index_set_mirror(self._h, int(enabled)))
 

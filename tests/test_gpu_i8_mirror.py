@@ -29,7 +29,8 @@ def check(idx, A, Q, k, metric, mask=None, expect_bytes=None):
     return stats
 
 
-@pytest.mark.parametrize("d", [256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096])
+@pytest.mark.parametrize("d", [256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096,
+                               128, 384, 640, 896, 1152, 2176, 3968])   # ... and rows of an odd number of 128-element halves
 def test_every_supported_row_length_matches_the_oracle(d):
     from neumann_amd import GpuFlatIndex
     n = 70_000 if d <= 1536 else 20_000
