@@ -702,7 +702,12 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     }
     const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0) +  // + the K-halves' exchange
                        (size_t)WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 16 +                      // + pending tile maxima
+#ifdef NMN_MFMA_PACK
                        (I8 ? kNormSlots * 64 * 4 + (size_t)WAVES * (16 * 64 + 16) * 4 : 0);                // + (8-bit) |v~|^2 of the tiles' rows, the packed-store blocks
+#else
+                       (I8 ? kNormSlots * 64 * 4 : 0);  // + (8-bit) |v~|^2 of the tiles' rows (with the K-halves' exchange of the long rows
+                                                        //   the packed-store blocks of the measurement build would not fit in 160 KiB)
+#endif
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
 #ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
 #define NMN_MFMA_AUX 2
@@ -792,12 +797,13 @@ static hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
 }
 
 // The 8-bit mirror on the matrix cores: 64 stationary queries per workgroup (more queries: several query blocks of one
-// launch, folded onto one XCD like the long rows of the bf16 sweep), rows of whole 256-element groups up to 1536; with one bitmap
+// launch, folded onto one XCD like the long rows of the bf16 sweep), rows of whole 256-element groups up to 1536, and 2048 / 3072 with
+// 32 stationary queries per workgroup (K-halves on wave pairs); with one bitmap
 // for the batch or one per query (the epilogue's business: the sweep reads every row either way).
-template <int KC, int KS, int METRIC>
+template <int KC, int KS, int METRIC, int QG = 4>
 static hipError_t launch_kc_i8(const ScanParams& p, hipStream_t s) {
-    return (p.mask || p.qmasks) ? launch_one_mfma<KC, KS, 4, METRIC, true, 4, true>(p, s)
-                                : launch_one_mfma<KC, KS, 4, METRIC, false, 4, true>(p, s);
+    return (p.mask || p.qmasks) ? launch_one_mfma<KC, KS, QG, METRIC, true, 4, true>(p, s)
+                                : launch_one_mfma<KC, KS, QG, METRIC, false, 4, true>(p, s);
 }
 template <int METRIC>
 static hipError_t launch_metric_i8(const ScanParams& p, hipStream_t s) {
@@ -813,13 +819,18 @@ static hipError_t launch_metric_i8(const ScanParams& p, hipStream_t s) {
         case 4: return launch_kc_i8<2, 2, METRIC>(p, s);   // 1024
         case 5: return launch_kc_i8<5, 1, METRIC>(p, s);   // 1280
         case 6: return launch_kc_i8<3, 2, METRIC>(p, s);   // 1536
+        case 8: return launch_kc_i8<4, 2, METRIC, 2>(p, s);   // 2048: 32 stationary queries, K-halves on wave pairs (as the bf16 form)
+        case 12: return launch_kc_i8<6, 2, METRIC, 2>(p, s);  // 3072
         default: return hipErrorInvalidValue;
     }
 }
 bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric) {
     if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2))
         return false;
-    return dim <= ld && ld % 256u == 0 && ld >= 256u && ld <= 1536u;
+    // (3072 under a Euclidean metric stays on the bf16 mirror: on isotropic rows the 8-bit margin is ~1 sigma of the score
+    //  spread there — 5 000+ candidates per query, the crowd path, no gain: 2M x 3072, 64 queries 3.35 vs 3.37 ms)
+    if (ld == 3072u && (metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) return false;
+    return dim <= ld && ld % 256u == 0 && ld >= 256u && (ld <= 1536u || ld == 2048u || ld == 3072u);
 }
 
 // Can the MFMA sweep serve this shape?  Cosine / dot / Euclidean, row length a multiple of 128 floats: up to 768, or 1024 / 1280 /
