@@ -254,6 +254,11 @@ struct nmn_ivf {
         QState* qstate = nullptr;
         uint8_t* pin = nullptr;          // pinned: [queries nb x dim x 4 | probe rows nb x n_clusters x 8]
         uint32_t nb = 1;                 // queries of one chunk the buffers above are sized for (probe_slot_grow)
+        // a lone query's list scans enqueued right behind its bitmaps (one round trip per call): their results, device and pinned,
+        // two parts (list-major copy, younger vectors) of res_k entries each: [rows u64 | scores f32 | count u32]
+        uint8_t* res_dev = nullptr;
+        uint8_t* res_pin = nullptr;
+        uint64_t res_k = 0;
         bool busy = false;
     };
     std::vector<std::unique_ptr<ProbeSlot>> slots;
@@ -289,6 +294,8 @@ extern "C" nmn_status nmn_ivf_destroy(nmn_ivf* ivf) {
                         (void*)sl->qinfo, (void*)sl->qstate})
             if (p) (void)hipFree(p);
         if (sl->pin) (void)hipHostFree(sl->pin);
+        if (sl->res_dev) (void)hipFree(sl->res_dev);
+        if (sl->res_pin) (void)hipHostFree(sl->res_pin);
     }
     if (ivf->stream) (void)hipStreamDestroy(ivf->stream);
     if (ivf->cvec) nmn_index_destroy(ivf->cvec);
@@ -692,8 +699,12 @@ extern "C" nmn_status nmn_ivf_centroids(nmn_ivf* ivf, float* out, uint64_t cap_f
 }
 
 // a free probe slot (created on demand; waits when kMaxSlots are all busy)
-static nmn_status probe_slot_acquire(nmn_ivf* ivf, nmn_ivf::ProbeSlot** out) {
+static nmn_status probe_slot_acquire(nmn_ivf* ivf, nmn_ivf::ProbeSlot** out, uint32_t* busy_now = nullptr) {
     std::unique_lock<std::mutex> lk(ivf->slot_mu);
+    if (busy_now) {
+        *busy_now = 1;
+        for (auto& sl : ivf->slots) *busy_now += sl->busy ? 1u : 0u;
+    }
     for (;;) {
         for (auto& sl : ivf->slots)
             if (!sl->busy) {
@@ -802,7 +813,8 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
     std::vector<uint64_t> tmp_ids;
     std::vector<float> tmp_dist;
     nmn_ivf::ProbeSlot* sl = nullptr;
-    nmn_status st = probe_slot_acquire(ivf, &sl);
+    uint32_t searches_now = 1;  // searches of this index in flight, this one included
+    nmn_status st = probe_slot_acquire(ivf, &sl, &searches_now);
     if (st != NMN_OK) return st;
     struct Release {
         nmn_ivf* ivf;
@@ -927,18 +939,82 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
                                    c_rows, sl->mask, (uint64_t)mask_words);
             }
             IVF_TRY(hipGetLastError());
+            // A lone query, nobody else searching: its list scans are enqueued HERE, on this stream, behind the bitmaps they read —
+            // the probe order, both result lists and the counts come back in one copy each behind ONE wait (the call used to be two
+            // round trips: 0.235 ms at 2M x 768 of which the scans' kernels are a third).  With other searches in flight the scans
+            // go through the flat index's host path below instead, where the coalescer merges concurrent probes into batched sweeps.
+            static const bool no_direct = getenv("NMN_IVF_NO_DIRECT") != nullptr;  // (A/B switch)
+            const bool direct = nb == 1 && nq == 1 && searches_now <= 1 && !no_direct && kk1 <= NMN_MAX_TOP_K;
+            const size_t part_bytes = ((size_t)kk1 * 12 + 4 + 15) & ~(size_t)15;
+            if (direct) {
+                if (sl->res_k < kk1) {
+                    IVF_TRY(hipStreamSynchronize(s));
+                    if (sl->res_dev) (void)hipFree(sl->res_dev);
+                    if (sl->res_pin) (void)hipHostFree(sl->res_pin);
+                    sl->res_dev = sl->res_pin = nullptr;
+                    sl->res_k = 0;
+                    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&sl->res_dev), 2 * part_bytes));
+                    IVF_TRY(hipHostMalloc(reinterpret_cast<void**>(&sl->res_pin), 2 * part_bytes, hipHostMallocDefault));
+                    sl->res_k = kk1;
+                }
+                const size_t pb = (((size_t)sl->res_k * 12 + 4 + 15) & ~(size_t)15);
+                auto part = [&](uint8_t* base, int i, uint64_t** r, float** sc, uint32_t** c) {
+                    uint8_t* b = base + (size_t)i * pb;
+                    *r = reinterpret_cast<uint64_t*>(b);
+                    *sc = reinterpret_cast<float*>(b + (size_t)sl->res_k * 8);
+                    *c = reinterpret_cast<uint32_t*>(b + (size_t)sl->res_k * 12);
+                };
+                uint64_t* r;
+                float* sc;
+                uint32_t* c;
+                if (c_rows) {
+                    part(sl->res_dev, 0, &r, &sc, &c);
+                    st = index_search_device(ivf->cvec, sl->qraw, 1, (uint32_t)kk1, kMetricNegL2, sl->mask_c, r, sc, c, s);
+                    if (st != NMN_OK) return st;
+                }
+                if (c_rows < n_rows) {
+                    part(sl->res_dev, 1, &r, &sc, &c);
+                    st = index_search_device(ivf->vectors, sl->qraw, 1, (uint32_t)kk1, kMetricNegL2, sl->mask, r, sc, c, s);
+                    if (st != NMN_OK) return st;
+                }
+                IVF_TRY(hipMemcpyAsync(sl->res_pin, sl->res_dev, 2 * pb, hipMemcpyDeviceToHost, s));
+            }
             IVF_TRY(hipMemcpyAsync(probe_host_all, sl->probe_rows, (size_t)nb * ivf->n_clusters * 8, hipMemcpyDeviceToHost, s));
             IVF_TRY(hipStreamSynchronize(s));
+            if (direct) {
+                const size_t pb = (((size_t)sl->res_k * 12 + 4 + 15) & ~(size_t)15);
+                auto take = [&](int i, std::vector<uint64_t>& ids, std::vector<float>& dist, std::vector<uint32_t>& cnt) {
+                    const uint8_t* b = sl->res_pin + (size_t)i * pb;
+                    const uint64_t* r = reinterpret_cast<const uint64_t*>(b);
+                    const float* sc = reinterpret_cast<const float*>(b + (size_t)sl->res_k * 8);
+                    ids.assign(r, r + kk1);
+                    dist.assign(sc, sc + kk1);
+                    cnt.assign(1, std::min<uint32_t>(*reinterpret_cast<const uint32_t*>(b + (size_t)sl->res_k * 12), (uint32_t)kk1));
+                };
+                batched_c = batched_t = false;
+                if (c_rows) {
+                    take(0, bc_ids, bc_dist, bc_cnt);
+                    batched_c = true;
+                }
+                if (c_rows < n_rows) {
+                    take(1, bt_ids, bt_dist, bt_cnt);
+                    batched_t = true;
+                }
+                if (stats) {  // (what the host path reports for the last list scan of a call)
+                    st = nmn_index_last_stats(c_rows ? ivf->cvec : ivf->vectors, s, stats);
+                    if (st != NMN_OK) return st;
+                }
+            }
             // 2a. the chunk's list scans, batched where that pays (results at k + 1, picked up query by query below)
             hint_c.assign(nb, 0);
             hint_t.assign(nb, 0);
             for (uint32_t i = 0; i < nb; i++) probed_of(probe_host_all + (size_t)i * ivf->n_clusters, &hint_c[i], &hint_t[i]);
-            batched_c = batched_t = false;
-            if (c_rows) {
+            if (!direct) batched_c = batched_t = false;
+            if (c_rows && !direct) {
                 st = scan_many(ivf->cvec, sl->mask_c, hint_c, qh, nb, bc_ids, bc_dist, bc_cnt, &batched_c, (stats && q + nb == nq) ? stats : nullptr);
                 if (st != NMN_OK) return st;
             }
-            if (c_rows < n_rows) {
+            if (c_rows < n_rows && !direct) {
                 st = scan_many(ivf->vectors, sl->mask, hint_t, qh, nb, bt_ids, bt_dist, bt_cnt, &batched_t,
                                (stats && q + nb == nq && !c_rows) ? stats : nullptr);
                 if (st != NMN_OK) return st;
