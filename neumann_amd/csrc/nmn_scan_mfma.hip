@@ -812,6 +812,17 @@ static hipError_t launch_metric_i8(const ScanParams& p, hipStream_t s) {
         return e ? atoi(e) == 8 : false;
     }();
     if (waves8 && p.ld == 768u && !p.mask && !p.qmasks) return launch_one_mfma<3, 1, 4, METRIC, false, 8, true>(p, s);
+    // more than 64 queries in the pass and rows of <= 768 elements: 128 stationary queries per workgroup, two query groups per
+    // wave (192 VGPRs of h / l fragments at 768, as the bf16 form) — one pass over the mirror instead of two folded query blocks
+    static const bool no_qg8 = getenv("NMN_MFMA_I8_NO_128") != nullptr;  // (A/B switch)
+    if (p.nq > 64 && !no_qg8) {
+        switch (p.ld / 256u) {
+            case 1: return launch_kc_i8<1, 1, METRIC, 8>(p, s);
+            case 2: return launch_kc_i8<1, 2, METRIC, 8>(p, s);
+            case 3: return launch_kc_i8<3, 1, METRIC, 8>(p, s);
+            default: break;
+        }
+    }
     switch (p.ld / 256u) {  // = row bytes / 256: the unit the bf16 launcher calls ld / kStageK
         case 1: return launch_kc_i8<1, 1, METRIC>(p, s);   // 256
         case 2: return launch_kc_i8<1, 2, METRIC>(p, s);   // 512
