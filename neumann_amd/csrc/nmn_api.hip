@@ -1222,7 +1222,7 @@ static uint32_t batch_queries(const nmn_index* idx, int metric) {
 }
 // requests that may share a batch: the candidate pipeline (k <= NMN_MAX_TOP_K), at most one sweep's worth of queries
 static bool mergeable(const nmn_index* idx, const HostReq& r) {
-    return coalesce_enabled() && r.k <= NMN_MAX_TOP_K && r.nq <= batch_queries(idx, r.metric);
+    return coalesce_enabled() && !r.own_batch && r.k <= NMN_MAX_TOP_K && r.nq <= batch_queries(idx, r.metric);
 }
 // Same metric, and filters that can share a sweep.  Filters are compared by address: two calls blocked in here with
 // the same mask pointer necessarily mean the same bits (a caller changing them under a running search races with its
@@ -1585,6 +1585,7 @@ nmn_status nmn::index_search_hostio_many(nmn_index* idx, const HostSearchSpec* s
         r.out_counts = specs[i].out_count;
         r.stats = i + 1 == n ? stats : nullptr;
         r.local = i != 0;
+        r.own_batch = i == 0 && n > 1;
         if (i) extras.push_back(&r);
     }
     return host_submit(idx, reqs[0], extras.data(), extras.size());

@@ -112,6 +112,7 @@ struct HostReq {
     std::condition_variable cv;
     bool done = false, lead = false;  // guarded by m
     bool local = false;  // rides in the batch of the request that brought it along (index_search_hostio_many): nobody waits on it
+    bool own_batch = false;  // brings its own riders along: must LEAD (riding in somebody else's batch would leave them unserved)
 };
 
 struct nmn_index {

@@ -289,6 +289,58 @@ def test_many_queries_per_call_share_the_centroid_phase(n, d, c, nprobe, young):
         assert np.array_equal(two[0], gpu.search(Q, 9)[0][:2]) and np.array_equal(two[1], gpu.search(Q, 9)[1][:2])
 
 
+def test_concurrent_multi_query_calls_each_lead_their_own_batch():
+    """Several threads, each calling search with 24 queries: every call hands its list scans to the flat index as a batch of its
+    own.  While the shard is busy such a request waits in the coalescer's queue — where it must not be picked up as a rider of
+    somebody else's batch (its own riders would never be served) — and answers must equal the sequential ones."""
+    import threading
+    from neumann_amd.ivf import GpuIvfFlat
+    rng = np.random.default_rng(5)
+    n, d, nlist, k = 40_000, 128, 32, 10
+    X = (rng.standard_normal((n, d)) + 2.0 * rng.standard_normal((nlist, d))[rng.integers(0, nlist, n)]).astype(np.float32)
+    ivf = GpuIvfFlat.build(X[:8000], nlist, nprobe=4, max_iterations=3, seed=3, init_method="random", capacity_rows=n)
+    with ivf:
+        ivf.add(X[8000:])
+        Q = rng.standard_normal((8 * 24, d)).astype(np.float32) + X[rng.integers(0, n, 8 * 24)]
+        want = [ivf.search(Q[t * 24:(t + 1) * 24], k) for t in range(8)]
+        singles = [ivf.search(Q[j], k) for j in range(0, 8 * 24, 7)]
+        got, errs = [None] * 8, []
+        got1 = [None] * len(singles)
+        start = threading.Barrier(10)
+
+        def many(t):
+            try:
+                start.wait()
+                for _ in range(4):
+                    got[t] = ivf.search(Q[t * 24:(t + 1) * 24], k)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        def single(off):
+            try:
+                start.wait()
+                for _ in range(3):
+                    for i, j in enumerate(range(0, 8 * 24, 7)):
+                        if i % 2 == off:
+                            got1[i] = ivf.search(Q[j], k)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=many, args=(t,)) for t in range(8)] + [threading.Thread(target=single, args=(o,)) for o in (0, 1)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=120)
+        assert not any(x.is_alive() for x in th), "a search never came back"
+        assert not errs, errs
+        for t in range(8):
+            for a, b in zip(want[t], got[t]):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), t
+        for i in range(len(singles)):
+            for a, b in zip(singles[i], got1[i]):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), i
+
+
 # ---- the list-major copy (round 3) ---------------------------------------------------------------------------------------
 def test_list_major_copy_matches_oracle_through_adds_and_relayouts():
     """>= 4096 vectors: probes read a second copy of the vectors ordered by list (contiguous ranges) and map its rows back to
