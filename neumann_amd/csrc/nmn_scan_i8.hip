@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                     if (left < 64) mcache &= (1ull << left) - 1ull;
                 }
                 bool walk_here = walk;
-                if (walk && CH <= NMN_I8_WALK_PIPE_CH) {
+                if (walk && CH <= 3) {
                     // short rows: a step is few loads under a fixed cost per row (list entry, factors, score); from ~20 participating
                     // rows per tile on the tile-by-tile steps are cheaper (measured at 768: selectivity 0.5 0.72 vs 0.75 of peak)
                     uint32_t tot = (uint32_t)__builtin_popcountll(mcache);
