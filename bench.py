@@ -789,7 +789,15 @@ def main():
                  "collective_backend": "nccl (RCCL over xGMI)" if backend == "nccl" else backend,
                  "rank_id_all_gather": "ranks 0..N-1 seen in order on every rank before the measurement",
                  "rows_per_gpu": rows_per_gpu, "gather_plus_merge_ms": float(np.median(gm[2:])),
-                 "gather_bytes_per_rank": int(state["searchers"][0]._bufs["size"]), "host": "one process per GPU (torch.distributed)"}
+                 "gather_bytes_per_rank": int(state["searchers"][0]._bufs["size"]), "host": "one process per GPU (torch.distributed)",
+                 # how to read `value` across N: a query scans the WHOLE corpus, every GPU its shard.  Under weak scaling the corpus
+                 # grows with N (10M rows per GPU), so queries/s staying level IS linear scaling — the quantity that grows with N is
+                 # the shard scans (one GPU, one query, its rows) the job completes per second:
+                 "shard_scans_per_s": None, "corpus_rows_scanned_per_s": None,
+                 "reading": ("weak scaling: rows_total = N x rows_per_gpu; value is queries/s over ALL rows, so value(N) ~ value(1) is "
+                             "100 % efficiency and shard_scans_per_s = N x value is the aggregate that grows with N"
+                             if args.scaling == "weak" else
+                             "strong scaling: rows_total is fixed, every GPU scans 1/N of it; value(N) ~ N x value(1) is 100 % efficiency")}
 
     # ---- the sweeps this one replaced, on the same index / queries / loop: the f32 corpus (§8(d)'s pricing), the bf16 mirror ----
     legs = {}
@@ -895,6 +903,9 @@ def main():
                  "--dim", str(args.dim), "--k", str(args.k), "--metric", args.metric], 240)
         except Exception as e:
             multi["one_process_handle"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and multi is not None and "reading" in multi:
+        multi["shard_scans_per_s"] = value * world
+        multi["corpus_rows_scanned_per_s"] = value * total_rows
     if rank == 0:
         sweep_key, sweep_txt, pricing = SWEEP[elem_bytes]
         line = {
