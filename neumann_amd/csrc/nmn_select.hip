@@ -289,26 +289,23 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         //  loads — under the 8-bit margin ct is ~700 at 1M rows, k = 100: 16 loads per thread in flight instead of 8)
         constexpr int VR = NMN_SELECT_VR;
         for (uint32_t e0 = tid; e0 < tot; e0 += kSelThreads * VR) {
-            uint32_t kb[VR], rr[VR];
+            uint32_t kb[VR];  // (only the loaded scores wait in registers: the row of an element is read from LT again when it is appended)
 #pragma unroll
             for (int u = 0; u < VR; u++) {
                 const uint32_t e = e0 + (uint32_t)u * kSelThreads;
                 kb[u] = kScoreSentinelBits;
-                rr[u] = 0;
                 if (e < tot) {
                     const unsigned long long ent = LT[e >> 6];
-                    if ((uint32_t)(ent >> 32) >= T2m) {
-                        rr[u] = (uint32_t)(ent & 0xFFFFFFFFull) * kTileRows + (e & 63u);
-                        kb[u] = score_bits(rr[u]);
-                    }
+                    if ((uint32_t)(ent >> 32) >= T2m) kb[u] = score_bits((uint32_t)(ent & 0xFFFFFFFFull) * kTileRows + (e & 63u));
                 }
             }
 #pragma unroll
             for (int u = 0; u < VR; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
                 const uint32_t key = bits_to_key(kb[u]);
                 const bool pr = key != kKeyMasked && key >= T2m;
                 const uint32_t pos = wave_append(pr, &s_w[2]);
-                if (pr && pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | rr[u];
+                if (pr && pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | ((uint32_t)(LT[min(e, tot - 1u) >> 6] & 0xFFFFFFFFull) * kTileRows + (e & 63u));
             }
         }
         __syncthreads();
