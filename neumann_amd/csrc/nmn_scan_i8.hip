@@ -171,6 +171,9 @@ constexpr uint32_t kWalkRows = NMN_I8_WALK_ROWS;
 #ifndef NMN_I8_MASKED_QREG_CH   // masked sweeps keep the query planes in registers up to this many chunk groups (else they are read from LDS)
 #define NMN_I8_MASKED_QREG_CH 6
 #endif
+#ifndef NMN_I8_QREG_CH          // ... and unmasked sweeps (measurement knob: 0 = the planes always come from LDS)
+#define NMN_I8_QREG_CH 6
+#endif
 #ifndef NMN_I8_WALK_DENSE
 #define NMN_I8_WALK_DENSE 20u
 #endif
@@ -187,7 +190,7 @@ __device__ __forceinline__ float row_share(float v) {  // lane N of the caller's
 template <int METRIC, bool MASKED, int NQ, int CH, bool SINGLE>
 __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) int qsi[];  // [NQ][2][chunks] x 16 B: h plane, l plane of every query
-    constexpr bool QREG = SINGLE && NQ == 1 && (!MASKED || CH <= NMN_I8_MASKED_QREG_CH);
+    constexpr bool QREG = SINGLE && NQ == 1 && (MASKED ? CH <= NMN_I8_MASKED_QREG_CH : CH <= NMN_I8_QREG_CH);
     const uint32_t ld = p.ld, chunks = ld >> 4;
     const uint32_t q0 = blockIdx.y * NQ;
     {
