@@ -499,10 +499,12 @@ def next_rows_child(args):
         ivf = GpuIvfFlat.build(rows_of(0, tn), C_, nprobe=nprobe, max_iterations=3, seed=42, init_method="kmeans++", capacity_rows=rn)
         t_train = time.perf_counter() - t0
         with ivf:
+            batches = [rows_of(a, min(a + 300_000, rn)) for a in range(tn, rn, 300_000)]  # (generated before the clock starts)
             t0 = time.perf_counter()
-            for a in range(tn, rn, 300_000):
-                ivf.add(rows_of(a, min(a + 300_000, rn)))
+            for b in batches:
+                ivf.add(b)
             t_add = time.perf_counter() - t0
+            del batches
             Q = rows_of(12345, 12345 + 32) + np.float32(0.05)
             ivf.search(Q[0], k)
             reps = 64
