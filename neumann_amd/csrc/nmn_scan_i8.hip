@@ -171,6 +171,9 @@ constexpr uint32_t kWalkRows = NMN_I8_WALK_ROWS;
 #ifndef NMN_I8_MASKED_QREG_CH   // masked sweeps keep the query planes in registers up to this many chunk groups (else they are read from LDS)
 #define NMN_I8_MASKED_QREG_CH 6
 #endif
+#ifndef NMN_I8_NARROW           // 1: rows of 128 elements take the eight-lanes-per-row steps (0: the 16-lane mapping, for the A/B)
+#define NMN_I8_NARROW 1
+#endif
 #ifndef NMN_I8_QREG_CH          // ... and unmasked sweeps (measurement knob: 0 = the planes always come from LDS)
 #define NMN_I8_QREG_CH 6
 #endif
@@ -350,6 +353,7 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
 #endif
     uint64_t mcache = 0;
     const bool walk = MASKED && p.walk != 0;
+    const bool narrow = !MASKED && !SINGLE && CH == 1 && chunks == 8u && NMN_I8_NARROW;  // rows of exactly 128 elements
     for (uint32_t rel = 0; rel < p.tiles_per_wave; rel++) {
         const uint32_t tile = tile_at(rel);
         if (tile >= p.n_tiles) break;
@@ -537,7 +541,8 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
         // lane L finishes tile row (L & 15) * 4 + (L >> 4).  Its scale (and magnitude) are requested HERE, before the tile's rows:
         // a sparse tile is a chain of dependent memory round trips per wave (bitmap -> rows -> these factors -> store), and
         // at selectivity 0.1 a tile is two row steps — the factors' trip alone was a third of the chain.
-        const uint32_t mybit = j * 4u + grp;
+        // (rows of 128 elements, no bitmap: eight lanes per row, eight rows per step — see `narrow` below; lane L finishes row (L & 7) * 8 + (L >> 3))
+        const uint32_t mybit = narrow ? (lane & 7u) * 8u + (lane >> 3) : j * 4u + grp;
         const bool valid = ((mword >> mybit) & 1ull) != 0;
         const uint64_t myrow = r0 + mybit;
         const uint64_t srow = valid ? myrow : r0;  // (rows that do not take part: any valid address of the tile)
@@ -586,7 +591,28 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                 }
             }
         }
-        if (!compacted) {
+        if (narrow) {
+            // 128-byte rows: the 16-lanes-per-row mapping would idle half of every load (0.38 of peak at 10M x 128).  Here a row is
+            // 8 lanes x 16 bytes, a step is 8 rows, and the tile's 8 steps (8 KiB per wave) are all in flight before the first product.
+            const uint32_t j8 = lane & 7u, g8 = lane >> 3;
+            v4i x8[8];
+#pragma unroll
+            for (int st = 0; st < 8; st++)
+                x8[st] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(mat + (r0 + (uint32_t)st * 8u + g8) * (uint64_t)ld) + j8);  // (the mirror is allocated in whole tiles)
+#pragma unroll
+            for (int st = 0; st < 8; st++) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    int hi = 0, lo = 0;
+                    dot16(x8[st], qs4[(uint32_t)q * 2u * chunks + j8], qs4[(uint32_t)q * 2u * chunks + chunks + j8], hi, lo);
+                    float t = (float)hi + (float)lo * 0.00390625f;
+                    t += __shfl_xor(t, 1);
+                    t += __shfl_xor(t, 2);
+                    t += __shfl_xor(t, 4);
+                    if (j8 == (uint32_t)st) mydot[q] = t;
+                }
+            }
+        } else if (!compacted) {
             constexpr int kSteps = CH <= 3 ? 4 : 2;  // row steps whose loads are in flight together (>= 6 x 16 B per lane)
 #pragma unroll kSteps
             for (uint32_t s = 0; s < 16; s++) {
