@@ -26,6 +26,7 @@
 // (8 VGPRs per chunk and lane: 24 at 768, 48 at 1536): no LDS traffic at all in the loop.  Algorithmic bytes per row:
 // dim (+ 4 B scale, 4 B magnitude read, 4 B score written); per launch rows * dim = 7.68 GB at 10M x 768.
 #include <algorithm>
+#include <type_traits>
 
 #include "nmn_internal.h"
 
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
 #endif
     uint64_t mcache = 0;
     const bool walk = MASKED && p.walk != 0;
-    const bool narrow = !MASKED && !SINGLE && CH == 1 && chunks == 8u && NMN_I8_NARROW;  // rows of exactly 128 elements
+    const bool narrow = !MASKED && !SINGLE && (chunks == 8u || chunks == 24u) && NMN_I8_NARROW;  // rows of exactly 128 / 384 elements
     for (uint32_t rel = 0; rel < p.tiles_per_wave; rel++) {
         const uint32_t tile = tile_at(rel);
         if (tile >= p.n_tiles) break;
@@ -592,26 +593,42 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
             }
         }
         if (narrow) {
-            // 128-byte rows: the 16-lanes-per-row mapping would idle half of every load (0.38 of peak at 10M x 128).  Here a row is
-            // 8 lanes x 16 bytes, a step is 8 rows, and the tile's 8 steps (8 KiB per wave) are all in flight before the first product.
+            // 128-byte rows: the 16-lanes-per-row mapping would idle half of every load (0.38 of peak at 10M x 128); 384-byte rows a
+            // quarter (one and a half 256-byte groups).  Here a row is 8 lanes x L8 16-byte loads (L8 = 1 / 3), a step is 8 rows, and
+            // steps are issued kG at a time (128: the tile's 8 steps, 8 KiB per wave; 384: 4 steps, 12 KiB) before the first product.
             const uint32_t j8 = lane & 7u, g8 = lane >> 3;
-            v4i x8[8];
+            auto narrow_tile = [&](auto l8c) __attribute__((always_inline)) {
+                constexpr int L8 = decltype(l8c)::value;
+                constexpr int kG = L8 == 1 ? 8 : 4;
 #pragma unroll
-            for (int st = 0; st < 8; st++)
-                x8[st] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(mat + (r0 + (uint32_t)st * 8u + g8) * (uint64_t)ld) + j8);  // (the mirror is allocated in whole tiles)
+                for (int s0 = 0; s0 < 8; s0 += kG) {
+                    v4i x8[kG][L8];
 #pragma unroll
-            for (int st = 0; st < 8; st++) {
+                    for (int st = 0; st < kG; st++) {
+                        const v4i* rowp = reinterpret_cast<const v4i*>(mat + (r0 + (uint32_t)(s0 + st) * 8u + g8) * (uint64_t)ld);  // (the mirror is allocated in whole tiles)
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    int hi = 0, lo = 0;
-                    dot16(x8[st], qs4[(uint32_t)q * 2u * chunks + j8], qs4[(uint32_t)q * 2u * chunks + chunks + j8], hi, lo);
-                    float t = (float)hi + (float)lo * 0.00390625f;
-                    t += __shfl_xor(t, 1);
-                    t += __shfl_xor(t, 2);
-                    t += __shfl_xor(t, 4);
-                    if (j8 == (uint32_t)st) mydot[q] = t;
+                        for (int c = 0; c < L8; c++) x8[st][c] = __builtin_nontemporal_load(rowp + (uint32_t)c * 8u + j8);
+                    }
+#pragma unroll
+                    for (int st = 0; st < kG; st++) {
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            int hi = 0, lo = 0;
+#pragma unroll
+                            for (int c = 0; c < L8; c++)
+                                dot16(x8[st][c], qs4[(uint32_t)q * 2u * chunks + (uint32_t)c * 8u + j8],
+                                      qs4[(uint32_t)q * 2u * chunks + chunks + (uint32_t)c * 8u + j8], hi, lo);
+                            float t = (float)hi + (float)lo * 0.00390625f;
+                            t += __shfl_xor(t, 1);
+                            t += __shfl_xor(t, 2);
+                            t += __shfl_xor(t, 4);
+                            if (j8 == (uint32_t)(s0 + st)) mydot[q] = t;
+                        }
+                    }
                 }
-            }
+            };
+            if (chunks == 8u) narrow_tile(std::integral_constant<int, 1>{});
+            else narrow_tile(std::integral_constant<int, 3>{});
         } else if (!compacted) {
             constexpr int kSteps = CH <= 3 ? 4 : 2;  // row steps whose loads are in flight together (>= 6 x 16 B per lane)
 #pragma unroll kSteps
