@@ -354,7 +354,11 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
 #endif
     uint64_t mcache = 0;
     const bool walk = MASKED && p.walk != 0;
-    const bool narrow = !MASKED && !SINGLE && (chunks == 8u || chunks == 24u) && NMN_I8_NARROW;  // rows of exactly 128 / 384 elements
+    // rows of exactly 128 / 384 elements: eight lanes per row (under a bitmap: the tile-by-tile steps only — chunks of tiles dense
+    // enough to skip the survivor walk; the walk itself keeps the 16-lane mapping)
+    // (384 under a bitmap keeps the 16-lane steps: its three loads per lane cost the kernel a wave per SIMD, which the walk
+    //  needs more — measured 0.57 -> 0.36 of peak at selectivity 0.25 against 0.66 -> 0.72 at 0.9)
+    const bool narrow = !SINGLE && ((CH == 1 && chunks == 8u) || (!MASKED && CH == 2 && chunks == 24u)) && NMN_I8_NARROW;
     for (uint32_t rel = 0; rel < p.tiles_per_wave; rel++) {
         const uint32_t tile = tile_at(rel);
         if (tile >= p.n_tiles) break;
@@ -564,7 +568,7 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
         bool compacted = false;
         if constexpr (MASKED) {
             const uint32_t cnt = (uint32_t)__builtin_popcountll(mword);
-            if (cnt <= kCompactMaxRows) {  // wave-uniform: sparse tile, every step reads 4 participating rows
+            if (cnt <= kCompactMaxRows && !narrow) {  // wave-uniform: sparse tile, every step reads 4 participating rows
                 compacted = true;
                 float* stg = reinterpret_cast<float*>(qsi + (size_t)NQ * (ld >> 1)) + (threadIdx.x >> 6) * (NQ * 64);
                 uint32_t* tab = reinterpret_cast<uint32_t*>(qsi + (size_t)NQ * (ld >> 1) + 4 * (NQ * 64)) + (threadIdx.x >> 6) * 64;
@@ -599,15 +603,20 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
             const uint32_t j8 = lane & 7u, g8 = lane >> 3;
             auto narrow_tile = [&](auto l8c) __attribute__((always_inline)) {
                 constexpr int L8 = decltype(l8c)::value;
-                constexpr int kG = L8 == 1 ? 8 : 4;
+                constexpr int kG = (L8 == 1 ? 8 : 4) / (MASKED ? 2 : 1);  // (under a bitmap half as many: the walk next door lives on occupancy)
 #pragma unroll
                 for (int s0 = 0; s0 < 8; s0 += kG) {
                     v4i x8[kG][L8];
 #pragma unroll
                     for (int st = 0; st < kG; st++) {
-                        const v4i* rowp = reinterpret_cast<const v4i*>(mat + (r0 + (uint32_t)(s0 + st) * 8u + g8) * (uint64_t)ld);  // (the mirror is allocated in whole tiles)
+                        const uint32_t rbit = (uint32_t)(s0 + st) * 8u + g8;
+                        const bool on = !MASKED || ((mword >> rbit) & 1ull) != 0;  // (rows the bitmap excludes are not read)
+                        const v4i* rowp = reinterpret_cast<const v4i*>(mat + (r0 + rbit) * (uint64_t)ld);  // (the mirror is allocated in whole tiles)
 #pragma unroll
-                        for (int c = 0; c < L8; c++) x8[st][c] = __builtin_nontemporal_load(rowp + (uint32_t)c * 8u + j8);
+                        for (int c = 0; c < L8; c++) {
+                            if (on) x8[st][c] = __builtin_nontemporal_load(rowp + (uint32_t)c * 8u + j8);
+                            else x8[st][c] = (v4i){0, 0, 0, 0};
+                        }
                     }
 #pragma unroll
                     for (int st = 0; st < kG; st++) {
@@ -627,8 +636,8 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                     }
                 }
             };
-            if (chunks == 8u) narrow_tile(std::integral_constant<int, 1>{});
-            else narrow_tile(std::integral_constant<int, 3>{});
+            if constexpr (!SINGLE && CH == 1) narrow_tile(std::integral_constant<int, 1>{});  // (the kernel of 128-element rows)
+            else if constexpr (!SINGLE && CH == 2 && !MASKED) narrow_tile(std::integral_constant<int, 3>{});  // (... of 384-element rows)
         } else if (!compacted) {
             constexpr int kSteps = CH <= 3 ? 4 : 2;  // row steps whose loads are in flight together (>= 6 x 16 B per lane)
 #pragma unroll kSteps
