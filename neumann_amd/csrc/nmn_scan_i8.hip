@@ -476,6 +476,56 @@ __global__ void __launch_bounds__(256) scan_i8_kernel(ScanParams p) {
                                     finish(s0 + 4u, eb, acc, fb);
                                 }
                             }
+                        } else if (!SINGLE && CH == 1 && narrow) {
+                            // 128-element rows: EIGHT listed rows per step, eight lanes each (lanes 0 / 1 / 2 of a row's eight fetch its
+                            // factors), two steps' loads in flight
+                            const uint32_t j8 = lane & 7u, g8 = lane >> 3, base8 = lane & ~7u;
+                            const float* fptr8 = p.i8_scale;
+                            if constexpr (METRIC == NMN_METRIC_COSINE) fptr8 = j8 == 1 ? p.norms : fptr8;
+                            if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) fptr8 = j8 == 1 ? p.i8_vv : (j8 == 2 ? p.norms : fptr8);
+                            const bool f_lane8 = j8 == 0 || (METRIC == NMN_METRIC_COSINE && j8 == 1) ||
+                                                 (METRIC == NMN_METRIC_EUCLIDEAN && (j8 == 1 || (j8 == 2 && any_est_b)));
+                            for (uint32_t s0 = 0; s0 < S; s0 += 16u) {
+                                uint32_t e2[2];
+                                v4i x2[2];
+                                float f2[2];
+#pragma unroll
+                                for (int h = 0; h < 2; h++) {
+                                    const uint32_t idx = s0 + (uint32_t)h * 8u + g8;
+                                    e2[h] = idx < S ? (uint32_t)wtab[idx] : 0xFFFFu;
+                                    const uint64_t row = e2[h] != 0xFFFFu ? row_of(e2[h]) : 0ull;
+                                    x2[h] = (v4i){0, 0, 0, 0};
+                                    f2[h] = 0.f;
+                                    if (e2[h] != 0xFFFFu) {
+                                        x2[h] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(mat + row * (uint64_t)ld) + j8);
+                                        if (f_lane8) f2[h] = fptr8[row];
+                                    }
+                                }
+#pragma unroll
+                                for (int h = 0; h < 2; h++) {
+                                    const bool active = e2[h] != 0xFFFFu;
+                                    const float sr = __shfl(f2[h], (int)base8);
+                                    float vn = 1.f, vb = 0.f;
+                                    if constexpr (METRIC != NMN_METRIC_DOT_PRODUCT) vn = __shfl(f2[h], (int)base8 + 1);
+                                    if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) vb = __shfl(f2[h], (int)base8 + 2);
+                                    (void)vb;
+#pragma unroll
+                                    for (int q = 0; q < NQ; q++) {
+                                        int hi = 0, lo = 0;
+                                        dot16(x2[h], qs4[(uint32_t)q * 2u * chunks + j8], qs4[(uint32_t)q * 2u * chunks + chunks + j8], hi, lo);
+                                        float t = (float)hi + (float)lo * 0.00390625f;
+                                        t += __shfl_xor(t, 1);
+                                        t += __shfl_xor(t, 2);
+                                        t += __shfl_xor(t, 4);
+                                        const float dot = t * (qsc[q] * sr);
+                                        float sc;
+                                        if constexpr (METRIC == NMN_METRIC_COSINE) sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
+                                        else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) sc = qq8[q] < 0.f ? l2_from_dot(qmag[q] * qmag[q], vb * vb, dot, neg) : l2_from_dot(qq8[q], vn, dot, neg);
+                                        else sc = dot;
+                                        if (j8 == 0 && active) wsc[q * kWalkRows + s0 + (uint32_t)h * 8u + g8] = f2u(sc);
+                                    }
+                                }
+                            }
                         } else {
                             for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
                                 const uint32_t e = entry_of(s0);
