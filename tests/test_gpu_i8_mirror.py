@@ -315,6 +315,7 @@ print("WALK-OK")
 
 
 @pytest.mark.parametrize("n,d,waves", [(300_000, 256, "256"), (300_000, 1536, "256"), (200_000, 2048, "256"), (1_200_000, 256, "256"),
+                                        (300_000, 128, "256"), (300_000, 128, ""), (300_000, 384, "256"),   # eight-lane steps (128), the guarded last group (384)
                                         (300_000, 768, ""), (300_000, 768, "nowalk")])
 def test_survivor_walk_of_masked_sweeps_matches_the_oracle(n, d, waves):
     """The masked 8-bit sweep lists the participating rows of up to 64 tiles of a wave and reads them four per step across
