@@ -42,3 +42,11 @@ PY
   rm -rf $O/pmc_$c
 done
 tail -4 $O/gpu_suite_pytest.log; head -12 $O/timeline_i8.txt; cat $O/pmc_mfma_i8_10Mx768.txt
+# the same headline loop with ONE stream (steps serialised): here the trace's average duration of the sweep kernel is directly
+# comparable with roofline.avg_kernel_ms of the bench line (which times the kernel with HIP events, one step on the device at a time)
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace1 -o t -- python $R/bench.py --streams 1 --steps 50 --warmup 5 --rebuilds 1 --no-cpu-baseline --no-other-configs --batched 0 --callers 0 --no-live-pmc --no-parity --no-mirror-legs > $O/bench_traced_1stream.json 2> $O/bench_traced1.err
+DB=$(find $O/trace1 -name "*.db" | head -1)
+python $R/tools/prof_summary.py $DB "bench.py --streams 1 --steps 50 --warmup 5 --rebuilds 1 --no-mirror-legs (one step on the device at a time)" > $O/kernel_trace_1stream.txt 2>&1
+rm -rf $O/trace1
+head -6 $O/kernel_trace_1stream.txt
