@@ -16,28 +16,31 @@ merged on-device.  `--scaling weak` (default; BASELINE config 4) keeps `--rows` 
 `--scaling strong` splits `--rows` rows over the GPUs.  At N = 1 the two are the same run.
 
 Prints ONE JSON line (rank 0):
-  value / ms_per_step   (N > 1 under weak scaling: value = N x queries_per_s_over_all_rows, the aggregate of shard scans — see
-                value_counts) median over `--rebuilds` index rebuilds (each: W warmup steps, then EXACTLY K timed steps between a
-                barrier + synchronize on both sides, max over ranks); `rebuilds` lists every draw — where the driver puts a
+  value / ms_per_step   queries per second over the WHOLE corpus (rows_total rows) at every N — BASELINE.json's metric.  Under weak
+                scaling the corpus grows with N, so `value` staying level is linear scaling; shard scans/s (N x value) is under
+                `multi_gpu`.  The median over `--rebuilds` index rebuilds (each: W warmup steps, then EXACTLY K timed steps between
+                a barrier + synchronize on both sides, max over ranks); `rebuilds` lists every draw — where the driver puts a
                 15 GB buffer moves a single draw by several per cent
   dtype         what the sweep computes in.  The approximate sweep of 1-2 queries reads the shard's 8-BIT mirror (int8 codes,
                 one scale per row, int32 accumulation); every candidate it selects is re-scored from the f32 corpus in the
                 reference's f32 operation order, so the answer is the reference's bit for bit (`parity`)
-  roofline      the dominant kernel of the timed loop.  `achieved` / `frac` count the bytes that kernel is asked to read
-                (rows x dim x bytes_per_corpus_element, `pricing` says so); right beside them `achieved_priced_as_survey_8d` /
-                `frac_priced_as_survey_8d` give the same kernel time priced as SURVEY.md §8(d) writes it (rows x dim x 4: an
-                EFFECTIVE rate that exceeds the HBM peak because fewer bytes move).  `avg_kernel_ms` is the HIP-event average
-                of that kernel in `kernel_timing_loop` (steps enqueued one at a time, nothing else on the device: the clean
-                kernel duration); the timed loop keeps two steps in flight on two streams, where sweeps overlap
-  roofline_f32_corpus / roofline_bf16_mirror  (default single-GPU run) the same index, queries, streams, steps with
-                nmn_index_set_mirror(0) / (2): the sweep of the row-major f32 corpus exactly as §8(d) prices it, and the
-                2-byte mirror the 8-bit one replaced; same answer required
-  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on a bounded row sample
+  roofline      the dominant kernel of the timed loop.  `avg_kernel_ms` = HIP events the library records on the launch stream
+                around that kernel in EVERY timed step (nmn_index_scan_history), of the very loop `value` comes from; sweeps of a
+                shard never run side by side (the next one starts, on the device, when the previous one ends; the selection /
+                rescore tail of a step runs under the next step's sweep), so kernel <= step.  `achieved` / `frac` count the bytes
+                that kernel is asked to read (rows x dim x bytes_per_corpus_element, `pricing` says so); `frac_priced_as_survey_8d`
+                prices the same kernel time as SURVEY.md §8(d) writes it (rows x dim x 4: an EFFECTIVE rate).
+  roofline.f32_corpus   SURVEY §8(d)'s own measurement: the same index, queries, streams, steps with nmn_index_set_mirror(0) — the
+                sweep of the row-major f32 corpus, priced at rows x dim x 4 bytes per query: {queries_per_s, avg_kernel_ms,
+                achieved, frac, traffic}.  roofline.bf16_mirror: the 2-byte mirror, for the record.  Same answer required.
+  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on the WHOLE corpus when the host's RAM
+                holds its twin (else a 1M-row sample, flagged `extrapolated`)
   parity        size-independent exactness certificate of the last timed result (see certificate())
-  batched, concurrent_callers, other_configs, next_rows   further legs of the default single-GPU run (config 3; 64 / 128
-                host threads; configs 2 and 5; SURVEY §8(f): filtered SIMILAR end to end, IVF probe, upload, index load)
-  multi_gpu     (N > 1) rccl_ranks (ranks seen by a real all-gather of rank ids), rows_per_gpu[], gather_plus_merge_ms, and
-                `one_process_handle`: the same GPUs driven by ONE process through the C ABI's nmn_sharded handle
+  batched, concurrent_callers, other_configs, next_rows   further legs of the default single-GPU run (config 3 against BOTH its
+                bounds: HBM and the matrix cores; 64 / 128 host threads; configs 2 and 5; SURVEY §8(f): filtered SIMILAR end to
+                end, IVF probe, upload, index load)
+  multi_gpu     (N > 1) rccl_ranks (ranks seen by a real all-gather of rank ids), rows_per_gpu[], gather_plus_merge_ms,
+                shard_scans_per_s, and `one_process_handle`: the same GPUs driven by ONE process through the C ABI's nmn_sharded
 """
 import argparse
 import json
@@ -54,6 +57,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable by a copy)
+MFMA_I8_PEAK_TOPS = 3944.0     # dense int8, v_mfma_i32_16x16x64_i8 (MI355X_MICROARCH.md, matrix-core table)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (same table)
 SEED_CORPUS = 0x5EED0003
 SEED_QUERY = 0x5EED0002
 METRICS = {"cosine": 0, "euclidean": 1, "dot": 2}
@@ -93,7 +98,7 @@ def parse():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (then it comes from profiles/pmc_traffic.json)")
     ap.add_argument("--no-mirror-legs", "--no-f32-leg", dest="no_mirror_legs", action="store_true",
-                    help="skip the roofline_f32_corpus / roofline_bf16_mirror legs")
+                    help="skip the roofline.f32_corpus / roofline.bf16_mirror legs")
     ap.add_argument("--always-gather", action="store_true",
                     help="run the all-gather + device merge even with one rank (what the N>1 step adds, on a 1-GPU box)")
     ap.add_argument("--batched", type=int, default=64,
@@ -154,14 +159,24 @@ def spawn_ranks(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(args, metric, total_rows, device):
-    """Time the CPU oracle on a bounded row sample (and, as the checker, compare the GPU path with it
-    on that same sample); returns the cpu_baseline object."""
+def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
+    """Time the CPU oracle (and, as the checker, compare the GPU path with it on the same rows); returns the cpu_baseline
+    object.  The WHOLE configured corpus when the host's RAM holds its twin (SURVEY §8(d) allows extrapolation only where it
+    does not): `gpu_answer` = (query index, rows, scores, counts) of the resident GPU index for one of the timed queries.
+    Otherwise a 1M-row sample, scaled linearly and flagged as extrapolated."""
     from oracle import oracle_c as oc
     from neumann_amd import GpuFlatIndex
     cores = os.cpu_count() or 1
-    sample_rows = min(1_000_000, total_rows)  # 3 GB at dim 768: enough rows per thread on a 256-thread host
+    try:
+        ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    except (ValueError, OSError):
+        ram = 0
+    full_bytes = total_rows * args.dim * 4
+    full = ram >= 2 * full_bytes + (16 << 30) and not os.environ.get("NMN_BENCH_CPU_SAMPLE")
+    sample_rows = total_rows if full else min(1_000_000, total_rows)
+    t0 = time.perf_counter()
     A = oc.synth(SEED_CORPUS, 0, sample_rows, args.dim, nthreads=cores)
+    synth_s = time.perf_counter() - t0
     Q = oc.synth(SEED_QUERY, 0, 4, args.dim)
     oc.search(A, Q[0], args.k, metric, partial=True, nthreads=cores, native=True)  # warm (page-in, threads)
     t0 = time.perf_counter()
@@ -176,20 +191,27 @@ def cpu_baseline(args, metric, total_rows, device):
     t0 = time.perf_counter()
     n1 = min(50_000, sample_rows)
     oc.search(A[:n1], Q[0], args.k, metric, partial=True, nthreads=1, native=True)
-    dt1 = (time.perf_counter() - t0) * (sample_rows / float(n1))
-    # checker: the HIP path on the same sample rows must return the oracle's rows and scores
-    with GpuFlatIndex(args.dim, sample_rows, row_base=0, device=device) as small:
-        small.fill_synthetic(SEED_CORPUS, sample_rows)
-        gr, gs, gc = small.search(Q[1], args.k, metric)
-    sample_ok = bool(gc[0] == er.size and np.array_equal(gr[0, :er.size], er) and np.all(gs[0, :er.size] == es))
+    dt1 = (time.perf_counter() - t0) * (1_000_000 / float(n1))
+    # checker: the HIP path on the same rows must return the oracle's rows and scores
+    if full and gpu_answer is not None:
+        qi, gr, gs, gc = gpu_answer
+        er, es = oc.search(A, Q[qi], args.k, metric, partial=True, nthreads=cores, native=True)
+    else:
+        with GpuFlatIndex(args.dim, sample_rows, row_base=0, device=device) as small:
+            small.fill_synthetic(SEED_CORPUS, sample_rows)
+            gr, gs, gc = small.search(Q[1], args.k, metric)
+    sample_ok = bool(gc[0] == er.size and np.array_equal(gr[0, :er.size].astype(np.uint64), er.astype(np.uint64)) and np.all(gs[0, :er.size] == es))
+    del A
     qps_full = 1.0 / (dt * (total_rows / sample_rows))
     return {
         "value": qps_full, "unit": "queries/s", "cores": cores, "kind": "port",
-        "sample": f"{reps} queries x {sample_rows} rows x {args.dim} (same generator/seed), "
-                  f"{dt * 1e3:.2f} ms/query on {cores} threads, extrapolated linearly to {total_rows} rows; "
-                  f"1 thread: {dt1 * 1e3:.1f} ms per {sample_rows} rows. Optimistic for the reference "
-                  f"(flat array, per-thread partial top-k; the Rust path also pays a BTreeMap lookup, two clones "
-                  f"per row and a full sort, published 193-367 ns/row)",
+        "sample": (f"{reps} queries x the WHOLE corpus, {sample_rows} rows x {args.dim} (same generator/seed; host twin built in "
+                   f"{synth_s:.1f} s), {dt * 1e3:.1f} ms/query on {cores} threads, nothing extrapolated" if full else
+                   f"{reps} queries x {sample_rows} rows x {args.dim} (same generator/seed), {dt * 1e3:.2f} ms/query on {cores} threads, "
+                   f"EXTRAPOLATED linearly to {total_rows} rows (host RAM {ram >> 30} GiB does not hold two corpus twins)") +
+                  f"; 1 thread: {dt1 * 1e3:.0f} ms per 1M rows. Optimistic for the reference (flat array, per-thread partial "
+                  f"top-k; the Rust path also pays a BTreeMap lookup, two clones per row and a full sort, published 193-367 ns/row)",
+        "extrapolated": not full, "rows_timed": sample_rows,
         "gbps": sample_rows * args.dim * 4 / dt / 1e9,
         "gpu_matches_oracle_on_sample": sample_ok,
     }
@@ -372,26 +394,21 @@ def measure_batched(args, idx, dev, metric, total_rows, torch, certify=True):
             return searchers[i % 2].search_device(q_dev[i % 4], metric)
 
     steps = max(6, min(args.steps, 16))
+    idx.set_timing(True)  # HIP events around the sweep (its launches and the bound kernels between them), read back after the loop
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
+    for st_ in streams:
+        idx.scan_history(st_)
     t0 = time.perf_counter()
     for i in range(steps):
         out = step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rows, scores, counts = (t.cpu().numpy().copy() for t in out)
-    idx.set_timing(True)
-    sweep_ms = []
-    elem_bytes = 4
-    for i in range(6):
-        torch.cuda.synchronize()  # the sweep alone on the device: its HIP events must not span another step's kernels
-        step(i)
-        st = idx.last_stats(streams[i % 2])
-        if st.scan_ms > 0:
-            sweep_ms.append(st.scan_ms)
-        if st.rows_scanned:
-            elem_bytes = int(st.bytes_scanned // (st.rows_scanned * args.dim))
+    sweep_ms = [x for st_ in streams for x in idx.scan_history(st_) if x > 0]
+    st = idx.last_stats(streams[(steps - 1) % 2])
+    elem_bytes = int(st.bytes_scanned // (st.rows_scanned * args.dim)) if st.rows_scanned else 4
     idx.set_timing(False)
     torch.cuda.synchronize()
     qh = q_host[(steps - 1) % 4]
@@ -687,62 +704,76 @@ def main():
             return state["searchers"][i % n_streams].search_device(q_dev[i % n_query_sets], metric, mask_t=mask_dev)
 
     def timed_loop():
-        """W untimed steps, EXACTLY K timed steps between fences; the elapsed time is the max over ranks."""
+        """W untimed steps, EXACTLY K timed steps between fences; the elapsed time is the max over ranks.  The library's HIP
+        events around the dominant kernel (recorded on the stream it is launched on) are on for the whole loop; the durations
+        of the K timed steps are read back after the closing fence — the kernel time is OF the timed region, so it cannot
+        exceed the step time (sweeps of a large shard never run side by side: nmn_index.h, sweep chain)."""
+        idx = state["idx"]
+        idx.set_timing(True)
         for i in range(args.warmup):
             step(i)
         fence()
+        for st_ in streams:
+            idx.scan_history(st_)  # drop the warm-up's entries
         t0 = time.perf_counter()
         for i in range(args.steps):
             out = step(i)
         fence()
         elapsed = time.perf_counter() - t0
+        scan_ms = [x for st_ in streams for x in idx.scan_history(st_) if x > 0]
+        st = idx.last_stats(streams[(args.steps - 1) % n_streams])
+        eb = int(st.bytes_scanned // (st.rows_scanned * args.dim)) if st.rows_scanned else 4
+        idx.set_timing(False)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, tuple(t.cpu().numpy().copy() for t in out)  # result of the last timed step
+        info = {"scan_ms": scan_ms, "elem_bytes": eb, "candidates": int(st.candidates_rescored), "total_ms_last": float(st.total_ms)}
+        return elapsed, tuple(t.cpu().numpy().copy() for t in out), info  # result of the last timed step
 
-    def kernel_timing_loop():
-        """The dominant kernel's duration: HIP events the library records on the launch stream, steps enqueued and waited for
-        one at a time (its events must not span another step's kernels).  Also the whole pipeline's span in that loop."""
+    def isolated_kernel_ms(n=8):
+        """The same kernel with nothing else on the device (one step at a time, waited for): what the timed loop's figure is
+        compared with.  Not used for `roofline.achieved`."""
         idx = state["idx"]
         idx.set_timing(True)
-        scan_ms, total_ms, cands = [], [], []
-        eb = 4
-        for i in range(min(max(args.steps, 5), 30)):
+        out = []
+        for i in range(n):
             torch.cuda.synchronize()
             step(i)
             st = idx.last_stats(streams[i % n_streams])
             if st.scan_ms > 0:
-                scan_ms.append(st.scan_ms)
-                total_ms.append(st.total_ms)
-                cands.append(st.candidates_rescored)
-            if st.rows_scanned:
-                eb = int(st.bytes_scanned // (st.rows_scanned * args.dim))
+                out.append(st.scan_ms)
         idx.set_timing(False)
+        for st_ in streams:
+            idx.scan_history(st_)
         fence()
-        return scan_ms, total_ms, eb, cands
+        return float(np.mean(out)) if out else None
 
     default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
                         args.metric == "cosine" and args.mask >= 1.0 and args.mirror == 1)
     extras = world == 1 and not args.always_gather
 
     # ---- the headline: median over index rebuilds --------------------------------------------------------------------
-    draws, batched_draws = [], []
+    draws, batched_draws, infos = [], [], []
     last_out = None
     for b in range(max(1, args.rebuilds)):
         build_index()
-        elapsed, last_out = timed_loop()
+        elapsed, last_out, info = timed_loop()
         draws.append(elapsed)
+        infos.append(info)
         if extras and args.batched > 0 and args.nq == 1 and args.mask >= 1.0 and args.mirror == 1:
             batched_draws.append(measure_batched(args, state["idx"], dev, metric, total_rows, torch,
                                                  certify=(b == max(1, args.rebuilds) - 1)))
     idx = state["idx"]
-    elapsed = float(np.median(draws))
+    med = int(np.argsort(draws)[len(draws) // 2])  # the median draw: `value`, `ms_per_step` AND the kernel time come from this one loop
+    elapsed = float(draws[med])
     ms_per_step = elapsed / args.steps * 1e3
     value = args.nq * args.steps / elapsed
-    scan_ms, total_ms, elem_bytes, cands = kernel_timing_loop()
+    scan_ms, elem_bytes, cands = infos[med]["scan_ms"], infos[med]["elem_bytes"], [i["candidates"] for i in infos]
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
+    hbm = idx.hbm_bytes()  # before the legs below build another mirror
+    hbm_bytes_per_row = (hbm[0] + hbm[1] + hbm[2]) / max(idx.rows, 1)
+    scan_alone = isolated_kernel_ms() if world == 1 else None
     # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3 queries at dim >= 768, else >= 5), else 4 (VALU; 2 on
     # the 8-bit mirror) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
     ld128 = (args.dim + 127) // 128 * 128  # nmn_index_create pads rows just short of a supported multiple of 128 up to it
@@ -797,21 +828,21 @@ def main():
                  # grows with N (10M rows per GPU), so queries/s staying level IS linear scaling — the quantity that grows with N is
                  # the shard scans (one GPU, one query, its rows) the job completes per second:
                  "shard_scans_per_s": None, "corpus_rows_scanned_per_s": None,
-                 "reading": ("weak scaling: rows_total = N x rows_per_gpu; `value` = shard_scans_per_s = N x queries_per_s_over_all_rows, the "
-                             "aggregate that grows with N; queries_per_s_over_all_rows staying level from N = 1 up is 100 % efficiency"
+                 "reading": ("weak scaling: rows_total = N x rows_per_gpu; `value` = queries/s over all rows_total rows — staying level from "
+                             "N = 1 up is 100 % efficiency; shard_scans_per_s = N x value is the aggregate that grows with N"
                              if args.scaling == "weak" else
                              "strong scaling: rows_total is fixed, every GPU scans 1/N of it; value(N) ~ N x value(1) is 100 % efficiency")}
 
-    # ---- the sweeps this one replaced, on the same index / queries / loop: the f32 corpus (§8(d)'s pricing), the bf16 mirror ----
+    # ---- the other sweeps on the same index / queries / loop: the row-major f32 corpus (SURVEY §8(d)'s pricing), the bf16 mirror ----
     legs = {}
     if extras and elem_bytes < 4 and not args.no_mirror_legs and args.k <= 4096 and args.nq == 1 and args.mirror == 1:
-        for mode, name in ((0, "roofline_f32_corpus"), (2, "roofline_bf16_mirror")):
+        for mode, name in ((0, "f32_corpus"), (2, "bf16_mirror")):
             if mode == 2 and elem_bytes == 2:
                 continue  # the headline already is the bf16 mirror
             idx.set_mirror(mode)
-            e2, out2 = timed_loop()
-            scan2, total2, eb2, c2 = kernel_timing_loop()
+            e2, out2, info2 = timed_loop()
             idx.set_mirror(args.mirror)
+            scan2, eb2 = info2["scan_ms"], info2["elem_bytes"]
             k_ms = float(np.mean(scan2)) if scan2 else float("nan")
             b2 = alg_bytes_for(eb2)
             ach = b2 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
@@ -821,12 +852,14 @@ def main():
             same = bool(np.array_equal(out2[0], last_out[0]) and np.array_equal(out2[1].view(np.uint32), last_out[1].view(np.uint32)))
             legs[name] = {"what": f"nmn_index_set_mirror({mode}): scan_kernel streams the " + SWEEP[eb2][1] +
                                   "; same index, queries, streams, steps and warmup as the headline loop",
-                          "value": args.nq * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
-                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS if scan2 else None,
-                          "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": b2, "bytes_per_corpus_element": eb2,
-                          "pricing": SWEEP[eb2][2],
+                          "queries_per_s": args.nq * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": ach / HBM_PEAK_GBS if scan2 else None,
+                          "avg_kernel_ms": k_ms, "kernel_launches_timed": len(scan2),
+                          "algorithmic_bytes_per_launch": b2, "bytes_per_corpus_element": eb2,
+                          "pricing": SWEEP[eb2][2], "kernel": "nmn::scan_kernel",
                           "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
-                          "candidates_rescored": int(np.median(c2)) if c2 else None,
+                          "candidates_rescored": info2["candidates"],
                           "traffic": pmc_traffic(local_rows, args, eb2)[0], "traffic_source": pmc_traffic(local_rows, args, eb2)[1],
                           "exact_topk_certified": cert2["exact_topk_certified"] if cert2 else None,
                           "same_answer_as_headline_sweep": same}
@@ -844,9 +877,18 @@ def main():
                    "value": float(np.median(vals)), "unit": "queries/s", "rebuilds": vals,
                    "ms_per_step": float(np.median([b["ms_per_step"] for b in batched_draws])), "steps": batched_draws[-1]["steps"],
                    "sweep_ms_incl_sampling_pass": sweep_med, "sweep_ms_rebuilds": sw, "query_blocks_per_launch": (nq + per_sweep - 1) // per_sweep,
+                   # config 3 is reported against BOTH bounds.  HBM: the mirror's bytes once per 64-128 queries.
+                   # Matrix cores: 2*rows*dim*nq operations per query plane (the 8-bit sweep multiplies two int8 planes of
+                   # every query, h and l: twice the operations of the bf16 form) against the dense peak of that type.
                    "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
-                                "kernel": "nmn::scan_mfma_kernel (+3% sampling pass)", "bytes_per_corpus_element": eb3,
-                                "frac_priced_as_survey_8d": gbps * 4 / eb3 / HBM_PEAK_GBS},
+                                "kernel": "nmn::scan_mfma_kernel (sweep incl. its sampling pass)", "bytes_per_corpus_element": eb3,
+                                "frac_priced_as_survey_8d": gbps * 4 / eb3 / HBM_PEAK_GBS,
+                                "mfma": (lambda planes, peak, name: {
+                                    "bound": name, "planes_per_query": planes,
+                                    "achieved_tops": planes * 2.0 * idx.rows * args.dim * nq / (sweep_med * 1e-3) / 1e12,
+                                    "peak_tops": peak, "unit": "TOP/s" if eb3 == 1 else "TFLOP/s",
+                                    "frac": planes * 2.0 * idx.rows * args.dim * nq / (sweep_med * 1e-3) / 1e12 / peak})(
+                                    *((2, MFMA_I8_PEAK_TOPS, "mfma_i8") if eb3 == 1 else (1, MFMA_BF16_PEAK_TFLOPS, "mfma_bf16")))},
                    "exact_topk_certified_3_of_batch": batched_draws[-1]["certified"]}
 
     # Single-query calls from many host threads at once (the reference's Arc<VectorEngine> under concurrent clients):
@@ -867,7 +909,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, metric, total_rows, dev_index)
+        ga = None
+        if args.mask >= 1.0 and args.nq == 1:  # the resident index's answer to one of the baseline's queries, for the checker
+            ga = (1,) + tuple(idx.search(q_host[1][0], args.k, metric))
+        cpu = cpu_baseline(args, metric, total_rows, dev_index, ga)
 
     traffic, traffic_src = pmc_traffic(local_rows, args, elem_bytes)
     traffic_rw = None
@@ -880,7 +925,7 @@ def main():
             if key in live:
                 traffic, traffic_src = live[key]["hbm_bytes_per_launch"], live[key]["source"]
                 traffic_rw = [live[key]["read_bytes_corrected"], live[key]["write_bytes"]]
-            for name, key2 in (("roofline_f32_corpus", "f32"), ("roofline_bf16_mirror", "bf16")):
+            for name, key2 in (("f32_corpus", "f32"), ("bf16_mirror", "bf16")):
                 if name in legs and key2 in live:
                     legs[name]["traffic"], legs[name]["traffic_source"] = live[key2]["hbm_bytes_per_launch"], live[key2]["source"]
                     legs[name]["traffic_read_write"] = [live[key2]["read_bytes_corrected"], live[key2]["write_bytes"]]
@@ -906,27 +951,41 @@ def main():
                  "--dim", str(args.dim), "--k", str(args.k), "--metric", args.metric], 240)
         except Exception as e:
             multi["one_process_handle"] = {"error": f"{type(e).__name__}: {e}"}
-    # What `value` counts.  One step = one batch of queries against the WHOLE corpus, every GPU scanning its shard.  With a fixed
-    # corpus (N = 1, or --scaling strong) the units are queries.  Under WEAK scaling the corpus is N x `--rows`: the unit each rank
-    # processes per step is one scan of ITS `--rows`-row shard, and the whole job completes N of them per query — `value` is that
-    # aggregate (units all ranks processed / time: the quantity that grows with N when the path scales), i.e. queries/s
-    # normalised to the `--rows`-row workload BASELINE.json quotes the metric on; the plain queries/s over all N x rows rows is
-    # `queries_per_s_over_all_rows` right beside it, and the two are the same number at N = 1.
-    q_all = value
-    if args.scaling == "weak" and world > 1:
-        value = q_all * world
+    # What `value` counts: queries per second against the WHOLE corpus, at every N (BASELINE.json's metric).  One step = one
+    # batch of queries; every GPU scans its shard of all `rows_total` rows.  Under WEAK scaling (config 4) the corpus grows with
+    # N — `--rows` rows per GPU — so `value` staying level from N = 1 up IS linear scaling; the quantity that grows with N, shard
+    # scans per second (N x value), is reported under `multi_gpu` only.
     if rank == 0 and multi is not None and "reading" in multi:
-        multi["shard_scans_per_s"] = q_all * world
-        multi["corpus_rows_scanned_per_s"] = q_all * total_rows
+        multi["shard_scans_per_s"] = value * world
+        multi["corpus_rows_scanned_per_s"] = value * total_rows
     if rank == 0:
         sweep_key, sweep_txt, pricing = SWEEP[elem_bytes]
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if scan_ms else None,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_read_write": traffic_rw,
+                "kernel": kernel_name, "avg_kernel_ms": scan_avg, "kernel_launches_timed": len(scan_ms),
+                "avg_kernel_ms_from": "HIP events recorded by the library on the launch stream around the kernel, in EVERY step of the "
+                                      "timed loop `value` comes from (nmn_index_scan_history); sweeps of one shard never overlap "
+                                      "(sweep chain), so kernel <= step",
+                "avg_kernel_ms_alone": scan_alone,
+                "pricing": "bytes the kernel is asked to read: " + pricing,
+                "bytes_per_corpus_element": elem_bytes,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                # the same kernel time priced as SURVEY §8(d) writes it (N*d*4 per query): an EFFECTIVE rate, not a bandwidth
+                "achieved_priced_as_survey_8d": achieved * 4 / elem_bytes if scan_ms else None,
+                "frac_priced_as_survey_8d": achieved * 4 / elem_bytes / HBM_PEAK_GBS if scan_ms else None,
+                "candidates_rescored": int(np.median(cands)) if cands else None,
+                # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
+                "measured_read_ceiling": read_ceiling,
+                "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None,
+                # SURVEY §8(d)'s own measurement — the sweep of the row-major f32 corpus, rows*dim*4 bytes per query — on the same
+                # index, queries, streams and steps (nmn_index_set_mirror(0)); and the bf16 mirror, for the record
+                "f32_corpus": legs.get("f32_corpus"),
+                "bf16_mirror": legs.get("bf16_mirror")}
         line = {
             "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "queries_per_s_over_all_rows": q_all,
-            "value_counts": ("queries/s over the whole corpus" if not (args.scaling == "weak" and world > 1) else
-                             f"shard scans/s = {world} GPUs x {q_all:.1f} queries/s over all {total_rows} rows: every query is {world} scans of a "
-                             f"{args.rows}-row shard, the workload the N = 1 figure is quoted on (weak scaling: the corpus grows with N)"),
+            "value_counts": "queries/s over the whole corpus (rows_total rows), at every N",
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": f"{sweep_key} sweep + f32 exact rescore (results bit-equal to the f32 reference path)" if sweep_key != "f32" else "f32",
@@ -939,27 +998,9 @@ def main():
                        "rows_total": total_rows, "rows_per_gpu": local_rows, "dim": args.dim, "k": args.k,
                        "nq": args.nq, "streams": n_streams,
                        "approximate_sweep": sweep_txt + "; every candidate re-scored from the f32 corpus in the reference's order",
+                       "hbm_bytes_per_row": hbm_bytes_per_row, "hbm_bytes_per_element": hbm_bytes_per_row / args.dim,
                        "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if scan_ms else None,
-                         # the same kernel time priced as SURVEY §8(d) writes it (N*d*4 per query): an EFFECTIVE rate
-                         "achieved_priced_as_survey_8d": achieved * 4 / elem_bytes if scan_ms else None,
-                         "frac_priced_as_survey_8d": achieved * 4 / elem_bytes / HBM_PEAK_GBS if scan_ms else None,
-                         "pricing": "bytes the kernel is asked to read: " + pricing,
-                         "bytes_per_corpus_element": elem_bytes,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_read_write": traffic_rw,
-                         "kernel": kernel_name, "avg_kernel_ms": scan_avg,
-                         "avg_kernel_ms_from": "kernel_timing_loop: hipEvents around the kernel, one step on the device at a time",
-                         "kernel_timing_loop": {"ms_per_step": float(np.mean(total_ms)) if total_ms else None,
-                                                "queries_per_s": (args.nq * 1e3 / float(np.mean(total_ms))) if total_ms else None,
-                                                "note": "same loop as avg_kernel_ms: kernel <= step here; the timed loop overlaps two steps"},
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "candidates_rescored": int(np.median(cands)) if cands else None,
-                         # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
-                         "measured_read_ceiling": read_ceiling,
-                         "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None},
-            "roofline_f32_corpus": legs.get("roofline_f32_corpus"),
-            "roofline_bf16_mirror": legs.get("roofline_bf16_mirror"),
+            "roofline": roof,
             "cpu_baseline": cpu,
             "parity": parity,
             "multi_gpu": multi,

@@ -169,16 +169,32 @@ nmn_status nmn_index_search_device(nmn_index* idx, const float* queries_dev, uin
 
 /* Stats of the last search enqueued on `stream` (synchronises that stream). */
 nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_search_stats* stats);
-/* Which matrix the approximate sweep streams.  enabled == 1 (default): the smallest mirror that serves the call — the shard's
- * 8-BIT mirror (int8 codes with a scale per row, 1 byte per corpus element; sweeps of 1-2 queries over rows of whole
- * 256-element groups: 256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096) or else its bf16 mirror (2 bytes per element; every
- * row length, and every query batch on the matrix cores); both are built on first use and carry their MEASURED rounding
- * error into the candidate margin, and a shard whose 8-bit margin keeps overflowing the candidate lists returns to the bf16
- * mirror by itself.  enabled == 2: the bf16 mirror only.  enabled == 0: the row-major f32 corpus itself — the sweep
- * SURVEY.md §8(d) prices at rows * dim * 4 bytes per query (bench.py's `roofline_f32_corpus` leg); query batches then run as
- * VALU sweeps of 4.  Results are identical in every mode (every candidate is re-scored from the f32 corpus in the
- * reference's order). */
+/* With timing on (nmn_index_set_timing): the sweep durations (HIP events on the launch stream, around the dominant kernel) of
+ * the searches enqueued on `stream` since the last call — at most the 64 most recent, oldest first; synchronises the stream.
+ * What bench.py averages over its timed loop for `roofline.achieved`. */
+nmn_status nmn_index_scan_history(nmn_index* idx, void* stream, float* scan_ms, uint32_t cap, uint32_t* n_out);
+/* Which matrix the approximate sweep streams.  enabled == 1 (default): the smallest mirror that serves the call —
+ *   the shard's 8-BIT mirror (int8 codes with a scale per row, 1 byte per corpus element) for sweeps of 1-2 queries over rows
+ *     whose stride is a multiple of 128 elements up to 4096 (128, 256, 384, ... — nmn_index_create pads row lengths just short
+ *     of one up to it), and for query batches (matrix cores) where the stride is a multiple of 256 up to 1536, or 2048, or 3072
+ *     (3072 under NMN_METRIC_EUCLIDEAN stays on the bf16 mirror);
+ *   else its bf16 mirror (2 bytes per element; every row stride, VALU sweeps and — strides of 128 .. 768, 1024, 1280, 1536,
+ *     2048, 3072, 4096 — the matrix cores);
+ *   else the f32 rows.
+ * A shard keeps ONE mirror by default: the one built while its rows arrive (the 8-bit one where the stride allows it: 5 bytes
+ * per element resident with the f32 rows; nmn_index_hbm_bytes reports it), and builds the other only when a call needs it.  A
+ * mirror that does not fit the device's free memory (with room to spare for workspaces) is not built: the call is served from
+ * the next one down — never an error.  Mirrors carry their MEASURED rounding error into the candidate margin, and a shard whose
+ * 8-bit margin keeps overflowing the candidate lists returns to the bf16 mirror by itself.
+ * enabled == 2: the bf16 mirror only.  enabled == 0: the row-major f32 corpus itself — the sweep SURVEY.md §8(d) prices at
+ * rows * dim * 4 bytes per query (bench.py's `roofline.f32_corpus`); query batches then run as VALU sweeps of 4.  Any other
+ * value: NMN_ERR_INVALID_ARGUMENT.  Results are identical in every mode (every candidate is re-scored from the f32 corpus in
+ * the reference's order). */
 nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled);
+/* Device memory the shard holds for its rows: corpus_bytes = the f32 rows (capacity x stride x 4), mirror_bytes = the 8-bit and
+ * bf16 mirrors that exist right now, with their per-row factors; per_row_bytes = magnitudes and their reciprocals.  Workspaces
+ * (per stream, sized by the largest search seen) are not counted.  Any pointer may be null. */
+nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes);
 /* Turn hipEvent timing of the scan kernel on/off for `*_device` searches (default off). */
 nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled);
 

@@ -185,6 +185,8 @@ static void ws_free(Workspace* w) {
     if (w->pin_out) (void)hipHostFree(w->pin_out);
     for (auto& e : w->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : w->hist)
+        if (e) (void)hipEventDestroy(e);
     delete w;
 }
 
@@ -227,7 +229,7 @@ static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32
     Workspace* w = nullptr;
     auto it = idx->ws.find(stream);
     if (it != idx->ws.end()) w = it->second;
-    uint32_t nqc = pass_queries(idx, nq);
+    uint32_t nqc = std::min(pass_queries(idx, nq), idx->ws_nq_limit);
     // k beyond NMN_MAX_TOP_K takes the large-k path, which needs no candidate lists
     uint32_t cand_cap = std::max<uint32_t>(std::min<uint32_t>(idx->cand_cap, NMN_MAX_TOP_K), std::min<uint32_t>(k, NMN_MAX_TOP_K));
     if (w && w->nq_cap >= nqc && w->cand_cap >= cand_cap) {
@@ -273,6 +275,11 @@ static void ws_release_core(Workspace* w) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
+    for (auto& e : w->hist) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    w->hist_head = w->hist_read = 0;
     w->allocated = false;
 }
 
@@ -321,12 +328,18 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
 // NMN_ERR_OUT_OF_MEMORY — instead of launching kernels on null pointers.
 static nmn_status ws_alloc(nmn_index* idx, Workspace* w) {
     if (w->allocated) return NMN_OK;
-    const nmn_status st = ws_alloc_core(idx, w);
-    if (st != NMN_OK) {
+    for (;;) {
+        const nmn_status st = ws_alloc_core(idx, w);
+        if (st == NMN_OK) break;
         const std::string keep = g_last_error;
         ws_release_core(w);
         g_last_error = keep;
-        return st;
+        // Not enough HBM for a pass of this many queries (the score matrix is nq x rows x 4 B: 2.6 GB for 64 queries over 10M
+        // rows): the batch runs as more passes of fewer queries instead of failing — remembered for the shard, so that later
+        // workspaces do not try the large size again.  One query per pass is the floor.
+        if (st != NMN_ERR_OUT_OF_MEMORY || w->nq_cap <= 1) return st;
+        w->nq_cap = std::max<uint32_t>(1, w->nq_cap / 4);
+        idx->ws_nq_limit = std::min(idx->ws_nq_limit, w->nq_cap);
     }
     w->allocated = true;
     return NMN_OK;
@@ -457,6 +470,8 @@ extern "C" nmn_status nmn_index_destroy(nmn_index* idx) {
                     (void*)idx->q8_l2_hint})
         if (p) (void)hipFree(p);
     if (idx->upload_ev) (void)hipEventDestroy(idx->upload_ev);
+    for (auto& e : idx->sweep_ev)
+        if (e) (void)hipEventDestroy(e);
     if (idx->norms) (void)hipFree(idx->norms);
     if (idx->inv_norms) (void)hipFree(idx->inv_norms);
     if (idx->max_norm_bits) (void)hipFree(idx->max_norm_bits);
@@ -487,9 +502,20 @@ extern "C" nmn_status nmn_index_set_rows(nmn_index* idx, uint64_t rows) {
 
 extern "C" nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    if (enabled < 0 || enabled > 2) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "nmn_index_set_mirror: enabled must be 0, 1 or 2");
     std::lock_guard<std::mutex> g(idx->mu);
     idx->mirror_off = enabled == 0;
     idx->i8_off = enabled == 2;
+    return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    const uint64_t elems = idx->cap_pad * (uint64_t)idx->ld;
+    if (corpus_bytes) *corpus_bytes = elems * 4ull;
+    if (mirror_bytes) *mirror_bytes = (idx->q8 ? elems + idx->cap_pad * 12ull : 0ull) + (idx->half ? elems * 2ull : 0ull);
+    if (per_row_bytes) *per_row_bytes = idx->cap_pad * 8ull;
     return NMN_OK;
 }
 
@@ -502,65 +528,104 @@ extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
 static hipError_t half_scratch_get(nmn_index* idx, uint64_t rows, float** out);
 static void half_scratch_trim(nmn_index* idx);
 
+// A mirror is an optimisation: it must never take the HBM the next workspace, shard or upload needs.  Before allocating one
+// the shard asks the driver how much memory is free and leaves the mirror alone unless `bytes` fit with this much to spare
+// (1/16 of the device, at least 2 GiB: workspaces of every shard sharing the device — 2.6 GB each for 64-query passes over 10M rows —, crowd pools, result blocks).  Eight
+// logical 10M x 768 shards on one 288-GB device (BASELINE config 4 on a single GPU: 246 GB of f32 rows) thus give the first
+// few shards their mirror and leave the rest on the f32 sweep.  NMN_MIRROR_RESERVE_MB overrides the reserve.
+static bool mirror_fits(size_t bytes) {
+    static const long long forced_mb = [] {
+        const char* e = getenv("NMN_MIRROR_RESERVE_MB");
+        return e ? atoll(e) : -1ll;
+    }();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;  // (no answer: let hipMalloc decide)
+    }
+    const size_t reserve = forced_mb >= 0 ? (size_t)forced_mb << 20 : std::max<size_t>(total_b / 16, (size_t)2 << 30);
+    return free_b >= bytes && free_b - bytes >= reserve;
+}
+
 // The bf16 mirror of the corpus (nmn_index::half) and its bookkeeping.  Not enough HBM is not an error: the shard then
-// stays on the f32 sweep (half_failed).
+// stays on the f32 sweep (half_failed).  All or nothing: a failure half way frees what it got.
 static nmn_status mirror_alloc(nmn_index* idx, hipStream_t stream) {
     if (idx->half || idx->half_failed) return NMN_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->half), (size_t)idx->cap_pad * idx->ld * 2);
+    const size_t bytes = (size_t)idx->cap_pad * idx->ld * 2;
+    hipError_t e = mirror_fits(bytes) ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->half_err_bits), 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->half_stats), 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->half), bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->half_err_bits, 0, 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->half_stats, 0, 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->half, 0, bytes, stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        idx->half = nullptr;
+        for (void** p : {(void**)&idx->half, (void**)&idx->half_err_bits, (void**)&idx->half_stats}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
         idx->half_failed = true;
         return NMN_OK;
     }
     idx->half_rows = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_err_bits), 8));
-    HIP_TRY(hipMemsetAsync(idx->half_err_bits, 0, 8, stream));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->half_stats), 8));
-    HIP_TRY(hipMemsetAsync(idx->half_stats, 0, 8, stream));
-    HIP_TRY(hipMemsetAsync(idx->half, 0, (size_t)idx->cap_pad * idx->ld * 2, stream));
     return NMN_OK;
 }
 
-// The 8-bit mirror (nmn_index::q8).  Not enough HBM is not an error: the shard stays on the bf16 mirror (q8_failed).
+// The 8-bit mirror (nmn_index::q8).  Not enough HBM is not an error: the shard stays on the bf16 mirror / the f32 corpus
+// (q8_failed).  All or nothing — the small buffers first: a shard whose q8 is set has EVERY q8_* buffer (the sweeps
+// dereference all of them), a failure at any step frees all seven and sets q8_failed.
+static void q8_release(nmn_index* idx) {
+    for (void** p : {(void**)&idx->q8, (void**)&idx->q8_scale, (void**)&idx->q8_vv, (void**)&idx->q8_cos, (void**)&idx->q8_err_bits,
+                     (void**)&idx->q8_stats, (void**)&idx->q8_l2_hint}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    idx->q8_rows = 0;
+}
 static nmn_status q8_alloc(nmn_index* idx, hipStream_t stream) {
     if (idx->q8 || idx->q8_failed) return NMN_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx->q8), (size_t)idx->cap_pad * idx->ld);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_scale), (size_t)idx->cap_pad * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_vv), (size_t)idx->cap_pad * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_cos), (size_t)idx->cap_pad * 4);
+    const size_t bytes = (size_t)idx->cap_pad * idx->ld, per_row = (size_t)idx->cap_pad * 4;
+    hipError_t e = mirror_fits(bytes + 3 * per_row) ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_err_bits), 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_l2_hint), 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_stats), 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_scale), per_row);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_vv), per_row);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&idx->q8_cos), per_row);
+    int8_t* codes = nullptr;  // (idx->q8 is what "the mirror exists" means: set last)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&codes), bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->q8_err_bits, 0, 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->q8_l2_hint, 0, 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->q8_stats, 0, 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(codes, 0, bytes, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->q8_scale, 0, per_row, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->q8_vv, 0, per_row, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->q8_cos, 0, per_row, stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (idx->q8) (void)hipFree(idx->q8);
-        if (idx->q8_scale) (void)hipFree(idx->q8_scale);
-        if (idx->q8_vv) (void)hipFree(idx->q8_vv);
-        idx->q8 = nullptr;
-        idx->q8_scale = nullptr;
-        idx->q8_vv = nullptr;
+        if (codes) (void)hipFree(codes);
+        q8_release(idx);
         idx->q8_failed = true;
         return NMN_OK;
     }
+    idx->q8 = codes;
     idx->q8_rows = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_err_bits), 8));
-    HIP_TRY(hipMemsetAsync(idx->q8_err_bits, 0, 8, stream));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_l2_hint), 4));
-    HIP_TRY(hipMemsetAsync(idx->q8_l2_hint, 0, 4, stream));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->q8_stats), 8));
-    HIP_TRY(hipMemsetAsync(idx->q8_stats, 0, 8, stream));
-    HIP_TRY(hipMemsetAsync(idx->q8, 0, (size_t)idx->cap_pad * idx->ld, stream));
-    HIP_TRY(hipMemsetAsync(idx->q8_scale, 0, (size_t)idx->cap_pad * 4, stream));
-    HIP_TRY(hipMemsetAsync(idx->q8_vv, 0, (size_t)idx->cap_pad * 4, stream));
-    HIP_TRY(hipMemsetAsync(idx->q8_cos, 0, (size_t)idx->cap_pad * 4, stream));
     return NMN_OK;
 }
 
-// rows the 8-bit mirror already holds were overwritten: re-quantize them in place (rows beyond it are converted lazily)
-static nmn_status q8_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream) {
-    if (!idx->q8 || row0 >= idx->q8_rows) return NMN_OK;
-    const uint64_t cnt = std::min(row0 + n, idx->q8_rows) - row0;
+// Rows were written: keep the 8-bit mirror current.  Rows it already holds are re-quantized in place; a write that starts inside
+// or right behind the rows it holds extends it when `extend` says so (bulk writes: the first search then finds the mirror
+// built); otherwise rows beyond it are converted lazily, by the first search that wants them (search_enqueue).
+static nmn_status q8_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream, bool extend = false) {
+    if (!idx->q8 || row0 > idx->q8_rows || n == 0) return NMN_OK;
+    const uint64_t end = extend ? row0 + n : std::min(row0 + n, idx->q8_rows);
+    if (end <= row0) return NMN_OK;
+    const uint64_t cnt = end - row0;
     float* scratch = nullptr;
     HIP_TRY(half_scratch_get(idx, cnt, &scratch));
     HIP_TRY(launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->q8_cos, idx->ld, row0, cnt, idx->norms, scratch, idx->q8_err_bits, stream));
+    idx->q8_rows = std::max(idx->q8_rows, end);
     if (idx->half_scratch_cap > (1u << 20)) {
         HIP_TRY(hipStreamSynchronize(stream));
         half_scratch_trim(idx);
@@ -568,15 +633,32 @@ static nmn_status q8_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_
     return NMN_OK;
 }
 
-// What every writer of rows runs behind the copy: magnitudes in reference order, and the bf16 mirror of the same rows.
+// Which mirror a shard builds while its rows arrive.  ONE: the 8-bit one (1 B per element: with the f32 rows 5 B per element
+// resident) where the row stride lets the 8-bit sweeps serve the shard's searches, else the bf16 one (2 B).  The other is
+// built on demand only — by the first search that needs it (a batch on a row length the 8-bit matrix-core sweep does not
+// cover; a shard whose 8-bit margin proved useless and that went back to the bf16 mirror, search_enqueue).
+static bool ingest_wants_q8(const nmn_index* idx) {
+    return !idx->mirror_off && !idx->i8_off && !no_i8() && !idx->q8_failed && idx->cap >= i8_min_rows() &&
+           scan_i8_supported(idx->ld, idx->dim, NMN_METRIC_COSINE);
+}
+
+// What every writer of rows runs behind the copy: magnitudes in reference order, and the shard's mirror of the same rows.
 // Rows in whole 32-float stages with no scalar tail take the ONE-PASS kernel (nmn_ingest.hip: one read of the f32 rows
 // feeds the magnitude chains, the bf16 pack and the error norms); a bulk write (>= 4096 rows) allocates the mirror right
 // away so that the first search finds it built.  Other shapes: norms_kernel now, the mirror lazily (search_enqueue).
 static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream) {
     static const bool no_ingest = env_set("NMN_NO_INGEST");  // measurement knob: the three-pass path of round 1
+    const bool bulk = n >= 4096 && row0 == 0;
+    const bool q8_first = ingest_wants_q8(idx);
+    if (bulk && q8_first && !idx->q8) {
+        nmn_status st = q8_alloc(idx, stream);
+        if (st != NMN_OK) return st;
+    }
+    // (a write of >= 4096 rows that starts inside or right behind the rows the 8-bit mirror holds extends it)
+    const bool q8_extend = idx->q8 && n >= 4096 && row0 <= idx->q8_rows;
     if (ingest_supported(idx->ld, idx->dim) && !no_ingest) {
-        const bool want_mirror = !idx->mirror_off && !no_half() && !idx->half_failed;
-        if (want_mirror && !idx->half && n >= 4096 && row0 == 0) {
+        const bool want_half = !q8_first && !idx->mirror_off && !no_half() && !idx->half_failed;
+        if (want_half && !idx->half && bulk) {
             nmn_status st = mirror_alloc(idx, stream);
             if (st != NMN_OK) return st;
         }
@@ -584,7 +666,7 @@ static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStr
         HIP_TRY(launch_ingest(idx->corpus, idx->ld, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, with_half ? idx->half : nullptr,
                               idx->half_err_bits, stream));
         if (with_half) idx->half_rows = std::max(idx->half_rows, row0 + n);
-        return q8_patch(idx, row0, n, stream);
+        return q8_patch(idx, row0, n, stream, q8_extend);
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, stream));
     if (idx->half && row0 < idx->half_rows) {
@@ -599,7 +681,7 @@ static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStr
             half_scratch_trim(idx);
         }
     }
-    return q8_patch(idx, row0, n, stream);
+    return q8_patch(idx, row0, n, stream, q8_extend);
 }
 
 static nmn_status upload_common(nmn_index* idx, const float* src, bool src_is_host, uint64_t row0, uint64_t n,
@@ -780,16 +862,62 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
-        // The approximate sweep reads the shard's bf16 MIRROR (half the bytes of the f32 corpus; its measured rounding
-        // error is part of the candidate margin): >= 3-5 queries of a cosine / dot batch go through the matrix cores (one
-        // sweep per 64 queries; Euclidean too), everything else through the VALU sweep (4 queries per sweep).  The mirror is
-        // allocated and filled on first use and extended when rows were uploaded since.
+        // The approximate sweep reads a MIRROR of the shard where one serves the call (its measured rounding error is part of
+        // the candidate margin; every candidate is re-scored from the f32 rows): the 8-BIT mirror (1 B per element,
+        // nmn_scan_i8.hip / nmn_scan_mfma.hip) for 1-2 queries on rows of whole 128-element halves and for batches on the row
+        // lengths its matrix-core sweep covers; else the bf16 mirror (2 B; VALU sweep, or the matrix cores from 3-5 queries on);
+        // else the f32 corpus.  A shard keeps ONE mirror by default — the one built while its rows arrived (rows_written) — and
+        // builds the other only when a call needs it: here, on first use, extended when rows were uploaded since.  Each has
+        // its own on/off switch: data whose margin keeps overflowing the candidate lists pays a mirror pass AND an f32 retry
+        // per query, so every 256th search the host reads the counters select_kernel keeps and, if more than half of the recent
+        // queries were retried, leaves that mirror alone for the next 8192 searches.
         const bool mfma_shape = nqc >= mfma_min_queries(idx) && n_rows > 0 && scan_mfma_supported(idx->ld, idx->dim, (int)metric) &&
                                 !no_mfma();
-        bool use_half = n_rows > 0 && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
-                        !idx->mirror_off && (mfma_shape || (!no_half() && idx->half_calls >= idx->half_off_until));
-        if (!mfma_shape && idx->half_stats && (++idx->half_calls & 255u) == 0 && idx->half_calls >= idx->half_off_until) {
+        const bool mirrors_on = n_rows > 0 && !idx->mirror_off;
+        static const bool no_i8_masked_mfma = getenv("NMN_NO_I8_MASKED_MFMA") != nullptr;  // (A/B: bitmap batches on the bf16 mirror, as until round 3)
+        const bool i8_shape = mfma_shape ? (!((mask_dev || qmasks_dev) && no_i8_masked_mfma) && !no_i8_mfma() &&
+                                            scan_mfma_i8_supported(idx->ld, idx->dim, (int)metric))
+                                         : (nqc <= 2 && !qmasks_dev && scan_i8_supported(idx->ld, idx->dim, (int)metric));
+        const bool i8_enabled = mirrors_on && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() && !idx->q8_failed;
+        bool use_i8 = i8_enabled && i8_shape && idx->q8_calls >= idx->q8_off_until;
+        if (i8_enabled && i8_shape && idx->q8_stats && (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {
             uint32_t now[2] = {0, 0};  // a plain read of two counters other streams may still be adding to: good enough
+            if (hipMemcpy(now, idx->q8_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                const uint32_t total = now[0] - idx->q8_seen[0], retried = now[1] - idx->q8_seen[1];
+                idx->q8_seen[0] = now[0];
+                idx->q8_seen[1] = now[1];
+                if (total >= 64 && retried * 2 > total) {
+                    idx->q8_off_until = idx->q8_calls + 8192;
+                    use_i8 = false;
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (use_i8) {
+            if (!idx->q8) {
+                st = q8_alloc(idx, stream);
+                if (st != NMN_OK) return st;
+                if (!idx->q8) use_i8 = false;  // not enough HBM: the bf16 mirror or the f32 corpus serves
+            }
+            if (use_i8 && idx->q8_rows < n_rows) {
+                const uint64_t cnt = n_rows - idx->q8_rows;
+                float* scratch = nullptr;
+                HIP_TRY(half_scratch_get(idx, cnt, &scratch));
+                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->q8_cos, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
+                                               idx->q8_err_bits, stream);
+                // rare (first search, or rows uploaded since): wait here so that searches enqueued on OTHER streams
+                // afterwards may rely on the mirror without cross-stream events
+                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
+                half_scratch_trim(idx);
+                if (ce != hipSuccess) return fail_hip(ce, "8-bit mirror");
+                idx->q8_rows = n_rows;
+            }
+        }
+        bool use_half = !use_i8 && mirrors_on && scan_half_supported(idx->ld, (int)metric) && !idx->half_failed &&
+                        (mfma_shape || (!no_half() && idx->half_calls >= idx->half_off_until));
+        if (!use_i8 && !mfma_shape && idx->half_stats && (++idx->half_calls & 255u) == 0 && idx->half_calls >= idx->half_off_until) {
+            uint32_t now[2] = {0, 0};
             if (hipMemcpy(now, idx->half_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
                 const uint32_t total = now[0] - idx->half_seen[0], retried = now[1] - idx->half_seen[1];
                 idx->half_seen[0] = now[0];
@@ -814,58 +942,13 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 HIP_TRY(half_scratch_get(idx, cnt, &scratch));
                 hipError_t ce = launch_half_rows(idx->corpus, idx->half, idx->ld, idx->half_rows, cnt, idx->norms, scratch,
                                                  idx->half_err_bits, stream);
-                // rare (first search, or rows uploaded since): wait here so that searches enqueued on OTHER streams
-                // afterwards may rely on the mirror without cross-stream events
-                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
+                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // (as for the 8-bit mirror: other streams may rely on it from now on)
                 half_scratch_trim(idx);
                 if (ce != hipSuccess) return fail_hip(ce, "bf16 mirror");
                 idx->half_rows = n_rows;
             }
         }
-        const bool use_mfma = mfma_shape && use_half;  // the matrix-core sweep has no f32 variant
-        // 1-2 queries on rows of whole 256-element groups: the 8-BIT mirror (one byte per element, nmn_scan_i8.hip), with its own
-        // measured margin and its own on/off switch; built on first use, extended when rows were uploaded since
-        // ... and unmasked batches on rows of 256 .. 1536 elements take the matrix-core sweep over the same 8-bit mirror
-        const bool i8_ok = use_half && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() && !idx->q8_failed &&
-                           idx->q8_calls >= idx->q8_off_until;
-        const bool i8_valu = i8_ok && !use_mfma && nqc <= 2 && !qmasks_dev && scan_i8_supported(idx->ld, idx->dim, (int)metric);
-        static const bool no_i8_masked_mfma = getenv("NMN_NO_I8_MASKED_MFMA") != nullptr;  // (A/B: bitmap batches on the bf16 mirror, as until round 3)
-        const bool i8_mfma = i8_ok && use_mfma && !((mask_dev || qmasks_dev) && no_i8_masked_mfma) && !no_i8_mfma() &&
-                             scan_mfma_i8_supported(idx->ld, idx->dim, (int)metric);
-        bool use_i8 = i8_valu || i8_mfma;
-        if (use_half && (i8_valu || i8_mfma || (idx->q8_stats && idx->q8_calls < idx->q8_off_until)) && idx->q8_stats &&
-            (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {
-            uint32_t now[2] = {0, 0};
-            if (hipMemcpy(now, idx->q8_stats, 8, hipMemcpyDeviceToHost) == hipSuccess) {
-                const uint32_t total = now[0] - idx->q8_seen[0], retried = now[1] - idx->q8_seen[1];
-                idx->q8_seen[0] = now[0];
-                idx->q8_seen[1] = now[1];
-                if (total >= 64 && retried * 2 > total) {
-                    idx->q8_off_until = idx->q8_calls + 8192;
-                    use_i8 = false;
-                }
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-        if (use_i8) {
-            if (!idx->q8) {
-                st = q8_alloc(idx, stream);
-                if (st != NMN_OK) return st;
-                if (!idx->q8) use_i8 = false;  // not enough HBM: the bf16 mirror serves
-            }
-            if (use_i8 && idx->q8_rows < n_rows) {
-                const uint64_t cnt = n_rows - idx->q8_rows;
-                float* scratch = nullptr;
-                HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-                hipError_t ce = launch_q8_rows(idx->corpus, idx->q8, idx->q8_scale, idx->q8_vv, idx->q8_cos, idx->ld, idx->q8_rows, cnt, idx->norms, scratch,
-                                               idx->q8_err_bits, stream);
-                if (ce == hipSuccess) ce = hipStreamSynchronize(stream);  // (as for the bf16 mirror: other streams may rely on it from now on)
-                half_scratch_trim(idx);
-                if (ce != hipSuccess) return fail_hip(ce, "8-bit mirror");
-                idx->q8_rows = n_rows;
-            }
-        }
+        const bool use_mfma = mfma_shape && (use_half || use_i8);  // the matrix-core sweep has no f32 variant
         if (qmasks_host && !use_mfma) {
             // per-query bitmaps need the matrix-core sweep: this pass runs query by query instead
             for (uint32_t i = 0; i < nqc; i++) {
@@ -880,7 +963,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         w->last_elem_bytes = use_i8 ? 1u : use_half ? 2u : 4u;
         // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
-        const bool f32_retry = use_half && !use_mfma && n_rows >= (1u << 18);
+        const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18);
         // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
@@ -933,7 +1016,18 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.walk = (sp.strided && !no_walk) ? 1u : 0u;
             sp.tile_step = 1;
             sp.skip_key = nullptr;
-            if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[1], stream));
+            // the sweep chain (nmn_index.h): on a large shard this sweep starts when the previous search's sweep — enqueued on
+            // another stream — has ended; its own tail then runs under the next sweep.  NMN_NO_SWEEP_CHAIN=1: the A/B.
+            static const bool no_chain = getenv("NMN_NO_SWEEP_CHAIN") != nullptr;
+            const bool chain = !no_chain && (uint64_t)n_rows * idx->ld * w->last_elem_bytes >= (256ull << 20);
+            if (chain && idx->sweep_seq && idx->sweep_stream != stream)
+                HIP_TRY(hipStreamWaitEvent(stream, idx->sweep_ev[(idx->sweep_seq - 1) & 3u], 0));
+            if (w->timed && qa == 0) {
+                HIP_TRY(hipEventRecord(w->ev[1], stream));
+                hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory)];
+                if (!h) HIP_TRY(hipEventCreate(&h));
+                HIP_TRY(hipEventRecord(h, stream));
+            }
             // Batched sweep on a large shard: a sampling pass over every 32nd tile (tile maxima only) bounds
             // the k-th best score of each query from below, so the main sweep writes scores only for the few
             // tiles that can still hold a candidate.
@@ -993,7 +1087,20 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             } else {
                 HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
             }
-            if (w->timed && qa == 0) HIP_TRY(hipEventRecord(w->ev[2], stream));
+            if (w->timed && qa == 0) {
+                HIP_TRY(hipEventRecord(w->ev[2], stream));
+                hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory) + 1];
+                if (!h) HIP_TRY(hipEventCreate(&h));
+                HIP_TRY(hipEventRecord(h, stream));
+                w->hist_head++;
+            }
+            if (chain) {
+                hipEvent_t& ce = idx->sweep_ev[idx->sweep_seq & 3u];
+                if (!ce) HIP_TRY(hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(ce, stream));
+                idx->sweep_seq++;
+                idx->sweep_stream = stream;
+            }
 
             SelectParams sel{};
             sel.scores = w->scores;
@@ -1207,6 +1314,31 @@ extern "C" nmn_status nmn_index_last_stats(nmn_index* idx, void* stream, nmn_sea
     std::lock_guard<std::mutex> g(idx->mu);
     auto it = idx->ws.find(s);
     return stats_collect(idx, it == idx->ws.end() ? nullptr : it->second, stats);
+}
+
+extern "C" nmn_status nmn_index_scan_history(nmn_index* idx, void* stream, float* scan_ms, uint32_t cap, uint32_t* n_out) {
+    if (!idx || !n_out || (!scan_ms && cap)) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null argument");
+    *n_out = 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipStreamSynchronize(s));
+    std::lock_guard<std::mutex> g(idx->mu);
+    auto it = idx->ws.find(s);
+    if (it == idx->ws.end()) return NMN_OK;
+    Workspace* w = it->second;
+    const uint64_t avail = std::min<uint64_t>(w->hist_head - w->hist_read, Workspace::kTimingHistory);
+    const uint64_t take = std::min<uint64_t>(avail, cap);
+    for (uint64_t i = w->hist_head - take; i < w->hist_head; i++) {  // the most recent `take`, oldest first
+        float ms = -1.f;
+        const uint32_t slot = (uint32_t)(i % Workspace::kTimingHistory);
+        if (hipEventElapsedTime(&ms, w->hist[2 * slot], w->hist[2 * slot + 1]) != hipSuccess) {
+            (void)hipGetLastError();
+            ms = -1.f;
+        }
+        scan_ms[(*n_out)++] = ms;
+    }
+    w->hist_read = w->hist_head;
+    return NMN_OK;
 }
 
 // ---- host-buffer searches: coalescing of concurrent callers into query batches ------------------------

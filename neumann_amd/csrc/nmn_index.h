@@ -76,6 +76,12 @@ struct Workspace {
     uint64_t* lk_keys = nullptr; size_t lk_keys_cap = 0;  // composite keys of the large-k path (k > NMN_MAX_TOP_K)
     // timing + stats of the last search
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // with timing on, the events around the sweep of the last kTimingHistory searches on this stream (nmn_index_scan_history: the
+    // sweep's duration averaged over a timed loop, not just its last step)
+    static constexpr uint32_t kTimingHistory = 64;
+    hipEvent_t hist[2 * kTimingHistory] = {};
+    uint64_t hist_head = 0;    // searches recorded so far
+    uint64_t hist_read = 0;    // ... and handed out
     bool timed = false;
     uint64_t seen_upload_seq = 0;  // last asynchronous upload this workspace's stream has been ordered behind
     bool allocated = false;  // every buffer of ws_alloc exists (set last; a partial allocation is rolled back)
@@ -120,6 +126,7 @@ struct nmn_index {
     uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
     int device = 0;
     uint32_t cand_cap = kDefaultCandCap;
+    uint32_t ws_nq_limit = 0xFFFFFFFFu;  // queries per pipeline pass the device's free memory allowed (ws_alloc lowers it on OOM)
     bool no_single_launch = false;  // NMN_INDEX_NO_SINGLE_LAUNCH
     float* corpus = nullptr;
     float* half = nullptr;       // bf16 mirror of `corpus` every approximate sweep reads (half the bytes); lazy
@@ -156,6 +163,12 @@ struct nmn_index {
     float* inv_norms = nullptr;         // 1 / |v| (0 for a zero row): what the batched cosine sweep multiplies by (one rcp per ROW at
                                         // ingest instead of one per (row, query) in every sweep's epilogue)
     uint32_t* max_norm_bits = nullptr;
+    // Sweeps of a large shard never run side by side: each is HBM-bound on its own, so two at once each take twice as long and
+    // every query waits for both.  A search on another stream waits (on the device) for the previous search's SWEEP — not for its
+    // selection / rescore tail, which runs under the next sweep (nmn_api.hip: sweep chain).
+    hipEvent_t sweep_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t sweep_seq = 0;
+    hipStream_t sweep_stream = nullptr;
     hipEvent_t upload_ev = nullptr;     // recorded behind the latest nmn_index_upload_device (nmn_api.hip: upload_fence_*)
     uint64_t upload_seq = 0;
     hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot

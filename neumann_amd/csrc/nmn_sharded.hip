@@ -656,6 +656,7 @@ extern "C" nmn_status nmn_sharded_set_timing(nmn_sharded* s, int32_t enabled) {
 }
 extern "C" nmn_status nmn_sharded_set_mirror(nmn_sharded* s, int32_t enabled) {
     if (!s) return set_error(NMN_ERR_INVALID_ARGUMENT, "null handle");
+    if (enabled < 0 || enabled > 2) return set_error(NMN_ERR_INVALID_ARGUMENT, "nmn_sharded_set_mirror: enabled must be 0, 1 or 2");
     SoloGuard turn(s);
     for (nmn_index* i : s->shard) (void)nmn_index_set_mirror(i, enabled);
     return NMN_OK;

@@ -231,9 +231,23 @@ class GpuFlatIndex:
 
     def set_mirror(self, enabled):
         """What approximate sweeps read.  True / 1 (default): the smallest mirror that serves the shape — the 8-bit mirror for
-        1-2 queries over rows whose stride is a multiple of 128 elements (batches: of 256, up to 1536), else the bf16 mirror.  2: the bf16 mirror only.  False / 0: the
+        1-2 queries over rows whose stride is a multiple of 128 elements up to 4096 (batches: of 256 up to 1536, 2048, 3072), else the bf16
+        mirror; a shard keeps one mirror and builds the other only when a call needs it (include/neumann_gpu.h).  2: the bf16 mirror only.  False / 0: the
         f32 corpus itself (rows*dim*4 bytes per query, SURVEY §8(d)'s pricing).  Results are identical in every mode."""
         _capi.check(self._lib.nmn_index_set_mirror(self._h, int(enabled)))
+
+    def scan_history(self, stream=None):
+        """Sweep durations (ms) of the timed searches enqueued on `stream` since the last call (at most the 64 most recent)."""
+        buf = (C.c_float * 64)()
+        n = C.c_uint32(0)
+        _capi.check(self._lib.nmn_index_scan_history(self._h, _stream_ptr(stream), buf, 64, C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
+
+    def hbm_bytes(self):
+        """(corpus_bytes, mirror_bytes, per_row_bytes) the shard holds in device memory right now (nmn_index_hbm_bytes)."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _capi.check(self._lib.nmn_index_hbm_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def set_timing(self, enabled):
         _capi.check(self._lib.nmn_index_set_timing(self._h, 1 if enabled else 0))

@@ -121,7 +121,7 @@ class GpuShardedIndex:
 
     def set_mirror(self, enabled):
         from . import _capi
-        _capi.check(self._lib.nmn_sharded_set_mirror(self._h, 1 if enabled else 0))
+        _capi.check(self._lib.nmn_sharded_set_mirror(self._h, int(enabled)))
 
     def last_gather_ms(self):
         import ctypes as C

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "config4_full: BASELINE config 4 at its full row count on ONE GPU (80M x 768 f32 = 246 GB of "
+                                       "HBM, ~1-2 min); deselect with -m 'gpu and not config4_full'")
 
 
 def pytest_sessionstart(session):

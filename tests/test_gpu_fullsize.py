@@ -3,6 +3,7 @@ oracle on a host twin of the same synthetic corpus — rows identical, scores bi
 
     config 2   1M x 768  cosine TOP-100, one query            (+ planted near-duplicates of the query)
     config 3   10M x 768 cosine TOP-100, 64 queries per call  (the matrix-core sweep over the bf16 mirror)
+    config 4   80M x 768 row-range sharded 8 ways: the FULL row count on ONE 288-GB GPU (eight logical shards of 10M rows)
     config 5   10M x 1536 Euclidean TOP-1000 with a WHERE-predicate bitmap, selectivity 1.0 / 0.5 / 0.1
 
 The oracle (oracle/nmn_oracle.c, reference-order arithmetic of vector_engine/src/lib.rs:2049-2101, 2231-2266 and
@@ -140,6 +141,112 @@ def test_config4_shape_eight_shards_of_10Mx768_merge_to_unsharded(corpus_10Mx768
     mr, ms, mc = merge_topk_host(np.stack(lists_r), np.stack(lists_s), np.stack(lists_c), k)
     er, es = _oracle(A, q, k, 0)
     _check_query(mr, ms, mc, 0, er, es)
+
+
+def _device_memory_gb():
+    import torch
+    free, total = torch.cuda.mem_get_info(0)
+    return free / 2**30, total / 2**30
+
+
+@pytest.mark.config4_full
+def test_config4_80Mx768_eight_shards_of_10M_rows_on_one_gpu():
+    """BASELINE config 4 at its FULL row count: 80M x 768 f32 (245.8 GB) as eight row-range shards of 10M rows — shard g owns the
+    global rows [g * 10M, (g + 1) * 10M), SURVEY §8(e) — behind the one-process handle (nmn_sharded_*), all eight on device 0
+    of a 288-GB MI355X (one GPU per shard is the driver's 8-GPU run; the partitioning, the per-shard pipelines, the packed
+    gather and merge_top_k — query_router/src/distributed.rs:413-433 — are the same code).  The mirrors do not all fit beside
+    246 GB of rows: shards that find no room decline theirs and sweep the f32 rows; the answers must not depend on it.
+    Checked: (1) one query per call and a 64-query batch, TOP-100 cosine, every answer of the single queries and three of the
+    batch certified exact by the product's reference-order kernels (corpus-wide rank count, bit-equal scores, order);
+    (2) two single queries and two of the batch against the CPU oracle on a host twin built shard by shard (30.7 GB at a
+    time) and merged with nmn_merge_topk_host; (3) rows planted in the LAST shard come back first, with global ids >= 70M."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import certificate
+    from neumann_amd import GpuShardedIndex
+    from neumann_amd._capi import GATHER_PEER
+    from neumann_amd.flat_index import merge_topk_host
+    free_gb, total_gb = _device_memory_gb()
+    if free_gb < 262:
+        pytest.skip(f"80M x 768 f32 needs ~250 GB of free HBM on one device; this one has {free_gb:.0f} of {total_gb:.0f} GB free")
+    _need_ram(80)
+    G, per, d, k, nq = 8, 10_000_000, 768, 100, 64
+    n = G * per
+    seed = 0x5EED0003
+    Q1 = oc.synth(0x5EED0002, 4000, 4, d)
+    QB = oc.synth(0x5EED0002, 5000, nq, d)
+    # near-duplicates of query 0 in the last shard: a scaled copy (cosine 1 up to rounding) and two perturbed ones
+    rng = np.random.default_rng(0x5EED0004)
+    planted = {}
+    for j, local in enumerate((9_999_999, 1_234_567, 64)):
+        v = Q1[0] * np.float32(1.0 + 0.5 * j)
+        v[rng.integers(0, d, size=3 * j)] += np.float32(2e-3)
+        planted[local] = v.astype(np.float32)
+    with GpuShardedIndex(d, n, G, devices=[0] * G, gather=GATHER_PEER) as sh:
+        sh.fill_synthetic(seed, n)
+        assert sh.rows == n and [sh.shard_rows(g) for g in range(G)] == [per] * G
+        assert [sh.global_row(g, 0) for g in range(G)] == [g * per for g in range(G)]
+        last = sh.shard(G - 1)
+        for local, v in planted.items():
+            last.set_row(local, v)
+        hbm = [sh.shard(g).hbm_bytes() for g in range(G)]
+        assert sum(h[0] for h in hbm) == n * d * 4
+        shards = [sh.shard(g) for g in range(G)]
+
+        # (1) one query per call
+        singles = []
+        elem_bytes = set()
+        for qi in range(4):
+            rows, scores, counts, st = sh.search(Q1[qi], k, 0, with_stats=True)
+            assert counts[0] == k and st.rows_scanned == n
+            elem_bytes.add(st.bytes_scanned / (n * d))
+            c = certificate(shards, Q1[qi], 0, rows, scores, counts, 1, None)
+            assert c["exact_topk_certified"], (qi, c)
+            singles.append((rows.copy(), scores.copy(), counts.copy()))
+        # the planted rows of the last shard lead query 0's list, under their GLOBAL ids
+        top3 = set(int(r) for r in singles[0][0][0, :3])
+        assert top3 == {(G - 1) * per + local for local in planted}, top3
+        # 100 best of 80M uniformly spread rows: every list reaches into the last shard's range (P(miss) = (7/8)^100 ~ 1e-6)
+        assert all(int(r[0].max()) >= 70_000_000 for r, _, _ in singles)
+
+        # 64 queries per call (shards that kept a mirror take the matrix-core sweep, the others f32 VALU sweeps of four)
+        rows_b, scores_b, counts_b, st_b = sh.search(QB, k, 0, with_stats=True)
+        assert np.all(counts_b == k) and st_b.rows_scanned == n
+        for qi in (0, 31, 63):
+            c = certificate(shards, QB[qi], 0, rows_b[qi:qi + 1], scores_b[qi:qi + 1], counts_b[qi:qi + 1], 1, None)
+            assert c["exact_topk_certified"], (qi, c)
+        # the same lists from single-query calls (a different sweep on most shards): bit-equal
+        r1, s1, c1 = sh.search(QB[31], k, 0)
+        assert np.array_equal(r1[0], rows_b[31]) and np.array_equal(s1[0].view(np.uint32), scores_b[31].view(np.uint32))
+        # which mirrors the shards ended up with is the library's business; that they do not all fit is this test's premise
+        hbm_after = [sh.shard(g).hbm_bytes() for g in range(G)]
+        with_mirror = sum(1 for h in hbm_after if h[1] > 0)
+        assert with_mirror < G, "eight 10M x 768 shards with mirrors cannot fit 288 GB: somebody must have declined"
+        print(f"config 4 on one GPU: {with_mirror} of {G} shards hold a mirror; bytes/element swept by the single queries: "
+              f"{sorted(elem_bytes)}; HBM {sum(sum(h) for h in hbm_after) / 2**30:.1f} GiB in shards")
+
+    # (2) the oracle, shard by shard on a host twin of 10M rows at a time, merged as ResultMerger::merge_top_k does
+    checks = [("single", 0, Q1[0]), ("single", 1, Q1[1]), ("batch", 0, QB[0]), ("batch", 63, QB[63])]
+    per_shard = {i: ([], [], []) for i in range(len(checks))}
+    for g in range(G):
+        A = oc.synth(seed, g * per, per, d, nthreads=CORES)
+        if g == G - 1:
+            for local, v in planted.items():
+                A[local] = v
+        for i, (_, _, q) in enumerate(checks):
+            er, es = oc.search(A, q, k, 0, nthreads=CORES, partial=True, native=True, row_base=g * per)
+            rr = np.full(k, NO_ROW, dtype=np.uint64)
+            ss = np.full(k, -np.inf, dtype=np.float32)
+            rr[:er.size] = er
+            ss[:er.size] = es
+            per_shard[i][0].append(rr[None])
+            per_shard[i][1].append(ss[None])
+            per_shard[i][2].append(np.array([er.size], dtype=np.uint32))
+        del A
+    for i, (kind, qi, _) in enumerate(checks):
+        mr, ms, mc = merge_topk_host(np.stack(per_shard[i][0]), np.stack(per_shard[i][1]), np.stack(per_shard[i][2]), k)
+        got = singles[qi] if kind == "single" else (rows_b[qi:qi + 1], scores_b[qi:qi + 1], counts_b[qi:qi + 1])
+        _check_query(got[0], got[1], got[2], 0, mr[0, :mc[0]], ms[0, :mc[0]])
 
 
 def test_config5_10Mx1536_l2_top1000_masked():
