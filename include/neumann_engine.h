@@ -277,6 +277,9 @@ uint64_t nmn_engine_count_matching(nmn_engine* e, const nmn_filter* f);
 uint64_t nmn_engine_mirror_builds(nmn_engine* e);
 /* rows the GPU mirror of (default collection, dim) holds on each GPU: out[0 .. min(cap, shards)); returns the shard count */
 uint32_t nmn_engine_mirror_shard_rows(nmn_engine* e, uint64_t dim, uint64_t* out, uint32_t cap);
+/* device memory of that mirror, summed over its shards: out[0] = the f32 rows, out[1] = the 8-bit / bf16 mirrors that exist right
+ * now (which ones a shard builds: nmn_index_set_mirror in neumann_gpu.h), out[2] = per-row factors; returns the shard count */
+uint32_t nmn_engine_mirror_hbm_bytes(nmn_engine* e, uint64_t dim, uint64_t out[3]);
 /* Pre-filter predicates evaluated by the GPU predicate kernel over the metadata columns, and how many
  * times a column set was (re)built from the store (instrumentation of SURVEY.md §8f-2). */
 uint64_t nmn_engine_device_filter_evals(nmn_engine* e);

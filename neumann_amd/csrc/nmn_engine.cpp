@@ -2221,6 +2221,27 @@ uint32_t nmn_engine_mirror_shard_rows(nmn_engine* e, uint64_t dim, uint64_t* out
     return G;
 }
 
+// device memory of the mirror of (default collection, dim), summed over its shards: out[0] = f32 rows, out[1] = the 8-bit / bf16
+// mirrors that exist right now, out[2] = per-row factors (nmn_index_hbm_bytes); returns the number of shards (0: no such mirror)
+uint32_t nmn_engine_mirror_hbm_bytes(nmn_engine* e, uint64_t dim, uint64_t out[3]) {
+    if (!e || !out) return 0;
+    WriteLock g(e);
+    out[0] = out[1] = out[2] = 0;
+    auto it = e->dflt.mirrors.find(dim);
+    if (it == e->dflt.mirrors.end() || !it->second->has_rows()) return 0;
+    Mirror* m = it->second.get();
+    mirror_flush(&e->dflt, m, dim);
+    const uint32_t G = m->idx ? 1u : nmn_sharded_shards(m->sh);
+    for (uint32_t i = 0; i < G; i++) {
+        uint64_t a = 0, b = 0, c = 0;
+        (void)nmn_index_hbm_bytes(m->idx ? m->idx : nmn_sharded_shard(m->sh, i), &a, &b, &c);
+        out[0] += a;
+        out[1] += b;
+        out[2] += c;
+    }
+    return G;
+}
+
 int32_t nmn_engine_mirror_cached(nmn_engine* e, const char* coll) {
     if (!e) return 0;
     WriteLock g(e);

@@ -136,6 +136,7 @@ ENGINE_SIGNATURES = {
     "nmn_engine_count_matching": (C.c_uint64, [vp, vp]),
     "nmn_engine_mirror_builds": (C.c_uint64, [vp]),
     "nmn_engine_mirror_shard_rows": (C.c_uint32, [vp, C.c_uint64, vp, C.c_uint32]),
+    "nmn_engine_mirror_hbm_bytes": (C.c_uint32, [vp, C.c_uint64, vp]),
     "nmn_engine_device_filter_evals": (C.c_uint64, [vp]),
     "nmn_engine_column_builds": (C.c_uint64, [vp]),
     "nmn_engine_mirror_cached": (C.c_int32, [vp, C.c_char_p]),
@@ -854,6 +855,12 @@ class VectorEngine:
         out = (C.c_uint64 * 64)()
         n = int(_lib().nmn_engine_mirror_shard_rows(self._h, int(dim), out, 64))
         return [int(out[i]) for i in range(min(n, 64))]
+
+    def mirror_hbm_bytes(self, dim):
+        """(f32 row bytes, mirror bytes, per-row bytes) of the default collection's GPU mirror of `dim`; None without one."""
+        out = (C.c_uint64 * 3)()
+        n = int(_lib().nmn_engine_mirror_hbm_bytes(self._h, int(dim), out))
+        return (int(out[0]), int(out[1]), int(out[2])) if n else None
 
     def mirror_builds(self):
         return int(_lib().nmn_engine_mirror_builds(self._h))

@@ -743,6 +743,93 @@ def test_native_threads_searching_while_writers_write():
     assert all("writers=2" in l for l in lines)
 
 
+def test_interleaved_stores_deletes_and_searches_on_the_8_bit_mirror(E):
+    """The incremental mirror protocol (lib.rs:1840-1868, 1915-1925) on a collection large enough for the pipeline path and
+    the 8-bit mirror (80 000 x 256: beyond the single-launch search, row stride a multiple of 128): overwrites re-quantize
+    rows in place, appends extend the mirror at the next search, deletes tombstone — interleaved with searches of every
+    metric, each compared with the oracle over the current contents; then the same from threads (lib.rs:5615-5669's
+    contract: searches and stores from many threads, no error, full lists), and a last comparison with the oracle."""
+    rng = np.random.default_rng(4242)
+    n0, d = 80_000, 256
+    A0 = rng.standard_normal((n0, d)).astype(np.float32)
+    eng = E.VectorEngine()
+    eng.batch_store_embeddings([f"k{i}" for i in range(n0)], A0)
+    model = {f"k{i}": A0[i] for i in range(n0)}
+    next_key = n0
+
+    def check(metric=None):
+        keys = sorted(model, key=lambda s: int(s[1:]))
+        A = np.stack([model[k_] for k_ in keys])
+        q = rng.standard_normal(d).astype(np.float32)
+        k = int(rng.choice([1, 10, 100]))
+        metric = metric if metric is not None else (E.DistanceMetric.Cosine, E.DistanceMetric.Euclidean, E.DistanceMetric.DotProduct)[int(rng.integers(0, 3))]
+        res = eng.search_similar_with_metric(q, k, metric)
+        er, es = oc.search(A, q, k, int(metric), nthreads=8, partial=True, native=True)
+        assert [np.float32(r.score) for r in res] == list(es)
+        assert [r.key for r in res] == [keys[int(i)] for i in er]   # (random rows: no ties)
+
+    check(E.DistanceMetric.Cosine)
+    hb = eng.mirror_hbm_bytes(d)
+    assert hb is not None and hb[1] == hb[0] // 4 + 12 * (hb[2] // 8), ("the mirror of this collection is the 8-bit one (1 B per element)", hb)
+    for step in range(120):
+        op = rng.random()
+        if op < 0.35:                              # append
+            key = f"k{next_key}"
+            next_key += 1
+            model[key] = rng.standard_normal(d).astype(np.float32)
+            eng.store_embedding(key, model[key])
+        elif op < 0.6:                             # overwrite
+            key = f"k{int(rng.integers(0, n0))}"
+            if key in model:
+                model[key] = rng.standard_normal(d).astype(np.float32)
+                eng.store_embedding(key, model[key])
+        elif op < 0.75:                            # delete
+            key = f"k{int(rng.integers(0, n0))}"
+            if key in model:
+                eng.delete_embedding(key)
+                del model[key]
+        else:
+            check()
+    check()
+    # threads: 6 searchers, 2 writers of NEW keys (what they wrote is known afterwards)
+    errors = []
+    written = [{} for _ in range(2)]
+
+    def searcher(t):
+        try:
+            r = np.random.default_rng(100 + t)
+            for j in range(40):
+                res = eng.search_similar(r.standard_normal(d).astype(np.float32), 10)
+                assert len(res) == 10
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    def writer(t):
+        try:
+            r = np.random.default_rng(200 + t)
+            for j in range(60):
+                key = f"k{1_000_000 * (t + 1) + j}"
+                v = r.standard_normal(d).astype(np.float32)
+                eng.store_embedding(key, v)
+                written[t][key] = v
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=searcher, args=(t,)) for t in range(6)] + [threading.Thread(target=writer, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for w in written:
+        model.update(w)
+    assert eng.count() == len(model)
+    for metric in (E.DistanceMetric.Cosine, E.DistanceMetric.Euclidean, E.DistanceMetric.DotProduct):
+        check(metric)
+    hb = eng.mirror_hbm_bytes(d)
+    assert hb is not None and hb[1] > 0 and hb[1] < hb[0] // 2, ("still one 8-bit mirror after the soak", hb)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("NMN_FUZZ_SEEDS", "6"))))
 def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
     """Stores are only recorded next to a live mirror and uploaded in batches before the next search: any order of

@@ -138,6 +138,58 @@ def test_the_8_bit_mirror_switches_itself_off_when_its_margin_is_useless():
         assert st.bytes_scanned == st.rows_scanned * d * 2, "the shard should have left the 8-bit mirror alone by now"
 
 
+def test_a_shard_leaves_the_8_bit_mirror_when_its_data_drifts_and_returns_when_it_drifts_back():
+    """The switch under drift.  A healthy shard (isotropic rows) is overwritten, piece by piece, with rows that
+    all point the same way — the 8-bit margin then covers every row, each query pays the 8-bit pass AND an f32 retry, and
+    within a few hundred searches the shard must go back to the bf16 mirror (built on demand at that moment: a shard keeps one
+    mirror until it needs the other).  The rows are then overwritten with healthy data again: the off period (8192 searches)
+    runs out, the shard re-enters the 8-bit mirror — which was kept current through every overwrite while nobody read it — and
+    stays there.  Every answer on the way is the oracle's, whichever mirror served it; the resident bytes are checked too."""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 300_000, 256, 20
+    rng = np.random.default_rng(77)
+    H = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal(d).astype(np.float32)
+    U = (c[None, :] + np.float32(0.05) * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    H2 = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((6, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(H)
+        elems = idx.hbm_bytes()[0] // 4
+        assert idx.hbm_bytes()[1] == elems + 12 * (idx.hbm_bytes()[2] // 8), "one mirror while the rows arrive: the 8-bit one"
+        for i in range(6):
+            check(idx, H, Q[i], k, i % 3, expect_bytes=1)
+        # drift in: four uploads of 75 000 rows each, searches in between (a mixed shard is still answered exactly)
+        A = H.copy()
+        for part in range(4):
+            lo, hi = part * 75_000, (part + 1) * 75_000
+            A[lo:hi] = U[lo:hi]
+            idx.upload(U[lo:hi], row0=lo)
+            check(idx, A, Q[part], k, 0)
+        for i in range(600):                           # the switch looks at its counters every 256th call
+            idx.search(Q[i % 6], k, 0)
+        st = check(idx, U, Q[0], k, 0)
+        assert st.bytes_scanned == st.rows_scanned * d * 2, "the shard should have left the 8-bit mirror by now"
+        assert idx.hbm_bytes()[1] == 3 * elems + 12 * (idx.hbm_bytes()[2] // 8), "... and built the bf16 mirror when it did"
+        for i in range(6):
+            check(idx, U, Q[i], k, i % 3)
+        # drift back: healthy rows again, written while the 8-bit mirror is switched off (it is re-quantized in place all the same)
+        for part in range(4):
+            lo, hi = part * 75_000, (part + 1) * 75_000
+            A[lo:hi] = H2[lo:hi]
+            idx.upload(H2[lo:hi], row0=lo)
+            check(idx, A, Q[part], k, 1)
+        st = check(idx, H2, Q[0], k, 0)
+        assert st.bytes_scanned == st.rows_scanned * d * 2, "still inside the off period"
+        for i in range(8192 + 256):                    # the off period is counted in searches
+            idx.search(Q[i % 6], k, 0)
+        for i in range(6):
+            check(idx, H2, Q[i], k, i % 3, expect_bytes=1)   # back on the 8-bit mirror, and exact
+        for i in range(600):                           # ... and it stays: healthy data does not trip the switch
+            idx.search(Q[i % 6], k, 0)
+        check(idx, H2, Q[0], k, 0, expect_bytes=1)
+
+
 def test_non_finite_rows_and_queries():
     from neumann_amd import GpuFlatIndex
     n, d, k = 90_000, 512, 30
