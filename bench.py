@@ -394,7 +394,7 @@ def measure_batched(args, idx, dev, metric, total_rows, torch, certify=True):
             return searchers[i % 2].search_device(q_dev[i % 4], metric)
 
     steps = max(6, min(args.steps, 16))
-    idx.set_timing(True)  # HIP events around the sweep (its launches and the bound kernels between them), read back after the loop
+    idx.set_timing(2)  # HIP events around the sweep (its launches and the bound kernels between them), read back after the loop
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
@@ -709,7 +709,7 @@ def main():
         of the K timed steps are read back after the closing fence — the kernel time is OF the timed region, so it cannot
         exceed the step time (sweeps of a large shard never run side by side: nmn_index.h, sweep chain)."""
         idx = state["idx"]
-        idx.set_timing(True)
+        idx.set_timing(2)  # the two events around the sweep, nothing else
         for i in range(args.warmup):
             step(i)
         fence()
@@ -728,7 +728,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        info = {"scan_ms": scan_ms, "elem_bytes": eb, "candidates": int(st.candidates_rescored), "total_ms_last": float(st.total_ms)}
+        info = {"scan_ms": scan_ms, "elem_bytes": eb, "candidates": int(st.candidates_rescored)}
         return elapsed, tuple(t.cpu().numpy().copy() for t in out), info  # result of the last timed step
 
     def isolated_kernel_ms(n=8):

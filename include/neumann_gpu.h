@@ -195,7 +195,9 @@ nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled);
  * bf16 mirrors that exist right now, with their per-row factors; per_row_bytes = magnitudes and their reciprocals.  Workspaces
  * (per stream, sized by the largest search seen) are not counted.  Any pointer may be null. */
 nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes);
-/* Turn hipEvent timing of the scan kernel on/off for `*_device` searches (default off). */
+/* hipEvent timing of searches (default 0 = off).  1: events at the start and end of the pipeline and around its sweep (scan_ms,
+ * total_ms of nmn_index_last_stats).  2: the two events around the sweep only (scan_ms, nmn_index_scan_history) — what a timed
+ * loop can afford on a small shard: every event is a packet of its own in the queue (1M x 768: four more cost ~9 % of a step). */
 nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled);
 
 /* Reference-order scores of arbitrary rows (the exact-rescore kernel exposed on its own):

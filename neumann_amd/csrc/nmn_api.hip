@@ -521,7 +521,7 @@ extern "C" nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes
 
 extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
-    idx->timing = enabled != 0;
+    idx->timing = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     return NMN_OK;
 }
 
@@ -544,7 +544,12 @@ static bool mirror_fits(size_t bytes) {
         return true;  // (no answer: let hipMalloc decide)
     }
     const size_t reserve = forced_mb >= 0 ? (size_t)forced_mb << 20 : std::max<size_t>(total_b / 16, (size_t)2 << 30);
-    return free_b >= bytes && free_b - bytes >= reserve;
+    const bool fits = free_b >= bytes && free_b - bytes >= reserve;
+    static const bool trace = env_set("NMN_TRACE_MIRROR");
+    if (trace)
+        fprintf(stderr, "[nmn] mirror of %.2f GiB: %.2f of %.2f GiB free, reserve %.2f -> %s\n", bytes / 1073741824.0, free_b / 1073741824.0,
+                total_b / 1073741824.0, reserve / 1073741824.0, fits ? "built" : "declined");
+    return fits;
 }
 
 // The bf16 mirror of the corpus (nmn_index::half) and its bookkeeping.  Not enough HBM is not an error: the shard then
@@ -642,17 +647,41 @@ static bool ingest_wants_q8(const nmn_index* idx) {
            scan_i8_supported(idx->ld, idx->dim, NMN_METRIC_COSINE);
 }
 
-// What every writer of rows runs behind the copy: magnitudes in reference order, and the shard's mirror of the same rows.
-// Rows in whole 32-float stages with no scalar tail take the ONE-PASS kernel (nmn_ingest.hip: one read of the f32 rows
-// feeds the magnitude chains, the bf16 pack and the error norms); a bulk write (>= 4096 rows) allocates the mirror right
-// away so that the first search finds it built.  Other shapes: norms_kernel now, the mirror lazily (search_enqueue).
+// rows the bf16 mirror already holds were overwritten: re-round them in place (re-deriving the mirror "from row0 on" made one
+// overwritten row near the top cost a conversion of the whole shard at the next search); rows beyond it are converted lazily
+static nmn_status half_patch(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream) {
+    if (!idx->half || row0 >= idx->half_rows) return NMN_OK;
+    const uint64_t cnt = std::min(row0 + n, idx->half_rows) - row0;
+    float* scratch = nullptr;
+    HIP_TRY(half_scratch_get(idx, cnt, &scratch));
+    HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row0, cnt, idx->norms, scratch, idx->half_err_bits, stream));
+    if (idx->half_scratch_cap > (1u << 20)) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        half_scratch_trim(idx);
+    }
+    return NMN_OK;
+}
+
+// What every writer of rows runs behind the copy: magnitudes in reference order, and the shard's mirror of the same rows — in
+// ONE read of the new rows where their shape allows it (nmn_ingest.hip): ingest_q8_kernel for a shard whose mirror is the 8-bit
+// one (magnitudes, codes, scales, error maxima; rows of whole 128-element halves up to 2048), ingest_kernel for the bf16 one
+// (rows of whole 32-float stages).  A bulk write (>= 4096 rows from row 0) allocates the mirror right away so that the first
+// search finds it built.  Other shapes: norms_kernel now, the mirror by its own kernels (here for rows it already holds, else
+// lazily in search_enqueue).
 static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStream_t stream) {
-    static const bool no_ingest = env_set("NMN_NO_INGEST");  // measurement knob: the three-pass path of round 1
+    static const bool no_ingest = env_set("NMN_NO_INGEST");  // measurement knob: the separate passes of rounds 1-3
     const bool bulk = n >= 4096 && row0 == 0;
     const bool q8_first = ingest_wants_q8(idx);
     if (bulk && q8_first && !idx->q8) {
         nmn_status st = q8_alloc(idx, stream);
         if (st != NMN_OK) return st;
+    }
+    if (idx->q8 && row0 <= idx->q8_rows && ingest_q8_supported(idx->ld, idx->dim) && !no_ingest) {
+        // the 8-bit mirror stays a prefix of the rows: a write inside or right behind it is quantized by the same read
+        HIP_TRY(launch_ingest_q8(idx->corpus, idx->ld, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, idx->q8, idx->q8_scale, idx->q8_vv,
+                                 idx->q8_cos, idx->q8_err_bits, stream));
+        idx->q8_rows = std::max(idx->q8_rows, row0 + n);
+        return half_patch(idx, row0, n, stream);  // (a bf16 mirror built on demand beside it)
     }
     // (a write of >= 4096 rows that starts inside or right behind the rows the 8-bit mirror holds extends it)
     const bool q8_extend = idx->q8 && n >= 4096 && row0 <= idx->q8_rows;
@@ -669,18 +698,8 @@ static nmn_status rows_written(nmn_index* idx, uint64_t row0, uint64_t n, hipStr
         return q8_patch(idx, row0, n, stream, q8_extend);
     }
     HIP_TRY(launch_norms(idx->corpus, idx->ld, idx->dim, row0, n, idx->norms, idx->inv_norms, idx->max_norm_bits, stream));
-    if (idx->half && row0 < idx->half_rows) {
-        // rows the mirror already holds are patched in place (re-deriving the mirror "from row0 on" made one overwritten
-        // row near the top cost a conversion of the whole shard at the next search); rows beyond it are converted lazily
-        const uint64_t cnt = std::min(row0 + n, idx->half_rows) - row0;
-        float* scratch = nullptr;
-        HIP_TRY(half_scratch_get(idx, cnt, &scratch));
-        HIP_TRY(launch_half_rows(idx->corpus, idx->half, idx->ld, row0, cnt, idx->norms, scratch, idx->half_err_bits, stream));
-        if (idx->half_scratch_cap > (1u << 20)) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            half_scratch_trim(idx);
-        }
-    }
+    nmn_status st = half_patch(idx, row0, n, stream);
+    if (st != NMN_OK) return st;
     return q8_patch(idx, row0, n, stream, q8_extend);
 }
 
@@ -755,6 +774,7 @@ static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* quer
     if (n_sort > w->lk_keys_cap) HIP_TRY(hipStreamSynchronize(stream));  // the old buffer may still be in use
     HIP_TRY(grow(&w->lk_keys, &w->lk_keys_cap, (size_t)n_sort));
     w->timed = idx->timing;
+    w->scan_ev_in_hist = false;
     w->last_nq = nq;
     w->last_rows_scanned = n_rows;
     w->last_elem_bytes = 4;
@@ -859,7 +879,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     w->last_nq = nq;
     w->last_rows_scanned = n_rows;
     w->last_masked = mask_dev != nullptr || qmasks_dev != nullptr;
-    if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
+    w->scan_ev_in_hist = false;
+    if (w->timed == 1) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
         // The approximate sweep reads a MIRROR of the shard where one serves the call (its measured rounding error is part of
@@ -879,6 +900,19 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                                             scan_mfma_i8_supported(idx->ld, idx->dim, (int)metric))
                                          : (nqc <= 2 && !qmasks_dev && scan_i8_supported(idx->ld, idx->dim, (int)metric));
         const bool i8_enabled = mirrors_on && n_rows >= i8_min_rows() && !idx->i8_off && !no_i8() && !idx->q8_failed;
+        // 3-4 queries on rows too short for the matrix cores to pay (mfma_min_queries): one bf16 VALU sweep of four reads 2 B per
+        // element — and so do two 8-bit sweeps of two.  A shard that holds the 8-bit mirror and no bf16 one runs the pass as
+        // pairs instead of building (and keeping: 2 more bytes per element) a second mirror for it.
+        if (!mfma_shape && nqc > 2 && nqc <= 4 && i8_enabled && !idx->half && idx->q8 && !qmasks_dev && !qmasks_host &&
+            idx->q8_calls >= idx->q8_off_until && scan_i8_supported(idx->ld, idx->dim, (int)metric)) {
+            for (uint32_t i = 0; i < nqc; i += 2) {
+                st = search_enqueue(idx, w, queries_dev + (size_t)(qa + i) * idx->dim, std::min(2u, nqc - i), k, metric, mask_dev,
+                                    out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i, stream);
+                if (st != NMN_OK) return st;
+            }
+            w->last_nq = nq;
+            continue;
+        }
         bool use_i8 = i8_enabled && i8_shape && idx->q8_calls >= idx->q8_off_until;
         if (i8_enabled && i8_shape && idx->q8_stats && (++idx->q8_calls & 255u) == 0 && idx->q8_calls >= idx->q8_off_until) {
             uint32_t now[2] = {0, 0};  // a plain read of two counters other streams may still be adding to: good enough
@@ -1019,11 +1053,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // the sweep chain (nmn_index.h): on a large shard this sweep starts when the previous search's sweep — enqueued on
             // another stream — has ended; its own tail then runs under the next sweep.  NMN_NO_SWEEP_CHAIN=1: the A/B.
             static const bool no_chain = getenv("NMN_NO_SWEEP_CHAIN") != nullptr;
-            const bool chain = !no_chain && (uint64_t)n_rows * idx->ld * w->last_elem_bytes >= (256ull << 20);
+            const bool chain = !no_chain && (uint64_t)n_rows * idx->ld * w->last_elem_bytes >= (2ull << 30);  // (sweeps of >= ~0.35 ms: below, the two
+            // event packets of the chain cost more than the overlap of two short sweeps — 1M x 768: 5.8 k q/s without, 5.6 k with)
             if (chain && idx->sweep_seq && idx->sweep_stream != stream)
                 HIP_TRY(hipStreamWaitEvent(stream, idx->sweep_ev[(idx->sweep_seq - 1) & 3u], 0));
             if (w->timed && qa == 0) {
-                HIP_TRY(hipEventRecord(w->ev[1], stream));
                 hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory)];
                 if (!h) HIP_TRY(hipEventCreate(&h));
                 HIP_TRY(hipEventRecord(h, stream));
@@ -1088,11 +1122,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
             }
             if (w->timed && qa == 0) {
-                HIP_TRY(hipEventRecord(w->ev[2], stream));
                 hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory) + 1];
                 if (!h) HIP_TRY(hipEventCreate(&h));
                 HIP_TRY(hipEventRecord(h, stream));
                 w->hist_head++;
+                w->scan_ev_in_hist = true;
             }
             if (chain) {
                 hipEvent_t& ce = idx->sweep_ev[idx->sweep_seq & 3u];
@@ -1241,7 +1275,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.out_counts = out_counts + qa;
         HIP_TRY(launch_final(fp, stream));
     }
-    if (w->timed) HIP_TRY(hipEventRecord(w->ev[3], stream));
+    if (w->timed == 1) HIP_TRY(hipEventRecord(w->ev[3], stream));
     return NMN_OK;
 }
 
@@ -1299,8 +1333,14 @@ static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* 
     stats->bytes_scanned = w->last_rows_scanned * (uint64_t)idx->dim * (uint64_t)w->last_elem_bytes;
     if (w->timed) {
         float a = 0.f, b = 0.f;
-        if (w->last_rows_scanned && hipEventElapsedTime(&a, w->ev[1], w->ev[2]) == hipSuccess) stats->scan_ms = a;
-        if (hipEventElapsedTime(&b, w->ev[0], w->ev[3]) == hipSuccess) stats->total_ms = b;
+        hipEvent_t e1 = w->ev[1], e2 = w->ev[2];
+        if (w->scan_ev_in_hist && w->hist_head) {  // (the pipeline keeps the sweep's events in the history ring)
+            const uint32_t slot = (uint32_t)((w->hist_head - 1) % Workspace::kTimingHistory);
+            e1 = w->hist[2 * slot];
+            e2 = w->hist[2 * slot + 1];
+        }
+        if (w->last_rows_scanned && e1 && e2 && hipEventElapsedTime(&a, e1, e2) == hipSuccess) stats->scan_ms = a;
+        if (w->timed == 1 && hipEventElapsedTime(&b, w->ev[0], w->ev[3]) == hipSuccess) stats->total_ms = b;
         (void)hipGetLastError();
     }
     return NMN_OK;

@@ -82,7 +82,8 @@ struct Workspace {
     hipEvent_t hist[2 * kTimingHistory] = {};
     uint64_t hist_head = 0;    // searches recorded so far
     uint64_t hist_read = 0;    // ... and handed out
-    bool timed = false;
+    int timed = 0;             // nmn_index_set_timing level of the last search: 0 off, 1 every event, 2 the sweep's two only
+    bool scan_ev_in_hist = false;  // the last search's sweep events are hist[] entries (the candidate pipeline), not ev[1..2] (large-k path)
     uint64_t seen_upload_seq = 0;  // last asynchronous upload this workspace's stream has been ordered behind
     bool allocated = false;  // every buffer of ws_alloc exists (set last; a partial allocation is rolled back)
     uint32_t last_nq = 0;
@@ -174,7 +175,7 @@ struct nmn_index {
     hipStream_t host_stream = nullptr;  // = host_slots[0]: uploads, exact helpers, and the first search slot
     std::mutex mu;       // guards every field below and all enqueueing; NOT held while a host-buffer search waits
     std::unordered_map<hipStream_t, Workspace*> ws;
-    bool timing = false;
+    int timing = 0;  // nmn_index_set_timing: 0 off, 1 on, 2 sweep events only
     // Host-buffer searches from several threads overlap on the GPU: each takes one of kHostSlots (stream + workspace),
     // enqueues under `mu`, releases `mu` and waits for its own stream.  Anything that changes the shard (upload,
     // set_row, ...) first waits under `mu` until no slot is busy.

@@ -421,7 +421,194 @@ hipError_t launch_exact_rows(const float* corpus, const float* norms, uint32_t l
 }
 
 namespace {
+
+// ---- ONE read of freshly written rows: magnitudes in the reference's order AND their 8-bit mirror --------------------------------
+// What a shard whose mirror is the 8-bit one derives from new rows (until round 4 three kernels read them three
+// times — ingest_kernel for the magnitudes, q8_rows_kernel twice over for max |v| and the codes, q8_err_kernel for the error
+// maxima).  The int8 code of an element needs the row's scale s_r = max |v| / 127, i.e. the whole row, before the first code
+// can be formed: the row has to wait ON CHIP.  64 rows x 3 KB do not fit a wave's share of the LDS, so here the shape is the
+// sweep's instead of the ingest kernel's: SIXTEEN LANES PER ROW, four rows per wave and step, the row held in REGISTERS —
+// lane l of a row group loads the 16-byte chunks l, l + 16, ... (KJ = ld / 64 non-temporal loads, whole 256-byte segments per
+// row and instruction), so the row is 4 * KJ VGPRs (48 at 768 elements, 128 at 2048 — the longest this kernel takes).
+//   * magnitude, hnsw.rs:198-229: accumulator e of the reference's eight walks the chunks of eight c = 0, 1, 2, ... in order.
+//     Element 64 j + 4 l + t sits in load j, lane l, component t: chunk c = 8 j + l / 2, accumulator e = 4 (l & 1) + t.  So a
+//     chain runs through the lanes of one parity, 0 -> 2 -> ... -> 14 (odd: 1 -> ... -> 15), then on to load j + 1 — a
+//     rotate-right-by-two of the 16-lane DPP row per step: acc = row_ror:2(acc) + v * v, four independent chains (t) per lane
+//     interleaved.  Every lane executes every step; the lane pair the chain has reached holds its true value, the others hold
+//     values nobody reads (pair p at step p takes what pair p - 1 computed at step p - 1, before that pair overwrites it).
+//     Seven lanes in eight idle through the chain: 8 * KJ dependent steps per four rows — a fraction of what the row's bytes
+//     cost to fetch (see the traffic note below), and the price of not reading them twice.  Multiply and add are rounded
+//     separately (this translation unit is built with -ffp-contract=off), the eight sums meet left to right from -0.0, sqrt is
+//     correctly rounded: simd::magnitude bit for bit, as ingest_kernel computes it.
+//   * scale, codes, |s c|^2, s / |v|, the row's quantization error |v - s c|: exactly q8_rows_kernel's definitions
+//     (nmn_scan_i8.hip: a non-finite element -> scale 0, codes 0, infinite error), reductions over the DPP row.
+//   * maxima (|v|, |e_r|, |e_r| / |v_r|) per wave in registers: three atomics per wave and launch.
+// Traffic: rows * ld * 4 read + rows * ld written (+ 24 B per row) — 38.6 GB for 10M x 768; bound: HBM.
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float row16_max(float v) {  // all-reduce over a 16-lane DPP row (row_ror 8, 4, 2, 1)
+    v = __builtin_fmaxf(v, dppf<0x128>(v));
+    v = __builtin_fmaxf(v, dppf<0x124>(v));
+    v = __builtin_fmaxf(v, dppf<0x122>(v));
+    v = __builtin_fmaxf(v, dppf<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_add(float v) {
+    v = v + dppf<0x128>(v);
+    v = v + dppf<0x124>(v);
+    v = v + dppf<0x122>(v);
+    v = v + dppf<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ int row16_addi(int v) {
+    v += dppi<0x128>(v);
+    v += dppi<0x124>(v);
+    v += dppi<0x122>(v);
+    v += dppi<0x121>(v);
+    return v;
+}
+
+constexpr int kQ8Waves = 4;  // waves per workgroup (they never meet)
+
+template <int KJ>
+__global__ void __launch_bounds__(kQ8Waves * 64) ingest_q8_kernel(const float* __restrict__ corpus, uint32_t ld, uint64_t row0, uint64_t n,
+                                                                  float* __restrict__ norms, float* __restrict__ inv_norms,
+                                                                  uint32_t* __restrict__ max_norm_bits, int8_t* __restrict__ q8,
+                                                                  float* __restrict__ scale, float* __restrict__ vv, float* __restrict__ cosf,
+                                                                  uint32_t* __restrict__ err_bits) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 15u, rg = lane >> 4;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    float mx_norm = 0.f, mx_err = 0.f, mx_rel = 0.f;
+    for (uint64_t rb = wave * 4; rb < n; rb += n_waves * 4) {
+        const uint64_t ri = rb + rg;
+        const bool live = ri < n;
+        const uint64_t r = row0 + (live ? ri : n - 1);  // (a ragged last group re-reads the last row; nothing of it is stored)
+        const float* src = corpus + r * (uint64_t)ld + l * 4u;
+        v4f x[KJ];
+#pragma unroll
+        for (int j = 0; j < KJ; j++) x[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + j * 64));
+        // ---- the reference's eight chains, and max |v| on the side
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float mx = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < KJ; j++) {
+            float p[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                p[t] = x[j][t] * x[j][t];
+                const float ax = __builtin_fabsf(x[j][t]);
+                bad = bad || !(ax <= 3.0e38f);  // inf or NaN
+                mx = __builtin_fmaxf(mx, ax);
+            }
+#pragma unroll
+            for (int step = 0; step < 8; step++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = dppf<0x122>(acc[t]) + p[t];  // row_ror:2 — the chain moves on to the next lane pair
+            }
+        }
+        // lanes 14 (accumulators 0-3) and 15 (4-7) of the row group hold the eight sums: lane 15 adds them left to right from -0.0
+        float lo[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) lo[t] = dppf<0x111>(acc[t]);  // row_shr:1 — lane 15 sees lane 14's
+        float rsum = -0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) rsum = rsum + lo[t];
+#pragma unroll
+        for (int t = 0; t < 4; t++) rsum = rsum + acc[t];
+        const float mag = dppf<0x15F>(__builtin_sqrtf(rsum));  // row_newbcast:15 — lane 15's (the only meaningful one) to its row group
+        // ---- the row's scale and codes
+        mx = row16_max(mx);
+        bad = row16_addi(bad ? 1 : 0) != 0;
+        const float sc = (bad || mx == 0.f) ? 0.f : mx / 127.0f;
+        const float inv = sc > 0.f ? 127.0f / mx : 0.f;
+        float err2 = 0.f;
+        int cc = 0;  // c.c of this lane's codes: an exact integer
+        uint32_t* dst = reinterpret_cast<uint32_t*>(q8 + r * (uint64_t)ld) + l;
+#pragma unroll
+        for (int j = 0; j < KJ; j++) {
+            uint32_t pk = 0u;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float c = __builtin_rintf(x[j][t] * inv);
+                c = __builtin_fminf(__builtin_fmaxf(c, -127.0f), 127.0f);
+                if (!(c == c)) c = 0.f;
+                const float e = x[j][t] - sc * c;
+                err2 = err2 + e * e;
+                cc += (int)c * (int)c;
+                pk |= ((uint32_t)(int)c & 0xFFu) << (8 * t);
+            }
+            if (live) __builtin_nontemporal_store(pk, dst + j * 16);  // (4 bytes per lane, 64 contiguous bytes per row group)
+        }
+        err2 = row16_add(err2);
+        cc = row16_addi(cc);
+        if (live && l == 15u) {
+            norms[r] = mag;
+            inv_norms[r] = mag == 0.0f ? 0.0f : 1.0f / mag;
+            scale[r] = sc;
+            vv[r] = (sc * sc) * (float)cc;
+            cosf[r] = (mag > 0.f && mag <= 3.0e38f) ? sc / mag : 0.f;
+            if (mag == mag) mx_norm = __builtin_fmaxf(mx_norm, mag);
+            // (q8_err_kernel's rules: slack for the order of the sums; a non-finite row vouches for nothing)
+            const float e = __builtin_sqrtf(bad ? __builtin_inff() : err2) * 1.0005f;
+            if (e > 0.f) {
+                mx_err = __builtin_fmaxf(mx_err, e);
+                if (mag > 0.f || !(mag == mag)) {
+                    float rel = e / mag * 1.0005f;
+                    if (!(rel == rel)) rel = __builtin_inff();
+                    mx_rel = __builtin_fmaxf(mx_rel, rel);
+                }
+            }
+        }
+    }
+    // non-negative floats: bit order == value order
+    mx_norm = wave_max(mx_norm);
+    mx_err = wave_max(mx_err);
+    mx_rel = wave_max(mx_rel);
+    if (lane == 0) {
+        if (mx_norm > 0.f) atomicMax(max_norm_bits, __float_as_uint(mx_norm));
+        if (mx_err > 0.f) atomicMax(err_bits, __float_as_uint(mx_err));
+        if (mx_rel > 0.f) atomicMax(err_bits + 1, __float_as_uint(mx_rel));
+    }
+}
+
+template <int KJ>
+hipError_t launch_ingest_q8_kj(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms, uint32_t* max_norm_bits,
+                               int8_t* q8, float* scale, float* vv, float* cosf, uint32_t* err_bits, hipStream_t s) {
+    const uint64_t groups = (n + 3) / 4;
+    // ~16 waves per CU on a full device; every wave owns the row groups wave, wave + n_waves, ...
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((groups + kQ8Waves - 1) / kQ8Waves, 256ull * 4ull);
+    hipLaunchKernelGGL(ingest_q8_kernel<KJ>, dim3(blocks), dim3(kQ8Waves * 64), 0, s, corpus, ld, row0, n, norms, inv_norms, max_norm_bits, q8, scale,
+                       vv, cosf, err_bits);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+// rows the fused kernel takes: no scalar tail in the reference's magnitude, whole 128-element halves, at most 2048 elements
+// (the row waits in registers: 4 VGPRs per 64 elements)
+bool ingest_q8_supported(uint32_t ld, uint32_t dim) { return dim % 8u == 0 && ld % 128u == 0 && ld >= 128u && ld <= 2048u; }
+
+hipError_t launch_ingest_q8(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms, uint32_t* max_norm_bits,
+                            int8_t* q8, float* scale, float* vv, float* cosf, uint32_t* err_bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+#define NMN_Q8_CASE(KJ_) \
+    case KJ_: return launch_ingest_q8_kj<KJ_>(corpus, ld, row0, n, norms, inv_norms, max_norm_bits, q8, scale, vv, cosf, err_bits, s);
+    switch (ld / 64u) {
+        NMN_Q8_CASE(2) NMN_Q8_CASE(4) NMN_Q8_CASE(6) NMN_Q8_CASE(8) NMN_Q8_CASE(10) NMN_Q8_CASE(12) NMN_Q8_CASE(14) NMN_Q8_CASE(16)
+        NMN_Q8_CASE(18) NMN_Q8_CASE(20) NMN_Q8_CASE(22) NMN_Q8_CASE(24) NMN_Q8_CASE(26) NMN_Q8_CASE(28) NMN_Q8_CASE(30) NMN_Q8_CASE(32)
+        default: return hipErrorInvalidValue;
+    }
+#undef NMN_Q8_CASE
+}
 
 // rows whose layout the one-pass kernel takes: whole reference chunks (no scalar tail) and whole 32-float stages
 bool ingest_supported(uint32_t ld, uint32_t dim) { return dim % 8u == 0 && ld % kStageFloats == 0 && ld >= (uint32_t)kStageFloats; }

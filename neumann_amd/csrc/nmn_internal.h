@@ -147,6 +147,11 @@ hipError_t launch_exact_rows(const float* corpus, const float* norms, uint32_t l
                              uint32_t nql, uint32_t nq, int metric, hipStream_t s);
 hipError_t launch_ingest(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms,
                          uint32_t* max_norm_bits, float* half, uint32_t* err_bits, hipStream_t s);
+// ONE read of freshly written rows for a shard whose mirror is the 8-bit one (nmn_ingest.hip): magnitudes in reference order, int8
+// codes, scales, |s c|^2, s / |v|, and the quantization-error maxima folded into err_bits[0..1] — launch_ingest + launch_q8_rows in one
+bool ingest_q8_supported(uint32_t ld, uint32_t dim);
+hipError_t launch_ingest_q8(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms, uint32_t* max_norm_bits,
+                            int8_t* q8, float* scale, float* vv, float* cosf, uint32_t* err_bits, hipStream_t s);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);

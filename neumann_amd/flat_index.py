@@ -250,7 +250,8 @@ class GpuFlatIndex:
         return int(a.value), int(b.value), int(c.value)
 
     def set_timing(self, enabled):
-        _capi.check(self._lib.nmn_index_set_timing(self._h, 1 if enabled else 0))
+        """0 / False: off; 1 / True: every event (scan_ms and total_ms of last_stats); 2: the sweep's two events only."""
+        _capi.check(self._lib.nmn_index_set_timing(self._h, int(enabled)))
 
     def last_stats(self, stream=None):
         st = _capi.SearchStats()
