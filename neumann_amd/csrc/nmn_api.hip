@@ -857,7 +857,13 @@ static uint32_t mfma_min_queries(const nmn_index* idx) {
 static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* queries_dev, uint32_t nq, uint32_t k,
                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                  float* out_scores, uint32_t* out_counts, hipStream_t stream,
-                                 const uint64_t* const* qmasks_dev = nullptr, const uint64_t* const* qmasks_host = nullptr) {
+                                 const uint64_t* const* qmasks_dev = nullptr, const uint64_t* const* qmasks_host = nullptr,
+                                 bool short_chain = false) {
+    // short_chain (the host-buffer API, which waits for the answer anyway — host_batch_body): only the launches every search needs,
+    // qprep -> sweep -> select -> rescore -> final.  A query whose candidate list overflows is not followed up on the device (crowd
+    // kernels, f32 retry sweep, second selection, exact scan of everything, device-wide selection: six launches that return at once
+    // in the common case, ~2.5 us each in a dependent chain, more under another stream's sweep): final_kernel reports it as
+    // out_counts[q] = 0xFFFFFFFF and the host runs the whole chain for the call again.
     nmn_status st = ws_alloc(idx, w);
     if (st != NMN_OK) return st;
     st = upload_fence_wait(idx, w, stream);  // rows uploaded asynchronously on another stream must have landed
@@ -907,7 +913,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             idx->q8_calls >= idx->q8_off_until && scan_i8_supported(idx->ld, idx->dim, (int)metric)) {
             for (uint32_t i = 0; i < nqc; i += 2) {
                 st = search_enqueue(idx, w, queries_dev + (size_t)(qa + i) * idx->dim, std::min(2u, nqc - i), k, metric, mask_dev,
-                                    out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i, stream);
+                                    out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i, stream, nullptr,
+                                    nullptr, short_chain);
                 if (st != NMN_OK) return st;
             }
             w->last_nq = nq;
@@ -988,7 +995,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             for (uint32_t i = 0; i < nqc; i++) {
                 st = search_enqueue(idx, w, queries_dev + (size_t)(qa + i) * idx->dim, 1, k, metric, qmasks_host[qa + i],
                                     out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i,
-                                    stream);
+                                    stream, nullptr, nullptr, short_chain);
                 if (st != NMN_OK) return st;
             }
             w->last_nq = nq;
@@ -997,7 +1004,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         w->last_elem_bytes = use_i8 ? 1u : use_half ? 2u : 4u;
         // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
-        const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18);
+        const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18) && !short_chain;
         // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
@@ -1160,13 +1167,18 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.retry_follows = f32_retry ? 1 : 0;
             sel.half_stats = f32_retry ? (use_i8 ? idx->q8_stats : idx->half_stats) : (use_i8 && use_mfma) ? idx->q8_stats : nullptr;
             sel.count_overflows = (use_i8 && use_mfma) ? 1 : 0;
+            if (short_chain && !use_mfma && (use_i8 || use_half) && n_rows >= (1u << 18)) {
+                // (no retry selection whose launches could be counted: the mirror's on/off switch counts this selection's overflows)
+                sel.half_stats = use_i8 ? idx->q8_stats : idx->half_stats;
+                sel.count_overflows = 1;
+            }
             sel.l2_hint = (use_i8 && !use_mfma && metric == NMN_METRIC_EUCLIDEAN) ? idx->q8_l2_hint : nullptr;
             sel.fb_sync_reset = w->fb_sync;  // (nullable) zeroed for the device-wide fallback selection further down this stream
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));
                 sel.k_extra = w->k_extra;
             }
-            const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && !no_crowd();
+            const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && !no_crowd() && !short_chain;
             sel.crowd_follows = crowd ? 1 : 0;
             sel.crowd_count_reset = crowd ? w->crowd_ctr : nullptr;
             HIP_TRY(launch_select(sel, stream));
@@ -1231,8 +1243,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // eight-lanes-per-row form of rescore_kernel's fallback duty — Euclidean's sequential sum 11 -> 4.7 ms per 10M x 768,
             // dot / cosine 5.2 -> 4.7 (NMN_NO_EXACT_ROWS=1: the old form, for the A/B)
             static const bool no_exact_rows = getenv("NMN_NO_EXACT_ROWS") != nullptr;
-            const bool exact_rows = !no_exact_rows && n_rows >= (1u << 18) && exact_rows_supported(idx->ld, idx->dim, (int)metric);  // (small shards: not worth a launch)
-            rp.skip_fallback = exact_rows ? 1 : 0;
+            const bool exact_rows = !no_exact_rows && n_rows >= (1u << 18) && exact_rows_supported(idx->ld, idx->dim, (int)metric) && !short_chain;  // (small shards: not worth a launch)
+            rp.skip_fallback = (exact_rows || short_chain) ? 1 : 0;  // (short chain: flagged queries are the host's to follow up)
             HIP_TRY(launch_rescore(rp, stream));
             if (exact_rows)  // (returns at once unless a query of the pass is flagged)
                 HIP_TRY(launch_exact_rows(idx->corpus, idx->norms, idx->ld, n_rows, w->qpad, w->qinfo, w->qstate, 1, mask_dev,
@@ -1270,6 +1282,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.nq = nqc;
         fp.k = k;
         fp.cand_cap = w->cand_cap;
+        fp.short_chain = short_chain ? 1 : 0;
         fp.out_rows = out_rows + (size_t)qa * k;
         fp.out_scores = out_scores + (size_t)qa * k;
         fp.out_counts = out_counts + qa;
@@ -1613,20 +1626,32 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         }
         separately = sum < 1.1 * sweep_us + fixed_us;
     }
-    if (separately) {
-        size_t q0 = 0;
-        for (size_t i = 0; i < n_reqs && st == NMN_OK; i++) {
-            st = search_enqueue(idx, w, w->h_queries + q0 * dim, reqs[i]->nq, k, (nmn_metric)first.metric, eff_mask[i],
-                                d_rows + q0 * k, d_scores + q0 * k, d_counts + q0, s);
-            q0 += reqs[i]->nq;
-        }
-    } else if (!qmasks.empty())
-        st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, nullptr, d_rows, d_scores, d_counts, s,
-                            w->h_qmasks, qmasks.data());
-    else
-        st = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s);
+    // The chain of a search on a shard of >= 2^18 rows is 5 launches that do the work and 6 that only act when a candidate list
+    // overflowed.  This call waits for its answer anyway, so it enqueues the five (search_enqueue: short_chain), looks at the
+    // counts that come back, and only when final_kernel flagged a query runs the call again with the whole chain.
+    static const bool no_short = env_set("NMN_NO_SHORT_CHAIN");  // (A/B switch)
+    const bool try_short = !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18);
+    auto enqueue_all = [&](bool short_chain) -> nmn_status {
+        nmn_status e = NMN_OK;
+        if (separately) {
+            size_t q0 = 0;
+            for (size_t i = 0; i < n_reqs && e == NMN_OK; i++) {
+                e = search_enqueue(idx, w, w->h_queries + q0 * dim, reqs[i]->nq, k, (nmn_metric)first.metric, eff_mask[i],
+                                   d_rows + q0 * k, d_scores + q0 * k, d_counts + q0, s, nullptr, nullptr, short_chain);
+                q0 += reqs[i]->nq;
+            }
+        } else if (!qmasks.empty())
+            e = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, nullptr, d_rows, d_scores, d_counts, s,
+                               w->h_qmasks, qmasks.data(), short_chain);
+        else
+            e = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s, nullptr,
+                               nullptr, short_chain);
+        if (e != NMN_OK) return e;
+        HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
+        return NMN_OK;
+    };
+    st = enqueue_all(try_short);
     if (st != NMN_OK) return st;
-    HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
     std::vector<unsigned long long> pred_selected(n_pred, 0ull);
     if (n_pred && words) {  // the predicates' counts (word 0 of each counter block): small, one strided copy
         HIP_TRY(hipMemcpyAsync(w->pin_pred + pred_block_bytes, w->pred_counts, n_pred * pred_count_stride * 8,
@@ -1634,6 +1659,18 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     }
     lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
     HIP_TRY(hipStreamSynchronize(s));
+    if (try_short) {
+        const uint32_t* hc = reinterpret_cast<const uint32_t*>(w->pin_out + off_counts);
+        bool flagged = false;
+        for (uint32_t q = 0; q < nq; q++) flagged = flagged || hc[q] == 0xFFFFFFFFu;
+        if (flagged) {  // (this slot is still ours: no writer can have changed the shard)
+            lk.lock();
+            st = enqueue_all(false);
+            lk.unlock();
+            if (st != NMN_OK) return st;
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
     if (n_pred && words)
         for (size_t j = 0; j < n_pred; j++)
             pred_selected[j] = reinterpret_cast<const unsigned long long*>(w->pin_pred + pred_block_bytes)[j * pred_count_stride];

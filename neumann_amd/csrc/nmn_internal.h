@@ -249,6 +249,7 @@ struct FinalParams {
     uint64_t n_rows;
     uint64_t row_base;
     uint32_t nq, k, cand_cap;
+    int short_chain;             // 1: a query whose candidate list overflowed is reported (out_counts[q] = 0xFFFFFFFF), not answered
     uint64_t* out_rows;          // [nq][k]
     float* out_scores;
     uint32_t* out_counts;

@@ -880,6 +880,10 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     const uint32_t tid = threadIdx.x;
     uint32_t n;
     const uint32_t mode = p.qstate[q].overflow;
+    if (mode && p.short_chain) {  // (block-uniform) the short chain: nobody computed what the lists below would need — the host follows up
+        if (tid == 0) p.out_counts[q] = 0xFFFFFFFFu;
+        return;
+    }
     if (mode == 2) {
         const uint32_t off = p.crowd_offset[q];
         n = crowd_select_into(p.crowd_rows + off, p.crowd_scores + off, p.qstate[q].cand_count, p.k, list, hist, &pick, s_misc);
