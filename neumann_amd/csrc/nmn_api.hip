@@ -1314,7 +1314,7 @@ extern "C" nmn_status nmn_index_search_device(nmn_index* idx, const float* queri
 
 nmn_status nmn::index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric_i,
                                     const uint64_t* mask_dev, uint64_t* out_rows_dev, float* out_scores_dev,
-                                    uint32_t* out_counts_dev, hipStream_t stream) {
+                                    uint32_t* out_counts_dev, hipStream_t stream, bool short_chain) {
     const nmn_metric metric = (nmn_metric)metric_i;
     nmn_status st = check_search_args(idx, queries_dev, nq, k, metric_i == kMetricNegL2 ? NMN_METRIC_EUCLIDEAN : metric,
                                       out_rows_dev, out_scores_dev, out_counts_dev);
@@ -1325,8 +1325,9 @@ nmn_status nmn::index_search_device(nmn_index* idx, const float* queries_dev, ui
     Workspace* w = nullptr;
     st = ws_get(idx, s, nq, k, &w);
     if (st != NMN_OK) return st;
+    static const bool no_short = env_set("NMN_NO_SHORT_CHAIN");
     return search_enqueue(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows_dev, out_scores_dev,
-                          out_counts_dev, s);
+                          out_counts_dev, s, nullptr, nullptr, short_chain && !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18));
 }
 
 static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* stats) {

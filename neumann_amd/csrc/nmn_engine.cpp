@@ -1777,13 +1777,14 @@ nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t di
         }
         if (bounded) {
             // `let keys = self.store.scan("").into_iter().take(max_scan)` (lib.rs:3179-3180): only the first max_scan keys of
-            // the scan take part (then the `_embedding` / dimension filter): a selection bitmap over the mirror's rows
-            WriteLock wr(e);
-            Collection* c = &e->entities;
-            Mirror* m = nullptr;
-            st = get_mirror(e, c, dim, &m);
-            if (st == NMN_OK && dl.expired()) st = err_timeout("search_entities", dl.ms);
-            if (st == NMN_OK && m->has_rows()) {
+            // the scan take part (then the `_embedding` / dimension filter): a selection bitmap over the mirror's rows.
+            // (The reference's scan("") counts EVERY key of the store towards max_scan; this mirror of the engine holds entity
+            //  keys only, so the bound is applied to them — INTEGRATION.md §5 states the deviation.)
+            // Locking as locked_search: the mirror is built / patched under the exclusive lock, the bitmap and the GPU search
+            // run under the shared one, so bounded searches overlap with every other reader.
+            auto bounded_search = [&](Collection* c, Mirror* m) -> nmn_status {
+                if (dl.expired()) return err_timeout("search_entities", dl.ms);
+                if (!m->has_rows()) return NMN_OK;
                 std::vector<uint64_t> sel(m->live.size(), 0ull);
                 uint64_t seen = 0, picked = 0;
                 const uint64_t limit = scan_limit(e);
@@ -1797,8 +1798,31 @@ nmn_status nmn_engine_search_entities(nmn_engine* e, const float* q, uint64_t di
                     }
                 }
                 const HostSelection hs{sel.data(), picked};
-                st = gpu_topk(c, m, q, top_k, NMN_METRIC_COSINE, nullptr, res, &hs);
-                if (st == NMN_OK && dl.expired()) st = err_timeout("search_entities", dl.ms);
+                nmn_status s2 = gpu_topk(c, m, q, top_k, NMN_METRIC_COSINE, nullptr, res, &hs);
+                if (s2 == NMN_OK && dl.expired()) s2 = err_timeout("search_entities", dl.ms);
+                return s2;
+            };
+            bool served = false;
+            for (int attempt = 0; attempt < 2 && !served && st == NMN_OK; attempt++) {
+                {
+                    ReadLock rd(e);
+                    Collection* c = &e->entities;
+                    auto it = c->mirrors.find(dim);
+                    if (it != c->mirrors.end() && it->second->dirty.empty()) {
+                        st = bounded_search(c, it->second.get());
+                        served = true;
+                        break;
+                    }
+                }
+                WriteLock wr(e);  // the mirror is missing or has stores pending: build / patch it exclusively, search shared
+                Mirror* m = nullptr;
+                st = get_mirror(e, &e->entities, dim, &m);
+            }
+            if (!served && st == NMN_OK) {  // stores keep arriving between our two locks: serve this one exclusively
+                WriteLock wr(e);
+                Mirror* m = nullptr;
+                st = get_mirror(e, &e->entities, dim, &m);
+                if (st == NMN_OK) st = bounded_search(&e->entities, m);
             }
         } else {
             st = locked_search(e, [&] { return &e->entities; }, q, dim, top_k, NMN_METRIC_COSINE, "search_entities", dl, res);

@@ -237,8 +237,10 @@ nmn_status index_search_hostio_many(nmn_index* idx, const HostSearchSpec* specs,
                                     nmn_search_stats* stats);
 
 // nmn_index_search_device with the internal metrics allowed (everything in device memory, asynchronous)
+// short_chain: for callers that wait for the answer on the host — only the five launches every search needs; a query whose
+// candidate list overflowed comes back as out_counts[q] == 0xFFFFFFFF and must be searched again WITHOUT short_chain
 nmn_status index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric,
                                const uint64_t* mask_dev, uint64_t* out_rows_dev, float* out_scores_dev,
-                               uint32_t* out_counts_dev, hipStream_t stream);
+                               uint32_t* out_counts_dev, hipStream_t stream, bool short_chain = false);
 
 }  // namespace nmn

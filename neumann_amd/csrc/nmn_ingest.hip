@@ -513,6 +513,9 @@ __global__ void __launch_bounds__(kQ8Waves * 64) ingest_q8_kernel(const float* _
             for (int step = 0; step < 8; step++) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) acc[t] = dppf<0x122>(acc[t]) + p[t];  // row_ror:2 — the chain moves on to the next lane pair
+                // (keep the four chains interleaved: left alone the scheduler runs one chain's eight steps back to back, each behind
+                //  an s_nop for the DPP read-after-write hazard)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // lanes 14 (accumulators 0-3) and 15 (4-7) of the row group hold the eight sums: lane 15 adds them left to right from -0.0
@@ -531,23 +534,27 @@ __global__ void __launch_bounds__(kQ8Waves * 64) ingest_q8_kernel(const float* _
         const float sc = (bad || mx == 0.f) ? 0.f : mx / 127.0f;
         const float inv = sc > 0.f ? 127.0f / mx : 0.f;
         float err2 = 0.f;
-        int cc = 0;  // c.c of this lane's codes: an exact integer
+        float ccf = 0.f;  // c.c of this lane's codes: integers, exact in f32 (<= 128 elements x 127^2 < 2^24 per lane)
         uint32_t* dst = reinterpret_cast<uint32_t*>(q8 + r * (uint64_t)ld) + l;
+        // (the kernel is VALU-issue bound beside the chains above: every instruction per element counts — the clamp is one
+        //  v_med3, c.c and the error accumulate by explicit FMAs, the four codes of a load are packed by v_cvt_pk_u8_f32 on
+        //  c + 128 and flipped to two's complement by one XOR per word)
 #pragma unroll
         for (int j = 0; j < KJ; j++) {
             uint32_t pk = 0u;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 float c = __builtin_rintf(x[j][t] * inv);
-                c = __builtin_fminf(__builtin_fmaxf(c, -127.0f), 127.0f);
-                if (!(c == c)) c = 0.f;
+                c = __builtin_amdgcn_fmed3f(c, -127.0f, 127.0f);
+                c = bad ? 0.f : c;  // (a non-finite row: scale 0, codes 0)
                 const float e = x[j][t] - sc * c;
-                err2 = err2 + e * e;
-                cc += (int)c * (int)c;
-                pk |= ((uint32_t)(int)c & 0xFFu) << (8 * t);
+                err2 = __builtin_fmaf(e, e, err2);
+                ccf = __builtin_fmaf(c, c, ccf);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(c + 128.0f, (uint32_t)t, pk);
             }
-            if (live) __builtin_nontemporal_store(pk, dst + j * 16);  // (4 bytes per lane, 64 contiguous bytes per row group)
+            if (live) __builtin_nontemporal_store(pk ^ 0x80808080u, dst + j * 16);  // (4 bytes per lane, 64 contiguous bytes per row group)
         }
+        int cc = (int)ccf;
         err2 = row16_add(err2);
         cc = row16_addi(cc);
         if (live && l == 15u) {

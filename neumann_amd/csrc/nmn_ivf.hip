@@ -964,23 +964,42 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
                     *sc = reinterpret_cast<float*>(b + (size_t)sl->res_k * 8);
                     *c = reinterpret_cast<uint32_t*>(b + (size_t)sl->res_k * 12);
                 };
-                uint64_t* r;
-                float* sc;
-                uint32_t* c;
-                if (c_rows) {
-                    part(sl->res_dev, 0, &r, &sc, &c);
-                    st = index_search_device(ivf->cvec, sl->qraw, 1, (uint32_t)kk1, kMetricNegL2, sl->mask_c, r, sc, c, s);
+                // (this call waits for its answer: the list scans take the SHORT launch chain, nmn_index.h — a scan whose candidate
+                //  list overflowed reports it in its count and is repeated below with the whole chain)
+                auto enqueue_scans = [&](bool short_chain, bool want_c, bool want_t) -> nmn_status {
+                    uint64_t* r;
+                    float* sc;
+                    uint32_t* c;
+                    nmn_status e = NMN_OK;
+                    if (c_rows && want_c) {
+                        part(sl->res_dev, 0, &r, &sc, &c);
+                        e = index_search_device(ivf->cvec, sl->qraw, 1, (uint32_t)kk1, kMetricNegL2, sl->mask_c, r, sc, c, s, short_chain);
+                        if (e != NMN_OK) return e;
+                    }
+                    if (c_rows < n_rows && want_t) {
+                        part(sl->res_dev, 1, &r, &sc, &c);
+                        e = index_search_device(ivf->vectors, sl->qraw, 1, (uint32_t)kk1, kMetricNegL2, sl->mask, r, sc, c, s, short_chain);
+                        if (e != NMN_OK) return e;
+                    }
+                    if (hipMemcpyAsync(sl->res_pin, sl->res_dev, 2 * pb, hipMemcpyDeviceToHost, s) != hipSuccess)
+                        return set_error(NMN_ERR_STORAGE, "ivf: result copy");
+                    return NMN_OK;
+                };
+                st = enqueue_scans(true, true, true);
+                if (st != NMN_OK) return st;
+                IVF_TRY(hipMemcpyAsync(probe_host_all, sl->probe_rows, (size_t)nb * ivf->n_clusters * 8, hipMemcpyDeviceToHost, s));
+                IVF_TRY(hipStreamSynchronize(s));
+                auto flagged = [&](int i) { return *reinterpret_cast<const uint32_t*>(sl->res_pin + (size_t)i * pb + (size_t)sl->res_k * 12) == 0xFFFFFFFFu; };
+                const bool again_c = c_rows && flagged(0), again_t = c_rows < n_rows && flagged(1);
+                if (again_c || again_t) {
+                    st = enqueue_scans(false, again_c, again_t);
                     if (st != NMN_OK) return st;
+                    IVF_TRY(hipStreamSynchronize(s));
                 }
-                if (c_rows < n_rows) {
-                    part(sl->res_dev, 1, &r, &sc, &c);
-                    st = index_search_device(ivf->vectors, sl->qraw, 1, (uint32_t)kk1, kMetricNegL2, sl->mask, r, sc, c, s);
-                    if (st != NMN_OK) return st;
-                }
-                IVF_TRY(hipMemcpyAsync(sl->res_pin, sl->res_dev, 2 * pb, hipMemcpyDeviceToHost, s));
+            } else {
+                IVF_TRY(hipMemcpyAsync(probe_host_all, sl->probe_rows, (size_t)nb * ivf->n_clusters * 8, hipMemcpyDeviceToHost, s));
+                IVF_TRY(hipStreamSynchronize(s));
             }
-            IVF_TRY(hipMemcpyAsync(probe_host_all, sl->probe_rows, (size_t)nb * ivf->n_clusters * 8, hipMemcpyDeviceToHost, s));
-            IVF_TRY(hipStreamSynchronize(s));
             if (direct) {
                 const size_t pb = (((size_t)sl->res_k * 12 + 4 + 15) & ~(size_t)15);
                 auto take = [&](int i, std::vector<uint64_t>& ids, std::vector<float>& dist, std::vector<uint32_t>& cnt) {

@@ -32,4 +32,16 @@ import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1], round(d['value']), d['ms_per_step'], d['roofline']['avg_kernel_ms'], d['rebuilds']['queries_per_s'])
 P
 done
+# the launch chain of a host-buffer search (nmn_index_search) on 1M x 768: kernel trace of 40 calls, the timeline of three of them
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/prof_host -o host -- python -c "
+import sys; sys.path.insert(0,'$GRAFT_REPO_ROOT')
+import numpy as np
+from neumann_amd import GpuFlatIndex, synth_rows
+idx = GpuFlatIndex(768, 1_000_000, device=0); idx.fill_synthetic(3, 1_000_000)
+Q = synth_rows(5, 0, 8, 768)
+for i in range(40): idx.search(Q[i % 8], 100, 0)
+idx.close()
+" > /dev/null 2>&1)
+python tools/trace_gantt.py $OUT/prof_host/host_results.db --kernel scan_i8_kernel --skip 20 --steps 3 > $OUT/host_chain_gantt.txt 2>&1; cat $OUT/host_chain_gantt.txt
+python tools/prof_summary.py $OUT/prof_host/host_results.db "40 x nmn_index_search(nq=1, k=100) on 1M x 768 (host-buffer API, short chain)" > $OUT/host_chain_kernels.txt 2>&1
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"
