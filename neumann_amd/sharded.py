@@ -162,7 +162,7 @@ class GpuShardedIndex:
         _capi.check(self._lib.nmn_sharded_search(self._h, C.c_void_p(q.ctypes.data), nq, k, int(metric),
                                                  None if m is None else C.c_void_p(m.ctypes.data),
                                                  C.c_void_p(out_rows.ctypes.data), C.c_void_p(out_scores.ctypes.data),
-                                                 C.c_void_p(out_counts.ctypes.data), C.byref(stats)))
+                                                 C.c_void_p(out_counts.ctypes.data), C.byref(stats) if with_stats else None))
         if with_stats:
             return out_rows, out_scores, out_counts, stats
         return out_rows, out_scores, out_counts
