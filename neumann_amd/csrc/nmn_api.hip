@@ -288,6 +288,12 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
     w->score_stride = idx->cap_pad;
     w->n_tiles_cap = (uint32_t)(idx->cap_pad / kTileRows);
     const size_t nq = w->nq_cap;
+    {
+        // test hook (tests/test_gpu_edge_cases.py): passes of more than n queries "do not fit" — what a nearly full device does to
+        // a 64-query pass over 10M rows (2.6 GB of scores), without having to fill 288 GiB first
+        static const long test_max_nq = [] { const char* e = getenv("NMN_WS_TEST_MAX_NQ"); return e ? atol(e) : 0l; }();
+        if (test_max_nq > 0 && (long)nq > test_max_nq) return fail_hip(hipErrorOutOfMemory, "workspace (NMN_WS_TEST_MAX_NQ)");
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->scores), std::max<size_t>(nq * w->score_stride, 64) * 4));
     w->tmax_stride = ((uint64_t)w->n_tiles_cap + 3) & ~3ull;  // rows of tmax stay 16-B aligned (uint4 sweeps)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->tmax), std::max<size_t>(nq * w->tmax_stride, 4) * 4));
@@ -1326,8 +1332,12 @@ nmn_status nmn::index_search_device(nmn_index* idx, const float* queries_dev, ui
     st = ws_get(idx, s, nq, k, &w);
     if (st != NMN_OK) return st;
     static const bool no_short = env_set("NMN_NO_SHORT_CHAIN");
+    // (MEASUREMENT ONLY: what the six rare-path launches cost the asynchronous API — with this set an overflowed query is NOT
+    //  followed up by anybody and comes back with count 0xFFFFFFFF)
+    static const bool force_short = env_set("NMN_MEASURE_DEVICE_SHORT_CHAIN");
     return search_enqueue(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows_dev, out_scores_dev,
-                          out_counts_dev, s, nullptr, nullptr, short_chain && !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18));
+                          out_counts_dev, s, nullptr, nullptr,
+                          (short_chain || force_short) && !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18));
 }
 
 static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* stats) {

@@ -410,7 +410,10 @@ hipError_t launch_exact_rows(const float* corpus, const float* norms, uint32_t l
     p.nq = nq;
     p.metric = metric;
     const uint64_t n_tiles = (n_rows + 63) / 64;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_tiles + kWaves - 1) / kWaves, 512);
+    // (one workgroup per CU and some; with many queries in the pass fewer per query: the launch returns at once unless a query is
+    //  flagged, and 512 x 64 workgroups that only look at a flag and leave cost 21 us per 64-query batch)
+    const uint32_t per_q = std::min<uint32_t>(512u, std::max<uint32_t>(32u, 2048u / std::max<uint32_t>(nq, 1u)));
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_tiles + kWaves - 1) / kWaves, per_q);
     const size_t lds = (size_t)kWaves * kRing * kStageBytes + (size_t)ld * 4;
     const bool l2 = metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2 || metric == kMetricNegL2Sq;
     auto kern = l2 ? exact_rows_kernel<0> : exact_rows_kernel<1>;
@@ -502,13 +505,16 @@ __global__ void __launch_bounds__(kQ8Waves * 64) ingest_q8_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < KJ; j++) {
             float p[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                p[t] = x[j][t] * x[j][t];
-                const float ax = __builtin_fabsf(x[j][t]);
-                bad = bad || !(ax <= 3.0e38f);  // inf or NaN
-                mx = __builtin_fmaxf(mx, ax);
+            {
+                const f2v a = {x[j][0], x[j][1]}, b = {x[j][2], x[j][3]};
+                const f2v pa = a * a, pb = b * b;  // (multiplies only: rounded as the reference's, never fused with the chain's adds)
+                p[0] = pa[0];
+                p[1] = pa[1];
+                p[2] = pb[0];
+                p[3] = pb[1];
             }
+#pragma unroll
+            for (int t = 0; t < 4; t++) mx = __builtin_fmaxf(mx, __builtin_fabsf(x[j][t]));  // (v_max skips NaNs: see `bad` below)
 #pragma unroll
             for (int step = 0; step < 8; step++) {
 #pragma unroll
@@ -530,7 +536,9 @@ __global__ void __launch_bounds__(kQ8Waves * 64) ingest_q8_kernel(const float* _
         const float mag = dppf<0x15F>(__builtin_sqrtf(rsum));  // row_newbcast:15 — lane 15's (the only meaningful one) to its row group
         // ---- the row's scale and codes
         mx = row16_max(mx);
-        bad = row16_addi(bad ? 1 : 0) != 0;
+        // a non-finite element: an infinity is the row's maximum; a NaN went through the sum of squares (non-negative terms: the
+        // sum is NaN only if an element is) — one test per row instead of one per element
+        bad = !(mx <= 3.0e38f) || !(mag == mag);
         const float sc = (bad || mx == 0.f) ? 0.f : mx / 127.0f;
         const float inv = sc > 0.f ? 127.0f / mx : 0.f;
         float err2 = 0.f;
@@ -539,21 +547,30 @@ __global__ void __launch_bounds__(kQ8Waves * 64) ingest_q8_kernel(const float* _
         // (the kernel is VALU-issue bound beside the chains above: every instruction per element counts — the clamp is one
         //  v_med3, c.c and the error accumulate by explicit FMAs, the four codes of a load are packed by v_cvt_pk_u8_f32 on
         //  c + 128 and flipped to two's complement by one XOR per word)
+        // two elements per instruction where the ISA has a packed form (v_pk_mul / v_pk_fma / v_pk_add_f32)
+        const f2v inv2 = {inv, inv}, nsc2 = {-sc, -sc}, ok2 = {bad ? 0.f : 1.f, bad ? 0.f : 1.f}, b128 = {128.0f, 128.0f};
+        f2v err2v = {0.f, 0.f}, ccv = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < KJ; j++) {
             uint32_t pk = 0u;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                float c = __builtin_rintf(x[j][t] * inv);
-                c = __builtin_amdgcn_fmed3f(c, -127.0f, 127.0f);
-                c = bad ? 0.f : c;  // (a non-finite row: scale 0, codes 0)
-                const float e = x[j][t] - sc * c;
-                err2 = __builtin_fmaf(e, e, err2);
-                ccf = __builtin_fmaf(c, c, ccf);
-                pk = __builtin_amdgcn_cvt_pk_u8_f32(c + 128.0f, (uint32_t)t, pk);
+            for (int h = 0; h < 2; h++) {
+                const f2v xv = {x[j][2 * h], x[j][2 * h + 1]};
+                f2v cv = xv * inv2;
+                cv[0] = __builtin_amdgcn_fmed3f(__builtin_rintf(cv[0]), -127.0f, 127.0f);  // (a NaN comes out as -127: finite)
+                cv[1] = __builtin_amdgcn_fmed3f(__builtin_rintf(cv[1]), -127.0f, 127.0f);
+                cv = cv * ok2;  // (a non-finite row: scale 0, codes 0)
+                const f2v ev = __builtin_elementwise_fma(nsc2, cv, xv);
+                err2v = __builtin_elementwise_fma(ev, ev, err2v);
+                ccv = __builtin_elementwise_fma(cv, cv, ccv);
+                const f2v bv = cv + b128;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(bv[0], (uint32_t)(2 * h), pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(bv[1], (uint32_t)(2 * h + 1), pk);
             }
             if (live) __builtin_nontemporal_store(pk ^ 0x80808080u, dst + j * 16);  // (4 bytes per lane, 64 contiguous bytes per row group)
         }
+        err2 = err2v[0] + err2v[1];
+        ccf = ccv[0] + ccv[1];
         int cc = (int)ccf;
         err2 = row16_add(err2);
         cc = row16_addi(cc);

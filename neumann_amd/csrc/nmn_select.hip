@@ -208,6 +208,13 @@ hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uin
     return hipGetLastError();
 }
 
+// measurement build (tools/build_variant.sh seltrace "-DNMN_SELECT_TRACE" nmn_select): query 0 prints where its selection's time goes
+// (100 MHz wall clock ticks = 10 ns), one line per call
+#ifdef NMN_SELECT_TRACE
+#define SEL_MARK(i) do { if (q == 0 && tid == 0) sel_t[i] = wall_clock64(); } while (0)
+#else
+#define SEL_MARK(i) do { } while (0)
+#endif
 constexpr uint32_t kCompCap = 8192;
 constexpr uint32_t kBailTiles = 1024;  // tiles within the margin beyond which a selection hands over to the crowd kernels (when they follow)
 constexpr size_t kSelectLds = 2 * kCompCap * 8 + kMaxScanWaves * 4 + kBins * 4;  // 152 KiB
@@ -225,6 +232,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t nql = p.nql;
+#ifdef NMN_SELECT_TRACE
+    unsigned long long sel_t[10] = {};
+#endif
+    SEL_MARK(0);
     if (p.retry && p.qstate[q].overflow != 1) {  // block-uniform: this query's first selection stood (or its crowd list did)
         // ... or it was found hopeless for the retry (below): the retry sweep skipped it, from here on it is an ordinary overflow
         if (tid == 0 && p.qstate[q].overflow == 4u) p.qstate[q].overflow = 1u;
@@ -251,7 +262,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 
     for (uint32_t i = tid; i < kMaxScanWaves; i += kSelThreads) wk[i] = i < W ? wmax[i] : kKeyMasked;
     __syncthreads();
+    SEL_MARK(1);
     const uint32_t vw = count_valid([&](uint32_t e) { return wk[e]; }, W, &s_w[0]);
+    SEL_MARK(2);
     if (vw == 0) {
         if (tid == 0) { p.qstate[q].cand_count = 0; p.qstate[q].n_valid = 0; }
         return;
@@ -261,6 +274,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     if (vw >= k) Tw = radix2([&](uint32_t e) { return wk[e]; }, W, k, hist, &pick);
     // scores of tiles whose maximum is below `skip` were never written by the batched sweep: no threshold that
     // gates a read of scores[] may fall below it (rows below it cannot be in the top-k anyway)
+    SEL_MARK(3);
     const uint32_t skip = p.skip_key ? p.skip_key[q] : kKeyNaN;
     const uint32_t Twm = max(margin_key(Tw, qi), skip);
     if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
@@ -291,6 +305,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         }
     }
     __syncthreads();
+    SEL_MARK(4);
     const uint32_t ct = s_w[1];
     uint32_t Tc = Twm;
     bool done = false;
@@ -325,6 +340,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         if (ct > k) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);
         const uint32_t T2m = max(margin_key(T2, qi), skip);
         Tc = T2m;
+        SEL_MARK(5);
         // ---- level R: compact (key,row) of rows >= T2m in tiles >= T2m (la is dead: LR may be written)
         __syncthreads();
         const uint32_t tot = ct * kTileRows;
@@ -352,10 +368,12 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             }
         }
         __syncthreads();
+        SEL_MARK(6);
         const uint32_t cr = s_w[2];
         if (cr <= kCompCap) {
             uint32_t T3 = T2;
             if (cr > k) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
+            SEL_MARK(7);
             Tc = max(margin_key(T3, qi), skip);  // >= T2m: every row that can matter is in LR
             for (uint32_t e = tid; e < cr; e += kSelThreads) {
                 const unsigned long long ent = LR[e];
@@ -377,6 +395,14 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                     const float tau = key_to_score(Tc);
                     *p.l2_hint = (tau > 0.0f && tau <= 1.0f) ? 1.0f / tau - 1.0f : 0.0f;
                 }
+#ifdef NMN_SELECT_TRACE
+                if (q == 0) {
+                    sel_t[8] = wall_clock64();
+                    printf("select W=%u vw=%u nA=%u ct=%u cr=%u cand=%u | ticks: load %llu count %llu radixW %llu tiles %llu radixT %llu rows %llu radixR %llu out %llu total %llu\n",
+                           W, vw, nA, ct, cr, c, sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], sel_t[5] - sel_t[4],
+                           sel_t[6] - sel_t[5], sel_t[7] - sel_t[6], sel_t[8] - sel_t[7], sel_t[8] - sel_t[0]);
+                }
+#endif
             }
             done = true;
         }

@@ -482,3 +482,42 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+_WS_CHILD = r"""
+import sys
+import numpy as np
+from oracle import oracle_c as oc
+from neumann_amd import GpuFlatIndex
+n, d, k, nq = 300_000, 256, 50, 64
+A = oc.synth(0x77, 0, n, d, nthreads=8)
+Q = oc.synth(0x78, 0, nq, d)
+keep = np.random.default_rng(3).random(n) < 0.4
+with GpuFlatIndex(d, n) as idx:
+    idx.fill_synthetic(0x77, n)
+    for metric, mask in ((0, None), (1, oc.mask_from_bool(keep)), (2, None)):
+        rows, scores, counts = idx.search(Q, k, metric, mask=mask)
+        for qi in range(nq):
+            er, es = oc.search(A, Q[qi], k, metric, mask=mask, nthreads=8, partial=True, native=True)
+            assert counts[qi] == er.size and np.array_equal(rows[qi, :er.size], er), (metric, qi)
+            assert np.array_equal(scores[qi, :er.size].view(np.uint32), es.view(np.uint32)), (metric, qi)
+    r1, s1, c1 = idx.search(Q[:3], k, 0)      # a smaller batch afterwards: the learned pass size still serves
+    r0, s0, c0 = idx.search(Q, k, 0)
+    assert np.array_equal(r1, r0[:3]) and np.array_equal(s1.view(np.uint32), s0[:3].view(np.uint32))
+print("WS-OK")
+"""
+
+
+def test_query_passes_shrink_when_the_workspace_does_not_fit():
+    """A device too full for the score matrix of a 64-query pass (nq x rows x 4 B: 2.6 GB at 10M rows — config 4 on one GPU)
+    must serve the batch as more passes of fewer queries, not fail with NMN_ERR_OUT_OF_MEMORY (ws_alloc, nmn_api.hip).  The test
+    hook NMN_WS_TEST_MAX_NQ=8 makes every pass of more than 8 queries "not fit": 64 -> 16 -> 4 queries per pass; all 64 answers of
+    three metrics (one under a bitmap) must be the oracle's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMN_WS_TEST_MAX_NQ="8")
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", _WS_CHILD], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "WS-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
