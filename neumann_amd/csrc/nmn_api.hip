@@ -1185,7 +1185,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel.k_extra = w->k_extra;
             }
             const bool crowd = w->crowd_cap != 0 && n_rows >= kCrowdMinRows && !no_crowd() && !short_chain;
-            sel.crowd_follows = crowd ? 1 : 0;
+            // (short chain: the selection still hands over early when thousands of tiles are within the margin — nobody follows on
+            //  the device, final_kernel flags the query and the host's second pass brings the crowd kernels)
+            sel.crowd_follows = (crowd || (short_chain && n_rows >= kCrowdMinRows)) ? 1 : 0;
             sel.crowd_count_reset = crowd ? w->crowd_ctr : nullptr;
             HIP_TRY(launch_select(sel, stream));
             if (crowd) {  // three launches that return at once unless a candidate list overflowed
@@ -1335,9 +1337,16 @@ nmn_status nmn::index_search_device(nmn_index* idx, const float* queries_dev, ui
     // (MEASUREMENT ONLY: what the six rare-path launches cost the asynchronous API — with this set an overflowed query is NOT
     //  followed up by anybody and comes back with count 0xFFFFFFFF)
     static const bool force_short = env_set("NMN_MEASURE_DEVICE_SHORT_CHAIN");
+    if (short_chain) idx->short_calls++;
     return search_enqueue(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows_dev, out_scores_dev,
                           out_counts_dev, s, nullptr, nullptr,
-                          (short_chain || force_short) && !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18));
+                          ((short_chain && idx->short_calls > idx->short_off_until) || force_short) && !no_short && k <= NMN_MAX_TOP_K &&
+                              idx->rows >= (1u << 18));
+}
+
+void nmn::index_short_chain_flagged(nmn_index* idx) {
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->short_off_until = idx->short_calls + 256;
 }
 
 static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* stats) {
@@ -1641,7 +1650,8 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     // overflowed.  This call waits for its answer anyway, so it enqueues the five (search_enqueue: short_chain), looks at the
     // counts that come back, and only when final_kernel flagged a query runs the call again with the whole chain.
     static const bool no_short = env_set("NMN_NO_SHORT_CHAIN");  // (A/B switch)
-    const bool try_short = !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18);
+    idx->short_calls++;
+    const bool try_short = !no_short && k <= NMN_MAX_TOP_K && idx->rows >= (1u << 18) && idx->short_calls > idx->short_off_until;
     auto enqueue_all = [&](bool short_chain) -> nmn_status {
         nmn_status e = NMN_OK;
         if (separately) {
@@ -1676,6 +1686,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         for (uint32_t q = 0; q < nq; q++) flagged = flagged || hc[q] == 0xFFFFFFFFu;
         if (flagged) {  // (this slot is still ours: no writer can have changed the shard)
             lk.lock();
+            idx->short_off_until = idx->short_calls + 256;  // (searches that keep overflowing: the whole chain at once for a while)
             st = enqueue_all(false);
             lk.unlock();
             if (st != NMN_OK) return st;

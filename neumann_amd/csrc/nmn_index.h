@@ -127,6 +127,10 @@ struct nmn_index {
     uint64_t cap = 0, cap_pad = 0, rows = 0, row_base = 0;
     int device = 0;
     uint32_t cand_cap = kDefaultCandCap;
+    // short launch chain (host-buffer searches, nmn_api.hip): a shard whose searches keep overflowing their candidate lists (k = 1000
+    // under an 8-bit margin: ~6000 rows within it) would pay a short pass AND the whole chain every time — after a flagged call the
+    // next 256 searches enqueue the whole chain at once
+    uint64_t short_calls = 0, short_off_until = 0;
     uint32_t ws_nq_limit = 0xFFFFFFFFu;  // queries per pipeline pass the device's free memory allowed (ws_alloc lowers it on OOM)
     bool no_single_launch = false;  // NMN_INDEX_NO_SINGLE_LAUNCH
     float* corpus = nullptr;
@@ -242,5 +246,7 @@ nmn_status index_search_hostio_many(nmn_index* idx, const HostSearchSpec* specs,
 nmn_status index_search_device(nmn_index* idx, const float* queries_dev, uint32_t nq, uint32_t k, int metric,
                                const uint64_t* mask_dev, uint64_t* out_rows_dev, float* out_scores_dev,
                                uint32_t* out_counts_dev, hipStream_t stream, bool short_chain = false);
+// a caller of index_search_device(short_chain = true) found a flagged query: the shard leaves the short chain alone for a while
+void index_short_chain_flagged(nmn_index* idx);
 
 }  // namespace nmn

@@ -992,6 +992,8 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
                 auto flagged = [&](int i) { return *reinterpret_cast<const uint32_t*>(sl->res_pin + (size_t)i * pb + (size_t)sl->res_k * 12) == 0xFFFFFFFFu; };
                 const bool again_c = c_rows && flagged(0), again_t = c_rows < n_rows && flagged(1);
                 if (again_c || again_t) {
+                    if (again_c) index_short_chain_flagged(ivf->cvec);
+                    if (again_t) index_short_chain_flagged(ivf->vectors);
                     st = enqueue_scans(false, again_c, again_t);
                     if (st != NMN_OK) return st;
                     IVF_TRY(hipStreamSynchronize(s));
