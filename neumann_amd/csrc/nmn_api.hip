@@ -1063,6 +1063,38 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.walk = (sp.strided && !no_walk) ? 1u : 0u;
             sp.tile_step = 1;
             sp.skip_key = nullptr;
+            // Batched sweep on a large shard: a sampling pass over every 32nd tile (tile maxima only) bounds
+            // the k-th best score of each query from below, so the main sweep writes scores only for the few
+            // tiles that can still hold a candidate.
+            // (NMN_SAMPLE_STEP = 64 / 128: a coarser sample for the A/B — never finer than kSampleStep, which sizes the buffers)
+            // (Tried in round 4: the pass — 3 % of the mirror's bytes and a one-workgroup-per-query bound kernel, 51 + 24 us of mostly
+            //  ramp-up and latency — enqueued AHEAD of the sweep chain's wait, to run under the previous batch's main sweep.  It takes
+            //  from that sweep what it saves its own: 64 queries 1.678 vs 1.679 ms per step, 128 queries 2.55-2.59 vs 2.49-2.50
+            //  (profiles/r04h_sampling_pass_ahead_of_chain_ab.txt).  NMN_SAMPLE_AHEAD_OF_CHAIN=1 keeps the A/B.)
+            static const uint32_t sample_step = [] {
+                const char* e = getenv("NMN_SAMPLE_STEP");
+                const long v = e ? atol(e) : 0;
+                return (v == 64 || v == 128 || v == 256) ? (uint32_t)v : kSampleStep;
+            }();
+            static const bool sample_behind = getenv("NMN_SAMPLE_AHEAD_OF_CHAIN") == nullptr;
+            const uint32_t n_sample = (n_tiles + sample_step - 1) / sample_step;
+            const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
+            auto sampling_pass = [&]() -> nmn_status {
+                ScanParams ss = sp;
+                ss.tile_step = sample_step;
+                ss.n_tiles = n_sample;
+                ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
+                ss.tmax = w->tsample;
+                ss.tmax_stride = w->n_sample_cap;
+                HIP_TRY(launch_scan_mfma(ss, stream));
+                HIP_TRY(launch_sample_bound(w->tsample, w->n_sample_cap, n_sample, w->qinfo, nqc, k, w->skip_key, stream));
+                sp.skip_key = w->skip_key;
+                return NMN_OK;
+            };
+            if (sample && !sample_behind) {
+                st = sampling_pass();
+                if (st != NMN_OK) return st;
+            }
             // the sweep chain (nmn_index.h): on a large shard this sweep starts when the previous search's sweep — enqueued on
             // another stream — has ended; its own tail then runs under the next sweep.  NMN_NO_SWEEP_CHAIN=1: the A/B.
             static const bool no_chain = getenv("NMN_NO_SWEEP_CHAIN") != nullptr;
@@ -1075,27 +1107,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 if (!h) HIP_TRY(hipEventCreate(&h));
                 HIP_TRY(hipEventRecord(h, stream));
             }
-            // Batched sweep on a large shard: a sampling pass over every 32nd tile (tile maxima only) bounds
-            // the k-th best score of each query from below, so the main sweep writes scores only for the few
-            // tiles that can still hold a candidate.
-            // (NMN_SAMPLE_STEP = 64 / 128: a coarser sample for the A/B — never finer than kSampleStep, which sizes the buffers)
-            static const uint32_t sample_step = [] {
-                const char* e = getenv("NMN_SAMPLE_STEP");
-                const long v = e ? atol(e) : 0;
-                return (v == 64 || v == 128 || v == 256) ? (uint32_t)v : kSampleStep;
-            }();
-            const uint32_t n_sample = (n_tiles + sample_step - 1) / sample_step;
-            const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
-            if (sample) {
-                ScanParams ss = sp;
-                ss.tile_step = sample_step;
-                ss.n_tiles = n_sample;
-                ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
-                ss.tmax = w->tsample;
-                ss.tmax_stride = w->n_sample_cap;
-                HIP_TRY(launch_scan_mfma(ss, stream));
-                HIP_TRY(launch_sample_bound(w->tsample, w->n_sample_cap, n_sample, w->qinfo, nqc, k, w->skip_key, stream));
-                sp.skip_key = w->skip_key;
+            if (sample && sample_behind) {
+                st = sampling_pass();
+                if (st != NMN_OK) return st;
             }
             // More than 64 queries per pass: the score stores of the sweep are what its epilogue costs (a written tile is four
             // store instructions per query group with one query's lanes active, each holding the wave's issue slot behind the
