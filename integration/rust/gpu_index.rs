@@ -78,6 +78,15 @@ impl GpuFlatIndex {
         unsafe { ffi::nmn_index_rows(self.raw) as usize }
     }
 
+    /// Device memory the shard holds: (f32 rows, mirrors that exist right now, per-row factors), in bytes.  A shard keeps the
+    /// f32 rows plus ONE approximate copy by default (int8 codes where the row stride is a multiple of 128 elements: 5 bytes per
+    /// element in all); what `VectorEngine::gpu_memory_usage()` would sum over its `gpu_cache`.
+    pub fn hbm_bytes(&self) -> (u64, u64, u64) {
+        let (mut a, mut b, mut c) = (0u64, 0u64, 0u64);
+        unsafe { ffi::nmn_index_hbm_bytes(self.raw, &mut a, &mut b, &mut c) };
+        (a, b, c)
+    }
+
     /// Same shape as `HNSWIndex::search` (tensor_store/src/hnsw.rs:2055): (row, score), best first; ties by row id.
     /// `mask`: bit i of word i/64 = row i takes part (pre-filter bitmap, the `live` bitmap of lazy deletes, or both ANDed).
     pub fn search(&self, q: &[f32], k: usize, metric: DistanceMetric, mask: Option<&[u64]>) -> Result<Vec<(usize, f32)>> {

@@ -66,15 +66,28 @@ __device__ __forceinline__ float dot8_group(const float* __restrict__ a, const f
     return r;
 }
 
+// lane T of the caller's 8-lane group (lanes 8g .. 8g+7 of the wave), to all eight: two DPP moves — row_newbcast:T into the
+// lanes 0-7 of every 16-lane DPP row (bank_mask 0x3), row_newbcast:8+T into its lanes 8-15 (bank_mask 0xC) — instead of a
+// ds_bpermute through the LDS crossbar (what __shfl with a computed lane compiles to: ~70 cycles a piece in a dependent chain)
+template <int T>
+__device__ __forceinline__ float group8_bcast(float v) {
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + T, 0xF, 0x3, false);
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(v), 0x158 + T, 0xF, 0xC, false);
+    return __int_as_float(r);
+}
+
 // lib.rs:2249-2253: one strictly sequential sum.  The 8 threads of a group split the LOADS and the
 // (x-y)^2 products (thread l owns elements i with i % 8 == l); the sum itself is then accumulated in
-// element order by pulling each product from its owner with a shuffle, so the order of the additions is
-// exactly 0,1,2,...,d-1.
+// element order by pulling each product from its owner (group8_bcast), so the order of the additions is
+// exactly 0,1,2,...,d-1.  Elements past `dim` (the last chunk of a row whose length is not a multiple of eight, the chunks a
+// batch of PF reaches beyond the row) contribute (0 - 0)^2 = +0.0: added to a sum that is +0.0 or larger once the first real
+// product is in — the running sum starts at -0.0 and -0.0 + (+0.0) = +0.0, every product being >= +0.0 — they change nothing,
+// so the additions carry no bounds test (the test cost the chain a compare and a select per element).
+// Round 4: 58 -> see profiles/r04k_* us for the 6 400 rows x 1536 elements a TOP-1000 query's crowd re-scores.
 template <int PF>
 __device__ __forceinline__ float euclid_sumsq_seq(const float* __restrict__ q, const float* __restrict__ v,
                                                   uint32_t dim, uint32_t l) {
     float s = -0.0f;
-    const int base = (int)(threadIdx.x & 63u & ~7u);
     const uint32_t chunks = (dim + 7u) >> 3;
     for (uint32_t c0 = 0; c0 < chunks; c0 += PF) {
         float pr[PF];
@@ -88,11 +101,14 @@ __device__ __forceinline__ float euclid_sumsq_seq(const float* __restrict__ q, c
         }
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const float pt = __shfl(pr[i], base + t);
-                if (8u * (c0 + (uint32_t)i) + (uint32_t)t < dim) s = add_rn(s, pt);
-            }
+            s = add_rn(s, group8_bcast<0>(pr[i]));
+            s = add_rn(s, group8_bcast<1>(pr[i]));
+            s = add_rn(s, group8_bcast<2>(pr[i]));
+            s = add_rn(s, group8_bcast<3>(pr[i]));
+            s = add_rn(s, group8_bcast<4>(pr[i]));
+            s = add_rn(s, group8_bcast<5>(pr[i]));
+            s = add_rn(s, group8_bcast<6>(pr[i]));
+            s = add_rn(s, group8_bcast<7>(pr[i]));
         }
     }
     return s;

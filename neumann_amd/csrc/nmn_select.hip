@@ -6,6 +6,7 @@
 // (query_router/src/distributed.rs:413-433).  Order everywhere: score descending, ties by ascending
 // row id; NaN scores last.
 #include <algorithm>
+#include <type_traits>
 
 #include "nmn_select_dev.h"
 
@@ -285,22 +286,81 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t nA = s_w[0];
     // ---- level T: compact (key,tile) of tiles >= Twm in passing waves -------------------------
     {
-        const uint32_t slots = nA * tpw;
-        for (uint32_t e0 = tid; e0 < slots; e0 += kSelThreads * V) {
-            uint32_t tk[V], tt[V];
+        // The tile maxima of the passing waves: nA x tpw of them (k = 100 at 10M rows: ~800 x 39; k = 1000 of ~4000 waves: the wave
+        // level prunes next to nothing, ~3300 x 39 = 128 k) through this one workgroup.  No integer division per element — a flat
+        // index split by / tpw and % tpw cost this loop 60 of its 100 us at 128 k elements (round 4, profiles/r04j_*): the lanes of
+        // a wave take the dimension that is contiguous in memory — the tiles j of one scan wave, or (strided sweeps: tile j of wave w
+        // is j * W + w) neighbouring passing waves of one j — in pieces of P = a power of two, 64 / P pieces per wave, and the
+        // workgroup's 16 waves stride the other dimension, V pieces in flight each.
+        const uint32_t wv = tid >> 6, ln = tid & 63u;
+        // ... and when the wave level prunes less than half of the tiles (k = 1000: 82 % of the waves pass) the passing waves are not
+        // looked up at all: the query's tile maxima are read LINEARLY, 16 bytes per lane (a tile that reaches Twm sits in a wave that
+        // does, so the set is the same) — 38 loads per wave instead of 205 dependent ones: 75-95 us -> see profiles/r04j_*.
+        const bool dense = (uint64_t)nA * tpw * 2ull >= (uint64_t)n_tiles && (p.tmax_stride & 3ull) == 0ull;
+        if (dense) {
+            const uint4* t4 = reinterpret_cast<const uint4*>(tmax);
+            const uint32_t n4 = (n_tiles + 3u) >> 2;
+            for (uint32_t e0 = tid; e0 < n4; e0 += kSelThreads * V) {
+                uint4 v4[V];
 #pragma unroll
-            for (int u = 0; u < V; u++) {
-                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
-                tt[u] = e < slots ? tile_of(la[e / tpw], e % tpw) : 0xFFFFFFFFu;
-                tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
+                for (int u = 0; u < V; u++) {
+                    const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                    v4[u] = e < n4 ? t4[e] : make_uint4(kKeyMasked, kKeyMasked, kKeyMasked, kKeyMasked);
+                }
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    const uint32_t t0 = (e0 + (uint32_t)u * kSelThreads) * 4u;
+                    const uint32_t kk4[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) cnt += (t0 + (uint32_t)c < n_tiles && kk4[c] != kKeyMasked && kk4[c] >= Twm) ? 1u : 0u;
+                    // one LDS atomic per wave and load: an inclusive scan of the lanes' counts places every lane's entries
+                    uint32_t incl = cnt;
+#pragma unroll
+                    for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+                        const uint32_t t = (uint32_t)__shfl_up((int)incl, (int)dd);
+                        if (ln >= dd) incl += t;
+                    }
+                    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+                    if (total == 0) continue;  // (wave-uniform)
+                    uint32_t base = 0;
+                    if (ln == 0) base = atomicAdd(&s_w[1], total);
+                    base = (uint32_t)__shfl((int)base, 0);
+                    uint32_t pos = base + incl - cnt;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (t0 + (uint32_t)c < n_tiles && kk4[c] != kKeyMasked && kk4[c] >= Twm) {
+                            if (pos < kCompCap) LT[pos] = ((unsigned long long)kk4[c] << 32) | (t0 + (uint32_t)c);
+                            pos++;
+                        }
+                    }
+                }
             }
+        }
+        const uint32_t n_in = dense ? 0u : (strided ? nA : tpw), n_out = strided ? tpw : nA;   // inner: across lanes; outer: across waves / iterations
+        uint32_t lgP = 0;
+        while (lgP < 6u && (1u << lgP) < n_in) lgP++;
+        const uint32_t P = 1u << lgP, per = 64u >> lgP;          // lanes per piece, pieces (outer indices) per wave and step
+        const uint32_t in_l = ln & (P - 1u), sub = ln >> lgP;
+        for (uint32_t in0 = 0; in0 < n_in; in0 += 64u) {          // (only rows of more than 64 tiles per wave / passing waves loop here)
+            const uint32_t in = in0 + in_l;
+            for (uint32_t o0 = wv * per; o0 < n_out; o0 += (kSelThreads / 64) * per * V) {
+                uint32_t tk[V], tt[V];
 #pragma unroll
-            for (int u = 0; u < V; u++) {
-                // (appends are counted per wave, one LDS atomic for all its lanes: on a degenerate shard every element passes,
-                // and 64 lanes adding to one LDS word serialize)
-                const bool pr = tk[u] != kKeyMasked && tk[u] >= Twm;
-                const uint32_t pos = wave_append(pr, &s_w[1]);
-                if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
+                for (int u = 0; u < V; u++) {
+                    const uint32_t o = o0 + (uint32_t)u * (kSelThreads / 64) * per + sub;
+                    const bool ok = in < n_in && o < n_out;
+                    tt[u] = ok ? (strided ? tile_of(la[in], o) : tile_of(la[o], in)) : 0xFFFFFFFFu;
+                    tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
+                }
+#pragma unroll
+                for (int u = 0; u < V; u++) {
+                    // (appends are counted per wave, one LDS atomic for all its lanes: on a degenerate shard every element passes,
+                    // and 64 lanes adding to one LDS word serialize)
+                    const bool pr = tk[u] != kKeyMasked && tk[u] >= Twm;
+                    const uint32_t pos = wave_append(pr, &s_w[1]);
+                    if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
+                }
             }
         }
     }
@@ -332,6 +392,13 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                 const float tau = key_to_score(T2m);
                 *p.l2_hint = (tau > 0.0f && tau <= 1.0f) ? 1.0f / tau - 1.0f : 0.0f;
             }
+#ifdef NMN_SELECT_TRACE
+            if (q == 0) {
+                sel_t[5] = wall_clock64();
+                printf("select (hands over) W=%u vw=%u nA=%u ct=%u strided=%d | ticks: load %llu count %llu radixW %llu tiles %llu radixT %llu total %llu\n", W, vw, nA,
+                       ct, (int)strided, sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], sel_t[5] - sel_t[4], sel_t[5] - sel_t[0]);
+            }
+#endif
         }
         return;
     }
