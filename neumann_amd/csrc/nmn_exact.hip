@@ -89,14 +89,25 @@ __device__ __forceinline__ float euclid_sumsq_seq(const float* __restrict__ q, c
                                                   uint32_t dim, uint32_t l) {
     float s = -0.0f;
     const uint32_t chunks = (dim + 7u) >> 3;
-    for (uint32_t c0 = 0; c0 < chunks; c0 += PF) {
-        float pr[PF];
+    // the loads of batch b + 1 are in flight under the additions of batch b (the chain does not depend on them): a batch used to
+    // wait for its own loads first — twelve round trips per 1536-element row, two thirds of the row's time
+    float xa[PF], ya[PF];
+    auto load = [&](uint32_t c0, float (&x)[PF], float (&y)[PF]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
             const uint32_t e = 8u * (c0 + (uint32_t)i) + l;
-            const float x = e < dim ? q[e] : 0.0f;
-            const float y = e < dim ? v[e] : 0.0f;
-            const float d = sub_rn(x, y);
+            x[i] = e < dim ? q[e] : 0.0f;
+            y[i] = e < dim ? v[e] : 0.0f;
+        }
+    };
+    load(0, xa, ya);
+    for (uint32_t c0 = 0; c0 < chunks; c0 += PF) {
+        float xn[PF], yn[PF];
+        load(c0 + PF, xn, yn);  // (past the end: every element fails e < dim, nothing is read)
+        float pr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const float d = sub_rn(xa[i], ya[i]);
             pr[i] = mul_rn(d, d);
         }
 #pragma unroll
@@ -109,6 +120,11 @@ __device__ __forceinline__ float euclid_sumsq_seq(const float* __restrict__ q, c
             s = add_rn(s, group8_bcast<5>(pr[i]));
             s = add_rn(s, group8_bcast<6>(pr[i]));
             s = add_rn(s, group8_bcast<7>(pr[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            xa[i] = xn[i];
+            ya[i] = yn[i];
         }
     }
     return s;

@@ -300,7 +300,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         if (dense) {
             const uint4* t4 = reinterpret_cast<const uint4*>(tmax);
             const uint32_t n4 = (n_tiles + 3u) >> 2;
-            for (uint32_t e0 = tid; e0 < n4; e0 += kSelThreads * V) {
+            // (the loop runs on the WAVE's first index: every lane of a wave takes every trip, the scan below reads lane 63)
+            for (uint32_t b0 = tid & ~63u; b0 < n4; b0 += kSelThreads * V) {
+                const uint32_t e0 = b0 + ln;
                 uint4 v4[V];
 #pragma unroll
                 for (int u = 0; u < V; u++) {

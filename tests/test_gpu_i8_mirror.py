@@ -304,8 +304,17 @@ def test_euclidean_estimator_follows_the_data():
     Q = oc.synth(0x52, 0, 4, d)
     with GpuFlatIndex(d, n) as idx:
         idx.fill_synthetic(0x51, n)
-        c = [check(idx, A, Q[i], k, 1, expect_bytes=1).candidates_rescored for i in range(4)]
+        # counted through the asynchronous API (one pass per query, the whole chain): a host-buffer search whose candidate list
+        # overflows is followed up by a second pass (short chain, round 4) — and that pass already has the first one's history
+        import torch
+        qd = torch.from_numpy(Q).cuda()
+        c = []
+        for i in range(4):
+            idx.search_device(qd[i:i + 1], k, 1)
+            c.append(idx.last_stats().candidates_rescored)
         assert c[1] < c[0] and c[2] < c[0] and c[3] < c[0], c
+        for i in range(4):
+            check(idx, A, Q[i], k, 1, expect_bytes=1)
         keep = np.random.default_rng(2).random(n) < 0.2
         check(idx, A, Q[0], k, 1, mask=oc.mask_from_bool(keep), expect_bytes=1)
         check(idx, A, Q[:2], k, 1, expect_bytes=1)      # two queries per sweep
