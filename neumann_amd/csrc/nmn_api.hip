@@ -1057,6 +1057,16 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 return (uint32_t)std::min<long>(std::max<long>(v, 64), (long)kMaxScanWaves);
             }();
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
+            // 8-bit batches of <= 64 queries on rows of 768 elements: the queries-in-LDS sweep (nmn_scan_i8b.hip).  Its scan waves are
+            // WAVES (4 per workgroup, each with its own tile range and wmax entry): tiles_per_wave, bx_base / bx_count count waves.
+            const bool use_i8b = use_mfma && use_i8 && scan_i8b_supported(idx->ld, idx->dim, (int)metric, nqc);
+            static const uint32_t i8b_waves = [] {  // tuning knob: NMN_I8B_WAVES in [256, kMaxScanWaves], a multiple of 4
+                const char* e = getenv("NMN_I8B_WAVES");
+                long v = e ? atol(e) : (long)kMaxScanWaves;
+                return (uint32_t)std::min<long>(std::max<long>(v, 256), (long)kMaxScanWaves) & ~3u;
+            }();
+            if (use_i8b) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + i8b_waves - 1) / i8b_waves);
+            auto launch_batch_sweep = [&](const ScanParams& x) -> hipError_t { return use_i8b ? launch_scan_i8b(x, stream) : launch_scan_mfma(x, stream); };
             sp.metric = (int)metric;
             sp.strided = (!use_mfma && mask_dev) ? 1u : 0u;  // masked VALU sweeps: a wave takes every W-th tile (runs of selected rows spread over all waves)
             static const bool no_walk = getenv("NMN_NO_WALK") != nullptr;  // (A/B switch of the survivor walk)
@@ -1084,9 +1094,10 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 ss.tile_step = sample_step;
                 ss.n_tiles = n_sample;
                 ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
+                if (use_i8b) ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 1023) / 1024);  // (one workgroup per CU, four waves each)
                 ss.tmax = w->tsample;
                 ss.tmax_stride = w->n_sample_cap;
-                HIP_TRY(launch_scan_mfma(ss, stream));
+                HIP_TRY(launch_batch_sweep(ss));
                 HIP_TRY(launch_sample_bound(w->tsample, w->n_sample_cap, n_sample, w->qinfo, nqc, k, w->skip_key, stream));
                 sp.skip_key = w->skip_key;
                 return NMN_OK;
@@ -1126,7 +1137,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return (uint32_t)n;
             }();
-            const uint32_t first_blocks = mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
+            const uint32_t first_blocks = use_i8b ? (mfma_blocks >= 12u * n_cu ? 4u * n_cu : 0u)  // (scan waves: four per workgroup)
+                                                  : mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
             static const uint32_t refine_min_nq = [] {  // (A/B knob: NMN_REFINE_MIN_NQ)
                 const char* e = getenv("NMN_REFINE_MIN_NQ");
                 return e ? (uint32_t)atol(e) : 65u;
@@ -1139,14 +1151,14 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 ScanParams sa = sp;
                 sa.bx_base = 0;
                 sa.bx_count = first_blocks;
-                HIP_TRY(launch_scan_mfma(sa, stream));
+                HIP_TRY(launch_batch_sweep(sa));
                 HIP_TRY(launch_sample_bound(w->tmax, w->tmax_stride, first_blocks * sp.tiles_per_wave, w->qinfo, nqc, k, w->skip_key, stream, 1));
                 ScanParams sb = sp;
                 sb.bx_base = first_blocks;
                 sb.bx_count = 0;
-                HIP_TRY(launch_scan_mfma(sb, stream));
+                HIP_TRY(launch_batch_sweep(sb));
             } else {
-                HIP_TRY(use_mfma ? launch_scan_mfma(sp, stream) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
+                HIP_TRY(use_mfma ? launch_batch_sweep(sp) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
             }
             if (w->timed && qa == 0) {
                 hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory) + 1];

@@ -158,6 +158,10 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
 // ... over the 8-bit mirror (p.corpus_i8 set: launch_scan_mfma dispatches on it): unmasked batches, rows of 256 .. 1536 elements
 bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric);
+// ... with the QUERIES in LDS and the rows loaded straight into registers as MFMA fragments (nmn_scan_i8b.hip): up to 64 queries
+// per pass over rows of 768 elements; same outputs, but a scan wave is a WAVE there (tiles_per_wave, bx_base / bx_count in waves)
+bool scan_i8b_supported(uint32_t ld, uint32_t dim, int metric, uint32_t nq);
+hipError_t launch_scan_i8b(const ScanParams& p, hipStream_t s);
 
 struct SelectParams {
     const uint32_t* scores;  // score_at(row, q, nql)

@@ -1,0 +1,463 @@
+// nmn_scan_i8b.hip — batched queries (3..64 per sweep) over the 8-bit mirror: queries in LDS, rows straight into registers.
+//
+// The matrix-core sweep of nmn_scan_mfma.hip keeps the QUERIES in registers (a wave owns 16 of them for the whole row)
+// and streams the ROWS through an LDS ring that all four waves of a workgroup read: every stage is a counted wait and a
+// workgroup barrier, every wave reads every stage (4x the stage bytes of LDS traffic), and a tile's epilogue in any wave
+// holds up the other three at the next barrier.  Over the 8-bit mirror — half the HBM time per stage, twice the MFMAs
+// (two int8 planes per query) — that loop runs at 5.8 TB/s and the whole sweep at 0.60-0.64 of the HBM peak
+// (docs/kernel-scan-mfma-i8.md).
+//
+// This kernel turns the two operands round:
+//   * the 64 QUERIES of the pass (int8 planes h, l of q = s_q (h + l / 256) + e_q, qprep_kernel) sit in LDS in fragment
+//     order, [k-step][query group, plane][lane] x 16 B — 96 KiB at 768 elements, written once per workgroup, read-only
+//     afterwards: ds_read_b128 at lane * 16, conflict-free;
+//   * the ROWS go from HBM into VGPRs as MFMA A-fragments (global_load_dwordx4: lane (n = lane & 15, g = lane >> 4) holds
+//     bytes [64 ks + 16 g, +16) of row n of a 16-row block — 16 rows x 64 B per instruction, the two halves of a 128-byte
+//     line by two consecutive k-steps).  A wave owns WHOLE tiles (64 rows x all 64 queries): a k-step is 4 row-block
+//     fragments (16 VGPRs) x 8 query fragments from LDS = 32 v_mfma_i32_16x16x64_i8, one LDS read per four MFMAs (the
+//     ring kernel: one per two).  The loads of the NEXT tile's k-step ks are issued right behind the MFMAs of this tile's
+//     k-step ks, into the registers those just freed: a whole tile (48 KiB per wave, 192 KiB per CU) is always in flight,
+//     and nothing in the loop is shared between waves — no barrier, no counted hand-over; a wave's epilogue costs that
+//     wave alone while its loads keep landing.
+//   * a wave is a "scan wave" of the selection (select_kernel): contiguous tile range, one wmax entry — 4096 of them, as in
+//     the VALU sweeps.  Workgroups exist only to share the LDS copy of the queries.
+// Outputs (scores / tmax / wmax, the sampling pass, skip_key, launch ranges) are those of scan_mfma_kernel<.., I8 = true>:
+// the rest of the chain does not know which of the two ran.  Margins: qprep_kernel, approx_pass 1 | 2 | 4 — the products
+// are exact integers either way, the epilogue's float arithmetic is the ring kernel's.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "nmn_internal.h"
+
+#ifdef NMN_I8B_TIMING  // measurement build: per scan wave, cycles in the k-loop / in the epilogue / in all, tiles (s_memtime)
+__device__ unsigned long long nmn_i8b_dbg[4096 * 4];
+extern "C" int nmn_i8b_debug_read(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nmn_i8b_dbg), sizeof(nmn_i8b_dbg));
+}
+#endif
+
+namespace nmn {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+#ifndef NMN_I8B_RING   // registers of query fragments in flight between LDS and the matrix cores (x 4 VGPRs)
+#define NMN_I8B_RING 8
+#endif
+#ifndef NMN_I8B_AHEAD  // fragments a ds_read_b128 is issued ahead of its MFMAs (< NMN_I8B_RING)
+#define NMN_I8B_AHEAD 6
+#endif
+
+template <bool NEG>
+__device__ __forceinline__ float l2_score_q(float qq8, float vv, float dot) {  // |q~ - v~|^2 = |q~|^2 + |v~|^2 - 2 q~.v~
+    const float d2 = __builtin_fmaxf(__builtin_fmaf(-2.0f, dot, qq8 + vv), 0.0f);
+    const float d = __builtin_amdgcn_sqrtf(d2);
+    return NEG ? -d : __builtin_amdgcn_rcpf(1.0f + d);
+}
+
+// Row loads are BUFFER loads: a 128-bit descriptor in SGPRs (rebuilt per tile by scalar adds), ONE 32-bit lane offset for all
+// of them, the row block in the scalar offset and the k-step in the instruction's immediate — no 64-bit address arithmetic
+// in the vector unit, no address registers to spill; a descriptor of zero records makes the loads behind a wave's last tile
+// return zeros without touching memory.
+constexpr uint32_t kRsrcFlags = 0x00020000u;  // gfx9-family raw buffer: DATA_FORMAT = 32 bit
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+template <int POLICY>
+__device__ __forceinline__ u4 load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POLICY ? 2 : 0);  // aux 2: non-temporal
+}
+
+// KSTEPS = row bytes / 64 (k-steps of a row); POLICY: cache policy of the row loads (0 default, 1 non-temporal)
+template <int KSTEPS, int METRIC, bool MASKED, int POLICY>
+__global__ void __launch_bounds__(256, 1) scan_i8b_kernel(ScanParams p) {
+    constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;
+    constexpr bool kScaled = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_DOT_PRODUCT;
+    constexpr int kFrags = KSTEPS * 8;  // query fragments per row: [k-step][group 0..3][plane h, l]
+    constexpr int R = NMN_I8B_RING, LA = NMN_I8B_AHEAD;
+    static_assert(LA < R && kFrags % R == 0 && KSTEPS % 2 == 0, "fragment ring; k-steps in pairs");
+    constexpr uint32_t ld = KSTEPS * 64;  // bytes per row of the mirror (= p.ld elements)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    u4* const bq = reinterpret_cast<u4*>(lds_u);                  // [kFrags][64 lanes] x 16 B
+    uint32_t* const tk_pend = lds_u + (uint32_t)kFrags * 64u * 4u;  // pending tile maxima: [wave][group][16 queries][4 tiles]
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g = lane >> 4, n = lane & 15u;
+
+    // ---- the queries: fragment order, zero for queries beyond nq --------------------------------------------------
+    {
+        const char* qb = reinterpret_cast<const char*>(p.qi8);
+        for (uint32_t e = threadIdx.x; e < (uint32_t)kFrags * 64u; e += 256u) {
+            const uint32_t ks = e >> 9, f = (e >> 6) & 7u, l = e & 63u;
+            const uint32_t q = (f >> 1) * 16u + (l & 15u), pl = f & 1u;
+            u4 v = {0u, 0u, 0u, 0u};
+            if (q < p.nq) v = *reinterpret_cast<const u4*>(qb + ((size_t)q * 2u + pl) * ld + ks * 64u + (l >> 4) * 16u);
+            bq[e] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave's tiles ---------------------------------------------------------------------------------------
+    const uint32_t wv = blockIdx.x * 4u + wave;          // wave of this launch
+    if (p.bx_count && wv >= p.bx_count) return;
+    const uint32_t sw = p.bx_base + wv;                  // scan wave: index into wmax, owner of tiles [t0, t1)
+    const uint32_t tstep = p.tile_step;                  // 1, or S on the sampling pass (tile index i -> tile i * S)
+    const bool sampling = tstep > 1;
+    const uint32_t t0 = sw * p.tiles_per_wave;
+    if (t0 >= p.n_tiles) return;
+    const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+
+    const char* const mirror = reinterpret_cast<const char*>(p.corpus_i8);
+    constexpr uint32_t kTileBytes = kTileRows * ld;
+    auto tile_rsrc = [&](uint32_t tile_, bool on) -> __amdgpu_buffer_rsrc_t {
+        return make_rsrc(mirror + (uint64_t)tile_ * tstep * kTileBytes, on ? kTileBytes : 0u);
+    };
+    const uint32_t voff = n * ld + g * 16u;  // row n of a 16-row block, 16-byte chunk g of a k-step
+
+    // per-lane constants of the four query groups: C column n of group H is query H * 16 + n
+    // (kept small on purpose: everything else about a query — its number, its addresses — is re-derived from n per tile)
+    uint32_t skip_h[4], wmax_h[4];
+    float invq_h[4], qq_h[kL2 ? 4 : 1];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const uint32_t qn = (uint32_t)h * 16u + n;
+        const bool ok = qn < p.nq;
+        const float qmag = ok ? p.qinfo[qn].qmag : 0.f;
+        const float qsc = ok ? p.qinfo[qn].qscale : 0.f;
+        // per-query factor: s_q / |q| (cosine), s_q (dot product; also what scales the Euclidean dot)
+        invq_h[h] = METRIC == NMN_METRIC_COSINE ? (qmag == 0.f ? 0.f : qsc * __builtin_amdgcn_rcpf(qmag)) : qsc;
+        if constexpr (kL2) qq_h[h] = ok ? p.qinfo[qn].qq8 : 0.f;
+        skip_h[h] = (ok && p.skip_key) ? p.skip_key[qn] : kKeyNaN;  // kKeyNaN: write every tile
+        wmax_h[h] = kKeyMasked;
+    }
+    // per-row factor of the epilogue: s_r / |v| (cosine) or s_r (dot, Euclidean); Euclidean also |v~|^2 of the row as stored
+    // (buffer loads like the rows: descriptor over the whole array, the tile in the scalar offset, g * 16 bytes per lane)
+    const uint32_t fbytes = (uint32_t)min((uint64_t)p.n_tiles * tstep * kTileRows * 4ull, 0xFFFFFFFFull);
+    const __amdgpu_buffer_rsrc_t rf_rs = make_rsrc(METRIC == NMN_METRIC_COSINE ? p.i8_cos : p.i8_scale, fbytes);
+    const __amdgpu_buffer_rsrc_t rv_rs = make_rsrc(p.i8_vv, fbytes);
+    (void)rv_rs;
+
+    // The row factors (and bitmap words) of a tile are asked for a whole tile AHEAD of the tile that uses them: loads return in
+    // issue order, so a factor load issued at the start of "its" tile sits in the queue behind the next tile's rows by the time
+    // the epilogue wants it — on a saturated memory system that is a full tile period away, the epilogue waited out the period,
+    // issued nothing meanwhile, and the sweep ran at memory time PLUS epilogue time (measured: 1.73 ms against 1.32 without the
+    // epilogue, whose arithmetic is 0.19 ms).
+    auto load_factors = [&](uint32_t tile_, f4 (&rf_)[4], f4 (&rv_)[kL2 ? 4 : 1], uint64_t (&mw_)[MASKED ? 4 : 1]) __attribute__((always_inline)) {
+        const uint64_t rt = (uint64_t)tile_ * tstep;  // real tile index (sampling pass: every tstep-th)
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            rf_[rb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rf_rs, g * 16u + (uint32_t)rb * 64u, (uint32_t)rt * 256u, 0));
+            if constexpr (kL2) rv_[rb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rv_rs, g * 16u + (uint32_t)rb * 64u, (uint32_t)rt * 256u, 0));
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
+                const uint32_t qn = (uint32_t)h * 16u + n;
+                const uint64_t* mq = p.qmasks ? (qn < p.nq ? p.qmasks[qn] : nullptr) : p.mask;
+                mw_[h] = (mq && tile_ < t1) ? mq[rt] : ~0ull;
+            }
+        }
+    };
+    f4 rf[4], rv[kL2 ? 4 : 1], rfn[4], rvn[kL2 ? 4 : 1];
+    uint64_t mw_h[MASKED ? 4 : 1], mwn_h[MASKED ? 4 : 1];
+    load_factors(t0, rfn, rvn, mwn_h);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: the first tile's fragments, the first query fragments ------------------------------------------
+    u4 a[KSTEPS][4];
+    {
+        const __amdgpu_buffer_rsrc_t r0 = tile_rsrc(t0, true);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) a[ks][rb] = load16<POLICY>(r0, voff + (uint32_t)ks * 64u, (uint32_t)rb * 16u * ld);
+            if (ks & 1) __builtin_amdgcn_sched_barrier(0);  // (in THIS order: loads return in issue order, and k-step 0 is wanted first)
+        }
+    }
+    u4 b[R];
+#pragma unroll
+    for (int F = 0; F < LA; F++) b[F % R] = bq[(uint32_t)F * 64u + lane];
+
+#ifdef NMN_I8B_TIMING
+    unsigned long long tk_sum = 0, te_sum = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t tile = t0; tile < t1; tile++) {
+#ifdef NMN_I8B_TIMING
+        const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
+        const uint64_t rtile = (uint64_t)tile * tstep;  // real tile index (sampling pass: every tstep-th)
+        // this tile's factors were asked for a tile ago; the next tile's go out now
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            rf[rb] = rfn[rb];
+            if constexpr (kL2) rv[rb] = rvn[rb];
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) mw_h[h] = mwn_h[h];
+        }
+        load_factors(tile + 1u, rfn, rvn, mwn_h);
+        // the next tile's descriptor (past the wave's range: zero records — the loads return zeros, no memory traffic)
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(tile + 1u, tile + 1u < t1);
+
+        v4i ach[4][4], acl[4][4];  // [row block][query group]: int32 sums of the h plane / the l plane
+        const v4i zero = {0, 0, 0, 0};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                const int F = ks * 8 + f;
+                b[(F + LA) % R] = bq[(uint32_t)((F + LA) % kFrags) * 64u + lane];
+                const v4i bv = __builtin_bit_cast(v4i, b[F % R]);
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const v4i av = __builtin_bit_cast(v4i, a[ks][rb]);
+#ifdef NMN_I8B_NO_MFMA  // measurement only: the loads without the products (answers are wrong)
+                    if (ks == 0) { ach[rb][f >> 1] = zero; acl[rb][f >> 1] = zero; }
+                    if (f == 0) ach[rb][0] += av + bv;
+#else
+                    if ((f & 1) == 0)
+                        ach[rb][f >> 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, ks == 0 ? zero : ach[rb][f >> 1], 0, 0, 0);
+                    else
+                        acl[rb][f >> 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, ks == 0 ? zero : acl[rb][f >> 1], 0, 0, 0);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifndef NMN_I8B_NO_LOADS  // (measurement only: the products without the loads — every tile multiplies the first one's rows)
+            // the next tile's rows into the registers just consumed — by PAIRS of k-steps: the two 64-byte halves of a row's 128-byte
+            // line are asked for back to back (NMN_I8B_SINGLE: k-step by k-step, the A/B)
+#ifdef NMN_I8B_SINGLE
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) a[ks][rb] = load16<POLICY>(nrs, voff + (uint32_t)ks * 64u, (uint32_t)rb * 16u * ld);
+#else
+            if (ks & 1) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    a[ks - 1][rb] = load16<POLICY>(nrs, voff + (uint32_t)(ks - 1) * 64u, (uint32_t)rb * 16u * ld);
+                    a[ks][rb] = load16<POLICY>(nrs, voff + (uint32_t)ks * 64u, (uint32_t)rb * 16u * ld);
+                }
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+
+#ifdef NMN_I8B_TIMING
+        const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+        tk_sum += t_b - t_a;
+#endif
+        // ---- epilogue: scores, per-(query, tile) maximum, score writes -------------------------------------------
+#ifdef NMN_I8B_NO_EPILOGUE
+        {  // measurement only: the sweep without its epilogue (answers are wrong)
+            int sink_v = 0;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sink_v += ach[rb][h][e] + acl[rb][h][e];
+            if (sink_v == 0x12345678) p.tmax[0] = 1u;
+            continue;
+        }
+#endif
+        const uint64_t r0 = rtile * kTileRows;
+        const uint64_t left = p.n_rows - r0;
+        // score stores are buffer stores: the tile's block of scores[] ([query][64 rows] f32) behind a per-tile descriptor,
+        // the lane's query and rows in a 32-bit offset
+        const __amdgpu_buffer_rsrc_t sc_rs = make_rsrc(p.scores + rtile * p.nql * 64ull, p.nql * 256u);
+        uint32_t n_v = n;
+        asm volatile("" : "+v"(n_v));  // (opaque per tile: what is derived from it — query numbers, store addresses — is not kept across the loop)
+        auto finish_group = [&](auto hc) __attribute__((always_inline)) {
+            constexpr int H = decltype(hc)::value;
+            const uint32_t qn = (uint32_t)H * 16u + n_v;
+            const bool q_ok = qn < p.nq;
+            const uint32_t skip = skip_h[H];
+            const float inv_q = invq_h[H], qq = qq_h[kL2 ? H : 0];
+            (void)qq;
+            auto store_scores = [&](int rb, const u4& w) __attribute__((always_inline)) {
+                __builtin_amdgcn_raw_buffer_store_b128(w, sc_rs, qn * 256u + g * 16u + (uint32_t)rb * 64u, 0, 0);
+            };
+            uint64_t mword = ~0ull;
+            if constexpr (MASKED) mword = mw_h[H];
+            if (left < 64) mword &= (1ull << left) - 1ull;
+            // h.c + (l.c) / 256: exact integers well below 2^24 * 256, one rounding of 2^-24 relative each
+            f4 fin[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) fin[rb][e] = __builtin_fmaf((float)acl[rb][H][e], 0.00390625f, (float)ach[rb][H][e]);
+            // the maximum over the four lane groups of a query, the tile and wave maxima, and whether this lane's query writes
+            // the tile's scores (only where the tile can still hold a candidate: skip_key, the sampled bound)
+            auto publish = [&](uint32_t tkey) __attribute__((always_inline)) -> bool {
+                const auto r32 = __builtin_amdgcn_permlane32_swap(tkey, tkey, false, false);
+                tkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
+                const auto r16 = __builtin_amdgcn_permlane16_swap(tkey, tkey, false, false);
+                tkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
+                // tile maxima leave in groups of four tiles (one 16-byte store per query); ragged ends one by one
+                {
+                    const uint32_t slot = tile & 3u;  // (wave-uniform)
+                    uint32_t* mine = tk_pend + ((wave * 4u + (uint32_t)H) * 16u + n_v) * 4u;
+                    if (g == 0) mine[slot] = tkey;
+                    if (slot == 3u || tile + 1u == t1) {
+                        const uint32_t g0 = tile & ~3u, first = max(g0, t0);
+                        if (q_ok && g == 0) {
+                            uint32_t* dst = p.tmax + (uint64_t)qn * p.tmax_stride + g0;
+                            const u4 v = *reinterpret_cast<const u4*>(mine);
+                            if (first == g0 && slot == 3u && (p.tmax_stride & 3ull) == 0ull) {
+                                *reinterpret_cast<u4*>(dst) = v;
+                            } else {
+                                if (first <= g0 + 0u) dst[0] = v[0];
+                                if (first <= g0 + 1u && slot >= 1u) dst[1] = v[1];
+                                if (first <= g0 + 2u && slot >= 2u) dst[2] = v[2];
+                                if (first <= g0 + 3u && slot >= 3u) dst[3] = v[3];
+                            }
+                        }
+                    }
+                }
+                wmax_h[H] = max(wmax_h[H], tkey);
+#ifdef NMN_I8B_NO_SCORE_WRITES
+                return false;
+#else
+                return q_ok && !sampling && tkey != kKeyMasked && tkey >= skip;
+#endif
+            };
+            auto l2_of = [&](float acc_v, float vn_v, float vv_v) __attribute__((always_inline)) -> float {
+                return l2_score_q<METRIC == kMetricNegL2>(qq, vv_v, acc_v * (inv_q * vn_v));  // vn_v = s_r
+            };
+            if (mword == ~0ull) {
+                float m = -__builtin_inff();
+                u4 bits[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    f4 sc = fin[rb];
+                    if constexpr (kScaled) sc = sc * rf[rb];
+                    if constexpr (kL2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) sc[e] = l2_of(sc[e], rf[rb][e], rv[rb][e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if constexpr (!kScaled) bits[rb][e] = f2u(sc[e]);
+                        m = __builtin_fmaxf(m, sc[e]);  // v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its key
+                    }
+                }
+                if constexpr (kScaled) m = m * inv_q;  // (>= 0: monotone, rounding included)
+                if (publish(score_to_key(m))) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++) {
+                        u4 w;
+                        if constexpr (kScaled) {
+                            const f4 sc = fin[rb] * rf[rb];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) w[e] = f2u(sc[e] * inv_q);
+                        } else {
+                            w = bits[rb];
+                        }
+                        store_scores(rb, w);
+                    }
+                }
+            } else {
+                uint32_t tkey = kKeyMasked;
+                u4 bits[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const uint32_t mrow = ((uint32_t)(mword >> ((uint32_t)rb * 16u)) & 0xFFFFu) >> (g * 4u);  // bits 0..3: this lane's 4 rows
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const bool valid = ((mrow >> (uint32_t)e) & 1u) != 0;
+                        float sc = fin[rb][e];
+                        if constexpr (kScaled) sc = (sc * rf[rb][e]) * inv_q;
+                        if constexpr (kL2) sc = l2_of(sc, rf[rb][e], rv[rb][e]);
+                        bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
+                        if (valid) tkey = max(tkey, score_to_key(sc));
+                    }
+                }
+                if (publish(tkey)) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++)
+                        store_scores(rb, bits[rb]);
+                }
+            }
+        };
+        finish_group(std::integral_constant<int, 0>{});
+        finish_group(std::integral_constant<int, 1>{});
+        finish_group(std::integral_constant<int, 2>{});
+        finish_group(std::integral_constant<int, 3>{});
+#ifdef NMN_I8B_TIMING
+        te_sum += __builtin_amdgcn_s_memtime() - t_b;
+#endif
+    }
+#ifdef NMN_I8B_TIMING
+    if (!sampling && lane == 0) {
+        nmn_i8b_dbg[sw * 4 + 0] = tk_sum;
+        nmn_i8b_dbg[sw * 4 + 1] = te_sum;
+        nmn_i8b_dbg[sw * 4 + 2] = __builtin_amdgcn_s_memtime() - t_begin;
+        nmn_i8b_dbg[sw * 4 + 3] = t1 - t0;
+    }
+#endif
+    if (sampling) return;  // the sampling pass leaves only tmax
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const uint32_t qn = (uint32_t)h * 16u + n;
+        if (qn < p.nq && g == 0) p.wmax[(size_t)qn * p.wmax_stride + sw] = wmax_h[h];
+    }
+}
+
+template <int KSTEPS, int METRIC, bool MASKED>
+hipError_t launch_one(const ScanParams& p, hipStream_t s) {
+    const uint32_t waves_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    if (p.bx_base >= waves_all) return hipSuccess;
+    const uint32_t waves = p.bx_count ? std::min(p.bx_count, waves_all - p.bx_base) : waves_all - p.bx_base;
+    ScanParams pf = p;
+    pf.bx_count = waves;
+    const size_t lds = (size_t)KSTEPS * 8 * 64 * 16 + 4 * 4 * 16 * 16;  // the queries + the pending tile maxima
+    // cache policy of the row loads: a 128-byte line is read as two 64-byte halves by two instructions a k-step apart, so the
+    // line must survive in the vector cache between them — non-temporal loads (what every other sweep uses) re-fetch it
+    // (tools/micro/read_bw.hip "fragment": 5.4 vs 6.4 TB/s).  NMN_I8B_NT=1: the A/B.
+    static const bool nt = getenv("NMN_I8B_NT") != nullptr;
+    auto kern = nt ? scan_i8b_kernel<KSTEPS, METRIC, MASKED, 1> : scan_i8b_kernel<KSTEPS, METRIC, MASKED, 0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((waves + 3u) / 4u), dim3(256), lds, s, pf);
+    return hipGetLastError();
+}
+
+template <int METRIC>
+hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
+    const bool masked = p.mask || p.qmasks;
+    switch (p.ld / 64u) {
+        case 12: return masked ? launch_one<12, METRIC, true>(p, s) : launch_one<12, METRIC, false>(p, s);  // 768
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// rows of 768 elements, up to 64 queries per pass (the queries' two planes take ld * 128 bytes of LDS)
+bool scan_i8b_supported(uint32_t ld, uint32_t dim, int metric, uint32_t nq) {
+    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2))
+        return false;
+    static const bool off = getenv("NMN_NO_I8B") != nullptr;  // (A/B switch: the LDS-ring kernel serves everything)
+    return !off && dim <= ld && ld == 768u && nq <= 64u;
+}
+
+// p.tiles_per_wave = tiles per WAVE (a scan wave of the selection), p.bx_base / bx_count in waves
+hipError_t launch_scan_i8b(const ScanParams& p, hipStream_t s) {
+    switch (p.metric) {
+        case NMN_METRIC_COSINE: return launch_metric<NMN_METRIC_COSINE>(p, s);
+        case NMN_METRIC_EUCLIDEAN: return launch_metric<NMN_METRIC_EUCLIDEAN>(p, s);
+        case kMetricNegL2: return launch_metric<kMetricNegL2>(p, s);
+        default: return launch_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+    }
+}
+
+}  // namespace nmn
