@@ -31,7 +31,7 @@
 #include "nmn_internal.h"
 
 #ifdef NMN_I8B_TIMING  // measurement build: per scan wave, cycles in the k-loop / in the epilogue / in all, tiles (s_memtime)
-__device__ unsigned long long nmn_i8b_dbg[4096 * 4];
+__device__ unsigned long long nmn_i8b_dbg[4096 * 8];
 extern "C" int nmn_i8b_debug_read(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(nmn_i8b_dbg), sizeof(nmn_i8b_dbg));
 }
@@ -45,11 +45,16 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+constexpr int kI8bWaves = 8;  // waves per workgroup: two per SIMD (<= 256 registers each) — while one is in its epilogue or
+                              // blocked on the memory pipeline the other multiplies
+#ifndef NMN_I8B_DEPTH  // k-steps of rows a wave keeps in flight (x 2 KiB; the ring of A registers: x 8 VGPRs)
+#define NMN_I8B_DEPTH 8
+#endif
 #ifndef NMN_I8B_RING   // registers of query fragments in flight between LDS and the matrix cores (x 4 VGPRs)
-#define NMN_I8B_RING 8
+#define NMN_I8B_RING 4
 #endif
 #ifndef NMN_I8B_AHEAD  // fragments a ds_read_b128 is issued ahead of its MFMAs (< NMN_I8B_RING)
-#define NMN_I8B_AHEAD 6
+#define NMN_I8B_AHEAD 3
 #endif
 
 template <bool NEG>
@@ -74,25 +79,30 @@ __device__ __forceinline__ u4 load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, ui
 
 // KSTEPS = row bytes / 64 (k-steps of a row); POLICY: cache policy of the row loads (0 default, 1 non-temporal)
 template <int KSTEPS, int METRIC, bool MASKED, int POLICY>
-__global__ void __launch_bounds__(256, 1) scan_i8b_kernel(ScanParams p) {
+__global__ void __launch_bounds__(512, 1) scan_i8b_kernel(ScanParams p) {
     constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;
     constexpr bool kScaled = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_DOT_PRODUCT;
-    constexpr int kFrags = KSTEPS * 8;  // query fragments per row: [k-step][group 0..3][plane h, l]
+    constexpr int kFragsRow = KSTEPS * 8;  // query fragments per row: [k-step][group 0..3][plane h, l]
+    constexpr int kIdx = 2 * KSTEPS;       // k-steps of a tile: two half-tiles of 32 rows, KSTEPS each
+    constexpr int D = NMN_I8B_DEPTH;       // k-steps of rows in flight = the ring of A registers (x 2 row blocks x 4 VGPRs)
     constexpr int R = NMN_I8B_RING, LA = NMN_I8B_AHEAD;
-    static_assert(LA < R && kFrags % R == 0 && KSTEPS % 2 == 0, "fragment ring; k-steps in pairs");
-    constexpr uint32_t ld = KSTEPS * 64;  // bytes per row of the mirror (= p.ld elements)
+    static_assert(LA < R && (kIdx * 8) % R == 0 && KSTEPS % 2 == 0 && D % 2 == 0 && kIdx % D == 0 && D <= kIdx, "rings");
+    constexpr uint32_t ld = KSTEPS * 64;   // bytes per row of the mirror (= p.ld elements)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
-    u4* const bq = reinterpret_cast<u4*>(lds_u);                  // [kFrags][64 lanes] x 16 B
-    uint32_t* const tk_pend = lds_u + (uint32_t)kFrags * 64u * 4u;  // pending tile maxima: [wave][group][16 queries][4 tiles]
+    u4* const bq = reinterpret_cast<u4*>(lds_u);                       // [kFragsRow][64 lanes] x 16 B
+    uint32_t* const tk_pend = lds_u + (uint32_t)kFragsRow * 64u * 4u;  // pending tile maxima: [wave][group][16 queries][4 tiles]
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
+#ifdef NMN_I8B_TIMING
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- the queries: fragment order, zero for queries beyond nq --------------------------------------------------
     {
         const char* qb = reinterpret_cast<const char*>(p.qi8);
-        for (uint32_t e = threadIdx.x; e < (uint32_t)kFrags * 64u; e += 256u) {
+        for (uint32_t e = threadIdx.x; e < (uint32_t)kFragsRow * 64u; e += 512u) {
             const uint32_t ks = e >> 9, f = (e >> 6) & 7u, l = e & 63u;
             const uint32_t q = (f >> 1) * 16u + (l & 15u), pl = f & 1u;
             u4 v = {0u, 0u, 0u, 0u};
@@ -103,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) scan_i8b_kernel(ScanParams p) {
     __syncthreads();
 
     // ---- this wave's tiles ---------------------------------------------------------------------------------------
-    const uint32_t wv = blockIdx.x * 4u + wave;          // wave of this launch
+    const uint32_t wv = blockIdx.x * (uint32_t)kI8bWaves + wave;  // wave of this launch
     if (p.bx_count && wv >= p.bx_count) return;
     const uint32_t sw = p.bx_base + wv;                  // scan wave: index into wmax, owner of tiles [t0, t1)
     const uint32_t tstep = p.tile_step;                  // 1, or S on the sampling pass (tile index i -> tile i * S)
@@ -136,49 +146,55 @@ __global__ void __launch_bounds__(256, 1) scan_i8b_kernel(ScanParams p) {
         wmax_h[h] = kKeyMasked;
     }
     // per-row factor of the epilogue: s_r / |v| (cosine) or s_r (dot, Euclidean); Euclidean also |v~|^2 of the row as stored
-    // (buffer loads like the rows: descriptor over the whole array, the tile in the scalar offset, g * 16 bytes per lane)
+    // (buffer loads like the rows: descriptor over the whole array, the half-tile in the scalar offset, g * 16 bytes per lane)
     const uint32_t fbytes = (uint32_t)min((uint64_t)p.n_tiles * tstep * kTileRows * 4ull, 0xFFFFFFFFull);
     const __amdgpu_buffer_rsrc_t rf_rs = make_rsrc(METRIC == NMN_METRIC_COSINE ? p.i8_cos : p.i8_scale, fbytes);
     const __amdgpu_buffer_rsrc_t rv_rs = make_rsrc(p.i8_vv, fbytes);
     (void)rv_rs;
 
-    // The row factors (and bitmap words) of a tile are asked for a whole tile AHEAD of the tile that uses them: loads return in
-    // issue order, so a factor load issued at the start of "its" tile sits in the queue behind the next tile's rows by the time
-    // the epilogue wants it — on a saturated memory system that is a full tile period away, the epilogue waited out the period,
-    // issued nothing meanwhile, and the sweep ran at memory time PLUS epilogue time (measured: 1.73 ms against 1.32 without the
-    // epilogue, whose arithmetic is 0.19 ms).
-    auto load_factors = [&](uint32_t tile_, f4 (&rf_)[4], f4 (&rv_)[kL2 ? 4 : 1], uint64_t (&mw_)[MASKED ? 4 : 1]) __attribute__((always_inline)) {
+    // The row factors (and bitmap words) of a half-tile are asked for a half-tile AHEAD of the one that uses them: loads return
+    // in issue order, so a factor load issued at the start of "its" half sits in the queue behind the rows in flight by the time
+    // the epilogue wants it.
+    auto load_factors = [&](uint32_t tile_, uint32_t half_, f4 (&rf_)[2], f4 (&rv_)[kL2 ? 2 : 1], uint64_t (&mw_)[MASKED ? 4 : 1]) __attribute__((always_inline)) {
         const uint64_t rt = (uint64_t)tile_ * tstep;  // real tile index (sampling pass: every tstep-th)
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-            rf_[rb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rf_rs, g * 16u + (uint32_t)rb * 64u, (uint32_t)rt * 256u, 0));
-            if constexpr (kL2) rv_[rb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rv_rs, g * 16u + (uint32_t)rb * 64u, (uint32_t)rt * 256u, 0));
+        for (int rb = 0; rb < 2; rb++) {
+            rf_[rb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rf_rs, g * 16u + (uint32_t)rb * 64u, (uint32_t)rt * 256u + half_ * 128u, 0));
+            if constexpr (kL2) rv_[rb] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rv_rs, g * 16u + (uint32_t)rb * 64u, (uint32_t)rt * 256u + half_ * 128u, 0));
         }
         if constexpr (MASKED) {
+            if (half_ == 0) {  // (the tile's 64-bit word serves both halves)
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
-                // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
-                const uint32_t qn = (uint32_t)h * 16u + n;
-                const uint64_t* mq = p.qmasks ? (qn < p.nq ? p.qmasks[qn] : nullptr) : p.mask;
-                mw_[h] = (mq && tile_ < t1) ? mq[rt] : ~0ull;
+                for (int h = 0; h < 4; h++) {
+                    // one bitmap for the batch, or one per query (lanes with the same n = the same query: same word)
+                    const uint32_t qn = (uint32_t)h * 16u + n;
+                    const uint64_t* mq = p.qmasks ? (qn < p.nq ? p.qmasks[qn] : nullptr) : p.mask;
+                    mw_[h] = (mq && tile_ < t1) ? mq[rt] : ~0ull;
+                }
             }
         }
     };
-    f4 rf[4], rv[kL2 ? 4 : 1], rfn[4], rvn[kL2 ? 4 : 1];
+    f4 rf[2], rv[kL2 ? 2 : 1], rfn[2], rvn[kL2 ? 2 : 1];
     uint64_t mw_h[MASKED ? 4 : 1], mwn_h[MASKED ? 4 : 1];
-    load_factors(t0, rfn, rvn, mwn_h);
+    load_factors(t0, 0u, rfn, rvn, mwn_h);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- prologue: the first tile's fragments, the first query fragments ------------------------------------------
-    u4 a[KSTEPS][4];
-    {
-        const __amdgpu_buffer_rsrc_t r0 = tile_rsrc(t0, true);
+    // ---- prologue: the first D k-steps of the first tile, the first query fragments -------------------------------
+    // A ring: slot idx % D holds k-step idx of the tile (idx = half * KSTEPS + ks), two 16-row blocks each
+    u4 a[D][2];
+    auto issue_pair = [&](__amdgpu_buffer_rsrc_t rs, int idx0) __attribute__((always_inline)) {  // k-steps idx0, idx0 + 1 (the two halves of the rows' 128-byte lines)
+        const int hf = idx0 / KSTEPS, ks0 = idx0 % KSTEPS;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++) {
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) a[ks][rb] = load16<POLICY>(r0, voff + (uint32_t)ks * 64u, (uint32_t)rb * 16u * ld);
-            if (ks & 1) __builtin_amdgcn_sched_barrier(0);  // (in THIS order: loads return in issue order, and k-step 0 is wanted first)
+        for (int rb = 0; rb < 2; rb++) {
+            a[idx0 % D][rb] = load16<POLICY>(rs, voff + (uint32_t)ks0 * 64u, (uint32_t)(hf * 32 + rb * 16) * ld);
+            a[(idx0 + 1) % D][rb] = load16<POLICY>(rs, voff + (uint32_t)(ks0 + 1) * 64u, (uint32_t)(hf * 32 + rb * 16) * ld);
         }
+    };
+    __amdgpu_buffer_rsrc_t crs = tile_rsrc(t0, true);
+#pragma unroll
+    for (int i = 0; i < D; i += 2) {
+        issue_pair(crs, i);
+        __builtin_amdgcn_sched_barrier(0);  // (in THIS order: loads return in issue order, and k-step 0 is wanted first)
     }
     u4 b[R];
 #pragma unroll
@@ -189,37 +205,52 @@ __global__ void __launch_bounds__(256, 1) scan_i8b_kernel(ScanParams p) {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     for (uint32_t tile = t0; tile < t1; tile++) {
-#ifdef NMN_I8B_TIMING
-        const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-#endif
         const uint64_t rtile = (uint64_t)tile * tstep;  // real tile index (sampling pass: every tstep-th)
-        // this tile's factors were asked for a tile ago; the next tile's go out now
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-            rf[rb] = rfn[rb];
-            if constexpr (kL2) rv[rb] = rvn[rb];
-        }
-        if constexpr (MASKED) {
-#pragma unroll
-            for (int h = 0; h < 4; h++) mw_h[h] = mwn_h[h];
-        }
-        load_factors(tile + 1u, rfn, rvn, mwn_h);
         // the next tile's descriptor (past the wave's range: zero records — the loads return zeros, no memory traffic)
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(tile + 1u, tile + 1u < t1);
+        const uint64_t r0 = rtile * kTileRows;
+        const uint64_t left = p.n_rows - r0;
+        // score stores are buffer stores: the tile's block of scores[] ([query][64 rows] f32) behind a per-tile descriptor,
+        // the lane's query and rows in a 32-bit offset
+        const __amdgpu_buffer_rsrc_t sc_rs = make_rsrc(p.scores + rtile * p.nql * 64ull, p.nql * 256u);
+        uint32_t n_v = n;
+        asm volatile("" : "+v"(n_v));  // (opaque per tile: what is derived from it — query numbers, store addresses — is not kept across the loop)
+        uint32_t keyA[4];  // first half's maximum key per group
+        bool wroteA[4];    // ... and whether its scores were written
 
-        v4i ach[4][4], acl[4][4];  // [row block][query group]: int32 sums of the h plane / the l plane
+        v4i ach[2][4], acl[2][4];  // [row block][query group]: int32 sums of the h plane / the l plane
         const v4i zero = {0, 0, 0, 0};
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++) {
+        for (int idx = 0; idx < kIdx; idx++) {
+            const int half = idx / KSTEPS, ks = idx % KSTEPS;
+            if (ks == 0) {
+#ifdef NMN_I8B_TIMING
+                const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+                tk_sum -= t_a;
+#endif
+                // this half's factors were asked for a half ago; the next half's go out now
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    rf[rb] = rfn[rb];
+                    if constexpr (kL2) rv[rb] = rvn[rb];
+                }
+                if constexpr (MASKED) {
+                    if (half == 0) {
+#pragma unroll
+                        for (int h = 0; h < 4; h++) mw_h[h] = mwn_h[h];
+                    }
+                }
+                load_factors(half == 0 ? tile : tile + 1u, half == 0 ? 1u : 0u, rfn, rvn, mwn_h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int f = 0; f < 8; f++) {
-                const int F = ks * 8 + f;
-                b[(F + LA) % R] = bq[(uint32_t)((F + LA) % kFrags) * 64u + lane];
+                const int F = idx * 8 + f;
+                b[(F + LA) % R] = bq[(uint32_t)((F + LA) % kFragsRow) * 64u + lane];
                 const v4i bv = __builtin_bit_cast(v4i, b[F % R]);
 #pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    const v4i av = __builtin_bit_cast(v4i, a[ks][rb]);
+                for (int rb = 0; rb < 2; rb++) {
+                    const v4i av = __builtin_bit_cast(v4i, a[idx % D][rb]);
 #ifdef NMN_I8B_NO_MFMA  // measurement only: the loads without the products (answers are wrong)
                     if (ks == 0) { ach[rb][f >> 1] = zero; acl[rb][f >> 1] = zero; }
                     if (f == 0) ach[rb][0] += av + bv;
@@ -233,175 +264,172 @@ __global__ void __launch_bounds__(256, 1) scan_i8b_kernel(ScanParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef NMN_I8B_NO_LOADS  // (measurement only: the products without the loads — every tile multiplies the first one's rows)
-            // the next tile's rows into the registers just consumed — by PAIRS of k-steps: the two 64-byte halves of a row's 128-byte
-            // line are asked for back to back (NMN_I8B_SINGLE: k-step by k-step, the A/B)
-#ifdef NMN_I8B_SINGLE
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) a[ks][rb] = load16<POLICY>(nrs, voff + (uint32_t)ks * 64u, (uint32_t)rb * 16u * ld);
-#else
-            if (ks & 1) {
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    a[ks - 1][rb] = load16<POLICY>(nrs, voff + (uint32_t)(ks - 1) * 64u, (uint32_t)rb * 16u * ld);
-                    a[ks][rb] = load16<POLICY>(nrs, voff + (uint32_t)ks * 64u, (uint32_t)rb * 16u * ld);
-                }
+            // k-steps idx - 1 + D, idx + D (of this tile or the next) into the registers just consumed — by PAIRS: the two 64-byte
+            // halves of a row's 128-byte line are asked for back to back
+            if (idx & 1) {
+                if (idx - 1 + D < kIdx) issue_pair(crs, idx - 1 + D);
+                else issue_pair(nrs, idx - 1 + D - kIdx);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #endif
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
+            if (ks != KSTEPS - 1) continue;
 
+            // ---- epilogue of a half-tile: scores, maxima; the tile's maximum and its score writes after the second half ----
 #ifdef NMN_I8B_TIMING
-        const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-        tk_sum += t_b - t_a;
+            const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+            tk_sum += t_b;
 #endif
-        // ---- epilogue: scores, per-(query, tile) maximum, score writes -------------------------------------------
 #ifdef NMN_I8B_NO_EPILOGUE
-        {  // measurement only: the sweep without its epilogue (answers are wrong)
-            int sink_v = 0;
+            {  // measurement only: the sweep without its epilogue (answers are wrong)
+                int sink_v = 0;
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++)
+                for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                for (int h = 0; h < 4; h++)
+                    for (int h = 0; h < 4; h++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) sink_v += ach[rb][h][e] + acl[rb][h][e];
-            if (sink_v == 0x12345678) p.tmax[0] = 1u;
-            continue;
-        }
+                        for (int e = 0; e < 4; e++) sink_v += ach[rb][h][e] + acl[rb][h][e];
+                if (sink_v == 0x12345678) p.tmax[0] = 1u;
+                continue;
+            }
 #endif
-        const uint64_t r0 = rtile * kTileRows;
-        const uint64_t left = p.n_rows - r0;
-        // score stores are buffer stores: the tile's block of scores[] ([query][64 rows] f32) behind a per-tile descriptor,
-        // the lane's query and rows in a 32-bit offset
-        const __amdgpu_buffer_rsrc_t sc_rs = make_rsrc(p.scores + rtile * p.nql * 64ull, p.nql * 256u);
-        uint32_t n_v = n;
-        asm volatile("" : "+v"(n_v));  // (opaque per tile: what is derived from it — query numbers, store addresses — is not kept across the loop)
-        auto finish_group = [&](auto hc) __attribute__((always_inline)) {
-            constexpr int H = decltype(hc)::value;
-            const uint32_t qn = (uint32_t)H * 16u + n_v;
-            const bool q_ok = qn < p.nq;
-            const uint32_t skip = skip_h[H];
-            const float inv_q = invq_h[H], qq = qq_h[kL2 ? H : 0];
-            (void)qq;
-            auto store_scores = [&](int rb, const u4& w) __attribute__((always_inline)) {
-                __builtin_amdgcn_raw_buffer_store_b128(w, sc_rs, qn * 256u + g * 16u + (uint32_t)rb * 64u, 0, 0);
-            };
-            uint64_t mword = ~0ull;
-            if constexpr (MASKED) mword = mw_h[H];
-            if (left < 64) mword &= (1ull << left) - 1ull;
-            // h.c + (l.c) / 256: exact integers well below 2^24 * 256, one rounding of 2^-24 relative each
-            f4 fin[4];
+            auto finish_group = [&](auto hc) __attribute__((always_inline)) {
+                constexpr int H = decltype(hc)::value;
+                const uint32_t qn = (uint32_t)H * 16u + n_v;
+                const bool q_ok = qn < p.nq;
+                const uint32_t skip = skip_h[H];
+                const float inv_q = invq_h[H], qq = qq_h[kL2 ? H : 0];
+                (void)qq;
+                auto store_scores = [&](int hf, int rb, const u4& w) __attribute__((always_inline)) {
+                    __builtin_amdgcn_raw_buffer_store_b128(w, sc_rs, qn * 256u + g * 16u + (uint32_t)(hf * 32 + rb * 16) * 4u, 0, 0);
+                };
+                uint32_t mhalf = 0xFFFFFFFFu;  // this half's 32 rows of the tile's bitmap word
+                if constexpr (MASKED) mhalf = (uint32_t)(mw_h[H] >> (half * 32));
+                if (left < 64) {
+                    const uint64_t lm = (1ull << left) - 1ull;
+                    mhalf &= (uint32_t)(lm >> (half * 32));
+                }
+                // h.c + (l.c) / 256: exact integers well below 2^24 * 256, one rounding of 2^-24 relative each
+                f4 fin[2];
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++)
+                for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) fin[rb][e] = __builtin_fmaf((float)acl[rb][H][e], 0.00390625f, (float)ach[rb][H][e]);
-            // the maximum over the four lane groups of a query, the tile and wave maxima, and whether this lane's query writes
-            // the tile's scores (only where the tile can still hold a candidate: skip_key, the sampled bound)
-            auto publish = [&](uint32_t tkey) __attribute__((always_inline)) -> bool {
-                const auto r32 = __builtin_amdgcn_permlane32_swap(tkey, tkey, false, false);
-                tkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
-                const auto r16 = __builtin_amdgcn_permlane16_swap(tkey, tkey, false, false);
-                tkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
-                // tile maxima leave in groups of four tiles (one 16-byte store per query); ragged ends one by one
+                    for (int e = 0; e < 4; e++) fin[rb][e] = __builtin_fmaf((float)acl[rb][H][e], 0.00390625f, (float)ach[rb][H][e]);
+                auto l2_of = [&](float acc_v, float vn_v, float vv_v) __attribute__((always_inline)) -> float {
+                    return l2_score_q<METRIC == kMetricNegL2>(qq, vv_v, acc_v * (inv_q * vn_v));  // vn_v = s_r
+                };
+                // this lane's key of the half and its score words
+                uint32_t hkey;
+                u4 bits[2];
+                if (mhalf == 0xFFFFFFFFu) {
+                    float m = -__builtin_inff();
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) {
+                        f4 sc = fin[rb];
+                        if constexpr (kScaled) sc = (sc * rf[rb]) * inv_q;
+                        if constexpr (kL2) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) sc[e] = l2_of(sc[e], rf[rb][e], rv[rb][e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            bits[rb][e] = f2u(sc[e]);
+                            m = __builtin_fmaxf(m, sc[e]);  // v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its key
+                        }
+                    }
+                    hkey = score_to_key(m);
+                } else {
+                    hkey = kKeyMasked;
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) {
+                        const uint32_t mrow = ((mhalf >> ((uint32_t)rb * 16u)) & 0xFFFFu) >> (g * 4u);  // bits 0..3: this lane's 4 rows
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const bool valid = ((mrow >> (uint32_t)e) & 1u) != 0;
+                            float sc = fin[rb][e];
+                            if constexpr (kScaled) sc = (sc * rf[rb][e]) * inv_q;
+                            if constexpr (kL2) sc = l2_of(sc, rf[rb][e], rv[rb][e]);
+                            bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
+                            if (valid) hkey = max(hkey, score_to_key(sc));
+                        }
+                    }
+                }
+                // the maximum over the four lane groups of a query (v_permlane32_swap / v_permlane16_swap: no LDS round trip)
                 {
-                    const uint32_t slot = tile & 3u;  // (wave-uniform)
-                    uint32_t* mine = tk_pend + ((wave * 4u + (uint32_t)H) * 16u + n_v) * 4u;
-                    if (g == 0) mine[slot] = tkey;
-                    if (slot == 3u || tile + 1u == t1) {
-                        const uint32_t g0 = tile & ~3u, first = max(g0, t0);
-                        if (q_ok && g == 0) {
-                            uint32_t* dst = p.tmax + (uint64_t)qn * p.tmax_stride + g0;
-                            const u4 v = *reinterpret_cast<const u4*>(mine);
-                            if (first == g0 && slot == 3u && (p.tmax_stride & 3ull) == 0ull) {
-                                *reinterpret_cast<u4*>(dst) = v;
-                            } else {
-                                if (first <= g0 + 0u) dst[0] = v[0];
-                                if (first <= g0 + 1u && slot >= 1u) dst[1] = v[1];
-                                if (first <= g0 + 2u && slot >= 2u) dst[2] = v[2];
-                                if (first <= g0 + 3u && slot >= 3u) dst[3] = v[3];
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(hkey, hkey, false, false);
+                    hkey = max((uint32_t)r32[0], (uint32_t)r32[1]);
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(hkey, hkey, false, false);
+                    hkey = max((uint32_t)r16[0], (uint32_t)r16[1]);
+                }
+#ifdef NMN_I8B_NO_SCORE_WRITES
+                const bool may_write = false;
+#else
+                const bool may_write = q_ok && !sampling;
+#endif
+                if (half == 0) {
+                    // Scores are only worth their HBM write when the tile can still hold a candidate (skip_key: the sampled bound).
+                    // The first half does not know the tile's maximum yet: it writes if ITS maximum qualifies; if only the second half
+                    // qualifies the first half's rows (all below skip_key: no candidates) are written as sentinels then.
+                    keyA[H] = hkey;
+                    wroteA[H] = may_write && hkey != kKeyMasked && hkey >= skip;
+                    if (wroteA[H]) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++) store_scores(0, rb, bits[rb]);
+                    }
+                } else {
+                    const uint32_t tkey = max(keyA[H], hkey);
+                    // tile maxima leave in groups of four tiles (one 16-byte store per query); ragged ends one by one
+                    {
+                        const uint32_t slot = tile & 3u;  // (wave-uniform)
+                        uint32_t* mine = tk_pend + ((wave * 4u + (uint32_t)H) * 16u + n_v) * 4u;
+                        if (g == 0) mine[slot] = tkey;
+                        if (slot == 3u || tile + 1u == t1) {
+                            const uint32_t g0 = tile & ~3u, first = max(g0, t0);
+                            if (q_ok && g == 0) {
+                                uint32_t* dst = p.tmax + (uint64_t)qn * p.tmax_stride + g0;
+                                const u4 v = *reinterpret_cast<const u4*>(mine);
+                                if (first == g0 && slot == 3u && (p.tmax_stride & 3ull) == 0ull) {
+                                    *reinterpret_cast<u4*>(dst) = v;
+                                } else {
+                                    if (first <= g0 + 0u) dst[0] = v[0];
+                                    if (first <= g0 + 1u && slot >= 1u) dst[1] = v[1];
+                                    if (first <= g0 + 2u && slot >= 2u) dst[2] = v[2];
+                                    if (first <= g0 + 3u && slot >= 3u) dst[3] = v[3];
+                                }
                             }
                         }
                     }
-                }
-                wmax_h[H] = max(wmax_h[H], tkey);
-#ifdef NMN_I8B_NO_SCORE_WRITES
-                return false;
-#else
-                return q_ok && !sampling && tkey != kKeyMasked && tkey >= skip;
-#endif
-            };
-            auto l2_of = [&](float acc_v, float vn_v, float vv_v) __attribute__((always_inline)) -> float {
-                return l2_score_q<METRIC == kMetricNegL2>(qq, vv_v, acc_v * (inv_q * vn_v));  // vn_v = s_r
-            };
-            if (mword == ~0ull) {
-                float m = -__builtin_inff();
-                u4 bits[4];
+                    wmax_h[H] = max(wmax_h[H], tkey);
+                    if (may_write && tkey != kKeyMasked && tkey >= skip) {
 #pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    f4 sc = fin[rb];
-                    if constexpr (kScaled) sc = sc * rf[rb];
-                    if constexpr (kL2) {
+                        for (int rb = 0; rb < 2; rb++) store_scores(1, rb, bits[rb]);
+                        if (!wroteA[H]) {
+                            const u4 sent = {kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits};
 #pragma unroll
-                        for (int e = 0; e < 4; e++) sc[e] = l2_of(sc[e], rf[rb][e], rv[rb][e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if constexpr (!kScaled) bits[rb][e] = f2u(sc[e]);
-                        m = __builtin_fmaxf(m, sc[e]);  // v_max_f32 skips NaNs; an all-NaN lane reports -inf, an upper bound of its key
-                    }
-                }
-                if constexpr (kScaled) m = m * inv_q;  // (>= 0: monotone, rounding included)
-                if (publish(score_to_key(m))) {
-#pragma unroll
-                    for (int rb = 0; rb < 4; rb++) {
-                        u4 w;
-                        if constexpr (kScaled) {
-                            const f4 sc = fin[rb] * rf[rb];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) w[e] = f2u(sc[e] * inv_q);
-                        } else {
-                            w = bits[rb];
+                            for (int rb = 0; rb < 2; rb++) store_scores(0, rb, sent);
                         }
-                        store_scores(rb, w);
                     }
                 }
-            } else {
-                uint32_t tkey = kKeyMasked;
-                u4 bits[4];
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    const uint32_t mrow = ((uint32_t)(mword >> ((uint32_t)rb * 16u)) & 0xFFFFu) >> (g * 4u);  // bits 0..3: this lane's 4 rows
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const bool valid = ((mrow >> (uint32_t)e) & 1u) != 0;
-                        float sc = fin[rb][e];
-                        if constexpr (kScaled) sc = (sc * rf[rb][e]) * inv_q;
-                        if constexpr (kL2) sc = l2_of(sc, rf[rb][e], rv[rb][e]);
-                        bits[rb][e] = valid ? f2u(sc) : kScoreSentinelBits;
-                        if (valid) tkey = max(tkey, score_to_key(sc));
-                    }
-                }
-                if (publish(tkey)) {
-#pragma unroll
-                    for (int rb = 0; rb < 4; rb++)
-                        store_scores(rb, bits[rb]);
-                }
-            }
-        };
-        finish_group(std::integral_constant<int, 0>{});
-        finish_group(std::integral_constant<int, 1>{});
-        finish_group(std::integral_constant<int, 2>{});
-        finish_group(std::integral_constant<int, 3>{});
+            };
+            finish_group(std::integral_constant<int, 0>{});
+            finish_group(std::integral_constant<int, 1>{});
+            finish_group(std::integral_constant<int, 2>{});
+            finish_group(std::integral_constant<int, 3>{});
 #ifdef NMN_I8B_TIMING
-        te_sum += __builtin_amdgcn_s_memtime() - t_b;
+            te_sum += __builtin_amdgcn_s_memtime() - t_b;
 #endif
+        }
+        crs = nrs;
     }
 #ifdef NMN_I8B_TIMING
     if (!sampling && lane == 0) {
-        nmn_i8b_dbg[sw * 4 + 0] = tk_sum;
-        nmn_i8b_dbg[sw * 4 + 1] = te_sum;
-        nmn_i8b_dbg[sw * 4 + 2] = __builtin_amdgcn_s_memtime() - t_begin;
-        nmn_i8b_dbg[sw * 4 + 3] = t1 - t0;
+        nmn_i8b_dbg[sw * 8 + 0] = tk_sum;
+        nmn_i8b_dbg[sw * 8 + 1] = te_sum;
+        nmn_i8b_dbg[sw * 8 + 2] = __builtin_amdgcn_s_memtime() - t_begin;
+        nmn_i8b_dbg[sw * 8 + 3] = t1 - t0;
+        nmn_i8b_dbg[sw * 8 + 4] = t_entry;
+        nmn_i8b_dbg[sw * 8 + 5] = t_begin;
+        nmn_i8b_dbg[sw * 8 + 6] = __builtin_amdgcn_s_memtime();
+        nmn_i8b_dbg[sw * 8 + 7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 4 /* HW_ID: wave, simd, ... */) | ((unsigned long long)blockIdx.x << 32);
     }
 #endif
     if (sampling) return;  // the sampling pass leaves only tmax
@@ -419,7 +447,7 @@ hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves = p.bx_count ? std::min(p.bx_count, waves_all - p.bx_base) : waves_all - p.bx_base;
     ScanParams pf = p;
     pf.bx_count = waves;
-    const size_t lds = (size_t)KSTEPS * 8 * 64 * 16 + 4 * 4 * 16 * 16;  // the queries + the pending tile maxima
+    const size_t lds = (size_t)KSTEPS * 8 * 64 * 16 + (size_t)kI8bWaves * 4 * 16 * 16;  // the queries + the pending tile maxima
     // cache policy of the row loads: a 128-byte line is read as two 64-byte halves by two instructions a k-step apart, so the
     // line must survive in the vector cache between them — non-temporal loads (what every other sweep uses) re-fetch it
     // (tools/micro/read_bw.hip "fragment": 5.4 vs 6.4 TB/s).  NMN_I8B_NT=1: the A/B.
@@ -427,7 +455,7 @@ hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     auto kern = nt ? scan_i8b_kernel<KSTEPS, METRIC, MASKED, 1> : scan_i8b_kernel<KSTEPS, METRIC, MASKED, 0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((waves + 3u) / 4u), dim3(256), lds, s, pf);
+    hipLaunchKernelGGL(kern, dim3((waves + (uint32_t)kI8bWaves - 1u) / (uint32_t)kI8bWaves), dim3(kI8bWaves * 64), lds, s, pf);
     return hipGetLastError();
 }
 
