@@ -1058,7 +1058,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }();
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
             // 8-bit batches of <= 64 queries on rows of 768 elements: the queries-in-LDS sweep (nmn_scan_i8b.hip).  Its scan waves are
-            // WAVES (8 per workgroup, each with its own tile range and wmax entry): tiles_per_wave, bx_base / bx_count count waves.
+            // WAVES (4 per workgroup, each with its own tile range and wmax entry): tiles_per_wave, bx_base / bx_count count waves.
             const bool use_i8b = use_mfma && use_i8 && scan_i8b_supported(idx->ld, idx->dim, (int)metric, nqc);
             static const uint32_t i8b_waves = [] {  // tuning knob: NMN_I8B_WAVES in [256, kMaxScanWaves], a multiple of 8
                 const char* e = getenv("NMN_I8B_WAVES");
@@ -1094,7 +1094,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 ss.tile_step = sample_step;
                 ss.n_tiles = n_sample;
                 ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
-                if (use_i8b) ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 2047) / 2048);  // (one workgroup per CU, eight waves each)
+                if (use_i8b) ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 1023) / 1024);  // (one workgroup per CU, four waves each)
                 ss.tmax = w->tsample;
                 ss.tmax_stride = w->n_sample_cap;
                 HIP_TRY(launch_batch_sweep(ss));
@@ -1137,7 +1137,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return (uint32_t)n;
             }();
-            const uint32_t first_blocks = use_i8b ? 0u  // (its 512 workgroups are two rounds: a bound refined after the first would serve half the sweep)
+            const uint32_t first_blocks = use_i8b ? (mfma_blocks >= 12u * n_cu ? 4u * n_cu : 0u)  // (scan waves: four per workgroup — the first round)
                                                   : mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
             static const uint32_t refine_min_nq = [] {  // (A/B knob: NMN_REFINE_MIN_NQ)
                 const char* e = getenv("NMN_REFINE_MIN_NQ");

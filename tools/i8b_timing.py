@@ -10,8 +10,12 @@ W = int(os.environ.get("I8B_WG_WAVES", "8"))
 with GpuFlatIndex(dim, rows) as idx:
     idx.fill_synthetic(3, rows)
     Q = synth_rows(4, 0, nq * 2, dim)
-    for i in range(4):
-        idx.search(Q[(i % 2) * nq:(i % 2 + 1) * nq], 100, 0)
+    idx.set_timing(True)
+    ms = []
+    for i in range(8):
+        _, _, _, st = idx.search(Q[(i % 2) * nq:(i % 2 + 1) * nq], 100, 0, with_stats=True)
+        ms.append(st.scan_ms)
+    print("scan_ms (sampling pass + bound kernels + main sweep) of the last calls:", [round(x, 3) for x in ms[-4:]])
     lib = ctypes.CDLL(os.environ["NEUMANN_GPU_LIB"])
     buf = np.zeros(4096 * 8, dtype=np.uint64)
     rc = lib.nmn_i8b_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
