@@ -295,7 +295,7 @@ static nmn_status for_each_shard(nmn_sharded* s, const std::function<nmn_status(
 // ---- the collective ----------------------------------------------------------------------------------------------------
 // lane[g].block (`bytes` each) of every shard -> lane[0].gathered[g * bytes ...] (RCCL: -> every lane's `gathered`).  Enqueued
 // on the lanes' streams behind whatever produced the blocks; on return the merging stream (lane 0) is ordered behind all of
-// them.  RCCL: the caller holds collective_mutex() until every lane's stream has drained.
+// them.  RCCL: the caller holds collective_mutex() around this call (one issue order of the collectives on every device).
 static nmn_status sharded_gather(nmn_sharded* s, size_t bytes) {
     const uint32_t G = s->n_shards;
     ShardLane& root = s->lane[0];
@@ -797,10 +797,13 @@ static nmn_status sharded_run_body(nmn_sharded* s, const float* queries, uint32_
         S_TRY(hipSetDevice(s->device[0]));
         S_TRY(hipEventRecord(s->ev_g0, root.stream));
     }
-    // (RCCL: collectives of different handles must not interleave across the devices — held until every rank has drained)
-    std::unique_lock<std::mutex> coll(collective_mutex(), std::defer_lock);
-    if (s->gather == NMN_GATHER_RCCL) coll.lock();
+    // (RCCL: collectives of different communicators must be ISSUED in the same order on every device — two handles searched from
+    //  two threads — so the group call is made under a process-wide lock.  Only the issue: once every rank's all-gather sits in
+    //  its stream the order is fixed, and the merge, the copy back and the drain of one handle do not hold up the searches of
+    //  the others (it used to be held until every rank had drained).)
     {
+        std::unique_lock<std::mutex> coll(collective_mutex(), std::defer_lock);
+        if (s->gather == NMN_GATHER_RCCL) coll.lock();
         const nmn_status st = sharded_gather(s, pl.size);
         if (st != NMN_OK) return st;
     }
@@ -819,7 +822,6 @@ static nmn_status sharded_run_body(nmn_sharded* s, const float* queries, uint32_
             S_TRY(hipSetDevice(s->device[g]));
             S_TRY(hipStreamSynchronize(s->lane[g].stream));
         }
-    if (coll.owns_lock()) coll.unlock();
     memcpy(out_rows, s->pin_out, (size_t)nq * k * 8);
     memcpy(out_scores, s->pin_out + pl.off_scores, (size_t)nq * k * 4);
     memcpy(out_counts, s->pin_out + pl.off_counts, (size_t)nq * 4);
