@@ -86,14 +86,17 @@ __device__ __forceinline__ u4 load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, ui
 // wave), and it is never away from its load stream for longer than a fragment.  (Measured on the forms this replaces —
 // epilogue behind the k-loop: one wave per SIMD 1.70 ms per 64-query sweep of 10M x 768, two waves per SIMD 1.60-1.69, without
 // the epilogue 1.32-1.38; the LDS-ring kernel 1.46-1.49.)
-template <int KSTEPS, int METRIC, bool MASKED, int POLICY>
+// NG: query groups of 16 the pass holds (1 .. 4): everything per query group — LDS fragments, MFMAs, accumulators, epilogue slices —
+// scales with it; a pass of <= 16 queries does a quarter of the matrix-core and VALU work of a pass of 64 for the same bytes.
+template <int KSTEPS, int METRIC, bool MASKED, int POLICY, int NG>
 __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams p) {
+    constexpr int NF = 2 * NG;  // query fragments per k-step: [group][plane h, l]
     constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN || METRIC == kMetricNegL2;
     constexpr bool kScaled = METRIC == NMN_METRIC_COSINE || METRIC == NMN_METRIC_DOT_PRODUCT;
-    constexpr int kFragsRow = KSTEPS * 8;  // query fragments per row: [k-step][group 0..3][plane h, l]
+    constexpr int kFragsRow = KSTEPS * NF;  // query fragments per row: [k-step][group][plane h, l]
     constexpr int kIdx = 2 * KSTEPS;       // k-steps of a tile: two half-tiles of 32 rows, KSTEPS each = the rows in flight per wave
     constexpr int R = NMN_I8B_RING, LA = NMN_I8B_AHEAD;
-    static_assert(LA < R && kFragsRow % R == 0 && KSTEPS % 2 == 0 && kFragsRow >= 96, "rings; the epilogue's 24 slices need 96 fragment slots");
+    static_assert(LA < R && kFragsRow % R == 0 && KSTEPS % 2 == 0 && kFragsRow >= 24 * NG, "rings; the epilogue's 5 NG slices need 24 NG fragment slots");
     constexpr uint32_t ld = KSTEPS * 64;   // bytes per row of the mirror (= p.ld elements)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
     u4* const bq = reinterpret_cast<u4*>(lds_u);                       // [kFragsRow][64 lanes] x 16 B
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
     {
         const char* qb = reinterpret_cast<const char*>(p.qi8);
         for (uint32_t e = threadIdx.x; e < (uint32_t)kFragsRow * 64u; e += (uint32_t)kI8bWaves * 64u) {
-            const uint32_t ks = e >> 9, f = (e >> 6) & 7u, l = e & 63u;
+            const uint32_t ks = (e >> 6) / (uint32_t)NF, f = (e >> 6) % (uint32_t)NF, l = e & 63u;
             const uint32_t q = (f >> 1) * 16u + (l & 15u), pl = f & 1u;
             u4 v = {0u, 0u, 0u, 0u};
             if (q < p.nq) v = *reinterpret_cast<const u4*>(qb + ((size_t)q * 2u + pl) * ld + ks * 64u + (l >> 4) * 16u);
@@ -138,10 +141,10 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
 
     // per-lane constants of the four query groups: C column n of group H is query H * 16 + n
     // (kept small on purpose: everything else about a query — its number, its addresses — is re-derived from n where it is used)
-    uint32_t skip_h[4], wmax_h[4];
-    float invq_h[4], qq_h[kL2 ? 4 : 1];
+    uint32_t skip_h[NG], wmax_h[NG];
+    float invq_h[NG], qq_h[kL2 ? NG : 1];
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
+    for (int h = 0; h < NG; h++) {
         const uint32_t qn = (uint32_t)h * 16u + n;
         const bool ok = qn < p.nq;
         const float qmag = ok ? p.qinfo[qn].qmag : 0.f;
@@ -194,13 +197,13 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
         return (mq && tile_ < t1) ? mq[(uint64_t)tile_ * tstep] : ~0ull;
     };
     Factors fc[2], fn[2];  // [half parity]
-    uint64_t mwc[MASKED ? 4 : 1], mwn[MASKED ? 4 : 1], mwe[MASKED ? 4 : 1];  // bitmap words per group: the tile being multiplied, the next one, the previous one
+    uint64_t mwc[MASKED ? NG : 1], mwn[MASKED ? NG : 1], mwe[MASKED ? NG : 1];  // bitmap words per group: the tile being multiplied, the next one, the previous one
     (void)mwc; (void)mwe;
     load_factors(t0, 0u, fn[0]);
     load_factors(t0, 1u, fn[1]);
     if constexpr (MASKED) {
 #pragma unroll
-        for (int h = 0; h < 4; h++) mwn[h] = mask_word(t0, h);
+        for (int h = 0; h < NG; h++) mwn[h] = mask_word(t0, h);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -228,19 +231,19 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
     for (int F = 0; F < LA; F++) b[F % R] = bq[(uint32_t)F * 64u + lane];
 
     // accumulators: [set = half parity][row block][query group], int32 sums of the h plane / the l plane
-    v4i ach[2][2][4], acl[2][2][4];
+    v4i ach[2][2][NG], acl[2][2][NG];
     const v4i zero = {0, 0, 0, 0};
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-        for (int h = 0; h < 4; h++) ach[1][rb][h] = acl[1][rb][h] = zero;  // (the first half's epilogue slices run on "half -1")
+        for (int h = 0; h < NG; h++) ach[1][rb][h] = acl[1][rb][h] = zero;  // (the first half's epilogue slices run on "half -1")
 
     // state of the epilogue in progress
-    float m_h[4];          // running maximum of the half being finished, per group (before the query's factor)
-    uint32_t keyA[4];      // first half's maximum key per group
-    bool wroteA[4];        // ... and whether its scores were written
+    float m_h[NG];          // running maximum of the half being finished, per group (before the query's factor)
+    uint32_t keyA[NG];      // first half's maximum key per group
+    bool wroteA[NG];        // ... and whether its scores were written
 #pragma unroll
-    for (int h = 0; h < 4; h++) { m_h[h] = -__builtin_inff(); keyA[h] = kKeyMasked; wroteA[h] = false; }
+    for (int h = 0; h < NG; h++) { m_h[h] = -__builtin_inff(); keyA[h] = kKeyMasked; wroteA[h] = false; }
 
 #ifdef NMN_I8B_TIMING
     unsigned long long tk_sum = 0, te_sum = 0;
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
             if constexpr (MASKED) {
                 if (half == 0) {
 #pragma unroll
-                    for (int h = 0; h < 4; h++) {
+                    for (int h = 0; h < NG; h++) {
                         mwc[h] = mwn[h];
                         mwn[h] = mask_word(tile + 1u, h);
                     }
@@ -276,9 +279,9 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
             }
             // rows of the tile being finished that take part, as this lane sees them (8 bits: [rb][e]); the bitmap word of a tile is
             // current until the next tile's half 0 has replaced it, so half 1 of tile - 1 is finished from the copy `mwe`
-            uint32_t rows_h[4];
+            uint32_t rows_h[NG];
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
+            for (int h = 0; h < NG; h++) {
                 uint64_t w = ~0ull;
                 if constexpr (MASKED) w = half == 0 ? mwe[h] : mwc[h];
                 if (eleft < 64) w &= (1ull << eleft) - 1ull;
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
             if constexpr (MASKED) {
                 if (half == 0) {
 #pragma unroll
-                    for (int h = 0; h < 4; h++) mwe[h] = mwc[h];  // (this tile's word, for its half 1's slices in the next iteration)
+                    for (int h = 0; h < NG; h++) mwe[h] = mwc[h];  // (this tile's word, for its half 1's slices in the next iteration)
                 }
             }
             bool ragged = false;
@@ -415,8 +418,8 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
             for (int ks = 0; ks < KSTEPS; ks++) {
                 const int idx = half * KSTEPS + ks;
 #pragma unroll
-                for (int f = 0; f < 8; f++) {
-                    const int F = ks * 8 + f;  // fragment slot of this half: 0 .. kFragsRow - 1
+                for (int f = 0; f < NF; f++) {
+                    const int F = ks * NF + f;  // fragment slot of this half: 0 .. kFragsRow - 1
                     b[(F + LA) % R] = bq[(uint32_t)((F + LA) % kFragsRow) * 64u + lane];
                     const v4i bv = __builtin_bit_cast(v4i, b[F % R]);
 #pragma unroll
@@ -437,9 +440,9 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
 #endif
                     }
 #ifndef NMN_I8B_NO_EPILOGUE  // (measurement only: the sweep without its epilogue — answers are wrong)
-                    // the slices of the half being finished: 16 value slices in slots 4, 8, .., 64, the four groups' finish in 72, 78, 84, 90
-                    if (F >= 4 && F <= 64 && F % 4 == 0) value_slice(F / 4 - 1);
-                    if (F >= 72 && F <= 90 && (F - 72) % 6 == 0) finish_slice((F - 72) / 6);
+                    // the slices of the half being finished: 4 NG value slices in slots 4, 8, .., 16 NG, the groups' finish in 16 NG + 4, + 8, ..
+                    if (F >= 4 && F <= 16 * NG && F % 4 == 0) value_slice(F / 4 - 1);
+                    if (F >= 16 * NG + 4 && F <= 16 * NG + 4 * NG && (F - 16 * NG) % 4 == 0) finish_slice((F - 16 * NG) / 4 - 1);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -474,38 +477,46 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
 #endif
     if (sampling) return;  // the sampling pass leaves only tmax
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
+    for (int h = 0; h < NG; h++) {
         const uint32_t qn = (uint32_t)h * 16u + n;
         if (qn < p.nq && g == 0) p.wmax[(size_t)qn * p.wmax_stride + sw] = wmax_h[h];
     }
 }
 
-template <int KSTEPS, int METRIC, bool MASKED>
+template <int KSTEPS, int METRIC, bool MASKED, int NG>
 hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     if (p.bx_base >= waves_all) return hipSuccess;
     const uint32_t waves = p.bx_count ? std::min(p.bx_count, waves_all - p.bx_base) : waves_all - p.bx_base;
     ScanParams pf = p;
     pf.bx_count = waves;
-    const size_t lds = (size_t)KSTEPS * 8 * 64 * 16 + (size_t)kI8bWaves * 4 * 16 * 16;  // the queries + the pending tile maxima
-    // cache policy of the row loads: a 128-byte line is read as two 64-byte halves by two instructions a k-step apart, so the
-    // line must survive in the vector cache between them — non-temporal loads (what every other sweep uses) re-fetch it
+    const size_t lds = (size_t)KSTEPS * 2 * NG * 64 * 16 + (size_t)kI8bWaves * 4 * 16 * 16;  // the queries + the pending tile maxima
+    // cache policy of the row loads: a 128-byte line is read as two 64-byte halves by two instructions, so the line must survive in
+    // the vector cache between them — non-temporal loads (what every other sweep uses) re-fetch it
     // (tools/micro/read_bw.hip "fragment": 5.4 vs 6.4 TB/s).  NMN_I8B_NT=1: the A/B.
     static const bool nt = getenv("NMN_I8B_NT") != nullptr;
-    auto kern = nt ? scan_i8b_kernel<KSTEPS, METRIC, MASKED, 1> : scan_i8b_kernel<KSTEPS, METRIC, MASKED, 0>;
+    auto kern = nt ? scan_i8b_kernel<KSTEPS, METRIC, MASKED, 1, NG> : scan_i8b_kernel<KSTEPS, METRIC, MASKED, 0, NG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((waves + (uint32_t)kI8bWaves - 1u) / (uint32_t)kI8bWaves), dim3(kI8bWaves * 64), lds, s, pf);
     return hipGetLastError();
 }
 
-template <int METRIC>
-hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
-    const bool masked = p.mask || p.qmasks;
-    switch (p.ld / 64u) {
-        case 12: return masked ? launch_one<12, METRIC, true>(p, s) : launch_one<12, METRIC, false>(p, s);  // 768
+template <int METRIC, bool MASKED>
+hipError_t launch_groups(const ScanParams& p, hipStream_t s) {
+    if (p.ld != 768u) return hipErrorInvalidValue;
+    switch ((p.nq + 15u) / 16u) {
+        case 1: return launch_one<12, METRIC, MASKED, 1>(p, s);
+        case 2: return launch_one<12, METRIC, MASKED, 2>(p, s);
+        case 3: return launch_one<12, METRIC, MASKED, 3>(p, s);
+        case 4: return launch_one<12, METRIC, MASKED, 4>(p, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int METRIC>
+hipError_t launch_metric(const ScanParams& p, hipStream_t s) {
+    return (p.mask || p.qmasks) ? launch_groups<METRIC, true>(p, s) : launch_groups<METRIC, false>(p, s);
 }
 
 }  // namespace
