@@ -339,7 +339,58 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                 }
             }
         }
-        const uint32_t n_in = dense ? 0u : (strided ? nA : tpw), n_out = strided ? tpw : nA;   // inner: across lanes; outer: across waves / iterations
+        // Contiguous ranges (unmasked sweeps), tpw >= 8: the tile maxima of a passing wave are tpw consecutive words — 16 bytes per
+        // lane, ceil(tpw / 4) lanes per passing wave, several passing waves per load instruction.  10M x 768: 750 passing waves x 39
+        // tiles were six round trips of 39-of-64-lane dword loads (25 us of the selection's 62, profiles/r04y_*); now two.
+#ifndef NMN_SELECT_TILES_DWORD
+        const bool quads = !dense && !strided && tpw >= 8u;
+#else
+        const bool quads = false;
+#endif
+        if (quads) {
+            const uint32_t q4 = (tpw + 3u) >> 2;  // quads per passing wave
+            uint32_t lgQ = 0;
+            while (lgQ < 6u && (1u << lgQ) < q4) lgQ++;
+            const uint32_t PQ = 1u << lgQ, perw = 64u >> lgQ;  // lanes per passing wave, passing waves per wave and load
+            const uint32_t quad = ln & (PQ - 1u), sub = ln >> lgQ;
+            struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
+            for (uint32_t q40 = 0; q40 < q4; q40 += 64u) {  // (only ranges of more than 256 tiles per wave loop here)
+                const uint32_t qd = q40 + quad;
+                for (uint32_t o0 = wv * perw; o0 < nA; o0 += (kSelThreads / 64) * perw * V) {
+                    uint32_t tk[V][4], tb[V];
+#pragma unroll
+                    for (int u = 0; u < V; u++) {
+                        const uint32_t o = o0 + (uint32_t)u * (kSelThreads / 64) * perw + sub;
+                        const bool ok = qd < q4 && o < nA;
+                        tb[u] = ok ? la[o] * tpw + qd * 4u : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) tk[u][c] = kKeyMasked;
+                        if (ok) {
+                            const uint32_t lim = min(la[o] * tpw + tpw, n_tiles);  // end of this wave's range
+                            if (tb[u] + 3u < lim) {
+                                const Quad v = *reinterpret_cast<const Quad*>(tmax + tb[u]);
+#pragma unroll
+                                for (int c = 0; c < 4; c++) tk[u][c] = v.v[c];
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; c++)
+                                    if (tb[u] + (uint32_t)c < lim) tk[u][c] = tmax[tb[u] + (uint32_t)c];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < V; u++) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const bool pr = tk[u][c] != kKeyMasked && tk[u][c] >= Twm;
+                            const uint32_t pos = wave_append(pr, &s_w[1]);
+                            if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)tk[u][c] << 32) | (tb[u] + (uint32_t)c);
+                        }
+                    }
+                }
+            }
+        }
+        const uint32_t n_in = (dense || quads) ? 0u : (strided ? nA : tpw), n_out = strided ? tpw : nA;   // inner: across lanes; outer: across waves / iterations
         uint32_t lgP = 0;
         while (lgP < 6u && (1u << lgP) < n_in) lgP++;
         const uint32_t P = 1u << lgP, per = 64u >> lgP;          // lanes per piece, pieces (outer indices) per wave and step
@@ -415,6 +466,40 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         const uint32_t tot = ct * kTileRows;
         // (this gather is the longest chain of the kernel: ct x 64 scores through ONE workgroup, a memory round trip per batch of
         //  loads — under the 8-bit margin ct is ~700 at 1M rows, k = 100: 16 loads per thread in flight instead of 8)
+#ifndef NMN_SELECT_ROWS_DWORD
+        // 16 bytes per lane: the 64 scores of a tile are one 256-byte block of scores[] (score_at), so 16 lanes take a tile and a
+        // load instruction four tiles per wave — a quarter of the loads (and of the LT look-ups) of the dword form below, which is
+        // kept for the A/B (-DNMN_SELECT_ROWS_DWORD): profiles/r04y_* has this gather at 17 of the selection's 41 us at 1M x 768.
+        (void)tot;
+        constexpr int VR4 = NMN_SELECT_VR / 4;
+        const uint32_t tot4 = ct * (kTileRows / 4u);
+        for (uint32_t e0 = tid; e0 < tot4; e0 += kSelThreads * VR4) {
+            uint4 kb[VR4];
+#pragma unroll
+            for (int u = 0; u < VR4; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                kb[u] = make_uint4(kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits, kScoreSentinelBits);
+                if (e < tot4) {
+                    const unsigned long long ent = LT[e >> 4];
+                    if ((uint32_t)(ent >> 32) >= T2m)
+                        kb[u] = *reinterpret_cast<const uint4*>(p.scores + score_at((uint64_t)(uint32_t)(ent & 0xFFFFFFFFull) * kTileRows + (e & 15u) * 4u, q, nql));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < VR4; u++) {
+                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                const uint32_t row0 = (uint32_t)(LT[min(e, tot4 - 1u) >> 4] & 0xFFFFFFFFull) * kTileRows + (e & 15u) * 4u;
+                const uint32_t bits4[4] = {kb[u].x, kb[u].y, kb[u].z, kb[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t key = bits_to_key(bits4[c]);
+                    const bool pr = key != kKeyMasked && key >= T2m;
+                    const uint32_t pos = wave_append(pr, &s_w[2]);
+                    if (pr && pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | (row0 + (uint32_t)c);
+                }
+            }
+        }
+#else
         constexpr int VR = NMN_SELECT_VR;
         for (uint32_t e0 = tid; e0 < tot; e0 += kSelThreads * VR) {
             uint32_t kb[VR];  // (only the loaded scores wait in registers: the row of an element is read from LT again when it is appended)
@@ -436,6 +521,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                 if (pr && pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | ((uint32_t)(LT[min(e, tot - 1u) >> 6] & 0xFFFFFFFFull) * kTileRows + (e & 63u));
             }
         }
+#endif
         __syncthreads();
         SEL_MARK(6);
         const uint32_t cr = s_w[2];
