@@ -1,24 +1,26 @@
 // nmn_scan_i8b.hip — batched queries (3..64 per sweep) over the 8-bit mirror: queries in LDS, rows straight into registers.
+// OPT-IN (NMN_I8B=1): exact on the whole batched suite, measured SLOWER than the LDS-ring kernel it was built to beat
+// (1.65-1.73 vs 1.46-1.50 ms per 64-query sweep of 10M x 768; no batch size at which it wins) — docs/kernel-scan-i8b.md has the
+// account, profiles/r04q_*, r04x_* the numbers.  Kept because it is the other point in the design space, and measured.
 //
 // The matrix-core sweep of nmn_scan_mfma.hip keeps the QUERIES in registers (a wave owns 16 of them for the whole row)
 // and streams the ROWS through an LDS ring that all four waves of a workgroup read: every stage is a counted wait and a
 // workgroup barrier, every wave reads every stage (4x the stage bytes of LDS traffic), and a tile's epilogue in any wave
-// holds up the other three at the next barrier.  Over the 8-bit mirror — half the HBM time per stage, twice the MFMAs
-// (two int8 planes per query) — that loop runs at 5.8 TB/s and the whole sweep at 0.60-0.64 of the HBM peak
-// (docs/kernel-scan-mfma-i8.md).
+// holds up the other three at the next barrier.
 //
 // This kernel turns the two operands round:
-//   * the 64 QUERIES of the pass (int8 planes h, l of q = s_q (h + l / 256) + e_q, qprep_kernel) sit in LDS in fragment
-//     order, [k-step][query group, plane][lane] x 16 B — 96 KiB at 768 elements, written once per workgroup, read-only
-//     afterwards: ds_read_b128 at lane * 16, conflict-free;
-//   * the ROWS go from HBM into VGPRs as MFMA A-fragments (global_load_dwordx4: lane (n = lane & 15, g = lane >> 4) holds
-//     bytes [64 ks + 16 g, +16) of row n of a 16-row block — 16 rows x 64 B per instruction, the two halves of a 128-byte
-//     line by two consecutive k-steps).  A wave owns WHOLE tiles (64 rows x all 64 queries): a k-step is 4 row-block
-//     fragments (16 VGPRs) x 8 query fragments from LDS = 32 v_mfma_i32_16x16x64_i8, one LDS read per four MFMAs (the
-//     ring kernel: one per two).  The loads of the NEXT tile's k-step ks are issued right behind the MFMAs of this tile's
-//     k-step ks, into the registers those just freed: a whole tile (48 KiB per wave, 192 KiB per CU) is always in flight,
-//     and nothing in the loop is shared between waves — no barrier, no counted hand-over; a wave's epilogue costs that
-//     wave alone while its loads keep landing.
+//   * the QUERIES of the pass (int8 planes h, l of q = s_q (h + l / 256) + e_q, qprep_kernel; NG = ceil(nq / 16) groups of 16)
+//     sit in LDS in fragment order, [k-step][query group, plane][lane] x 16 B — 96 KiB at 768 elements and 64 queries, written
+//     once per workgroup, read-only afterwards: ds_read_b128 at lane * 16, conflict-free;
+//   * the ROWS go from HBM into registers as MFMA A-fragments (buffer_load_dwordx4 with a per-tile descriptor: lane (n = lane & 15,
+//     g = lane >> 4) holds bytes [64 ks + 16 g, +16) of row n of a 16-row block — 16 rows x 64 B per instruction; the two halves
+//     of a row's 128-byte line are asked for back to back, as a pair of k-steps).  A wave owns WHOLE tiles (64 rows x all the
+//     queries), worked as two half-tiles of 32 rows with an accumulator set each; the loads of the NEXT tile's k-step go out
+//     right behind the MFMAs of this tile's, into the registers those just freed: a tile (48 KiB per wave, 192 KiB per CU) is
+//     always asked for, and nothing in the loop is shared between waves — no barrier, no counted hand-over;
+//   * the EPILOGUE of half-tile X - 1 (int32 -> f32, row factors, running maxima, keys, score writes) is issued in slices between
+//     the MFMAs of half-tile X (see the kernel's comment); the MFMAs are inline asm so that their accumulators stay in
+//     architectural VGPRs, where VALU instructions can read them, and the rows in AGPRs, where the loads put them;
 //   * a wave is a "scan wave" of the selection (select_kernel): contiguous tile range, one wmax entry — 4096 of them, as in
 //     the VALU sweeps.  Workgroups exist only to share the LDS copy of the queries.
 // Outputs (scores / tmax / wmax, the sampling pass, skip_key, launch ranges) are those of scan_mfma_kernel<.., I8 = true>:
@@ -46,9 +48,6 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int kI8bWaves = 4;  // waves per workgroup: one per SIMD, up to 512 registers each
-#ifndef NMN_I8B_DEPTH  // k-steps of rows a wave keeps in flight (x 2 KiB; the ring of A registers: x 8 VGPRs)
-#define NMN_I8B_DEPTH 8
-#endif
 #ifndef NMN_I8B_RING   // registers of query fragments in flight between LDS and the matrix cores (x 4 VGPRs)
 #define NMN_I8B_RING 4
 #endif
@@ -246,7 +245,8 @@ __global__ void __launch_bounds__(kI8bWaves * 64, 1) scan_i8b_kernel(ScanParams 
     for (int h = 0; h < NG; h++) { m_h[h] = -__builtin_inff(); keyA[h] = kKeyMasked; wroteA[h] = false; }
 
 #ifdef NMN_I8B_TIMING
-    unsigned long long tk_sum = 0, te_sum = 0;
+    unsigned long long tk_sum = 0;
+    const unsigned long long te_sum = 0;  // (the epilogue has no time of its own in this form: it is inside the k-loop)
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     // One iteration = one tile: half 0 (with the slices of the PREVIOUS tile's half 1), half 1 (with those of this tile's half 0).

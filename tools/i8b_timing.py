@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from neumann_amd import GpuFlatIndex, synth_rows
 rows, dim, nq = 10_000_000, 768, 64
-W = int(os.environ.get("I8B_WG_WAVES", "8"))
+W = int(os.environ.get("I8B_WG_WAVES", "4"))
 with GpuFlatIndex(dim, rows) as idx:
     idx.fill_synthetic(3, rows)
     Q = synth_rows(4, 0, nq * 2, dim)
