@@ -134,6 +134,82 @@ static __device__ uint32_t exact_select_walk(Walk&& walk, uint32_t k, unsigned l
 }
 
 
+// ---- wave-level sorting (no barriers): one composite per lane ---------------------------------------------------------------
+static __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// the wave's 64 values in descending order (lane i = rank i): bitonic network over lane exchanges
+static __device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned long long o = shfl_xor_u64(v, (int)stride);
+            const bool keep_max = ((lane & stride) == 0) == ((lane & size) == 0);
+            v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
+// a bitonic sequence across the lanes -> descending order
+static __device__ __forceinline__ unsigned long long wave_merge_desc(unsigned long long v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t stride = 32; stride > 0; stride >>= 1) {
+        const unsigned long long o = shfl_xor_u64(v, (int)stride);
+        v = ((lane & stride) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+    }
+    return v;
+}
+// The first min(n_live, k) composites (score key << 32 | ~row) of list[0 .. n) in descending order, as (global row, score) pairs
+// padded to k with (UINT64_MAX, -inf).  `n` slots, of which `n_live` are entries (the others 0); entries are distinct (distinct
+// rows).  `list` must hold ceil(n / 64) * 64 entries and is overwritten.
+//
+// Runs and ranks instead of a workgroup-wide bitonic sort: every wave sorts runs of 64 in registers (lane exchanges, no barrier),
+// ONE barrier, then an entry's output slot is simply the number of entries before it — its index in its own run plus, by
+// binary search, the entries of every other run that are greater (the merge_kernel's argument, within one list); a search
+// stops as soon as the rank reaches k.  ~600 candidates (k = 100 under the 8-bit margin): 13.4 us of final_kernel -> see
+// profiles/r04y_*; the bitonic network was 55 barrier steps for 1024 slots (-DNMN_SORT_BITONIC keeps it for the A/B).
+#ifndef NMN_SORT_BITONIC
+static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint32_t n_live, uint32_t k, uint64_t row_base,
+                                     uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63u, nw = nthr >> 6;
+    const uint32_t nruns = (n + 63u) >> 6;
+    for (uint32_t r = wave; r < nruns; r += nw) {  // (wave-uniform)
+        const uint32_t i = r * 64u + lane;
+        const unsigned long long v = i < n ? list[i] : 0ull;
+        list[i] = wave_sort_desc(v, lane);
+    }
+    __syncthreads();
+    const uint32_t cnt = min(n_live, k);
+    for (uint32_t i = cnt + tid; i < k; i += nthr) {
+        out_rows[i] = UINT64_MAX;
+        out_scores[i] = u2f(0xFF800000u);  // -inf
+    }
+    for (uint32_t i = tid; i < nruns * 64u; i += nthr) {
+        const unsigned long long v = list[i];
+        if (v == 0ull) continue;
+        const uint32_t own = i >> 6;
+        uint32_t rank = i & 63u;
+        for (uint32_t r = 0; r < nruns && rank < k; r++) {
+            if (r == own) continue;
+            const unsigned long long* run = list + r * 64u;  // descending; zeros (never greater) at its end
+            uint32_t lo = 0, hi = 64;                         // lo = entries of this run that are greater than v
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (run[mid] > v) lo = mid + 1u;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            out_rows[rank] = row_base + (uint64_t)(0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull));
+            out_scores[rank] = key_to_score((uint32_t)(v >> 32));
+        }
+    }
+    if (tid == 0) *out_count = cnt;
+}
+#else
 // Descending bitonic sort of list[0 .. np2) (np2 a power of two, unused slots 0) by the whole workgroup, then the first
 // min(n, k) composites (score key << 32 | ~row) as (global row, score) pairs padded to k with (UINT64_MAX, -inf).
 // `n` slots are sorted, of which `n_live` are entries (the rest 0: they sort last).
@@ -173,34 +249,8 @@ static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint3
     }
     if (tid == 0) *out_count = cnt;
 }
+#endif
 
-// ---- wave-level sorting (no barriers): one composite per lane ---------------------------------------------------------------
-static __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
-    return ((unsigned long long)hi << 32) | lo;
-}
-// the wave's 64 values in descending order (lane i = rank i): bitonic network over lane exchanges
-static __device__ __forceinline__ unsigned long long wave_sort_desc(unsigned long long v, uint32_t lane) {
-#pragma unroll
-    for (uint32_t size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            const unsigned long long o = shfl_xor_u64(v, (int)stride);
-            const bool keep_max = ((lane & stride) == 0) == ((lane & size) == 0);
-            v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
-        }
-    }
-    return v;
-}
-// a bitonic sequence across the lanes -> descending order
-static __device__ __forceinline__ unsigned long long wave_merge_desc(unsigned long long v, uint32_t lane) {
-#pragma unroll
-    for (uint32_t stride = 32; stride > 0; stride >>= 1) {
-        const unsigned long long o = shfl_xor_u64(v, (int)stride);
-        v = ((lane & stride) == 0) ? (v > o ? v : o) : (v < o ? v : o);
-    }
-    return v;
-}
 // The 64 largest of list[0 .. n64 * 64) (n64 <= waves of the workgroup; empty slots 0), descending, in WAVE 0 (lane i = rank
 // i); every thread of the workgroup calls.  Each wave sorts its 64 in registers, then a tree of merges that keep the top 64
 // of two sorted runs (max of A[i] and B[63 - i] is a bitonic sequence of exactly those): one LDS exchange and two barriers
