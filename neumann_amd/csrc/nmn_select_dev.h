@@ -168,11 +168,57 @@ static __device__ __forceinline__ unsigned long long wave_merge_desc(unsigned lo
 // Runs and ranks instead of a workgroup-wide bitonic sort: every wave sorts runs of 64 in registers (lane exchanges, no barrier),
 // ONE barrier, then an entry's output slot is simply the number of entries before it — its index in its own run plus, by
 // binary search, the entries of every other run that are greater (the merge_kernel's argument, within one list); a search
-// stops as soon as the rank reaches k.  ~600 candidates (k = 100 under the 8-bit margin): 13.4 us of final_kernel -> see
-// profiles/r04y_*; the bitonic network was 55 barrier steps for 1024 slots (-DNMN_SORT_BITONIC keeps it for the A/B).
-#ifndef NMN_SORT_BITONIC
+// stops as soon as the rank reaches k.  ~600 candidates (k = 100 under the 8-bit margin): final_kernel 13.4 -> 8.2 us
+// (profiles/r04y_*); the bitonic network is 55 barrier steps for 1024 slots.  Lists of up to one entry per thread only; longer
+// ones keep the network (-DNMN_SORT_BITONIC: always the network, the A/B).
+// Descending bitonic sort of list[0 .. np2) (np2 a power of two, unused slots 0) by the whole workgroup, then the first
+// min(n, k) composites (score key << 32 | ~row) as (global row, score) pairs padded to k with (UINT64_MAX, -inf).
+// `n` slots are sorted, of which `n_live` are entries (the rest 0: they sort last).
+static __device__ void sort_and_emit_bitonic(unsigned long long* list, uint32_t n, uint32_t n_live, uint32_t k, uint64_t row_base,
+                                     uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + tid; i < np2; i += nthr) list[i] = 0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (np2 >> 1); t += nthr) {
+                const uint32_t lo = ((t / stride) * stride * 2u) + (t % stride);
+                const uint32_t hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = list[lo], b = list[hi];
+                if ((a < b) == desc) {
+                    list[lo] = b;
+                    list[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t cnt = min(n_live, k);
+    for (uint32_t i = tid; i < k; i += nthr) {
+        uint64_t row = UINT64_MAX;
+        float sc = u2f(0xFF800000u);  // -inf
+        if (i < cnt) {
+            const unsigned long long v = list[i];
+            row = row_base + (uint64_t)(0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull));
+            sc = key_to_score((uint32_t)(v >> 32));
+        }
+        out_rows[i] = row;
+        out_scores[i] = sc;
+    }
+    if (tid == 0) *out_count = cnt;
+}
+
 static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint32_t n_live, uint32_t k, uint64_t row_base,
                                      uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
+#ifdef NMN_SORT_BITONIC
+    return sort_and_emit_bitonic(list, n, n_live, k, row_base, out_rows, out_scores, out_count);
+#endif
+    // (more than one entry per thread: a wave runs a full rank search in every pass in which ANY of its lanes holds a top entry —
+    //  4096 near-equal candidates of a clustered IVF list took 100 us this way against the network's 36: the network keeps those)
+    if (n > blockDim.x) return sort_and_emit_bitonic(list, n, n_live, k, row_base, out_rows, out_scores, out_count);
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63u, nw = nthr >> 6;
     const uint32_t nruns = (n + 63u) >> 6;
     for (uint32_t r = wave; r < nruns; r += nw) {  // (wave-uniform)
@@ -209,47 +255,6 @@ static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint3
     }
     if (tid == 0) *out_count = cnt;
 }
-#else
-// Descending bitonic sort of list[0 .. np2) (np2 a power of two, unused slots 0) by the whole workgroup, then the first
-// min(n, k) composites (score key << 32 | ~row) as (global row, score) pairs padded to k with (UINT64_MAX, -inf).
-// `n` slots are sorted, of which `n_live` are entries (the rest 0: they sort last).
-static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint32_t n_live, uint32_t k, uint64_t row_base,
-                                     uint64_t* out_rows, float* out_scores, uint32_t* out_count) {
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t i = n + tid; i < np2; i += nthr) list[i] = 0ull;
-    __syncthreads();
-    for (uint32_t size = 2; size <= np2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < (np2 >> 1); t += nthr) {
-                const uint32_t lo = ((t / stride) * stride * 2u) + (t % stride);
-                const uint32_t hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = list[lo], b = list[hi];
-                if ((a < b) == desc) {
-                    list[lo] = b;
-                    list[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const uint32_t cnt = min(n_live, k);
-    for (uint32_t i = tid; i < k; i += nthr) {
-        uint64_t row = UINT64_MAX;
-        float sc = u2f(0xFF800000u);  // -inf
-        if (i < cnt) {
-            const unsigned long long v = list[i];
-            row = row_base + (uint64_t)(0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull));
-            sc = key_to_score((uint32_t)(v >> 32));
-        }
-        out_rows[i] = row;
-        out_scores[i] = sc;
-    }
-    if (tid == 0) *out_count = cnt;
-}
-#endif
 
 // The 64 largest of list[0 .. n64 * 64) (n64 <= waves of the workgroup; empty slots 0), descending, in WAVE 0 (lane i = rank
 // i); every thread of the workgroup calls.  Each wave sorts its 64 in registers, then a tree of merges that keep the top 64
