@@ -1582,11 +1582,20 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     const size_t words = (size_t)((idx->rows + 63) / 64);
     // packed result block: rows (8-byte aligned) | scores | counts
     const size_t off_scores = on * sizeof(uint64_t), off_counts = off_scores + on * sizeof(float);
-    const size_t pack_bytes = off_counts + (size_t)nq * sizeof(uint32_t);
+    const size_t res_bytes = off_counts + (size_t)nq * sizeof(uint32_t);
+    // ... | the predicates' row counters (8-byte aligned): they come back with the results in ONE copy (a second small D2H behind
+    // the first cost a filtered search ~12 us of its 0.31 ms: profiles/r04y_*)
+    size_t n_pred = 0;
+    for (size_t i = 0; i < n_reqs; i++) n_pred += reqs[i]->pred_cols ? 1 : 0;
+    const size_t pred_count_stride = (n_pred && words) ? 1 + (size_t)pred_batch_blocks(idx->rows, (uint32_t)n_pred) : 0;
+    const size_t off_pred = (res_bytes + 7) & ~(size_t)7;
+    const size_t pack_bytes = off_pred + n_pred * pred_count_stride * 8;
     HIP_TRY(grow(&w->h_queries, &w->h_queries_cap, qn));
     HIP_TRY(grow(&w->h_pack, &w->h_pack_cap, pack_bytes));
     HIP_TRY(grow_pinned(&w->pin_in, &w->pin_in_cap, qn * sizeof(float)));
     HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes));
+    unsigned long long* const d_pred_counts = reinterpret_cast<unsigned long long*>(w->h_pack + off_pred);
+    const unsigned long long* const h_pred_counts = reinterpret_cast<const unsigned long long*>(w->pin_out + off_pred);
     {
         float* dst = reinterpret_cast<float*>(w->pin_in);
         for (size_t i = 0; i < n_reqs; i++) {
@@ -1596,10 +1605,8 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     }
     HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
     // ---- predicates of the batch: one launch on this stream, each into its own bitmap -------------------------
-    size_t n_pred = 0;
-    for (size_t i = 0; i < n_reqs; i++) n_pred += reqs[i]->pred_cols ? 1 : 0;
     std::vector<const uint64_t*> eff_mask(n_reqs);  // the bitmap each request's queries are searched with
-    size_t pred_words = 0, pred_count_stride = 0, pred_block_bytes = 0;
+    size_t pred_words = 0;
     if (n_pred && words) {
         const nmn_columns* cols = nullptr;
         for (size_t i = 0; i < n_reqs; i++)
@@ -1607,10 +1614,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         pred_words = (size_t)columns_words(cols);
         if (pred_words < words || columns_device(cols) != idx->device)
             return fail_arg(NMN_ERR_INVALID_ARGUMENT, "metadata columns do not cover the shard's rows (or live on another device)");
-        const uint32_t blocks = pred_batch_blocks(idx->rows, (uint32_t)n_pred);
-        pred_count_stride = 1 + (size_t)blocks;
         HIP_TRY(grow(&w->pred_masks, &w->pred_masks_cap, n_pred * pred_words));
-        HIP_TRY(grow(&w->pred_counts, &w->pred_counts_cap, n_pred * pred_count_stride));
         size_t off = n_pred * pred_desc_bytes();
         std::vector<uint32_t> ops_off(n_pred), consts_off(n_pred);
         size_t j = 0;
@@ -1624,13 +1628,12 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         }
         const size_t block_bytes = off;
         HIP_TRY(grow(&w->pred_block, &w->pred_block_cap, block_bytes));
-        pred_block_bytes = (block_bytes + 15) & ~(size_t)15;  // the counts come back right behind the staged block
-        HIP_TRY(grow_pinned(&w->pin_pred, &w->pin_pred_cap, pred_block_bytes + n_pred * pred_count_stride * 8));
+        HIP_TRY(grow_pinned(&w->pin_pred, &w->pin_pred_cap, block_bytes));
         j = 0;
         for (size_t i = 0; i < n_reqs; i++) {
             if (!reqs[i]->pred_cols) continue;
             pred_desc_write(w->pin_pred + j * pred_desc_bytes(), ops_off[j], (uint32_t)(reqs[i]->pred_ops.size() / pred_op_bytes()),
-                            consts_off[j], w->pred_masks + j * pred_words, w->pred_counts + j * pred_count_stride);
+                            consts_off[j], w->pred_masks + j * pred_words, d_pred_counts + j * pred_count_stride);
             memcpy(w->pin_pred + ops_off[j], reqs[i]->pred_ops.data(), reqs[i]->pred_ops.size());
             if (reqs[i]->pred_n_consts) memcpy(w->pin_pred + consts_off[j], reqs[i]->pred_consts, (size_t)reqs[i]->pred_n_consts * 8);
             j++;
@@ -1674,8 +1677,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     // and serve the members separately when that is the cheaper way (few, selective filters).
     bool separately = false;
     if (!qmasks.empty() && n_pred && n_reqs <= 16) {
-        HIP_TRY(hipMemcpyAsync(w->pin_pred + pred_block_bytes, w->pred_counts, n_pred * pred_count_stride * 8,
-                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(w->pin_out + off_pred, d_pred_counts, n_pred * pred_count_stride * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const double sweep_us = (double)idx->rows * idx->ld * 2.0 / 5.5e6, fixed_us = 100.0;
         double sum = 0.0;
@@ -1683,8 +1685,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         for (size_t i = 0; i < n_reqs; i++) {
             double sel = selectivity_of(idx, *reqs[i]);
             if (reqs[i]->pred_cols)
-                sel = (double)reinterpret_cast<const unsigned long long*>(w->pin_pred + pred_block_bytes)[(j++) * pred_count_stride] /
-                      (double)std::max<uint64_t>(idx->rows, 1);
+                sel = (double)h_pred_counts[(j++) * pred_count_stride] / (double)std::max<uint64_t>(idx->rows, 1);
             sum += std::max(fixed_us, sel * sweep_us);
         }
         separately = sum < 1.1 * sweep_us + fixed_us;
@@ -1717,10 +1718,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     st = enqueue_all(try_short);
     if (st != NMN_OK) return st;
     std::vector<unsigned long long> pred_selected(n_pred, 0ull);
-    if (n_pred && words) {  // the predicates' counts (word 0 of each counter block): small, one strided copy
-        HIP_TRY(hipMemcpyAsync(w->pin_pred + pred_block_bytes, w->pred_counts, n_pred * pred_count_stride * 8,
-                               hipMemcpyDeviceToHost, s));
-    }
+    // (the predicates' counts — word 0 of each counter block — came back with the results: the tail of the packed block)
     lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
     HIP_TRY(hipStreamSynchronize(s));
     if (try_short) {
@@ -1738,7 +1736,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     }
     if (n_pred && words)
         for (size_t j = 0; j < n_pred; j++)
-            pred_selected[j] = reinterpret_cast<const unsigned long long*>(w->pin_pred + pred_block_bytes)[j * pred_count_stride];
+            pred_selected[j] = h_pred_counts[j * pred_count_stride];
     // hand the results out: the first k_i of each query's k-list are that request's answer (same total order)
     const uint64_t* h_rows = reinterpret_cast<const uint64_t*>(w->pin_out);
     const float* h_scores = reinterpret_cast<const float*>(w->pin_out + off_scores);

@@ -59,7 +59,7 @@ struct Workspace {
     // predicates of a batch: staged programs, result bitmaps [requests][words], counters [requests][1 + blocks]
     uint8_t* pred_block = nullptr; size_t pred_block_cap = 0;            // device
     uint64_t* pred_masks = nullptr; size_t pred_masks_cap = 0;           // device
-    unsigned long long* pred_counts = nullptr; size_t pred_counts_cap = 0;  // device
+    unsigned long long* pred_counts = nullptr; size_t pred_counts_cap = 0;  // (unused since round 4: the counters live in the tail of h_pack and come back with the results)
     uint8_t* pin_pred = nullptr; size_t pin_pred_cap = 0;                // pinned host staging of pred_block
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
     uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
