@@ -1049,12 +1049,13 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 return (uint32_t)std::min<long>(std::max<long>(v, 256), (long)kMaxScanWaves);
             }();
             sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + wave_target - 1) / wave_target);
-            // Sweeps of 0.25 .. 2 GiB (1M x 768 on the 8-bit mirror: 0.13 ms) run on 768 waves — 192 workgroups, three quarters of
+            // Sweeps of 0.125 .. 2 GiB (1M x 768 on the 8-bit mirror: 0.13 ms) run on 768 waves — 192 workgroups, three quarters of
             // the CUs — instead of 4096: the sweep is HBM-bound either way (0.1279 -> 0.1298 ms), and the CUs and wave slots it
             // leaves free are where the OTHER stream's selection / rescore tail runs while it streams.  Under 4096 persistent
             // waves that tail waited for slots (profiles/r04z_gantt_2streams.txt) and a pipelined caller got 0.158 ms per step out
             // of a 0.128-ms sweep; with 768: 0.1335 ms, 6 330 -> 7 490 q/s at 1M x 768, 3 700 -> 4 255 at 2M
-            // (profiles/r04s_scan_waves_by_rows.txt; from 4M rows on 4096 waves win again — there the sweep chain hides the tail).
+            // (profiles/r04s_scan_waves_by_rows.txt; from 4M rows on 4096 waves win again — there the sweep chain hides the tail; the
+            //  band's edges: 200 k x 768 +2 %, 300 k +5 %, 2.5M +11 %, 3M +2.5 %, 100 k -3 %).
             static const bool waves_pinned = getenv("NMN_SCAN_WAVES") != nullptr;
             static const uint32_t small_waves = [] {  // (A/B knob: NMN_SCAN_WAVES_SMALL, 0 = off)
                 const char* e = getenv("NMN_SCAN_WAVES_SMALL");
@@ -1063,7 +1064,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }();
             {
                 const uint64_t sweep_bytes = (uint64_t)n_rows * idx->ld * w->last_elem_bytes;
-                if (!waves_pinned && small_waves && !use_mfma && !mask_dev && sweep_bytes >= (256ull << 20) && sweep_bytes < (2ull << 30))
+                if (!waves_pinned && small_waves && !use_mfma && !mask_dev && sweep_bytes >= (128ull << 20) && sweep_bytes < (2ull << 30))
                     sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + small_waves - 1) / small_waves);
             }
             // workgroups of the MFMA sweep: 4 per CU in sequence (one resident at a time) evens out the CUs' finish
