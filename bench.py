@@ -15,32 +15,37 @@ uses the ranks it is given and refuses a WORLD_SIZE that is not N.  The corpus i
 merged on-device.  `--scaling weak` (default; BASELINE config 4) keeps `--rows` rows PER GPU — 80M x 768 on 8 GPUs;
 `--scaling strong` splits `--rows` rows over the GPUs.  At N = 1 the two are the same run.
 
-Prints ONE JSON line (rank 0):
-  value / ms_per_step   queries per second over the WHOLE corpus (rows_total rows) at every N — BASELINE.json's metric.  Under weak
-                scaling the corpus grows with N, so `value` staying level is linear scaling; shard scans/s (N x value) is under
-                `multi_gpu`.  The median over `--rebuilds` index rebuilds (each: W warmup steps, then EXACTLY K timed steps between
-                a barrier + synchronize on both sides, max over ranks); `rebuilds` lists every draw — where the driver puts a
-                15 GB buffer moves a single draw by several per cent
-  dtype         what the sweep computes in.  The approximate sweep of 1-2 queries reads the shard's 8-BIT mirror (int8 codes,
-                one scale per row, int32 accumulation); every candidate it selects is re-scored from the f32 corpus in the
-                reference's f32 operation order, so the answer is the reference's bit for bit (`parity`)
-  roofline      the dominant kernel of the timed loop.  `avg_kernel_ms` = HIP events the library records on the launch stream
-                around that kernel in EVERY timed step (nmn_index_scan_history), of the very loop `value` comes from; sweeps of a
-                shard never run side by side (the next one starts, on the device, when the previous one ends; the selection /
-                rescore tail of a step runs under the next step's sweep), so kernel <= step.  `achieved` / `frac` count the bytes
-                that kernel is asked to read (rows x dim x bytes_per_corpus_element, `pricing` says so); `frac_priced_as_survey_8d`
-                prices the same kernel time as SURVEY.md §8(d) writes it (rows x dim x 4: an EFFECTIVE rate).
-  roofline.f32_corpus   SURVEY §8(d)'s own measurement: the same index, queries, streams, steps with nmn_index_set_mirror(0) — the
-                sweep of the row-major f32 corpus, priced at rows x dim x 4 bytes per query: {queries_per_s, avg_kernel_ms,
-                achieved, frac, traffic}.  roofline.bf16_mirror: the 2-byte mirror, for the record.  Same answer required.
-  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores) on the WHOLE corpus when the host's RAM
-                holds its twin (else a 1M-row sample, flagged `extrapolated`)
+Prints ONE JSON line (rank 0).  The driver's record keeps the top-level scalars and the SCALARS of `roofline`, `config` and
+`cpu_baseline`; everything a checker needs is therefore a flat scalar there (nested objects carry the detail for a reader):
+  value / ms_per_step   queries per second over the WHOLE corpus (rows_total rows) at every N — BASELINE.json's metric — with the
+                sweep reading the ROW-MAJOR F32 CORPUS (`--mirror 0`, the default: SURVEY §8(d) prices the path on rows*dim*4
+                bytes per query and north_star asks for coalesced reads of the f32 rows).  Under weak scaling the corpus grows
+                with N, so `value` staying level is linear scaling; shard scans/s (N x value) is under `multi_gpu`.  The median
+                over `--rebuilds` index rebuilds (each: W warmup steps, then EXACTLY K timed steps between a barrier +
+                synchronize on both sides, max over ranks); `rebuilds` lists every draw
+  dtype         "f32": what the headline sweep reads and computes in
+  roofline      the dominant kernel of the timed loop (nmn::scan_kernel over the f32 rows).  `avg_kernel_ms` = HIP events the
+                library records on the launch stream around that kernel in EVERY timed step (nmn_index_scan_history), of the
+                very loop `value` comes from; sweeps of a shard never run side by side (the next one starts, on the device, when
+                the previous one ends; the selection / rescore tail of a step runs under the next step's sweep), so kernel <=
+                step.  `achieved` = algorithmic bytes (rows x dim x 4 per query) / avg_kernel_ms; `traffic` = PMC bytes per launch
+  roofline.i8_mirror_* / bf16_mirror_*   the SAME loop (index, queries, streams, steps) on the library's own default: the sweep
+                reads the shard's 8-bit (or bf16) mirror and every candidate is re-scored from the f32 rows in the reference's
+                order — the same answer bit for bit (…_exact_and_same_answer), an exact acceleration priced on the bytes the
+                mirror sweep is asked to read (…_frac_on_mirror_bytes), never a §8(d) figure
+  roofline.c3_f32_* / c3_i8_*   config 3 (64 queries per step) on the f32 corpus (…_frac: 30.72 GB per batch / sweep time / 8 TB/s)
+                and on the mirror; roofline.c2_* / c5_mask*_*: configs 2 and 5 (child runs), f32 sweep and mirror sweep each
+  config.shards_with_mirror   how many of the N shards served the mirror leg from a mirror (a shard short of HBM declines its
+                mirror and sweeps f32 rows: correct, slower — it must be visible); config.bytes_per_corpus_element: the headline's
+  cpu_baseline  the CPU oracle (oracle/nmn_oracle.c, -O3 -march=native, all host cores; cpu_model says which) on the WHOLE
+                corpus when the host's RAM holds its twin (else a 1M-row sample, flagged `extrapolated`)
   parity        size-independent exactness certificate of the last timed result (see certificate())
-  batched, concurrent_callers, other_configs, next_rows   further legs of the default single-GPU run (config 3 against BOTH its
-                bounds: HBM and the matrix cores; 64 / 128 host threads; configs 2 and 5; SURVEY §8(f): filtered SIMILAR end to
-                end, IVF probe, upload, index load)
+  mirror_legs, batched, concurrent_callers, other_configs, next_rows   the detail behind the flat scalars, and further legs of
+                the default single-GPU run (64 / 128 host threads; SURVEY §8(f): filtered SIMILAR end to end, IVF probe, upload,
+                index load)
   multi_gpu     (N > 1) rccl_ranks (ranks seen by a real all-gather of rank ids), rows_per_gpu[], gather_plus_merge_ms,
-                shard_scans_per_s, and `one_process_handle`: the same GPUs driven by ONE process through the C ABI's nmn_sharded
+                shard_scans_per_s, bytes per corpus element of every rank's sweeps, and `one_process_handle`: the same GPUs
+                driven by ONE process through the C ABI's nmn_sharded
 """
 import argparse
 import json
@@ -86,8 +91,10 @@ def parse():
                     help="index builds the timed loop is repeated over; value = the median (buffer placement moves one draw by several %%)")
     ap.add_argument("--mask", type=float, default=1.0,
                     help="selectivity of a synthetic WHERE-predicate bitmap (config 5); 1.0 = no mask")
-    ap.add_argument("--mirror", type=int, default=1, choices=[0, 1, 2],
-                    help="nmn_index_set_mirror: 1 = smallest mirror that serves the call (default), 2 = bf16 only, 0 = f32 corpus")
+    ap.add_argument("--mirror", type=int, default=0, choices=[0, 1, 2],
+                    help="nmn_index_set_mirror of the HEADLINE loop: 0 = the row-major f32 corpus (default: SURVEY §8(d) prices the path on "
+                         "rows*dim*4 bytes, and `value` / `roofline` are that sweep), 1 = the smallest mirror that serves the call (the "
+                         "library's own default; reported beside the headline as roofline.i8_mirror_*), 2 = bf16 mirror only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--callers", type=int, default=64, help="host threads of the concurrent-callers leg (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
@@ -99,6 +106,7 @@ def parse():
                     help="do not measure roofline.traffic with rocprofv3 child runs (then it comes from profiles/pmc_traffic.json)")
     ap.add_argument("--no-mirror-legs", "--no-f32-leg", dest="no_mirror_legs", action="store_true",
                     help="skip the roofline.f32_corpus / roofline.bf16_mirror legs")
+    ap.add_argument("--legs", default="i8,bf16", help="mirror sweeps measured beside an f32 headline (comma list of i8, bf16)")
     ap.add_argument("--always-gather", action="store_true",
                     help="run the all-gather + device merge even with one rank (what the N>1 step adds, on a 1-GPU box)")
     ap.add_argument("--batched", type=int, default=64,
@@ -204,7 +212,7 @@ def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
     del A
     qps_full = 1.0 / (dt * (total_rows / sample_rows))
     return {
-        "value": qps_full, "unit": "queries/s", "cores": cores, "kind": "port",
+        "value": qps_full, "unit": "queries/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
         "sample": (f"{reps} queries x the WHOLE corpus, {sample_rows} rows x {args.dim} (same generator/seed; host twin built in "
                    f"{synth_s:.1f} s), {dt * 1e3:.1f} ms/query on {cores} threads, nothing extrapolated" if full else
                    f"{reps} queries x {sample_rows} rows x {args.dim} (same generator/seed), {dt * 1e3:.2f} ms/query on {cores} threads, "
@@ -217,6 +225,24 @@ def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
     }
 
 
+def _cpu_model():
+    """Model name of the host CPU (stated next to the core count), sockets x model when there are several."""
+    try:
+        names, phys = [], set()
+        cur = None
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                cur = l.split(":", 1)[1].strip()
+                names.append(cur)
+            elif l.startswith("physical id"):
+                phys.add(l.split(":", 1)[1].strip())
+        if not names:
+            return None
+        return (f"{len(phys)} x " if len(phys) > 1 else "") + names[0] + f" ({len(names)} hardware threads)"
+    except OSError:
+        return None
+
+
 def _child_json(cmd, timeout):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -226,9 +252,10 @@ def _child_json(cmd, timeout):
 
 
 def other_configs():
-    """BASELINE.json configs 2 and 5 as child runs (each needs its own resident corpus: 3 GB and 61 GB)."""
+    """BASELINE.json configs 2 and 5 as child runs (each needs its own resident corpus: 3 GB and 61 GB).  Every child is this
+    script on that workload: headline = the f32-corpus sweep, the library's default mirror sweep beside it — both come back."""
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--batched", "0", "--callers", "0",
-            "--no-mirror-legs", "--no-live-pmc", "--warmup", "3", "--rebuilds", "1"]
+            "--legs", "i8", "--no-live-pmc", "--warmup", "3", "--rebuilds", "1"]
     runs = [("config2_1Mx768_cosine_top100", ["--rows", "1000000", "--steps", "200", "--rebuilds", "3"]),
             ("config5_10Mx1536_l2_top1000_mask1.0", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12"]),
             ("config5_10Mx1536_l2_top1000_mask0.5", ["--dim", "1536", "--metric", "euclidean", "--k", "1000", "--steps", "12",
@@ -238,13 +265,22 @@ def other_configs():
     out = {}
     for name, extra in runs:
         try:
-            d = _child_json(base + extra, 240)
-            out[name] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
-                         "ms_per_step": d["ms_per_step"], "sweep": d["dtype"], "roofline_frac": d["roofline"]["frac"],
-                         "achieved_GBps": d["roofline"]["achieved"], "bytes_per_corpus_element": d["roofline"]["bytes_per_corpus_element"],
-                         "frac_priced_as_survey_8d": d["roofline"]["frac_priced_as_survey_8d"], "kernel": d["roofline"]["kernel"],
-                         "candidates_rescored": d["roofline"].get("candidates_rescored"),
-                         "exact_topk_certified": d["parity"]["exact_topk_certified"] if d["parity"] else None}
+            d = _child_json(base + extra, 300)
+            r = d["roofline"]
+            o = {"workload": d["config"]["workload"],
+                 # the f32-corpus sweep, priced as SURVEY §8(d): kept rows x dim x 4 (+ the bitmap) per query
+                 "f32_qps": d["value"], "f32_ms_per_step": d["ms_per_step"], "f32_avg_kernel_ms": r["avg_kernel_ms"],
+                 "f32_frac": r["frac"], "f32_achieved_GBps": r["achieved"], "f32_kernel": r["kernel"],
+                 "f32_bytes_per_corpus_element": r["bytes_per_corpus_element"], "f32_step_frac": r["step_priced_as_survey_8d_frac"],
+                 "f32_exact": d["parity"]["exact_topk_certified"] if d["parity"] else None}
+            for tag in ("i8", "bf16"):  # the library's default sweep on this shape (the 8-bit mirror, else the bf16 one)
+                if f"{tag}_mirror_queries_per_s" in r:
+                    o.update({f"{tag}_qps": r[f"{tag}_mirror_queries_per_s"], f"{tag}_ms_per_step": r[f"{tag}_mirror_ms_per_step"],
+                              f"{tag}_avg_kernel_ms": r[f"{tag}_mirror_avg_kernel_ms"],
+                              f"{tag}_frac_on_mirror_bytes": r[f"{tag}_mirror_frac_on_mirror_bytes"],
+                              f"{tag}_exact": r[f"{tag}_mirror_exact_and_same_answer"],
+                              f"{tag}_candidates_rescored": d["mirror_legs"][tag]["candidates_rescored"]})
+            out[name] = o
         except Exception as e:  # a child failing must not take the headline line down with it
             out[name] = {"error": f"{type(e).__name__}: {e}"}
     return out
@@ -750,20 +786,30 @@ def main():
         return float(np.mean(out)) if out else None
 
     default_workload = (args.rows == 10_000_000 and args.dim == 768 and args.k == 100 and args.nq == 1 and
-                        args.metric == "cosine" and args.mask >= 1.0 and args.mirror == 1)
+                        args.metric == "cosine" and args.mask >= 1.0 and args.mirror == 0)
     extras = world == 1 and not args.always_gather
+    leg_modes = [] if (args.no_mirror_legs or args.mirror != 0 or args.k > 4096 or args.nq != 1) else \
+        [m for m, nm in ((1, "i8"), (2, "bf16")) if nm in args.legs.split(",")]
 
     # ---- the headline: median over index rebuilds --------------------------------------------------------------------
-    draws, batched_draws, infos = [], [], []
+    draws, batched_draws, infos = [], {}, []
     last_out = None
+    do_batched = extras and args.batched > 0 and args.nq == 1 and args.mask >= 1.0 and args.k <= 4096
     for b in range(max(1, args.rebuilds)):
         build_index()
         elapsed, last_out, info = timed_loop()
         draws.append(elapsed)
         infos.append(info)
-        if extras and args.batched > 0 and args.nq == 1 and args.mask >= 1.0 and args.mirror == 1:
-            batched_draws.append(measure_batched(args, state["idx"], dev, metric, total_rows, torch,
-                                                 certify=(b == max(1, args.rebuilds) - 1)))
+        if b == 0:
+            hbm0 = state["idx"].hbm_bytes()  # what the shard holds for the headline loop (before a leg below builds a mirror)
+        if do_batched:
+            # config 3 on the SAME resident index: first on the sweep the headline uses, then (headline = f32 corpus) on the
+            # library's default — the smallest mirror that serves the batch, built on first use
+            for mode in ([args.mirror] + ([1] if args.mirror == 0 and not args.no_mirror_legs else [])):
+                state["idx"].set_mirror(mode)
+                batched_draws.setdefault(mode, []).append(
+                    measure_batched(args, state["idx"], dev, metric, total_rows, torch, certify=(b == max(1, args.rebuilds) - 1)))
+            state["idx"].set_mirror(args.mirror)
     idx = state["idx"]
     med = int(np.argsort(draws)[len(draws) // 2])  # the median draw: `value`, `ms_per_step` AND the kernel time come from this one loop
     elapsed = float(draws[med])
@@ -771,8 +817,7 @@ def main():
     value = args.nq * args.steps / elapsed
     scan_ms, elem_bytes, cands = infos[med]["scan_ms"], infos[med]["elem_bytes"], [i["candidates"] for i in infos]
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
-    hbm = idx.hbm_bytes()  # before the legs below build another mirror
-    hbm_bytes_per_row = (hbm[0] + hbm[1] + hbm[2]) / max(idx.rows, 1)
+    hbm_bytes_per_row = (hbm0[0] + hbm0[1] + hbm0[2]) / max(local_rows, 1)
     scan_alone = isolated_kernel_ms() if world == 1 else None
     # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3 queries at dim >= 768, else >= 5), else 4 (VALU; 2 on
     # the 8-bit mirror) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
@@ -782,18 +827,23 @@ def main():
     kc = ld128 // 128 if (ld128 <= 4096 and (ld128 - args.dim) * 8 <= args.dim) else 0
     mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
     mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and kc and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
-            and args.k <= 4096 and args.mirror != 0)
+            and args.k <= 4096)
     passes = 1 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
     if args.k > 4096:
         passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
+    if world > 1:
+        leg_modes = [m for m in leg_modes if m == 1]  # N > 1: the library's default sweep only (a second mirror per rank buys nothing)
 
     def alg_bytes_for(eb):  # excluded rows are never read
         return (kept_rows * args.dim * eb + (local_rows // 8 if mask_dev is not None else 0)) * passes
 
+    def kernel_of(eb):
+        return ("nmn::exact_scan_kernel" if args.k > 4096 else "nmn::scan_mfma_kernel" if mfma else
+                "nmn::scan_i8_kernel" if eb == 1 else "nmn::scan_kernel")
+
     alg_bytes = alg_bytes_for(elem_bytes)
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
-    kernel_name = ("nmn::exact_scan_kernel" if args.k > 4096 else "nmn::scan_mfma_kernel" if mfma else
-                   "nmn::scan_i8_kernel" if elem_bytes == 1 else "nmn::scan_kernel")
+    kernel_name = kernel_of(elem_bytes)
 
     # ---- read ceiling of this device: the scan's access pattern with the arithmetic removed ----
     read_ceiling = idx.read_probe(3) if local_rows else None
@@ -833,72 +883,91 @@ def main():
                              if args.scaling == "weak" else
                              "strong scaling: rows_total is fixed, every GPU scans 1/N of it; value(N) ~ N x value(1) is 100 % efficiency")}
 
-    # ---- the other sweeps on the same index / queries / loop: the row-major f32 corpus (SURVEY §8(d)'s pricing), the bf16 mirror ----
-    legs = {}
-    if extras and elem_bytes < 4 and not args.no_mirror_legs and args.k <= 4096 and args.nq == 1 and args.mirror == 1:
-        for mode, name in ((0, "f32_corpus"), (2, "bf16_mirror")):
-            if mode == 2 and elem_bytes == 2:
-                continue  # the headline already is the bf16 mirror
-            idx.set_mirror(mode)
-            e2, out2, info2 = timed_loop()
-            idx.set_mirror(args.mirror)
-            scan2, eb2 = info2["scan_ms"], info2["elem_bytes"]
-            k_ms = float(np.mean(scan2)) if scan2 else float("nan")
-            b2 = alg_bytes_for(eb2)
-            ach = b2 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
-            cert2 = None
-            if not args.no_parity:
-                cert2 = certificate(idx, q_last, metric, out2[0].view(np.uint64), out2[1], out2[2], world, dev, mask_host)
-            same = bool(np.array_equal(out2[0], last_out[0]) and np.array_equal(out2[1].view(np.uint32), last_out[1].view(np.uint32)))
-            legs[name] = {"what": f"nmn_index_set_mirror({mode}): scan_kernel streams the " + SWEEP[eb2][1] +
-                                  "; same index, queries, streams, steps and warmup as the headline loop",
-                          "queries_per_s": args.nq * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
-                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": ach / HBM_PEAK_GBS if scan2 else None,
-                          "avg_kernel_ms": k_ms, "kernel_launches_timed": len(scan2),
-                          "algorithmic_bytes_per_launch": b2, "bytes_per_corpus_element": eb2,
-                          "pricing": SWEEP[eb2][2], "kernel": "nmn::scan_kernel",
-                          "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
-                          "candidates_rescored": info2["candidates"],
-                          "traffic": pmc_traffic(local_rows, args, eb2)[0], "traffic_source": pmc_traffic(local_rows, args, eb2)[1],
-                          "exact_topk_certified": cert2["exact_topk_certified"] if cert2 else None,
-                          "same_answer_as_headline_sweep": same}
+    def per_rank(v):
+        """[v of rank 0, ..., v of rank N-1] (an integer per rank) — which sweep every shard used must be visible in the line"""
+        if world == 1:
+            return [int(v)]
+        t = torch.tensor([int(v)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return [int(x.item()) for x in got]
 
-    batched = None
-    if batched_draws:
-        vals = [b["value"] for b in batched_draws]
-        sw = [b["sweep_ms"] for b in batched_draws]
-        eb3 = batched_draws[-1]["elem_bytes"]
+    headline_eb = per_rank(elem_bytes)
+
+    # ---- the same loop on the shard's MIRRORS: the library's default sweep (1 B per element where the shape allows it, every
+    # candidate re-scored from the f32 rows: the same answer, bit for bit) and the bf16 mirror.  Same index, queries, streams,
+    # steps, warmup; at N > 1 every rank runs them (timed_loop's collectives), and which ranks got their mirror is reported ----
+    legs = {}
+    mirror_eb = None
+    for mode in leg_modes:
+        idx.set_mirror(mode)
+        e2, out2, info2 = timed_loop()
+        idx.set_mirror(args.mirror)
+        scan2, eb2 = info2["scan_ms"], info2["elem_bytes"]
+        ebs = per_rank(eb2)
+        if mode == 1:
+            mirror_eb = ebs
+        name = SWEEP[eb2][0]
+        if name in legs or eb2 == elem_bytes:
+            continue  # (a shape the 8-bit sweeps do not serve: mode 1 already was the bf16 mirror; or no mirror fitted at all)
+        k_ms = float(np.mean(scan2)) if scan2 else float("nan")
+        b2 = alg_bytes_for(eb2)
+        ach = b2 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
+        cert2 = None
+        if not args.no_parity:
+            cert2 = certificate(idx, q_last, metric, out2[0].view(np.uint64), out2[1], out2[2], world, dev, mask_host)
+        same = bool(np.array_equal(out2[0], last_out[0]) and np.array_equal(out2[1].view(np.uint32), last_out[1].view(np.uint32)))
+        legs[name] = {"what": f"nmn_index_set_mirror({mode}): the sweep streams the " + SWEEP[eb2][1] +
+                              "; same index, queries, streams, steps and warmup as the headline loop",
+                      "queries_per_s": args.nq * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                      "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": ach / HBM_PEAK_GBS if scan2 else None,
+                      "avg_kernel_ms": k_ms, "kernel_launches_timed": len(scan2),
+                      "algorithmic_bytes_per_launch": b2, "bytes_per_corpus_element": eb2, "bytes_per_corpus_element_by_rank": ebs,
+                      "pricing": SWEEP[eb2][2], "kernel": kernel_of(eb2),
+                      "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
+                      "candidates_rescored": info2["candidates"],
+                      "traffic": pmc_traffic(local_rows, args, eb2)[0], "traffic_source": pmc_traffic(local_rows, args, eb2)[1],
+                      "exact_topk_certified": cert2["exact_topk_certified"] if cert2 else None,
+                      "same_answer_as_headline_sweep": same}
+    hbm1 = idx.hbm_bytes()
+
+    def batched_summary(draws_, mode):
+        vals = [b["value"] for b in draws_]
+        sw = [b["sweep_ms"] for b in draws_]
+        eb3 = draws_[-1]["elem_bytes"]
         nq = args.batched
         per_sweep = 128 if ((args.dim // 128 <= 6 or args.dim // 128 in (8, 10)) and nq > 64) else 32 if args.dim // 128 in (16, 24, 32) else 64
         sweep_med = float(np.median(sw))
         gbps = idx.rows * args.dim * eb3 / (sweep_med * 1e-3) / 1e9
-        batched = {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step (MFMA sweep)",
-                   "value": float(np.median(vals)), "unit": "queries/s", "rebuilds": vals,
-                   "ms_per_step": float(np.median([b["ms_per_step"] for b in batched_draws])), "steps": batched_draws[-1]["steps"],
-                   "sweep_ms_incl_sampling_pass": sweep_med, "sweep_ms_rebuilds": sw, "query_blocks_per_launch": (nq + per_sweep - 1) // per_sweep,
-                   # config 3 is reported against BOTH bounds.  HBM: the mirror's bytes once per 64-128 queries.
-                   # Matrix cores: 2*rows*dim*nq operations per query plane (the 8-bit sweep multiplies two int8 planes of
-                   # every query, h and l: twice the operations of the bf16 form) against the dense peak of that type.
-                   "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
-                                "kernel": "nmn::scan_mfma_kernel (sweep incl. its sampling pass)", "bytes_per_corpus_element": eb3,
-                                "frac_priced_as_survey_8d": gbps * 4 / eb3 / HBM_PEAK_GBS,
-                                "mfma": (lambda planes, peak, name: {
-                                    "bound": name, "planes_per_query": planes,
-                                    "achieved_tops": planes * 2.0 * idx.rows * args.dim * nq / (sweep_med * 1e-3) / 1e12,
-                                    "peak_tops": peak, "unit": "TOP/s" if eb3 == 1 else "TFLOP/s",
-                                    "frac": planes * 2.0 * idx.rows * args.dim * nq / (sweep_med * 1e-3) / 1e12 / peak})(
-                                    *((2, MFMA_I8_PEAK_TOPS, "mfma_i8") if eb3 == 1 else (1, MFMA_BF16_PEAK_TFLOPS, "mfma_bf16")))},
-                   "exact_topk_certified_3_of_batch": batched_draws[-1]["certified"]}
+        planes, peak, pname = (2, MFMA_I8_PEAK_TOPS, "mfma_i8") if eb3 == 1 else (1, MFMA_BF16_PEAK_TFLOPS, "mfma_bf16")
+        ops = planes * 2.0 * idx.rows * args.dim * nq / (sweep_med * 1e-3) / 1e12
+        return {"workload": f"{total_rows}x{args.dim} f32 {args.metric} TOP-{args.k}, nq={nq}/step", "mirror_mode": mode,
+                "sweep": SWEEP[eb3][1], "value": float(np.median(vals)), "unit": "queries/s", "rebuilds": vals,
+                "ms_per_step": float(np.median([b["ms_per_step"] for b in draws_])), "steps": draws_[-1]["steps"],
+                "sweep_ms_incl_sampling_pass": sweep_med, "sweep_ms_rebuilds": sw, "query_blocks_per_launch": (nq + per_sweep - 1) // per_sweep,
+                # SURVEY §8(d): config 3 is reported against BOTH bounds.  HBM: the streamed matrix's bytes once per 64-128 queries
+                # (f32 corpus: rows*dim*4 — §8(d)'s own figure).  Matrix cores: 2*rows*dim*nq operations per query plane (the 8-bit sweep
+                # multiplies two int8 planes of every query: twice the operations of the bf16 form) against the dense peak of the type.
+                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                             "kernel": "nmn::scan_mfma_kernel (sweep incl. its sampling pass)", "bytes_per_corpus_element": eb3,
+                             "frac_priced_as_survey_8d": gbps * 4 / eb3 / HBM_PEAK_GBS,
+                             "mfma": {"bound": pname, "planes_per_query": planes, "achieved_tops": ops, "peak_tops": peak,
+                                      "unit": "TOP/s" if eb3 == 1 else "TFLOP/s", "frac": ops / peak}},
+                "exact_topk_certified_3_of_batch": draws_[-1]["certified"]}
+
+    batched = {("f32_corpus" if mode == 0 else "mirror"): batched_summary(d_, mode) for mode, d_ in batched_draws.items()} or None
 
     # Single-query calls from many host threads at once (the reference's Arc<VectorEngine> under concurrent clients):
-    # the C ABI merges callers that arrive while the shard is busy into one query batch.  Native threads, 1 second.
+    # the C ABI merges callers that arrive while the shard is busy into one query batch.  Native threads, 1 second.  On the
+    # library's default (mirror) configuration — this leg is about the request coalescer, not about a sweep.
     callers = None
-    if extras and args.callers > 0 and args.nq == 1 and args.mask >= 1.0 and args.k <= 4096 and args.mirror == 1:
+    if extras and args.callers > 0 and args.nq == 1 and args.mask >= 1.0 and args.k <= 4096 and default_workload:
+        idx.set_mirror(1)
         cq = _synth(SEED_QUERY + 2, 0, args.callers, args.dim)
         r = idx.callers_probe(cq, args.k, metric, seconds=1.0)
         callers = {"workload": f"{args.callers} host threads, each nmn_index_search(nq=1, k={args.k}) in a loop, "
-                               f"{total_rows}x{args.dim} f32 {args.metric}",
+                               f"{total_rows}x{args.dim} f32 {args.metric}, library default (mirror) sweep",
                    "value": r["calls_per_s"], "unit": "queries/s", "threads": args.callers,
                    "sweeps_carrying_2_or_more_calls": r["merged_batches"], "calls_in_them": r["merged_calls"],
                    "answers_differing_from_a_lone_call": r["mismatches"]}
@@ -906,6 +975,7 @@ def main():
         r2 = idx.callers_probe(cq2, args.k, metric, seconds=1.0)
         callers["with_twice_the_threads"] = {"threads": 2 * args.callers, "value": r2["calls_per_s"], "unit": "queries/s",
                                              "answers_differing_from_a_lone_call": r2["mismatches"]}
+        idx.set_mirror(args.mirror)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -925,10 +995,10 @@ def main():
             if key in live:
                 traffic, traffic_src = live[key]["hbm_bytes_per_launch"], live[key]["source"]
                 traffic_rw = [live[key]["read_bytes_corrected"], live[key]["write_bytes"]]
-            for name, key2 in (("f32_corpus", "f32"), ("bf16_mirror", "bf16")):
-                if name in legs and key2 in live:
-                    legs[name]["traffic"], legs[name]["traffic_source"] = live[key2]["hbm_bytes_per_launch"], live[key2]["source"]
-                    legs[name]["traffic_read_write"] = [live[key2]["read_bytes_corrected"], live[key2]["write_bytes"]]
+            for name in legs:
+                if name in live:
+                    legs[name]["traffic"], legs[name]["traffic_source"] = live[name]["hbm_bytes_per_launch"], live[name]["source"]
+                    legs[name]["traffic_read_write"] = [live[name]["read_bytes_corrected"], live[name]["write_bytes"]]
     fill_s = state["fill_s"]
     idx.close()  # the children (and the one-process handle) need the HBM
     state["idx"] = None
@@ -958,6 +1028,9 @@ def main():
     if rank == 0 and multi is not None and "reading" in multi:
         multi["shard_scans_per_s"] = value * world
         multi["corpus_rows_scanned_per_s"] = value * total_rows
+        multi["headline_bytes_per_corpus_element_by_rank"] = headline_eb
+        multi["mirror_leg_bytes_per_corpus_element_by_rank"] = mirror_eb
+        multi["shards_with_mirror"] = None if mirror_eb is None else sum(1 for x in mirror_eb if x < 4)
     if rank == 0:
         sweep_key, sweep_txt, pricing = SWEEP[elem_bytes]
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -971,17 +1044,46 @@ def main():
                 "pricing": "bytes the kernel is asked to read: " + pricing,
                 "bytes_per_corpus_element": elem_bytes,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                # the same kernel time priced as SURVEY §8(d) writes it (N*d*4 per query): an EFFECTIVE rate, not a bandwidth
+                # the same kernel time priced as SURVEY §8(d) writes it (N*d*4 per query): for the f32 headline the same number
                 "achieved_priced_as_survey_8d": achieved * 4 / elem_bytes if scan_ms else None,
                 "frac_priced_as_survey_8d": achieved * 4 / elem_bytes / HBM_PEAK_GBS if scan_ms else None,
+                "step_priced_as_survey_8d_frac": (kept_rows * args.dim * 4 * passes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "candidates_rescored": int(np.median(cands)) if cands else None,
                 # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
                 "measured_read_ceiling": read_ceiling,
-                "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None,
-                # SURVEY §8(d)'s own measurement — the sweep of the row-major f32 corpus, rows*dim*4 bytes per query — on the same
-                # index, queries, streams and steps (nmn_index_set_mirror(0)); and the bf16 mirror, for the record
-                "f32_corpus": legs.get("f32_corpus"),
-                "bf16_mirror": legs.get("bf16_mirror")}
+                "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None}
+        # ---- everything else a checker needs, as FLAT scalars (the driver's record keeps scalars of `roofline` / `config` /
+        # `cpu_baseline` and drops nested objects): the mirror sweeps of the same loop; configs 3, 2, 5 on BOTH sweeps.
+        # "<x>_frac" prices the f32 sweeps as SURVEY §8(d) does (rows*dim*4 per query or batch); "<x>_frac_on_mirror_bytes" prices a
+        # mirror sweep on the bytes IT is asked to read (rows*dim*1 or *2) — an exact acceleration, never a §8(d) figure ----
+        for name, leg in legs.items():
+            pfx = f"{name}_mirror_"
+            roof[pfx + "queries_per_s"] = leg["queries_per_s"]
+            roof[pfx + "ms_per_step"] = leg["ms_per_step"]
+            roof[pfx + "avg_kernel_ms"] = leg["avg_kernel_ms"]
+            roof[pfx + "frac_on_mirror_bytes"] = leg["frac"]
+            roof[pfx + "traffic"] = leg["traffic"]
+            roof[pfx + "exact_and_same_answer"] = bool(leg["exact_topk_certified"] and leg["same_answer_as_headline_sweep"]) \
+                if leg["exact_topk_certified"] is not None else None
+        cname = "c3" if (args.rows == 10_000_000 and args.dim == 768 and args.batched == 64 and args.metric == "cosine" and args.k == 100) \
+            else f"batch{args.batched}"
+        for key, bsum in (batched or {}).items():
+            tag = SWEEP[bsum["roofline"]["bytes_per_corpus_element"]][0]
+            pfx = f"{cname}_{tag}_"
+            roof[pfx + "qps"] = bsum["value"]
+            roof[pfx + "ms_per_batch"] = bsum["ms_per_step"]
+            roof[pfx + "sweep_ms"] = bsum["sweep_ms_incl_sampling_pass"]
+            roof[pfx + ("frac" if tag == "f32" else "frac_on_mirror_bytes")] = bsum["roofline"]["frac"]
+            roof[pfx + "mfma_frac"] = bsum["roofline"]["mfma"]["frac"]
+            roof[pfx + "exact"] = bsum["exact_topk_certified_3_of_batch"]
+        for cfg_name, o in (others or {}).items():
+            pfx = cfg_name.split("_")[0].replace("config", "c") + ("_mask" + cfg_name.rsplit("mask", 1)[1] if "mask" in cfg_name else "") + "_"
+            if "error" in o:
+                roof[pfx + "error"] = o["error"][:100]
+                continue
+            for k_, v_ in o.items():
+                if isinstance(v_, (int, float, bool)) or v_ is None:
+                    roof[pfx + k_] = v_
         line = {
             "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -997,12 +1099,18 @@ def main():
                                    + (f", WHERE mask selectivity {args.mask}" if args.mask < 1.0 else ""),
                        "rows_total": total_rows, "rows_per_gpu": local_rows, "dim": args.dim, "k": args.k,
                        "nq": args.nq, "streams": n_streams,
-                       "approximate_sweep": sweep_txt + "; every candidate re-scored from the f32 corpus in the reference's order",
+                       "sweep": sweep_txt + ("; every candidate re-scored from the f32 corpus in the reference's order" if elem_bytes < 4 else
+                                             " (row-major, resident in HBM), approximate score per row; candidates re-scored in the reference's order"),
+                       "bytes_per_corpus_element": elem_bytes,
+                       "shards": world, "shards_on_f32_sweep_in_headline": sum(1 for x in headline_eb if x == 4),
+                       "shards_with_mirror": None if mirror_eb is None else sum(1 for x in mirror_eb if x < 4),
                        "hbm_bytes_per_row": hbm_bytes_per_row, "hbm_bytes_per_element": hbm_bytes_per_row / args.dim,
+                       "hbm_bytes_per_element_after_legs": (hbm1[0] + hbm1[1] + hbm1[2]) / max(local_rows, 1) / args.dim,
                        "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": parity,
+            "mirror_legs": legs or None,
             "multi_gpu": multi,
             "batched": batched,
             "concurrent_callers": callers,
