@@ -21,6 +21,7 @@ ARCH = "gfx950"
 SOURCES = {
     "nmn_scan.hip": [],
     "nmn_scan_mfma.hip": [],
+    "nmn_scan_mfma_f32.hip": [],
     "nmn_scan_i8.hip": [],
     "nmn_scan_i8b.hip": [],
     "nmn_select.hip": [],
@@ -36,7 +37,7 @@ SOURCES = {
     "nmn_persist.hip": [],
     "nmn_engine.cpp": ["-ffp-contract=off"],
 }
-HEADERS = ["nmn_internal.h", "nmn_index.h", "nmn_persist.h", "nmn_select_dev.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
+HEADERS = ["nmn_internal.h", "nmn_index.h", "nmn_scan_mfma_kernel.h", "nmn_persist.h", "nmn_select_dev.h", os.path.join("..", "..", "include", "neumann_gpu.h"),
            os.path.join("..", "..", "include", "neumann_engine.h")]
 
 

@@ -995,7 +995,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 idx->half_rows = n_rows;
             }
         }
-        const bool use_mfma = mfma_shape && (use_half || use_i8);  // the matrix-core sweep has no f32 variant
+        // The matrix-core sweep reads whichever matrix serves the pass: a mirror, or — none built, none allowed, none fitting — the f32
+        // rows themselves, rounded to bf16 in registers (nmn_scan_mfma_f32.hip: rows*dim*4 bytes once per 64-128 queries, where the VALU
+        // sweep of four queries would read them 16-32 times).  NMN_NO_F32_MFMA=1: the A/B (VALU sweeps of four, as until round 4).
+        static const bool no_f32_mfma = env_set("NMN_NO_F32_MFMA");
+        const bool use_mfma = mfma_shape && (use_half || use_i8 || !no_f32_mfma);
+        const bool mfma_f32 = use_mfma && !use_half && !use_i8;
         if (qmasks_host && !use_mfma) {
             // per-query bitmaps need the matrix-core sweep: this pass runs query by query instead
             for (uint32_t i = 0; i < nqc; i++) {
@@ -1014,8 +1019,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
-                             use_i8 ? (1 | 2 | 4 | (use_mfma ? 0 : 8)) : ((use_mfma ? 1 : 0) | (use_half ? 2 : 0)), stream,
-                             use_i8 ? idx->q8_err_bits : use_half ? idx->half_err_bits : nullptr, use_i8 ? w->qi8 : nullptr,
+                             use_i8 ? (1 | 2 | 4 | (use_mfma ? 0 : 8)) : ((use_mfma ? 1 : 0) | ((use_half || mfma_f32) ? 2 : 0)), stream,
+                             // (f32 rows rounded to bf16 on the fly: the rounding is the mirror's — its measured error norms where a
+                             //  complete bf16 mirror happens to exist, else the a-priori bound |e_r| <= 2^-8 |v_r| of qprep_kernel)
+                             use_i8 ? idx->q8_err_bits : (use_half || (mfma_f32 && idx->half && idx->half_rows >= n_rows)) ? idx->half_err_bits : nullptr,
+                             use_i8 ? w->qi8 : nullptr,
                              (use_i8 && !use_mfma) ? idx->q8_l2_hint : nullptr, f32_retry ? w->qinfo_f32 : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};

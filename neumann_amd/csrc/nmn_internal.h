@@ -156,6 +156,8 @@ hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, 
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
+// ... over the row-major f32 corpus itself (no mirror pointer set: launch_scan_mfma dispatches here), nmn_scan_mfma_f32.hip
+hipError_t launch_scan_mfma_f32(const ScanParams& p, hipStream_t s);
 // ... over the 8-bit mirror (p.corpus_i8 set: launch_scan_mfma dispatches on it): unmasked batches, rows of 256 .. 1536 elements
 bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric);
 // ... with the QUERIES in LDS and the rows loaded straight into registers as MFMA fragments (nmn_scan_i8b.hip): up to 64 queries

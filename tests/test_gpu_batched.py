@@ -51,6 +51,59 @@ def test_mfma_batch_matches_oracle(metric, n, d, nq, k):
         check_batch(idx, A, Q, k, metric, mask=oc.mask_from_bool(rng.random(n) < 0.3))
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 768, 64, 100), (20011, 768, 5, 10), (9000, 128, 16, 20), (30000, 256, 70, 50),
+                                      (4000, 384, 33, 7), (7000, 512, 64, 100), (100, 640, 8, 200),
+                                      (20000, 768, 128, 50), (9000, 256, 100, 20), (5000, 640, 65, 10), (7000, 384, 129, 30),
+                                      (6000, 1024, 100, 20), (20000, 1024, 64, 50), (12000, 1536, 33, 100), (9000, 1280, 7, 10),
+                                      (6000, 2048, 40, 10), (5000, 3072, 33, 20), (2500, 4096, 40, 10),
+                                      (6000, 1000, 40, 10), (3000, 1408, 70, 5)])
+def test_mfma_batch_over_the_f32_rows_matches_oracle(n, d, nq, k):
+    """nmn_index_set_mirror(0): batches take the matrix-core sweep over the ROW-MAJOR F32 CORPUS (nmn_scan_mfma_f32.hip: rows
+    rounded to bf16 in registers, a-priori rounding bound in the margin) — config 3 as SURVEY §8(d) prices it, and what a shard
+    whose mirror did not fit runs.  Every query's rows and scores are the oracle's, all metrics, with and without a bitmap."""
+    from neumann_amd import GpuFlatIndex
+    A = oc.synth(1000 + n + d, 0, n, d)
+    Q = oc.synth(2000 + nq, 0, nq, d)
+    Q[nq // 2] = A[n // 3]                       # one query equal to a stored row
+    with GpuFlatIndex(d, n, single_launch=False) as idx:
+        idx.set_mirror(0)                        # (before the rows arrive: no mirror is ever built)
+        idx.fill_synthetic(1000 + n + d, n)
+        for metric in (0, 1, 2):
+            st = check_batch(idx, A, Q, k, metric)
+            assert st.fallback_queries == 0
+            assert st.bytes_scanned == st.rows_scanned * d * 4, "the f32 rows were not what the sweep read"
+        rng = np.random.default_rng(n)
+        check_batch(idx, A, Q, k, 0, mask=oc.mask_from_bool(rng.random(n) < 0.3))
+        assert idx.hbm_bytes()[1] == 0, "a mirror was built under set_mirror(0)"
+
+
+def test_f32_rows_matrix_core_sweep_on_a_large_shard_with_planted_neighbours():
+    """The f32-rows matrix-core sweep with its sampling pass and the two-launch bound refinement (2.2M x 128, 96 queries), near
+    copies of some queries planted across the shard, Euclidean near-zero distances included; and the same batch answered by the
+    VALU sweeps of four (NMN_NO_F32_MFMA is process-wide, so the comparison is with the oracle)."""
+    from neumann_amd import GpuFlatIndex
+    n, d, nq, k = 2_200_000, 128, 96, 25
+    A = oc.synth(777, 0, n, d, nthreads=8)
+    Q = oc.synth(778, 0, nq, d)
+    Q[5] = A[2_000_001]
+    Q[6] = A[17]
+    with GpuFlatIndex(d, n) as idx:
+        idx.set_mirror(0)
+        idx.fill_synthetic(777, n)
+        for metric in (0, 1, 2):
+            rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
+            assert st.fallback_queries == 0 and st.bytes_scanned == st.rows_scanned * d * 4
+            for qi in list(range(0, nq, 9)) + [5, 6]:
+                er, es = oc.search(A, Q[qi], k, metric, nthreads=8, partial=True, native=True)
+                assert counts[qi] == k and np.array_equal(rows[qi], er) and np.all(scores[qi] == es), (metric, qi)
+        keep = np.random.default_rng(3).random(n) < 0.3
+        mask = oc.mask_from_bool(keep)
+        rows, scores, counts = idx.search(Q, k, 0, mask=mask)
+        for qi in (0, 5, 6, 50, 95):
+            er, es = oc.search(A, Q[qi], k, 0, mask=mask, nthreads=8, partial=True, native=True)
+            assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es), qi
+
+
 @pytest.mark.parametrize("n,d,nq,k", [(9000, 300, 64, 20), (7000, 200, 33, 10), (12000, 100, 128, 10), (5000, 96, 40, 5),
                                       (3000, 896, 40, 10), (2000, 2560, 33, 5)])
 def test_wide_rows_flag_pads_to_the_matrix_core_stride(n, d, nq, k):

@@ -90,9 +90,9 @@ def corpus_10Mx768():
 
 
 def test_config3_10Mx768_cosine_top100_batch64(corpus_10Mx768):
-    """BASELINE config 3: 64 queries per call — one matrix-core sweep of the 8-bit mirror (and, for the record, of the bf16
-    mirror it replaced: nmn_index_set_mirror(2)), every candidate re-scored from the f32 corpus.  All 64 lists of both sweeps
-    are compared with the oracle."""
+    """BASELINE config 3: 64 queries per call — one matrix-core sweep of the 8-bit mirror, of the bf16 mirror it replaced
+    (nmn_index_set_mirror(2)) and of the f32 rows themselves (nmn_index_set_mirror(0)), every candidate re-scored from the f32
+    corpus.  All 64 lists of all three sweeps are compared with the oracle."""
     from neumann_amd import GpuFlatIndex
     A = corpus_10Mx768
     n, d = A.shape
@@ -109,6 +109,12 @@ def test_config3_10Mx768_cosine_top100_batch64(corpus_10Mx768):
         for qi in range(nq):
             er, es = _oracle(A, Q[qi], k, 0, literal=qi in (0, 63))
             _check_query(rows, scores, counts, qi, er, es)
+        # config 3 as SURVEY §8(d) prices it: the 64-query batch over the ROW-MAJOR F32 CORPUS (nmn_index_set_mirror(0): the
+        # matrix-core sweep reads the f32 rows, rounds them to bf16 in registers) — all 64 lists are the mirror sweeps' = the oracle's
+        idx.set_mirror(0)
+        rows0, scores0, counts0, st0 = idx.search(Q, k, 0, with_stats=True)
+        assert st0.bytes_scanned == n * d * 4 and st0.fallback_queries == 0, "nmn_index_set_mirror(0): the f32 corpus, one sweep per batch"
+        assert np.array_equal(rows0, rows) and np.array_equal(scores0.view(np.uint32), scores.view(np.uint32)) and np.array_equal(counts0, counts)
         # the headline configuration on the same corpus: one query per call — over the 8-bit mirror (the default), the bf16 mirror
         # and the f32 corpus
         for mode, nbytes in ((1, 1), (2, 2), (0, 4)):
