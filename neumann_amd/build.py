@@ -23,7 +23,6 @@ SOURCES = {
     "nmn_scan_mfma.hip": [],
     "nmn_scan_mfma_f32.hip": [],
     "nmn_scan_i8.hip": [],
-    "nmn_scan_i8b.hip": [],
     "nmn_select.hip": [],
     "nmn_exact.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "nmn_synth.hip": ["-ffp-contract=off"],

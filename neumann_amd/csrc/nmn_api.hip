@@ -1083,16 +1083,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 return (uint32_t)std::min<long>(std::max<long>(v, 64), (long)kMaxScanWaves);
             }();
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
-            // 8-bit batches of <= 64 queries on rows of 768 elements: the queries-in-LDS sweep (nmn_scan_i8b.hip).  Its scan waves are
-            // WAVES (4 per workgroup, each with its own tile range and wmax entry): tiles_per_wave, bx_base / bx_count count waves.
-            const bool use_i8b = use_mfma && use_i8 && scan_i8b_supported(idx->ld, idx->dim, (int)metric, nqc);
-            static const uint32_t i8b_waves = [] {  // tuning knob: NMN_I8B_WAVES in [256, kMaxScanWaves], a multiple of 8
-                const char* e = getenv("NMN_I8B_WAVES");
-                long v = e ? atol(e) : (long)kMaxScanWaves;
-                return (uint32_t)std::min<long>(std::max<long>(v, 256), (long)kMaxScanWaves) & ~7u;
-            }();
-            if (use_i8b) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + i8b_waves - 1) / i8b_waves);
-            auto launch_batch_sweep = [&](const ScanParams& x) -> hipError_t { return use_i8b ? launch_scan_i8b(x, stream) : launch_scan_mfma(x, stream); };
+            auto launch_batch_sweep = [&](const ScanParams& x) -> hipError_t { return launch_scan_mfma(x, stream); };
             sp.metric = (int)metric;
             sp.strided = (!use_mfma && mask_dev) ? 1u : 0u;  // masked VALU sweeps: a wave takes every W-th tile (runs of selected rows spread over all waves)
             static const bool no_walk = getenv("NMN_NO_WALK") != nullptr;  // (A/B switch of the survivor walk)
@@ -1120,12 +1111,23 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 ss.tile_step = sample_step;
                 ss.n_tiles = n_sample;
                 ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
-                if (use_i8b) ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 1023) / 1024);  // (one workgroup per CU, four waves each)
                 ss.tmax = w->tsample;
                 ss.tmax_stride = w->n_sample_cap;
+                // the sampled tiles are FINISHED by this pass (maxima into the sweep's tmax, scores written: 1/32 of the score matrix,
+                // 80 MB at 10M rows x 64 queries) and the main sweep does not stream them again: 3 % fewer bytes per batch
+                // (NMN_SAMPLE_REREAD=1: the A/B — tile maxima only, every tile read again by the main sweep, as until round 4)
+                // Not on the 8-bit mirror: there the pass reads 0.24 GB and the stores of its 80 MB cost as much as reading them again saves
+                // (10M x 768, 64 queries: f32 rows 5.28 -> 5.12 ms, bf16 mirror 2.77 -> 2.65, 8-bit 1.538 -> 1.548; profiles/r05d_*).
+                static const bool reread_env = getenv("NMN_SAMPLE_REREAD") != nullptr;
+                const bool reread = reread_env || use_i8;
+                if (!reread) {
+                    ss.tmax_main = w->tmax;
+                    ss.tmax_main_stride = w->tmax_stride;
+                }
                 HIP_TRY(launch_batch_sweep(ss));
                 HIP_TRY(launch_sample_bound(w->tsample, w->n_sample_cap, n_sample, w->qinfo, nqc, k, w->skip_key, stream));
                 sp.skip_key = w->skip_key;
+                sp.skip_sampled = reread ? 0u : sample_step;
                 return NMN_OK;
             };
             if (sample && !sample_behind) {
@@ -1163,8 +1165,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return (uint32_t)n;
             }();
-            const uint32_t first_blocks = use_i8b ? (mfma_blocks >= 12u * n_cu ? 4u * n_cu : 0u)  // (scan waves: four per workgroup — the first round)
-                                                  : mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
+            const uint32_t first_blocks = mfma_blocks >= 3u * n_cu ? (n_cu & ~7u) : 0u;  // (a multiple of 8: the folded grid's tile ranges)
             static const uint32_t refine_min_nq = [] {  // (A/B knob: NMN_REFINE_MIN_NQ)
                 const char* e = getenv("NMN_REFINE_MIN_NQ");
                 return e ? (uint32_t)atol(e) : 65u;
@@ -1172,7 +1173,9 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // (the 8-bit sweep's wider margin makes ~11 % of the (tile, query) pairs write their scores under the sampled bound —
             //  0.18 of its 1.55 ms at 64 queries — so it takes the refinement from 3 queries on: 10M x 768 1.53 -> 1.50 ms,
             //  5M x 1536 Euclidean 1.55 -> 1.39 ms)
-            const uint32_t refine_from = (use_i8 && !getenv("NMN_REFINE_MIN_NQ")) ? 3u : refine_min_nq;
+            // (the f32-rows sweep rounds rows AND margin a priori — 2.5x the bf16 mirror's measured margin — and takes it from 3 on as well:
+            //  10M x 768, 64 queries 5.24-5.29 -> 4.96 ms, profiles/r05c_f32_mfma_knobs_ab.txt)
+            const uint32_t refine_from = ((use_i8 || mfma_f32) && !getenv("NMN_REFINE_MIN_NQ")) ? 3u : refine_min_nq;
             if (use_mfma && sample && nqc >= refine_from && !no_refine && first_blocks >= 64 && (uint64_t)first_blocks * sp.tiles_per_wave >= 4ull * k) {
                 ScanParams sa = sp;
                 sa.bx_base = 0;

@@ -112,6 +112,9 @@ struct ScanParams {
     uint32_t tile_step;      // 1: every tile; S: sample pass over tiles 0,S,2S,.. (tile maxima only -> tmax[q][i])
     uint32_t fold_ny;        // > 1: 1-D grid folded over this many query blocks (set by the launcher)
     const uint32_t* skip_key;  // nullable [nq]: scores of a tile are written only if its maximum key >= skip_key[q]
+    uint32_t* tmax_main;     // sampling pass (tile_step = S > 1), nullable: also FINISH the sampled tiles for the main sweep — their
+    uint64_t tmax_main_stride;  // maxima into tmax_main[q][tile] and their scores written — so that the main sweep need not read them again
+    uint32_t skip_sampled;   // main sweep: S > 0 = tiles that are multiples of S were finished by the sampling pass: not streamed
     uint32_t ld;             // floats per row, multiple of 8
     uint32_t n_tiles;
     uint32_t nq;
@@ -160,10 +163,6 @@ hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
 hipError_t launch_scan_mfma_f32(const ScanParams& p, hipStream_t s);
 // ... over the 8-bit mirror (p.corpus_i8 set: launch_scan_mfma dispatches on it): unmasked batches, rows of 256 .. 1536 elements
 bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric);
-// ... with the QUERIES in LDS and the rows loaded straight into registers as MFMA fragments (nmn_scan_i8b.hip): up to 64 queries
-// per pass over rows of 768 elements; same outputs, but a scan wave is a WAVE there (tiles_per_wave, bx_base / bx_count in waves)
-bool scan_i8b_supported(uint32_t ld, uint32_t dim, int metric, uint32_t nq);
-hipError_t launch_scan_i8b(const ScanParams& p, hipStream_t s);
 
 struct SelectParams {
     const uint32_t* scores;  // score_at(row, q, nql)

@@ -10,6 +10,11 @@ namespace nmn {
 // stages of 32 KiB ([64 rows][128 f32]: KS = 2), KC = ld / 128 stages per row
 template <int KC, int METRIC, int QG>
 static hipError_t launch_kc_f32(const ScanParams& p, hipStream_t s) {
+#ifdef NMN_MFMA_F32_KS1  // measurement build: 16-KiB stages ([64 rows][64 f32]), a ring of eight (rows of <= 1536 elements with 64 queries)
+    if constexpr (QG == 4 && KC <= 12)
+        return (p.mask || p.qmasks) ? launch_one_mfma<2 * KC, 1, QG, METRIC, true, 4, false, true>(p, s)
+                                    : launch_one_mfma<2 * KC, 1, QG, METRIC, false, 4, false, true>(p, s);
+#endif
     return (p.mask || p.qmasks) ? launch_one_mfma<KC, 2, QG, METRIC, true, 4, false, true>(p, s)
                                 : launch_one_mfma<KC, 2, QG, METRIC, false, 4, false, true>(p, s);
 }

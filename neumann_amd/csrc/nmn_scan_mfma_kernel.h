@@ -295,7 +295,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     const uint32_t t0 = bx * p.tiles_per_wave;  // tiles per WORKGROUP on this path
     if (t0 >= p.n_tiles) return;
     const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
-    const uint32_t n_stage = (t1 - t0) * KC;
+    // Main sweep behind a sampling pass (p.skip_sampled = S): the tiles that are multiples of S were finished by that pass — tile
+    // maxima in tmax, scores written — and are NOT streamed again (3 % of the matrix at S = 32).  The workgroup walks the other
+    // tiles of its range: the j-th tile of the shard that is not a multiple of S is j + j / (S - 1) + 1; below tile t there are
+    // t - ceil(t / S) of them.  S = 0: every tile (j is the tile).
+    const uint32_t S = sampling ? 0u : p.skip_sampled;
+    auto walked_below = [&](uint32_t t) -> uint32_t { return S ? t - (t + S - 1u) / S : t; };
+    auto tile_of = [&](uint32_t j) -> uint32_t { return S ? j + j / (S - 1u) + 1u : j; };
+    const uint32_t j0 = walked_below(t0), j1 = walked_below(t1);
+    const uint32_t n_stage = (j1 - j0) * KC;
 
     uint32_t loff[kPieces];  // per-lane source byte offsets of the DMA pieces this wave moves per stage
 #pragma unroll
@@ -320,11 +328,11 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // (the magnitudes of stage kRing - 1's tile too: its pieces go out during the first iteration)
             if (kNeedNorms && wave == 0 && s0 % KC == 0)
             {
-                norms_dma(norm_src, (uint64_t)(t0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kNormSlots) * 64u, lane);
-                if constexpr (I8 && kL2) norms_dma(p.i8_vv, (uint64_t)(t0 + s0 / KC) * tstep, nrm2 + ((s0 / KC) % kNormSlots) * 64u, lane);
+                norms_dma(norm_src, (uint64_t)tile_of(j0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kNormSlots) * 64u, lane);
+                if constexpr (I8 && kL2) norms_dma(p.i8_vv, (uint64_t)tile_of(j0 + s0 / KC) * tstep, nrm2 + ((s0 / KC) % kNormSlots) * 64u, lane);
             }
             if (s0 < kRing - 1)
-                stage_dma<AUX, kPieces>(stage_src(t0 + s0 / KC, s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
+                stage_dma<AUX, kPieces>(stage_src(tile_of(j0 + s0 / KC), s0 % KC), loff, lds + (s0 % kRing) * (kStageBytes / 4), wave);
         } else if (s0 < kRing - 1) {
             // A range shorter than the ring (a small shard: one tile per workgroup is KC stages, the ring of 16-KiB stages holds
             // eight): the loop's counted wait — "at most kRing - 2 younger stages in flight" — only says that stage sidx has landed
@@ -353,7 +361,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     // interleave more than the overlap returned.)
     // tile maxima of the current group of four tiles (see publish): [wave][query group of the wave][16 queries][4 tiles] in LDS
     uint32_t* const tk_pend = reinterpret_cast<uint32_t*>(nrm + kNormSlots * 64 + (kHalfK ? QG * 64 * 16 : 0));
-    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile) __attribute__((always_inline)) {
+    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast) __attribute__((always_inline)) {
         constexpr int H = decltype(half_c)::value;
         const uint32_t qn = qn_h[H];
         const bool q_ok = q_ok_h[H];
@@ -365,8 +373,8 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
         const uint64_t rtile = (uint64_t)ftile * tstep;  // real tile index (sampling pass: every tstep-th)
         const uint64_t r0 = rtile * kTileRows;
-        const float* nslot = nrm + ((ftile - t0) % kNormSlots) * 64u;
-        const float* nslot2 = nrm2 + ((ftile - t0) % kNormSlots) * 64u;  // (I8, Euclidean)
+        const float* nslot = nrm + (frel % kNormSlots) * 64u;   // (frel: the tile's position in this workgroup's walk)
+        const float* nslot2 = nrm2 + (frel % kNormSlots) * 64u;  // (I8, Euclidean)
         (void)nslot2;
         uint64_t mword = ~0ull;
         if constexpr (MASKED) {
@@ -404,8 +412,9 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 const uint32_t slot = ftile & 3u;  // (wave-uniform)
                 uint32_t* mine = tk_pend + (((uint32_t)wave * (uint32_t)kHalves + (uint32_t)H) * 16u + n) * 4u;
                 if (g == 0) mine[slot] = tkey;
-                if (slot == 3u || ftile + 1u == t1) {
-                    const uint32_t g0 = ftile & ~3u, first = max(g0, t0);
+                if (slot == 3u || flast) {
+                    // (a group whose first tile was the sampling pass's — multiples of S are multiples of 4 — keeps that entry)
+                    const uint32_t g0 = ftile & ~3u, first = max((S && g0 % S == 0u) ? g0 + 1u : g0, t0);
                     if (q_ok && g == 0) {
                         uint32_t* dst = p.tmax + (uint64_t)qn * p.tmax_stride + g0;
                         const u4 v = *reinterpret_cast<const u4*>(mine);
@@ -422,10 +431,14 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             }
 #endif
             wmax_h[H] = max(wmax_h[H], tkey);
+            // the sampling pass finishing its tiles for the main sweep (p.tmax_main set): the key into the sweep's tmax as well, and the
+            // tile's scores written whatever they are (no bound exists yet; 1/S of the tiles)
+            const bool finish_sampled = sampling && p.tmax_main != nullptr;
+            if (finish_sampled && q_ok && g == 0) p.tmax_main[(uint64_t)qn * p.tmax_main_stride + rtile] = tkey;
 #ifdef NMN_MFMA_NO_SCORE_WRITES
             return false;
 #else
-            return q_ok && !sampling && tkey != kKeyMasked && tkey >= skip;
+            return q_ok && (!sampling || finish_sampled) && tkey != kKeyMasked && tkey >= skip;
 #endif
         };
         // The two cases are two complete code paths (key, publish, stores): merged behind one `publish` the compiler carried
@@ -538,7 +551,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             }
         }
     };
-    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile) __attribute__((always_inline)) {
+    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast) __attribute__((always_inline)) {
 #ifdef NMN_MFMA_NO_EPILOGUE
         {  // measurement only (-DNMN_MFMA_NO_EPILOGUE build): the sweep without its epilogue (answers are wrong)
             float sink_v = 0.f;
@@ -550,12 +563,13 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             return;
         }
 #endif
-        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile);
-        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile);
+        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile, frel, flast);
+        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile, frel, flast);
     };
 
     uint32_t sidx = 0;  // running stage index of this workgroup
-    for (uint32_t tile = t0; tile < t1; tile++) {
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t tile = tile_of(j);
         f4 acc[4][kAccGroups];  // [row block][query group of this wave]
         v4i ach[I8 ? 4 : 1][kAccGroups], acl[I8 ? 4 : 1][kAccGroups];  // (I8) int32 sums of the h plane / the l plane
 #pragma unroll
@@ -588,7 +602,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // read / MFMA / DMA interleave laid out below.
             const uint32_t ns = sidx + (kRing - 1);
             const bool issue = ns < n_stage;
-            const uint32_t nt = t0 + ns / KC, nkc = ns % KC;
+            const uint32_t nt = tile_of(j0 + ns / KC), nkc = ns % KC;
             const char* const nsrc = issue ? stage_src(nt, nkc) : mirror;
             const uint32_t lmask = issue ? 0xFFFFFFFFu : 0u;  // (scalar: the per-lane offsets are ANDed away in the tail)
             float* const nbuf = lds + (ns % kRing) * (kStageBytes / 4);
@@ -670,9 +684,9 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // (issued for the tile of stage ns + 1, i.e. BEFORE that stage's pieces go out in the next iteration: in-order vmcnt then
             // lands it with them, and every wave passes a barrier behind wave 0's wait before the tile's epilogue reads it)
             if (kNeedNorms && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) {
-                const uint32_t nt1 = t0 + (ns + 1u) / KC;
-                norms_dma(norm_src, (uint64_t)nt1 * tstep, nrm + ((nt1 - t0) % kNormSlots) * 64u, lane);
-                if constexpr (I8 && kL2) norms_dma(p.i8_vv, (uint64_t)nt1 * tstep, nrm2 + ((nt1 - t0) % kNormSlots) * 64u, lane);
+                const uint32_t nrel = (ns + 1u) / KC, nt1 = tile_of(j0 + nrel);
+                norms_dma(norm_src, (uint64_t)nt1 * tstep, nrm + (nrel % kNormSlots) * 64u, lane);
+                if constexpr (I8 && kL2) norms_dma(p.i8_vv, (uint64_t)nt1 * tstep, nrm2 + (nrel % kNormSlots) * 64u, lane);
             }
         }
         if constexpr (I8) {
@@ -703,16 +717,22 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                     acc[rb][0] += *reinterpret_cast<const f4*>(xch + ((grp * 64u + lane) * 4u + (uint32_t)rb) * 4u);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            finish_tile(acc, tile);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
+            finish_tile(acc, tile, j - j0, j + 1u == j1);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
         } else {
-            finish_tile(acc, tile);
+            finish_tile(acc, tile, j - j0, j + 1u == j1);
         }
     }
     wait_vm_imm<0>();  // the dummy pieces of the tail must have landed before this workgroup's LDS is handed to the next one
-    if (sampling) return;  // the sampling pass leaves only tmax
+    if (sampling) return;  // the sampling pass leaves tile maxima (and, finishing its tiles for the main sweep, their scores)
 #pragma unroll
     for (int h = 0; h < kHalves; h++)
-        if (q_ok_h[h] && g == 0) p.wmax[(size_t)qn_h[h] * p.wmax_stride + bx] = wmax_h[h];
+        if (q_ok_h[h] && g == 0) {
+            // the workgroup's maximum covers every tile of its range: those the sampling pass finished come from tmax
+            if (S)
+                for (uint32_t ts = ((t0 + S - 1u) / S) * S; ts < t1; ts += S)
+                    wmax_h[h] = max(wmax_h[h], p.tmax[(uint64_t)qn_h[h] * p.tmax_stride + ts]);
+            p.wmax[(size_t)qn_h[h] * p.wmax_stride + bx] = wmax_h[h];
+        }
 }
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES, bool I8 = false, bool F32 = false>

@@ -237,58 +237,3 @@ def test_more_than_64_queries_on_a_large_shard_two_launch_sweep():
         for qi in (0, 5, 6, 50, 95):
             er, es = oc.search(A, Q[qi], k, 0, mask=mask, nthreads=8, partial=True, native=True)
             assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es), qi
-
-
-_I8B_CHILD = r'''
-import sys
-import numpy as np
-from oracle import oracle_c as oc
-from neumann_amd import GpuFlatIndex
-U64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
-def check(idx, A, Q, k, metric, mask=None, qs=None, native=False):
-    rows, scores, counts, st = idx.search(Q, k, metric, mask=mask, with_stats=True)
-    assert st.bytes_scanned == st.rows_scanned * A.shape[1], "the 8-bit mirror was not swept"
-    for qi in (qs if qs is not None else range(Q.shape[0])):
-        er, es = oc.search(A, Q[qi], k, metric, mask=mask, nthreads=8, partial=native, native=native)
-        c = er.size
-        assert counts[qi] == c and np.array_equal(rows[qi, :c], er) and np.all(scores[qi, :c] == es), (metric, qi)
-        assert np.all(rows[qi, c:] == U64_MAX)
-d = 768
-for n, nq, k in ((20000, 64, 100), (20011, 33, 10), (77, 5, 100), (64 * 4097 + 5, 64, 40)):
-    A = oc.synth(500 + n, 0, n, d, nthreads=8)
-    Q = oc.synth(600 + nq, 0, nq, d)
-    Q[nq // 2] = A[n // 3]
-    with GpuFlatIndex(d, n) as idx:
-        idx.fill_synthetic(500 + n, n)
-        for metric in (0, 1, 2):
-            check(idx, A, Q, k, metric)
-            check(idx, A, Q, k, metric, mask=oc.mask_from_bool(np.random.default_rng(n).random(n) < 0.3))
-# a shard with a sampling pass (>= 32768 sampled... tiles): the bound gates the score writes of both halves of a tile
-n, nq, k = 2_200_000, 64, 25
-A = oc.synth(4242, 0, n, d, nthreads=8)
-Q = oc.synth(4243, 0, nq, d)
-Q[3] = A[1_234_567]
-with GpuFlatIndex(d, n) as idx:
-    idx.fill_synthetic(4242, n)
-    for metric in (0, 1, 2):
-        check(idx, A, Q, k, metric, qs=(0, 3, 17, 40, 63), native=True)
-    check(idx, A, Q, k, 0, mask=oc.mask_from_bool(np.random.default_rng(1).random(n) < 0.2), qs=(0, 3, 63), native=True)
-print("I8B-OK")
-'''
-
-
-def test_queries_in_lds_sweep_matches_the_oracle():
-    """NMN_I8B=1: batches of <= 64 queries over rows of 768 elements take scan_i8b_kernel (nmn_scan_i8b.hip: the queries in LDS,
-    the rows loaded straight into registers as MFMA fragments, the epilogue of a half-tile issued between the MFMAs of the
-    next one) instead of the LDS-ring kernel.  Opt-in — it measures slower — but it must stay exact: all three metrics, with
-    and without a bitmap, a ragged last tile, a shard smaller than one tile, a shard with a sampling pass."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ)
-    env["NMN_I8B"] = "1"
-    env["NMN_I8_MIN_ROWS"] = "1"
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    r = subprocess.run([sys.executable, "-c", _I8B_CHILD], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "I8B-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

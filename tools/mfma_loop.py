@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--metric", type=int, default=0)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--mirror", type=int, default=1, help="nmn_index_set_mirror before the rows arrive: 1 default, 2 bf16, 0 the f32 rows")
     ap.add_argument("--realloc", type=int, default=1, help="build the index this many times in the same process (placement A/B)")
     ap.add_argument("shapes", nargs="*", default=["10000000:768"])
     a = ap.parse_args()
@@ -29,6 +30,7 @@ def main():
         rows, dim = (int(x) for x in sh.split(":"))
         for _round in range(a.realloc):
           with GpuFlatIndex(dim, rows) as idx:
+              idx.set_mirror(a.mirror)
               idx.fill_synthetic(3, rows)
               idx.set_timing(True)
               Q = synth_rows(4, 0, a.nq * 4, dim)
@@ -40,9 +42,10 @@ def main():
                   _, _, _, st = idx.search(Q[j * a.nq:(j + 1) * a.nq], a.k, a.metric, with_stats=True)
                   t.append(st.scan_ms)
               t = np.sort(np.array(t))
-              gb = rows * dim * 2 / 1e6  # GB per ms -> TB/s below
+              eb = st.bytes_scanned // max(1, st.rows_scanned * dim)  # bytes per element the sweep read (1 / 2 / 4)
+              gb = rows * dim * eb / 1e6  # GB per ms -> TB/s below
               print(f"{a.tag or os.environ.get('NEUMANN_GPU_LIB', 'default').split('_')[-1]:>10} wgs={os.environ.get('NMN_MFMA_WGS', '-'):>5} "
-                    f"{rows}x{dim} nq={a.nq}: scan_ms min {t[0]:.3f} p25 {t[len(t) // 4]:.3f} med {np.median(t):.3f} p90 {t[int(len(t) * 0.9)]:.3f}"
+                    f"{rows}x{dim} nq={a.nq} {eb} B/elem: scan_ms min {t[0]:.3f} p25 {t[len(t) // 4]:.3f} med {np.median(t):.3f} p90 {t[int(len(t) * 0.9)]:.3f}"
                     f"  | med -> {gb / np.median(t):.0f} GB/s = {gb / np.median(t) / 8000:.3f} of 8 TB/s (sampling pass included)")
 
 
