@@ -231,9 +231,52 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                                                    const uint32_t* __restrict__ half_err_bits, uint32_t* __restrict__ qi8,
                                                    const float* __restrict__ l2_hint, QInfo* __restrict__ qinfo_plain) {
     const uint32_t q = blockIdx.x;
-    const float* src = queries + (size_t)q * dim;
-    float* dst = qpad + (size_t)q * ld;
-    for (uint32_t i = threadIdx.x; i < ld; i += 64) dst[i] = i < dim ? src[i] : 0.0f;
+    // The query comes into LDS in ONE round trip (every load of the block in flight together) and every later phase — the padded
+    // copy, |q| in reference order, the bf16 / int8 roundings — reads it there.  (Until round 5 each phase looped over global
+    // memory, a dependent load per 64 elements: 10 us at 768 elements and 25 us at 1536 in front of EVERY search, profiles/r05g_*.)
+    extern __shared__ __attribute__((aligned(16))) float qprep_lds[];  // [ld]
+    float* const src = qprep_lds;
+    {
+        const float* gsrc = queries + (size_t)q * dim;
+        if ((dim & 3u) == 0u && (reinterpret_cast<uintptr_t>(gsrc) & 15u) == 0u) {
+            typedef float qf4 __attribute__((ext_vector_type(4)));
+            const uint32_t n4 = dim >> 2;
+            for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += 64u * 8u) {
+                qf4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * 64u;
+                    v[u] = i < n4 ? reinterpret_cast<const qf4*>(gsrc)[i] : (qf4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * 64u;
+                    if (i < n4) reinterpret_cast<qf4*>(src)[i] = v[u];
+                }
+            }
+        } else {
+            for (uint32_t i0 = threadIdx.x; i0 < dim; i0 += 64u * 16u) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * 64u;
+                    v[u] = i < dim ? gsrc[i] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * 64u;
+                    if (i < dim) src[i] = v[u];
+                }
+            }
+        }
+        for (uint32_t i = dim + threadIdx.x; i < ld; i += 64) src[i] = 0.0f;
+        __syncthreads();
+    }
+    typedef float qv4 __attribute__((ext_vector_type(4)));
+    {
+        qv4* dst4 = reinterpret_cast<qv4*>(qpad + (size_t)q * ld);  // (ld is a multiple of 8, qpad rows 16-byte aligned)
+        for (uint32_t i = threadIdx.x; i < (ld >> 2); i += 64) dst4[i] = reinterpret_cast<const qv4*>(src)[i];
+    }
     const float ss = dot8_group<32>(src, src, dim, threadIdx.x & 7u);
     // MFMA sweep: the stationary copy of this query is bf16 — its rounding error |q - bf16(q)| goes into the margin
     float qerr2 = 0.0f;
@@ -254,23 +297,30 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         }
         qscale = (bad || mx == 0.0f) ? 0.0f : mx / 127.0f;
         const float inv = qscale > 0.0f ? 127.0f / mx : 0.0f;
-        int8_t* hp = reinterpret_cast<int8_t*>(qi8) + (size_t)q * 2u * ld;
-        int8_t* lp = hp + ld;
-        for (uint32_t i = threadIdx.x; i < ld; i += 64) {
-            float h = 0.0f, l = 0.0f;
-            if (i < dim && qscale > 0.0f) {
-                const float t = src[i] * inv;
-                h = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(t), -127.0f), 127.0f);
-                l = __builtin_fminf(__builtin_fmaxf(__builtin_rintf((t - h) * 256.0f), -127.0f), 127.0f);
-                const float qt = qscale * (h + l * 0.00390625f);
-                const float e = src[i] - qt;
-                qerr2 = qerr2 + e * e;
-                qq8 = qq8 + qt * qt;
-            } else if (i < dim) {
-                qerr2 = bad ? __builtin_inff() : qerr2;  // a non-finite query: infinite margin, the exact paths answer
+        uint32_t* hp = qi8 + (size_t)q * 2u * (ld >> 2);  // four codes per word (ld is a multiple of 8)
+        uint32_t* lp = hp + (ld >> 2);
+        for (uint32_t i4 = threadIdx.x; i4 < (ld >> 2); i4 += 64) {
+            uint32_t hw = 0u, lw = 0u;
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; c++) {
+                const uint32_t i = i4 * 4u + c;
+                float h = 0.0f, l = 0.0f;
+                if (i < dim && qscale > 0.0f) {
+                    const float t = src[i] * inv;
+                    h = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(t), -127.0f), 127.0f);
+                    l = __builtin_fminf(__builtin_fmaxf(__builtin_rintf((t - h) * 256.0f), -127.0f), 127.0f);
+                    const float qt = qscale * (h + l * 0.00390625f);
+                    const float e = src[i] - qt;
+                    qerr2 = qerr2 + e * e;
+                    qq8 = qq8 + qt * qt;
+                } else if (i < dim) {
+                    qerr2 = bad ? __builtin_inff() : qerr2;  // a non-finite query: infinite margin, the exact paths answer
+                }
+                hw |= ((uint32_t)(int)h & 0xFFu) << (8u * c);
+                lw |= ((uint32_t)(int)l & 0xFFu) << (8u * c);
             }
-            hp[i] = (int8_t)(int)h;
-            lp[i] = (int8_t)(int)l;
+            hp[i4] = hw;
+            lp[i4] = lw;
         }
         for (int off = 32; off > 0; off >>= 1) {
             qerr2 = qerr2 + __shfl_down(qerr2, off);
@@ -408,7 +458,12 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
                         hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8, const float* l2_hint, QInfo* qinfo_plain) {
-    hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), 0, s, queries, dim, ld, metric, max_norm_bits, qpad,
+    const size_t lds = (size_t)ld * sizeof(float);  // the query (nmn_index_create: one query fits the 160 KiB LDS)
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qprep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), lds, s, queries, dim, ld, metric, max_norm_bits, qpad,
                        qinfo, qstate, mfma_pass, half_err_bits, qi8, l2_hint, qinfo_plain);
     return hipGetLastError();
 }

@@ -101,6 +101,49 @@ __device__ uint32_t radix2(KeyAt key_at, uint32_t n, uint32_t kk, uint32_t* hist
     return (b1 << 21) | (pick->bin << 10);
 }
 
+// The same two digits with four barriers instead of ten: two padded histograms (hA, hB: kHistPad words each, any LDS nobody else is
+// using during the call), every wave picks the crossing bins for itself (wave_pick).  On return both may be overwritten.
+// MEASURED SLOWER in select_kernel (profiles/r05i_select_phases.txt: a pick over <= 4096 keys 4.1 -> 4.7-6.0 us): the workgroup is
+// 16 waves on 4 SIMDs, so what every wave does redundantly costs 4 x its instructions of SIMD time — wave_pick's ~200 VALU
+// instructions (32 bins per lane) outweigh the six barriers saved.  Phases of this kernel are instruction-bound, not barrier-bound.
+// Kept for sample_bound_kernel's register form only (a lone launch between two sweeps, where it measured the same).
+template <typename KeyAt>
+__device__ uint32_t radix2w(KeyAt key_at, uint32_t n, uint32_t kk, uint32_t* hA, uint32_t* hB) {
+    const uint32_t tid = threadIdx.x;
+    constexpr int V = 8;
+    for (uint32_t b = tid; b < kHistPad; b += kSelThreads) {
+        hA[b] = 0;
+        hB[b] = 0;
+    }
+    __syncthreads();
+    for (uint32_t e0 = tid; e0 < n; e0 += kSelThreads * V) {
+        uint32_t kv[V];
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+            const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+            kv[u] = e < n ? key_at(e) : kKeyMasked;
+        }
+#pragma unroll
+        for (int u = 0; u < V; u++) hist_add_wave(hA, kv[u] != kKeyMasked, hpad(kv[u] >> 21));
+    }
+    __syncthreads();
+    const PickResult p1 = wave_pick(hA, kk);
+    for (uint32_t e0 = tid; e0 < n; e0 += kSelThreads * V) {
+        uint32_t kv[V];
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+            const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+            kv[u] = e < n ? key_at(e) : kKeyMasked;
+        }
+#pragma unroll
+        for (int u = 0; u < V; u++) hist_add_wave(hB, kv[u] != kKeyMasked && (kv[u] >> 21) == p1.bin, hpad((kv[u] >> 10) & 2047u));
+    }
+    __syncthreads();
+    const PickResult p2 = wave_pick(hB, kk - p1.above);
+    __syncthreads();  // every wave is done with the histograms
+    return (p1.bin << 21) | (p2.bin << 10);
+}
+
 // count of valid (non-zero) gathered keys
 template <typename KeyAt>
 __device__ uint32_t count_valid(KeyAt key_at, uint32_t n, uint32_t* s_word) {
@@ -146,7 +189,7 @@ __global__ void __launch_bounds__(kSelThreads) sample_bound_kernel(const uint32_
                                                                    uint64_t stride, uint32_t n_sample,
                                                                    const QInfo* __restrict__ qinfo, uint32_t k,
                                                                    uint32_t* __restrict__ skip_key, int combine_max) {
-    __shared__ uint32_t hist[kBins];
+    __shared__ uint32_t hist[kHistPad], hist2[kHistPad];
     __shared__ PickResult pick;
     __shared__ uint32_t s_cnt;
     const uint32_t q = blockIdx.x;
@@ -173,25 +216,21 @@ __global__ void __launch_bounds__(kSelThreads) sample_bound_kernel(const uint32_
         if (loc) atomicAdd(&s_cnt, loc);
         __syncthreads();
         if (s_cnt >= k) {  // (block-uniform)
-            uint32_t b1 = 0, above1 = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < NV; u++) {
-                    const uint32_t key = kv[u];
-                    const bool in = key != kKeyMasked && (pass == 0 || (key >> 21) == b1);
-                    hist_add_wave(hist, in, pass == 0 ? key >> 21 : (key >> 10) & 2047u);
-                }
-                __syncthreads();
-                pick_bin(hist, kBins, pass == 0 ? k : k - above1, &pick);
-                if (pass == 0) {
-                    b1 = pick.bin;
-                    above1 = pick.above;
-                }
-                __syncthreads();
+            // two padded histograms, every wave picks for itself (nmn_select_dev.h): three barriers for both digits
+            for (uint32_t b = tid; b < kHistPad; b += kSelThreads) {
+                hist[b] = 0;
+                hist2[b] = 0;
             }
-            skip = margin_key((b1 << 21) | (pick.bin << 10), qinfo[q]);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NV; u++) hist_add_wave(hist, kv[u] != kKeyMasked, hpad(kv[u] >> 21));
+            __syncthreads();
+            const PickResult p1 = wave_pick(hist, k);
+#pragma unroll
+            for (int u = 0; u < NV; u++) hist_add_wave(hist2, kv[u] != kKeyMasked && (kv[u] >> 21) == p1.bin, hpad((kv[u] >> 10) & 2047u));
+            __syncthreads();
+            const PickResult p2 = wave_pick(hist2, k - p1.above);
+            skip = margin_key((p1.bin << 21) | (p2.bin << 10), qinfo[q]);
         }
     } else {
         auto key_at = [&](uint32_t e) { return keys[e]; };
@@ -218,7 +257,7 @@ hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uin
 #endif
 constexpr uint32_t kCompCap = 8192;
 constexpr uint32_t kBailTiles = 1024;  // tiles within the margin beyond which a selection hands over to the crowd kernels (when they follow)
-constexpr size_t kSelectLds = 2 * kCompCap * 8 + kMaxScanWaves * 4 + kBins * 4;  // 152 KiB
+constexpr size_t kSelectLds = 2 * kCompCap * 8 + kMaxScanWaves * 4 + kHistPad * 4;  // 152.25 KiB
 
 __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sel_lds[];
@@ -230,6 +269,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     uint32_t* lb = la + kListCap;                                  // generic path: tile list
     __shared__ PickResult pick;
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_vw;
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t nql = p.nql;
@@ -261,10 +301,33 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t k = p.k + (p.k_extra ? *p.k_extra : 0u);
     constexpr int V = 8;
 
-    for (uint32_t i = tid; i < kMaxScanWaves; i += kSelThreads) wk[i] = i < W ? wmax[i] : kKeyMasked;
+    // the wave maxima into LDS, counted on the way (one phase: the count used to be a second walk over them, two barriers more)
+    if (tid == 0) s_vw = 0;
+    uint32_t my_valid = 0;
+    {
+        uint32_t wv4[kMaxScanWaves / kSelThreads];
+#pragma unroll
+        for (int u = 0; u < (int)(kMaxScanWaves / kSelThreads); u++) {
+            const uint32_t i = tid + (uint32_t)u * kSelThreads;
+            wv4[u] = i < W ? wmax[i] : kKeyMasked;
+        }
+#pragma unroll
+        for (int u = 0; u < (int)(kMaxScanWaves / kSelThreads); u++) {
+            wk[tid + (uint32_t)u * kSelThreads] = wv4[u];
+            my_valid += wv4[u] != kKeyMasked;
+        }
+    }
     __syncthreads();
     SEL_MARK(1);
-    const uint32_t vw = count_valid([&](uint32_t e) { return wk[e]; }, W, &s_w[0]);
+    {
+        // one LDS atomic per wave
+        uint32_t t = my_valid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += (uint32_t)__shfl_xor((int)t, off);
+        if ((tid & 63u) == 0 && t) atomicAdd(&s_vw, t);
+    }
+    __syncthreads();
+    const uint32_t vw = s_vw;  // (s_vw is written nowhere else: no race with the counters reset below)
     SEL_MARK(2);
     if (vw == 0) {
         if (tid == 0) { p.qstate[q].cand_count = 0; p.qstate[q].n_valid = 0; }
@@ -378,13 +441,21 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                             }
                         }
                     }
+                    // (one LDS atomic per wave and trip for all 4 * V elements of its lanes; it was one per element)
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int u = 0; u < V; u++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) cnt += (tk[u][c] != kKeyMasked && tk[u][c] >= Twm) ? 1u : 0u;
+                    uint32_t pos = wave_append_cnt(cnt, &s_w[1]);
 #pragma unroll
                     for (int u = 0; u < V; u++) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            const bool pr = tk[u][c] != kKeyMasked && tk[u][c] >= Twm;
-                            const uint32_t pos = wave_append(pr, &s_w[1]);
-                            if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)tk[u][c] << 32) | (tb[u] + (uint32_t)c);
+                            if (tk[u][c] != kKeyMasked && tk[u][c] >= Twm) {
+                                if (pos < kCompCap) LT[pos] = ((unsigned long long)tk[u][c] << 32) | (tb[u] + (uint32_t)c);
+                                pos++;
+                            }
                         }
                     }
                 }
@@ -406,13 +477,17 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                     tt[u] = ok ? (strided ? tile_of(la[in], o) : tile_of(la[o], in)) : 0xFFFFFFFFu;
                     tk[u] = tt[u] < n_tiles ? tmax[tt[u]] : kKeyMasked;
                 }
+                // (appends are counted per wave and trip: one LDS atomic for all V elements of all its lanes)
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int u = 0; u < V; u++) cnt += (tk[u] != kKeyMasked && tk[u] >= Twm) ? 1u : 0u;
+                uint32_t pos = wave_append_cnt(cnt, &s_w[1]);
 #pragma unroll
                 for (int u = 0; u < V; u++) {
-                    // (appends are counted per wave, one LDS atomic for all its lanes: on a degenerate shard every element passes,
-                    // and 64 lanes adding to one LDS word serialize)
-                    const bool pr = tk[u] != kKeyMasked && tk[u] >= Twm;
-                    const uint32_t pos = wave_append(pr, &s_w[1]);
-                    if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
+                    if (tk[u] != kKeyMasked && tk[u] >= Twm) {
+                        if (pos < kCompCap) LT[pos] = ((unsigned long long)tk[u] << 32) | tt[u];
+                        pos++;
+                    }
                 }
             }
         }
@@ -471,9 +546,11 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         // load instruction four tiles per wave — a quarter of the loads (and of the LT look-ups) of the dword form below, which is
         // kept for the A/B (-DNMN_SELECT_ROWS_DWORD): profiles/r04y_* has this gather at 17 of the selection's 41 us at 1M x 768.
         (void)tot;
-        constexpr int VR4 = NMN_SELECT_VR / 4;
+        // (12 loads per thread in flight: 768 tiles per round trip — k = 100 is one or two trips; one LDS atomic per wave and trip)
+        constexpr int VR4 = 12;
         const uint32_t tot4 = ct * (kTileRows / 4u);
-        for (uint32_t e0 = tid; e0 < tot4; e0 += kSelThreads * VR4) {
+        for (uint32_t b0 = tid & ~63u; b0 < tot4; b0 += kSelThreads * VR4) {  // (on the wave's first index: every lane takes every trip)
+            const uint32_t e0 = b0 + (tid & 63u);
             uint4 kb[VR4];
 #pragma unroll
             for (int u = 0; u < VR4; u++) {
@@ -485,17 +562,46 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                         kb[u] = *reinterpret_cast<const uint4*>(p.scores + score_at((uint64_t)(uint32_t)(ent & 0xFFFFFFFFull) * kTileRows + (e & 15u) * 4u, q, nql));
                 }
             }
+            // "key >= T2m" as ONE float compare per score: the key order is the score order (-0.0 == +0.0 on both sides), a NaN score
+            // and the sentinel (a NaN pattern) compare false as their keys (<= kKeyNaN) do — valid whenever T2m is a score's key; a threshold
+            // at or below the NaN key (fewer than k valid tiles) takes the key form.  The keys of the few that pass are formed below.
+            const bool by_float = T2m >= kKeyNegInf;  // (keys between the NaN key and key(-inf) are no score's: key form)
+            const float tau2 = key_to_score(T2m);
+            uint32_t m[VR4];  // which of the four scores of load u pass
+            if (by_float) {
 #pragma unroll
-            for (int u = 0; u < VR4; u++) {
-                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
-                const uint32_t row0 = (uint32_t)(LT[min(e, tot4 - 1u) >> 4] & 0xFFFFFFFFull) * kTileRows + (e & 15u) * 4u;
-                const uint32_t bits4[4] = {kb[u].x, kb[u].y, kb[u].z, kb[u].w};
+                for (int u = 0; u < VR4; u++)
+                    m[u] = (u2f(kb[u].x) >= tau2 ? 1u : 0u) | (u2f(kb[u].y) >= tau2 ? 2u : 0u) | (u2f(kb[u].z) >= tau2 ? 4u : 0u) | (u2f(kb[u].w) >= tau2 ? 8u : 0u);
+            } else {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t key = bits_to_key(bits4[c]);
-                    const bool pr = key != kKeyMasked && key >= T2m;
-                    const uint32_t pos = wave_append(pr, &s_w[2]);
-                    if (pr && pos < kCompCap) LR[pos] = ((unsigned long long)key << 32) | (row0 + (uint32_t)c);
+                for (int u = 0; u < VR4; u++) {
+                    const uint32_t bits4[4] = {kb[u].x, kb[u].y, kb[u].z, kb[u].w};
+                    m[u] = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t key = bits_to_key(bits4[c]);
+                        m[u] |= (key != kKeyMasked && key >= T2m) ? (1u << c) : 0u;
+                    }
+                }
+            }
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int u = 0; u < VR4; u++) cnt += (uint32_t)__builtin_popcount(m[u]);
+            uint32_t pos = wave_append_cnt(cnt, &s_w[2]);
+            if (cnt) {
+#pragma unroll
+                for (int u = 0; u < VR4; u++) {
+                    if (m[u] == 0u) continue;
+                    const uint32_t bits4[4] = {kb[u].x, kb[u].y, kb[u].z, kb[u].w};
+                    const uint32_t e = e0 + (uint32_t)u * kSelThreads;
+                    const uint32_t row0 = (uint32_t)(LT[min(e, tot4 - 1u) >> 4] & 0xFFFFFFFFull) * kTileRows + (e & 15u) * 4u;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if ((m[u] >> c) & 1u) {
+                            if (pos < kCompCap) LR[pos] = ((unsigned long long)bits_to_key(bits4[c]) << 32) | (row0 + (uint32_t)c);
+                            pos++;
+                        }
+                    }
                 }
             }
         }

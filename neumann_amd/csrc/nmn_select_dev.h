@@ -77,6 +77,72 @@ static __device__ __forceinline__ void hist_add_wave(uint32_t* hist, bool in, ui
     else if (in && bin != b0) atomicAdd(&hist[bin], 1u);
 }
 
+// ---- selection with few barriers (round 5) ------------------------------------------------------------------------------------
+// select_kernel is a chain of short workgroup-wide phases, and on a 16-wave workgroup every barrier-separated phase costs ~0.4 us
+// whatever it does (profiles/r05h_select_phases.txt: three radix picks over <= 4096 LDS-resident keys took 4 us EACH, ten barriers a
+// piece).  These helpers cut the barriers: the histogram is PADDED (one word per 32 bins) so that a lane can read 32 adjacent
+// bins without bank conflicts, and then every WAVE finds the crossing bin for itself from the finished histogram — no partial
+// sums through LDS, no publication of the result, no barrier.
+constexpr uint32_t kHistPad = kBins + kBins / 32;  // words of a padded histogram
+static __device__ __forceinline__ uint32_t hpad(uint32_t bin) { return bin + (bin >> 5); }
+
+// hist (padded, kBins bins, complete: the caller has synchronized) -> the bin holding the kk-th largest key and the number of
+// keys in the bins above it (1 <= kk <= total), computed redundantly by every wave; all 64 lanes must call.
+static __device__ __forceinline__ PickResult wave_pick(const uint32_t* hist, uint32_t kk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t h[32];
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        h[j] = hist[33u * lane + (uint32_t)j];  // bins 32 * lane + j
+        s += h[j];
+    }
+    uint32_t S = s;  // inclusive suffix sum over the lanes (higher lane = higher bins)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_down((int)S, off);
+        if (lane + (uint32_t)off < 64u) S += t;
+    }
+    const uint32_t above = S - s;
+    const bool cross = S >= kk && above < kk;
+    uint32_t bin = 0, ab = 0, a = above;
+    bool found = false;
+#pragma unroll
+    for (int j = 31; j >= 0; j--) {
+        const bool here = !found && a + h[j] >= kk;
+        if (here) {
+            bin = 32u * lane + (uint32_t)j;
+            ab = a;
+        }
+        found = found || here;
+        a += h[j];
+    }
+    const unsigned long long m = __ballot(cross);
+    const int src = m ? __builtin_ctzll(m) : 0;
+    PickResult r;
+    r.bin = (uint32_t)__shfl((int)bin, src);
+    r.above = (uint32_t)__shfl((int)ab, src);
+    return r;
+}
+
+// cnt items per lane -> the slot of this lane's first item: ONE LDS atomic per wave (a scan of the lanes' counts places them),
+// where wave_append pays one per item.  All 64 lanes must call (wave-uniform control flow).
+static __device__ __forceinline__ uint32_t wave_append_cnt(uint32_t cnt, uint32_t* counter) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, (int)dd);
+        if (lane >= dd) incl += t;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (total == 0) return 0;  // (wave-uniform)
+    uint32_t base = 0;
+    if (lane == 63u) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, 63);
+    return base + incl - cnt;
+}
+
 // `walk(f)`: calls f(row, key) for every element, the same number of times on every lane (key == kKeyMasked: skip).
 template <class Walk>
 static __device__ uint32_t exact_select_walk(Walk&& walk, uint32_t k, unsigned long long* list, uint32_t* hist, PickResult* pick,
@@ -240,10 +306,14 @@ static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint3
         for (uint32_t r = 0; r < nruns && rank < k; r++) {
             if (r == own) continue;
             const unsigned long long* run = list + r * 64u;  // descending; zeros (never greater) at its end
-            uint32_t lo = 0, hi = 64;                         // lo = entries of this run that are greater than v
+            // lo = entries of this run that come before v: the greater ones — and, in EARLIER runs, equal ones too.  Composites are
+            // distinct by construction (distinct rows), but should a list ever carry a row twice the ranks are still a permutation
+            // (ties ordered by list position) and every slot below cnt is written.
+            const bool ge = r < own;
+            uint32_t lo = 0, hi = 64;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (run[mid] > v) lo = mid + 1u;
+                if (ge ? run[mid] >= v : run[mid] > v) lo = mid + 1u;
                 else hi = mid;
             }
             rank += lo;
