@@ -187,13 +187,16 @@ nmn_status nmn_index_scan_history(nmn_index* idx, void* stream, float* scan_ms, 
  * the next one down — never an error.  Mirrors carry their MEASURED rounding error into the candidate margin, and a shard whose
  * 8-bit margin keeps overflowing the candidate lists returns to the bf16 mirror by itself.
  * enabled == 2: the bf16 mirror only.  enabled == 0: the row-major f32 corpus itself — the sweep SURVEY.md §8(d) prices at
- * rows * dim * 4 bytes per query (bench.py's `roofline.f32_corpus`); query batches then run as VALU sweeps of 4.  Any other
+ * rows * dim * 4 bytes per query (bench.py's headline: `value`, `roofline`); query batches then take the matrix-core sweep over
+ * the f32 rows themselves (rounded to bf16 in registers: the rows' bytes once per 64-128 queries, nmn_scan_mfma_f32.hip).  Any other
  * value: NMN_ERR_INVALID_ARGUMENT.  Results are identical in every mode (every candidate is re-scored from the f32 corpus in
  * the reference's order). */
 nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled);
 /* Device memory the shard holds for its rows: corpus_bytes = the f32 rows (capacity x stride x 4), mirror_bytes = the 8-bit and
  * bf16 mirrors that exist right now, with their per-row factors; per_row_bytes = magnitudes and their reciprocals.  Workspaces
- * (per stream, sized by the largest search seen) are not counted.  Any pointer may be null. */
+ * (per stream, sized by the largest search seen) are not counted.  Any pointer may be null.  Side effect: a mirror that was
+ * declined (or a query pass that was shrunk) because the device was short of memory is given another chance by the next search
+ * that wants it — such verdicts also expire by themselves every 4096 searches. */
 nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes);
 /* hipEvent timing of searches (default 0 = off).  1: events at the start and end of the pipeline and around its sweep (scan_ms,
  * total_ms of nmn_index_last_stats).  2: the two events around the sweep only (scan_ms, nmn_index_scan_history) — what a timed

@@ -518,6 +518,8 @@ extern "C" nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled) {
 extern "C" nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
+    idx->q8_failed = idx->half_failed = false;  // (whoever asks about memory has usually just changed it: see squeeze_calls)
+    idx->ws_nq_limit = 0xFFFFFFFFu;
     const uint64_t elems = idx->cap_pad * (uint64_t)idx->ld;
     if (corpus_bytes) *corpus_bytes = elems * 4ull;
     if (mirror_bytes) *mirror_bytes = (idx->q8 ? elems + idx->cap_pad * 12ull : 0ull) + (idx->half ? elems * 2ull : 0ull);
@@ -864,7 +866,10 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                                  nmn_metric metric, const uint64_t* mask_dev, uint64_t* out_rows,
                                  float* out_scores, uint32_t* out_counts, hipStream_t stream,
                                  const uint64_t* const* qmasks_dev = nullptr, const uint64_t* const* qmasks_host = nullptr,
-                                 bool short_chain = false) {
+                                 bool short_chain = false, bool nested = false) {
+    // nested: a part of a pass that search_enqueue itself split (pairs of a 3-4-query pass on the 8-bit mirror, the queries of a
+    // pass with per-query bitmaps that cannot take the matrix-core sweep): the timing events and the history entry belong to the
+    // OUTER call — one entry per search, total_ms over the whole of it (every part used to re-record them).
     // short_chain (the host-buffer API, which waits for the answer anyway — host_batch_body): only the launches every search needs,
     // qprep -> sweep -> select -> rescore -> final.  A query whose candidate list overflows is not followed up on the device (crowd
     // kernels, f32 retry sweep, second selection, exact scan of everything, device-wide selection: six launches that return at once
@@ -885,14 +890,35 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         }
         return search_large_k(idx, w, queries_dev, nq, k, metric, mask_dev, out_rows, out_scores, out_counts, stream);
     }
+    // A mirror declined (mirror_fits / hipMalloc) or a pass shrunk (ws_alloc) for lack of HBM is a verdict on the device's memory at
+    // THAT moment — a sibling shard building, a large workspace alive.  It is re-examined every 4096 searches (and by
+    // nmn_index_hbm_bytes): the flags are cleared, the next call that wants the mirror / the larger pass simply tries again, and
+    // a device that is still full declines again at the cost of one hipMemGetInfo (the verdicts used to be for life).
+    if ((idx->q8_failed || idx->half_failed || idx->ws_nq_limit != 0xFFFFFFFFu) && (++idx->squeeze_calls & 4095u) == 0) {
+        idx->q8_failed = idx->half_failed = false;
+        idx->ws_nq_limit = 0xFFFFFFFFu;
+    }
     const uint64_t n_rows = idx->rows;
     const uint32_t n_tiles = (uint32_t)((n_rows + kTileRows - 1) / kTileRows);
-    w->timed = idx->timing;
-    w->last_nq = nq;
-    w->last_rows_scanned = n_rows;
-    w->last_masked = mask_dev != nullptr || qmasks_dev != nullptr;
-    w->scan_ev_in_hist = false;
-    if (w->timed == 1) HIP_TRY(hipEventRecord(w->ev[0], stream));
+    if (!nested) {
+        w->timed = idx->timing;
+        w->last_nq = nq;
+        w->last_rows_scanned = n_rows;
+        w->last_masked = mask_dev != nullptr || qmasks_dev != nullptr;
+        w->scan_ev_in_hist = false;
+        if (w->timed == 1) HIP_TRY(hipEventRecord(w->ev[0], stream));
+    }
+    // the parts of a split pass, timed as ONE sweep entry of the history ring
+    auto hist_mark = [&](int which) -> nmn_status {
+        hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory) + which];
+        if (!h) HIP_TRY(hipEventCreate(&h));
+        HIP_TRY(hipEventRecord(h, stream));
+        if (which == 1) {
+            w->hist_head++;
+            w->scan_ev_in_hist = true;
+        }
+        return NMN_OK;
+    };
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
         // The approximate sweep reads a MIRROR of the shard where one serves the call (its measured rounding error is part of
@@ -917,13 +943,16 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // pairs instead of building (and keeping: 2 more bytes per element) a second mirror for it.
         if (!mfma_shape && nqc > 2 && nqc <= 4 && i8_enabled && !idx->half && idx->q8 && !qmasks_dev && !qmasks_host &&
             idx->q8_calls >= idx->q8_off_until && scan_i8_supported(idx->ld, idx->dim, (int)metric)) {
+            const bool mark = w->timed && qa == 0 && !nested;
+            if (mark && (st = hist_mark(0)) != NMN_OK) return st;
             for (uint32_t i = 0; i < nqc; i += 2) {
                 st = search_enqueue(idx, w, queries_dev + (size_t)(qa + i) * idx->dim, std::min(2u, nqc - i), k, metric, mask_dev,
                                     out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i, stream, nullptr,
-                                    nullptr, short_chain);
+                                    nullptr, short_chain, true);
                 if (st != NMN_OK) return st;
             }
-            w->last_nq = nq;
+            if (mark && (st = hist_mark(1)) != NMN_OK) return st;
+            w->last_elem_bytes = 1u;
             continue;
         }
         bool use_i8 = i8_enabled && i8_shape && idx->q8_calls >= idx->q8_off_until;
@@ -1003,16 +1032,18 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         const bool mfma_f32 = use_mfma && !use_half && !use_i8;
         if (qmasks_host && !use_mfma) {
             // per-query bitmaps need the matrix-core sweep: this pass runs query by query instead
+            const bool mark = w->timed && qa == 0 && !nested;
+            if (mark && (st = hist_mark(0)) != NMN_OK) return st;
             for (uint32_t i = 0; i < nqc; i++) {
                 st = search_enqueue(idx, w, queries_dev + (size_t)(qa + i) * idx->dim, 1, k, metric, qmasks_host[qa + i],
                                     out_rows + (size_t)(qa + i) * k, out_scores + (size_t)(qa + i) * k, out_counts + qa + i,
-                                    stream, nullptr, nullptr, short_chain);
+                                    stream, nullptr, nullptr, short_chain, true);
                 if (st != NMN_OK) return st;
             }
-            w->last_nq = nq;
+            if (mark && (st = hist_mark(1)) != NMN_OK) return st;
             continue;
         }
-        w->last_elem_bytes = use_i8 ? 1u : use_half ? 2u : 4u;
+        w->last_elem_bytes = use_i8 ? 1u : use_half ? 2u : 4u;  // (nested parts too: what the sweeps of this pass read)
         // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
         const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18) && !short_chain;
@@ -1141,7 +1172,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // event packets of the chain cost more than the overlap of two short sweeps — 1M x 768: 5.8 k q/s without, 5.6 k with)
             if (chain && idx->sweep_seq && idx->sweep_stream != stream)
                 HIP_TRY(hipStreamWaitEvent(stream, idx->sweep_ev[(idx->sweep_seq - 1) & 3u], 0));
-            if (w->timed && qa == 0) {
+            if (w->timed && qa == 0 && !nested) {
                 hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory)];
                 if (!h) HIP_TRY(hipEventCreate(&h));
                 HIP_TRY(hipEventRecord(h, stream));
@@ -1189,7 +1220,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             } else {
                 HIP_TRY(use_mfma ? launch_batch_sweep(sp) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
             }
-            if (w->timed && qa == 0) {
+            if (w->timed && qa == 0 && !nested) {
                 hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory) + 1];
                 if (!h) HIP_TRY(hipEventCreate(&h));
                 HIP_TRY(hipEventRecord(h, stream));
@@ -1351,7 +1382,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.out_counts = out_counts + qa;
         HIP_TRY(launch_final(fp, stream));
     }
-    if (w->timed == 1) HIP_TRY(hipEventRecord(w->ev[3], stream));
+    if (w->timed == 1 && !nested) HIP_TRY(hipEventRecord(w->ev[3], stream));
     return NMN_OK;
 }
 

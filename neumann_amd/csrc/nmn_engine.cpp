@@ -2235,7 +2235,10 @@ uint32_t nmn_engine_mirror_shard_rows(nmn_engine* e, uint64_t dim, uint64_t* out
     auto it = e->dflt.mirrors.find(dim);
     if (it == e->dflt.mirrors.end() || !it->second->has_rows()) return 0;
     Mirror* m = it->second.get();
-    mirror_flush(&e->dflt, m, dim);
+    if (!mirror_flush(&e->dflt, m, dim)) {  // (a failed flush leaves a mirror nobody may trust: dropped, as every other caller does)
+        e->dflt.mirrors.erase(it);
+        return 0;
+    }
     if (m->idx) {
         if (out && cap) out[0] = nmn_index_rows(m->idx);
         return 1;
@@ -2249,12 +2252,13 @@ uint32_t nmn_engine_mirror_shard_rows(nmn_engine* e, uint64_t dim, uint64_t* out
 // mirrors that exist right now, out[2] = per-row factors (nmn_index_hbm_bytes); returns the number of shards (0: no such mirror)
 uint32_t nmn_engine_mirror_hbm_bytes(nmn_engine* e, uint64_t dim, uint64_t out[3]) {
     if (!e || !out) return 0;
-    WriteLock g(e);
+    // an accounting query: the shared lock, and no flush of pending rows — the sizes depend on the shards' CAPACITY, not on which
+    // rows have been copied (it used to take the exclusive lock, flush, and ignore the flush's verdict)
+    ReadLock g(e);
     out[0] = out[1] = out[2] = 0;
     auto it = e->dflt.mirrors.find(dim);
     if (it == e->dflt.mirrors.end() || !it->second->has_rows()) return 0;
     Mirror* m = it->second.get();
-    mirror_flush(&e->dflt, m, dim);
     const uint32_t G = m->idx ? 1u : nmn_sharded_shards(m->sh);
     for (uint32_t i = 0; i < G; i++) {
         uint64_t a = 0, b = 0, c = 0;

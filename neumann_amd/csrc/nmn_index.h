@@ -132,6 +132,8 @@ struct nmn_index {
     // next 256 searches enqueue the whole chain at once
     uint64_t short_calls = 0, short_off_until = 0;
     uint32_t ws_nq_limit = 0xFFFFFFFFu;  // queries per pipeline pass the device's free memory allowed (ws_alloc lowers it on OOM)
+    uint64_t squeeze_calls = 0;          // searches since a mirror was declined / a pass was shrunk for lack of HBM: every 4096th clears
+                                         // the verdicts (q8_failed, half_failed, ws_nq_limit) so that a TRANSIENT squeeze does not last
     bool no_single_launch = false;  // NMN_INDEX_NO_SINGLE_LAUNCH
     float* corpus = nullptr;
     float* half = nullptr;       // bf16 mirror of `corpus` every approximate sweep reads (half the bytes); lazy

@@ -801,11 +801,22 @@ static nmn_status sharded_run_body(nmn_sharded* s, const float* queries, uint32_
     //  two threads — so the group call is made under a process-wide lock.  Only the issue: once every rank's all-gather sits in
     //  its stream the order is fixed, and the merge, the copy back and the drain of one handle do not hold up the searches of
     //  the others (it used to be held until every rank had drained).)
+    //  with only the ISSUE under the lock, two communicators are in flight on the same devices while other host threads
+    //  make implicitly synchronising HIP calls (a blocking hipMemcpy of a shard's counters, hipMalloc / hipFree of a workspace) —
+    //  the RCCL guidance on concurrent communicators names that as a hang hazard, and no multi-GPU hardware has been available to
+    //  test it on.  So by default the lock is kept until this handle's all-gathers have COMPLETED on every rank (its lanes drained:
+    //  the gather is the last thing in each); NMN_RCCL_NARROW_LOCK=1 restores the issue-only lock for whoever can measure it.)
     {
         std::unique_lock<std::mutex> coll(collective_mutex(), std::defer_lock);
         if (s->gather == NMN_GATHER_RCCL) coll.lock();
         const nmn_status st = sharded_gather(s, pl.size);
         if (st != NMN_OK) return st;
+        static const bool narrow = getenv("NMN_RCCL_NARROW_LOCK") != nullptr;
+        if (s->gather == NMN_GATHER_RCCL && !narrow)
+            for (uint32_t g = 0; g < G; g++) {
+                S_TRY(hipSetDevice(s->device[g]));
+                S_TRY(hipStreamSynchronize(s->lane[g].stream));
+            }
     }
     // ---- merge_top_k on the merging device, one D2H ---------------------------------------------------------------------
     S_TRY(hipSetDevice(s->device[0]));

@@ -6,7 +6,7 @@ cd $R
 export TMPDIR=/tmp
 for sel in 0.5 0.1 0.01; do for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/mpmc
-  (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d /tmp/mpmc -o p -- python $R/tools/mask_pmc_child.py $sel > /tmp/mpmc.json 2>/dev/null)
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d /tmp/mpmc -o p -- python $R/tools/search_child.py --rows 10000000 --dim 1536 --metric 1 --k 1000 --mask $sel --mirror 1 --api device --reps 4 > /tmp/mpmc.json 2>/dev/null)
   DB=$(find /tmp/mpmc -name "*.db" | head -1)
   python - "$DB" /tmp/mpmc.json $c <<'PY'
 import json, sqlite3, sys
@@ -17,6 +17,6 @@ big = [x for x in scan if x * 2 >= max(scan)]
 scale = 1024 * (2 if c == "FETCH_SIZE" else 1)   # KiB; gfx950: FETCH_SIZE reports half the bytes of 16-B-per-lane reads
 b = sum(big) / len(big) * scale
 kept = info["kept_rows"] * info["dim"]
-print(f"selectivity {info['sel']}: {c} of scan_i8_kernel (masked, survivor walk) {b/1e9:.4f} GB per sweep over {len(big)} sweeps; the kept rows' codes: {kept/1e9:.4f} GB -> {b/kept:.3f}x")
+print(f"selectivity {info['mask']}: {c} of scan_i8_kernel (masked, survivor walk) {b/1e9:.4f} GB per sweep over {len(big)} sweeps; the kept rows' codes: {kept/1e9:.4f} GB -> {b/kept:.3f}x")
 PY
 done; done
