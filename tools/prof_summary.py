@@ -15,10 +15,13 @@ def main():
         "from kernels group by name order by 6 desc"))
     total = sum(r[5] for r in rows) or 1
     print(f"# rocprofv3 --kernel-trace --stats summary: {title}")
-    print(f"# {'kernel':<100} {'calls':>6} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'total_us':>12} {'pct':>6}")
+    print(f"# (full = the launches of at least half the template's longest: a template also serves launches that return at once — the f32 retry")
+    print(f"#  behind a mirror sweep, the sampling pass of a batch — which the plain average mixes in)")
+    print(f"# {'kernel':<100} {'calls':>6} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'total_us':>12} {'pct':>6} {'full':>5} {'full_avg_us':>12}")
     for name, n, avg, mn, mx, tot in rows:
+        full = [r[0] for r in db.execute("select end-start from kernels where name=? and (end-start)*2 >= ?", (name, mx))]
         print(f"{name[:100]:<102} {n:>6} {avg / 1e3:>10.1f} {mn / 1e3:>10.1f} {mx / 1e3:>10.1f} {tot / 1e3:>12.1f} "
-              f"{100.0 * tot / total:>6.2f}")
+              f"{100.0 * tot / total:>6.2f} {len(full):>5} {sum(full) / max(len(full), 1) / 1e3:>12.1f}")
 
 
 if __name__ == "__main__":
