@@ -1193,6 +1193,31 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
         }
     }
     __syncthreads();
+    // More candidates than threads (an IVF probe of clustered lists, a margin that lets a few thousand rows through) and k below
+    // that: sort_and_emit would take the workgroup-wide bitonic network over 2048 / 4096 slots — 36 us of an IVF probe's 173
+    // (profiles/r05q_*).  Only the k best are wanted: a two-digit radix pick over the candidates' keys gives a key T with at least k
+    // candidates at or above it (and, ties aside, few more); those are compacted and sorted by runs and ranks like any short list.
+    // More than one per thread still at or above T (thousands of equal scores): the network, as before.
+    if (mode == 0 && n > (uint32_t)kSelThreads && p.k < (uint32_t)kSelThreads) {  // (block-uniform)
+        __shared__ unsigned long long top[kSelThreads];
+        const uint32_t T = radix2([&](uint32_t e) { return (uint32_t)(list[e] >> 32); }, n, p.k, hist, &pick);
+        if (tid == 0) s_misc[0] = 0;
+        __syncthreads();
+        for (uint32_t b0 = tid & ~63u; b0 < n; b0 += kSelThreads) {  // (on the wave's first index: wave_append needs whole waves)
+            const uint32_t i = b0 + (tid & 63u);
+            const unsigned long long v = i < n ? list[i] : 0ull;
+            const bool pr = i < n && (uint32_t)(v >> 32) >= T;
+            const uint32_t pos = wave_append(pr, &s_misc[0]);
+            if (pr && pos < (uint32_t)kSelThreads) top[pos] = v;
+        }
+        __syncthreads();
+        const uint32_t c = s_misc[0];
+        if (c <= (uint32_t)kSelThreads) {  // (>= k by construction)
+            if (tid < c) list[tid] = top[tid];
+            n = c;
+        }
+        __syncthreads();
+    }
     sort_and_emit(list, n, n, p.k, p.row_base, p.out_rows + (size_t)q * p.k, p.out_scores + (size_t)q * p.k, p.out_counts + q);
 }
 
