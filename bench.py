@@ -174,7 +174,7 @@ def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
     Otherwise a 1M-row sample, scaled linearly and flagged as extrapolated."""
     from oracle import oracle_c as oc
     from neumann_amd import GpuFlatIndex
-    cores = os.cpu_count() or 1
+    cores, quota = _effective_cores()
     try:
         ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
     except (ValueError, OSError):
@@ -213,8 +213,10 @@ def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
     qps_full = 1.0 / (dt * (total_rows / sample_rows))
     return {
         "value": qps_full, "unit": "queries/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+        "host_hardware_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
         "sample": (f"{reps} queries x the WHOLE corpus, {sample_rows} rows x {args.dim} (same generator/seed; host twin built in "
-                   f"{synth_s:.1f} s), {dt * 1e3:.1f} ms/query on {cores} threads, nothing extrapolated" if full else
+                   f"{synth_s:.1f} s), {dt * 1e3:.1f} ms/query on {cores} threads"
+                   f"{f' (the cgroup CPU quota of this container: {quota:g} CPUs of the {os.cpu_count()} hardware threads)' if quota else ''}, nothing extrapolated" if full else
                    f"{reps} queries x {sample_rows} rows x {args.dim} (same generator/seed), {dt * 1e3:.2f} ms/query on {cores} threads, "
                    f"EXTRAPOLATED linearly to {total_rows} rows (host RAM {ram >> 30} GiB does not hold two corpus twins)") +
                   f"; 1 thread: {dt1 * 1e3:.0f} ms per 1M rows. Optimistic for the reference (flat array, per-thread partial "
@@ -223,6 +225,33 @@ def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
         "gbps": sample_rows * args.dim * 4 / dt / 1e9,
         "gpu_matches_oracle_on_sample": sample_ok,
     }
+
+
+def _effective_cores():
+    """Host threads this process may actually run at once: the smaller of the visible CPUs, the affinity mask and the cgroup's CPU
+    quota (cpu.max = "quota period": the GPU boxes show 256 hardware threads and grant 16 CPUs — 256 oracle threads on such a quota
+    run at HALF the rate of 16: the baseline is timed with what it is allowed to use, and says so)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
 
 
 def _cpu_model():

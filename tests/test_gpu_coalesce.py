@@ -149,8 +149,9 @@ def test_writers_drain_the_queue_and_hand_the_slot_back():
             assert np.array_equal(r0, r1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and c0[0] == c1[0]
 
 
-@pytest.mark.parametrize("n,d", [(40_000, 768), (30_000, 256), (25_000, 200)])  # matrix-core sweep from 3 / 5 queries / never
-def test_differently_filtered_callers_share_a_sweep(n, d):
+@pytest.mark.parametrize("n,d,mirror", [(40_000, 768, 1), (30_000, 256, 1), (25_000, 200, 1),  # matrix-core sweep from 3 / 5 queries / never
+                                        (40_000, 768, 0), (30_000, 256, 0)])  # ... over the f32 rows themselves (no mirror, round 5)
+def test_differently_filtered_callers_share_a_sweep(n, d, mirror):
     """Concurrent searches whose WHERE bitmaps differ (each in device memory, as the predicate kernel leaves them)
     ride one matrix-core sweep that reads one bitmap per query; where that sweep does not apply they must still
     come out right (query by query)."""
@@ -170,6 +171,7 @@ def test_differently_filtered_callers_share_a_sweep(n, d):
         mi = j % (n_masks + 1)                              # the last one: no filter at all
         jobs.append((oc.synth(102, j, 1, d)[0], (5, 40, 100)[j % 3], (0, 1, 2)[j % 3 if d != 200 else 0], mi))
     with GpuFlatIndex(d, n, single_launch=False) as idx:   # (see test_concurrent_callers_get_their_own_exact_answers)
+        idx.set_mirror(mirror)
         idx.upload(A)
         out = [None] * len(jobs)
         errs = []
@@ -206,6 +208,8 @@ def test_differently_filtered_callers_share_a_sweep(n, d):
             assert np.array_equal(rows[0, :c], er), (j, mi)
             assert np.all(scores[0, :c] == es), (j, mi)
             assert np.all(rows[0, c:] == U64_MAX)
+        if mirror == 0:
+            assert idx.hbm_bytes()[1] == 0, "a mirror was built under set_mirror(0)"
 
 
 @pytest.mark.parametrize("n,d", [(30_000, 768), (40_000, 128)])

@@ -125,6 +125,10 @@ def test_batched_queries_and_stats():
         r2, s2, c2, st2 = sh.search(Q[:2], k, 0, with_stats=True)
         assert st2.bytes_scanned == n * d * 4
         assert np.array_equal(r2, rows[:2]) and np.array_equal(s2.view(np.uint32), scores[:2].view(np.uint32))
+        # ... and the whole batch: the matrix-core sweep over every shard's f32 rows (round 5) — all 64 lists unchanged
+        r3, s3, c3, st3 = sh.search(Q, k, 0, with_stats=True)
+        assert st3.bytes_scanned == n * d * 4 and st3.fallback_queries == 0
+        assert np.array_equal(r3, rows) and np.array_equal(s3.view(np.uint32), scores.view(np.uint32)) and np.array_equal(c3, counts)
 
 
 def test_argument_errors():
