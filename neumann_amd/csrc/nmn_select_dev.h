@@ -303,17 +303,26 @@ static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint3
         if (v == 0ull) continue;
         const uint32_t own = i >> 6;
         uint32_t rank = i & 63u;
-        for (uint32_t r = 0; r < nruns && rank < k; r++) {
-            if (r == own) continue;
+        // entries of the other runs that come before v: the greater ones — and, in EARLIER runs, equal ones too.  Composites are
+        // distinct by construction (distinct rows), but should a list ever carry a row twice the ranks are still a permutation
+        // (ties ordered by list position) and every slot below cnt is written.  Two loops, one comparison each: a
+        // per-step choice between > and >= cost final_kernel 8.7 -> 12 us at ~600 candidates (profiles/r05j_*).
+        for (uint32_t r = 0; r < own && rank < k; r++) {
             const unsigned long long* run = list + r * 64u;  // descending; zeros (never greater) at its end
-            // lo = entries of this run that come before v: the greater ones — and, in EARLIER runs, equal ones too.  Composites are
-            // distinct by construction (distinct rows), but should a list ever carry a row twice the ranks are still a permutation
-            // (ties ordered by list position) and every slot below cnt is written.
-            const bool ge = r < own;
             uint32_t lo = 0, hi = 64;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (ge ? run[mid] >= v : run[mid] > v) lo = mid + 1u;
+                if (run[mid] >= v) lo = mid + 1u;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        for (uint32_t r = own + 1u; r < nruns && rank < k; r++) {
+            const unsigned long long* run = list + r * 64u;
+            uint32_t lo = 0, hi = 64;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (run[mid] > v) lo = mid + 1u;
                 else hi = mid;
             }
             rank += lo;
