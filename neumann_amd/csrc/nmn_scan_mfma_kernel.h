@@ -5,6 +5,10 @@
 // rate (157 TFLOP/s) would bound it at 6.25 ms per 10M x 768 sweep, above the HBM floor (SURVEY.md §7 hard
 // part b), so the APPROXIMATE pass runs on bf16 MFMA.
 //
+// THREE streamed matrices share this kernel (template parameters I8 / F32): the shard's bf16 mirror (described first), its 8-bit
+// mirror (see `I8` below) and — round 5 — the row-major F32 CORPUS itself (see `F32` below: the f32 rows through the same ring,
+// rounded to bf16 in registers; SURVEY §8(d)'s bytes, and what a shard without a mirror runs).
+//
 // Corpus side: the sweep streams the shard's bf16 MIRROR (`half`, nmn_scan.hip: half_rows_kernel) — 2 bytes per
 // element, the same matrix the 1-4 query VALU sweep reads — so a sweep moves rows*dim*2 bytes.  Its rounding is
 // not compensated in the sweep: the mirror's MEASURED error norms (max |e_r| / |v_r|) go into the candidate margin

@@ -233,7 +233,8 @@ class GpuFlatIndex:
         """What approximate sweeps read.  True / 1 (default): the smallest mirror that serves the shape — the 8-bit mirror for
         1-2 queries over rows whose stride is a multiple of 128 elements up to 4096 (batches: of 256 up to 1536, 2048, 3072), else the bf16
         mirror; a shard keeps one mirror and builds the other only when a call needs it (include/neumann_gpu.h).  2: the bf16 mirror only.  False / 0: the
-        f32 corpus itself (rows*dim*4 bytes per query, SURVEY §8(d)'s pricing).  Results are identical in every mode."""
+        f32 corpus itself (rows*dim*4 bytes per query — or per batch of up to 64-128 queries on the matrix cores —, SURVEY §8(d)'s pricing;
+        set before the rows arrive, no mirror is ever built).  Results are identical in every mode."""
         _capi.check(self._lib.nmn_index_set_mirror(self._h, int(enabled)))
 
     def scan_history(self, stream=None):
