@@ -936,9 +936,11 @@ def main():
         ebs = per_rank(eb2)
         if mode == 1:
             mirror_eb = ebs
-        name = SWEEP[eb2][0]
-        if name in legs or eb2 == elem_bytes:
-            continue  # (a shape the 8-bit sweeps do not serve: mode 1 already was the bf16 mirror; or no mirror fitted at all)
+        # (every decision below is taken from the gathered lists, identical on all ranks: the certificate further down is a collective,
+        #  and a rank whose mirror did not fit must not leave its neighbours waiting in it)
+        name = SWEEP[min(ebs)][0]
+        if name in legs or ebs == headline_eb:
+            continue  # (a shape the 8-bit sweeps do not serve: mode 1 already was the bf16 mirror; or no mirror fitted anywhere)
         k_ms = float(np.mean(scan2)) if scan2 else float("nan")
         b2 = alg_bytes_for(eb2)
         ach = b2 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
