@@ -1,19 +1,7 @@
-O=gpurun_out/r05w; mkdir -p $O
-export TMPDIR=/tmp
-R=$PWD
-timeout 900 python -m pytest tests/test_gpu_parity_basic.py tests/test_gpu_i8_mirror.py tests/test_gpu_edge_cases.py tests/test_gpu_engine.py -x -q 2>&1 | tail -3 > $O/tests.txt
-for v in default default; do
-  if [ $v = default ]; then unset NEUMANN_GPU_LIB; else export NEUMANN_GPU_LIB=$R/neumann_amd/lib/variants/libneumann_gpu_$v.so; fi
-  for shape in "10000000 768" "5000000 1536" "3000000 2048" "20000000 256" "30000000 128"; do set -- $shape
-    rm -rf /tmp/prof_i; ( cd /tmp && rocprofv3 --kernel-trace -d /tmp/prof_i -o p -- python $R/tools/search_child.py --rows $1 --dim $2 --mirror 1 --api device --reps 1 > /dev/null 2>&1 )
-    python - $(find /tmp/prof_i -name "*.db" | head -1) $v $1 $2 <<'PY'
-import sqlite3, sys
-db = sqlite3.connect(sys.argv[1]); v, rows, dim = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-for name, dur in db.execute("select name, end-start from kernels where name like '%ingest_q8%'"):
-    ms = dur / 1e6; gb = rows * dim * 5 / 1e9
-    print(f"{v:9s} {rows} x {dim}: ingest_q8_kernel {ms:.3f} ms  ({gb:.1f} GB read + written -> {gb / ms:.2f} TB/s = {gb / ms / 8:.3f} of 8 TB/s)")
-PY
-  done
-done > $O/ingest_q8_ab.txt 2>&1
-unset NEUMANN_GPU_LIB
-cat $O/tests.txt $O/ingest_q8_ab.txt
+O=gpurun_out/r05s_soak; mkdir -p $O
+timeout 1500 python tools/soak.py --mirror 0 --rows 10000000 --dim 768 --queries 64 --out $O/soak_f32_10Mx768_b64.json > $O/soak_f32_10Mx768_b64.log 2>&1
+timeout 900 python tools/soak.py --mirror 0 --rows 10000000 --dim 768 --queries 128 --corpora iid,clustered --metrics cosine,euclidean --out $O/soak_f32_10Mx768_b128.json > $O/soak_f32_10Mx768_b128.log 2>&1
+timeout 900 python tools/soak.py --mirror 0 --rows 5000000 --dim 1536 --queries 64 --k 1000 --out $O/soak_f32_5Mx1536_k1000.json > $O/soak_f32_5Mx1536_k1000.log 2>&1
+timeout 600 python tools/soak.py --mirror 0 --rows 2000000 --dim 3072 --queries 40 --corpora iid,clustered --out $O/soak_f32_2Mx3072.json > $O/soak_f32_2Mx3072.log 2>&1
+timeout 600 python tools/soak.py --mirror 0 --rows 10000000 --dim 128 --queries 128 --corpora iid,duplicated --out $O/soak_f32_10Mx128_b128.json > $O/soak_f32_10Mx128_b128.log 2>&1
+tail -2 $O/*.log

@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--corpora", default="iid,clustered,duplicated")
     ap.add_argument("--metrics", default="cosine,euclidean,dot")
+    ap.add_argument("--mirror", type=int, default=1, help="nmn_index_set_mirror before the rows arrive: 1 = the library's default, 2 = bf16 only, "
+                    "0 = no mirror: single queries on the f32 VALU sweep, batches on the f32-rows matrix-core sweep (round 5)")
     ap.add_argument("--wide-rows", action="store_true", help="NMN_INDEX_WIDE_ROWS: 300 -> 384 etc., batches on the matrix cores")
     args = ap.parse_args()
 
@@ -63,7 +65,7 @@ def main():
                ("dot", DistanceMetric.DotProduct)]
     metrics = [m for m in metrics if m[0] in args.metrics.split(",")]
     corpora = args.corpora.split(",")
-    report = {"rows": args.rows, "dim": args.dim, "k": args.k, "cases": []}
+    report = {"rows": args.rows, "dim": args.dim, "k": args.k, "mirror": args.mirror, "cases": []}
     bad_total = 0
     n, d, nq = args.rows, args.dim, args.queries
     words = (n + 63) // 64
@@ -127,6 +129,7 @@ def main():
     # --- iid corpus (the bench's) --------------------------------------------------------------
     if "iid" in corpora:
         with GpuFlatIndex(d, n, row_base=0, device=0, wide_rows=args.wide_rows) as idx:
+            idx.set_mirror(args.mirror)
             idx.fill_synthetic(20240601, n)
             q = synth_rows(777, 0, nq, d)
             # half the queries ARE corpus rows (self-match at the top), the rest fresh
@@ -144,6 +147,7 @@ def main():
             return centres[which] + scale[:, None] * torch.randn(m, d, device=dev, generator=g)
 
         with GpuFlatIndex(d, n, row_base=0, device=0, wide_rows=args.wide_rows) as idx:
+            idx.set_mirror(args.mirror)
             fill_chunks(idx, clustered)
             q = (centres[torch.arange(nq, device=dev) % args.clusters]
                  + 1e-3 * torch.randn(nq, d, device=dev, generator=g)).cpu().numpy().astype(np.float32)
@@ -154,6 +158,7 @@ def main():
         base_rows = 100_003
         base = torch.randn(base_rows, d, device=dev, generator=g)
         with GpuFlatIndex(d, n, row_base=0, device=0, wide_rows=args.wide_rows) as idx:
+            idx.set_mirror(args.mirror)
             fill_chunks(idx, lambda r0, m: base[(torch.arange(r0, r0 + m, device=dev) * 7919) % base_rows])
             q = base[:nq].cpu().numpy().astype(np.float32)
             q[nq // 2:] += 0.05 * rng.standard_normal((nq - nq // 2, d)).astype(np.float32)
