@@ -1,7 +1,13 @@
-O=gpurun_out/r05s_soak; mkdir -p $O
-timeout 1500 python tools/soak.py --mirror 0 --rows 10000000 --dim 768 --queries 64 --out $O/soak_f32_10Mx768_b64.json > $O/soak_f32_10Mx768_b64.log 2>&1
-timeout 900 python tools/soak.py --mirror 0 --rows 10000000 --dim 768 --queries 128 --corpora iid,clustered --metrics cosine,euclidean --out $O/soak_f32_10Mx768_b128.json > $O/soak_f32_10Mx768_b128.log 2>&1
-timeout 900 python tools/soak.py --mirror 0 --rows 5000000 --dim 1536 --queries 64 --k 1000 --out $O/soak_f32_5Mx1536_k1000.json > $O/soak_f32_5Mx1536_k1000.log 2>&1
-timeout 600 python tools/soak.py --mirror 0 --rows 2000000 --dim 3072 --queries 40 --corpora iid,clustered --out $O/soak_f32_2Mx3072.json > $O/soak_f32_2Mx3072.log 2>&1
-timeout 600 python tools/soak.py --mirror 0 --rows 10000000 --dim 128 --queries 128 --corpora iid,duplicated --out $O/soak_f32_10Mx128_b128.json > $O/soak_f32_10Mx128_b128.log 2>&1
-tail -2 $O/*.log
+O=gpurun_out/r05z0; mkdir -p $O
+COMMON="--no-cpu-baseline --no-other-configs --batched 0 --callers 0 --no-mirror-legs --no-live-pmc --warmup 3 --steps 20 --rebuilds 2"
+for i in 1 2 3; do
+for v in default strided; do
+if [ $v = strided ]; then export NMN_SCAN_STRIDED=1; else unset NMN_SCAN_STRIDED; fi
+python bench.py $COMMON 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('%-8s %7.1f q/s  %.4f ms/step  kernel %.4f ms  frac %.4f  alone %.4f  certified %s draws %s' % ('$v', d['value'], d['ms_per_step'], r['avg_kernel_ms'], r['frac'], r['avg_kernel_ms_alone'], d['parity']['exact_topk_certified'], ['%.1f'%x for x in d['rebuilds']['queries_per_s']]))"
+done
+done > $O/strided_f32.txt 2>&1
+unset NMN_SCAN_STRIDED
+cat $O/strided_f32.txt
