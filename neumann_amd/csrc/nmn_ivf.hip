@@ -898,13 +898,19 @@ extern "C" nmn_status nmn_ivf_search(nmn_ivf* ivf, const float* queries, uint32_
             const uint32_t nb = std::min<uint32_t>(chunk, nq - q);
             memcpy(pin_q, qh, (size_t)ivf->dim * 4 * nb);
             IVF_TRY(hipMemcpyAsync(sl->qraw, pin_q, (size_t)ivf->dim * 4 * nb, hipMemcpyHostToDevice, s));
-            IVF_TRY(launch_qprep(sl->qraw, nb, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits, sl->qpad,
-                                 sl->qinfo, sl->qstate, 0, s));
+            // The centroid ranking is a squared-distance scan: it reads the first `dim` elements of each query and nothing qprep
+            // derives (no magnitude, no margins).  Where the rows are not padded (stride == dim) and the eight-lanes-per-row scan
+            // serves (fewer than 2^16 centroids) the raw queries ARE the padded ones: no qprep launch in front of it (5.6 us +
+            // a 4-us gap of a lone probe's ~150, profiles/r05q_*).
+            const bool raw_q = ivf->centroids->ld == ivf->dim && ivf->vectors->ld == ivf->dim && ivf->n_clusters < (1u << 16);
+            if (!raw_q)
+                IVF_TRY(launch_qprep(sl->qraw, nb, ivf->dim, ivf->vectors->ld, kMetricNegL2Sq, ivf->centroids->max_norm_bits, sl->qpad,
+                                     sl->qinfo, sl->qstate, 0, s));
             {
                 ExactScanParams ep{};
                 ep.corpus = ivf->centroids->corpus;
                 ep.norms = ivf->centroids->norms;
-                ep.qpad = sl->qpad;
+                ep.qpad = raw_q ? sl->qraw : sl->qpad;
                 ep.qinfo = sl->qinfo;
                 ep.scores = sl->cscores;
                 ep.n_rows = ivf->n_clusters;
