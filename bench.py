@@ -24,7 +24,7 @@ Prints ONE JSON line (rank 0).  The driver's record keeps the top-level scalars 
                 over `--rebuilds` index rebuilds (each: W warmup steps, then EXACTLY K timed steps between a barrier +
                 synchronize on both sides, max over ranks); `rebuilds` lists every draw
   dtype         "f32": what the headline sweep reads and computes in
-  roofline      the dominant kernel of the timed loop (nmn::scan_kernel over the f32 rows).  `avg_kernel_ms` = HIP events the
+  roofline      the dominant kernel of the timed loop (nmn::scan_ring_kernel over the f32 rows; nmn::scan_kernel for bitmaps / small shards).  `avg_kernel_ms` = HIP events the
                 library records on the launch stream around that kernel in EVERY timed step (nmn_index_scan_history), of the
                 very loop `value` comes from; sweeps of a shard never run side by side (the next one starts, on the device, when
                 the previous one ends; the selection / rescore tail of a step runs under the next step's sweep), so kernel <=
@@ -367,6 +367,8 @@ def live_pmc(args):
                     want = "true" if tag == "bf16" else "false"
                     v = [val for name, val in rows
                          if "scan_i8" not in name and (m := re.search(r"scan_kernel<[^>]*?(true|false)>", name)) and m.group(1) == want]
+                    if tag == "f32":  # one unmasked query over the f32 rows of a large shard: the ring sweep (nmn_scan_ring.hip)
+                        v += [val for name, val in rows if "scan_ring_kernel" in name]
                 if not v:
                     continue
                 big = [x for x in v if x * 2 >= max(v)]
@@ -866,9 +868,14 @@ def main():
     def alg_bytes_for(eb):  # excluded rows are never read
         return (kept_rows * args.dim * eb + (local_rows // 8 if mask_dev is not None else 0)) * passes
 
+    # (one unmasked f32 query, >= 4096 tiles, stride a multiple of 128 up to 4096: search_enqueue's use_ring)
+    ld_ring = (args.dim + 7) // 8 * 8 if not kc else ld128
+    ring = (args.nq == 1 and mask_dev is None and local_rows >= 4096 * 64 and ld_ring % 128 == 0 and ld_ring <= 4096
+            and not os.environ.get("NMN_NO_RING"))
+
     def kernel_of(eb):
         return ("nmn::exact_scan_kernel" if args.k > 4096 else "nmn::scan_mfma_kernel" if mfma else
-                "nmn::scan_i8_kernel" if eb == 1 else "nmn::scan_kernel")
+                "nmn::scan_i8_kernel" if eb == 1 else "nmn::scan_ring_kernel" if (eb == 4 and ring) else "nmn::scan_kernel")
 
     alg_bytes = alg_bytes_for(elem_bytes)
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")

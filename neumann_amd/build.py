@@ -20,6 +20,7 @@ ARCH = "gfx950"
 
 SOURCES = {
     "nmn_scan.hip": [],
+    "nmn_scan_ring.hip": [],
     "nmn_scan_mfma.hip": [],
     "nmn_scan_mfma_f32.hip": [],
     "nmn_scan_i8.hip": [],

@@ -1115,6 +1115,20 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }();
             if (use_mfma) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + mfma_wgs - 1) / mfma_wgs);  // per workgroup
             auto launch_batch_sweep = [&](const ScanParams& x) -> hipError_t { return launch_scan_mfma(x, stream); };
+            // One unmasked query over the f32 rows of a large shard (no mirror serves the call — the headline sweep of SURVEY §8(d)):
+            // the ring sweep (nmn_scan_ring.hip: f32 arithmetic, the rows through the LDS-DMA ring) instead of scan_kernel's register
+            // loads.  Workgroups as on the matrix-core path.  NMN_NO_RING=1: the A/B.
+            static const bool no_ring = getenv("NMN_NO_RING") != nullptr;
+            const bool use_ring = !no_ring && !use_mfma && !use_i8 && !use_half && nqc == 1 && !mask_dev && !qmasks_dev && n_tiles >= 4096u &&
+                                  metric != NMN_METRIC_SPARSE_COSINE_F64 && scan_ring_supported(idx->ld, idx->dim, (int)metric);
+            // (4096 workgroups, sixteen per CU in sequence: 0.836 of peak against 0.824-0.829 with 1024 and 0.80 with 256 at 10M x 768,
+            //  profiles/r05z9_*; knob NMN_RING_WGS)
+            static const uint32_t ring_wgs = [] {
+                const char* e = getenv("NMN_RING_WGS");
+                long v = e ? atol(e) : (long)kMaxScanWaves;
+                return (uint32_t)std::min<long>(std::max<long>(v, 64), (long)kMaxScanWaves);
+            }();
+            if (use_ring) sp.tiles_per_wave = std::max<uint32_t>(1, (n_tiles + ring_wgs - 1) / ring_wgs);  // per workgroup
             sp.metric = (int)metric;
             sp.strided = (!use_mfma && mask_dev) ? 1u : 0u;  // masked VALU sweeps: a wave takes every W-th tile (runs of selected rows spread over all waves)
             static const bool no_walk = getenv("NMN_NO_WALK") != nullptr;  // (A/B switch of the survivor walk)
@@ -1218,7 +1232,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sb.bx_count = 0;
                 HIP_TRY(launch_batch_sweep(sb));
             } else {
-                HIP_TRY(use_mfma ? launch_batch_sweep(sp) : use_i8 ? launch_scan_i8(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
+                HIP_TRY(use_mfma ? launch_batch_sweep(sp) : use_i8 ? launch_scan_i8(sp, stream) : use_ring ? launch_scan_ring(sp, stream) : launch_scan(sp, stream));  // (use_mfma && use_i8: sp.corpus_i8 selects the 8-bit form)
             }
             if (w->timed && qa == 0 && !nested) {
                 hipEvent_t& h = w->hist[2 * (w->hist_head % Workspace::kTimingHistory) + 1];

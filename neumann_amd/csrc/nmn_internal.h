@@ -128,6 +128,10 @@ struct ScanParams {
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
+// ONE unmasked query over the f32 rows, f32 arithmetic, the rows streamed through the LDS-DMA ring (nmn_scan_ring.hip);
+// tiles_per_wave = tiles per WORKGROUP there (wmax is indexed by workgroup, as on the matrix-core path)
+bool scan_ring_supported(uint32_t ld, uint32_t dim, int metric);
+hipError_t launch_scan_ring(const ScanParams& p, hipStream_t s);
 // converts rows [row0, row0+n) into the bf16 mirror and folds their rounding-error norms into err_bits[0..1]
 // (row_err2_scratch: n floats of device scratch)
 hipError_t launch_half_rows(const float* corpus, float* half, uint32_t ld, uint64_t row0, uint64_t n, const float* norms,
