@@ -660,6 +660,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                         for (int qg = 0; qg < kBG; qg++) {
                             if constexpr (I8) {
                                 const v4i av = __builtin_bit_cast(v4i, a[ks][rb]);
+#ifdef NMN_MFMA_NO_MFMA  // (measurement build: the fragments are read and folded, no matrix-core work — wrong answers, timing only)
+                                ach[rb][qg] ^= av;
+                                continue;
+#endif
                                 ach[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, bhi[kc * kSteps + ks][qg]), ach[rb][qg], 0, 0, 0);
 #ifndef NMN_MFMA_I8_NO_LO  // (measurement build: the sweep without the l plane's products — wrong answers, timing only)
                                 acl[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, blo[kc * kSteps + ks][qg]), acl[rb][qg], 0, 0, 0);

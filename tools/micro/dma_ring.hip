@@ -205,6 +205,29 @@ int main(int argc, char** argv) {
         run<32768, 4, 2, 512, 8, 2>("SEG  4x32K nt 8 waves + reads + MFMA (each wave whole stage)", buf, bytes, pitch, wgs, sink);
         return 0;
     }
+    if (pitch == 768 && argc > 2) {  // consumption models on the 8-bit sweep's stages
+        for (uint32_t wgs : {256u, 1024u}) {
+            run<16384, 8, 2, 256, 4, 0>("SEG  8x16K nt   ring alone", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 1>("SEG  8x16K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 2>("SEG  8x16K nt   + reads + 1 MFMA per read", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 3>("SEG  8x16K nt   + reads + MFMA + epilogue", buf, bytes, pitch, wgs, sink);
+            run<49152, 3, 2, 768, 4, 1>("ROWS 3x48K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
+            run<49152, 3, 2, 768, 4, 2>("ROWS 3x48K nt   + reads + 1 MFMA per read", buf, bytes, pitch, wgs, sink);
+        }
+        return 0;
+    }
+    if (pitch == 768) {  // the 8-bit mirror of 768-element rows: 256-B segments (the batched sweep's stages) against whole rows
+        for (uint32_t wgs : {256u, 512u, 1024u, 2048u}) {
+            run<16384, 8, 2, 256, 4>("SEG  64x256B  ring 8x16K nt (the 8-bit sweep)", buf, bytes, pitch, wgs, sink);
+            run<49152, 3, 2, 768, 4>("ROWS 64x768B  ring 3x48K nt, swizzled rows", buf, bytes, pitch, wgs, sink);
+            run<49152, 3, 2, 0, 4>("FULL 64 rows  ring 3x48K nt", buf, bytes, pitch, wgs, sink);
+            run<24576, 5, 2, 0, 4>("FULL 32 rows  ring 5x24K nt", buf, bytes, pitch, wgs, sink);
+            run<24576, 6, 2, 0, 4>("FULL 32 rows  ring 6x24K nt", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 0, 4>("FULL 16K      ring 8x16K nt", buf, bytes, pitch, wgs, sink);
+            run<12288, 10, 2, 0, 4>("FULL 16 rows  ring 10x12K nt", buf, bytes, pitch, wgs, sink);
+        }
+        return 0;
+    }
     for (uint32_t wgs : {256u, 512u, 1024u, 2048u}) {
         run<32768, 4, 2, 512, 4>("SEG  64x512B  ring 4x32K nt (round 1)", buf, bytes, pitch, wgs, sink);
         run<32768, 4, 0, 512, 4>("SEG  64x512B  ring 4x32K default", buf, bytes, pitch, wgs, sink);
