@@ -1,12 +1,13 @@
 #!/bin/bash
-# scratch: 2-wave workgroups, two per CU, two query groups per wave (8-bit batched sweep)
-R=$PWD
-python -m pytest tests/test_gpu_batched.py -x -q -k "i8 or q8 or mirror" 2>&1 | tail -2
-for round in 1 2; do
-  unset NEUMANN_GPU_LIB NMN_MFMA_WGS
-  python tools/mfma_loop.py --nq 64 --reps 16 --realloc 2 --mirror 1 --tag default 10000000:768 2>/dev/null
-  export NEUMANN_GPU_LIB=$R/neumann_amd/lib/variants/libneumann_gpu_w2.so
-  for w in 1024 2048; do
-    NMN_MFMA_WGS=$w python tools/mfma_loop.py --nq 64 --reps 16 --realloc 2 --mirror 1 --tag w2_$w 10000000:768 2>/dev/null
-  done
-done
+# scratch: masked ring sweep A/B (config 5 f32) through bench.py's headline loop
+COMMON="--no-cpu-baseline --no-other-configs --batched 0 --callers 0 --no-mirror-legs --no-live-pmc --warmup 3 --rebuilds 1 --dim 1536 --metric euclidean --k 1000 --steps 12"
+for m in 0.5 0.1 0.02 0.004; do
+for mode in ring scan ring256 scan; do
+  unset NMN_NO_RING_MASKED NMN_RING_MASK_WGS
+  if [ $mode = scan ]; then export NMN_NO_RING_MASKED=1; fi
+  if [ $mode = ring256 ]; then export NMN_RING_MASK_WGS=256; fi
+  timeout 120 python bench.py $COMMON --mask $m 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('mask $m %-7s %9.1f q/s  %.4f ms/step  kernel %.4f ms  frac %.3f  certified %s' % ('$mode', d['value'], d['ms_per_step'], r['avg_kernel_ms'], r['frac'], d['parity']['exact_topk_certified'] if d['parity'] else None))"
+done; done

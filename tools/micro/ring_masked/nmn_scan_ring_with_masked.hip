@@ -1,0 +1,540 @@
+// nmn_scan_ring.hip — ONE query over the row-major f32 corpus, f32 arithmetic, the rows streamed through the LDS-DMA ring.
+//
+// The headline sweep of the path (rows * dim * 4 bytes per query; vector_engine/src/lib.rs:2115-2228 is the loop it
+// replaces).  nmn_scan.hip's scan_kernel does the same job with register loads (16 lanes per row, 12 x 16 bytes per lane in
+// flight) and stands at 0.81-0.82 of the 8 TB/s HBM peak; round 5 measured the matrix-core sweep over the SAME f32 rows
+// (nmn_scan_mfma_f32.hip) at 0.85 with three queries (profiles/r05z7_*): what streams faster there is not the matrix core but the
+// data movement — global_load_lds pieces of 1 KiB into a ring of four 32-KiB stages, three always in flight per CU, no VGPRs, no
+// address arithmetic per load in the loop.  This kernel keeps that movement and does the arithmetic the headline must do in f32:
+//   * workgroup = 4 waves = one 64-row tile at a time, a contiguous range of tiles per workgroup; a stage is [64 rows][128 f32];
+//     wave w owns rows 16 w .. 16 w + 15 of every tile and takes them four at a time, SIXTEEN LANES PER ROW (scan_kernel's shape):
+//     lane (r4 = lane >> 4, j = lane & 15) reads the eight f32 at 8 j of row 16 w + 4 sub + r4 of the stage (two ds_read_b128 at the
+//     swizzled chunks 2 j, 2 j + 1; a quarter-wave reads one row's 512 contiguous bytes: no bank conflicts) and multiplies them
+//     into two accumulators per sub-step against the query's eight values for that column slice — the query sits in LDS behind
+//     the ring (two more 16-byte reads per stage and lane, the same 512 bytes for all four quarter-waves), so the stage loop is a
+//     plain loop over the row's ld / 128 stages: one kernel per metric for every row length, ~90 VGPRs.  (Query slices in
+//     registers with the stage loop unrolled measured the same at 768 elements and spilled from 1536 on.)
+//   * per tile: the sixteen lanes of a row meet (four DPP rotations), the row's score is formed as scan_kernel forms it (the same
+//     expressions: the candidate margins of qprep_kernel's plain-f32 case apply unchanged), 16 scores per wave are written, the
+//     tile maximum meets through LDS behind the next stage's barrier, the workgroup maximum at the end — the three-level
+//     hierarchy select_kernel reads, with `tiles_per_wave` = tiles per WORKGROUP as on the matrix-core path.
+// Approximate scores only (any summation order, FMA): exactness is restored by the rescore in the reference's order, as always.
+// Unmasked single queries on shards of >= 4096 tiles and row strides of whole 128-element stages up to 1536; everything else
+// stays on scan_kernel (bitmaps — it reads only the kept rows —, two queries, short shards, the f32 retry, f64 artifact scores).
+#include <algorithm>
+#include <cstdlib>
+
+#include "nmn_internal.h"
+
+namespace nmn {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRingStageBytes = 64 * 128 * 4;  // [64 rows][128 f32] = 32 KiB
+constexpr int kRingStages = 4;                 // 128 KiB, three stages in flight
+constexpr int kRingPieces = 8;                 // 1-KiB LDS-DMA instructions per wave and stage (2 rows x 512 B each)
+constexpr int kRingRowPitch = 128;             // floats between the rows of a stage
+
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// METRIC: NMN_METRIC_COSINE | NMN_METRIC_DOT_PRODUCT (dot products) or NMN_METRIC_EUCLIDEAN (sum of squared differences; kMetricNegL2
+// picks -d over 1 / (1 + d) in the epilogue).  KC = ld / 128 stages per row (runtime).
+template <int METRIC>
+__global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | [8 tiles][64] row magnitudes | [2][4] tile-maximum parts | query [ld]
+    float* const nrm = lds + kRingStages * (kRingStageBytes / 4);
+    uint32_t* const tpart = reinterpret_cast<uint32_t*>(nrm + 8 * 64);  // (8 slots: with one stage per row the ring runs 4 tiles ahead of the epilogue)
+    float* const qlds = nrm + 8 * 64 + 8;
+    const uint32_t KC = p.ld / 128u;
+    constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN;
+    constexpr bool kCos = METRIC == NMN_METRIC_COSINE;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r4 = lane >> 4, j = lane & 15u;
+    const uint32_t ld = p.ld;
+    const uint32_t row_bytes = ld * 4u;
+    const uint32_t bx = blockIdx.x;
+    const uint32_t t0 = bx * p.tiles_per_wave;  // tiles per WORKGROUP on this path
+    if (t0 >= p.n_tiles) return;
+    const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
+    const uint32_t n_stage = (t1 - t0) * KC;
+
+    // ---- the query into LDS (read back per stage: elements 128 kc + 8 j .. + 7 for this lane); visible behind the first stage's barrier
+    for (uint32_t i = threadIdx.x; i < (p.ld >> 2); i += 256u) reinterpret_cast<f4*>(qlds)[i] = reinterpret_cast<const f4*>(p.qpad)[i];
+    const float qmag = p.qinfo[0].qmag;
+
+    // DMA source offsets of this wave's pieces: piece pp = rows 2 (8 wave + pp) + lane / 32, LDS chunk lane % 32, source chunk
+    // (lane % 32) ^ (row & 15) (the swizzle lives on the source side: the LDS side of an LDS-DMA is wave base + lane * 16)
+    uint32_t loff[kRingPieces];
+#pragma unroll
+    for (int pp = 0; pp < kRingPieces; pp++) {
+        const uint32_t r = 2u * (wave * kRingPieces + (uint32_t)pp) + lane / 32u;
+        loff[pp] = r * row_bytes + (((lane % 32u) ^ (r & 15u)) * 16u);
+    }
+    const char* const mat = reinterpret_cast<const char*>(p.corpus);
+    auto stage_src = [&](uint32_t tile_, uint32_t kc_) -> const char* {
+        return mat + (uint64_t)tile_ * kTileRows * row_bytes + (uint64_t)kc_ * 512u;
+    };
+    auto issue_stage = [&](const char* src, uint32_t lmask, uint32_t slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pp = 0; pp < kRingPieces; pp++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (loff[pp] & lmask)),
+                                             (__attribute__((address_space(3))) void*)(lds + slot * (kRingStageBytes / 4) +
+                                                                                        (wave * kRingPieces + (uint32_t)pp) * 256u),
+                                             16, 0, 2);  // non-temporal: the rows are read once
+    };
+    auto norms_dma = [&](uint32_t tile_, uint32_t rel) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.norms + (uint64_t)tile_ * kTileRows + lane),
+                                         (__attribute__((address_space(3))) void*)(nrm + (rel & 7u) * 64u), 4, 0, 0);
+    };
+    // prologue: kRing - 1 stages in flight (dummy pieces where the range is shorter: the counted waits below count on them) — and the
+    // row magnitudes of the tile of stage kRing - 1 as well: its pieces go out in the first iteration, which asks for the magnitudes
+    // of the stage AFTER it only (rows of <= 384 elements start a new tile there)
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < kRingStages; s0++) {
+        if (s0 < n_stage) {
+            if (kCos && wave == 0 && s0 % KC == 0) norms_dma(t0 + s0 / KC, s0 / KC);
+            if (s0 < kRingStages - 1) issue_stage(stage_src(t0 + s0 / KC, s0 % KC), 0xFFFFFFFFu, s0 % kRingStages);
+        } else if (s0 < kRingStages - 1) {
+            issue_stage(mat, 0u, s0 % kRingStages);
+        }
+    }
+    // LDS read offsets (floats) of the four sub-steps: row 16 wave + 4 sub + r4, chunk (2 j) ^ (row & 15) and its partner (^ 4 floats)
+    constexpr int kSub = 4;
+    uint32_t off[kSub];
+#pragma unroll
+    for (int sub = 0; sub < kSub; sub++) {
+        const uint32_t rr = (uint32_t)sub * 4u + r4;  // row within the wave's sixteen (= row & 15 of the tile row 16 wave + rr)
+        off[sub] = (wave * 16u + rr) * kRingRowPitch + (((j * 2u) ^ rr) * 4u);
+    }
+
+    uint32_t wmax = kKeyMasked;   // (wave 0: over the finished tiles of the workgroup)
+    uint32_t sidx = 0;
+    // the stage the loop issues next (stage index sidx + kRingStages - 1), advanced incrementally: a division per stage costs more
+    // scalar instructions than the stage's arithmetic
+    uint32_t nt = t0 + (kRingStages - 1) / KC, nkc = (kRingStages - 1) % KC;
+    for (uint32_t tile = t0; tile < t1; tile++) {
+        float acc[kSub][2];
+#pragma unroll
+        for (int sub = 0; sub < kSub; sub++) acc[sub][0] = acc[sub][1] = 0.f;
+        for (uint32_t kc = 0; kc < KC; kc++, sidx++) {
+            const float* buf = lds + (sidx % kRingStages) * (kRingStageBytes / 4);
+            ring_wait_vm<(kRingStages - 2) * kRingPieces>();  // stage sidx has landed (pieces are issued for every stage, real or dummy)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kc == 0 && wave == 0 && tile > t0) {
+                // the previous tile's maximum: its four parts were written before this barrier
+                const uint32_t* tp = tpart + ((tile - 1u - t0) & 1u) * 4u;
+                const uint32_t m = max(max(tp[0], tp[1]), max(tp[2], tp[3]));
+                if (lane == 0) p.tmax[tile - 1u] = m;
+                wmax = max(wmax, m);
+            }
+            const uint32_t ns = sidx + (kRingStages - 1);
+            const bool issue = ns < n_stage;
+            const char* const nsrc = issue ? stage_src(nt, nkc) : mat;
+            const uint32_t lmask = issue ? 0xFFFFFFFFu : 0u;
+            float* const nbuf = lds + (ns % kRingStages) * (kRingStageBytes / 4);
+            f4 a[kSub][2];
+#pragma unroll
+            for (int sub = 0; sub < kSub; sub++) {
+                a[sub][0] = *reinterpret_cast<const f4*>(buf + off[sub]);
+                a[sub][1] = *reinterpret_cast<const f4*>(buf + (off[sub] ^ 4u));
+            }
+            const f4 q0 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u), q1 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u + 4u);
+#pragma unroll
+            for (int sub = 0; sub < kSub; sub++) {
+                // two pieces of the stage ahead per sub-step, in the shadow of the arithmetic
+#pragma unroll
+                for (int pp = sub * 2; pp < sub * 2 + 2; pp++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
+                                                     (__attribute__((address_space(3))) void*)(nbuf + (wave * kRingPieces + (uint32_t)pp) * 256u), 16, 0, 2);
+                const f4 x0 = a[sub][0], x1 = a[sub][1];
+                if constexpr (kL2) {
+                    const f4 d0 = x0 - q0, d1 = x1 - q1;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        acc[sub][0] = __builtin_fmaf(d0[e], d0[e], acc[sub][0]);
+                        acc[sub][1] = __builtin_fmaf(d1[e], d1[e], acc[sub][1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        acc[sub][0] = __builtin_fmaf(x0[e], q0[e], acc[sub][0]);
+                        acc[sub][1] = __builtin_fmaf(x1[e], q1[e], acc[sub][1]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // row magnitudes of the tile whose first stage goes out in the next iteration
+            if (++nkc == KC) {
+                nkc = 0;
+                nt++;
+            }
+            if (kCos && wave == 0 && ns + 1u < n_stage && nkc == 0) norms_dma(nt, nt - t0);
+        }
+        // ---- the tile's 16 rows of this wave: the sixteen lanes of a row meet (row_ror 8, 4, 2, 1: every lane of the DPP row holds the
+        // sum), then lane (r4, j) finishes row 4 (j & 3) + r4 of the wave's sixteen (four lanes per row: the write below takes j < 4)
+        float v = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < kSub; sub++) {
+            float t = acc[sub][0] + acc[sub][1];
+            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));
+            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));
+            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xF, 0xF, false));
+            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xF, 0xF, false));
+            if ((j & 3u) == (uint32_t)sub) v = t;
+        }
+        const uint32_t wrow = (j & 3u) * 4u + r4;  // this lane's row among the wave's sixteen
+        const uint64_t row = (uint64_t)tile * kTileRows + wave * 16u + wrow;
+        const bool valid = row < p.n_rows;
+        float sc;
+        if constexpr (kCos) {
+            const float vn = nrm[((tile - t0) & 7u) * 64u + wave * 16u + wrow];
+            sc = (vn == 0.f || qmag == 0.f) ? 0.f : v / (qmag * vn);
+        } else if constexpr (kL2) {
+            const float dist = sqrtf(fmaxf(v, 0.f));
+            sc = p.metric == kMetricNegL2 ? -dist : 1.0f / (1.0f + dist);
+        } else {
+            sc = v;
+        }
+        uint32_t key = valid ? score_to_key(sc) : kKeyMasked;
+        if (j < 4u) p.scores[row] = valid ? f2u(sc) : kScoreSentinelBits;  // (nql == 1: score_at(row, 0, 1) == row)
+        // the wave's maximum (every row's key is held by four lanes)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) key = max(key, (uint32_t)__shfl_xor((int)key, o));
+        if (lane == 0) tpart[((tile - t0) & 1u) * 4u + wave] = key;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    ring_wait_vm<0>();  // the dummy pieces of the tail have landed before this workgroup's LDS is handed on
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave == 0) {
+        const uint32_t* tp = tpart + ((t1 - 1u - t0) & 1u) * 4u;
+        const uint32_t m = max(max(tp[0], tp[1]), max(tp[2], tp[3]));
+        wmax = max(wmax, m);
+        if (lane == 0) {
+            p.tmax[t1 - 1u] = m;
+            p.wmax[bx] = wmax;
+        }
+    }
+}
+
+// ---- the same sweep under a predicate bitmap -------------------------------------------------------------------------------------
+// SURVEY §8(d) config 5 prices a filtered query at the KEPT rows' bytes ("masked rows are not read"), so the ring must carry kept
+// rows only.  An LDS-DMA instruction takes one global address PER LANE: a stage need not be 64 consecutive rows.  Here a stage is
+// [64 kept rows][128 f32] of a VIRTUAL tile — the next 64 kept rows of the workgroup's tiles, whatever tiles they sit in:
+//   * the workgroup owns the tiles bx, bx + W, bx + 2 W, ... (the strided assignment of masked sweeps: a selection that is a few
+//     runs of rows spreads over every workgroup) and takes them in CHUNKS: the bitmap words of up to 1024 tiles (four per thread), a
+//     workgroup-wide prefix sum of their popcounts, as many whole tiles as hold <= mask_cap(ld) kept rows; their kept rows are LISTED in
+//     LDS (16-bit entries: tile of the chunk << 6 | row of the tile), a wave and one step per tile;
+//   * the ring then runs over the list exactly as over a contiguous range — same stages, same counted waits, same arithmetic; only
+//     the eight source addresses a lane holds for a stage's pieces come from the list (re-read once per virtual tile).  Slots past
+//     the end of the list re-read its last row (cache hits) and are ignored.  Scores are PARKED in LDS: the loop holds no store, no
+//     row-magnitude load (the kept rows' magnitudes are gathered when the list is built) and no tile maximum;
+//   * after the ring has drained, the chunk's tiles leave as scan_kernel leaves them: a 256-byte block of scores per tile (kept
+//     rows: the parked score, the others: the sentinel), its maximum, nothing for a tile without kept rows but "nobody takes part".
+// Same approximate-score contract as above; select_kernel reads the strided hierarchy as it does behind scan_kernel.
+constexpr uint32_t kMaskChunkTiles = 1024;  // bitmap words looked at at once: four per thread (16-bit list entries: tile of the chunk << 6 | row)
+constexpr uint32_t kMaskCapMax = 2048;      // kept rows listed at once, at most (what the LDS behind the ring and the query leaves decides)
+constexpr uint32_t kMaskFixedBytes = kMaskChunkTiles * 8 + kMaskChunkTiles * 2 + 64;  // bitmap words, list offsets of the tiles, misc
+constexpr uint32_t kMaskLds = 160 * 1024;   // the whole LDS of a CU: one workgroup per CU anyway
+
+// kept rows a chunk may hold: 10 bytes each (list entry, parked score, magnitude) in what the ring, the query and the tiles' words leave
+__host__ __device__ inline uint32_t mask_cap(uint32_t ld) {
+    const uint32_t avail = kMaskLds - kRingStages * kRingStageBytes - ld * 4u - kMaskFixedBytes;
+    const uint32_t c = (avail / 10u) & ~63u;
+    return c < kMaskCapMax ? c : kMaskCapMax;
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(256, 1) scan_ring_masked_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | query [ld] | bitmap words | parked scores | magnitudes | list | offsets | misc
+    float* const qlds = lds + kRingStages * (kRingStageBytes / 4);
+    const uint32_t cap = mask_cap(p.ld);
+    uint64_t* const mw = reinterpret_cast<uint64_t*>(qlds + p.ld);
+    uint32_t* const park = reinterpret_cast<uint32_t*>(mw + kMaskChunkTiles);
+    float* const lnorm = reinterpret_cast<float*>(park + cap);
+    uint16_t* const list = reinterpret_cast<uint16_t*>(lnorm + cap);
+    uint16_t* const toff = list + cap;
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(toff + kMaskChunkTiles);  // [0..3] wave totals of the prefix sum, [4] tiles that fit, [5] their kept rows, [8..11] wave maxima
+    const uint32_t KC = p.ld / 128u;
+    constexpr bool kL2 = METRIC == NMN_METRIC_EUCLIDEAN;
+    constexpr bool kCos = METRIC == NMN_METRIC_COSINE;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r4 = lane >> 4, j = lane & 15u;
+    const uint32_t row_bytes = p.ld * 4u;
+    const uint32_t bx = blockIdx.x, W = gridDim.x, T = p.tiles_per_wave;
+    if (bx >= p.n_tiles) return;
+
+    for (uint32_t i = tid; i < (p.ld >> 2); i += 256u) reinterpret_cast<f4*>(qlds)[i] = reinterpret_cast<const f4*>(p.qpad)[i];
+    const float qmag = p.qinfo[0].qmag;
+    const char* const mat = reinterpret_cast<const char*>(p.corpus);
+
+    constexpr int kSub = 4;
+    uint32_t off[kSub];
+#pragma unroll
+    for (int sub = 0; sub < kSub; sub++) {
+        const uint32_t rr = (uint32_t)sub * 4u + r4;
+        off[sub] = (wave * 16u + rr) * kRingRowPitch + (((j * 2u) ^ rr) * 4u);
+    }
+    uint32_t wmax = kKeyMasked;  // (every lane of a wave: over the tiles the wave wrote out)
+
+    for (uint32_t jc = 0; jc < T;) {
+        // ---- the chunk: bitmap words of the tiles jc + 4 tid .. + 3, as many whole tiles as hold <= cap kept rows
+        const uint32_t n_here = min(kMaskChunkTiles, T - jc);
+        uint64_t w4[4];
+        uint32_t c4[4], tsum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t t = 4u * tid + u, tile = (jc + t) * W + bx;
+            const bool ok = t < n_here && tile < p.n_tiles;
+            w4[u] = ok ? p.mask[tile] : 0ull;
+            if (ok) {
+                const uint64_t left = p.n_rows - (uint64_t)tile * kTileRows;
+                if (left < 64) w4[u] &= (1ull << left) - 1ull;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            c4[u] = (uint32_t)__builtin_popcountll(w4[u]);
+            tsum += c4[u];
+        }
+        uint32_t incl = tsum;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (tid < 8u) misc[4 + tid] = 0u;  // (tiles that fit, their rows)
+        if (lane == 63u) misc[wave] = incl;
+        __syncthreads();
+        for (uint32_t ww = 0; ww < wave; ww++) incl += misc[ww];
+        {
+            uint32_t run = incl - tsum;  // kept rows of the chunk's tiles before this thread's four
+            uint32_t fit_t = 0, fit_rows = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t t = 4u * tid + u;
+                mw[t] = w4[u];
+                toff[t] = (uint16_t)min(run, 0xFFFFu);
+                run += c4[u];
+                if (t < n_here && run <= cap) {  // (monotone in t: the tiles that fit are a prefix; the first always does)
+                    fit_t = t + 1u;
+                    fit_rows = run;
+                }
+            }
+            if (fit_t) {
+                atomicMax(&misc[4], fit_t);
+                atomicMax(&misc[5], fit_rows);
+            }
+        }
+        __syncthreads();
+        const uint32_t n_fit = misc[4], S = misc[5];
+        // tiles nobody of which takes part: their maximum says so, which is all anybody reads of them
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t t = 4u * tid + u, tile = (jc + t) * W + bx;
+            if (t < n_fit && tile < p.n_tiles && w4[u] == 0ull) p.tmax[tile] = kKeyMasked;
+        }
+        // the list.  Few tiles (a dense bitmap): a wave and one step per tile — lane L's row, if kept, goes to the tile's offset +
+        // its rank among the kept; many tiles (a sparse one): every thread walks the bits of its own four tiles
+        if (n_fit <= 128u) {
+            for (uint32_t t = wave; t < n_fit; t += 4u) {
+                const uint64_t tw = mw[t];
+                if ((tw >> lane) & 1ull) list[toff[t] + (uint32_t)__builtin_popcountll(tw & ((1ull << lane) - 1ull))] = (uint16_t)((t << 6) | lane);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t t = 4u * tid + u;
+                if (t >= n_fit) continue;
+                uint64_t tw = w4[u];
+                uint32_t o = toff[t];
+                while (tw) {
+                    list[o++] = (uint16_t)((t << 6) | (uint32_t)__builtin_ctzll(tw));
+                    tw &= tw - 1ull;
+                }
+            }
+        }
+        __syncthreads();
+        auto row_of = [&](uint32_t e) -> uint64_t { return ((uint64_t)(jc + (e >> 6)) * W + bx) * kTileRows + (e & 63u); };
+        if constexpr (kCos) {
+            for (uint32_t i = tid; i < S; i += 256u) lnorm[i] = p.norms[row_of(list[i])];
+        }
+        const uint32_t nvt = (S + 63u) / 64u, n_stage = nvt * KC;
+        if (S) {
+            // ---- the ring over the list
+            const char* srcp[kRingPieces];  // this lane's source of each piece of the stage being ISSUED (first k-segment of its row)
+            auto set_issue_tile = [&](uint32_t vt) __attribute__((always_inline)) {
+#pragma unroll
+                for (int pp = 0; pp < kRingPieces; pp++) {
+                    const uint32_t r = 2u * (wave * kRingPieces + (uint32_t)pp) + lane / 32u;
+                    const uint32_t e = list[min(vt * 64u + r, S - 1u)];
+                    srcp[pp] = mat + row_of(e) * row_bytes + (((lane % 32u) ^ (r & 15u)) * 16u);
+                }
+            };
+            auto issue_stage = [&](bool real, uint32_t kc_, uint32_t slot) __attribute__((always_inline)) {
+#pragma unroll
+                for (int pp = 0; pp < kRingPieces; pp++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(real ? srcp[pp] + kc_ * 512u : mat),
+                                                     (__attribute__((address_space(3))) void*)(lds + slot * (kRingStageBytes / 4) +
+                                                                                                (wave * kRingPieces + (uint32_t)pp) * 256u),
+                                                     16, 0, 2);
+            };
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the bitmap words and magnitudes above: the counted waits below count DMA pieces only)
+            uint32_t it = 0, ikc = 0;  // the stage the loop issues next
+            set_issue_tile(0);
+#pragma unroll
+            for (uint32_t s0 = 0; s0 < kRingStages - 1; s0++) {
+                const bool real = s0 < n_stage;
+                issue_stage(real, ikc, s0);
+                if (real && ++ikc == KC) {
+                    ikc = 0;
+                    if (++it < nvt) set_issue_tile(it);
+                }
+            }
+            uint32_t sidx = 0;
+            for (uint32_t vt = 0; vt < nvt; vt++) {
+                float acc[kSub][2];
+#pragma unroll
+                for (int sub = 0; sub < kSub; sub++) acc[sub][0] = acc[sub][1] = 0.f;
+                for (uint32_t kc = 0; kc < KC; kc++, sidx++) {
+                    const float* buf = lds + (sidx % kRingStages) * (kRingStageBytes / 4);
+                    ring_wait_vm<(kRingStages - 2) * kRingPieces>();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    const uint32_t ns = sidx + (kRingStages - 1);
+                    const bool real = ns < n_stage;
+                    float* const nbuf = lds + (ns % kRingStages) * (kRingStageBytes / 4);
+                    f4 a[kSub][2];
+#pragma unroll
+                    for (int sub = 0; sub < kSub; sub++) {
+                        a[sub][0] = *reinterpret_cast<const f4*>(buf + off[sub]);
+                        a[sub][1] = *reinterpret_cast<const f4*>(buf + (off[sub] ^ 4u));
+                    }
+                    const f4 q0 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u), q1 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u + 4u);
+#pragma unroll
+                    for (int sub = 0; sub < kSub; sub++) {
+#pragma unroll
+                        for (int pp = sub * 2; pp < sub * 2 + 2; pp++)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(real ? srcp[pp] + ikc * 512u : mat),
+                                                             (__attribute__((address_space(3))) void*)(nbuf + (wave * kRingPieces + (uint32_t)pp) * 256u), 16, 0, 2);
+                        const f4 x0 = a[sub][0], x1 = a[sub][1];
+                        if constexpr (kL2) {
+                            const f4 d0 = x0 - q0, d1 = x1 - q1;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                acc[sub][0] = __builtin_fmaf(d0[e], d0[e], acc[sub][0]);
+                                acc[sub][1] = __builtin_fmaf(d1[e], d1[e], acc[sub][1]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                acc[sub][0] = __builtin_fmaf(x0[e], q0[e], acc[sub][0]);
+                                acc[sub][1] = __builtin_fmaf(x1[e], q1[e], acc[sub][1]);
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (real && ++ikc == KC) {  // the next stage to go out opens a new virtual tile: its rows' addresses
+                        ikc = 0;
+                        if (++it < nvt) set_issue_tile(it);
+                    }
+                }
+                float v = 0.f;
+#pragma unroll
+                for (int sub = 0; sub < kSub; sub++) {
+                    float t = acc[sub][0] + acc[sub][1];
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xF, 0xF, false));
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xF, 0xF, false));
+                    if ((j & 3u) == (uint32_t)sub) v = t;
+                }
+                const uint32_t slot = vt * 64u + wave * 16u + (j & 3u) * 4u + r4;  // position in the list of the row this lane finishes
+                if (j < 4u && slot < S) {
+                    float sc;
+                    if constexpr (kCos) {
+                        const float vn = lnorm[slot];
+                        sc = (vn == 0.f || qmag == 0.f) ? 0.f : v / (qmag * vn);
+                    } else if constexpr (kL2) {
+                        const float dist = sqrtf(fmaxf(v, 0.f));
+                        sc = p.metric == kMetricNegL2 ? -dist : 1.0f / (1.0f + dist);
+                    } else {
+                        sc = v;
+                    }
+                    park[slot] = f2u(sc);
+                }
+            }
+            ring_wait_vm<0>();  // (the dummy pieces of the tail)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // ---- the chunk's tiles leave: 256 bytes of scores (kept: parked, others: the sentinel) and the maximum, per tile
+        for (uint32_t t = wave; t < n_fit; t += 4u) {
+            const uint32_t tile = (jc + t) * W + bx;
+            if (tile >= p.n_tiles) break;  // (wave-uniform; later tiles of the chunk lie further out still)
+            const uint64_t tw = mw[t];
+            if (tw == 0ull) continue;  // (its maximum was written when the chunk was listed)
+            const bool set = ((tw >> lane) & 1ull) != 0;
+            const uint32_t bits = set ? park[(uint32_t)toff[t] + (uint32_t)__builtin_popcountll(tw & ((1ull << lane) - 1ull))] : kScoreSentinelBits;
+            p.scores[(uint64_t)tile * kTileRows + lane] = bits;  // (nql == 1)
+            uint32_t key = set ? score_to_key(u2f(bits)) : kKeyMasked;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) key = max(key, (uint32_t)__shfl_xor((int)key, o));
+            if (lane == 0) p.tmax[tile] = key;
+            wmax = max(wmax, key);
+        }
+        jc += n_fit;
+        __syncthreads();  // (list, words and offsets are rewritten by the next chunk)
+    }
+    if (lane == 0) misc[8 + wave] = wmax;
+    __syncthreads();
+    if (tid == 0) p.wmax[bx] = max(max(misc[8], misc[9]), max(misc[10], misc[11]));
+}
+
+template <int METRIC>
+hipError_t launch_ring_metric(const ScanParams& p, hipStream_t s) {
+    const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    const size_t lds = (size_t)kRingStages * kRingStageBytes + 8 * 64 * 4 + 8 * 4 + (size_t)p.ld * 4;
+    if (p.mask) {  // (strided tiles: workgroup b takes b, b + blocks, ...)
+        const size_t mlds = kMaskLds;
+        auto mkern = scan_ring_masked_kernel<METRIC>;
+        hipError_t me = hipFuncSetAttribute(reinterpret_cast<const void*>(mkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+        if (me != hipSuccess) return me;
+        hipLaunchKernelGGL(mkern, dim3(blocks), dim3(256), mlds, s, p);
+        return hipGetLastError();
+    }
+    auto kern = scan_ring_kernel<METRIC>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// one unmasked f32 query, row strides of whole 128-element stages this kernel is built for
+bool scan_ring_supported(uint32_t ld, uint32_t dim, int metric) {
+    if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) return false;
+    return dim <= ld && ld % 128u == 0 && ld >= 128u && ld <= 4096u;  // (the query behind the ring: 16 KiB at 4096 elements)
+}
+
+// p.nq == 1, p.nql == 1, no bitmap, p.tiles_per_wave = tiles per WORKGROUP, tmax / wmax / scores of query 0
+hipError_t launch_scan_ring(const ScanParams& p, hipStream_t s) {
+    switch (p.metric) {
+        case NMN_METRIC_COSINE: return launch_ring_metric<NMN_METRIC_COSINE>(p, s);
+        case NMN_METRIC_EUCLIDEAN:
+        case kMetricNegL2: return launch_ring_metric<NMN_METRIC_EUCLIDEAN>(p, s);
+        default: return launch_ring_metric<NMN_METRIC_DOT_PRODUCT>(p, s);
+    }
+}
+
+}  // namespace nmn
