@@ -65,8 +65,15 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
     const uint32_t t1 = min(t0 + p.tiles_per_wave, p.n_tiles);
     const uint32_t n_stage = (t1 - t0) * KC;
 
-    // ---- the query into LDS (read back per stage: elements 128 kc + 8 j .. + 7 for this lane); visible behind the first stage's barrier
-    for (uint32_t i = threadIdx.x; i < (p.ld >> 2); i += 256u) reinterpret_cast<f4*>(qlds)[i] = reinterpret_cast<const f4*>(p.qpad)[i];
+    // ---- the query into LDS (read back per stage: elements 128 kc + 8 j .. + 7 for this lane), by LDS-DMA as well: 1 KiB per
+    // instruction, wave w takes the KiBs w, w + 4, ...  No register round trip in front of the ring's first pieces — a workgroup's
+    // start is one memory latency, not two, sixteen times per CU and sweep — and these are the OLDEST entries of the wave's in-order
+    // queue: the first stage's counted wait covers them, its barrier makes them visible.
+    for (uint32_t c = wave; c * 256u < ld; c += 4u) {
+        if (c * 256u + lane * 4u < ld)  // (row strides are multiples of 128 floats: the last KiB may be half)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.qpad + c * 256u + lane * 4u),
+                                             (__attribute__((address_space(3))) void*)(qlds + c * 256u), 16, 0, 0);
+    }
     const float qmag = p.qinfo[0].qmag;
 
     // DMA source offsets of this wave's pieces: piece pp = rows 2 (8 wave + pp) + lane / 32, LDS chunk lane % 32, source chunk

@@ -1,8 +1,8 @@
 #!/bin/bash
-# scratch: what sits between two sweeps of the 2-stream pipeline (1M x 768 f32)
-R=$PWD; export TMPDIR=/tmp; cd /tmp
-COMMON="--no-cpu-baseline --no-other-configs --batched 0 --callers 0 --no-mirror-legs --no-live-pmc --warmup 5 --rebuilds 1 --no-parity"
-rm -rf /tmp/tr1
-timeout 300 rocprofv3 --kernel-trace -d /tmp/tr1 -o tr -- python $R/bench.py $COMMON --rows 1000000 --steps 60 > /tmp/tr1.log 2>&1
-DB=$(find /tmp/tr1 -name "*.db" | head -1)
-python $R/tools/trace_gantt.py $DB --kernel scan_ring_kernel --skip 30 --steps 3
+# scratch: ring kernel, query by LDS-DMA: tests + A/B old/new
+R=$PWD
+timeout 600 python -m pytest tests/test_gpu_ring.py -x -q 2>&1 | tail -2
+for r in 1 2 3; do for e in old new; do
+  if [ $e = old ]; then export NEUMANN_GPU_LIB=$R/neumann_amd/lib/variants/libneumann_gpu_old.so; else unset NEUMANN_GPU_LIB; fi
+  python tools/mfma_loop.py --nq 1 --reps 16 --realloc 2 --mirror 0 --tag $e 10000000:768 1000000:768 2>/dev/null
+done; done
