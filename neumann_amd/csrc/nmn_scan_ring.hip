@@ -133,7 +133,9 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
         for (uint32_t kc = 0; kc < KC; kc++, sidx++) {
             const float* buf = lds + (sidx % kRingStages) * (kRingStageBytes / 4);
             ring_wait_vm<(kRingStages - 2) * kRingPieces>();  // stage sidx has landed (pieces are issued for every stage, real or dummy)
-            __builtin_amdgcn_s_barrier();
+            // A wave reads only the rows its OWN pieces brought (rows 16 w .. 16 w + 15 of every stage): its counted wait is all the
+            // hand-over a stage needs.  The workgroup meets once per TILE — for the query (first tile) and the tile maxima's parts.
+            if (kc == 0) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kc == 0 && wave == 0 && tile > t0) {
                 // the previous tile's maximum: its four parts were written before this barrier
