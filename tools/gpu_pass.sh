@@ -1,13 +1,6 @@
 #!/bin/bash
-# scratch: final evidence on the final tree
-R=$PWD; mkdir -p gpurun_out
-( timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error" | tail -3 ) > gpurun_out/suite.txt 2>&1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/suite.txt 2>&1
-cat gpurun_out/suite.txt | tail -3
-timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-tail -c 600 gpurun_out/bench_default.json | head -c 300; echo
-export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/prof1
-timeout 400 rocprofv3 --kernel-trace -d /tmp/prof1 -o p -- python $R/bench.py --steps 20 --warmup 5 --streams 1 --rebuilds 1 --no-other-configs --no-cpu-baseline --callers 0 --no-live-pmc --batched 0 --legs i8 > /tmp/prof1.log 2>&1
-DB=$(find /tmp/prof1 -name "*.db" | head -1)
-python $R/tools/prof_summary.py $DB "python bench.py --steps 20 --warmup 5 --streams 1 --rebuilds 1 --no-other-configs --no-cpu-baseline --callers 0 --no-live-pmc --batched 0 --legs i8  (ONE stream: the headline loop on the f32 corpus, then the 8-bit mirror leg)" > $R/gpurun_out/trace_1stream.txt
-head -8 $R/gpurun_out/trace_1stream.txt | cut -c1-200
+# scratch: exactness soak of the f32 ring sweep after its two late changes
+mkdir -p gpurun_out
+timeout 600 python tools/soak.py --mirror 0 --rows 10000000 --dim 768 --out gpurun_out/soak_f32_10Mx768.json 2>&1 | tail -2
+timeout 400 python tools/soak.py --mirror 0 --rows 10000000 --dim 128 --out gpurun_out/soak_f32_10Mx128.json 2>&1 | tail -2
+timeout 400 python tools/soak.py --mirror 0 --rows 5000000 --dim 1536 --k 1000 --out gpurun_out/soak_f32_5Mx1536.json 2>&1 | tail -2
