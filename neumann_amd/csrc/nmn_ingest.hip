@@ -412,7 +412,7 @@ hipError_t launch_exact_rows(const float* corpus, const float* norms, uint32_t l
     const uint64_t n_tiles = (n_rows + 63) / 64;
     // (one workgroup per CU and some; with many queries in the pass fewer per query: the launch returns at once unless a query is
     //  flagged, and 512 x 64 workgroups that only look at a flag and leave cost 21 us per 64-query batch)
-    const uint32_t per_q = std::min<uint32_t>(512u, std::max<uint32_t>(32u, 2048u / std::max<uint32_t>(nq, 1u)));
+    const uint32_t per_q = std::min<uint32_t>(256u, std::max<uint32_t>(32u, 2048u / std::max<uint32_t>(nq, 1u)));  // (one workgroup per CU: it holds 128 KiB of LDS, and an idle launch waits for as many CUs to fall free under the other stream's sweep)
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_tiles + kWaves - 1) / kWaves, per_q);
     const size_t lds = (size_t)kWaves * kRing * kStageBytes + (size_t)ld * 4;
     const bool l2 = metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2 || metric == kMetricNegL2Sq;
