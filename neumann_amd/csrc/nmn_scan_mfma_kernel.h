@@ -669,7 +669,11 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                                 acl[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, blo[kc * kSteps + ks][qg]), acl[rb][qg], 0, 0, 0);
 #endif
                             } else if constexpr (F32) {
+#ifdef NMN_MFMA_F32_NOCVT  // (measurement build: the fragments go to the matrix cores unconverted — wrong answers, timing only)
+                                if (qg == 0) afrag[rb] = __builtin_bit_cast(s8, raw[ks][rb][0] ^ raw[ks][rb][1]);
+#else
                                 if (qg == 0) afrag[rb] = to_bf16x8(__builtin_bit_cast(f4, raw[ks][rb][0]), __builtin_bit_cast(f4, raw[ks][rb][1]));
+#endif
                                 acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
                             } else {
                                 acc[rb][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rb], bhi[kc * kSteps + ks][qg], acc[rb][qg], 0, 0, 0);
