@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     // interleave more than the overlap returned.)
     // tile maxima of the current group of four tiles (see publish): [wave][query group of the wave][16 queries][4 tiles] in LDS
     uint32_t* const tk_pend = reinterpret_cast<uint32_t*>(nrm + kNormSlots * 64 + (kHalfK ? QG * 64 * 16 : 0));
-    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast) __attribute__((always_inline)) {
+    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4]) __attribute__((always_inline)) {
         constexpr int H = decltype(half_c)::value;
         const uint32_t qn = qn_h[H];
         const bool q_ok = q_ok_h[H];
@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         // C layout: col = lane&15 (query), row = rb*16 + (lane>>4)*4 + reg
         const uint64_t rtile = (uint64_t)ftile * tstep;  // real tile index (sampling pass: every tstep-th)
         const uint64_t r0 = rtile * kTileRows;
-        const float* nslot = nrm + (frel % kNormSlots) * 64u;   // (frel: the tile's position in this workgroup's walk)
+        // (the tile's row magnitudes — inverse magnitudes, 8-bit scales — were read into `npre` at the top of the tile's LAST stage, under
+        //  its MFMAs: the epilogue starts without an LDS round trip)
         const float* nslot2 = nrm2 + (frel % kNormSlots) * 64u;  // (I8, Euclidean)
         (void)nslot2;
         uint64_t mword = ~0ull;
@@ -466,10 +467,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 if constexpr (kScaled) {
                     // (a zero row has inverse magnitude 0: its score is 0 like cosine_similarity's; v_rcp at ingest: 1 ulp,
                     // the margin has 1000x that slack)
-                    sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+                    sc = sc * npre[rb];
                 }
                 if constexpr (kL2) {
-                    const f4 vn = *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+                    const f4 vn = npre[rb];
                     f4 vv = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (I8) vv = *reinterpret_cast<const f4*>(nslot2 + (uint32_t)rb * 16u + g * 4u);
 #pragma unroll
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 u4 w;
                 if constexpr (kLazy) {
                     f4 sc = fin[rb];
-                    if constexpr (kScaled) sc = sc * *reinterpret_cast<const f4*>(nslot + (uint32_t)rb * 16u + g * 4u);
+                    if constexpr (kScaled) sc = sc * npre[rb];
 #pragma unroll
                     for (int e = 0; e < 4; e++) w[e] = f2u(kScaled ? sc[e] * inv_q : sc[e]);
                 } else {
@@ -536,7 +537,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             for (int rb = 0; rb < 4; rb++) {
                 const uint32_t rr = (uint32_t)rb * 16u + g * 4u;  // first of this lane's 4 rows
                 f4 vn = {1.f, 1.f, 1.f, 1.f}, vv = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (kNeedNorms) vn = *reinterpret_cast<const f4*>(nslot + rr);
+                if constexpr (kNeedNorms) vn = npre[rb];
                 if constexpr (I8 && kL2) vv = *reinterpret_cast<const f4*>(nslot2 + rr);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -555,7 +556,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             }
         }
     };
-    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast) __attribute__((always_inline)) {
+    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4]) __attribute__((always_inline)) {
 #ifdef NMN_MFMA_NO_EPILOGUE
         {  // measurement only (-DNMN_MFMA_NO_EPILOGUE build): the sweep without its epilogue (answers are wrong)
             float sink_v = 0.f;
@@ -567,14 +568,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             return;
         }
 #endif
-        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile, frel, flast);
-        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile, frel, flast);
+        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile, frel, flast, npre);
+        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile, frel, flast, npre);
     };
 
     uint32_t sidx = 0;  // running stage index of this workgroup
     for (uint32_t j = j0; j < j1; j++) {
         const uint32_t tile = tile_of(j);
         f4 acc[4][kAccGroups];  // [row block][query group of this wave]
+        f4 npre[4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};  // the tile's per-row factors (see finish_half)
         v4i ach[I8 ? 4 : 1][kAccGroups], acl[I8 ? 4 : 1][kAccGroups];  // (I8) int32 sums of the h plane / the l plane
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
@@ -645,6 +647,13 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                                                  (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            if constexpr (kNeedNorms) {
+                if (kc == KC - 1) {  // (compile time: the stage loop is unrolled)
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++)
+                        npre[rb] = *reinterpret_cast<const f4*>(nrm + ((j - j0) % kNormSlots) * 64u + (uint32_t)rb * 16u + g * 4u);
+                }
+            }
             read_batch(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -729,9 +738,9 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                     acc[rb][0] += *reinterpret_cast<const f4*>(xch + ((grp * 64u + lane) * 4u + (uint32_t)rb) * 4u);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            finish_tile(acc, tile, j - j0, j + 1u == j1);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
+            finish_tile(acc, tile, j - j0, j + 1u == j1, npre);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
         } else {
-            finish_tile(acc, tile, j - j0, j + 1u == j1);
+            finish_tile(acc, tile, j - j0, j + 1u == j1, npre);
         }
     }
     wait_vm_imm<0>();  // the dummy pieces of the tail must have landed before this workgroup's LDS is handed to the next one
