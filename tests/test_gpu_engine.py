@@ -896,3 +896,49 @@ def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
             check()
     check()
     assert eng.count() == len(model)
+
+
+# ---- router-level cases at the engine boundary (integration_tests/tests/distance_metrics.rs:37-140, edge_cases.rs:80-127) -------------
+@pytest.mark.parametrize("name,rows,query,metric,first,second", [
+    ("default_metric", {"vec:1": [1.0, 0.0, 0.0, 0.0], "vec:2": [0.9, 0.1, 0.0, 0.0], "vec:3": [0.0, 1.0, 0.0, 0.0]}, "vec:1", None, "vec:1", "vec:2"),
+    ("cosine", {"cos:1": [1.0, 0.0, 0.0, 0.0], "cos:2": [0.707, 0.707, 0.0, 0.0], "cos:3": [0.0, 1.0, 0.0, 0.0]}, "cos:1", "Cosine", "cos:1", None),
+    ("euclidean", {"euc:1": [0.5, 0.5, 0.5, 0.5], "euc:2": [0.6, 0.5, 0.5, 0.5], "euc:3": [1.0, 1.0, 1.0, 1.0]}, "euc:1", "Euclidean", "euc:1", "euc:2"),
+    ("dot_product", {"dot:1": [1.0, 0.0, 0.0, 0.0], "dot:2": [0.5, 0.5, 0.0, 0.0], "dot:3": [0.0, 0.0, 1.0, 0.0]}, "dot:1", "DotProduct", "dot:1", "dot:2"),
+    ("vector_with_cosine", {"target:1": [1.0, 0.0, 0.0, 0.0], "target:2": [0.8, 0.2, 0.0, 0.0], "target:3": [0.0, 0.0, 1.0, 0.0]},
+     [1.0, 0.0, 0.0, 0.0], "Cosine", "target:1", "target:2"),
+])
+def test_router_level_similar_cases(E, name, rows, query, metric, first, second):  # distance_metrics.rs:37-140
+    engine = E.VectorEngine()
+    for k, v in rows.items():
+        engine.store_embedding(k, v)
+    q = rows[query] if isinstance(query, str) else query
+    res = engine.search_similar(q, 3) if metric is None else engine.search_similar_with_metric(q, 3, getattr(E.DistanceMetric, metric))
+    assert len(res) == 3 and res[0].key == first
+    if second is not None:
+        assert res[1].key == second
+    assert res[0].score >= res[1].score >= res[2].score
+    # ... and the scores are the oracle's, bit for bit
+    keys = list(rows)
+    A = np.array([rows[k] for k in keys], F)
+    er, es = oc.search(A, np.asarray(q, F), 3, {None: 0, "Cosine": 0, "Euclidean": 1, "DotProduct": 2}[metric])
+    assert [r.key for r in res] == [keys[i] for i in er]
+    assert np.array_equal(np.array([r.score for r in res], F).view(np.uint32), es.view(np.uint32))
+
+
+def test_empty_store_then_single_embedding(E):  # edge_cases.rs:80-96
+    engine = E.VectorEngine()
+    q = (np.arange(32, dtype=F) * F(0.03125)).astype(F)
+    assert engine.search_similar(q, 10) == []
+    engine.store_embedding("single", q)
+    res = engine.search_similar(q, 10)
+    assert len(res) == 1 and res[0].key == "single"
+
+
+def test_zero_vector_handling(E):  # edge_cases.rs:98-127
+    engine = E.VectorEngine()
+    z = np.zeros(32, F)
+    engine.store_embedding("zero", z)
+    assert np.array_equal(engine.get_embedding("zero"), z)
+    assert engine.search_similar(z, 10) == []  # (a zero query: Ok([]), lib.rs:1966-1969)
+    res = engine.search_similar_with_metric(z, 10, E.DistanceMetric.Euclidean)
+    assert len(res) == 1 and res[0].key == "zero" and res[0].score == 1.0

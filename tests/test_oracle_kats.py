@@ -211,3 +211,43 @@ def test_sparse_cos64_kats():
     a = np.array([f(q, row) for row in A], np.float32)
     assert np.array_equal(a, onp.sparse_cos64_rows(A, q))
     assert np.array_equal(a, oc.scores_all(A, q, oc.SPARSE_COS64))
+
+
+# ---- router-level cases (integration_tests/tests/distance_metrics.rs:37-140: `SIMILAR ... LIMIT 3 [COSINE|EUCLIDEAN|DOT_PRODUCT]`):
+# the data and the assertions of those tests at the engine boundary the router calls (query_router/src/lib.rs:5429-5439)
+ROUTER_CASES = [  # (name, rows, query, metric, expected first key[, expected second key])
+    ("default_metric", {"vec:1": [1.0, 0.0, 0.0, 0.0], "vec:2": [0.9, 0.1, 0.0, 0.0], "vec:3": [0.0, 1.0, 0.0, 0.0]}, "vec:1", COS, "vec:1", "vec:2"),
+    ("cosine", {"cos:1": [1.0, 0.0, 0.0, 0.0], "cos:2": [0.707, 0.707, 0.0, 0.0], "cos:3": [0.0, 1.0, 0.0, 0.0]}, "cos:1", COS, "cos:1", None),
+    ("euclidean", {"euc:1": [0.5, 0.5, 0.5, 0.5], "euc:2": [0.6, 0.5, 0.5, 0.5], "euc:3": [1.0, 1.0, 1.0, 1.0]}, "euc:1", EUC, "euc:1", "euc:2"),
+    ("dot_product", {"dot:1": [1.0, 0.0, 0.0, 0.0], "dot:2": [0.5, 0.5, 0.0, 0.0], "dot:3": [0.0, 0.0, 1.0, 0.0]}, "dot:1", DOT, "dot:1", "dot:2"),
+    ("vector_with_cosine", {"target:1": [1.0, 0.0, 0.0, 0.0], "target:2": [0.8, 0.2, 0.0, 0.0], "target:3": [0.0, 0.0, 1.0, 0.0]},
+     [1.0, 0.0, 0.0, 0.0], COS, "target:1", "target:2"),
+]
+
+
+@pytest.mark.parametrize("case", ROUTER_CASES, ids=[c[0] for c in ROUTER_CASES])
+def test_router_level_similar_cases(case):  # integration_tests/tests/distance_metrics.rs:37-140
+    _, rows, query, metric, first, second = case
+    keys = list(rows)
+    A = [rows[k] for k in keys]
+    q = rows[query] if isinstance(query, str) else query
+    r, s = both(A, q, 3, metric)
+    assert len(r) == 3 and keys[r[0]] == first
+    if second is not None:
+        assert keys[r[1]] == second
+    assert all(s[i] >= s[i + 1] for i in range(2))
+
+
+def test_empty_store_then_single_embedding():  # integration_tests/tests/edge_cases.rs:80-96
+    q = (np.arange(32, dtype=F) * F(0.03125)).astype(F)
+    r, s = both(np.zeros((0, 32), F), q, 10, COS)
+    assert len(r) == 0
+    r, s = both([q], q, 10, COS)
+    assert list(r) == [0] and abs(s[0] - 1.0) < 1e-6
+
+
+def test_zero_vector_is_stored_and_searched_gracefully():  # integration_tests/tests/edge_cases.rs:98-127
+    z = np.zeros(32, F)
+    r, s = both([z], z, 10, EUC)         # (Euclidean scores a zero query: distance 0 -> 1.0)
+    assert list(r) == [0] and s[0] == 1.0
+    assert oc.compute_similarity(z, z) == 0.0   # cosine of two zero vectors: 0.0, not NaN (lib.rs:2257-2266)
