@@ -942,3 +942,31 @@ def test_zero_vector_handling(E):  # edge_cases.rs:98-127
     assert engine.search_similar(z, 10) == []  # (a zero query: Ok([]), lib.rs:1966-1969)
     res = engine.search_similar_with_metric(z, 10, E.DistanceMetric.Euclidean)
     assert len(res) == 1 and res[0].key == "zero" and res[0].score == 1.0
+
+
+def test_sparse_vectors_in_similarity_search(E):  # integration_tests/tests/sparse_vectors.rs:205-232, 412-438
+    engine = E.VectorEngine()
+    A = np.zeros((10, 64), F)
+    for i in range(10):
+        for j in range(10):
+            A[i, (i * 5 + j) % 64] = np.sin(F((i + j)) * F(0.1), dtype=F)
+        engine.store_embedding(f"sparse:{i}", A[i])
+    q = np.zeros(64, F)
+    for j in range(10):
+        q[j % 64] = np.sin(F(j) * F(0.1), dtype=F)
+    res = engine.search_similar(q, 5)
+    assert len(res) == 5
+    er, es = oc.search(A, q, 5, 0)
+    assert [r.key for r in res] == [f"sparse:{i}" for i in er]
+    assert np.array_equal(np.array([r.score for r in res], F).view(np.uint32), es.view(np.uint32))
+    engine2 = E.VectorEngine()
+    v = np.zeros((3, 100), F)
+    v[0, 0] = 1.0
+    v[1, 0] = v[1, 1] = 0.707
+    v[2, 1] = 1.0
+    for i in range(3):
+        engine2.store_embedding(f"v{i + 1}", v[i])
+    q2 = np.zeros(100, F)
+    q2[0] = 1.0
+    res = engine2.search_similar(q2, 3)
+    assert [r.key for r in res] == ["v1", "v2", "v3"]

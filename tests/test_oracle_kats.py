@@ -251,3 +251,31 @@ def test_zero_vector_is_stored_and_searched_gracefully():  # integration_tests/t
     r, s = both([z], z, 10, EUC)         # (Euclidean scores a zero query: distance 0 -> 1.0)
     assert list(r) == [0] and s[0] == 1.0
     assert oc.compute_similarity(z, z) == 0.0   # cosine of two zero vectors: 0.0, not NaN (lib.rs:2257-2266)
+
+
+def _sparse_rows():  # integration_tests/tests/sparse_vectors.rs:205-232 (values: f32 sin; only the result count is pinned there)
+    A = np.zeros((10, 64), F)
+    for i in range(10):
+        for j in range(10):
+            A[i, (i * 5 + j) % 64] = np.sin(F((i + j)) * F(0.1), dtype=F)
+    q = np.zeros(64, F)
+    for j in range(10):
+        q[j % 64] = np.sin(F(j) * F(0.1), dtype=F)
+    return A, q
+
+
+def test_sparse_vector_in_similarity_search():  # sparse_vectors.rs:205-232
+    A, q = _sparse_rows()
+    r, s = both(A, q, 5, COS)
+    assert len(r) == 5 and r[0] == 0  # (row 0 holds the query's own values)
+
+
+def test_vector_engine_sparse_search():  # sparse_vectors.rs:412-438
+    A = np.zeros((3, 100), F)
+    A[0, 0] = 1.0
+    A[1, 0] = A[1, 1] = 0.707
+    A[2, 1] = 1.0
+    q = np.zeros(100, F)
+    q[0] = 1.0
+    r, s = both(A, q, 3, COS)
+    assert list(r) == [0, 1, 2] and s[0] == 1.0 and s[2] == 0.0
