@@ -906,6 +906,12 @@ def test_random_interleaving_of_stores_deletes_and_searches(E, seed):
     ("dot_product", {"dot:1": [1.0, 0.0, 0.0, 0.0], "dot:2": [0.5, 0.5, 0.0, 0.0], "dot:3": [0.0, 0.0, 1.0, 0.0]}, "dot:1", "DotProduct", "dot:1", "dot:2"),
     ("vector_with_cosine", {"target:1": [1.0, 0.0, 0.0, 0.0], "target:2": [0.8, 0.2, 0.0, 0.0], "target:3": [0.0, 0.0, 1.0, 0.0]},
      [1.0, 0.0, 0.0, 0.0], "Cosine", "target:1", "target:2"),
+    # query_router/src/lib.rs:9436-9524
+    ("router_cosine", {"cos_a": [1.0, 0.0], "cos_b": [0.0, 1.0], "cos_c": [0.707, 0.707]}, [1.0, 0.0], "Cosine", "cos_a", "cos_c"),
+    ("router_euclidean", {"euc_a": [1.0, 0.0], "euc_b": [2.0, 0.0], "euc_c": [10.0, 0.0]}, [1.0, 0.0], "Euclidean", "euc_a", "euc_b"),
+    ("router_euclidean_zero_query", {"zero_origin": [0.0, 0.0], "zero_unit": [1.0, 0.0], "zero_far": [10.0, 0.0]}, [0.0, 0.0], "Euclidean",
+     "zero_origin", "zero_unit"),
+    ("router_dot_product", {"dot_a": [1.0, 0.0], "dot_b": [2.0, 0.0], "dot_c": [0.5, 0.0]}, [1.0, 0.0], "DotProduct", "dot_b", "dot_a"),
 ])
 def test_router_level_similar_cases(E, name, rows, query, metric, first, second):  # distance_metrics.rs:37-140
     engine = E.VectorEngine()

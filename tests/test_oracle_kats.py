@@ -222,6 +222,11 @@ ROUTER_CASES = [  # (name, rows, query, metric, expected first key[, expected se
     ("dot_product", {"dot:1": [1.0, 0.0, 0.0, 0.0], "dot:2": [0.5, 0.5, 0.0, 0.0], "dot:3": [0.0, 0.0, 1.0, 0.0]}, "dot:1", DOT, "dot:1", "dot:2"),
     ("vector_with_cosine", {"target:1": [1.0, 0.0, 0.0, 0.0], "target:2": [0.8, 0.2, 0.0, 0.0], "target:3": [0.0, 0.0, 1.0, 0.0]},
      [1.0, 0.0, 0.0, 0.0], COS, "target:1", "target:2"),
+    # query_router/src/lib.rs:9436-9524 (parsed_similar_{cosine,euclidean,euclidean_zero_query,dot_product}_metric)
+    ("router_cosine", {"cos_a": [1.0, 0.0], "cos_b": [0.0, 1.0], "cos_c": [0.707, 0.707]}, [1.0, 0.0], COS, "cos_a", "cos_c"),
+    ("router_euclidean", {"euc_a": [1.0, 0.0], "euc_b": [2.0, 0.0], "euc_c": [10.0, 0.0]}, [1.0, 0.0], EUC, "euc_a", "euc_b"),
+    ("router_euclidean_zero_query", {"zero_origin": [0.0, 0.0], "zero_unit": [1.0, 0.0], "zero_far": [10.0, 0.0]}, [0.0, 0.0], EUC, "zero_origin", "zero_unit"),
+    ("router_dot_product", {"dot_a": [1.0, 0.0], "dot_b": [2.0, 0.0], "dot_c": [0.5, 0.0]}, [1.0, 0.0], DOT, "dot_b", "dot_a"),
 ]
 
 
