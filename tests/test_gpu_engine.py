@@ -976,3 +976,57 @@ def test_sparse_vectors_in_similarity_search(E):  # integration_tests/tests/spar
     q2[0] = 1.0
     res = engine2.search_similar(q2, 3)
     assert [r.key for r in res] == ["v1", "v2", "v3"]
+
+
+def test_search_filtered_typed_comparisons(E):  # lib.rs:7491-7700
+    FC = E.FilterCondition
+
+    def engine_with(items):
+        e = E.VectorEngine()
+        for key, vec, meta in items:
+            if meta is None:
+                e.store_embedding(key, vec)
+            else:
+                e.store_embedding_with_metadata(key, vec, meta)
+        return e
+
+    # search_filtered_float_comparison (7491-7519)
+    e = engine_with([("high", [1.0, 0.0], {"score": 0.95}), ("low", [0.0, 1.0], {"score": 0.5})])
+    r = e.search_similar_filtered([1.0, 0.0], 10, FC.Gt("score", 0.8))
+    assert len(r) == 1 and r[0].key == "high"
+    # search_filtered_mixed_int_float_comparison (7522-7541): a float field against an int filter value
+    e = engine_with([("item", [1.0, 0.0], {"value": 50.5})])
+    assert len(e.search_similar_filtered([1.0, 0.0], 10, FC.Gt("value", 50))) == 1
+    # search_filtered_int_vs_float_filter (7544-7572): an int field against a float filter value, and the boundary 100 > 100.0
+    e = engine_with([("item", [1.0, 0.0], {"count": 100})])
+    assert len(e.search_similar_filtered([1.0, 0.0], 10, FC.Gt("count", 50.5))) == 1
+    assert e.search_similar_filtered([1.0, 0.0], 10, FC.Gt("count", 100.0)) == []
+    # search_filtered_null_comparison (7575-7601): an explicit null matches Eq(Null), a missing field does not
+    e = engine_with([("with_null", [1.0, 0.0], {"optional": None}), ("without_field", [0.0, 1.0], None)])
+    r = e.search_similar_filtered([1.0, 0.0], 10, FC.Eq("optional", None))
+    assert len(r) == 1 and r[0].key == "with_null"
+    # search_filtered_string_comparison (7604-7644): lexicographic order
+    e = engine_with([("item1", [1.0, 0.0], {"name": "apple"}), ("item2", [0.0, 1.0], {"name": "banana"})])
+    assert len(e.search_similar_filtered([1.0, 1.0], 10, FC.Gt("name", "app"))) == 2
+    r = e.search_similar_filtered([1.0, 1.0], 10, FC.Le("name", "apple"))
+    assert len(r) == 1 and r[0].key == "item1"
+    # search_filtered_bool_false (7647-7676)
+    e = engine_with([("active_item", [1.0, 0.0], {"active": True}), ("inactive_item", [0.0, 1.0], {"active": False})])
+    r = e.search_similar_filtered([1.0, 1.0], 10, FC.Eq("active", False))
+    assert len(r) == 1 and r[0].key == "inactive_item"
+    # search_filtered_incompatible_types (7679-7698)
+    e = engine_with([("item", [1.0, 0.0], {"value": "text"})])
+    assert e.search_similar_filtered([1.0, 0.0], 10, FC.Eq("value", 42)) == []
+    # search_filtered_contains / starts_with on their own stores (7155-7258)
+    e = engine_with([("item1", [1.0, 0.0], {"description": "blue shirt"}), ("item2", [0.0, 1.0], {"description": "red pants"})])
+    r = e.search_similar_filtered([1.0, 0.0], 10, FC.Contains("description", "shirt"))
+    assert len(r) == 1 and r[0].key == "item1"
+    e = engine_with([("item1", [1.0, 0.0], {"sku": "ABC123"}), ("item2", [0.0, 1.0], {"sku": "XYZ789"})])
+    r = e.search_similar_filtered([1.0, 0.0], 10, FC.StartsWith("sku", "ABC"))
+    assert len(r) == 1 and r[0].key == "item1"
+    e = engine_with([("item", [1.0, 0.0], {"count": 123})])
+    assert e.search_similar_filtered([1.0, 0.0], 10, FC.StartsWith("count", "1")) == []
+    assert e.search_similar_filtered([1.0, 0.0], 10, FC.Contains("count", "2")) == []
+    # search_filtered_missing_field (7261-7274)
+    e = engine_with([("item", [1.0, 0.0], None)])
+    assert e.search_similar_filtered([1.0, 0.0], 10, FC.Eq("missing", 42)) == []
