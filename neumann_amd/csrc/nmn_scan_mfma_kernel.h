@@ -362,7 +362,9 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     // ---- epilogue of one tile: scores, per-(query,tile) maximum, score writes — for the accumulators `facc` of tile `ftile`.
     // (One wave per SIMD: nothing overlaps it, so it is kept short — see kLazy below.  Deferring it into the next tile's first
     // stage was tried: its branches (partial tiles, score writes) cut that stage's basic block in two and cost the read / MFMA
-    // interleave more than the overlap returned.)
+    // interleave more than the overlap returned.  Round 5 tried it again branch-free: the arithmetic in seven chunks behind the MFMAs of the
+    // next tile's first seven k-steps, predicated by selects, the stores behind its second stage — exact (117 tests), f32 rows 4.91 vs
+    // 4.93 ms, bf16 mirror 2.60 vs 2.66: nothing / worse; tools/micro/mfma_deferred_epilogue.patch, profiles/r05zj_*.)
     // tile maxima of the current group of four tiles (see publish): [wave][query group of the wave][16 queries][4 tiles] in LDS
     uint32_t* const tk_pend = reinterpret_cast<uint32_t*>(nrm + kNormSlots * 64 + (kHalfK ? QG * 64 * 16 : 0));
     auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4]) __attribute__((always_inline)) {
