@@ -83,13 +83,33 @@ __global__ void __launch_bounds__(WAVES * 64, 1) ring_kernel(const char* __restr
     s8v bfrag[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) bfrag[i] = (s8v){(short)(lane + i), 1, 2, 3, 4, 5, 6, (short)i};
+    // WORK >= 4: the 8-bit batched sweep's arithmetic — two v_mfma_i32_16x16x64_i8 per fragment read (query planes h and l: 24 stationary
+    // fragments of 4 VGPRs each, as at 768 elements), eight int32 accumulators; WORK >= 5: + its tile epilogue every 3 stages (planes combined in
+    // float, per-row factors from LDS, tile maximum, key, the four lane groups' meeting, the pending maximum in LDS, a 16-byte store per query
+    // every fourth tile); WORK == 6: + the stage's DMA pieces spread over its k-steps instead of one burst behind the barrier.
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    v4i_ ih[4] = {}, il[4] = {};
+    v4i_ qh[12], ql[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        qh[i] = (v4i_){(int)(lane * 3 + i), 2 * i + 1, (int)lane, 7 - i};
+        ql[i] = (v4i_){(int)(lane + 5 * i), i - 3, 11, (int)(lane ^ i)};
+    }
+    float* const facs = lds + RING * (STAGE / 4);                                   // [64] per-row factors (WORK >= 5; 4 KiB behind the ring)
+    uint32_t* const pend = reinterpret_cast<uint32_t*>(lds + RING * (STAGE / 4) + 64) + (wave * 16u + (lane & 15u)) * 4u;
+    if constexpr (WORK >= 5) {
+        if (threadIdx.x < 64) facs[threadIdx.x] = 1.0f / (1.0f + threadIdx.x);
+    }
+    uint32_t wmaxk = 0, tile_no = 0;
     for (uint32_t s = 0; s < n_stage; s++) {
         const uint32_t after = n_stage - 1u - s < (uint32_t)(RING - 2) ? n_stage - 1u - s : (uint32_t)(RING - 2);
         if (after == RING - 2) wait_vm<(RING - 2) * PIECES>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + RING - 1 < n_stage) issue(s + RING - 1);
+        if constexpr (WORK != 6) {
+            if (s + RING - 1 < n_stage) issue(s + RING - 1);
+        }
         const float* buf = lds + (s % RING) * (STAGE / 4);
         if constexpr (WORK == 0) {
             // consume: every wave reads a quarter of the stage (4 ds_read_b128)
@@ -103,6 +123,26 @@ __global__ void __launch_bounds__(WAVES * 64, 1) ring_kernel(const char* __restr
             if constexpr (WORK == 1) {
 #pragma unroll
                 for (int i = 0; i < NR; i++) acc[0] += __uint_as_float(a[i][0] ^ a[i][3]);
+            } else if constexpr (WORK >= 4) {
+                const uint32_t kc3 = s % 3u;
+                const bool live = s + RING - 1 < n_stage;
+#pragma unroll
+                for (int i = 0; i < NR; i++) {
+                    const int ks = i / 4, rb = i % 4;
+                    const v4i_ av = __builtin_bit_cast(v4i_, a[i]);
+                    // (fragment index by stage of the tile: a select chain keeps the three sets in registers)
+                    const v4i_ fh = kc3 == 0 ? qh[ks] : kc3 == 1 ? qh[4 + ks] : qh[8 + ks];
+                    const v4i_ fl = kc3 == 0 ? ql[ks] : kc3 == 1 ? ql[4 + ks] : ql[8 + ks];
+                    ih[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, fh, ih[rb], 0, 0, 0);
+                    il[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, fl, il[rb], 0, 0, 0);
+                    if constexpr (WORK == 6) {
+                        if (rb == 3 && PIECES >= 4) {  // one piece of the stage ahead per k-step
+                            const uint32_t sn = s + RING - 1;
+                            if (live) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stage_src(sn) + loff[ks * PIECES / 4]),
+                                                                      (__attribute__((address_space(3))) void*)(lds + (sn % RING) * (STAGE / 4) + (wave * PIECES + ks * PIECES / 4) * 256u), 16, 0, AUX);
+                        }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < NR; i++)
@@ -126,7 +166,44 @@ __global__ void __launch_bounds__(WAVES * 64, 1) ring_kernel(const char* __restr
                 if ((lane >> 4) == 0) sink[64 + ((blockIdx.x * WAVES + wave) * 16u + (lane & 15u))] = m;
             }
         }
+        if constexpr (WORK >= 5) {
+            if (s % 3 == 2) {  // the tile's epilogue
+                const uint32_t g = lane >> 4;
+                float m = -1e30f;
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const v4f nv = *reinterpret_cast<const v4f*>(facs + rb * 16 + g * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float v = ((float)ih[rb][e] + (float)il[rb][e] * 0.00390625f) * nv[e];
+                        m = __builtin_fmaxf(m, v);
+                    }
+                    ih[rb] = (v4i_){0, 0, 0, 0};
+                    il[rb] = (v4i_){0, 0, 0, 0};
+                }
+                m *= 0.37f;
+                uint32_t key = __float_as_uint(m);
+                key = (key & 0x80000000u) ? ~key : (key | 0x80000000u);
+                if constexpr (WORK != 8) {
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+                    key = max((uint32_t)r32[0], (uint32_t)r32[1]);
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+                    key = max((uint32_t)r16[0], (uint32_t)r16[1]);
+                }
+                const uint32_t slot = tile_no & 3u;
+                if (g == 0 && WORK != 8) pend[slot] = key;
+                if (slot == 3u && WORK != 7 && WORK != 8) {
+                    if (g == 0) {
+                        const u4v v = *reinterpret_cast<const u4v*>(pend);
+                        *reinterpret_cast<u4v*>(sink + 4096 + ((size_t)((blockIdx.x * WAVES + wave) * 16u + (lane & 15u)) % 4096u) * 1024u + (tile_no & ~3u) % 1024u) = v;
+                    }
+                }
+                wmaxk = max(wmaxk, key);
+                tile_no++;
+            }
+        }
     }
+    if constexpr (WORK >= 4) acc[0] += (float)(ih[0][0] + il[1][1] + ih[2][2] + il[3][3]) + (float)wmaxk;
     if constexpr (WORK >= 2) acc += macc[0] + macc[1] + macc[2] + macc[3];
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = acc.x;
 }
@@ -143,7 +220,7 @@ static void run(const char* name, const char* src, uint64_t total_bytes, uint32_
         return;
     }
     auto k = ring_kernel<STAGE, RING, AUX, SEGB, WAVES, WORK>;
-    const size_t lds = (size_t)STAGE * RING;
+    const size_t lds = (size_t)STAGE * RING + (WORK >= 5 ? 4096 + 256 : 0);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         printf("%-44s: LDS %zu too large\n", name, lds);
         return;
@@ -184,7 +261,7 @@ int main(int argc, char** argv) {
     const uint64_t bytes = rows * pitch;
     char* buf = nullptr;
     float* sink = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&sink), 64) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&sink), (size_t)64 << 20) != hipSuccess) {
         printf("alloc failed\n");
         return 1;
     }
@@ -192,6 +269,22 @@ int main(int argc, char** argv) {
     else hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(buf), (size_t)(bytes / 4));
     hipDeviceSynchronize();
     printf("mirror %.2f GB, row pitch %u B\n", bytes / 1e9, pitch);
+    if (pitch == 768 && argc > 2) {  // consumption models on the 8-bit sweep's stages
+        for (uint32_t wgs : {256u, 1024u}) {
+            run<16384, 8, 2, 256, 4, 0>("SEG  8x16K nt   ring alone", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 1>("SEG  8x16K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 2>("SEG  8x16K nt   + reads + 1 MFMA per read", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 3>("SEG  8x16K nt   + reads + MFMA + epilogue", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 4>("SEG  8x16K nt   + reads + 2 i8 MFMAs per read", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 5>("SEG  8x16K nt   + 2 i8 MFMAs + the sweep's epilogue", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 6>("SEG  8x16K nt   + ... + DMA pieces spread over k-steps", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 7>("SEG  8x16K nt   + epilogue without the group store", buf, bytes, pitch, wgs, sink);
+            run<16384, 8, 2, 256, 4, 8>("SEG  8x16K nt   + epilogue: combine + factors + max only", buf, bytes, pitch, wgs, sink);
+            run<49152, 3, 2, 768, 4, 1>("ROWS 3x48K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
+            run<49152, 3, 2, 768, 4, 2>("ROWS 3x48K nt   + reads + 1 MFMA per read", buf, bytes, pitch, wgs, sink);
+        }
+        return 0;
+    }
     if (argc > 2) {  // consumption models on the two layouts, 1024 workgroups
         const uint32_t wgs = 1024;
         run<32768, 4, 2, 512, 4, 0>("SEG  4x32K nt   ring alone", buf, bytes, pitch, wgs, sink);
@@ -203,17 +296,6 @@ int main(int argc, char** argv) {
         run<24576, 6, 2, 0, 4, 3>("FULL 6x24K nt   + reads + MFMA + epilogue", buf, bytes, pitch, wgs, sink);
         run<16384, 8, 2, 256, 4, 2>("SEG  8x16K nt   + reads + MFMA", buf, bytes, pitch, wgs, sink);
         run<32768, 4, 2, 512, 8, 2>("SEG  4x32K nt 8 waves + reads + MFMA (each wave whole stage)", buf, bytes, pitch, wgs, sink);
-        return 0;
-    }
-    if (pitch == 768 && argc > 2) {  // consumption models on the 8-bit sweep's stages
-        for (uint32_t wgs : {256u, 1024u}) {
-            run<16384, 8, 2, 256, 4, 0>("SEG  8x16K nt   ring alone", buf, bytes, pitch, wgs, sink);
-            run<16384, 8, 2, 256, 4, 1>("SEG  8x16K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
-            run<16384, 8, 2, 256, 4, 2>("SEG  8x16K nt   + reads + 1 MFMA per read", buf, bytes, pitch, wgs, sink);
-            run<16384, 8, 2, 256, 4, 3>("SEG  8x16K nt   + reads + MFMA + epilogue", buf, bytes, pitch, wgs, sink);
-            run<49152, 3, 2, 768, 4, 1>("ROWS 3x48K nt   + whole-stage reads", buf, bytes, pitch, wgs, sink);
-            run<49152, 3, 2, 768, 4, 2>("ROWS 3x48K nt   + reads + 1 MFMA per read", buf, bytes, pitch, wgs, sink);
-        }
         return 0;
     }
     if (pitch == 768) {  // the 8-bit mirror of 768-element rows: 256-B segments (the batched sweep's stages) against whole rows
