@@ -62,6 +62,11 @@ constexpr int kStageK = 128;     // granularity of the row length this kernel ac
 #ifndef NMN_MFMA_OCC
 #define NMN_MFMA_OCC 1
 #endif
+#ifdef NMN_MFMA_NO_FENCES  // (measurement build: the stage body left to the compiler's scheduler)
+#define NMN_MFMA_FENCE() do { } while (0)
+#else
+#define NMN_MFMA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 constexpr int kRingBytes = NMN_MFMA_RING_KB * 1024;  // LDS given to the DMA ring: 8 stages of 16 KiB or 4 of 32 KiB
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -647,7 +652,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             for (int pp = 0; pp < kPieces; pp++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
                                                  (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
-            __builtin_amdgcn_sched_barrier(0);
+            NMN_MFMA_FENCE();
 #endif
             if constexpr (kNeedNorms) {
                 if (kc == KC - 1) {  // (compile time: the stage loop is unrolled)
@@ -657,7 +662,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 }
             }
             read_batch(0);
-            __builtin_amdgcn_sched_barrier(0);
+            NMN_MFMA_FENCE();
 #pragma unroll
             for (int b = 0; b < kNB; b++) {
                 if (b + 1 < kNB) read_batch(b + 1);
@@ -698,7 +703,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
                                                          (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
+                    NMN_MFMA_FENCE();
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
