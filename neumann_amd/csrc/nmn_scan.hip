@@ -135,6 +135,20 @@ __device__ __forceinline__ void row_partial(const v4f* __restrict__ rowp, bool a
 // is processed in COMPACTED steps — the 4 DPP rows of the wave always read 4 participating corpus rows — instead
 // of 16 fixed steps in which most 16-lane groups would idle and the wave would keep a quarter of its loads in flight.
 constexpr uint32_t kCompactMaxRows = 40;
+// The survivor walk of sparse bitmaps (round 5; nmn_scan_i8.hip has had it since round 3): a wave lists the participating rows of up to
+// 64 of its tiles at once (at most kWalkRows: eight full tiles always fit) and reads them four per step straight down the list — every
+// step full whatever the tile borders, no per-tile chain of dependent round trips (bitmap -> rows -> store); the scores are parked in
+// LDS and the tiles' 256-byte score blocks and maxima written at the end.  Taken when the 64 tiles hold on average at most
+// kWalkDense participating rows each (denser tiles are cheaper tile by tile); NMN_NO_WALK=1 (nmn_api.hip) turns it off.
+constexpr uint32_t kWalkRows = 512;
+#ifndef NMN_F32_WALK_DENSE
+#define NMN_F32_WALK_DENSE 20u
+#endif
+constexpr uint32_t kWalkDense = NMN_F32_WALK_DENSE;
+template <int N>
+__device__ __forceinline__ float row_share(float v) {  // lane N of the caller's 16-lane DPP row, to all of its lanes
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + N, 0xF, 0xF, false));
+}
 
 // METRIC: nmn_metric.  MASKED: predicate bitmap present.  NQ: queries per pass over the corpus.
 // CH: float4 loads per lane per chunk (CH KiB in flight per wave).  FULL: ld4 % (16*CH) == 0, no
@@ -194,7 +208,115 @@ __global__ void __launch_bounds__(256) scan_kernel(ScanParams p) {
             // from memory put one more load latency on every tile's dependent chain (word -> row addresses -> rows)
             if ((rel & 63u) == 0) {
                 const uint32_t tl = tile_at(rel + lane);
-                mcache = (rel + lane < p.tiles_per_wave && tl < p.n_tiles) ? p.mask[tl] : 0ull;
+                const bool tl_ok = rel + lane < p.tiles_per_wave && tl < p.n_tiles;
+                mcache = tl_ok ? p.mask[tl] : 0ull;
+                if (tl_ok) {
+                    const uint64_t left = p.n_rows - (uint64_t)tl * kTileRows;
+                    if (left < 64) mcache &= (1ull << left) - 1ull;
+                }
+                // (one or two queries per pass; the f64 artifact metric keeps its own trust rules in the tile-by-tile epilogue)
+                bool walk_here = NQ <= 2 && p.walk != 0 && p.metric != NMN_METRIC_SPARSE_COSINE_F64;
+                const uint32_t n_here = min(64u, p.tiles_per_wave - rel);
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(mcache);
+                if (walk_here) {
+                    uint32_t tot = cnt;
+#pragma unroll
+                    for (uint32_t d = 1; d < 64; d <<= 1) tot += (uint32_t)__shfl_xor((int)tot, d);
+                    walk_here = tot <= kWalkDense * n_here;
+                }
+                if (walk_here) {  // (wave-uniform) ---- the survivor walk: these (up to) 64 tiles at once
+                    float* const wbase = qs + (size_t)NQ * ld + 4 * (NQ * 64) + 4 * 64;  // behind the queries, the staging arrays and the rank tables
+                    uint16_t* const wtab = reinterpret_cast<uint16_t*>(wbase) + (threadIdx.x >> 6) * kWalkRows;
+                    uint32_t* const wsc = reinterpret_cast<uint32_t*>(wbase + 4 * (kWalkRows / 2)) + (threadIdx.x >> 6) * (NQ * kWalkRows);
+                    uint32_t incl = cnt;
+#pragma unroll
+                    for (uint32_t d = 1; d < 64; d <<= 1) {
+                        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+                        if (lane >= d) incl += t;
+                    }
+                    uint32_t base_lane = 0, base_cnt = 0;
+                    while (base_lane < n_here) {
+                        const uint64_t fit = __ballot(lane >= base_lane && lane < n_here && incl - base_cnt <= kWalkRows);
+                        const uint32_t end_lane = base_lane + (uint32_t)__builtin_popcountll(fit);  // (>= base_lane + 8 or n_here)
+                        const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(end_lane - 1)) - base_cnt;
+                        const bool mine = lane >= base_lane && lane < end_lane;
+                        const uint32_t off = incl - cnt - base_cnt;
+                        if (mine) {
+                            uint64_t w = mcache;
+                            uint32_t o = off;
+                            while (w) {
+                                wtab[o++] = (uint16_t)((lane << 6) | (uint32_t)__builtin_ctzll(w));
+                                w &= w - 1;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t s0 = 0; s0 < S; s0 += 4u) {
+                            const uint32_t e = s0 + grp < S ? (uint32_t)wtab[s0 + grp] : 0xFFFFu;
+                            const bool active = e != 0xFFFFu;
+                            const uint64_t row = active ? (uint64_t)tile_at(rel + (e >> 6)) * kTileRows + (e & 63u) : 0ull;
+                            float f = 0.f;  // lane 0 of the row's sixteen fetches its magnitude, ahead of the row itself
+                            if constexpr (METRIC == NMN_METRIC_COSINE) {
+                                if (active && j == 0) f = p.norms[row];
+                            }
+                            float acc[NQ];
+                            row_partial<METRIC, NQ, CH, FULL, NT, HALF>(reinterpret_cast<const v4f*>(mat + row * (uint64_t)mat_ld), active, j, chunks, ld4, qs4, acc);
+                            const float vn = METRIC == NMN_METRIC_COSINE ? row_share<0>(f) : 1.f;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) {
+                                const float dot = row16_sum(acc[q]);
+                                float sc;
+                                if constexpr (METRIC == NMN_METRIC_COSINE) {
+                                    sc = (vn == 0.f || qmag[q] == 0.f) ? 0.f : dot / (qmag[q] * vn);
+                                } else if constexpr (METRIC == NMN_METRIC_EUCLIDEAN) {
+                                    const float dist = sqrtf(fmaxf(dot, 0.f));
+                                    sc = p.metric == kMetricNegL2 ? -dist : 1.0f / (1.0f + dist);
+                                } else {
+                                    sc = dot;
+                                }
+                                if (j == 0 && active) wsc[q * kWalkRows + s0 + grp] = f2u(sc);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        // the tiles' score blocks (non-participating rows: the sentinel), tile by tile
+                        for (uint32_t tl2 = base_lane; tl2 < end_lane; tl2++) {
+                            const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)tl2);
+                            const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)tl2);
+                            const uint64_t w = ((uint64_t)whi << 32) | wlo;
+                            if (w == 0ull) continue;  // (its maximum says so below; nobody reads the scores of such a tile)
+                            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)tl2);
+                            const bool set = ((w >> lane) & 1ull) != 0;
+                            const uint32_t rank = (uint32_t)__builtin_popcountll(w & ((1ull << lane) - 1ull));
+                            const uint64_t row = (uint64_t)tile_at(rel + tl2) * kTileRows + lane;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) {
+                                const uint32_t bits = set ? wsc[q * kWalkRows + o + rank] : kScoreSentinelBits;
+                                if (q0 + q < p.nq) p.scores[score_at(row, q0 + q, p.nql)] = bits;
+                            }
+                        }
+                        // tile maxima: lane L walks its own tile's entries
+                        uint32_t m[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) m[q] = kKeyMasked;
+                        if (mine) {
+                            for (uint32_t i = 0; i < cnt; i++) {
+#pragma unroll
+                                for (int q = 0; q < NQ; q++) m[q] = max(m[q], score_to_key(u2f(wsc[q * kWalkRows + off + i])));
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            if (q0 + q < p.nq) {
+                                if (mine && tl_ok) p.tmax[(uint64_t)(q0 + q) * p.tmax_stride + tl] = m[q];
+                                wmax[q] = max(wmax[q], wave_max_u32(m[q]));
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        base_lane = end_lane;
+                        base_cnt += S;
+                    }
+                    rel += 63u;  // (the loop's own increment completes the 64)
+                    continue;
+                }
             }
             const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)mcache, (int)(rel & 63u));
             const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(mcache >> 32), (int)(rel & 63u));
@@ -314,7 +436,8 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const uint32_t waves = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     dim3 grid((waves + 3) / 4, (p.nq + NQ - 1) / NQ);
     // queries, plus (masked kernels) one [NQ][64] staging array and one 64-entry rank -> row table per wave for the compacted tiles
-    const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) : 0);  // + rank tables
+    const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) +  // + rank tables
+                                                                       (NQ <= 2 ? 4 * kWalkRows * sizeof(uint16_t) + 4 * NQ * kWalkRows * sizeof(uint32_t) : 0) : 0);  // + the walk's list and parked scores
     auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT, HALF>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

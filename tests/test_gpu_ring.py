@@ -71,3 +71,50 @@ def test_ring_sweep_with_planted_near_ties_and_a_tail_of_zero_rows():
         idx.upload(A)
         for metric in (0, 1, 2):
             _check(idx, A, q, k, metric)
+
+
+@pytest.mark.parametrize("mirror", [0, 2])
+@pytest.mark.parametrize("n,d,k", [(300_000, 768, 100), (270_011, 128, 10), (262_144 + 77, 384, 50), (280_000, 1536, 1000),
+                                   (300_000, 1000, 20), (1_200_000, 256, 30)])
+def test_masked_sweep_over_f32_and_bf16_rows_matches_oracle(n, d, k, mirror):
+    """scan_kernel under a bitmap, including its survivor walk (sparse bitmaps: the participating rows of 64 tiles listed and read four per
+    step): random bitmaps of every density, runs of rows (a time range, an IVF list), a single kept row, kept rows in a few tiles only
+    plus the ragged last tile, nobody, all but every 97th — one and two queries per call, every metric."""
+    from neumann_amd import GpuFlatIndex
+    A = oc.synth(9500 + n + d, 0, n, d, nthreads=8)
+    Q = oc.synth(9600 + d, 0, 2, d)
+    Q[1] = A[n - 2]
+    rng = np.random.default_rng(n + d)
+    masks = {}
+    for s in (0.9, 0.5, 0.1, 0.01, 0.0007):
+        masks["random %g" % s] = rng.random(n) < s
+    runs = np.zeros(n, bool)
+    for r in range(5):
+        a = int(rng.integers(0, n - 9000))
+        runs[a:a + int(rng.integers(100, 9000))] = True
+    masks["runs"] = runs
+    one = np.zeros(n, bool)
+    one[n - 2] = True
+    masks["one row"] = one
+    few = np.zeros(n, bool)
+    few[64 * 1000:64 * 1003] = True
+    few[n - 70:] = True
+    masks["few tiles + the ragged end"] = few
+    masks["nobody"] = np.zeros(n, bool)
+    allbut = np.ones(n, bool)
+    allbut[::97] = False
+    masks["all but every 97th"] = allbut
+    with GpuFlatIndex(d, n) as idx:
+        idx.set_mirror(mirror)
+        idx.fill_synthetic(9500 + n + d, n)
+        for name, keep in masks.items():
+            m = oc.mask_from_bool(keep)
+            for metric in (0, 1, 2):
+                for qi in range(2):
+                    st = _check(idx, A, Q[qi], k, metric, mask=m)
+                    assert st.fallback_queries == 0, name
+            # two queries in one call (NQ = 2)
+            rows, scores, counts = idx.search(Q, k, 0, mask=m)
+            for qi in range(2):
+                er, es = oc.search(A, Q[qi], k, 0, mask=m, nthreads=8, partial=True, native=True)
+                assert counts[qi] == er.size and np.array_equal(rows[qi, :er.size], er) and np.all(scores[qi, :er.size] == es), name
