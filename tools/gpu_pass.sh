@@ -1,8 +1,6 @@
 #!/bin/bash
-# scratch: final evidence on the final tree
-R=$PWD; mkdir -p gpurun_out
-( timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error" | tail -3 ) > gpurun_out/suite.txt 2>&1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/suite.txt
-cat gpurun_out/suite.txt | tail -3
-timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-tail -c 200 gpurun_out/bench_default.json; echo
+# scratch: exactness soak after the survivor walk
+mkdir -p gpurun_out
+timeout 600 python tools/soak.py --mirror 0 --rows 10000000 --dim 768 --out gpurun_out/soak_walk_f32_10Mx768.json 2>&1 | tail -1
+timeout 500 python tools/soak.py --mirror 2 --rows 5000000 --dim 1536 --k 1000 --out gpurun_out/soak_walk_bf16_5Mx1536.json 2>&1 | tail -1
+timeout 500 python tools/soak.py --mirror 0 --rows 10000000 --dim 128 --out gpurun_out/soak_walk_f32_10Mx128.json 2>&1 | tail -1
