@@ -72,6 +72,37 @@ SWEEP = {1: ("i8", "8-bit mirror (int8 codes, one f32 scale per row), int32 accu
          4: ("f32", "f32 corpus", "SURVEY §8(d): rows*dim*4, the f32 corpus")}
 
 
+# Kernel behind each nmn_search_stats.sweep_kind (include/neumann_gpu.h NMN_SWEEP_*): the library REPORTS which sweep served a
+# search; bench.py prints that, it does not re-derive the dispatch.
+KERNEL_OF_SWEEP = {"ring_f32": "nmn::scan_ring_kernel", "valu_f32": "nmn::scan_kernel", "valu_bf16": "nmn::scan_kernel",
+                   "valu_i8": "nmn::scan_i8_kernel", "mfma_f32": "nmn::scan_mfma_kernel", "mfma_bf16": "nmn::scan_mfma_kernel",
+                   "mfma_i8": "nmn::scan_mfma_kernel", "exact": "nmn::exact_scan_kernel", "none": None}
+# queries one corpus sweep of each kind serves (what `passes`, the sweeps per step, follows from)
+QUERIES_PER_SWEEP = {"ring_f32": 1, "valu_f32": 4, "valu_bf16": 4, "valu_i8": 2}  # (mfma_*: a whole pass; exact: the first query's scan is the timed launch)
+
+# The driver's record keeps the FIRST 24 keys of `roofline` (scalars; strings cut at 120 characters) — so the 24 figures a checker
+# needs to answer "what fraction of the roofline on EVERY BASELINE.json config" come first, in this order; everything else follows,
+# prose goes to the top-level `notes` (tests/test_bench_launcher_cpu.py asserts the order on a canned run).
+ROOFLINE_FIRST = (
+    "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_ms", "algorithmic_bytes_per_launch",
+    "c3_f32_frac", "c3_f32_ms_per_batch", "c3_f32_qps", "c2_f32_frac", "c2_f32_qps",
+    "c5_mask1.0_f32_frac", "c5_mask0.5_f32_frac", "c5_mask0.1_f32_frac", "c5_mask1.0_f32_qps", "c5_mask0.1_f32_qps",
+    "i8_mirror_queries_per_s", "i8_mirror_frac_on_mirror_bytes", "c3_i8_frac_on_mirror_bytes", "c3_i8_qps",
+    "ring_only_read_ceiling")
+ROOFLINE_PROSE = ("traffic_source", "avg_kernel_ms_from", "pricing", "traffic_read_write")
+
+
+def order_roofline(roof):
+    """(ordered roofline dict, notes dict): ROOFLINE_FIRST's keys first and in that order — present in EVERY line, None where a leg
+    did not run, so that the positions never shift —, then the remaining scalars; prose and lists move out into `notes`."""
+    notes = {k: roof[k] for k in ROOFLINE_PROSE if k in roof}
+    out = {k: roof.get(k) for k in ROOFLINE_FIRST}
+    for k, v in roof.items():
+        if k not in out and k not in notes:
+            out[k] = v
+    return out, notes
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +130,8 @@ def parse():
     ap.add_argument("--callers", type=int, default=64, help="host threads of the concurrent-callers leg (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline leg")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-published-shapes", action="store_true",
+                    help="skip cpu_baseline's pub_* scalars (the reference's own bench shapes, 1 000 x 128 ... 10 000 x 128, top-10)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra legs of the default single-GPU run: BASELINE.json's other single-GPU "
                          "configurations (config 2, config 5 with mask 1.0 / 0.5 / 0.1) and the SURVEY §8(f) legs")
@@ -224,7 +257,74 @@ def cpu_baseline(args, metric, total_rows, device, gpu_answer=None):
         "extrapolated": not full, "rows_timed": sample_rows,
         "gbps": sample_rows * args.dim * 4 / dt / 1e9,
         "gpu_matches_oracle_on_sample": sample_ok,
+        **({} if getattr(args, "no_published_shapes", False) else published_shapes(cores)),
     }
+
+
+# The only numbers the reference publishes (vector_engine/benches/vector_engine_bench.rs:40-77, `search_similar`
+# top-10 over uniform(-1,1) vectors): mean time per call on the authors' CPU.
+PUBLISHED_SEARCH_US = {"1000x128": 242.0, "1000x768": 367.0, "10000x128": 1930.0}
+
+
+def published_shapes(cores):
+    """The reference's own bench shapes through the host mirror of its API: nmn_engine_search_similar top-10 (host buffers: query
+    H2D, result D2H and key strings inside every call), p50 microseconds over 1 000 native back-to-back calls, beside the CPU oracle
+    on the same data (1 thread and all granted cores) and the reference's published figure; and the row count from which one GPU
+    call beats the 1-thread oracle at d = 128 / 768.  Flat scalars (they go under `cpu_baseline`, which the driver keeps)."""
+    from oracle import oracle_c as oc
+    from neumann_amd.engine import VectorEngine
+    out = {}
+    rng = np.random.default_rng(0x5EED0006)
+
+    def one(n, d, calls):
+        A = rng.uniform(-1.0, 1.0, (n, d)).astype(np.float32)
+        Q = rng.uniform(-1.0, 1.0, (16, d)).astype(np.float32)
+        eng = VectorEngine()
+        try:
+            eng.batch_store_embeddings([f"v{i}" for i in range(n)], A)
+            eng.search_probe(Q, 10, 20)  # builds the resident shard, warms the path
+            us = eng.search_probe(Q, 10, calls)
+            res = eng.search_similar(Q[0], 10)
+        finally:
+            eng.close() if hasattr(eng, "close") else None
+        er, es = oc.search(A, Q[0], 10, 0)
+        same = [r.key for r in res] == [f"v{int(i)}" for i in er] and np.array_equal(np.array([r.score for r in res], np.float32), es)
+        cpu = {}
+        for nt in sorted({1, cores}):
+            reps = max(20, min(calls, int(2e5 / max(n * d / 1e5, 1))))
+            oc.search(A, Q[0], 10, 0, partial=True, nthreads=nt, native=True)
+            t = []
+            for i in range(reps):
+                t0 = time.perf_counter()
+                oc.search(A, Q[i % 16], 10, 0, partial=True, nthreads=nt, native=True)
+                t.append((time.perf_counter() - t0) * 1e6)
+            cpu[nt] = float(np.median(t))
+        return float(np.median(us)), float(np.percentile(us, 99)), cpu, bool(same)
+
+    for n, d in ((1000, 128), (1000, 768), (10000, 128)):
+        key = f"{n}x{d}"
+        try:
+            p50, p99, cpu, same = one(n, d, 1000)
+            out[f"pub_{key}_gpu_p50_us"] = p50
+            out[f"pub_{key}_oracle_1t_us"] = cpu[1]
+            if cores != 1:
+                out[f"pub_{key}_oracle_{cores}t_us"] = cpu[cores]
+            out[f"pub_{key}_reference_published_us"] = PUBLISHED_SEARCH_US[key]
+            out[f"pub_{key}_same_answer"] = same
+        except Exception as e:
+            out[f"pub_{key}_error"] = f"{type(e).__name__}: {e}"[:100]
+    for d in (128, 768):  # the smallest corpus (powers of two) from which one GPU call is faster than the 1-thread oracle
+        cross = None
+        try:
+            for n in (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+                p50, _, cpu, _ = one(n, d, 200)
+                if p50 < cpu[1]:
+                    cross = n
+                    break
+        except Exception:
+            cross = None
+        out[f"pub_crossover_rows_d{d}"] = cross
+    return out
 
 
 def _effective_cores():
@@ -299,7 +399,7 @@ def other_configs():
             o = {"workload": d["config"]["workload"],
                  # the f32-corpus sweep, priced as SURVEY §8(d): kept rows x dim x 4 (+ the bitmap) per query
                  "f32_qps": d["value"], "f32_ms_per_step": d["ms_per_step"], "f32_avg_kernel_ms": r["avg_kernel_ms"],
-                 "f32_frac": r["frac"], "f32_achieved_GBps": r["achieved"], "f32_kernel": r["kernel"],
+                 "f32_frac": r["frac"], "f32_achieved_GBps": r["achieved"], "f32_kernel": r["kernel"], "f32_sweep_kind": r.get("sweep_kind"),
                  "f32_bytes_per_corpus_element": r["bytes_per_corpus_element"], "f32_step_frac": r["step_priced_as_survey_8d_frac"],
                  "f32_exact": d["parity"]["exact_topk_certified"] if d["parity"] else None}
             for tag in ("i8", "bf16"):  # the library's default sweep on this shape (the 8-bit mirror, else the bf16 one)
@@ -476,6 +576,7 @@ def measure_batched(args, idx, dev, metric, total_rows, torch, certify=True):
     sweep_ms = [x for st_ in streams for x in idx.scan_history(st_) if x > 0]
     st = idx.last_stats(streams[(steps - 1) % 2])
     elem_bytes = int(st.bytes_scanned // (st.rows_scanned * args.dim)) if st.rows_scanned else 4
+    sweep_kind, sweep_launches = st.sweep, int(st.sweep_launches)
     idx.set_timing(False)
     torch.cuda.synchronize()
     qh = q_host[(steps - 1) % 4]
@@ -487,7 +588,7 @@ def measure_batched(args, idx, dev, metric, total_rows, torch, certify=True):
             ok = ok and c["exact_topk_certified"]
     sweep = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
     return {"value": nq * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "sweep_ms": sweep,
-            "elem_bytes": elem_bytes, "certified": ok}
+            "elem_bytes": elem_bytes, "certified": ok, "sweep_kind": sweep_kind, "sweep_launches": sweep_launches}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -795,7 +896,8 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        info = {"scan_ms": scan_ms, "elem_bytes": eb, "candidates": int(st.candidates_rescored)}
+        info = {"scan_ms": scan_ms, "elem_bytes": eb, "candidates": int(st.candidates_rescored),
+                "sweep": st.sweep, "sweep_launches": int(st.sweep_launches)}
         return elapsed, tuple(t.cpu().numpy().copy() for t in out), info  # result of the last timed step
 
     def isolated_kernel_ms(n=8):
@@ -850,36 +952,23 @@ def main():
     scan_avg = float(np.mean(scan_ms)) if scan_ms else float("nan")
     hbm_bytes_per_row = (hbm0[0] + hbm0[1] + hbm0[2]) / max(local_rows, 1)
     scan_alone = isolated_kernel_ms() if world == 1 else None
-    # corpus sweeps per step: 64 queries per sweep on the MFMA path (>= 3 queries at dim >= 768, else >= 5), else 4 (VALU; 2 on
-    # the 8-bit mirror) — mirrors search_enqueue() / scan_mfma_supported() in neumann_amd/csrc
-    ld128 = (args.dim + 127) // 128 * 128  # nmn_index_create pads rows just short of a supported multiple of 128 up to it
-    while ld128 <= 4096 and not (ld128 // 128 <= 6 or ld128 // 128 in (8, 10, 12, 16, 24, 32)):
-        ld128 += 128
-    kc = ld128 // 128 if (ld128 <= 4096 and (ld128 - args.dim) * 8 <= args.dim) else 0
-    mfma_min = int(os.environ.get("NMN_MFMA_MIN_NQ") or 0) or (3 if args.dim >= 768 else 5)  # mfma_min_queries()
-    mfma = (args.nq >= mfma_min and args.metric in ("cosine", "dot", "euclidean") and kc and (kc <= 6 or kc in (8, 10, 12, 16, 24, 32))
-            and args.k <= 4096)
-    passes = 1 if mfma else ((args.nq + 3) // 4 if args.nq >= 3 else 1)
-    if args.k > 4096:
-        passes = 1  # large-k path: one exact scan per query, the first one is the timed launch
+    # corpus sweeps per step, from the sweep the LIBRARY says it ran (nmn_search_stats.sweep_kind): the matrix-core sweeps serve a
+    # whole pass of queries per corpus read, the VALU sweeps 4 (2 on the 8-bit mirror), the ring sweep and the large-k scan one
+    def passes_of(sweep):
+        per = QUERIES_PER_SWEEP.get(sweep)
+        return 1 if per is None else (args.nq + per - 1) // per
+
+    sweep_name = infos[med]["sweep"]
+    passes = passes_of(sweep_name)
     if world > 1:
         leg_modes = [m for m in leg_modes if m == 1]  # N > 1: the library's default sweep only (a second mirror per rank buys nothing)
 
-    def alg_bytes_for(eb):  # excluded rows are never read
-        return (kept_rows * args.dim * eb + (local_rows // 8 if mask_dev is not None else 0)) * passes
-
-    # (one unmasked f32 query, >= 4096 tiles, stride a multiple of 128 up to 4096: search_enqueue's use_ring)
-    ld_ring = (args.dim + 7) // 8 * 8 if not kc else ld128
-    ring = (args.nq == 1 and mask_dev is None and local_rows >= 4096 * 64 and ld_ring % 128 == 0 and ld_ring <= 4096
-            and not os.environ.get("NMN_NO_RING"))
-
-    def kernel_of(eb):
-        return ("nmn::exact_scan_kernel" if args.k > 4096 else "nmn::scan_mfma_kernel" if mfma else
-                "nmn::scan_i8_kernel" if eb == 1 else "nmn::scan_ring_kernel" if (eb == 4 and ring) else "nmn::scan_kernel")
+    def alg_bytes_for(eb, sweep=None):  # excluded rows are never read
+        return (kept_rows * args.dim * eb + (local_rows // 8 if mask_dev is not None else 0)) * passes_of(sweep or sweep_name)
 
     alg_bytes = alg_bytes_for(elem_bytes)
     achieved = alg_bytes / (scan_avg * 1e-3) / 1e9 if scan_ms else float("nan")
-    kernel_name = kernel_of(elem_bytes)
+    kernel_name = KERNEL_OF_SWEEP.get(sweep_name, sweep_name)
 
     # ---- read ceiling of this device: the scan's access pattern with the arithmetic removed ----
     read_ceiling = idx.read_probe(3) if local_rows else None
@@ -929,6 +1018,8 @@ def main():
         return [int(x.item()) for x in got]
 
     headline_eb = per_rank(elem_bytes)
+    kinds = list(KERNEL_OF_SWEEP)  # (an integer per rank travels; the names come back)
+    headline_kinds = [kinds[i] if 0 <= i < len(kinds) else "unknown" for i in per_rank(kinds.index(sweep_name) if sweep_name in kinds else -1)]
 
     # ---- the same loop on the shard's MIRRORS: the library's default sweep (1 B per element where the shape allows it, every
     # candidate re-scored from the f32 rows: the same answer, bit for bit) and the bf16 mirror.  Same index, queries, streams,
@@ -949,7 +1040,7 @@ def main():
         if name in legs or ebs == headline_eb:
             continue  # (a shape the 8-bit sweeps do not serve: mode 1 already was the bf16 mirror; or no mirror fitted anywhere)
         k_ms = float(np.mean(scan2)) if scan2 else float("nan")
-        b2 = alg_bytes_for(eb2)
+        b2 = alg_bytes_for(eb2, info2["sweep"])
         ach = b2 / (k_ms * 1e-3) / 1e9 if scan2 else float("nan")
         cert2 = None
         if not args.no_parity:
@@ -962,7 +1053,7 @@ def main():
                       "frac": ach / HBM_PEAK_GBS if scan2 else None,
                       "avg_kernel_ms": k_ms, "kernel_launches_timed": len(scan2),
                       "algorithmic_bytes_per_launch": b2, "bytes_per_corpus_element": eb2, "bytes_per_corpus_element_by_rank": ebs,
-                      "pricing": SWEEP[eb2][2], "kernel": kernel_of(eb2),
+                      "pricing": SWEEP[eb2][2], "kernel": KERNEL_OF_SWEEP.get(info2["sweep"], info2["sweep"]), "sweep_kind": info2["sweep"],
                       "frac_of_read_ceiling": (ach / read_ceiling) if (scan2 and read_ceiling) else None,
                       "candidates_rescored": info2["candidates"],
                       "traffic": pmc_traffic(local_rows, args, eb2)[0], "traffic_source": pmc_traffic(local_rows, args, eb2)[1],
@@ -988,7 +1079,8 @@ def main():
                 # (f32 corpus: rows*dim*4 — §8(d)'s own figure).  Matrix cores: 2*rows*dim*nq operations per query plane (the 8-bit sweep
                 # multiplies two int8 planes of every query: twice the operations of the bf16 form) against the dense peak of the type.
                 "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
-                             "kernel": "nmn::scan_mfma_kernel (sweep incl. its sampling pass)", "bytes_per_corpus_element": eb3,
+                             "kernel": f"{KERNEL_OF_SWEEP.get(draws_[-1]['sweep_kind'], draws_[-1]['sweep_kind'])} (every launch of the sweep)",
+                             "sweep_kind": draws_[-1]["sweep_kind"], "sweep_launches": draws_[-1]["sweep_launches"], "bytes_per_corpus_element": eb3,
                              "frac_priced_as_survey_8d": gbps * 4 / eb3 / HBM_PEAK_GBS,
                              "mfma": {"bound": pname, "planes_per_query": planes, "achieved_tops": ops, "peak_tops": peak,
                                       "unit": "TOP/s" if eb3 == 1 else "TFLOP/s", "frac": ops / peak}},
@@ -1087,8 +1179,11 @@ def main():
                 "frac_priced_as_survey_8d": achieved * 4 / elem_bytes / HBM_PEAK_GBS if scan_ms else None,
                 "step_priced_as_survey_8d_frac": (kept_rows * args.dim * 4 * passes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "candidates_rescored": int(np.median(cands)) if cands else None,
-                # measured in this run by nmn_index_read_probe: a pure read sweep, no arithmetic
-                "measured_read_ceiling": read_ceiling,
+                # what the library says it ran (nmn_search_stats.sweep_kind / sweep_launches), not bench.py's guess
+                "sweep_kind": sweep_name, "sweep_launches": infos[med]["sweep_launches"],
+                # measured in this run by nmn_index_read_probe: the sweep's own data movement (the ring kernel's LDS-DMA pieces, same
+                # workgroups and stages) with the arithmetic and every store removed — GB/s; the sweep cannot read faster than this
+                "ring_only_read_ceiling": read_ceiling,
                 "frac_of_read_ceiling": (achieved / read_ceiling) if (scan_ms and read_ceiling) else None}
         # ---- everything else a checker needs, as FLAT scalars (the driver's record keeps scalars of `roofline` / `config` /
         # `cpu_baseline` and drops nested objects): the mirror sweeps of the same loop; configs 3, 2, 5 on BOTH sweeps.
@@ -1114,6 +1209,7 @@ def main():
             roof[pfx + ("frac" if tag == "f32" else "frac_on_mirror_bytes")] = bsum["roofline"]["frac"]
             roof[pfx + "mfma_frac"] = bsum["roofline"]["mfma"]["frac"]
             roof[pfx + "exact"] = bsum["exact_topk_certified_3_of_batch"]
+            roof[pfx + "sweep_launches"] = bsum["roofline"]["sweep_launches"]
         for cfg_name, o in (others or {}).items():
             pfx = cfg_name.split("_")[0].replace("config", "c") + ("_mask" + cfg_name.rsplit("mask", 1)[1] if "mask" in cfg_name else "") + "_"
             if "error" in o:
@@ -1122,6 +1218,7 @@ def main():
             for k_, v_ in o.items():
                 if isinstance(v_, (int, float, bool)) or v_ is None:
                     roof[pfx + k_] = v_
+        roof, notes = order_roofline(roof)
         line = {
             "metric": "queries/sec, brute-force SIMILAR TOP-K (recall@K = 1.0 vs CPU oracle)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1144,8 +1241,17 @@ def main():
                        "shards_with_mirror": None if mirror_eb is None else sum(1 for x in mirror_eb if x < 4),
                        "hbm_bytes_per_row": hbm_bytes_per_row, "hbm_bytes_per_element": hbm_bytes_per_row / args.dim,
                        "hbm_bytes_per_element_after_legs": (hbm1[0] + hbm1[1] + hbm1[2]) / max(local_rows, 1) / args.dim,
-                       "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k"},
+                       "parallelism": f"row-range shards x{world}, RCCL all-gather of top-k",
+                       # flat scalars a SCALE_r*.json can be checked from (the driver keeps the scalars of `config`): the sweep every
+                       # rank's library reported, the ranks a real RCCL all-gather saw, what the collective + merge cost per step
+                       "sweep_kind": sweep_name, "sweep_kind_by_rank": ",".join(headline_kinds),
+                       "rccl_ranks": (multi or {}).get("rccl_ranks"), "gather_plus_merge_ms": (multi or {}).get("gather_plus_merge_ms"),
+                       # step-level (whole call, tail included) fractions of the other configs, priced as SURVEY §8(d)
+                       "c2_f32_step_frac": roof.get("c2_f32_step_frac"), "c5_mask0.1_f32_step_frac": roof.get("c5_mask0.1_f32_step_frac"),
+                       "filtered_similar_sel0.1_ms": ((next_rows or {}).get("filtered_similar_sel0.1") or {}).get("ms_per_query_wall"),
+                       "c3_f32_sweep_launches": roof.get("c3_f32_sweep_launches")},
             "roofline": roof,
+            "notes": notes,
             "cpu_baseline": cpu,
             "parity": parity,
             "mirror_legs": legs or None,

@@ -149,6 +149,13 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
                                                     uint64_t top_k, const nmn_filter* filter,
                                                     const nmn_filtered_config* config, nmn_results** out);
 
+/* Measurement aid (bench.py's `published_shapes` leg: the shapes of vector_engine/benches/vector_engine_bench.rs:40-77): `calls`
+ * back-to-back nmn_engine_search_similar calls from ONE host thread — call i with query i % n_queries of `queries` (HOST,
+ * n_queries x dim), results taken and freed as a caller would — each timed on the host's steady clock around the whole call
+ * (validation, H2D of the query, kernels, D2H, key strings): out_us[i] = microseconds of call i.  No Python in the loop. */
+nmn_status nmn_engine_search_probe(nmn_engine* e, const float* queries, uint64_t n_queries, uint64_t dim, uint64_t top_k,
+                                   uint64_t calls, float* out_us);
+
 /* results */
 uint64_t nmn_results_len(const nmn_results* r);
 const char* nmn_results_key(const nmn_results* r, uint64_t i);

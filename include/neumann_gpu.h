@@ -97,7 +97,22 @@ typedef struct nmn_search_stats {
     uint32_t fallback_queries;    /* queries that took the exact-fallback path */
     float scan_ms;                /* hipEvent span of the scan kernel(s); -1 if not timed */
     float total_ms;               /* hipEvent span scan+select+rescore+sort; -1 if not timed */
+    uint32_t sweep_kind;          /* NMN_SWEEP_*: which kernel streamed the rows for this search (the library's own dispatch decision) */
+    uint32_t sweep_launches;      /* kernel launches of that sweep per query pass (sampling pass and bound kernels included) */
 } nmn_search_stats;
+
+/* nmn_search_stats.sweep_kind: the kernel that read the corpus (or its mirror) for the last search. */
+#define NMN_SWEEP_NONE 0u       /* no rows (empty shard) */
+#define NMN_SWEEP_RING_F32 1u   /* nmn::scan_ring_kernel: one unmasked query, f32 rows through the LDS-DMA ring (SURVEY §8(d) headline) */
+#define NMN_SWEEP_VALU_F32 2u   /* nmn::scan_kernel over the f32 rows (bitmaps, 2-4 queries, small shards) */
+#define NMN_SWEEP_VALU_BF16 3u  /* nmn::scan_kernel over the bf16 mirror */
+#define NMN_SWEEP_VALU_I8 4u    /* nmn::scan_i8_kernel over the 8-bit mirror */
+#define NMN_SWEEP_MFMA_F32 5u   /* nmn::scan_mfma_kernel over the f32 rows (rounded to bf16 in registers) */
+#define NMN_SWEEP_MFMA_BF16 6u  /* nmn::scan_mfma_kernel over the bf16 mirror */
+#define NMN_SWEEP_MFMA_I8 7u    /* nmn::scan_mfma_kernel over the 8-bit mirror */
+#define NMN_SWEEP_EXACT 8u      /* exact reference-order scores of every row, no approximate sweep (tiny_search_kernel, large-k path) */
+/* Name of a NMN_SWEEP_* value ("ring_f32", "valu_f32", "valu_bf16", "valu_i8", "mfma_f32", "mfma_bf16", "mfma_i8", "exact", "none"). */
+const char* nmn_sweep_kind_str(uint32_t sweep_kind);
 
 /* ---- device / lifecycle ------------------------------------------------------------------- */
 
@@ -215,8 +230,10 @@ nmn_status nmn_index_count_exact(nmn_index* idx, const float* query, nmn_metric 
                                  const uint64_t* mask, float score, uint64_t* n_greater,
                                  uint64_t* n_equal);
 
-/* Measurement aid: a pure read sweep over the shard (the scan's access pattern without arithmetic), best of
- * `reps` runs, in GB/s.  What a read-only kernel can reach on this device; bench.py reports the scan against it. */
+/* Measurement aid: a pure read sweep over the shard, best of `reps` runs, in GB/s: the data movement of the sweep a single f32 query
+ * takes on this shard with the arithmetic and every store removed — the LDS-DMA ring of nmn::scan_ring_kernel where that kernel
+ * serves (>= 4096 tiles, stride a multiple of 128 up to 4096), nmn::scan_kernel's register loads elsewhere.  What a read-only
+ * kernel can reach on this device; bench.py reports the sweep against it (`ring_only_read_ceiling`). */
 nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double* gbps_out);
 
 /* Measurement aid: `threads` host threads call nmn_index_search(nq = 1, k, metric) in a loop for `seconds`, thread t

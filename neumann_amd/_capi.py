@@ -60,7 +60,16 @@ GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 class SearchStats(C.Structure):
     _fields_ = [("rows_scanned", C.c_uint64), ("bytes_scanned", C.c_uint64),
                 ("candidates_rescored", C.c_uint32), ("fallback_queries", C.c_uint32),
-                ("scan_ms", C.c_float), ("total_ms", C.c_float)]
+                ("scan_ms", C.c_float), ("total_ms", C.c_float),
+                ("sweep_kind", C.c_uint32), ("sweep_launches", C.c_uint32)]
+
+    @property
+    def sweep(self):
+        """Name of `sweep_kind` as the library spells it (nmn_sweep_kind_str): ring_f32, valu_f32, valu_bf16, valu_i8, mfma_f32, ..."""
+        return load().nmn_sweep_kind_str(self.sweep_kind).decode()
+
+
+SWEEP_NONE, SWEEP_RING_F32, SWEEP_VALU_F32, SWEEP_VALU_BF16, SWEEP_VALU_I8, SWEEP_MFMA_F32, SWEEP_MFMA_BF16, SWEEP_MFMA_I8, SWEEP_EXACT = range(9)
 
 
 class KMeansOptions(C.Structure):
@@ -85,6 +94,7 @@ SIGNATURES = {
     "nmn_status_str": (C.c_char_p, [C.c_int32]),
     "nmn_last_error": (C.c_char_p, []),
     "nmn_version": (C.c_char_p, []),
+    "nmn_sweep_kind_str": (C.c_char_p, [C.c_uint32]),
     "nmn_index_create": (C.c_int32, [C.POINTER(IndexDesc), C.POINTER(vp)]),
     "nmn_index_destroy": (C.c_int32, [vp]),
     "nmn_index_upload": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64]),

@@ -388,6 +388,11 @@ extern "C" const char* nmn_status_str(nmn_status s) {
     }
 }
 
+extern "C" const char* nmn_sweep_kind_str(uint32_t kind) {
+    static const char* const names[] = {"none", "ring_f32", "valu_f32", "valu_bf16", "valu_i8", "mfma_f32", "mfma_bf16", "mfma_i8", "exact"};
+    return kind <= NMN_SWEEP_EXACT ? names[kind] : "unknown";
+}
+
 extern "C" const char* nmn_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* nmn_version(void) { return "0.3.0"; }
 
@@ -786,6 +791,8 @@ static nmn_status search_large_k(nmn_index* idx, Workspace* w, const float* quer
     w->last_nq = nq;
     w->last_rows_scanned = n_rows;
     w->last_elem_bytes = 4;
+    w->last_sweep_kind = n_rows ? NMN_SWEEP_EXACT : NMN_SWEEP_NONE;
+    w->last_sweep_launches = n_rows ? 1u : 0u;
     w->last_masked = mask_dev != nullptr;
     if (w->timed) HIP_TRY(hipEventRecord(w->ev[0], stream));
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
@@ -905,6 +912,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         w->last_nq = nq;
         w->last_rows_scanned = n_rows;
         w->last_masked = mask_dev != nullptr || qmasks_dev != nullptr;
+        w->last_sweep_kind = NMN_SWEEP_NONE;
+        w->last_sweep_launches = 0;
         w->scan_ev_in_hist = false;
         if (w->timed == 1) HIP_TRY(hipEventRecord(w->ev[0], stream));
     }
@@ -1221,7 +1230,13 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             // (the f32-rows sweep rounds rows AND margin a priori — 2.5x the bf16 mirror's measured margin — and takes it from 3 on as well:
             //  10M x 768, 64 queries 5.24-5.29 -> 4.96 ms, profiles/r05c_f32_mfma_knobs_ab.txt)
             const uint32_t refine_from = ((use_i8 || mfma_f32) && !getenv("NMN_REFINE_MIN_NQ")) ? 3u : refine_min_nq;
-            if (use_mfma && sample && nqc >= refine_from && !no_refine && first_blocks >= 64 && (uint64_t)first_blocks * sp.tiles_per_wave >= 4ull * k) {
+            const bool refine = use_mfma && sample && nqc >= refine_from && !no_refine && first_blocks >= 64 && (uint64_t)first_blocks * sp.tiles_per_wave >= 4ull * k;
+            if (qa == 0) {  // what nmn_search_stats reports: the dispatch decision itself (first pass of the call; nested parts: the parts' kernel)
+                w->last_sweep_kind = use_mfma ? (use_i8 ? NMN_SWEEP_MFMA_I8 : use_half ? NMN_SWEEP_MFMA_BF16 : NMN_SWEEP_MFMA_F32)
+                                              : use_i8 ? NMN_SWEEP_VALU_I8 : use_ring ? NMN_SWEEP_RING_F32 : use_half ? NMN_SWEEP_VALU_BF16 : NMN_SWEEP_VALU_F32;
+                w->last_sweep_launches = (sample ? 2u : 0u) + (refine ? 3u : 1u);
+            }
+            if (refine) {
                 ScanParams sa = sp;
                 sa.bx_base = 0;
                 sa.bx_count = first_blocks;
@@ -1464,6 +1479,8 @@ static nmn_status stats_collect(nmn_index* idx, Workspace* w, nmn_search_stats* 
     }
     stats->rows_scanned = w->last_rows_scanned;  // upper bound when masked (excluded rows are skipped)
     stats->bytes_scanned = w->last_rows_scanned * (uint64_t)idx->dim * (uint64_t)w->last_elem_bytes;
+    stats->sweep_kind = w->last_sweep_kind;
+    stats->sweep_launches = w->last_sweep_launches;
     if (w->timed) {
         float a = 0.f, b = 0.f;
         hipEvent_t e1 = w->ev[1], e2 = w->ev[2];
@@ -1631,6 +1648,8 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
             first.stats->bytes_scanned = rows_now * (uint64_t)idx->dim * 4ull;  // exact scores straight from the f32 rows
             first.stats->scan_ms = -1.f;
             first.stats->total_ms = -1.f;
+            first.stats->sweep_kind = rows_now ? NMN_SWEEP_EXACT : NMN_SWEEP_NONE;  // (tiny_search_kernel: exact scores, one launch)
+            first.stats->sweep_launches = rows_now ? 1u : 0u;
         }
         return NMN_OK;
     }
@@ -2098,7 +2117,18 @@ extern "C" nmn_status nmn_index_coalesce_stats(nmn_index* idx, uint64_t* batches
 extern "C" nmn_status nmn_index_search(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
                                        nmn_metric metric, const uint64_t* mask, uint64_t* out_rows,
                                        float* out_scores, uint32_t* out_counts, nmn_search_stats* stats) {
-    return index_search_hostio(idx, queries, nq, k, (int)metric, mask, false, out_rows, out_scores, out_counts, stats);
+    const nmn_status st = index_search_hostio(idx, queries, nq, k, (int)metric, mask, false, out_rows, out_scores, out_counts, stats);
+    if (st == NMN_OK && stats && mask && stats->rows_scanned && idx->dim) {
+        // a host bitmap can be counted here: rows_scanned / bytes_scanned are the KEPT rows (excluded rows are never read), not
+        // the upper bound the device-mask entry points report
+        const uint64_t n = stats->rows_scanned, eb = stats->bytes_scanned / (n * idx->dim);
+        uint64_t kept = 0;
+        for (uint64_t wd = 0; wd < n / 64; wd++) kept += (uint64_t)__builtin_popcountll(mask[wd]);
+        if (n % 64) kept += (uint64_t)__builtin_popcountll(mask[n / 64] & ((1ull << (n % 64)) - 1));
+        stats->rows_scanned = kept;
+        stats->bytes_scanned = kept * idx->dim * eb;
+    }
+    return st;
 }
 
 extern "C" nmn_status nmn_index_search_dmask(nmn_index* idx, const float* queries, uint32_t nq, uint32_t k,
@@ -2131,10 +2161,18 @@ extern "C" nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double
     hipError_t e = hipEventCreate(&a);
     if (e == hipSuccess) e = hipEventCreate(&b);
     float best = 0.f;
-    if (e == hipSuccess) e = launch_read_probe(idx->corpus, idx->rows, idx->ld, sink, s);  // warm-up
+    // Where the headline sweep is the ring kernel (scan_ring_supported, >= 4096 tiles) the probe is THAT kernel's data movement with
+    // nothing behind it — same workgroups, stages and LDS-DMA pieces (the register-load probe below reads slower
+    // than the ring sweep itself and is no ceiling for it); elsewhere scan_kernel's access pattern with the arithmetic removed.
+    const uint64_t n_tiles = idx->rows / kTileRows;
+    const bool ring = n_tiles >= 4096u && scan_ring_supported(idx->ld, idx->dim, NMN_METRIC_DOT_PRODUCT) && !getenv("NMN_NO_RING");
+    const uint32_t ring_tpw = (uint32_t)std::max<uint64_t>(1, (n_tiles + kMaxScanWaves - 1) / kMaxScanWaves);
+    uint64_t probe_rows = ring ? n_tiles * kTileRows : idx->rows;
+    auto probe = [&]() { return ring ? launch_ring_probe(idx->corpus, idx->rows, idx->ld, ring_tpw, s) : launch_read_probe(idx->corpus, idx->rows, idx->ld, sink, s); };
+    if (e == hipSuccess) e = probe();  // warm-up
     for (uint32_t i = 0; i < std::max(reps, 1u) && e == hipSuccess; i++) {
         e = hipEventRecord(a, s);
-        if (e == hipSuccess) e = launch_read_probe(idx->corpus, idx->rows, idx->ld, sink, s);
+        if (e == hipSuccess) e = probe();
         if (e == hipSuccess) e = hipEventRecord(b, s);
         if (e == hipSuccess) e = hipEventSynchronize(b);
         float ms = 0.f;
@@ -2145,7 +2183,7 @@ extern "C" nmn_status nmn_index_read_probe(nmn_index* idx, uint32_t reps, double
     if (b) (void)hipEventDestroy(b);
     (void)hipFree(sink);
     if (e != hipSuccess) return fail_hip(e, "nmn_index_read_probe");
-    if (best > 0.f) *gbps_out = (double)idx->rows * idx->ld * 4.0 / (best * 1e-3) / 1e9;
+    if (best > 0.f) *gbps_out = (double)probe_rows * idx->ld * 4.0 / (best * 1e-3) / 1e9;
     return NMN_OK;
 }
 

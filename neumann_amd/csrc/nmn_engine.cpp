@@ -2141,6 +2141,24 @@ nmn_status nmn_engine_search_filtered_in_collection(nmn_engine* e, const char* c
     return st;
 }
 
+// ---- measurement aid: per-call latency of search_similar from one host thread (bench.py published_shapes) ----------
+nmn_status nmn_engine_search_probe(nmn_engine* e, const float* queries, uint64_t n_queries, uint64_t dim, uint64_t top_k,
+                                   uint64_t calls, float* out_us) {
+    if (!e || !queries || !out_us || n_queries == 0) return NMN_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < calls; i++) {
+        nmn_results* r = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const nmn_status st = nmn_engine_search_similar(e, queries + (i % n_queries) * dim, dim, top_k, &r);
+        uint64_t got = nmn_results_len(r);
+        volatile float sink = got ? nmn_results_score(r, got - 1) : 0.f;  // (the caller reads its answer)
+        (void)sink;
+        nmn_results_free(r);
+        out_us[i] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (st != NMN_OK) return st;
+    }
+    return NMN_OK;
+}
+
 // ---- results / lists / filters -------------------------------------------------------------------
 uint64_t nmn_results_len(const nmn_results* r) { return r ? r->keys.size() : 0; }
 const char* nmn_results_key(const nmn_results* r, uint64_t i) { return (r && i < r->keys.size()) ? r->keys[i].c_str() : nullptr; }

@@ -89,6 +89,8 @@ struct Workspace {
     uint32_t last_nq = 0;
     uint64_t last_rows_scanned = 0;
     uint32_t last_elem_bytes = 4;  // bytes per corpus element the last sweep read (2 on the bf16 mirror, 1 on the 8-bit one)
+    uint32_t last_sweep_kind = 0;      // NMN_SWEEP_* of the last search's (first pass's) sweep — reported, never re-derived by callers
+    uint32_t last_sweep_launches = 0;  // launches of that sweep (sampling pass + bound kernels + sweep launches)
     bool last_masked = false;
 };
 

@@ -160,6 +160,7 @@ bool ingest_q8_supported(uint32_t ld, uint32_t dim);
 hipError_t launch_ingest_q8(const float* corpus, uint32_t ld, uint64_t row0, uint64_t n, float* norms, float* inv_norms, uint32_t* max_norm_bits,
                             int8_t* q8, float* scale, float* vv, float* cosf, uint32_t* err_bits, hipStream_t s);
 hipError_t launch_read_probe(const float* corpus, uint64_t n_rows, uint32_t ld, float* sink, hipStream_t s);
+hipError_t launch_ring_probe(const float* corpus, uint64_t n_rows, uint32_t ld, uint32_t tiles_per_wg, hipStream_t s);  // nmn_scan_ring.hip
 // batched-query sweep on the matrix cores (nmn_scan_mfma.hip); tiles_per_wave = tiles per WORKGROUP there
 bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric);
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);

@@ -45,7 +45,9 @@ __device__ __forceinline__ void ring_wait_vm() {
 
 // METRIC: NMN_METRIC_COSINE | NMN_METRIC_DOT_PRODUCT (dot products) or NMN_METRIC_EUCLIDEAN (sum of squared differences; kMetricNegL2
 // picks -d over 1 / (1 + d) in the epilogue).  KC = ld / 128 stages per row (runtime).
-template <int METRIC>
+// PROBE: the same ring, waits and barriers with the arithmetic, the LDS reads and every store removed — what the data movement of this
+// very kernel reaches on this device (nmn_index_read_probe: bench.py's `ring_only_read_ceiling`; 7.0-7.2 TB/s at 10M x 768).
+template <int METRIC, bool PROBE = false>
 __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // ring | [8 tiles][64] row magnitudes | [2][4] tile-maximum parts | query [ld]
     float* const nrm = lds + kRingStages * (kRingStageBytes / 4);
@@ -69,12 +71,12 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
     // instruction, wave w takes the KiBs w, w + 4, ...  No register round trip in front of the ring's first pieces — a workgroup's
     // start is one memory latency, not two, sixteen times per CU and sweep — and these are the OLDEST entries of the wave's in-order
     // queue: the first stage's counted wait covers them, its barrier makes them visible.
-    for (uint32_t c = wave; c * 256u < ld; c += 4u) {
+    for (uint32_t c = wave; !PROBE && c * 256u < ld; c += 4u) {
         if (c * 256u + lane * 4u < ld)  // (row strides are multiples of 128 floats: the last KiB may be half)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.qpad + c * 256u + lane * 4u),
                                              (__attribute__((address_space(3))) void*)(qlds + c * 256u), 16, 0, 0);
     }
-    const float qmag = p.qinfo[0].qmag;
+    const float qmag = PROBE ? 1.f : p.qinfo[0].qmag;
 
     // DMA source offsets of this wave's pieces: piece pp = rows 2 (8 wave + pp) + lane / 32, LDS chunk lane % 32, source chunk
     // (lane % 32) ^ (row & 15) (the swizzle lives on the source side: the LDS side of an LDS-DMA is wave base + lane * 16)
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
 #pragma unroll
     for (uint32_t s0 = 0; s0 < kRingStages; s0++) {
         if (s0 < n_stage) {
-            if (kCos && wave == 0 && s0 % KC == 0) norms_dma(t0 + s0 / KC, s0 / KC);
+            if (!PROBE && kCos && wave == 0 && s0 % KC == 0) norms_dma(t0 + s0 / KC, s0 / KC);
             if (s0 < kRingStages - 1) issue_stage(stage_src(t0 + s0 / KC, s0 % KC), 0xFFFFFFFFu, s0 % kRingStages);
         } else if (s0 < kRingStages - 1) {
             issue_stage(mat, 0u, s0 % kRingStages);
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
             // hand-over a stage needs.  The workgroup meets once per TILE — for the query (first tile) and the tile maxima's parts.
             if (kc == 0) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kc == 0 && wave == 0 && tile > t0) {
+            if (!PROBE && kc == 0 && wave == 0 && tile > t0) {
                 // the previous tile's maximum: its four parts were written before this barrier
                 const uint32_t* tp = tpart + ((tile - 1u - t0) & 1u) * 4u;
                 const uint32_t m = max(max(tp[0], tp[1]), max(tp[2], tp[3]));
@@ -150,12 +152,16 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
             const uint32_t lmask = issue ? 0xFFFFFFFFu : 0u;
             float* const nbuf = lds + (ns % kRingStages) * (kRingStageBytes / 4);
             f4 a[kSub][2];
+            f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+            if constexpr (!PROBE) {
 #pragma unroll
-            for (int sub = 0; sub < kSub; sub++) {
-                a[sub][0] = *reinterpret_cast<const f4*>(buf + off[sub]);
-                a[sub][1] = *reinterpret_cast<const f4*>(buf + (off[sub] ^ 4u));
+                for (int sub = 0; sub < kSub; sub++) {
+                    a[sub][0] = *reinterpret_cast<const f4*>(buf + off[sub]);
+                    a[sub][1] = *reinterpret_cast<const f4*>(buf + (off[sub] ^ 4u));
+                }
+                q0 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u);
+                q1 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u + 4u);
             }
-            const f4 q0 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u), q1 = *reinterpret_cast<const f4*>(qlds + kc * 128u + j * 8u + 4u);
 #pragma unroll
             for (int sub = 0; sub < kSub; sub++) {
                 // two pieces of the stage ahead per sub-step, in the shadow of the arithmetic
@@ -163,6 +169,7 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
                 for (int pp = sub * 2; pp < sub * 2 + 2; pp++)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + (loff[pp] & lmask)),
                                                      (__attribute__((address_space(3))) void*)(nbuf + (wave * kRingPieces + (uint32_t)pp) * 256u), 16, 0, 2);
+                if constexpr (PROBE) continue;
                 const f4 x0 = a[sub][0], x1 = a[sub][1];
                 if constexpr (kL2) {
                     const f4 d0 = x0 - q0, d1 = x1 - q1;
@@ -185,8 +192,9 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
                 nkc = 0;
                 nt++;
             }
-            if (kCos && wave == 0 && ns + 1u < n_stage && nkc == 0) norms_dma(nt, nt - t0);
+            if (!PROBE && kCos && wave == 0 && ns + 1u < n_stage && nkc == 0) norms_dma(nt, nt - t0);
         }
+        if constexpr (PROBE) continue;
         // ---- the tile's 16 rows of this wave: the sixteen lanes of a row meet (row_ror 8, 4, 2, 1: every lane of the DPP row holds the
         // sum), then lane (r4, j) finishes row 4 (j & 3) + r4 of the wave's sixteen (four lanes per row: the write below takes j < 4)
         float v = 0.f;
@@ -223,7 +231,7 @@ __global__ void __launch_bounds__(256, 1) scan_ring_kernel(ScanParams p) {
     ring_wait_vm<0>();  // the dummy pieces of the tail have landed before this workgroup's LDS is handed on
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (wave == 0) {
+    if (!PROBE && wave == 0) {
         const uint32_t* tp = tpart + ((t1 - 1u - t0) & 1u) * 4u;
         const uint32_t m = max(max(tp[0], tp[1]), max(tp[2], tp[3]));
         wmax = max(wmax, m);
@@ -251,6 +259,24 @@ hipError_t launch_ring_metric(const ScanParams& p, hipStream_t s) {
 bool scan_ring_supported(uint32_t ld, uint32_t dim, int metric) {
     if (!(metric == NMN_METRIC_COSINE || metric == NMN_METRIC_DOT_PRODUCT || metric == NMN_METRIC_EUCLIDEAN || metric == kMetricNegL2)) return false;
     return dim <= ld && ld % 128u == 0 && ld >= 128u && ld <= 4096u;  // (the query behind the ring: 16 KiB at 4096 elements)
+}
+
+// The ring with nothing behind it: the read ceiling of the headline sweep's own data movement (same workgroups, stages, pieces).
+hipError_t launch_ring_probe(const float* corpus, uint64_t n_rows, uint32_t ld, uint32_t tiles_per_wg, hipStream_t s) {
+    ScanParams p{};
+    p.corpus = corpus;
+    p.n_rows = n_rows;
+    p.ld = ld;
+    p.n_tiles = (uint32_t)(n_rows / kTileRows);  // whole tiles only (no row guard in the probe)
+    p.tiles_per_wave = std::max<uint32_t>(1, tiles_per_wg);
+    if (p.n_tiles == 0) return hipSuccess;
+    const uint32_t blocks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
+    const size_t lds = (size_t)kRingStages * kRingStageBytes + 8 * 64 * 4 + 8 * 4 + (size_t)p.ld * 4;
+    auto kern = scan_ring_kernel<NMN_METRIC_DOT_PRODUCT, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
+    return hipGetLastError();
 }
 
 // p.nq == 1, p.nql == 1, no bitmap, p.tiles_per_wave = tiles per WORKGROUP, tmax / wmax / scores of query 0

@@ -859,6 +859,8 @@ static nmn_status sharded_run_body(nmn_sharded* s, const float* queries, uint32_
             stats->fallback_queries += one.fallback_queries;
             stats->scan_ms = std::max(stats->scan_ms, one.scan_ms);  // the shards run side by side: the slowest counts
             stats->total_ms = std::max(stats->total_ms, one.total_ms);
+            if (g == 0 || one.sweep_kind > stats->sweep_kind) stats->sweep_kind = one.sweep_kind;  // (shards of one handle take the same sweep unless a mirror did not fit on one)
+            stats->sweep_launches = std::max(stats->sweep_launches, one.sweep_launches);
         }
     }
     return NMN_OK;

@@ -59,6 +59,7 @@ ENGINE_SIGNATURES = {
     "nmn_engine_clear": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     "nmn_engine_batch_store": (C.c_int32, [vp, C.POINTER(C.c_char_p), vp, C.c_uint64, C.c_uint64]),
     "nmn_engine_search_similar": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "nmn_engine_search_probe": (C.c_int32, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
     "nmn_engine_get_metadata": (vp, [vp, C.c_char_p, C.POINTER(C.c_int32)]),
     "nmn_metalist_len": (C.c_uint64, [vp]),
     "nmn_metalist_name": (C.c_char_p, [vp, C.c_uint64]),
@@ -557,6 +558,15 @@ class VectorEngine:
         h = vp()
         _check(_lib().nmn_engine_search_similar(self._h, p, n, int(top_k), C.byref(h)))
         return self._take_results(h)
+
+    def search_probe(self, queries, top_k, calls):
+        """Microseconds of each of `calls` back-to-back search_similar calls made natively by one host thread (measurement aid,
+        nmn_engine_search_probe): query i % len(queries) for call i."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        out = np.empty(int(calls), dtype=np.float32)
+        _check(_lib().nmn_engine_search_probe(self._h, q.ctypes.data_as(vp), q.shape[0], q.shape[1], int(top_k), int(calls),
+                                              out.ctypes.data_as(vp)))
+        return out
 
     # ---- tensor_blob artifact similarity (tensor_blob/src/lib.rs:520-625) ----
     def blob_set_embedding(self, artifact_id, filename, embedding):

@@ -70,16 +70,22 @@ def test_config2_1Mx768_cosine_top100_single_query():
         for row, v in planted.items():
             idx.set_row(row, v)
             A[row] = v
-        for qi in range(8):
-            rows, scores, counts, st = idx.search(Q[qi], k, 0, with_stats=True)
-            er, es = _oracle(A, Q[qi], k, 0, literal=True)
-            _check_query(rows, scores, counts, 0, er, es)
-            assert st.fallback_queries == 0
-        # Euclidean and dot product over the same resident corpus
-        for metric in (1, 2):
-            rows, scores, counts = idx.search(Q[5], k, metric)
-            er, es = _oracle(A, Q[5], k, metric, literal=True)
-            _check_query(rows, scores, counts, 0, er, es)
+        want = [_oracle(A, Q[qi], k, 0, literal=True) for qi in range(8)]
+        want_m = {metric: _oracle(A, Q[5], k, metric, literal=True) for metric in (1, 2)}
+        # the library's default (8-bit mirror), the bf16 mirror, and — the sweep SURVEY §8(d) prices and bench.py's c2_f32_* quotes —
+        # the ROW-MAJOR F32 CORPUS through the LDS-DMA ring (nmn_scan_ring.hip): every list of every sweep is the oracle's
+        for mode, nbytes, sweep in ((1, 1, "valu_i8"), (2, 2, "valu_bf16"), (0, 4, "ring_f32")):
+            idx.set_mirror(mode)
+            for qi in range(8):
+                rows, scores, counts, st = idx.search(Q[qi], k, 0, with_stats=True)
+                _check_query(rows, scores, counts, 0, *want[qi])
+                assert st.fallback_queries == 0
+                assert st.bytes_scanned == n * d * nbytes and st.sweep == sweep, (mode, st.bytes_scanned, st.sweep)
+            # Euclidean and dot product over the same resident corpus
+            for metric in (1, 2):
+                rows, scores, counts, st = idx.search(Q[5], k, metric, with_stats=True)
+                _check_query(rows, scores, counts, 0, *want_m[metric])
+                assert st.bytes_scanned == n * d * nbytes and st.sweep == sweep and st.fallback_queries == 0, (mode, metric, st.sweep)
 
 
 @pytest.fixture(scope="module")
@@ -215,7 +221,7 @@ def test_config4_80Mx768_eight_shards_of_10M_rows_on_one_gpu():
         # 100 best of 80M uniformly spread rows: every list reaches into the last shard's range (P(miss) = (7/8)^100 ~ 1e-6)
         assert all(int(r[0].max()) >= 70_000_000 for r, _, _ in singles)
 
-        # 64 queries per call (shards that kept a mirror take the matrix-core sweep, the others f32 VALU sweeps of four)
+        # 64 queries per call (the matrix-core sweep on every shard: over its mirror where it kept one, else over its f32 rows — nmn_scan_mfma_f32.hip)
         rows_b, scores_b, counts_b, st_b = sh.search(QB, k, 0, with_stats=True)
         assert np.all(counts_b == k) and st_b.rows_scanned == n
         for qi in (0, 31, 63):
@@ -256,19 +262,28 @@ def test_config4_80Mx768_eight_shards_of_10M_rows_on_one_gpu():
 
 
 def test_config5_10Mx1536_l2_top1000_masked():
-    """BASELINE config 5: Euclidean TOP-1000 over 10M x 1536 with a selection bitmap of selectivity 1.0 / 0.5 / 0.1
-    (relational_engine's layout: bit i of word i/64, LSB first)."""
+    """BASELINE config 5: Euclidean TOP-1000 over 10M x 1536 with a selection bitmap of selectivity 1.0 / 0.5 / 0.1 / 0.02
+    (relational_engine's layout: bit i of word i/64, LSB first) — on the library's default sweep (the 8-bit mirror), on the bf16
+    mirror and on the ROW-MAJOR F32 CORPUS (nmn_index_set_mirror(0): the ring sweep without a bitmap, scan_kernel's survivor walk
+    under one — the kernels bench.py's c5_mask*_f32_* figures time), each against the oracle (search_with_pre_filter's survivor
+    scan, lib.rs:3514-3557).  The sweep reads the KEPT rows only: bytes_scanned = kept x dim x (1 | 2 | 4)."""
     from neumann_amd import GpuFlatIndex
     _need_ram(96)
     n, d, k = 10_000_000, 1536, 1000
     A = oc.synth(0x5EED0005, 0, n, d, nthreads=CORES)
-    Q = oc.synth(0x5EED0002, 3000, 3, d)
+    Q = oc.synth(0x5EED0002, 3000, 4, d)
     rng = np.random.default_rng(0x5EED0005)
     with GpuFlatIndex(d, n) as idx:
         idx.fill_synthetic(0x5EED0005, n)
-        for qi, sel in enumerate((1.0, 0.5, 0.1)):
-            mask = None if sel >= 1.0 else oc.mask_from_bool(rng.random(n) < sel)
-            rows, scores, counts, st = idx.search(Q[qi], k, 1, mask=mask, with_stats=True)
+        for qi, sel in enumerate((1.0, 0.5, 0.1, 0.02)):
+            keep = None if sel >= 1.0 else rng.random(n) < sel
+            mask = None if keep is None else oc.mask_from_bool(keep)
+            kept = n if keep is None else int(keep.sum())
             er, es = _oracle(A, Q[qi], k, 1, mask=mask, literal=sel == 0.1)
-            _check_query(rows, scores, counts, 0, er, es)
-            assert st.fallback_queries == 0
+            for mode, nbytes, sweeps in ((1, 1, ("valu_i8",)), (0, 4, ("ring_f32",) if keep is None else ("valu_f32",)), (2, 2, ("valu_bf16",))):
+                idx.set_mirror(mode)
+                rows, scores, counts, st = idx.search(Q[qi], k, 1, mask=mask, with_stats=True)
+                _check_query(rows, scores, counts, 0, er, es)
+                assert st.fallback_queries == 0, (sel, mode)
+                assert st.rows_scanned == kept and st.bytes_scanned == kept * d * nbytes, (sel, mode, st.rows_scanned, st.bytes_scanned)
+                assert st.sweep in sweeps, (sel, mode, st.sweep)
