@@ -209,10 +209,12 @@ nmn_status nmn_index_scan_history(nmn_index* idx, void* stream, float* scan_ms, 
 nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled);
 /* Device memory the shard holds for its rows: corpus_bytes = the f32 rows (capacity x stride x 4), mirror_bytes = the 8-bit and
  * bf16 mirrors that exist right now, with their per-row factors; per_row_bytes = magnitudes and their reciprocals.  Workspaces
- * (per stream, sized by the largest search seen) are not counted.  Any pointer may be null.  Side effect: a mirror that was
- * declined (or a query pass that was shrunk) because the device was short of memory is given another chance by the next search
- * that wants it — such verdicts also expire by themselves every 4096 searches. */
+ * (per stream, sized by the largest search seen) are not counted.  Any pointer may be null.  No side effects. */
 nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes);
+/* A mirror that was declined (or a query pass that was shrunk) because the device was short of memory stays declined until the
+ * verdict expires (every 4096 searches) — or until this call: the next search that wants the mirror / the larger pass asks the device
+ * again.  For a host that has just freed memory on the device (dropped a sibling shard, a collection). */
+nmn_status nmn_index_retry_declined(nmn_index* idx);
 /* hipEvent timing of searches (default 0 = off).  1: events at the start and end of the pipeline and around its sweep (scan_ms,
  * total_ms of nmn_index_last_stats).  2: the two events around the sweep only (scan_ms, nmn_index_scan_history) — what a timed
  * loop can afford on a small shard: every event is a packet of its own in the queue (1M x 768: four more cost ~9 % of a step). */

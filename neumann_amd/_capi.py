@@ -114,6 +114,7 @@ SIGNATURES = {
     "nmn_index_set_mirror": (C.c_int32, [vp, C.c_int32]),
     "nmn_index_scan_history": (C.c_int32, [vp, vp, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "nmn_index_hbm_bytes": (C.c_int32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "nmn_index_retry_declined": (C.c_int32, [vp]),
     "nmn_index_score_rows": (C.c_int32, [vp, vp, C.c_uint32, C.c_int32, vp, C.c_uint32, vp]),
     "nmn_index_count_exact": (C.c_int32, [vp, vp, C.c_int32, vp, C.c_float, u64p, u64p]),
     "nmn_index_read_probe": (C.c_int32, [vp, C.c_uint32, C.POINTER(C.c_double)]),

@@ -166,11 +166,11 @@ struct IdleGuard {
     }
 };
 
+static void ws_release_core(Workspace* w);
 static void ws_free(Workspace* w) {
     if (!w) return;
-    void* ptrs[] = {w->crowd_ctr, w->crowd_rows, w->crowd_scores, w->scores, w->tmax, w->wmax, w->tsample, w->skip_key, w->k_extra, w->qpad, w->qi8, w->qinfo, w->qinfo_f32, w->qstate, w->cand_rows, w->cand_scores, w->h_queries,
-                    w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist,
-                    w->h_counts2, w->lk_keys};
+    ws_release_core(w);  // everything ws_alloc made (the list lives in ONE place: round 6 found the fallback selection's four buffers missing here)
+    void* ptrs[] = {w->h_queries, w->h_mask, w->h_out_rows, w->h_out_scores, w->h_out_counts, w->h_rowlist, w->h_scorelist, w->lk_keys};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w->h_pack) (void)hipFree(w->h_pack);
@@ -215,7 +215,9 @@ static hipError_t grow_pinned(uint8_t** p, size_t* cap, size_t need) {
     return e;
 }
 
-constexpr uint32_t kSampleStep = 32;  // sampling pass of the batched sweep: every 32nd tile (3 % of the corpus; 64 / 128 measured the same)
+constexpr uint32_t kSampleStep = 32;
+// (scan_mfma_kernel's skip_sampled arithmetic divides by S - 1 and keeps the sampling pass's tile maxima in groups of four: ADVICE r05)
+static_assert(kSampleStep >= 4 && kSampleStep % 4 == 0, "the sampling step must be a multiple of 4");  // sampling pass of the batched sweep: every 32nd tile (3 % of the corpus; 64 / 128 measured the same)
 
 // queries per pipeline pass: bound the score matrix to ~4 GiB
 static uint32_t pass_queries(const nmn_index* idx, uint32_t nq) {
@@ -225,6 +227,7 @@ static uint32_t pass_queries(const nmn_index* idx, uint32_t nq) {
     return (uint32_t)std::min<uint64_t>(m, nq);
 }
 
+static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w);
 static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32_t k, Workspace** out) {
     Workspace* w = nullptr;
     auto it = idx->ws.find(stream);
@@ -241,6 +244,30 @@ static nmn_status ws_get(nmn_index* idx, hipStream_t stream, uint32_t nq, uint32
         HIP_TRY(hipStreamSynchronize(stream));
         nqc = std::max(nqc, w->nq_cap);
         cand_cap = std::max(cand_cap, w->cand_cap);
+        if (w->allocated && w->cand_cap >= cand_cap) {
+            // Only the query pass grows (a larger batch, or an out-of-memory verdict that expired): the larger workspace is tried
+            // BEFORE the working one is given up (on a device that is still full the old order freed a multi-GB
+            // workspace, failed to get the larger one and came back through the OOM loop — every time the verdict expired).
+            Workspace* wn = new (std::nothrow) Workspace();
+            if (!wn) return fail_arg(NMN_ERR_OUT_OF_MEMORY, "workspace alloc");
+            wn->stream = stream;
+            wn->nq_cap = nqc;
+            wn->cand_cap = cand_cap;
+            const nmn_status st = ws_alloc_core(idx, wn);
+            if (st == NMN_OK) {
+                wn->allocated = true;
+                idx->ws.erase(stream);
+                ws_free(w);
+                idx->ws[stream] = wn;
+                *out = wn;
+                return NMN_OK;
+            }
+            ws_free(wn);
+            if (st != NMN_ERR_OUT_OF_MEMORY) return st;
+            idx->ws_nq_limit = std::min(idx->ws_nq_limit, w->nq_cap);  // the working one serves, in more passes
+            *out = w;
+            return NMN_OK;
+        }
         idx->ws.erase(stream);
         ws_free(w);
     }
@@ -263,7 +290,7 @@ constexpr uint64_t kCrowdPool = 8ull << 20;
 static void ws_release_core(Workspace* w) {
     void** ptrs[] = {(void**)&w->scores, (void**)&w->tmax, (void**)&w->wmax, (void**)&w->tsample, (void**)&w->skip_key,
                      (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qi8, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
-                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
+                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->final_ticket, (void**)&w->run_slots, (void**)&w->run_bound, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
                      (void**)&w->crowd_rows, (void**)&w->crowd_scores, (void**)&w->fb_hist, (void**)&w->fb_list, (void**)&w->fb_count,
                      (void**)&w->fb_sync};
     for (void** p : ptrs) {
@@ -309,6 +336,11 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_rows), nq * w->cand_cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->final_ticket), nq * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->run_slots), nq * 256 * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->run_bound), ((nq + 127) & ~(size_t)127) * 4 + 512));  // (+ a 64-query group's LDS-DMA may start at any multiple of 64)
+    HIP_TRY(hipMemset(w->run_bound, 0, ((nq + 127) & ~(size_t)127) * 4 + 512));
+    HIP_TRY(hipMemset(w->final_ticket, 0, nq * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->h_counts2), 2 * sizeof(unsigned long long)));
     if (idx->cap_pad >= kCrowdMinRows) {
         // 8M entries, or 128K per query of the pass when that is more (a 128-query batch of crowded queries)
@@ -523,13 +555,22 @@ extern "C" nmn_status nmn_index_set_mirror(nmn_index* idx, int32_t enabled) {
 extern "C" nmn_status nmn_index_hbm_bytes(nmn_index* idx, uint64_t* corpus_bytes, uint64_t* mirror_bytes, uint64_t* per_row_bytes) {
     if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
     std::lock_guard<std::mutex> g(idx->mu);
-    idx->q8_failed = idx->half_failed = false;  // (whoever asks about memory has usually just changed it: see squeeze_calls)
-    idx->ws_nq_limit = 0xFFFFFFFFu;
+    // (an accounting getter, free of side effects since round 6 — ADVICE r05: a monitor polling it used to clear the shard's
+    //  out-of-memory verdicts, and every following batch then freed its working multi-GB workspace to retry the larger one on a device
+    //  that was still full; nmn_index_retry_declined is the explicit form, the 4096-search expiry the automatic one)
     const uint64_t elems = idx->cap_pad * (uint64_t)idx->ld;
     if (corpus_bytes) *corpus_bytes = elems * 4ull;
     if (mirror_bytes) *mirror_bytes = (idx->q8 ? elems + idx->cap_pad * 12ull : 0ull) + (idx->half ? elems * 2ull : 0ull);
     if (per_row_bytes) *per_row_bytes = idx->cap_pad * 8ull;
     return NMN_OK;
+}
+
+extern "C" nmn_status nmn_index_retry_declined(nmn_index* idx) {
+    if (!idx) return fail_arg(NMN_ERR_INVALID_ARGUMENT, "null index");
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->q8_failed = idx->half_failed = false;  // the next search that wants a declined mirror asks the device again (one hipMemGetInfo)
+    idx->ws_nq_limit = 0xFFFFFFFFu;             // ... and the next batch tries the full pass again (ws_get: the working workspace is kept
+    return NMN_OK;                              //     until the larger one exists)
 }
 
 extern "C" nmn_status nmn_index_set_timing(nmn_index* idx, int32_t enabled) {
@@ -930,6 +971,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
     };
     for (uint32_t qa = 0; qa < nq; qa += w->nq_cap) {
         const uint32_t nqc = std::min(w->nq_cap, nq - qa);
+        bool fused_tail = false;   // this pass ends in rescore_final_kernel (set where the rescore is enqueued)
+        RescoreParams rp_tail{};
         // The approximate sweep reads a MIRROR of the shard where one serves the call (its measured rounding error is part of
         // the candidate margin; every candidate is re-scored from the f32 rows): the 8-BIT mirror (1 B per element,
         // nmn_scan_i8.hip / nmn_scan_mfma.hip) for 1-2 queries on rows of whole 128-element halves and for batches on the row
@@ -1056,6 +1099,14 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
         const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18) && !short_chain;
+        // The batched sweep as ONE launch (round 6; ScanParams::run_*): the bound that gates its score stores rises inside the sweep
+        // itself — no sampling pass, no bound kernels, no split into two launches.  Unmasked batches on shards large enough for the
+        // sampled bound it replaces (>= 32 768 tiles), k <= 256 (slots per query: the power of two >= k, at least 128).
+        // NMN_NO_RUN_BOUND=1: the sampling pass + refinement, the A/B.
+        static const bool no_run_bound = env_set("NMN_NO_RUN_BOUND");
+        const bool run_bound = use_mfma && !no_run_bound && !no_sample() && !mask_dev && !qmasks_dev && k <= 256u &&
+                               n_tiles >= 1024u * kSampleStep && n_tiles / kSampleStep >= 4u * k;
+        const uint32_t run_S = !run_bound ? 0u : k <= 128u ? 128u : 256u;
         // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
@@ -1064,7 +1115,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                              //  complete bf16 mirror happens to exist, else the a-priori bound |e_r| <= 2^-8 |v_r| of qprep_kernel)
                              use_i8 ? idx->q8_err_bits : (use_half || (mfma_f32 && idx->half && idx->half_rows >= n_rows)) ? idx->half_err_bits : nullptr,
                              use_i8 ? w->qi8 : nullptr,
-                             (use_i8 && !use_mfma) ? idx->q8_l2_hint : nullptr, f32_retry ? w->qinfo_f32 : nullptr));
+                             (use_i8 && !use_mfma) ? idx->q8_l2_hint : nullptr, f32_retry ? w->qinfo_f32 : nullptr,
+                             run_bound ? w->run_slots : nullptr, run_S, run_bound ? w->run_bound : nullptr));
         if (n_rows > 0) {
             ScanParams sp{};
             sp.corpus = idx->corpus;
@@ -1159,7 +1211,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }();
             static const bool sample_behind = getenv("NMN_SAMPLE_AHEAD_OF_CHAIN") == nullptr;
             const uint32_t n_sample = (n_tiles + sample_step - 1) / sample_step;
-            const bool sample = use_mfma && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
+            const bool sample = use_mfma && !run_bound && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
+            if (run_bound) {
+                sp.run_slots = w->run_slots;
+                sp.run_bound = w->run_bound;
+                sp.run_S = run_S;
+            }
             auto sampling_pass = [&]() -> nmn_status {
                 ScanParams ss = sp;
                 ss.tile_step = sample_step;
@@ -1282,7 +1339,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.nq = nqc;
             sel.k = k;
             sel.cand_cap = w->cand_cap;
-            sel.skip_key = sp.skip_key;
+            sel.skip_key = run_bound ? w->run_bound : sp.skip_key;  // (the FINAL value of the running bound: every tile at or above it was written)
             sel.k_extra = nullptr;
             sel.retry = 0;
             sel.retry_follows = f32_retry ? 1 : 0;
@@ -1368,7 +1425,14 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             static const bool no_exact_rows = getenv("NMN_NO_EXACT_ROWS") != nullptr;
             const bool exact_rows = !no_exact_rows && n_rows >= (1u << 18) && exact_rows_supported(idx->ld, idx->dim, (int)metric) && !short_chain;  // (small shards: not worth a launch)
             rp.skip_fallback = (exact_rows || short_chain) ? 1 : 0;  // (short chain: flagged queries are the host's to follow up)
-            HIP_TRY(launch_rescore(rp, stream));
+            // The short chain CAN end in one launch — the last workgroup to finish a query's candidates sorts and emits them
+            // (rescore_final_kernel, nmn_exact.hip; NMN_FUSED_TAIL=1) — but it measured SLOWER than the two launches it replaces: the
+            // exact kernel needs 214 registers, so the fused workgroup is 512 threads and ranks two entries per thread — 27 us against
+            // 8 + 9 at 1M x 768 (~600 candidates; 33 us on 1024 threads with spills): profiles/r06d_*.  Off by default; exact either way.
+            static const bool fused_tail_on = env_set("NMN_FUSED_TAIL");
+            fused_tail = short_chain && fused_tail_on;
+            if (!fused_tail) HIP_TRY(launch_rescore(rp, stream));
+            rp_tail = rp;
             if (exact_rows)  // (returns at once unless a query of the pass is flagged)
                 HIP_TRY(launch_exact_rows(idx->corpus, idx->norms, idx->ld, n_rows, w->qpad, w->qinfo, w->qstate, 1, mask_dev,
                                           qmasks_dev ? qmasks_dev + qa : nullptr, w->scores, nqc, nqc, (int)metric, stream));
@@ -1389,6 +1453,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 HIP_TRY(launch_fallback_select(fb, stream));
             }
         }
+        if (n_rows == 0) fused_tail = false;
         FinalParams fp{};
         fp.fb_list = w->fb_list;
         fp.fb_count = w->fb_count;
@@ -1409,7 +1474,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.out_rows = out_rows + (size_t)qa * k;
         fp.out_scores = out_scores + (size_t)qa * k;
         fp.out_counts = out_counts + qa;
-        HIP_TRY(launch_final(fp, stream));
+        if (fused_tail) HIP_TRY(launch_rescore_final(rp_tail, fp, w->final_ticket, stream));
+        else HIP_TRY(launch_final(fp, stream));
     }
     if (w->timed == 1 && !nested) HIP_TRY(hipEventRecord(w->ev[3], stream));
     return NMN_OK;
@@ -1668,8 +1734,28 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     const size_t pack_bytes = off_pred + n_pred * pred_count_stride * 8;
     HIP_TRY(grow(&w->h_queries, &w->h_queries_cap, qn));
     HIP_TRY(grow(&w->h_pack, &w->h_pack_cap, pack_bytes));
-    HIP_TRY(grow_pinned(&w->pin_in, &w->pin_in_cap, qn * sizeof(float)));
-    HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes));
+    {
+        const uint8_t *in0 = w->pin_in, *out0 = w->pin_out;
+        HIP_TRY(grow_pinned(&w->pin_in, &w->pin_in_cap, qn * sizeof(float)));
+        HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes));
+        if (w->pin_in != in0 && hipHostGetDevicePointer(reinterpret_cast<void**>(&w->pin_in_dev), w->pin_in, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            w->pin_in_dev = nullptr;
+        }
+        if (w->pin_out != out0 && hipHostGetDevicePointer(reinterpret_cast<void**>(&w->pin_out_dev), w->pin_out, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            w->pin_out_dev = nullptr;
+        }
+    }
+    // Zero-copy I/O (round 6): the query block and the result block are pinned host memory the device can address, so the chain's
+    // first kernel (qprep) READS the queries from it and its last kernel WRITES rows | scores | counts into it — no H2D and no D2H
+    // copy packets around the chain (two blit kernels and their dependency gaps: ~10 us of a lone call's ~200,
+    // profiles/r05j_search_launch_chains.txt).  Small calls only (a batch's 200 KB of queries are better off as one DMA burst than as
+    // qprep's loads over PCIe); NMN_NO_ZERO_COPY=1: the staged copies, the A/B.
+    static const bool no_zero_copy = env_set("NMN_NO_ZERO_COPY");
+    const bool zero_copy = !no_zero_copy && w->pin_in_dev && w->pin_out_dev && qn * sizeof(float) <= (64u << 10) && res_bytes <= (256u << 10);
+    const float* const q_dev = zero_copy ? reinterpret_cast<const float*>(w->pin_in_dev) : w->h_queries;
+    uint8_t* const pack_dev = zero_copy ? w->pin_out_dev : w->h_pack;
     unsigned long long* const d_pred_counts = reinterpret_cast<unsigned long long*>(w->h_pack + off_pred);
     const unsigned long long* const h_pred_counts = reinterpret_cast<const unsigned long long*>(w->pin_out + off_pred);
     {
@@ -1679,7 +1765,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
             dst += (size_t)reqs[i]->nq * dim;
         }
     }
-    HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(w->h_queries, w->pin_in, qn * sizeof(float), hipMemcpyHostToDevice, s));
     // ---- predicates of the batch: one launch on this stream, each into its own bitmap -------------------------
     std::vector<const uint64_t*> eff_mask(n_reqs);  // the bitmap each request's queries are searched with
     size_t pred_words = 0;
@@ -1745,9 +1831,9 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         HIP_TRY(hipMemcpyAsync(w->h_mask, first.mask, words * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         mask_dev = w->h_mask;
     }
-    uint64_t* d_rows = reinterpret_cast<uint64_t*>(w->h_pack);
-    float* d_scores = reinterpret_cast<float*>(w->h_pack + off_scores);
-    uint32_t* d_counts = reinterpret_cast<uint32_t*>(w->h_pack + off_counts);
+    uint64_t* d_rows = reinterpret_cast<uint64_t*>(pack_dev);
+    float* d_scores = reinterpret_cast<float*>(pack_dev + off_scores);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(pack_dev + off_counts);
     // A mixed batch reads every row once; its members one by one read what their bitmaps select.  With predicates in
     // the batch the selectivities are known only now: fetch their counts (the launches above are tens of microseconds)
     // and serve the members separately when that is the cheaper way (few, selective filters).
@@ -1777,18 +1863,20 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         if (separately) {
             size_t q0 = 0;
             for (size_t i = 0; i < n_reqs && e == NMN_OK; i++) {
-                e = search_enqueue(idx, w, w->h_queries + q0 * dim, reqs[i]->nq, k, (nmn_metric)first.metric, eff_mask[i],
+                e = search_enqueue(idx, w, q_dev + q0 * dim, reqs[i]->nq, k, (nmn_metric)first.metric, eff_mask[i],
                                    d_rows + q0 * k, d_scores + q0 * k, d_counts + q0, s, nullptr, nullptr, short_chain);
                 q0 += reqs[i]->nq;
             }
         } else if (!qmasks.empty())
-            e = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, nullptr, d_rows, d_scores, d_counts, s,
+            e = search_enqueue(idx, w, q_dev, nq, k, (nmn_metric)first.metric, nullptr, d_rows, d_scores, d_counts, s,
                                w->h_qmasks, qmasks.data(), short_chain);
         else
-            e = search_enqueue(idx, w, w->h_queries, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s, nullptr,
+            e = search_enqueue(idx, w, q_dev, nq, k, (nmn_metric)first.metric, mask_dev, d_rows, d_scores, d_counts, s, nullptr,
                                nullptr, short_chain);
         if (e != NMN_OK) return e;
-        HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
+        if (!zero_copy) HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
+        else if (n_pred && words)  // (the results are already where the host reads them: only the predicates' counters travel)
+            HIP_TRY(hipMemcpyAsync(w->pin_out + off_pred, w->h_pack + off_pred, n_pred * pred_count_stride * 8, hipMemcpyDeviceToHost, s));
         return NMN_OK;
     };
     st = enqueue_all(try_short);

@@ -229,8 +229,13 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                                                    float* __restrict__ qpad, QInfo* __restrict__ qinfo,
                                                    QState* __restrict__ qstate, int mfma_pass,
                                                    const uint32_t* __restrict__ half_err_bits, uint32_t* __restrict__ qi8,
-                                                   const float* __restrict__ l2_hint, QInfo* __restrict__ qinfo_plain) {
+                                                   const float* __restrict__ l2_hint, QInfo* __restrict__ qinfo_plain,
+                                                   uint32_t* __restrict__ run_slots, uint32_t run_S, uint32_t* __restrict__ run_bound) {
     const uint32_t q = blockIdx.x;
+    if (run_S) {  // the one-launch batched sweep derives its score-store bound from these (ScanParams::run_*)
+        for (uint32_t i = threadIdx.x; i < run_S; i += 64u) run_slots[(size_t)q * run_S + i] = kKeyMasked;
+        if (threadIdx.x == 0) run_bound[q] = kKeyNaN;
+    }
     // The query comes into LDS in ONE round trip (every load of the block in flight together) and every later phase — the padded
     // copy, |q| in reference order, the bf16 / int8 roundings — reads it there.  (Until round 5 each phase looped over global
     // memory, a dependent load per 64 elements: 10 us at 768 elements and 25 us at 1536 in front of EVERY search, profiles/r05g_*.)
@@ -357,6 +362,14 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
         if (mfma_pass & 2) {  // bf16 mirror of the CORPUS (VALU and MFMA sweeps)
             split += 2.0f * rho_v;
             half_abs = half_err_bits ? 2.0f * u2f(half_err_bits[0]) : 7.9e-03f * u2f(*max_norm_bits);  // 2 max|e_r|
+            // The a-priori bound |e_r| <= 2^-8 |v_r| (f32 rows rounded to bf16 in registers, no mirror whose error was measured) holds
+            // for elements inside the bf16 range only: |x| > 3.39e38 rounds to +-inf, the approximate score becomes inf or NaN and the
+            // row could be dropped.  Such an element makes its row's magnitude — hence the shard's largest — at least
+            // that large: then no margin is claimed at all (infinite: every query of the pass takes the exact path).
+            if (!half_err_bits && !(u2f(*max_norm_bits) < 3.38e38f)) {
+                split = __builtin_inff();
+                half_abs = __builtin_inff();
+            }
         }
         if (mfma_pass & 1) {
             // bf16 QUERY on the MFMA sweep: q~ = q + e_q, v~ = v + e_v: |q~.v~ - q.v| <= |e_q||v~| + |q||e_v|
@@ -457,14 +470,15 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
 
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int mfma_pass,
-                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8, const float* l2_hint, QInfo* qinfo_plain) {
+                        hipStream_t s, const uint32_t* half_err_bits, uint32_t* qi8, const float* l2_hint, QInfo* qinfo_plain,
+                        uint32_t* run_slots, uint32_t run_S, uint32_t* run_bound) {
     const size_t lds = (size_t)ld * sizeof(float);  // the query (nmn_index_create: one query fits the 160 KiB LDS)
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qprep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(qprep_kernel, dim3(nq), dim3(64), lds, s, queries, dim, ld, metric, max_norm_bits, qpad,
-                       qinfo, qstate, mfma_pass, half_err_bits, qi8, l2_hint, qinfo_plain);
+                       qinfo, qstate, mfma_pass, half_err_bits, qi8, l2_hint, qinfo_plain, run_slots, run_S, run_bound);
     return hipGetLastError();
 }
 
@@ -529,6 +543,87 @@ hipError_t launch_rescore(const RescoreParams& p, hipStream_t s) {
     const uint32_t gx = std::max<uint32_t>(128u, (2048u + p.nq - 1) / p.nq);
     dim3 grid(gx, p.nq);
     hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- rescore + final in ONE launch (the short chain of the host-buffer API; round 6) ------------------------------------------
+// A search that waits for its answer (nmn_index_search and friends: search_enqueue's short chain) ran qprep -> sweep -> select ->
+// rescore -> final: two launches at the end of a DEPENDENT chain for ~600 candidates, each paying its launch (~4.5 us between two
+// dependent kernels, profiles/r05j_search_launch_chains.txt).  Here the workgroups that re-score a query's candidates take a ticket when
+// they are done, and the LAST one to finish orders the (exact key, row) composites and emits the top-k — final_kernel's ordinary
+// duty (sort_and_emit; a radix pre-pick when the list is longer than 1024), on 512 threads.  Release / acquire
+// through agent-scope fences around the ticket, as tiny_search_kernel does.  A query whose candidate list overflowed is reported
+// (out_counts[q] = 0xFFFFFFFF), never answered here: on the short chain the host follows up with the whole chain.
+// `ticket` [nq]: zero between launches (the last workgroup resets its query's).
+constexpr int kTailThreads = 512;  // two waves per SIMD: exact_score keeps its 200+ registers (1024 threads: 128, and it spilled — 33 us for ~600 candidates)
+__global__ void __launch_bounds__(kTailThreads) rescore_final_kernel(RescoreParams p, FinalParams f, uint32_t* ticket) {
+    __shared__ unsigned long long list[NMN_MAX_TOP_K];
+    __shared__ uint32_t hist[kBins];
+    __shared__ PickResult pick;
+    __shared__ uint32_t s_misc[2];
+    const uint32_t q = blockIdx.y, tid = threadIdx.x;
+    const uint32_t l = tid & 7u;
+    if (p.qstate[q].overflow) {  // (block-uniform)
+        if (blockIdx.x == 0 && tid == 0) f.out_counts[q] = 0xFFFFFFFFu;
+        return;
+    }
+    const float* qv = p.qpad + (size_t)q * p.ld;
+    const float qmag = p.qinfo[q].qmag;
+    const uint32_t count = min(p.qstate[q].cand_count, p.cand_cap);
+    constexpr uint32_t kPer = kTailThreads / 8;  // candidates per workgroup step: eight lanes each, in the reference's order
+    for (uint32_t c0 = blockIdx.x * kPer; c0 < count; c0 += gridDim.x * kPer) {
+        const uint32_t c = c0 + (tid >> 3);
+        const uint32_t cc = c < count ? c : count - 1;  // keep every 8-lane group converged
+        const uint32_t row = p.cand_rows[(size_t)q * p.cand_cap + cc];
+        const float vmag = p.metric == NMN_METRIC_COSINE ? p.norms[row] : 1.0f;
+        const float sc = exact_score(qv, p.corpus + (uint64_t)row * p.ld, p.dim, qmag, vmag, p.metric, l);
+        if (c < count && l == 0) p.cand_scores[(size_t)q * p.cand_cap + c] = sc;
+    }
+    __threadfence();  // this thread's scores are visible device-wide before the ticket says so
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = atomicAdd(ticket + q, 1u);
+        s_misc[0] = (t == gridDim.x - 1u) ? 1u : 0u;
+        if (t == gridDim.x - 1u) ticket[q] = 0u;  // (everybody else has come and gone: ready for the next launch on this stream)
+    }
+    __syncthreads();
+    if (s_misc[0] == 0u) return;
+    __threadfence();  // acquire: the other workgroups' scores
+    uint32_t n = min(count, (uint32_t)NMN_MAX_TOP_K);
+    for (uint32_t i = tid; i < n; i += kTailThreads) {
+        const uint32_t row = f.cand_rows[(size_t)q * f.cand_cap + i];
+        const uint32_t key = score_to_key(__builtin_nontemporal_load(p.cand_scores + (size_t)q * p.cand_cap + i));
+        list[i] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+    }
+    __syncthreads();
+    constexpr uint32_t kShort = 1024;  // lists up to this long are ordered by runs and ranks (two entries per thread here)
+    if (n > kShort && f.k < kShort) {  // (block-uniform) only the k best are wanted: final_kernel's pre-pick
+        __shared__ unsigned long long top[kShort];
+        const uint32_t T = radix2<kTailThreads>([&](uint32_t e) { return (uint32_t)(list[e] >> 32); }, n, f.k, hist, &pick);
+        if (tid == 0) s_misc[1] = 0;
+        __syncthreads();
+        for (uint32_t b0 = tid & ~63u; b0 < n; b0 += kTailThreads) {
+            const uint32_t i = b0 + (tid & 63u);
+            const unsigned long long v = i < n ? list[i] : 0ull;
+            const bool pr = i < n && (uint32_t)(v >> 32) >= T;
+            const uint32_t pos = wave_append(pr, &s_misc[1]);
+            if (pr && pos < kShort) top[pos] = v;
+        }
+        __syncthreads();
+        const uint32_t c = s_misc[1];
+        if (c <= kShort) {
+            for (uint32_t i = tid; i < c; i += kTailThreads) list[i] = top[i];
+            n = c;
+        }
+        __syncthreads();
+    }
+    sort_and_emit(list, n, n, f.k, f.row_base, f.out_rows + (size_t)q * f.k, f.out_scores + (size_t)q * f.k, f.out_counts + q);
+}
+
+hipError_t launch_rescore_final(const RescoreParams& p, const FinalParams& f, uint32_t* ticket, hipStream_t s) {
+    // cand_cap candidates = cand_cap / 128 workgroup steps; every workgroup of a query's row takes a ticket, so the row is short
+    const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>(32u, (p.cand_cap + kTailThreads / 8 - 1) / (kTailThreads / 8)));
+    hipLaunchKernelGGL(rescore_final_kernel, dim3(gx, p.nq), dim3(kTailThreads), 0, s, p, f, ticket);
     return hipGetLastError();
 }
 

@@ -47,6 +47,9 @@ struct Workspace {
     QState* qstate = nullptr;
     uint32_t* cand_rows = nullptr;
     float* cand_scores = nullptr;
+    uint32_t* run_slots = nullptr;     // [nq_cap][256] the one-launch batched sweep's slot maxima (ScanParams::run_slots)
+    uint32_t* run_bound = nullptr;     // [nq_cap rounded up to 128] ... and its published bounds
+    uint32_t* final_ticket = nullptr;  // [nq_cap] arrival counters of rescore_final_kernel (zero between launches)
     // staging for the host-buffer API
     float* h_queries = nullptr;  size_t h_queries_cap = 0;   // device copies of host inputs
     uint64_t* h_mask = nullptr;  size_t h_mask_cap = 0;
@@ -63,6 +66,8 @@ struct Workspace {
     uint8_t* pin_pred = nullptr; size_t pin_pred_cap = 0;                // pinned host staging of pred_block
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
     uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
+    uint8_t* pin_in_dev = nullptr;    // the same blocks as the device sees them (zero-copy I/O of the host-buffer API: qprep reads the
+    uint8_t* pin_out_dev = nullptr;   // queries from pinned host memory, the last kernel of the chain writes the results into it)
     // single-launch search of a small shard (tiny_search_kernel): candidate pool, ticket, and the result block the kernel
     // writes straight into pinned host memory ([rows 1024 x u64 | scores 1024 x f32 | count])
     unsigned long long* tiny_pool = nullptr;

@@ -76,6 +76,55 @@ __host__ __device__ inline uint32_t bits_to_key(uint32_t score_bits) {  // score
 }
 constexpr uint32_t kKeyNegInf = 0x007FFFFFu;  // score_to_key(-inf)
 
+// collection threshold key from the radix lower bound T and the query's error margins
+static __device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
+    uint32_t Tc = kKeyNaN;
+    if (T > kKeyNegInf) {
+        float tau = key_to_score(T);
+        float m_abs = qi.margin_abs;
+        if (qi.pad_sq > 0.0f) {
+            // 8-bit Euclidean sweep: the distance may be off by qi.pad AND, on top, its square by qi.pad_sq (both two-sided):
+            // the threshold distance d grows to sqrt((d + pad)^2 + pad_sq); the score is 1 / (1 + d), or -d (IVF list scan)
+            if (qi.neg_d != 0.0f) {
+                const float d = fmaxf(-tau, 0.0f) + qi.pad;
+                tau = -sqrtf(d * d + qi.pad_sq);
+            } else if (tau > 0.0f) {
+                const float d = fmaxf(1.0f / tau - 1.0f, 0.0f) + qi.pad;
+                tau = 1.0f / (1.0f + sqrtf(d * d + qi.pad_sq));
+            }
+            const float thr = tau - fabsf(tau) * qi.margin_rel;
+            uint32_t Tq = kKeyNaN;
+            if (thr == thr) {
+                Tq = score_to_key(thr);
+                if (Tq > T) Tq = T;
+                if (Tq < kKeyNaN) Tq = kKeyNaN;
+            }
+            return Tq;
+        }
+        // Euclidean score 1/(1+d) swept over the bf16 mirror: the distance may be off by up to qi.pad (two-sided), i.e.
+        // the threshold distance 1/tau - 1 grows by qi.pad
+        if (qi.pad > 0.0f && tau > 0.0f) tau = tau / (1.0f + qi.pad * tau);
+        // ... swept by the matrix cores (|q|^2 + |v|^2 - 2 q.v): the SQUARED distance may be off by up to -qi.pad
+        // (two-sided), i.e. the threshold distance d = 1/tau - 1 grows to sqrt(d^2 - qi.pad)
+        if (qi.pad < 0.0f && qi.margin_abs < 0.0f) {  // ... with the score -d of the IVF list scan (flag: margin_abs < 0)
+            const float d = fmaxf(-tau, 0.0f);
+            tau = -sqrtf(d * d - qi.pad);
+            m_abs = 0.0f;
+        } else if (qi.pad < 0.0f && tau > 0.0f) {
+            const float d = fmaxf(1.0f / tau - 1.0f, 0.0f);
+            tau = 1.0f / (1.0f + sqrtf(d * d - qi.pad));
+        }
+        const float thr = tau - m_abs - fabsf(tau) * qi.margin_rel;
+        if (thr == thr) {
+            Tc = score_to_key(thr);
+            if (Tc > T) Tc = T;
+            if (Tc < kKeyNaN) Tc = kKeyNaN;
+        }
+    }
+    return Tc;
+}
+
+
 // ---- layout of the approximate-score matrix -------------------------------------------------
 // scores[tile][query-in-pass][64 rows]: tile-major, so a batched sweep writes ONE contiguous block per
 // tile (64 queries x 256 B = 16 KiB) instead of 64 scattered 256-B pieces (that cost 1.5 ms of a 6.3 ms
@@ -125,6 +174,17 @@ struct ScanParams {
     uint32_t walk;           // masked 8-bit VALU sweep: 1 = the survivor walk (participating rows of up to 64 tiles listed and read four
                              // per step across tile borders, nmn_scan_i8.hip); 0 = tile by tile
     uint32_t bx_base, bx_count;  // MFMA sweep: this launch covers workgroups [bx_base, bx_base + bx_count) (0 = to the end)
+    // MFMA sweep, ONE launch per batch (round 6): the bound that gates the score stores is derived INSIDE the sweep.  run_S slots per
+    // query (a power of two >= k, <= 256; 0 = off): slot s holds the largest tile maximum seen so far among the tiles t with
+    // t % run_S == s (atomicMax by the workgroups that stream them).  The slots' sets of tiles are disjoint, so the smallest slot
+    // value is reached by run_S >= k different tiles: a valid lower bound on the k-th best approximate score at ANY moment, rising
+    // as the sweep proceeds.  Every wave re-reads the slots of one query every fourth tile (LDS-DMA, no VGPR-destination load in
+    // the loop) and publishes margin_key(min) into run_bound[q] (atomicMax); the workgroups pick the current run_bound up with the
+    // row magnitudes of each tile.  A tile writes its scores when its maximum reaches the bound it sees — never above the final
+    // value of run_bound, which is what select_kernel is given as skip_key.  qprep_kernel zeroes the slots and resets the bounds.
+    uint32_t* run_slots;     // [nq][run_S] keys (0 = no tile yet)
+    uint32_t* run_bound;     // [nq rounded up to 128] keys (kKeyNaN = no bound yet: every tile writes)
+    uint32_t run_S;
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
@@ -198,6 +258,7 @@ struct SelectParams {
     float* l2_hint;            // nullable: query 0's threshold distance is left here (feeds qprep's choice of the 8-bit Euclidean estimator)
     int count_overflows;       // 1: half_stats[1] counts the queries whose candidate list overflowed in THIS selection (batched 8-bit
                                // sweeps have no f32 retry whose selections could be counted)
+    int flat;                  // set by launch_select: shards of <= 16 384 tiles select from all their tile maxima at once (NMN_NO_FLAT_SELECT=1: off)
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);
@@ -265,6 +326,10 @@ struct FinalParams {
     uint32_t* out_counts;
 };
 hipError_t launch_final(const FinalParams& p, hipStream_t s);
+struct RescoreParams;
+// rescore + final as ONE launch for the short chain (nmn_exact.hip): the last workgroup to finish a query's candidates sorts and emits;
+// a query flagged `overflow` is reported as out_counts[q] = 0xFFFFFFFF.  `ticket` [nq] must be zero (the kernel leaves it zero).
+hipError_t launch_rescore_final(const RescoreParams& p, const FinalParams& f, uint32_t* ticket, hipStream_t s);
 
 // list l of each field starts `list_stride_bytes` * l bytes after list 0 (0 = contiguous [list][nq][k])
 hipError_t launch_merge(const uint64_t* rows, const float* scores, const uint32_t* counts, uint64_t list_stride_bytes,
@@ -277,7 +342,8 @@ hipError_t launch_norms(const float* corpus, uint32_t ld, uint32_t dim, uint64_t
 hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_t ld, int metric,
                         const uint32_t* max_norm_bits, float* qpad, QInfo* qinfo, QState* qstate, int approx_pass,
                         hipStream_t s, const uint32_t* half_err_bits = nullptr, uint32_t* qi8 = nullptr,
-                        const float* l2_hint = nullptr, QInfo* qinfo_plain = nullptr);  // qinfo_plain: also the approx_pass == 0 record (f32 retry)
+                        const float* l2_hint = nullptr, QInfo* qinfo_plain = nullptr,  // qinfo_plain: also the approx_pass == 0 record (f32 retry)
+                        uint32_t* run_slots = nullptr, uint32_t run_S = 0, uint32_t* run_bound = nullptr);  // (ScanParams::run_*: reset here)
 // approx_pass bits: 1 = the sweep's copy of the query is rounded (bf16 on the MFMA sweep; with bit 4 the int8 split
 // q = s_q (h + l / 256), written to qi8[q][2][ld] and QInfo.qscale), 2 = the sweep reads a mirror of the corpus
 // (half_err_bits = that mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep;

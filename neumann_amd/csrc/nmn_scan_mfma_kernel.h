@@ -178,6 +178,23 @@ __device__ __forceinline__ float l2_score_i8(float qq8, float vv, float dot) {  
 // LDS reads per lane, rounded to bf16 in registers (v_cvt_pk_bf16_f32, round to nearest even) on their way into the same
 // v_mfma_f32_16x16x32_bf16.  HBM bytes are those of the f32 rows, read once per 64-128 queries; the rounding of the rows is
 // bounded a priori (|e_r| <= 2^-8 |v_r|: qprep_kernel without measured error norms) instead of measured at a mirror's build.
+// bytes of dynamic LDS the kernel uses without the running bound (= where the running bound's block starts); one formula for the
+// kernel and for launch_one_mfma
+template <int KS, int QG, int WAVES, bool I8>
+__host__ __device__ constexpr uint32_t kRunLdsBase() {
+    return (uint32_t)(kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0) +
+                      WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 16 +
+#ifdef NMN_MFMA_PACK
+                      (I8 ? kNormSlots * 64 * 4 + WAVES * (16 * 64 + 16) * 4 : 0));
+#else
+                      (I8 ? kNormSlots * 64 * 4 : 0));
+#endif
+}
+template <int QG, int WAVES>
+__host__ __device__ constexpr uint32_t kRunLdsBytes() {
+    return (uint32_t)(kNormSlots * QG * 16 * 4 + WAVES * 256 * 4 + QG * 16 * (int)sizeof(QInfo));
+}
+
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES, bool I8 = false, bool F32 = false>
 __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(ScanParams p) {
     static_assert(!(I8 && F32), "one streamed matrix");
@@ -207,6 +224,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     constexpr bool kPack = false;
 #endif
     float* const pack_lds = nrm2 + kNormSlots * 64;
+    // (ScanParams::run_*) behind everything above — launch_one_mfma sizes the block for it:
+    //   bnd   [kNormSlots tiles][QG * 16] the published bounds as picked up with each tile's row magnitudes (LDS-DMA by wave 0)
+    //   slotb [WAVES][256]               the slots of the query a wave is refreshing (LDS-DMA by that wave)
+    //   qmrg  [QG * 16] QInfo            the margins of the workgroup's queries (read once, before the loop)
+    constexpr uint32_t kQ = (uint32_t)QG * 16u;
+    uint32_t* const bnd = reinterpret_cast<uint32_t*>(lds) + (kRunLdsBase<KS, QG, WAVES, I8>() >> 2);
+    uint32_t* const slotb = bnd + kNormSlots * kQ;
+    QInfo* const qmrg = reinterpret_cast<QInfo*>(slotb + (uint32_t)WAVES * 256u);
+    const uint32_t run_S = p.run_S;  // (scalar; 0 = the bound comes from p.skip_key, if any)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = lane >> 4, n = lane & 15u;
@@ -299,6 +325,21 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         wmax_h[h] = kKeyMasked;
     }
 
+    if (run_S) {  // the margins of the workgroup's queries into LDS: the refresh below must not load from global memory inside the loop
+        for (uint32_t i = threadIdx.x; i < kQ; i += (uint32_t)WAVES * 64u)
+            qmrg[i] = p.qinfo[min(q0 + i, p.nq - 1u)];
+        __syncthreads();
+    }
+    // the published bounds of the workgroup's queries, as they stand now, into slot `rel` of the bound ring (wave 0; 4 bytes per lane)
+    auto bound_dma = [&](uint32_t rel) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t h = 0; h < kQ; h += 64u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.run_bound + q0 + h + lane),
+                                             (__attribute__((address_space(3))) void*)(bnd + (rel % kNormSlots) * kQ + h), 4, 0, 16);  // sc1: agent scope —
+            // the bounds are raised by OTHER compute units' atomics (at L2): a load that may hit this CU's vector cache would keep
+            // reading the line it saw first (measured: every tile kept writing, the 8-bit sweep 1.5 -> 5.6 ms)
+    };
+    uint32_t pend_q = 0xFFFFFFFFu;  // (wave-uniform) the query whose slots this wave has in flight / in slotb
     const uint32_t tstep = p.tile_step;                  // 1, or S on the sampling pass (tile index i -> tile i*S)
     const bool sampling = tstep > 1;
     const uint32_t t0 = bx * p.tiles_per_wave;  // tiles per WORKGROUP on this path
@@ -335,6 +376,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     for (uint32_t s0 = 0; s0 < kRing; s0++) {
         if (s0 < n_stage) {
             // (the magnitudes of stage kRing - 1's tile too: its pieces go out during the first iteration)
+            if (run_S && wave == 0 && s0 % KC == 0) bound_dma(s0 / KC);
             if (kNeedNorms && wave == 0 && s0 % KC == 0)
             {
                 norms_dma(norm_src, (uint64_t)tile_of(j0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kNormSlots) * 64u, lane);
@@ -372,12 +414,15 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     // 4.93 ms, bf16 mirror 2.60 vs 2.66: nothing / worse; tools/micro/mfma_deferred_epilogue.patch, profiles/r05zj_*.)
     // tile maxima of the current group of four tiles (see publish): [wave][query group of the wave][16 queries][4 tiles] in LDS
     uint32_t* const tk_pend = reinterpret_cast<uint32_t*>(nrm + kNormSlots * 64 + (kHalfK ? QG * 64 * 16 : 0));
-    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4]) __attribute__((always_inline)) {
+    auto finish_half = [&](auto half_c, const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4],
+                           const uint32_t (&skp)[kHalves]) __attribute__((always_inline)) {
         constexpr int H = decltype(half_c)::value;
         const uint32_t qn = qn_h[H];
         const bool q_ok = q_ok_h[H];
         const float qmag = qmag_h[H];
-        const uint32_t skip = skip_h[H];
+        // (running bound: the value picked up with this tile's row magnitudes — kRing - 1 stages old, and every older value of a
+        //  bound that only rises is a valid one)
+        const uint32_t skip = run_S ? skp[H] : skip_h[H];  // (skp: read from the bound ring at the top of the tile's last stage, like npre)
         f4 fin[4];
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) fin[rb] = facc[rb][H];
@@ -450,7 +495,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 #ifdef NMN_MFMA_NO_SCORE_WRITES
             return false;
 #else
-            return q_ok && (!sampling || finish_sampled) && tkey != kKeyMasked && tkey >= skip;
+            const bool wr_ = q_ok && (!sampling || finish_sampled) && tkey != kKeyMasked && tkey >= skip;
+            // a tile that reaches the bound may raise its slot (one below the bound cannot: the bound is the smallest slot)
+            if (run_S && wr_ && g == 0) atomicMax(p.run_slots + (size_t)qn * run_S + (ftile & (run_S - 1u)), tkey);
+            return wr_;
 #endif
         };
         // The two cases are two complete code paths (key, publish, stores): merged behind one `publish` the compiler carried
@@ -563,7 +611,8 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             }
         }
     };
-    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4]) __attribute__((always_inline)) {
+    auto finish_tile = [&](const f4 (&facc)[4][kAccGroups], uint32_t ftile, uint32_t frel, bool flast, const f4 (&npre)[4],
+                           const uint32_t (&skp)[kHalves]) __attribute__((always_inline)) {
 #ifdef NMN_MFMA_NO_EPILOGUE
         {  // measurement only (-DNMN_MFMA_NO_EPILOGUE build): the sweep without its epilogue (answers are wrong)
             float sink_v = 0.f;
@@ -575,8 +624,8 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             return;
         }
 #endif
-        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile, frel, flast, npre);
-        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile, frel, flast, npre);
+        if (!kHalfK || kh == 0) finish_half(std::integral_constant<int, 0>{}, facc, ftile, frel, flast, npre, skp);
+        if constexpr (kHalves > 1) finish_half(std::integral_constant<int, 1>{}, facc, ftile, frel, flast, npre, skp);
     };
 
     uint32_t sidx = 0;  // running stage index of this workgroup
@@ -584,6 +633,9 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         const uint32_t tile = tile_of(j);
         f4 acc[4][kAccGroups];  // [row block][query group of this wave]
         f4 npre[4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};  // the tile's per-row factors (see finish_half)
+        uint32_t skp[kHalves];  // the running bounds of this lane's queries as picked up for this tile (meaningful when run_S)
+#pragma unroll
+        for (int h = 0; h < kHalves; h++) skp[h] = kKeyNaN;
         v4i ach[I8 ? 4 : 1][kAccGroups], acl[I8 ? 4 : 1][kAccGroups];  // (I8) int32 sums of the h plane / the l plane
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
@@ -654,6 +706,11 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                                                  (__attribute__((address_space(3))) void*)(nbuf + (wave * kPieces + (uint32_t)pp) * 256u), 16, 0, AUX);
             NMN_MFMA_FENCE();
 #endif
+            if (kc == KC - 1) {  // (compile time) — unconditionally: a branch on run_S would cut the stage's basic block in two
+#pragma unroll
+                for (int h = 0; h < kHalves; h++)
+                    skp[h] = bnd[((j - j0) % kNormSlots) * kQ + ((uint32_t)h * (uint32_t)WAVES + grp) * 16u + n];
+            }
             if constexpr (kNeedNorms) {
                 if (kc == KC - 1) {  // (compile time: the stage loop is unrolled)
 #pragma unroll
@@ -711,6 +768,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // the stage's basic block.  One extra entry in wave 0's vmcnt queue per tile: its next waits are one piece conservative.
             // (issued for the tile of stage ns + 1, i.e. BEFORE that stage's pieces go out in the next iteration: in-order vmcnt then
             // lands it with them, and every wave passes a barrier behind wave 0's wait before the tile's epilogue reads it)
+            if (run_S && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) bound_dma((ns + 1u) / KC);
             if (kNeedNorms && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) {
                 const uint32_t nrel = (ns + 1u) / KC, nt1 = tile_of(j0 + nrel);
                 norms_dma(norm_src, (uint64_t)nt1 * tstep, nrm + (nrel % kNormSlots) * 64u, lane);
@@ -745,9 +803,38 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                     acc[rb][0] += *reinterpret_cast<const f4*>(xch + ((grp * 64u + lane) * 4u + (uint32_t)rb) * 4u);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            finish_tile(acc, tile, j - j0, j + 1u == j1, npre);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
+            finish_tile(acc, tile, j - j0, j + 1u == j1, npre, skp);  // (the wave pairs already pay a barrier per tile here: their epilogue stays in place)
         } else {
-            finish_tile(acc, tile, j - j0, j + 1u == j1, npre);
+            finish_tile(acc, tile, j - j0, j + 1u == j1, npre, skp);
+        }
+        if (run_S) {  // (scalar branch) the running bound's refresh: one query per wave every four tiles
+            const uint32_t rel = j - j0;
+            if ((rel & 3u) == 3u && pend_q != 0xFFFFFFFFu) {
+                // the slots asked for three tiles ago have landed (in-order vmcnt: >= 2 stages of pieces were issued behind them and
+                // waited for since) — their minimum is reached by run_S >= k different tiles
+                // (3 * KC stages of kPieces pieces each: where that is fewer than the ring's usual kRing - 2 stages — one 16-KiB stage per
+                //  tile — wait for exactly that many)
+                constexpr int kYounger = 3 * KC * kPieces < (kRing - 2) * kPieces ? 3 * KC * kPieces : (kRing - 2) * kPieces;
+                wait_vm_imm<kYounger>();
+                const u4 sv = lane * 4u < run_S ? *reinterpret_cast<const u4*>(slotb + wave * 256u + lane * 4u) : (u4){~0u, ~0u, ~0u, ~0u};
+                uint32_t m = min(min(sv[0], sv[1]), min(sv[2], sv[3]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+                if (m != kKeyMasked && lane == 0) {  // (every slot has seen a tile)
+                    const uint32_t b = margin_key(m, qmrg[pend_q - q0]);
+                    atomicMax(p.run_bound + pend_q, b);
+                }
+            }
+            if ((rel & 3u) == 0u) {
+                // the next query in turn: this wave's groups, sixteen queries each, offset by the workgroup's number so that the resident
+                // workgroups are at different queries at any moment
+                const uint32_t turn = ((rel >> 2) + bx) % (16u * (uint32_t)kBG);
+                const uint32_t qq = q0 + ((turn / 16u) * (uint32_t)WAVES + grp) * 16u + (turn % 16u);
+                pend_q = (kh == 0 && qq < p.nq) ? qq : 0xFFFFFFFFu;
+                if (pend_q != 0xFFFFFFFFu && lane * 4u < run_S)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.run_slots + (size_t)pend_q * run_S + lane * 4u),
+                                                     (__attribute__((address_space(3))) void*)(slotb + wave * 256u), 16, 0, 16);  // sc1 (as for the bounds)
+            }
         }
     }
     wait_vm_imm<0>();  // the dummy pieces of the tail must have landed before this workgroup's LDS is handed to the next one
@@ -777,14 +864,12 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
         pf.fold_ny = ny;
         grid = dim3(((blocks + 7u) / 8u) * 8u * ny, 1);
     }
-    const size_t lds = kRingBytes + kNormSlots * 64 * 4 + (QG * 2 == WAVES ? QG * 64 * 4 * 16 : 0) +  // + the K-halves' exchange
-                       (size_t)WAVES * (QG * 2 == WAVES ? 1 : QG / WAVES) * 16 * 16 +                      // + pending tile maxima
-#ifdef NMN_MFMA_PACK
-                       (I8 ? kNormSlots * 64 * 4 + (size_t)WAVES * (16 * 64 + 16) * 4 : 0);                // + (8-bit) |v~|^2 of the tiles' rows, the packed-store blocks
-#else
-                       (I8 ? kNormSlots * 64 * 4 : 0);  // + (8-bit) |v~|^2 of the tiles' rows (with the K-halves' exchange of the long rows
-                                                        //   the packed-store blocks of the measurement build would not fit in 160 KiB)
-#endif
+    // ring | row magnitudes | the K-halves' exchange | pending tile maxima | (8-bit) |v~|^2 of the tiles' rows (with the K-halves'
+    // exchange of the long rows the packed-store blocks of the measurement build would not fit in 160 KiB) | (run_S) the running bound's block
+    const size_t lds = (size_t)kRunLdsBase<KS, QG, WAVES, I8>() + (size_t)kRunLdsBytes<QG, WAVES>();  // (always: the stage body reads a bound slot unconditionally)
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    if (p.skip_sampled && (p.skip_sampled < 4u || (p.skip_sampled & 3u))) return hipErrorInvalidValue;  // (tile_of divides by S - 1; tmax groups of four)
+    if (p.run_S && (p.run_S > 256u || (p.run_S & (p.run_S - 1u)) || p.tile_step > 1u || p.skip_sampled)) return hipErrorInvalidValue;
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
 #ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
 #define NMN_MFMA_AUX 2

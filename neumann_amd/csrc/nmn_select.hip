@@ -12,94 +12,10 @@
 
 namespace nmn {
 
-// collection threshold key from the radix lower bound T and the query's error margins
-__device__ __forceinline__ uint32_t margin_key(uint32_t T, const QInfo& qi) {
-    uint32_t Tc = kKeyNaN;
-    if (T > kKeyNegInf) {
-        float tau = key_to_score(T);
-        float m_abs = qi.margin_abs;
-        if (qi.pad_sq > 0.0f) {
-            // 8-bit Euclidean sweep: the distance may be off by qi.pad AND, on top, its square by qi.pad_sq (both two-sided):
-            // the threshold distance d grows to sqrt((d + pad)^2 + pad_sq); the score is 1 / (1 + d), or -d (IVF list scan)
-            if (qi.neg_d != 0.0f) {
-                const float d = fmaxf(-tau, 0.0f) + qi.pad;
-                tau = -sqrtf(d * d + qi.pad_sq);
-            } else if (tau > 0.0f) {
-                const float d = fmaxf(1.0f / tau - 1.0f, 0.0f) + qi.pad;
-                tau = 1.0f / (1.0f + sqrtf(d * d + qi.pad_sq));
-            }
-            const float thr = tau - fabsf(tau) * qi.margin_rel;
-            uint32_t Tq = kKeyNaN;
-            if (thr == thr) {
-                Tq = score_to_key(thr);
-                if (Tq > T) Tq = T;
-                if (Tq < kKeyNaN) Tq = kKeyNaN;
-            }
-            return Tq;
-        }
-        // Euclidean score 1/(1+d) swept over the bf16 mirror: the distance may be off by up to qi.pad (two-sided), i.e.
-        // the threshold distance 1/tau - 1 grows by qi.pad
-        if (qi.pad > 0.0f && tau > 0.0f) tau = tau / (1.0f + qi.pad * tau);
-        // ... swept by the matrix cores (|q|^2 + |v|^2 - 2 q.v): the SQUARED distance may be off by up to -qi.pad
-        // (two-sided), i.e. the threshold distance d = 1/tau - 1 grows to sqrt(d^2 - qi.pad)
-        if (qi.pad < 0.0f && qi.margin_abs < 0.0f) {  // ... with the score -d of the IVF list scan (flag: margin_abs < 0)
-            const float d = fmaxf(-tau, 0.0f);
-            tau = -sqrtf(d * d - qi.pad);
-            m_abs = 0.0f;
-        } else if (qi.pad < 0.0f && tau > 0.0f) {
-            const float d = fmaxf(1.0f / tau - 1.0f, 0.0f);
-            tau = 1.0f / (1.0f + sqrtf(d * d - qi.pad));
-        }
-        const float thr = tau - m_abs - fabsf(tau) * qi.margin_rel;
-        if (thr == thr) {
-            Tc = score_to_key(thr);
-            if (Tc > T) Tc = T;
-            if (Tc < kKeyNaN) Tc = kKeyNaN;
-        }
-    }
-    return Tc;
-}
-
 #ifndef NMN_SELECT_VR
 #define NMN_SELECT_VR 16
 #endif
 constexpr uint32_t kListCap = 4096;  // LDS work lists (waves, tiles); both bounded by kMaxScanWaves / cand_cap
-
-// Two 11-bit radix digits over n gathered keys (key_at(e) == 0: does not take part): returns T, the
-// lower edge of the 2^10-ulp bin that holds the kk-th largest key.  Requires kk <= #valid keys.
-// Loads are issued V at a time per thread so a single workgroup still keeps ~8K loads in flight.
-template <typename KeyAt>
-__device__ uint32_t radix2(KeyAt key_at, uint32_t n, uint32_t kk, uint32_t* hist, PickResult* pick) {
-    const uint32_t tid = threadIdx.x;
-    constexpr int V = 8;
-    uint32_t b1 = 0, above1 = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
-        __syncthreads();
-        for (uint32_t e0 = tid; e0 < n; e0 += kSelThreads * V) {
-            uint32_t kv[V];
-#pragma unroll
-            for (int u = 0; u < V; u++) {
-                const uint32_t e = e0 + (uint32_t)u * kSelThreads;
-                kv[u] = e < n ? key_at(e) : kKeyMasked;
-            }
-#pragma unroll
-            for (int u = 0; u < V; u++) {
-                const uint32_t key = kv[u];
-                const bool in = key != kKeyMasked && (pass == 0 || (key >> 21) == b1);
-                hist_add_wave(hist, in, pass == 0 ? key >> 21 : (key >> 10) & 2047u);  // (keys of one query crowd into few bins)
-            }
-        }
-        __syncthreads();
-        pick_bin(hist, kBins, pass == 0 ? kk : kk - above1, pick);
-        if (pass == 0) {
-            b1 = pick->bin;
-            above1 = pick->above;
-        }
-        __syncthreads();
-    }
-    return (b1 << 21) | (pick->bin << 10);
-}
 
 // The same two digits with four barriers instead of ten: two padded histograms (hA, hB: kHistPad words each, any LDS nobody else is
 // using during the call), every wave picks the crossing bins for itself (wave_pick).  On return both may be overwritten.
@@ -256,6 +172,9 @@ hipError_t launch_sample_bound(const uint32_t* tmax_sample, uint64_t stride, uin
 #define SEL_MARK(i) do { } while (0)
 #endif
 constexpr uint32_t kCompCap = 8192;
+constexpr uint32_t kFlatTiles = 16384;     // shards of up to this many tiles (1M rows) select from ALL their tile maxima at once (flat path)
+constexpr uint32_t kFlatGroupK = 256;      // ... and for k up to this, from the k-th largest of the 1024 per-thread group maxima
+constexpr uint32_t kShortRowList = 1024;  // row lists up to this long skip the third radix pick
 constexpr uint32_t kBailTiles = 1024;  // tiles within the margin beyond which a selection hands over to the crowd kernels (when they follow)
 constexpr size_t kSelectLds = 2 * kCompCap * 8 + kMaxScanWaves * 4 + kHistPad * 4;  // 152.25 KiB
 
@@ -301,10 +220,96 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     const uint32_t k = p.k + (p.k_extra ? *p.k_extra : 0u);
     constexpr int V = 8;
 
+    const uint32_t skip = p.skip_key ? p.skip_key[q] : kKeyNaN;
+    uint32_t vw = 0, Tw = kKeyNaN, Twm = kKeyNaN, nA = 0;  // (nA: passing waves — the trace build prints it; 0 on the flat path)
+    bool flat = false;
+    // ---- flat path (round 6): shards of <= 16 384 tiles (1M rows) --------------------------------------------------------------
+    // The three-level walk below pays a radix pick per level (4-5 us each on this 16-wave workgroup) and, behind the WAVE level's
+    // loose bound (the k-th largest of a few hundred wave maxima), gathers the scores of 5-7 k tiles where k (1 + small) hold a
+    // candidate: at 1M x 768, k = 100 the selection took 33-36 us — load 2, picks 4 + 4 + 5, tile maxima 7, row scores 11
+    // (profiles/r05k_select_phases.txt) — a quarter of a lone call's 130-us sweep.  A shard this small has few enough TILES to put
+    // every tile maximum of the query into LDS at once (64 KiB, where the row list will live afterwards): ONE pick over them gives
+    // the tile-level bound directly — the k-th largest tile maximum, the tightest bound the maxima can give —, the tiles that reach
+    // it (~k) are compacted from LDS, and the row gather reads ~k x 64 scores instead of ~6 k x 64.  No wave level at all.
+    // Lists that overflow (thousands of tiles inside the margin) and selections that hand over to the crowd kernels continue in
+    // the code below exactly as before: LT, ct, Tw / Twm mean the same things there.  NMN_NO_FLAT_SELECT=1 (host side): the A/B.
+    if (p.flat && n_tiles <= kFlatTiles) {
+        uint32_t* tk = reinterpret_cast<uint32_t*>(LR);  // [n_tiles] tile maxima of the query (dead before LR is filled)
+        if (tid == 0) { s_vw = 0; s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
+        __syncthreads();
+        uint32_t my_valid = 0, my_max = kKeyMasked;  // (my_max: the largest of this thread's <= 16 tile maxima; kKeyMasked = 0 is below every key)
+        if ((p.tmax_stride & 3ull) == 0ull) {
+            const uint4* t4 = reinterpret_cast<const uint4*>(tmax);
+            const uint32_t n4 = (n_tiles + 3u) >> 2;  // <= 4096: at most four 16-byte loads per thread, all in flight
+            uint4 v4[kFlatTiles / 4 / kSelThreads];
+#pragma unroll
+            for (int u = 0; u < (int)(kFlatTiles / 4 / kSelThreads); u++) {
+                const uint32_t e = tid + (uint32_t)u * kSelThreads;
+                v4[u] = e < n4 ? t4[e] : make_uint4(kKeyMasked, kKeyMasked, kKeyMasked, kKeyMasked);
+            }
+#pragma unroll
+            for (int u = 0; u < (int)(kFlatTiles / 4 / kSelThreads); u++) {
+                const uint32_t e = tid + (uint32_t)u * kSelThreads;
+                if (e >= n4) continue;
+                uint32_t kk4[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (e * 4u + (uint32_t)c >= n_tiles) kk4[c] = kKeyMasked;  // (the words behind the last tile are not this query's)
+                    my_valid += kk4[c] != kKeyMasked;
+                    my_max = max(my_max, kk4[c]);
+                }
+                *reinterpret_cast<uint4*>(tk + e * 4u) = make_uint4(kk4[0], kk4[1], kk4[2], kk4[3]);
+            }
+        } else {
+            for (uint32_t e = tid; e < n_tiles; e += kSelThreads) {
+                const uint32_t key = tmax[e];
+                tk[e] = key;
+                my_valid += key != kKeyMasked;
+                my_max = max(my_max, key);
+            }
+        }
+        wk[tid] = my_max;  // the group maxima: one per thread, disjoint sets of tiles
+        {
+            uint32_t t = my_valid, gv = my_max != kKeyMasked ? 1u : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                t += (uint32_t)__shfl_xor((int)t, off);
+                gv += (uint32_t)__shfl_xor((int)gv, off);
+            }
+            if ((tid & 63u) == 0 && t) {
+                atomicAdd(&s_vw, t);
+                atomicAdd(&s_w[0], gv);
+            }
+        }
+        __syncthreads();
+        vw = s_vw;  // (here: the valid TILES)
+        SEL_MARK(2);
+        const uint32_t vgroups = s_w[0];  // threads holding at least one valid tile
+        SEL_MARK(1);
+        if (vw == 0) {
+            if (tid == 0) { p.qstate[q].cand_count = 0; p.qstate[q].n_valid = 0; }
+            return;
+        }
+        // The bound: the k-th largest tile maximum — or, for small k, the k-th largest GROUP maximum (a thread's <= 16 tiles are a
+        // group: k groups whose best tile reaches T are k tiles that do, so T is a valid lower bound as well, and since a group rarely
+        // holds two of the best k tiles it admits k (1 + k / 2048) tiles instead of k).  The pick over 1024 keys, one per thread,
+        // is 4 us; over all 15 625 tile maxima it measured 11 (profiles/r06b_select_flat.txt).
+        if (k <= kFlatGroupK && vgroups >= k) Tw = radix2([&](uint32_t e) { return wk[e]; }, (uint32_t)kSelThreads, k, hist, &pick);
+        else if (vw >= k) Tw = radix2([&](uint32_t e) { return tk[e]; }, n_tiles, k, hist, &pick);
+        Twm = max(margin_key(Tw, qi), skip);
+        SEL_MARK(3);
+        for (uint32_t b0 = tid & ~63u; b0 < n_tiles; b0 += kSelThreads) {  // (on the wave's first index: wave_append needs whole waves)
+            const uint32_t e = b0 + (tid & 63u);
+            const uint32_t key = e < n_tiles ? tk[e] : kKeyMasked;
+            const bool pr = key != kKeyMasked && key >= Twm;
+            const uint32_t pos = wave_append(pr, &s_w[1]);
+            if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)key << 32) | e;
+        }
+        flat = true;
+    }
     // the wave maxima into LDS, counted on the way (one phase: the count used to be a second walk over them, two barriers more)
-    if (tid == 0) s_vw = 0;
-    uint32_t my_valid = 0;
-    {
+    auto load_wave_maxima = [&]() -> uint32_t {
+        uint32_t valid = 0;
         uint32_t wv4[kMaxScanWaves / kSelThreads];
 #pragma unroll
         for (int u = 0; u < (int)(kMaxScanWaves / kSelThreads); u++) {
@@ -314,9 +319,13 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 #pragma unroll
         for (int u = 0; u < (int)(kMaxScanWaves / kSelThreads); u++) {
             wk[tid + (uint32_t)u * kSelThreads] = wv4[u];
-            my_valid += wv4[u] != kKeyMasked;
+            valid += wv4[u] != kKeyMasked;
         }
-    }
+        return valid;
+    };
+    if (!flat) {
+    if (tid == 0) s_vw = 0;
+    const uint32_t my_valid = load_wave_maxima();
     __syncthreads();
     SEL_MARK(1);
     {
@@ -327,26 +336,24 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         if ((tid & 63u) == 0 && t) atomicAdd(&s_vw, t);
     }
     __syncthreads();
-    const uint32_t vw = s_vw;  // (s_vw is written nowhere else: no race with the counters reset below)
+    vw = s_vw;  // (s_vw is written nowhere else: no race with the counters reset below)
     SEL_MARK(2);
     if (vw == 0) {
         if (tid == 0) { p.qstate[q].cand_count = 0; p.qstate[q].n_valid = 0; }
         return;
     }
     // ---- level W ---------------------------------------------------------------------------
-    uint32_t Tw = kKeyNaN;
     if (vw >= k) Tw = radix2([&](uint32_t e) { return wk[e]; }, W, k, hist, &pick);
     // scores of tiles whose maximum is below `skip` were never written by the batched sweep: no threshold that
     // gates a read of scores[] may fall below it (rows below it cannot be in the top-k anyway)
     SEL_MARK(3);
-    const uint32_t skip = p.skip_key ? p.skip_key[q] : kKeyNaN;
-    const uint32_t Twm = max(margin_key(Tw, qi), skip);
+    Twm = max(margin_key(Tw, qi), skip);
     if (tid == 0) { s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
     __syncthreads();
     for (uint32_t i = tid; i < W; i += kSelThreads)
         if (wk[i] != kKeyMasked && wk[i] >= Twm) la[atomicAdd(&s_w[0], 1u)] = i;  // <= W <= kListCap
     __syncthreads();
-    const uint32_t nA = s_w[0];
+    nA = s_w[0];
     // ---- level T: compact (key,tile) of tiles >= Twm in passing waves -------------------------
     {
         // The tile maxima of the passing waves: nA x tpw of them (k = 100 at 10M rows: ~800 x 39; k = 1000 of ~4000 waves: the wave
@@ -492,6 +499,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             }
         }
     }
+    }  // (!flat)
     __syncthreads();
     SEL_MARK(4);
     const uint32_t ct = s_w[1];
@@ -532,7 +540,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     }
     if (ct <= kCompCap) {
         uint32_t T2 = Tw;
-        if (ct > k) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);
+        if (ct > k && !flat) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);  // (flat: Tw IS the tile-level bound)
         const uint32_t T2m = max(margin_key(T2, qi), skip);
         Tc = T2m;
         SEL_MARK(5);
@@ -633,7 +641,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         const uint32_t cr = s_w[2];
         if (cr <= kCompCap) {
             uint32_t T3 = T2;
-            if (cr > k) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
+            // (A row list this short goes to the rescore as it is: the third pick — 5 us — pruned NOTHING on ordinary data (cand == cr in
+            //  every line of profiles/r05k_select_phases.txt: one row per passing tile reaches the tile bound, and the row bound moves
+            //  by less than the margin), and <= 1024 candidates are one rescore step and one entry per thread of final_kernel's sort.)
+            if (cr > k && cr > min(kShortRowList, p.cand_cap)) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
             SEL_MARK(7);
             Tc = max(margin_key(T3, qi), skip);  // >= T2m: every row that can matter is in LR
             for (uint32_t e = tid; e < cr; e += kSelThreads) {
@@ -672,6 +683,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
 
     // ---- generic path (a compact list overflowed) ------------------------------------------------
     __syncthreads();
+    if (flat) {  // (block-uniform; the flat path never loaded the wave level: Twm — its tile-level threshold — gates waves as well)
+        (void)load_wave_maxima();
+        __syncthreads();
+    }
     if (ct > kCompCap) {
         // tile-level bound from the un-compacted tile keys of every valid wave
         if (tid == 0) s_w[1] = 0;
@@ -782,7 +797,10 @@ hipError_t launch_select(const SelectParams& p, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelectLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(select_kernel, dim3(p.nq), dim3(kSelThreads), kSelectLds, s, p);
+    static const bool no_flat = getenv("NMN_NO_FLAT_SELECT") != nullptr;  // (A/B switch of the flat path)
+    SelectParams pf = p;
+    pf.flat = no_flat ? 0 : 1;
+    hipLaunchKernelGGL(select_kernel, dim3(p.nq), dim3(kSelThreads), kSelectLds, s, pf);
     return hipGetLastError();
 }
 

@@ -18,13 +18,19 @@ struct PickResult {
 // (1 <= kk <= total).  Block-wide: every thread owns nbins/1024 adjacent bins, suffix sums by wave
 // shuffles + one LDS hop across the 16 waves; exactly one thread sees the crossing and publishes it.
 // Callers __syncthreads() before reading *out.
+template <int NT = kSelThreads>
 static __device__ void pick_bin(const uint32_t* hist, int nbins, uint32_t kk, PickResult* out) {
-    __shared__ uint32_t wtot[kSelThreads / 64];
+    __shared__ uint32_t wtot[NT / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int per = nbins / kSelThreads;  // 1 or 2
-    const uint32_t h0 = hist[tid * per];
-    const uint32_t h1 = per == 2 ? hist[tid * per + 1] : 0u;
-    const uint32_t s = h0 + h1;
+    constexpr int kMaxPer = kBins / NT;  // adjacent bins per thread at 2048 bins (1024 threads: 2, 512: 4)
+    const int per = nbins / NT;          // 1 .. kMaxPer
+    uint32_t h[kMaxPer];
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxPer; j++) {
+        h[j] = j < per ? hist[tid * per + j] : 0u;
+        s += h[j];
+    }
     uint32_t S = s;  // inclusive suffix sum inside the wave
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t t = __shfl_down(S, off);
@@ -33,16 +39,19 @@ static __device__ void pick_bin(const uint32_t* hist, int nbins, uint32_t kk, Pi
     if (lane == 0) wtot[wave] = S;
     __syncthreads();
     uint32_t above_waves = 0;
-    for (uint32_t w = wave + 1; w < kSelThreads / 64; w++) above_waves += wtot[w];
+    for (uint32_t w = wave + 1; w < NT / 64; w++) above_waves += wtot[w];
     const uint32_t Sfx = S + above_waves;  // keys in bins >= first bin of this thread
-    const uint32_t above = Sfx - s;        // keys in bins above this thread's bins
-    if (Sfx >= kk && above < kk) {
-        if (per == 2 && above + h1 >= kk) {
-            out->bin = tid * per + 1;
-            out->above = above;
-        } else {
-            out->bin = tid * per;
-            out->above = above + h1;
+    uint32_t above = Sfx - s;              // keys in bins above this thread's bins
+    if (Sfx >= kk && above < kk) {         // the crossing is in one of this thread's bins: the highest j with above(j) + h[j] >= kk
+#pragma unroll
+        for (int j = kMaxPer - 1; j >= 0; j--) {
+            if (j < per) {
+                if (above < kk && above + h[j] >= kk) {
+                    out->bin = tid * per + j;
+                    out->above = above;
+                }
+                above += h[j];
+            }
         }
     }
     __syncthreads();
@@ -141,6 +150,42 @@ static __device__ __forceinline__ uint32_t wave_append_cnt(uint32_t cnt, uint32_
     if (lane == 63u) base = atomicAdd(counter, total);
     base = (uint32_t)__shfl((int)base, 63);
     return base + incl - cnt;
+}
+
+// Two 11-bit radix digits over n gathered keys (key_at(e) == 0: does not take part): returns T, the
+// lower edge of the 2^10-ulp bin that holds the kk-th largest key.  Requires kk <= #valid keys.
+// Loads are issued V at a time per thread so a single workgroup still keeps ~8K loads in flight.
+template <int NT = kSelThreads, typename KeyAt>
+static __device__ uint32_t radix2(KeyAt key_at, uint32_t n, uint32_t kk, uint32_t* hist, PickResult* pick) {
+    const uint32_t tid = threadIdx.x;
+    constexpr int V = 8;
+    uint32_t b1 = 0, above1 = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int b = tid; b < kBins; b += NT) hist[b] = 0;
+        __syncthreads();
+        for (uint32_t e0 = tid; e0 < n; e0 += NT * V) {
+            uint32_t kv[V];
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t e = e0 + (uint32_t)u * NT;
+                kv[u] = e < n ? key_at(e) : kKeyMasked;
+            }
+#pragma unroll
+            for (int u = 0; u < V; u++) {
+                const uint32_t key = kv[u];
+                const bool in = key != kKeyMasked && (pass == 0 || (key >> 21) == b1);
+                hist_add_wave(hist, in, pass == 0 ? key >> 21 : (key >> 10) & 2047u);  // (keys of one query crowd into few bins)
+            }
+        }
+        __syncthreads();
+        pick_bin<NT>(hist, kBins, pass == 0 ? kk : kk - above1, pick);
+        if (pass == 0) {
+            b1 = pick->bin;
+            above1 = pick->above;
+        }
+        __syncthreads();
+    }
+    return (b1 << 21) | (pick->bin << 10);
 }
 
 // `walk(f)`: calls f(row, key) for every element, the same number of times on every lane (key == kKeyMasked: skip).
@@ -284,7 +329,7 @@ static __device__ void sort_and_emit(unsigned long long* list, uint32_t n, uint3
 #endif
     // (more than one entry per thread: a wave runs a full rank search in every pass in which ANY of its lanes holds a top entry —
     //  4096 near-equal candidates of a clustered IVF list took 100 us this way against the network's 36: the network keeps those)
-    if (n > blockDim.x) return sort_and_emit_bitonic(list, n, n_live, k, row_base, out_rows, out_scores, out_count);
+    if (n > max(blockDim.x, 1024u)) return sort_and_emit_bitonic(list, n, n_live, k, row_base, out_rows, out_scores, out_count);  // (a 512-thread workgroup ranks two entries per thread)
     const uint32_t tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63u, nw = nthr >> 6;
     const uint32_t nruns = (n + 63u) >> 6;
     for (uint32_t r = wave; r < nruns; r += nw) {  // (wave-uniform)

@@ -812,11 +812,15 @@ static nmn_status sharded_run_body(nmn_sharded* s, const float* queries, uint32_
         const nmn_status st = sharded_gather(s, pl.size);
         if (st != NMN_OK) return st;
         static const bool narrow = getenv("NMN_RCCL_NARROW_LOCK") != nullptr;
-        if (s->gather == NMN_GATHER_RCCL && !narrow)
+        if (s->gather == NMN_GATHER_RCCL && !narrow) {
+            // (an event behind each lane's all-gather, and the wait on THOSE: what the lock protects is the collective, not whatever
+            //  else a lane's stream may come to carry behind it — ADVICE r05)
             for (uint32_t g = 0; g < G; g++) {
                 S_TRY(hipSetDevice(s->device[g]));
-                S_TRY(hipStreamSynchronize(s->lane[g].stream));
+                S_TRY(hipEventRecord(s->lane[g].done, s->lane[g].stream));
             }
+            for (uint32_t g = 0; g < G; g++) S_TRY(hipEventSynchronize(s->lane[g].done));
+        }
     }
     // ---- merge_top_k on the merging device, one D2H ---------------------------------------------------------------------
     S_TRY(hipSetDevice(s->device[0]));

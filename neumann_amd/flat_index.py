@@ -250,6 +250,10 @@ class GpuFlatIndex:
         _capi.check(self._lib.nmn_index_hbm_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def retry_declined(self):
+        """Forget the shard's out-of-memory verdicts (a declined mirror, a shrunk query pass): the next search asks the device again."""
+        _capi.check(self._lib.nmn_index_retry_declined(self._h))
+
     def set_timing(self, enabled):
         """0 / False: off; 1 / True: every event (scan_ms and total_ms of last_stats); 2: the sweep's two events only."""
         _capi.check(self._lib.nmn_index_set_timing(self._h, int(enabled)))

@@ -36,6 +36,16 @@ def test_plain_bench_gpus_2_starts_two_ranks_and_certifies():
     assert abs(m["shard_scans_per_s"] - 2 * d["value"]) < 1e-6 * d["value"] and "whole corpus" in d["value_counts"]
     # the kernel time is OF the timed loop: it cannot exceed the step time
     assert 0 < d["roofline"]["avg_kernel_ms"] <= d["ms_per_step"] and d["roofline"]["kernel_launches_timed"] == 6
+    # a future SCALE_r*.json must be checkable from the scalars the driver keeps (`config`): the sweep every rank's LIBRARY
+    # reported, the ranks the collective saw, the cost of gather + merge per step
+    c = d["config"]
+    assert c["sweep_kind"] == "ring_f32" and c["sweep_kind_by_rank"] == "ring_f32,ring_f32" and d["roofline"]["kernel"] == "nmn::scan_ring_kernel"
+    assert c["rccl_ranks"] == 0 and c["gather_plus_merge_ms"] == m["gather_plus_merge_ms"] and c["shards"] == 2
+    assert list(d["roofline"])[:24] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_ms",
+                                        "algorithmic_bytes_per_launch", "c3_f32_frac", "c3_f32_ms_per_batch", "c3_f32_qps", "c2_f32_frac",
+                                        "c2_f32_qps", "c5_mask1.0_f32_frac", "c5_mask0.5_f32_frac", "c5_mask0.1_f32_frac",
+                                        "c5_mask1.0_f32_qps", "c5_mask0.1_f32_qps", "i8_mirror_queries_per_s",
+                                        "i8_mirror_frac_on_mirror_bytes", "c3_i8_frac_on_mirror_bytes", "c3_i8_qps", "ring_only_read_ceiling"]
     h = m["one_process_handle"]
     assert "error" not in h, h
     assert h["rows_per_gpu"] == [300000, 300000] and h["exact_topk_certified"] is True and h["gather"] == "peer copies"
@@ -53,3 +63,4 @@ def test_strong_scaling_splits_the_rows():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["rows_total"] == 200000
     assert d["multi_gpu"]["rows_per_gpu"] == [66667, 66667, 66666] and d["parity"]["exact_topk_certified"] is True
+    assert d["config"]["sweep_kind_by_rank"] == "valu_f32,valu_f32,valu_f32" and d["config"]["gather_plus_merge_ms"] > 0
