@@ -290,7 +290,7 @@ constexpr uint64_t kCrowdPool = 8ull << 20;
 static void ws_release_core(Workspace* w) {
     void** ptrs[] = {(void**)&w->scores, (void**)&w->tmax, (void**)&w->wmax, (void**)&w->tsample, (void**)&w->skip_key,
                      (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qi8, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
-                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->final_ticket, (void**)&w->run_slots, (void**)&w->run_bound, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
+                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->final_ticket, (void**)&w->done_ctr, (void**)&w->run_slots, (void**)&w->run_bound, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
                      (void**)&w->crowd_rows, (void**)&w->crowd_scores, (void**)&w->fb_hist, (void**)&w->fb_list, (void**)&w->fb_count,
                      (void**)&w->fb_sync};
     for (void** p : ptrs) {
@@ -337,7 +337,9 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_rows), nq * w->cand_cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->final_ticket), nq * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->run_slots), nq * 256 * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->done_ctr), 4));
+    HIP_TRY(hipMemset(w->done_ctr, 0, 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->run_slots), nq * 1024 * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->run_bound), ((nq + 127) & ~(size_t)127) * 4 + 512));  // (+ a 64-query group's LDS-DMA may start at any multiple of 64)
     HIP_TRY(hipMemset(w->run_bound, 0, ((nq + 127) & ~(size_t)127) * 4 + 512));
     HIP_TRY(hipMemset(w->final_ticket, 0, nq * 4));
@@ -1104,9 +1106,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // sampled bound it replaces (>= 32 768 tiles), k <= 256 (slots per query: the power of two >= k, at least 128).
         // NMN_NO_RUN_BOUND=1: the sampling pass + refinement, the A/B.
         static const bool no_run_bound = env_set("NMN_NO_RUN_BOUND");
-        const bool run_bound = use_mfma && !no_run_bound && !no_sample() && !mask_dev && !qmasks_dev && k <= 256u &&
+        static const bool wgs_pinned = getenv("NMN_MFMA_WGS") != nullptr;  // (the running maxima are one per workgroup of the DEFAULT 1024)
+        const bool run_bound = use_mfma && !no_run_bound && !no_sample() && !mask_dev && !qmasks_dev && k <= 256u && nqc <= 64u && !wgs_pinned &&
+                               idx->ld <= 1536u &&  // (longer rows: wave pairs per query group, whose LDS has no room for the refresh buffers)
                                n_tiles >= 1024u * kSampleStep && n_tiles / kSampleStep >= 4u * k;
-        const uint32_t run_S = !run_bound ? 0u : k <= 128u ? 128u : 256u;
+        const uint32_t run_S = run_bound ? k : 0u;  // (the rank of the bound among the <= 1024 workgroups' running maxima)
         // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
@@ -1211,14 +1215,17 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             }();
             static const bool sample_behind = getenv("NMN_SAMPLE_AHEAD_OF_CHAIN") == nullptr;
             const uint32_t n_sample = (n_tiles + sample_step - 1) / sample_step;
-            const bool sample = use_mfma && !run_bound && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
+            static const uint32_t run_dbg = [] { const char* e = getenv("NMN_RUN_BOUND_DEBUG"); return e ? (uint32_t)atol(e) : 0u; }();  // (measurement only)
+            const bool sample = use_mfma && (!run_bound || (run_dbg & 1u)) && n_sample >= 4u * k && n_sample >= 1024u && !no_sample();
             if (run_bound) {
                 sp.run_slots = w->run_slots;
                 sp.run_bound = w->run_bound;
                 sp.run_S = run_S;
+                sp.run_dbg = run_dbg;
             }
             auto sampling_pass = [&]() -> nmn_status {
                 ScanParams ss = sp;
+                ss.run_S = 0;
                 ss.tile_step = sample_step;
                 ss.n_tiles = n_sample;
                 ss.tiles_per_wave = std::max<uint32_t>(1, (n_sample + 255) / 256);
@@ -1339,7 +1346,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sel.nq = nqc;
             sel.k = k;
             sel.cand_cap = w->cand_cap;
-            sel.skip_key = run_bound ? w->run_bound : sp.skip_key;  // (the FINAL value of the running bound: every tile at or above it was written)
+            sel.skip_key = (run_bound && !(run_dbg & 1u)) ? w->run_bound : sp.skip_key;  // (the FINAL value of the running bound: every tile at or above it was written)
             sel.k_extra = nullptr;
             sel.retry = 0;
             sel.retry_follows = f32_retry ? 1 : 0;
@@ -1474,6 +1481,11 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         fp.out_rows = out_rows + (size_t)qa * k;
         fp.out_scores = out_scores + (size_t)qa * k;
         fp.out_counts = out_counts + qa;
+        if (w->poll_word_dev && !nested && qa + w->nq_cap >= nq && !fused_tail) {  // (the call's LAST launch publishes: host_batch_body polls)
+            fp.done_word = w->poll_word_dev;
+            fp.done_ctr = w->done_ctr;
+            fp.done_seq = w->done_seq;
+        }
         if (fused_tail) HIP_TRY(launch_rescore_final(rp_tail, fp, w->final_ticket, stream));
         else HIP_TRY(launch_final(fp, stream));
     }
@@ -1742,9 +1754,12 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
             (void)hipGetLastError();
             w->pin_in_dev = nullptr;
         }
-        if (w->pin_out != out0 && hipHostGetDevicePointer(reinterpret_cast<void**>(&w->pin_out_dev), w->pin_out, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            w->pin_out_dev = nullptr;
+        if (w->pin_out != out0) {
+            memset(w->pin_out, 0, w->pin_out_cap);  // (the polled sequence word must not hold a stale match)
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&w->pin_out_dev), w->pin_out, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                w->pin_out_dev = nullptr;
+            }
         }
     }
     // Zero-copy I/O (round 6): the query block and the result block are pinned host memory the device can address, so the chain's
@@ -1754,6 +1769,13 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     // qprep's loads over PCIe); NMN_NO_ZERO_COPY=1: the staged copies, the A/B.
     static const bool no_zero_copy = env_set("NMN_NO_ZERO_COPY");
     const bool zero_copy = !no_zero_copy && w->pin_in_dev && w->pin_out_dev && qn * sizeof(float) <= (64u << 10) && res_bytes <= (256u << 10);
+    // ... and a lone caller POLLS a word of that block instead of synchronising the stream (as the single-launch path of small shards
+    // does): final_kernel's last workgroup stores the call's sequence number behind the results (system-scope release), the host
+    // reads it a few microseconds before hipStreamSynchronize would return.  Bounded: 400 us, then the runtime's wait.
+    // NMN_NO_POLL=1: the A/B.
+    static const bool no_poll = env_set("NMN_NO_POLL") || env_set("NMN_FUSED_TAIL");  // (the fused tail's kernel does not publish)
+    const size_t off_done = (pack_bytes + 7) & ~(size_t)7;  // (grow_pinned allocates need + need / 2, at least 4096: the word fits)
+    const bool poll = zero_copy && !no_poll && n_reqs == 1 && nq <= 4 && k <= NMN_MAX_TOP_K && off_done + 8 <= w->pin_out_cap;
     const float* const q_dev = zero_copy ? reinterpret_cast<const float*>(w->pin_in_dev) : w->h_queries;
     uint8_t* const pack_dev = zero_copy ? w->pin_out_dev : w->h_pack;
     unsigned long long* const d_pred_counts = reinterpret_cast<unsigned long long*>(w->h_pack + off_pred);
@@ -1879,12 +1901,31 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
             HIP_TRY(hipMemcpyAsync(w->pin_out + off_pred, w->h_pack + off_pred, n_pred * pred_count_stride * 8, hipMemcpyDeviceToHost, s));
         return NMN_OK;
     };
+    volatile uint32_t* const done_host = reinterpret_cast<volatile uint32_t*>(w->pin_out + off_done);
+    auto arm_poll = [&](bool on) {
+        w->poll_word_dev = on ? reinterpret_cast<uint32_t*>(w->pin_out_dev + off_done) : nullptr;
+        if (on) w->done_seq++;
+    };
+    const bool poll_this = poll && !separately && qmasks.empty() && nq <= w->nq_cap;
+    arm_poll(poll_this);
     st = enqueue_all(try_short);
+    arm_poll(false);
     if (st != NMN_OK) return st;
     std::vector<unsigned long long> pred_selected(n_pred, 0ull);
     // (the predicates' counts — word 0 of each counter block — came back with the results: the tail of the packed block)
     lk.unlock();  // everything is enqueued: other threads may enqueue on their slots while this one waits
-    HIP_TRY(hipStreamSynchronize(s));
+    bool seen = false;
+    if (poll_this) {
+        const uint32_t want = w->done_seq;
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+        uint32_t spins = 0;
+        while (!(seen = (*done_host == want))) {
+            __builtin_ia32_pause();
+            if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() > give_up) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(s));
     if (try_short) {
         const uint32_t* hc = reinterpret_cast<const uint32_t*>(w->pin_out + off_counts);
         bool flagged = false;

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                                                    uint32_t* __restrict__ run_slots, uint32_t run_S, uint32_t* __restrict__ run_bound) {
     const uint32_t q = blockIdx.x;
     if (run_S) {  // the one-launch batched sweep derives its score-store bound from these (ScanParams::run_*)
-        for (uint32_t i = threadIdx.x; i < run_S; i += 64u) run_slots[(size_t)q * run_S + i] = kKeyMasked;
+        for (uint32_t i = threadIdx.x; i < 1024u; i += 64u) run_slots[(size_t)q * 1024u + i] = kKeyMasked;  // (ScanParams::run_slots: [nq][1024])
         if (threadIdx.x == 0) run_bound[q] = kKeyNaN;
     }
     // The query comes into LDS in ONE round trip (every load of the block in flight together) and every later phase — the padded

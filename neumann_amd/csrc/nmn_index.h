@@ -66,6 +66,9 @@ struct Workspace {
     uint8_t* pin_pred = nullptr; size_t pin_pred_cap = 0;                // pinned host staging of pred_block
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
     uint8_t* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned host
+    uint32_t done_seq = 0;            // sequence number of the last polled call on this workspace (FinalParams::done_*)
+    uint32_t* done_ctr = nullptr;     // device: arrival counter of the polled final_kernel launch (zero between launches)
+    uint32_t* poll_word_dev = nullptr;  // set by the host-buffer path around ONE search_enqueue call: the pinned word (device view) its final_kernel publishes into
     uint8_t* pin_in_dev = nullptr;    // the same blocks as the device sees them (zero-copy I/O of the host-buffer API: qprep reads the
     uint8_t* pin_out_dev = nullptr;   // queries from pinned host memory, the last kernel of the chain writes the results into it)
     // single-launch search of a small shard (tiny_search_kernel): candidate pool, ticket, and the result block the kernel

@@ -174,17 +174,18 @@ struct ScanParams {
     uint32_t walk;           // masked 8-bit VALU sweep: 1 = the survivor walk (participating rows of up to 64 tiles listed and read four
                              // per step across tile borders, nmn_scan_i8.hip); 0 = tile by tile
     uint32_t bx_base, bx_count;  // MFMA sweep: this launch covers workgroups [bx_base, bx_base + bx_count) (0 = to the end)
-    // MFMA sweep, ONE launch per batch (round 6): the bound that gates the score stores is derived INSIDE the sweep.  run_S slots per
-    // query (a power of two >= k, <= 256; 0 = off): slot s holds the largest tile maximum seen so far among the tiles t with
-    // t % run_S == s (atomicMax by the workgroups that stream them).  The slots' sets of tiles are disjoint, so the smallest slot
-    // value is reached by run_S >= k different tiles: a valid lower bound on the k-th best approximate score at ANY moment, rising
-    // as the sweep proceeds.  Every wave re-reads the slots of one query every fourth tile (LDS-DMA, no VGPR-destination load in
-    // the loop) and publishes margin_key(min) into run_bound[q] (atomicMax); the workgroups pick the current run_bound up with the
-    // row magnitudes of each tile.  A tile writes its scores when its maximum reaches the bound it sees — never above the final
-    // value of run_bound, which is what select_kernel is given as skip_key.  qprep_kernel zeroes the slots and resets the bounds.
-    uint32_t* run_slots;     // [nq][run_S] keys (0 = no tile yet)
+    // MFMA sweep, ONE launch per batch (round 6): the bound that gates the score stores is derived INSIDE the sweep.  Every workgroup
+    // publishes its running maximum per query (run_slots[q][workgroup], a plain store when it rises: the value the sweep leaves in
+    // wmax at its end, made visible early); the run_S-th largest of a query's <= 1024 running maxima (run_S = k) is reached by k
+    // different workgroups, hence k different tiles: a valid lower bound on the k-th best approximate score at ANY moment, rising as
+    // the sweep proceeds.  Every wave re-reads the maxima of one query every 16 tiles (LDS-DMA: no VGPR-destination load in the
+    // loop), selects the k-th largest and publishes margin_key(it) into run_bound[q] (atomicMax); the workgroups pick the current
+    // run_bound up with the row magnitudes of each tile.  A tile writes its scores when its maximum reaches the bound it sees —
+    // never above the final value of run_bound, which is what select_kernel is given as skip_key.  qprep_kernel resets both arrays.
+    uint32_t* run_slots;     // [nq][1024] the workgroups' running maxima (keys; 0 = nothing yet)
     uint32_t* run_bound;     // [nq rounded up to 128] keys (kKeyNaN = no bound yet: every tile writes)
-    uint32_t run_S;
+    uint32_t run_S;          // 0 = off; else the rank of the bound among the running maxima (= k)
+    uint32_t run_dbg;        // measurement only (NMN_RUN_BOUND_DEBUG): 1 = decide the stores by skip_key, 2 = no slot atomics, 4 = no refresh, 8 = no bound DMA
     int metric;
 };
 hipError_t launch_scan(const ScanParams& p, hipStream_t s);
@@ -324,6 +325,12 @@ struct FinalParams {
     uint64_t* out_rows;          // [nq][k]
     float* out_scores;
     uint32_t* out_counts;
+    // (nullable) a lone host caller polls a word of pinned host memory instead of synchronising the stream (as tiny_search_kernel's
+    // caller does): the LAST workgroup of the launch to finish (done_ctr: zero between launches) stores `done_seq` there,
+    // system-scope release, after every result store of the launch
+    uint32_t* done_word;
+    uint32_t* done_ctr;
+    uint32_t done_seq;
 };
 hipError_t launch_final(const FinalParams& p, hipStream_t s);
 struct RescoreParams;

@@ -190,9 +190,14 @@ __host__ __device__ constexpr uint32_t kRunLdsBase() {
                       (I8 ? kNormSlots * 64 * 4 : 0));
 #endif
 }
+constexpr int kRunVals = 1024;  // running maxima per query: one per workgroup of the sweep (ScanParams::run_slots; sweeps of <= 1024 workgroups)
+// the running bound's LDS block: the bound ring (every launch has it: the stage body reads a slot unconditionally), and — launches with
+// run_S only — the queries' margins and a refresh buffer per wave
+template <int QG>
+__host__ __device__ constexpr uint32_t kRunLdsRing() { return (uint32_t)(kNormSlots * QG * 16 * 4); }
 template <int QG, int WAVES>
 __host__ __device__ constexpr uint32_t kRunLdsBytes() {
-    return (uint32_t)(kNormSlots * QG * 16 * 4 + WAVES * 256 * 4 + QG * 16 * (int)sizeof(QInfo));
+    return kRunLdsRing<QG>() + (uint32_t)(QG * 16 * (int)sizeof(QInfo) + WAVES * kRunVals * 4);
 }
 
 template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES, bool I8 = false, bool F32 = false>
@@ -226,12 +231,12 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     float* const pack_lds = nrm2 + kNormSlots * 64;
     // (ScanParams::run_*) behind everything above — launch_one_mfma sizes the block for it:
     //   bnd   [kNormSlots tiles][QG * 16] the published bounds as picked up with each tile's row magnitudes (LDS-DMA by wave 0)
-    //   slotb [WAVES][256]               the slots of the query a wave is refreshing (LDS-DMA by that wave)
-    //   qmrg  [QG * 16] QInfo            the margins of the workgroup's queries (read once, before the loop)
+    //   qmrg  [QG * 16] QInfo            the margins of the workgroup's queries (read once, before the loop)          } launches with
+    //   slotb [WAVES][kRunVals]          the workgroups' running maxima of the query a wave is refreshing (LDS-DMA)   } run_S only
     constexpr uint32_t kQ = (uint32_t)QG * 16u;
     uint32_t* const bnd = reinterpret_cast<uint32_t*>(lds) + (kRunLdsBase<KS, QG, WAVES, I8>() >> 2);
-    uint32_t* const slotb = bnd + kNormSlots * kQ;
-    QInfo* const qmrg = reinterpret_cast<QInfo*>(slotb + (uint32_t)WAVES * 256u);
+    QInfo* const qmrg = reinterpret_cast<QInfo*>(bnd + kNormSlots * kQ);
+    uint32_t* const slotb = reinterpret_cast<uint32_t*>(qmrg + kQ);
     const uint32_t run_S = p.run_S;  // (scalar; 0 = the bound comes from p.skip_key, if any)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -331,11 +336,18 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         __syncthreads();
     }
     // the published bounds of the workgroup's queries, as they stand now, into slot `rel` of the bound ring (wave 0; 4 bytes per lane)
+    // (picked up every kPick-th tile, for that tile and the kPick - 1 behind it: one DMA instruction per tile measured 0.17 ms of the
+    //  8-bit sweep's 1.45 — profiles/r06k_*)
+#ifndef NMN_RUN_PICK  // (measurement builds)
+#define NMN_RUN_PICK 4
+#endif
+    constexpr uint32_t kPick = NMN_RUN_PICK;
     auto bound_dma = [&](uint32_t rel) __attribute__((always_inline)) {
+        if (rel % kPick) return;
 #pragma unroll
         for (uint32_t h = 0; h < kQ; h += 64u)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.run_bound + q0 + h + lane),
-                                             (__attribute__((address_space(3))) void*)(bnd + (rel % kNormSlots) * kQ + h), 4, 0, 16);  // sc1: agent scope —
+                                             (__attribute__((address_space(3))) void*)(bnd + ((rel / kPick) % kNormSlots) * kQ + h), 4, 0, 16);  // sc1: agent scope —
             // the bounds are raised by OTHER compute units' atomics (at L2): a load that may hit this CU's vector cache would keep
             // reading the line it saw first (measured: every tile kept writing, the 8-bit sweep 1.5 -> 5.6 ms)
     };
@@ -376,7 +388,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     for (uint32_t s0 = 0; s0 < kRing; s0++) {
         if (s0 < n_stage) {
             // (the magnitudes of stage kRing - 1's tile too: its pieces go out during the first iteration)
-            if (run_S && wave == 0 && s0 % KC == 0) bound_dma(s0 / KC);
+            if (run_S && !(p.run_dbg & 8u) && wave == 0 && s0 % KC == 0) bound_dma(s0 / KC);
             if (kNeedNorms && wave == 0 && s0 % KC == 0)
             {
                 norms_dma(norm_src, (uint64_t)tile_of(j0 + s0 / KC) * tstep, nrm + ((s0 / KC) % kNormSlots) * 64u, lane);
@@ -422,7 +434,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         const float qmag = qmag_h[H];
         // (running bound: the value picked up with this tile's row magnitudes — kRing - 1 stages old, and every older value of a
         //  bound that only rises is a valid one)
-        const uint32_t skip = run_S ? skp[H] : skip_h[H];  // (skp: read from the bound ring at the top of the tile's last stage, like npre)
+        const uint32_t skip = (run_S && !(p.run_dbg & 1u)) ? skp[H] : skip_h[H];  // (skp: read from the bound ring at the top of the tile's last stage, like npre)
         f4 fin[4];
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) fin[rb] = facc[rb][H];
@@ -487,6 +499,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 }
             }
 #endif
+            // (running bound: the workgroup's maximum so far, published when it rises — a plain store into the workgroup's OWN word, rare
+            //  after the first tiles.  The first form kept 128 slot maxima per query by atomicMax from every tile that reached the bound:
+            //  ~1M device-scope atomics per batch, queued in order with the DMA pieces in front of every counted wait — 4.95 -> 7.0 ms.)
+            if (run_S && !(p.run_dbg & 2u) && q_ok && g == 0 && tkey > wmax_h[H] && !sampling) p.run_slots[(size_t)qn * (uint32_t)kRunVals + bx] = tkey;
             wmax_h[H] = max(wmax_h[H], tkey);
             // the sampling pass finishing its tiles for the main sweep (p.tmax_main set): the key into the sweep's tmax as well, and the
             // tile's scores written whatever they are (no bound exists yet; 1/S of the tiles)
@@ -496,8 +512,6 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             return false;
 #else
             const bool wr_ = q_ok && (!sampling || finish_sampled) && tkey != kKeyMasked && tkey >= skip;
-            // a tile that reaches the bound may raise its slot (one below the bound cannot: the bound is the smallest slot)
-            if (run_S && wr_ && g == 0) atomicMax(p.run_slots + (size_t)qn * run_S + (ftile & (run_S - 1u)), tkey);
             return wr_;
 #endif
         };
@@ -709,7 +723,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             if (kc == KC - 1) {  // (compile time) — unconditionally: a branch on run_S would cut the stage's basic block in two
 #pragma unroll
                 for (int h = 0; h < kHalves; h++)
-                    skp[h] = bnd[((j - j0) % kNormSlots) * kQ + ((uint32_t)h * (uint32_t)WAVES + grp) * 16u + n];
+                    skp[h] = bnd[(((j - j0) / (uint32_t)NMN_RUN_PICK) % kNormSlots) * kQ + ((uint32_t)h * (uint32_t)WAVES + grp) * 16u + n];  // (kPick = 4)
             }
             if constexpr (kNeedNorms) {
                 if (kc == KC - 1) {  // (compile time: the stage loop is unrolled)
@@ -768,7 +782,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             // the stage's basic block.  One extra entry in wave 0's vmcnt queue per tile: its next waits are one piece conservative.
             // (issued for the tile of stage ns + 1, i.e. BEFORE that stage's pieces go out in the next iteration: in-order vmcnt then
             // lands it with them, and every wave passes a barrier behind wave 0's wait before the tile's epilogue reads it)
-            if (run_S && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) bound_dma((ns + 1u) / KC);
+            if (run_S && !(p.run_dbg & 8u) && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) bound_dma((ns + 1u) / KC);
             if (kNeedNorms && wave == 0 && ns + 1u < n_stage && (ns + 1u) % KC == 0) {
                 const uint32_t nrel = (ns + 1u) / KC, nt1 = tile_of(j0 + nrel);
                 norms_dma(norm_src, (uint64_t)nt1 * tstep, nrm + (nrel % kNormSlots) * 64u, lane);
@@ -783,7 +797,13 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 #pragma unroll
                 for (int qg = 0; qg < kAccGroups; qg++)
 #pragma unroll
+#ifdef NMN_MFMA_I8_INT_COMBINE  // (measurement build, VERDICT r05 #4's second lever: the planes combined in integers — one shift-add and
+                    // one conversion per element instead of two conversions and an FMA; exact only while |h.c| < 2^23, i.e. rows of <= 512
+                    // elements: at 768 the answers are WRONG, timing only — the 1/256 would fold into the per-query factor)
+                    for (int e = 0; e < 4; e++) acc[rb][qg][e] = (float)((ach[rb][qg][e] << 8) + acl[rb][qg][e]);
+#else
                     for (int e = 0; e < 4; e++) acc[rb][qg][e] = (float)ach[rb][qg][e] + (float)acl[rb][qg][e] * 0.00390625f;
+#endif
         }
         if constexpr (kHalfK) {
             // the two K-halves of a group meet: wave kh = 1 publishes, wave kh = 0 adds and finishes.  (The next
@@ -807,33 +827,52 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         } else {
             finish_tile(acc, tile, j - j0, j + 1u == j1, npre, skp);
         }
-        if (run_S) {  // (scalar branch) the running bound's refresh: one query per wave every four tiles
-            const uint32_t rel = j - j0;
-            if ((rel & 3u) == 3u && pend_q != 0xFFFFFFFFu) {
-                // the slots asked for three tiles ago have landed (in-order vmcnt: >= 2 stages of pieces were issued behind them and
-                // waited for since) — their minimum is reached by run_S >= k different tiles
-                // (3 * KC stages of kPieces pieces each: where that is fewer than the ring's usual kRing - 2 stages — one 16-KiB stage per
-                //  tile — wait for exactly that many)
-                constexpr int kYounger = 3 * KC * kPieces < (kRing - 2) * kPieces ? 3 * KC * kPieces : (kRing - 2) * kPieces;
-                wait_vm_imm<kYounger>();
-                const u4 sv = lane * 4u < run_S ? *reinterpret_cast<const u4*>(slotb + wave * 256u + lane * 4u) : (u4){~0u, ~0u, ~0u, ~0u};
-                uint32_t m = min(min(sv[0], sv[1]), min(sv[2], sv[3]));
+        if (run_S && !(p.run_dbg & 4u)) {  // (scalar branch) the running bound's refresh: one query per wave every kRefresh tiles
+            // Workgroup b refreshes at its tiles rel = b (mod kRefresh) — so at every moment a part of the resident workgroups is
+            // refreshing, each of them a different query of its waves' groups ((rel / kRefresh + b) mod 16): every query of
+            // the batch is refreshed by somebody every few tiles, from the sweep's first tiles on.  (All workgroups refreshing at rel = 0 mod 16,
+            // as first built, found nothing published at rel = 0 and came back at rel = 16: twenty tiles of every workgroup wrote all
+            // their scores before the first bound existed.)  The maxima are consumed kDelay tiles after they were asked for: by then at
+            // least kRing - 2 stages of pieces have been issued behind them and waited for (in-order vmcnt).
+#ifndef NMN_RUN_REFRESH  // (measurement builds)
+#define NMN_RUN_REFRESH 64
+#endif
+            constexpr uint32_t kRefresh = NMN_RUN_REFRESH;  // (16 measured 0.28 ms of the 8-bit sweep's 1.45: the waves of a workgroup meet at every stage's barrier,
+                                               //  so a refreshing wave holds the other three up)
+            constexpr uint32_t kDelay = (uint32_t)((kRing - 2 + KC - 1) / KC);
+            static_assert(kDelay >= 1 && kDelay < kRefresh, "refresh timing");
+            const uint32_t rel = j - j0, phase = bx % kRefresh;
+            if ((rel % kRefresh) == (phase + kDelay) % kRefresh && pend_q != 0xFFFFFFFFu) {
+                // The run_S-th largest of the maxima (run_S = k) is reached by k different workgroups, i.e. k different
+                // tiles: a valid lower bound on the k-th best approximate score.  Bitwise search over the upper 22 bits of the key
+                // (count of values >= candidate by ballots: no lane exchange), the low 10 bits left zero — a slightly lower bound.
+                wait_vm_imm<(kRing - 2) * kPieces>();  // (what every stage's wait asks for: kDelay tiles of pieces are behind the maxima)
+                uint32_t v[kRunVals / 64];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-                if (m != kKeyMasked && lane == 0) {  // (every slot has seen a tile)
-                    const uint32_t b = margin_key(m, qmrg[pend_q - q0]);
-                    atomicMax(p.run_bound + pend_q, b);
+                for (int i = 0; i < kRunVals / 256; i++) {
+                    const u4 x = *reinterpret_cast<const u4*>(slotb + wave * (uint32_t)kRunVals + (uint32_t)i * 256u + lane * 4u);
+                    v[4 * i + 0] = x[0]; v[4 * i + 1] = x[1]; v[4 * i + 2] = x[2]; v[4 * i + 3] = x[3];
                 }
+                uint32_t pre = 0;
+                for (int bit = 31; bit >= 10; bit--) {
+                    const uint32_t c = pre | (1u << bit);
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < kRunVals / 64; i++) cnt += (uint32_t)__builtin_popcountll(__ballot(v[i] >= c));
+                    if (cnt >= run_S) pre = c;  // (wave-uniform)
+                }
+                if (pre > kKeyNaN && lane == 0) atomicMax(p.run_bound + pend_q, margin_key(pre, qmrg[pend_q - q0]));
             }
-            if ((rel & 3u) == 0u) {
-                // the next query in turn: this wave's groups, sixteen queries each, offset by the workgroup's number so that the resident
-                // workgroups are at different queries at any moment
-                const uint32_t turn = ((rel >> 2) + bx) % (16u * (uint32_t)kBG);
+            if ((rel % kRefresh) == phase) {
+                const uint32_t turn = ((rel / kRefresh) + bx) % (16u * (uint32_t)kBG);  // (phase = bx mod 64 fixes bx mod 16: query t is asked for at phases t, t + 16, t + 32, t + 48)
                 const uint32_t qq = q0 + ((turn / 16u) * (uint32_t)WAVES + grp) * 16u + (turn % 16u);
                 pend_q = (kh == 0 && qq < p.nq) ? qq : 0xFFFFFFFFu;
-                if (pend_q != 0xFFFFFFFFu && lane * 4u < run_S)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.run_slots + (size_t)pend_q * run_S + lane * 4u),
-                                                     (__attribute__((address_space(3))) void*)(slotb + wave * 256u), 16, 0, 16);  // sc1 (as for the bounds)
+                if (pend_q != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int i = 0; i < kRunVals / 256; i++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.run_slots + (size_t)pend_q * (uint32_t)kRunVals + (uint32_t)i * 256u + lane * 4u),
+                                                         (__attribute__((address_space(3))) void*)(slotb + wave * (uint32_t)kRunVals + (uint32_t)i * 256u), 16, 0, 16);  // sc1 (as for the bounds)
+                }
             }
         }
     }
@@ -866,10 +905,10 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     }
     // ring | row magnitudes | the K-halves' exchange | pending tile maxima | (8-bit) |v~|^2 of the tiles' rows (with the K-halves'
     // exchange of the long rows the packed-store blocks of the measurement build would not fit in 160 KiB) | (run_S) the running bound's block
-    const size_t lds = (size_t)kRunLdsBase<KS, QG, WAVES, I8>() + (size_t)kRunLdsBytes<QG, WAVES>();  // (always: the stage body reads a bound slot unconditionally)
+    const size_t lds = (size_t)kRunLdsBase<KS, QG, WAVES, I8>() + (p.run_S ? (size_t)kRunLdsBytes<QG, WAVES>() : (size_t)kRunLdsRing<QG>());
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     if (p.skip_sampled && (p.skip_sampled < 4u || (p.skip_sampled & 3u))) return hipErrorInvalidValue;  // (tile_of divides by S - 1; tmax groups of four)
-    if (p.run_S && (p.run_S > 256u || (p.run_S & (p.run_S - 1u)) || p.tile_step > 1u || p.skip_sampled)) return hipErrorInvalidValue;
+    if (p.run_S && (p.run_S > 256u || blocks_all > (uint32_t)kRunVals || p.tile_step > 1u || (p.skip_sampled && !(p.run_dbg & 1u)))) return hipErrorInvalidValue;
     // AUX = 2: non-temporal LDS-DMA (the mirror is read once)
 #ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
 #define NMN_MFMA_AUX 2

@@ -1185,8 +1185,24 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
     const uint32_t tid = threadIdx.x;
     uint32_t n;
     const uint32_t mode = p.qstate[q].overflow;
+    // (a polling host caller: this workgroup's result stores — all threads' — are ordered before its arrival, the last arrival
+    //  publishes the sequence word)
+    auto publish_done = [&]() {
+        if (!p.done_word) return;
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t t = atomicAdd(p.done_ctr, 1u);
+            if (t == gridDim.x - 1u) {
+                *p.done_ctr = 0u;
+                __threadfence_system();
+                __hip_atomic_store(p.done_word, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     if (mode && p.short_chain) {  // (block-uniform) the short chain: nobody computed what the lists below would need — the host follows up
         if (tid == 0) p.out_counts[q] = 0xFFFFFFFFu;
+        publish_done();
         return;
     }
     if (mode == 2) {
@@ -1237,6 +1253,7 @@ __global__ void __launch_bounds__(kSelThreads) final_kernel(FinalParams p) {
         __syncthreads();
     }
     sort_and_emit(list, n, n, p.k, p.row_base, p.out_rows + (size_t)q * p.k, p.out_scores + (size_t)q * p.k, p.out_counts + q);
+    publish_done();
 }
 
 hipError_t launch_final(const FinalParams& p, hipStream_t s) {

@@ -1,15 +1,12 @@
-O=gpurun_out/r06e; mkdir -p $O
-python -m pytest tests/test_gpu_batched.py tests/test_gpu_sweep_kind.py -m gpu -x -q > $O/tests_a.log 2>&1; grep -n "passed\|failed" $O/tests_a.log | tail -2
-for r in 1 2; do
-for m in 0 2 1; do
-  python tools/mfma_loop.py --mirror $m --tag run$m --realloc 2 --reps 20 >> $O/mfma_ab.txt 2>&1
-  NMN_NO_RUN_BOUND=1 python tools/mfma_loop.py --mirror $m --tag old$m --realloc 2 --reps 20 >> $O/mfma_ab.txt 2>&1
-done; done
-python tools/mfma_loop.py --mirror 0 --tag run0_128 --nq 128 --reps 20 >> $O/mfma_ab.txt 2>&1
-NMN_NO_RUN_BOUND=1 python tools/mfma_loop.py --mirror 0 --tag old0_128 --nq 128 --reps 20 >> $O/mfma_ab.txt 2>&1
-python tools/mfma_loop.py --mirror 0 --tag run0_l2 --metric 1 --reps 20 5000000:1536 >> $O/mfma_ab.txt 2>&1
-NMN_NO_RUN_BOUND=1 python tools/mfma_loop.py --mirror 0 --tag old0_l2 --metric 1 --reps 20 5000000:1536 >> $O/mfma_ab.txt 2>&1
-python tools/mfma_loop.py --mirror 0 --tag run0_k256 --k 256 --reps 20 >> $O/mfma_ab.txt 2>&1
-NMN_NO_RUN_BOUND=1 python tools/mfma_loop.py --mirror 0 --tag old0_k256 --k 256 --reps 20 >> $O/mfma_ab.txt 2>&1
-grep -v amdgpu.ids $O/mfma_ab.txt
-python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "config3" > $O/tests_b.log 2>&1; grep -n "passed\|failed" $O/tests_b.log | tail -2
+O=gpurun_out/r06n; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/suite.log 2>&1; grep -n "passed\|failed" $O/suite.log | tail -2
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
+python - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r06n/bench.json") if l.startswith("{")][-1])
+r=d["roofline"]
+print("value",d["value"],"ms",d["ms_per_step"])
+for k in list(r)[:24]: print(k, r[k])
+for k in ("c3_f32_sweep_launches","c3_i8_sweep_launches","c3_f32_sweep_ms","c3_i8_sweep_ms","c2_f32_step_frac","c5_mask0.1_f32_step_frac","frac_of_read_ceiling"): print(k, r.get(k))
+print(d["config"]["filtered_similar_sel0.1_ms"]); print({k:v for k,v in d["cpu_baseline"].items() if k.startswith("pub_") and k!="pub_detail"})
+PY
