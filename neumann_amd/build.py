@@ -23,6 +23,7 @@ SOURCES = {
     "nmn_scan_ring.hip": [],
     "nmn_scan_mfma.hip": [],
     "nmn_scan_mfma_f32.hip": [],
+    "nmn_scan_mfma_i8x.hip": [],
     "nmn_scan_i8.hip": [],
     "nmn_select.hip": [],
     "nmn_exact.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],

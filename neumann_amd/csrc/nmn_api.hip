@@ -1016,10 +1016,15 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 const uint32_t total = now[0] - idx->q8_seen[0], retried = now[1] - idx->q8_seen[1];
                 idx->q8_seen[0] = now[0];
                 idx->q8_seen[1] = now[1];
-                if (total >= 64 && retried * 2 > total) {
+                // (batches on ONE query plane carry a wider margin: when more than an eighth of the recent queries overflowed under
+                //  it, the shard goes back to both planes first — and leaves the 8-bit mirror only if that overflows as well)
+                if (total >= 64 && idx->one_plane_recent && retried * 8 > total) {
+                    idx->one_plane_off_until = idx->q8_calls + 8192;
+                } else if (total >= 64 && retried * 2 > total) {
                     idx->q8_off_until = idx->q8_calls + 8192;
                     use_i8 = false;
                 }
+                idx->one_plane_recent = false;
             } else {
                 (void)hipGetLastError();
             }
@@ -1100,6 +1105,16 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         w->last_elem_bytes = use_i8 ? 1u : use_half ? 2u : 4u;  // (nested parts too: what the sweeps of this pass read)
         // A mirror pass whose margin admits more than cand_cap rows must not fall into the exact scan of everything (85 ms
         // for 10M x 1536 Euclidean): large shards get an f32 retry sweep that only runs for the queries that overflowed.
+        // 8-bit matrix-core batches under cosine / dot product multiply ONE int8 plane of every query (the sweep is instruction-bound at
+        // the package power limit: the second plane's MFMAs were 0.18 of its 1.53 ms at 10M x 768 x 64); the query's coarser rounding is
+        // measured and widens the margin like the rows' own.  NMN_I8_TWO_PLANES=1: both planes, the A/B.
+        static const bool two_planes = env_set("NMN_I8_TWO_PLANES");
+        // Where it pays (profiles/r06p_*): cosine, k <= 128 — 10M x 768: 64 queries 1.53 -> 1.38-1.48 ms, 128 queries 2.29 -> 1.80; the
+        // candidate lists grow (~900 -> ~4 000 rows for the worst query of a batch at 10M rows), which k = 1000 (1.75 -> 1.90 ms) and the
+        // dot product's absolute margin (5M x 1536: 1.38 -> 1.51) do not repay.
+        const bool one_plane = use_i8 && use_mfma && !two_planes && metric == NMN_METRIC_COSINE && k <= 128u &&
+                               scan_mfma_i8_one_plane_supported((int)metric) && idx->q8_calls >= idx->one_plane_off_until;
+        if (one_plane) idx->one_plane_recent = true;
         const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18) && !short_chain;
         // The batched sweep as ONE launch (round 6; ScanParams::run_*): the bound that gates its score stores rises inside the sweep
         // itself — no sampling pass, no bound kernels, no split into two launches.  Unmasked batches on shards large enough for the
@@ -1114,7 +1129,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // (one launch prepares the query for the mirror sweep and, in qinfo_f32, for the f32 retry behind it)
         HIP_TRY(launch_qprep(queries_dev + (size_t)qa * idx->dim, nqc, idx->dim, idx->ld, (int)metric,
                              idx->max_norm_bits, w->qpad, w->qinfo, w->qstate,
-                             use_i8 ? (1 | 2 | 4 | (use_mfma ? 0 : 8)) : ((use_mfma ? 1 : 0) | ((use_half || mfma_f32) ? 2 : 0)), stream,
+                             use_i8 ? (1 | 2 | 4 | (use_mfma ? (one_plane ? 16 : 0) : 8)) : ((use_mfma ? 1 : 0) | ((use_half || mfma_f32) ? 2 : 0)), stream,
                              // (f32 rows rounded to bf16 on the fly: the rounding is the mirror's — its measured error norms where a
                              //  complete bf16 mirror happens to exist, else the a-priori bound |e_r| <= 2^-8 |v_r| of qprep_kernel)
                              use_i8 ? idx->q8_err_bits : (use_half || (mfma_f32 && idx->half && idx->half_rows >= n_rows)) ? idx->half_err_bits : nullptr,
@@ -1126,6 +1141,7 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
             sp.corpus = idx->corpus;
             sp.corpus_half = use_half ? idx->half : nullptr;
             sp.corpus_i8 = use_i8 ? idx->q8 : nullptr;
+            sp.i8_one_plane = one_plane ? 1u : 0u;
             sp.i8_scale = idx->q8_scale;
             sp.i8_vv = idx->q8_vv;
             sp.i8_cos = idx->q8_cos;
@@ -1749,7 +1765,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     {
         const uint8_t *in0 = w->pin_in, *out0 = w->pin_out;
         HIP_TRY(grow_pinned(&w->pin_in, &w->pin_in_cap, qn * sizeof(float)));
-        HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes));
+        HIP_TRY(grow_pinned(&w->pin_out, &w->pin_out_cap, pack_bytes + 16));  // (+ the polled sequence word, in the block's LAST 8 bytes)
         if (w->pin_in != in0 && hipHostGetDevicePointer(reinterpret_cast<void**>(&w->pin_in_dev), w->pin_in, 0) != hipSuccess) {
             (void)hipGetLastError();
             w->pin_in_dev = nullptr;
@@ -1774,8 +1790,11 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     // reads it a few microseconds before hipStreamSynchronize would return.  Bounded: 400 us, then the runtime's wait.
     // NMN_NO_POLL=1: the A/B.
     static const bool no_poll = env_set("NMN_NO_POLL") || env_set("NMN_FUSED_TAIL");  // (the fused tail's kernel does not publish)
-    const size_t off_done = (pack_bytes + 7) & ~(size_t)7;  // (grow_pinned allocates need + need / 2, at least 4096: the word fits)
-    const bool poll = zero_copy && !no_poll && n_reqs == 1 && nq <= 4 && k <= NMN_MAX_TOP_K && off_done + 8 <= w->pin_out_cap;
+    // (the word lives in the LAST 8 bytes of the pinned block, where no call's results ever reach: placed right behind the results it
+    //  moved with k, and a row id an earlier, larger call had left there matched a sequence number — a k = 1 search returned before
+    //  its kernels had run; tests/test_gpu_parity_basic.py caught it)
+    const size_t off_done = (w->pin_out_cap - 8) & ~(size_t)7;
+    const bool poll = zero_copy && !no_poll && n_reqs == 1 && nq <= 4 && k <= NMN_MAX_TOP_K && pack_bytes + 16 <= w->pin_out_cap;
     const float* const q_dev = zero_copy ? reinterpret_cast<const float*>(w->pin_in_dev) : w->h_queries;
     uint8_t* const pack_dev = zero_copy ? w->pin_out_dev : w->h_pack;
     unsigned long long* const d_pred_counts = reinterpret_cast<unsigned long long*>(w->h_pack + off_pred);
@@ -1906,7 +1925,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         w->poll_word_dev = on ? reinterpret_cast<uint32_t*>(w->pin_out_dev + off_done) : nullptr;
         if (on) w->done_seq++;
     };
-    const bool poll_this = poll && !separately && qmasks.empty() && nq <= w->nq_cap;
+    const bool poll_this = poll && !separately && qmasks.empty() && nq <= w->nq_cap && n_pred == 0;  // (a predicate's counters travel in a copy BEHIND the chain's last kernel)
     arm_poll(poll_this);
     st = enqueue_all(try_short);
     arm_poll(false);

@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(64) qprep_kernel(const float* __restrict__ que
                 if (i < dim && qscale > 0.0f) {
                     const float t = src[i] * inv;
                     h = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(t), -127.0f), 127.0f);
-                    l = __builtin_fminf(__builtin_fmaxf(__builtin_rintf((t - h) * 256.0f), -127.0f), 127.0f);
+                    l = (mfma_pass & 16) ? 0.0f : __builtin_fminf(__builtin_fmaxf(__builtin_rintf((t - h) * 256.0f), -127.0f), 127.0f);  // (16: one plane)
                     const float qt = qscale * (h + l * 0.00390625f);
                     const float e = src[i] - qt;
                     qerr2 = qerr2 + e * e;

@@ -166,6 +166,8 @@ struct nmn_index {
     bool q8_failed = false;
     uint32_t q8_seen[2] = {0, 0};
     uint64_t q8_calls = 0, q8_off_until = 0;
+    uint64_t one_plane_off_until = 0;  // batches multiply both query planes again until q8_calls reaches this (their one-plane margin kept overflowing)
+    bool one_plane_recent = false;     // a batch since the last look at q8_stats used one plane
     // Mirror on/off switch: data whose rounding margin keeps overflowing the candidate capacity (a row of enormous norm
     // under a Euclidean metric, ...) pays a bf16 pass AND an f32 retry per query.  select_kernel counts both in
     // half_stats; every 256th search the host reads them and, if more than half of the recent queries were retried, leaves

@@ -185,6 +185,7 @@ struct ScanParams {
     uint32_t* run_slots;     // [nq][1024] the workgroups' running maxima (keys; 0 = nothing yet)
     uint32_t* run_bound;     // [nq rounded up to 128] keys (kKeyNaN = no bound yet: every tile writes)
     uint32_t run_S;          // 0 = off; else the rank of the bound among the running maxima (= k)
+    uint32_t i8_one_plane;   // 8-bit matrix-core sweep: 1 = the queries' h plane only (qprep approx_pass bit 16 measured the rounding accordingly)
     uint32_t run_dbg;        // measurement only (NMN_RUN_BOUND_DEBUG): 1 = decide the stores by skip_key, 2 = no slot atomics, 4 = no refresh, 8 = no bound DMA
     int metric;
 };
@@ -229,6 +230,9 @@ hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s);
 hipError_t launch_scan_mfma_f32(const ScanParams& p, hipStream_t s);
 // ... over the 8-bit mirror (p.corpus_i8 set: launch_scan_mfma dispatches on it): unmasked batches, rows of 256 .. 1536 elements
 bool scan_mfma_i8_supported(uint32_t ld, uint32_t dim, int metric);
+// ... with ONE query plane (p.i8_one_plane; cosine / dot product): nmn_scan_mfma_i8x.hip
+bool scan_mfma_i8_one_plane_supported(int metric);
+hipError_t launch_scan_mfma_i8_one(const ScanParams& p, hipStream_t s);
 
 struct SelectParams {
     const uint32_t* scores;  // score_at(row, q, nql)
@@ -354,6 +358,7 @@ hipError_t launch_qprep(const float* queries, uint32_t nq, uint32_t dim, uint32_
 // approx_pass bits: 1 = the sweep's copy of the query is rounded (bf16 on the MFMA sweep; with bit 4 the int8 split
 // q = s_q (h + l / 256), written to qi8[q][2][ld] and QInfo.qscale), 2 = the sweep reads a mirror of the corpus
 // (half_err_bits = that mirror's measured rounding errors: [0] max |e_r|, [1] max |e_r| / |v_r|); 0 = plain f32 sweep;
+// 16 (with 4): ONE query plane — l = 0, the residual q - s_q h is the measured rounding (the matrix-core 8-bit sweep, ONE = true);
 // 8 (with 4, Euclidean, the 1-2 query sweep): the estimator may be chosen per query from *l2_hint, the threshold distance of
 // the shard's previous Euclidean selection (nmn_scan_i8.hip: "which Euclidean estimator")
 struct RescoreParams {

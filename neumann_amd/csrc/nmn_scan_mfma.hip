@@ -142,6 +142,7 @@ bool scan_mfma_supported(uint32_t ld, uint32_t dim, int metric) {
 // p.tiles_per_wave = tiles per WORKGROUP; wmax is indexed by workgroup.
 hipError_t launch_scan_mfma(const ScanParams& p, hipStream_t s) {
     if (!p.corpus_i8 && !p.corpus_half) return launch_scan_mfma_f32(p, s);  // no mirror: the f32 rows themselves (nmn_scan_mfma_f32.hip)
+    if (p.corpus_i8 && p.i8_one_plane) return launch_scan_mfma_i8_one(p, s);  // one query plane (nmn_scan_mfma_i8x.hip)
     if (p.corpus_i8) {  // the 8-bit mirror
         switch (p.metric) {
             case NMN_METRIC_COSINE: return launch_metric_i8<NMN_METRIC_COSINE>(p, s);

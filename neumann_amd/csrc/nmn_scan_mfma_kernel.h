@@ -200,9 +200,14 @@ __host__ __device__ constexpr uint32_t kRunLdsBytes() {
     return kRunLdsRing<QG>() + (uint32_t)(QG * 16 * (int)sizeof(QInfo) + WAVES * kRunVals * 4);
 }
 
-template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES, bool I8 = false, bool F32 = false>
+// ONE (8-bit form, round 6): ONE query plane — the stationary query is s_q h alone, one v_mfma_i32_16x16x64_i8 per fragment instead
+// of two (and half the B-fragment registers).  The query's rounding |q - s_q h| is measured by qprep_kernel (approx_pass bit 16) and
+// enters the margin like any other: ~2^-8 |q| instead of ~2^-16 |q|, i.e. about the rows' own 8-bit rounding again.  Cosine and dot
+// product batches (nmn_scan_mfma_i8x.hip); 10M x 768, 64 queries: 1.53 -> 1.35 ms as a timing build (profiles/r06o_*).
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int AUX, int WAVES, bool I8 = false, bool F32 = false, bool ONE = false>
 __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(ScanParams p) {
     static_assert(!(I8 && F32), "one streamed matrix");
+    static_assert(!ONE || I8, "one query plane: the 8-bit form only");
     constexpr int kStageElems = 128 * KS;                        // bf16 elements of a row per stage (I8: 256 * KS, F32: 64 * KS — the same BYTES)
     constexpr int kStageBytes = kTileRows * kStageElems * 2;     // 16 / 32 KiB of bf16
     constexpr int kRowPitch = kStageElems / 2;                   // LDS row pitch of a stage, in floats
@@ -276,7 +281,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
     constexpr int kBK = KC * kSteps;                  // ... of a row
     constexpr int kBG = kHalfK ? 1 : QG / WAVES;      // query groups of this wave: groups wave, wave + WAVES, ...
     s8 bhi[kBK][kBG];
-    s8 blo[I8 ? kBK : 1][kBG];  // (I8) the l plane of the query split
+    s8 blo[(I8 && !ONE) ? kBK : 1][kBG];  // (I8, two planes) the l plane of the query split
 #pragma unroll
     for (int qg = 0; qg < kBG; qg++) {
         const uint32_t qq = q0 + ((uint32_t)qg * (uint32_t)WAVES + grp) * 16u + n;
@@ -291,10 +296,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
                 u4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
                 if (ok) {
                     h = *reinterpret_cast<const u4*>(qb + k0b);
-                    l = *reinterpret_cast<const u4*>(qb + ld + k0b);
+                    if constexpr (!ONE) l = *reinterpret_cast<const u4*>(qb + ld + k0b);
                 }
                 bhi[kc][qg] = __builtin_bit_cast(s8, h);
-                blo[kc][qg] = __builtin_bit_cast(s8, l);
+                if constexpr (!ONE) blo[kc][qg] = __builtin_bit_cast(s8, l);
             }
             continue;
         } else {
@@ -753,7 +758,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
 #endif
                                 ach[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, bhi[kc * kSteps + ks][qg]), ach[rb][qg], 0, 0, 0);
 #ifndef NMN_MFMA_I8_NO_LO  // (measurement build: the sweep without the l plane's products — wrong answers, timing only)
-                                acl[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, blo[kc * kSteps + ks][qg]), acl[rb][qg], 0, 0, 0);
+                                if constexpr (!ONE) acl[rb][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, __builtin_bit_cast(v4i, blo[kc * kSteps + ks][qg]), acl[rb][qg], 0, 0, 0);
 #endif
                             } else if constexpr (F32) {
 #ifdef NMN_MFMA_F32_NOCVT  // (measurement build: the fragments go to the matrix cores unconverted — wrong answers, timing only)
@@ -796,6 +801,10 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
             for (int rb = 0; rb < 4; rb++)
 #pragma unroll
                 for (int qg = 0; qg < kAccGroups; qg++)
+                    if constexpr (ONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[rb][qg][e] = (float)ach[rb][qg][e];  // (exact: |h.c| <= 3072 * 127^2 < 2^26, one rounding of 2^-24)
+                    } else
 #pragma unroll
 #ifdef NMN_MFMA_I8_INT_COMBINE  // (measurement build, VERDICT r05 #4's second lever: the planes combined in integers — one shift-add and
                     // one conversion per element instead of two conversions and an FMA; exact only while |h.c| < 2^23, i.e. rows of <= 512
@@ -889,7 +898,7 @@ __global__ void __launch_bounds__(WAVES * 64, NMN_MFMA_OCC) scan_mfma_kernel(Sca
         }
 }
 
-template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES, bool I8 = false, bool F32 = false>
+template <int KC, int KS, int QG, int METRIC, bool MASKED, int WAVES, bool I8 = false, bool F32 = false, bool ONE = false>
 static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
     const uint32_t blocks_all = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
     if (p.bx_base >= blocks_all) return hipSuccess;
@@ -913,7 +922,7 @@ static hipError_t launch_one_mfma(const ScanParams& p, hipStream_t s) {
 #ifndef NMN_MFMA_AUX  // cache policy of the LDS-DMA (cpol bits: 1 sc0, 2 nt, 16 sc1); measurement builds override
 #define NMN_MFMA_AUX 2
 #endif
-    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, NMN_MFMA_AUX, WAVES, I8, F32>;
+    auto kern = scan_mfma_kernel<KC, KS, QG, METRIC, MASKED, NMN_MFMA_AUX, WAVES, I8, F32, ONE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
