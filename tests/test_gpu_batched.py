@@ -237,3 +237,35 @@ def test_more_than_64_queries_on_a_large_shard_two_launch_sweep():
         for qi in (0, 5, 6, 50, 95):
             er, es = oc.search(A, Q[qi], k, 0, mask=mask, nthreads=8, partial=True, native=True)
             assert np.array_equal(rows[qi], er) and np.all(scores[qi] == es), qi
+
+
+@pytest.mark.parametrize("d,metric", [(256, 0), (128, 1), (256, 2)])
+def test_one_launch_sweep_with_the_running_bound_matches_oracle(d, metric):
+    """Shards of >= 32 768 tiles sweep a batch in ONE launch (round 6): the bound that gates the score stores rises inside the sweep —
+    every workgroup publishes its running maximum, waves re-read the maxima and publish the k-th largest (ScanParams::run_*,
+    nmn_scan_mfma_kernel.h).  All three streamed matrices (f32 rows, bf16 mirror, 8-bit mirror — cosine batches there on ONE query
+    plane), every list against the oracle; planted near-copies of two queries sit in the LAST tiles, where the bound is tightest."""
+    from neumann_amd import GpuFlatIndex
+    n, k, nq = 2_150_000, 10, 8          # 33 594 tiles
+    A = oc.synth(7700 + d, 0, n, d, nthreads=8)
+    Q = oc.synth(7800 + d, 0, nq, d)
+    rng = np.random.default_rng(d)
+    with GpuFlatIndex(d, n) as idx:
+        idx.fill_synthetic(7700 + d, n)
+        for j in range(6):
+            row = n - 1 - 97 * j
+            v = (Q[j % 2] * np.float32(1.0 + 0.1 * j) + rng.standard_normal(d).astype(np.float32) * np.float32(1e-3)).astype(np.float32)
+            idx.set_row(row, v)
+            A[row] = v
+        want = [oc.search(A, Q[i], k, metric, nthreads=8, partial=True, native=True) for i in range(nq)]
+        for mode, nbytes in ((0, 4), (2, 2), (1, 1)):
+            if mode == 1 and d % 256:
+                continue                  # (the 8-bit matrix-core sweep takes strides that are multiples of 256)
+            idx.set_mirror(mode)
+            rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
+            assert st.bytes_scanned == n * d * nbytes and st.sweep.startswith("mfma_"), (mode, st.sweep, st.bytes_scanned)
+            assert st.sweep_launches == 1, (mode, st.sweep_launches)
+            assert st.fallback_queries == 0
+            for i in range(nq):
+                er, es = want[i]
+                assert counts[i] == er.size and np.array_equal(rows[i, :er.size], er) and np.all(scores[i, :er.size] == es), (mode, i)
