@@ -521,3 +521,26 @@ def test_query_passes_shrink_when_the_workspace_does_not_fit():
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", _WS_CHILD], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WS-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_hbm_bytes_is_a_plain_getter_and_retry_declined_is_the_explicit_form():
+    """nmn_index_hbm_bytes has no side effects any more (a monitor polling it used to clear the shard's out-of-memory
+    verdicts); nmn_index_retry_declined is the entry point for a host that has just freed device memory.  Both are callable at any
+    time, between searches whose answers do not change."""
+    from neumann_amd import GpuFlatIndex
+    rng = np.random.default_rng(41)
+    n, d, k = 40_000, 256, 10
+    A = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((8, d)).astype(np.float32)
+    with GpuFlatIndex(d, n) as idx:
+        idx.upload(A)
+        r0, s0, c0 = idx.search(Q, k, 0)
+        a = idx.hbm_bytes()
+        for _ in range(5):
+            assert idx.hbm_bytes() == a
+        idx.retry_declined()
+        r1, s1, c1 = idx.search(Q, k, 0)
+        assert np.array_equal(r0, r1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(c0, c1)
+        for i in range(8):
+            er, es = oc.search(A, Q[i], k, 0)
+            assert np.array_equal(r1[i], er) and np.all(s1[i] == es)

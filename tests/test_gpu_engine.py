@@ -1030,3 +1030,21 @@ def test_search_filtered_typed_comparisons(E):  # lib.rs:7491-7700
     # search_filtered_missing_field (7261-7274)
     e = engine_with([("item", [1.0, 0.0], None)])
     assert e.search_similar_filtered([1.0, 0.0], 10, FC.Eq("missing", 42)) == []
+
+
+def test_search_probe_times_native_calls_and_returns_the_same_answers(E):
+    """nmn_engine_search_probe (bench.py's published_shapes leg: the reference's own bench shapes, vector_engine_bench.rs:40-77): N native
+    back-to-back search_similar calls, one duration per call; the engine's answer for the same query is the oracle's."""
+    rng = np.random.default_rng(7)
+    n, d = 1000, 128
+    A = rng.uniform(-1.0, 1.0, (n, d)).astype(F)
+    Q = rng.uniform(-1.0, 1.0, (4, d)).astype(F)
+    eng = E.VectorEngine()
+    eng.batch_store_embeddings([f"v{i}" for i in range(n)], A)
+    us = eng.search_probe(Q, 10, 50)
+    assert us.shape == (50,) and np.all(us > 0) and np.all(np.isfinite(us))
+    res = eng.search_similar(Q[1], 10)
+    er, es = oc.search(A, Q[1], 10, 0)
+    assert [r.key for r in res] == [f"v{int(i)}" for i in er]
+    assert np.array_equal(np.array([r.score for r in res], dtype=F), es)
+    eng.close()
