@@ -175,7 +175,7 @@ static void ws_free(Workspace* w) {
         if (p) (void)hipFree(p);
     if (w->h_pack) (void)hipFree(w->h_pack);
     if (w->h_qmasks) (void)hipFree(w->h_qmasks);
-    for (void* p : {(void*)w->pred_block, (void*)w->pred_masks, (void*)w->pred_counts})
+    for (void* p : {(void*)w->pred_block, (void*)w->pred_masks, (void*)w->pred_counts, (void*)w->pred_ticket})
         if (p) (void)hipFree(p);
     if (w->tiny_pool) (void)hipFree(w->tiny_pool);
     if (w->tiny_ticket) (void)hipFree(w->tiny_ticket);
@@ -1810,6 +1810,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
     // ---- predicates of the batch: one launch on this stream, each into its own bitmap -------------------------
     std::vector<const uint64_t*> eff_mask(n_reqs);  // the bitmap each request's queries are searched with
     size_t pred_words = 0;
+    bool pred_ticket_on = false;
     if (n_pred && words) {
         const nmn_columns* cols = nullptr;
         for (size_t i = 0; i < n_reqs; i++)
@@ -1818,6 +1819,16 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         if (pred_words < words || columns_device(cols) != idx->device)
             return fail_arg(NMN_ERR_INVALID_ARGUMENT, "metadata columns do not cover the shard's rows (or live on another device)");
         HIP_TRY(grow(&w->pred_masks, &w->pred_masks_cap, n_pred * pred_words));
+        // (NMN_PRED_TICKET=1: the last block of each program sums the partial counts itself — no count_reduce launch.  Built and
+        //  measured SLOWER: a release fence + one atomic per block, 2 400 blocks, in a streaming kernel: filtered SIMILAR 0.269 ->
+        //  0.383 ms (0.61 with the fence in every thread); the 5.8-us launch it saves stays.  Off.)
+        static const bool pred_ticket_env = env_set("NMN_PRED_TICKET");
+        pred_ticket_on = pred_ticket_env;
+        if (pred_ticket_on && n_pred > w->pred_ticket_cap) {  // (zeroed once: the kernel leaves every counter at zero)
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(grow(&w->pred_ticket, &w->pred_ticket_cap, std::max<size_t>(n_pred, 64)));
+            HIP_TRY(hipMemset(w->pred_ticket, 0, w->pred_ticket_cap * sizeof(uint32_t)));
+        }
         size_t off = n_pred * pred_desc_bytes();
         std::vector<uint32_t> ops_off(n_pred), consts_off(n_pred);
         size_t j = 0;
@@ -1836,13 +1847,16 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         for (size_t i = 0; i < n_reqs; i++) {
             if (!reqs[i]->pred_cols) continue;
             pred_desc_write(w->pin_pred + j * pred_desc_bytes(), ops_off[j], (uint32_t)(reqs[i]->pred_ops.size() / pred_op_bytes()),
-                            consts_off[j], w->pred_masks + j * pred_words, d_pred_counts + j * pred_count_stride);
+                            consts_off[j], w->pred_masks + j * pred_words, d_pred_counts + j * pred_count_stride,
+                            // (zero copy: the selected-row total of each predicate lands in the pinned result block by itself)
+                            zero_copy ? reinterpret_cast<unsigned long long*>(w->pin_out_dev + off_pred) + j * pred_count_stride : nullptr,
+                            pred_ticket_on ? w->pred_ticket + j : nullptr);
             memcpy(w->pin_pred + ops_off[j], reqs[i]->pred_ops.data(), reqs[i]->pred_ops.size());
             if (reqs[i]->pred_n_consts) memcpy(w->pin_pred + consts_off[j], reqs[i]->pred_consts, (size_t)reqs[i]->pred_n_consts * 8);
             j++;
         }
         HIP_TRY(hipMemcpyAsync(w->pred_block, w->pin_pred, block_bytes, hipMemcpyHostToDevice, s));
-        HIP_TRY(launch_pred_batch(cols, w->pred_block, (uint32_t)n_pred, idx->rows, s));
+        HIP_TRY(launch_pred_batch(cols, w->pred_block, (uint32_t)n_pred, idx->rows, s, pred_ticket_on));
     }
     {
         size_t j = 0;
@@ -1916,8 +1930,8 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
                                nullptr, short_chain);
         if (e != NMN_OK) return e;
         if (!zero_copy) HIP_TRY(hipMemcpyAsync(w->pin_out, w->h_pack, pack_bytes, hipMemcpyDeviceToHost, s));
-        else if (n_pred && words)  // (the results are already where the host reads them: only the predicates' counters travel)
-            HIP_TRY(hipMemcpyAsync(w->pin_out + off_pred, w->h_pack + off_pred, n_pred * pred_count_stride * 8, hipMemcpyDeviceToHost, s));
+        // (zero copy: the results and the predicates' totals are already where the host reads them — count_reduce_batch_kernel wrote
+        //  the totals into the pinned block when it formed them, ahead of the sweep)
         return NMN_OK;
     };
     volatile uint32_t* const done_host = reinterpret_cast<volatile uint32_t*>(w->pin_out + off_done);
@@ -1925,7 +1939,7 @@ static nmn_status host_batch_body(nmn_index* idx, std::unique_lock<std::mutex>& 
         w->poll_word_dev = on ? reinterpret_cast<uint32_t*>(w->pin_out_dev + off_done) : nullptr;
         if (on) w->done_seq++;
     };
-    const bool poll_this = poll && !separately && qmasks.empty() && nq <= w->nq_cap && n_pred == 0;  // (a predicate's counters travel in a copy BEHIND the chain's last kernel)
+    const bool poll_this = poll && !separately && qmasks.empty() && nq <= w->nq_cap;
     arm_poll(poll_this);
     st = enqueue_all(try_short);
     arm_poll(false);

@@ -182,12 +182,39 @@ struct ProgDesc {
     uint32_t consts_off, pad;    // byte offset of the constants
     uint64_t* mask;              // result bitmap of this program
     unsigned long long* counts;  // [0] total, [1 ..] per-block partials
+    unsigned long long* host_total;  // nullable: the total ALSO goes here — pinned host memory the caller reads without a copy (round 6)
+    uint32_t* ticket;            // nullable (zero between launches): the LAST block of the program to finish sums the partials itself —
+                                 // no count_reduce launch behind the evaluation (round 6)
 };
 __global__ __launch_bounds__(256) void pred_eval_batch_kernel(const uint8_t* __restrict__ base,
                                                               const uint64_t* __restrict__ valid, uint64_t n_rows) {
     const ProgDesc d = reinterpret_cast<const ProgDesc*>(base)[blockIdx.y];
     pred_eval_body(reinterpret_cast<const DevOp*>(base + d.ops_off), d.n_ops,
                    reinterpret_cast<const uint64_t*>(base + d.consts_off), valid, n_rows, d.mask, d.counts + 1);
+    if (!d.ticket) return;  // (block-uniform)
+    __shared__ uint32_t s_last;
+    __shared__ unsigned long long acc[256];
+    if (threadIdx.x == 0) {
+        __threadfence();  // (this thread wrote the block's partial; a fence in all 256 threads of 2 400 blocks cost 0.3 ms)
+        const uint32_t t = atomicAdd(d.ticket, 1u);
+        s_last = t == gridDim.x - 1u ? 1u : 0u;
+        if (s_last) *d.ticket = 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // acquire: the other blocks' partials
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256) s += __builtin_nontemporal_load(d.counts + 1 + i);
+    acc[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t step = 128; step > 0; step >>= 1) {
+        if (threadIdx.x < step) acc[threadIdx.x] += acc[threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        d.counts[0] = acc[0];
+        if (d.host_total) *d.host_total = acc[0];
+    }
 }
 __global__ __launch_bounds__(256) void count_reduce_batch_kernel(const uint8_t* __restrict__ base, uint32_t n_blocks) {
     __shared__ unsigned long long acc[256];
@@ -200,7 +227,10 @@ __global__ __launch_bounds__(256) void count_reduce_batch_kernel(const uint8_t* 
         if (threadIdx.x < step) acc[threadIdx.x] += acc[threadIdx.x + step];
         __syncthreads();
     }
-    if (threadIdx.x == 0) d.counts[0] = acc[0];
+    if (threadIdx.x == 0) {
+        d.counts[0] = acc[0];
+        if (d.host_total) *d.host_total = acc[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void count_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n,
@@ -525,7 +555,7 @@ nmn_status columns_compile(const nmn_columns* c, const nmn_pred_op* prog, uint32
 size_t pred_desc_bytes() { return sizeof(ProgDesc); }
 size_t pred_op_bytes() { return sizeof(DevOp); }
 void pred_desc_write(uint8_t* dst, uint32_t ops_off, uint32_t n_ops, uint32_t consts_off, uint64_t* mask,
-                     unsigned long long* counts) {
+                     unsigned long long* counts, unsigned long long* host_total, uint32_t* ticket) {
     ProgDesc d;
     d.ops_off = ops_off;
     d.n_ops = n_ops;
@@ -533,6 +563,8 @@ void pred_desc_write(uint8_t* dst, uint32_t ops_off, uint32_t n_ops, uint32_t co
     d.pad = 0;
     d.mask = mask;
     d.counts = counts;
+    d.host_total = host_total;
+    d.ticket = ticket;
     memcpy(dst, &d, sizeof d);
 }
 // blocks per program (the grid stays around kPredMaxBlocks); counts of a program: 1 + pred_batch_blocks words
@@ -544,11 +576,11 @@ uint32_t pred_batch_blocks(uint64_t n_rows, uint32_t n_prog) {
 }
 // dev_block: [ProgDesc x n_prog | ops and constants], already on the device (same stream)
 hipError_t launch_pred_batch(const nmn_columns* c, const uint8_t* dev_block, uint32_t n_prog, uint64_t n_rows,
-                             hipStream_t s) {
+                             hipStream_t s, bool counts_by_ticket) {
     if (n_prog == 0 || n_rows == 0) return hipSuccess;
     const uint32_t blocks = pred_batch_blocks(n_rows, n_prog);
     hipLaunchKernelGGL(pred_eval_batch_kernel, dim3(blocks, n_prog), dim3(256), 0, s, dev_block, c->valid, n_rows);
-    hipLaunchKernelGGL(count_reduce_batch_kernel, dim3(n_prog), dim3(256), 0, s, dev_block, blocks);
+    if (!counts_by_ticket) hipLaunchKernelGGL(count_reduce_batch_kernel, dim3(n_prog), dim3(256), 0, s, dev_block, blocks);  // (else: every descriptor carries a ticket)
     return hipGetLastError();
 }
 uint64_t columns_words(const nmn_columns* c) { return c ? c->words : 0; }

@@ -62,6 +62,7 @@ struct Workspace {
     // predicates of a batch: staged programs, result bitmaps [requests][words], counters [requests][1 + blocks]
     uint8_t* pred_block = nullptr; size_t pred_block_cap = 0;            // device
     uint64_t* pred_masks = nullptr; size_t pred_masks_cap = 0;           // device
+    uint32_t* pred_ticket = nullptr; size_t pred_ticket_cap = 0;         // device, zero between launches: one arrival counter per predicate of a batch
     unsigned long long* pred_counts = nullptr; size_t pred_counts_cap = 0;  // (unused since round 4: the counters live in the tail of h_pack and come back with the results)
     uint8_t* pin_pred = nullptr; size_t pin_pred_cap = 0;                // pinned host staging of pred_block
     uint8_t* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned host
@@ -227,10 +228,11 @@ nmn_status columns_compile(const nmn_columns* c, const nmn_pred_op* prog, uint32
 size_t pred_desc_bytes();
 size_t pred_op_bytes();
 void pred_desc_write(uint8_t* dst, uint32_t ops_off, uint32_t n_ops, uint32_t consts_off, uint64_t* mask,
-                     unsigned long long* counts);
+                     unsigned long long* counts, unsigned long long* host_total = nullptr,  // host_total: nullable, pinned host memory (device view)
+                     uint32_t* ticket = nullptr);  // ticket: nullable, zero between launches (the last block sums the partials: launch_pred_batch(.., true))
 uint32_t pred_batch_blocks(uint64_t n_rows, uint32_t n_prog);
 hipError_t launch_pred_batch(const nmn_columns* c, const uint8_t* dev_block, uint32_t n_prog, uint64_t n_rows,
-                             hipStream_t s);
+                             hipStream_t s, bool counts_by_ticket = false);
 uint64_t columns_words(const nmn_columns* c);
 int columns_device(const nmn_columns* c);
 
