@@ -307,6 +307,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         }
         flat = true;
     }
+    // (Larger shards keep the three-level walk.  The same idea with the tile maxima STREAMED twice instead of held in LDS — pass 1:
+    //  per-thread group maxima, pick, pass 2: compaction — was built and measured at 10M rows: one workgroup walks the 625 KB of a
+    //  query's tile maxima at ~40 GB/s, 12.5 + 18.5 us for the two passes: 40-49 us against the walk's 28 (f32 rows) / 45 (8-bit);
+    //  level at 3M rows.  profiles/r06aa_select_streamed_flat_path.txt.  Removed.)
     // the wave maxima into LDS, counted on the way (one phase: the count used to be a second walk over them, two barriers more)
     auto load_wave_maxima = [&]() -> uint32_t {
         uint32_t valid = 0;
