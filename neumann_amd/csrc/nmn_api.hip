@@ -290,7 +290,7 @@ constexpr uint64_t kCrowdPool = 8ull << 20;
 static void ws_release_core(Workspace* w) {
     void** ptrs[] = {(void**)&w->scores, (void**)&w->tmax, (void**)&w->wmax, (void**)&w->tsample, (void**)&w->skip_key,
                      (void**)&w->k_extra, (void**)&w->qpad, (void**)&w->qi8, (void**)&w->qinfo, (void**)&w->qinfo_f32, (void**)&w->qstate,
-                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->final_ticket, (void**)&w->done_ctr, (void**)&w->run_slots, (void**)&w->run_bound, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
+                     (void**)&w->cand_rows, (void**)&w->cand_scores, (void**)&w->split_sg, (void**)&w->split_ctr, (void**)&w->final_ticket, (void**)&w->done_ctr, (void**)&w->run_slots, (void**)&w->run_bound, (void**)&w->h_counts2, (void**)&w->crowd_ctr,
                      (void**)&w->crowd_rows, (void**)&w->crowd_scores, (void**)&w->fb_hist, (void**)&w->fb_list, (void**)&w->fb_count,
                      (void**)&w->fb_sync};
     for (void** p : ptrs) {
@@ -336,6 +336,13 @@ static nmn_status ws_alloc_core(nmn_index* idx, Workspace* w) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->qstate), nq * sizeof(QState)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_rows), nq * w->cand_cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->cand_scores), nq * w->cand_cap * sizeof(float)));
+    {
+        const size_t nqs = std::min<size_t>(nq, 4);  // (the split selection serves calls of <= 4 queries)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->split_sg), nqs * 1024 * 4));
+        HIP_TRY(hipMemset(w->split_sg, 0, nqs * 1024 * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->split_ctr), nqs * 16));
+        HIP_TRY(hipMemset(w->split_ctr, 0, nqs * 16));
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->final_ticket), nq * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->done_ctr), 4));
     HIP_TRY(hipMemset(w->done_ctr, 0, 4));
@@ -1374,6 +1381,8 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
                 sel.count_overflows = 1;
             }
             sel.l2_hint = (use_i8 && !use_mfma && metric == NMN_METRIC_EUCLIDEAN) ? idx->q8_l2_hint : nullptr;
+            sel.split_sg = w->split_sg;    // (launch_select decides whether the query's selection is split over several workgroups)
+            sel.split_ctr = w->split_ctr;
             sel.fb_sync_reset = w->fb_sync;  // (nullable) zeroed for the device-wide fallback selection further down this stream
             if (metric == NMN_METRIC_SPARSE_COSINE_F64) {
                 HIP_TRY(launch_count_untrusted(idx->norms, n_rows, w->k_extra, stream));

@@ -49,6 +49,8 @@ struct Workspace {
     float* cand_scores = nullptr;
     uint32_t* run_slots = nullptr;     // [nq_cap][256] the one-launch batched sweep's slot maxima (ScanParams::run_slots)
     uint32_t* run_bound = nullptr;     // [nq_cap rounded up to 128] ... and its published bounds
+    uint32_t* split_sg = nullptr;      // [nq_cap][1024] super-group maxima of the split selection (SelectParams::split_sg), zero between launches
+    uint32_t* split_ctr = nullptr;     // [nq_cap][4] its counters
     uint32_t* final_ticket = nullptr;  // [nq_cap] arrival counters of rescore_final_kernel (zero between launches)
     // staging for the host-buffer API
     float* h_queries = nullptr;  size_t h_queries_cap = 0;   // device copies of host inputs

@@ -264,6 +264,13 @@ struct SelectParams {
     int count_overflows;       // 1: half_stats[1] counts the queries whose candidate list overflowed in THIS selection (batched 8-bit
                                // sweeps have no f32 retry whose selections could be counted)
     int flat;                  // set by launch_select: shards of <= 16 384 tiles select from all their tile maxima at once (NMN_NO_FLAT_SELECT=1: off)
+    // Lone callers on LARGE shards (round 6): `split` workgroups per query, each holding a part of the query's tile maxima in LDS
+    // (<= 16 384 tiles per part); the parts meet ONCE — per-thread group maxima folded by atomicMax into split_sg[q][1024], an
+    // arrival counter — pick the same bound from the 1024 super-group maxima, then each compacts and gathers ITS tiles and appends
+    // its candidates to the query's list; the last part to finish writes the query's state.  0 = one workgroup per query.
+    uint32_t split;
+    uint32_t* split_sg;        // [nq][1024] keys, zero between launches
+    uint32_t* split_ctr;       // [nq][4]: arrived at the bound | candidates so far | finished | trouble flag; zero between launches
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);

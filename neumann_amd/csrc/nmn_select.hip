@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     __shared__ PickResult pick;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_vw;
-    const uint32_t q = blockIdx.x;
+    const uint32_t S = p.split ? p.split : 1u;  // parts per query (see SelectParams::split)
+    const uint32_t q = blockIdx.x / S, part = blockIdx.x % S;
     const uint32_t tid = threadIdx.x;
     const uint32_t nql = p.nql;
 #ifdef NMN_SELECT_TRACE
@@ -201,9 +202,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         if (tid == 0 && p.qstate[q].overflow == 4u) p.qstate[q].overflow = 1u;
         return;
     }
-    if (p.half_stats && tid == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
-    if (p.crowd_count_reset && tid == 0) p.crowd_count_reset[q] = 0u;  // the crowd kernels behind this selection count from zero
-    if (p.fb_sync_reset && q == 0 && tid == 0) {  // arrival counter + abort flag of the fallback_select launch that follows on this stream
+    if (p.half_stats && tid == 0 && part == 0) atomicAdd(p.half_stats + (p.retry ? 1 : 0), 1u);  // feeds the shard's mirror on/off switch
+    if (p.crowd_count_reset && tid == 0 && part == 0) p.crowd_count_reset[q] = 0u;  // the crowd kernels behind this selection count from zero
+    if (p.fb_sync_reset && q == 0 && part == 0 && tid == 0) {  // arrival counter + abort flag of the fallback_select launch that follows on this stream
         p.fb_sync_reset[0] = 0ull;
         p.fb_sync_reset[1] = 0ull;
     }
@@ -233,7 +234,130 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     // it (~k) are compacted from LDS, and the row gather reads ~k x 64 scores instead of ~6 k x 64.  No wave level at all.
     // Lists that overflow (thousands of tiles inside the margin) and selections that hand over to the crowd kernels continue in
     // the code below exactly as before: LT, ct, Tw / Twm mean the same things there.  NMN_NO_FLAT_SELECT=1 (host side): the A/B.
-    if (p.flat && n_tiles <= kFlatTiles) {
+    // ---- split selection (round 6): S workgroups per query on shards too large for the flat path ----------------------------------
+    // One workgroup walks the 625 KB of a 10M-row query's tile maxima at ~40 GB/s (profiles/r06aa_*); S of them hold a part each in
+    // LDS.  They meet once: every thread's maximum over ITS tiles of the part is folded into split_sg[q][thread] (atomicMax: 1024
+    // super-groups, each a disjoint set of tiles), an arrival counter says when all parts are in, and every part picks the SAME bound
+    // — the k-th largest super-group maximum: k super-groups, k tiles — for itself.  Then a part is a flat selection over its own
+    // tiles, except that its candidates go behind the other parts' (a slice reserved by one global atomic) and the last part to finish
+    // writes the query's state.  Anything unusual in a part — a list that overflows, a crowd to hand over — flags the query
+    // `overflow` with the common tile-level threshold: the crowd kernels / the host's follow-up take it from there.
+    // (a part's end: candidates are in; the last part to arrive writes the state and leaves the meeting places zeroed)
+    auto split_finish = [&](bool trouble, uint32_t thr_common) {
+        __shared__ uint32_t s_last;
+        uint32_t* ctr = p.split_ctr + 4u * q;
+        __syncthreads();
+        if (tid == 0) {
+            // (the meeting is through device-scope atomics only; the candidate rows the parts wrote are for the NEXT kernel, which the
+            //  kernel boundary orders behind all of them: no fence)
+            uint32_t flagged = 0;
+            if (trouble) flagged = atomicOr(ctr + 3, 1u);
+            asm volatile("" ::"v"(flagged));  // (returned: performed before the arrival is counted)
+            const uint32_t t = atomicAdd(ctr + 2, 1u);
+            s_last = t == S - 1u ? 1u : 0u;
+            if (s_last) {
+                const uint32_t total = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t trb = __hip_atomic_load(ctr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                QState st;
+                st.n_valid = vw;
+                st.thr_key = thr_common;
+                st.overflow = (trb || total > p.cand_cap) ? 1u : 0u;
+                st.cand_count = st.overflow ? 0u : total;
+                p.qstate[q] = st;
+                if (p.count_overflows && p.half_stats && st.overflow) atomicAdd(p.half_stats + 1, 1u);
+                if (p.l2_hint && q == 0) {
+                    const float tau = key_to_score(thr_common);
+                    *p.l2_hint = (tau > 0.0f && tau <= 1.0f) ? 1.0f / tau - 1.0f : 0.0f;
+                }
+                ctr[0] = 0u; ctr[1] = 0u; ctr[2] = 0u; ctr[3] = 0u;
+#ifdef NMN_SELECT_TRACE
+                if (q == 0) {
+                    const unsigned long long t_now = wall_clock64();
+                    printf("select (split, last of %u parts: part %u) cand=%u trouble=%u | ticks: load %llu meet %llu pick %llu compaction %llu rest %llu total %llu\n", S, part,
+                           total, trb, sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], t_now - sel_t[4], t_now - sel_t[0]);
+                }
+#endif
+            }
+        }
+        __syncthreads();
+        if (s_last) p.split_sg[(size_t)q * kSelThreads + tid] = kKeyMasked;  // (every part has long read them)
+    };
+    if (S > 1) {
+        uint32_t* tk = reinterpret_cast<uint32_t*>(LR);
+        uint32_t* ctr = p.split_ctr + 4u * q;
+        const uint32_t per = ((n_tiles + S - 1u) / S + 3u) & ~3u;  // tiles per part: a multiple of 4 (16-byte loads), <= kFlatTiles (launch_select)
+        const uint32_t tA = min(part * per, n_tiles), tB = min(tA + per, n_tiles), nloc = tB - tA;
+        if (tid == 0) { s_vw = 0; s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
+        __syncthreads();
+        uint32_t my_valid = 0, my_max = kKeyMasked;
+        {
+            const uint4* t4 = reinterpret_cast<const uint4*>(tmax + tA);
+            const uint32_t n4 = (nloc + 3u) >> 2;
+            uint4 v4[kFlatTiles / 4 / kSelThreads];
+#pragma unroll
+            for (int u = 0; u < (int)(kFlatTiles / 4 / kSelThreads); u++) {
+                const uint32_t e = tid + (uint32_t)u * kSelThreads;
+                v4[u] = e < n4 ? t4[e] : make_uint4(kKeyMasked, kKeyMasked, kKeyMasked, kKeyMasked);
+            }
+#pragma unroll
+            for (int u = 0; u < (int)(kFlatTiles / 4 / kSelThreads); u++) {
+                const uint32_t e = tid + (uint32_t)u * kSelThreads;
+                if (e >= n4) continue;
+                uint32_t kk4[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (e * 4u + (uint32_t)c >= nloc) kk4[c] = kKeyMasked;
+                    my_valid += kk4[c] != kKeyMasked;
+                    my_max = max(my_max, kk4[c]);
+                }
+                *reinterpret_cast<uint4*>(tk + e * 4u) = make_uint4(kk4[0], kk4[1], kk4[2], kk4[3]);
+            }
+        }
+        // (a RETURNING atomic: the wave waits for it, so it has been performed when the arrival below is counted — a release fence per
+        //  thread would write the L2 back 1024 x S times; cf. NMN_PRED_TICKET in nmn_api.hip)
+        uint32_t seen_before = 0;
+        if (my_max != kKeyMasked) seen_before = atomicMax(p.split_sg + (size_t)q * kSelThreads + tid, my_max);
+        asm volatile("" ::"v"(seen_before));
+        {
+            uint32_t t = my_valid;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += (uint32_t)__shfl_xor((int)t, off);
+            if ((tid & 63u) == 0 && t) atomicAdd(&s_vw, t);
+        }
+        __syncthreads();
+        vw = s_vw;
+        SEL_MARK(1);
+        if (tid == 0) {
+            atomicAdd(ctr + 0, 1u);
+            // all parts are resident together (S <= 16 workgroups per query, lone callers only): wait for them — but never for ever:
+            // a part that gives up after ~2 ms picks its bound from whatever super-group maxima are in (still a valid bound)
+            const unsigned long long t_end = wall_clock64() + 200000ull;
+            while (__hip_atomic_load(ctr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S && wall_clock64() < t_end) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        SEL_MARK(2);
+        {
+            const uint32_t g = __hip_atomic_load(p.split_sg + (size_t)q * kSelThreads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wk[tid] = g;
+            uint32_t gv = g != kKeyMasked ? 1u : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) gv += (uint32_t)__shfl_xor((int)gv, off);
+            if ((tid & 63u) == 0 && gv) atomicAdd(&s_w[0], gv);
+        }
+        __syncthreads();
+        if (s_w[0] >= k) Tw = radix2([&](uint32_t e) { return wk[e]; }, (uint32_t)kSelThreads, k, hist, &pick);  // (block-uniform)
+        Twm = max(margin_key(Tw, qi), skip);
+        SEL_MARK(3);
+        for (uint32_t b0 = tid & ~63u; b0 < nloc; b0 += kSelThreads) {
+            const uint32_t e = b0 + (tid & 63u);
+            const uint32_t key = e < nloc ? tk[e] : kKeyMasked;
+            const bool pr = key != kKeyMasked && key >= Twm;
+            const uint32_t pos = wave_append(pr, &s_w[1]);
+            if (pr && pos < kCompCap) LT[pos] = ((unsigned long long)key << 32) | (tA + e);
+        }
+        flat = true;
+    }
+    if (S == 1 && p.flat && n_tiles <= kFlatTiles) {
         uint32_t* tk = reinterpret_cast<uint32_t*>(LR);  // [n_tiles] tile maxima of the query (dead before LR is filled)
         if (tid == 0) { s_vw = 0; s_w[0] = 0; s_w[1] = 0; s_w[2] = 0; s_w[3] = 0; }
         __syncthreads();
@@ -515,6 +639,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     // tile-level bound — the k-th largest maximum among the tiles gathered so far (any subset gives a valid lower bound on the
     // k-th best score) — and go.  crowd_alloc turns the query into a crowd (every row >= the bound is re-scored exactly), or,
     // if that is more than an eighth of the shard, leaves it to the f32 retry like any other overflow.
+    if (S > 1 && ((p.crowd_follows && !p.retry && ct > kBailTiles) || ct > kCompCap)) {  // (block-uniform) a part in trouble: the query overflows
+        split_finish(true, Twm);
+        return;
+    }
     if (p.crowd_follows && !p.retry && ct > kBailTiles) {
         const uint32_t have = min(ct, kCompCap);
         uint32_t T2 = Tw;
@@ -544,7 +672,9 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     }
     if (ct <= kCompCap) {
         uint32_t T2 = Tw;
-        if (ct > k && !flat) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);  // (flat: Tw IS the tile-level bound)
+        // (flat / split: Tw IS the tile-level bound — unless no bound could be formed there: fewer than k super-groups hold a tile when
+        //  a bitmap keeps a few runs of rows, an IVF probe's lists; then the tiles of THIS list give one, as on the walk)
+        if (ct > k && (!flat || Tw == kKeyNaN)) T2 = radix2([&](uint32_t e) { return (uint32_t)(LT[e] >> 32); }, ct, k, hist, &pick);
         const uint32_t T2m = max(margin_key(T2, qi), skip);
         Tc = T2m;
         SEL_MARK(5);
@@ -651,6 +781,28 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             if (cr > k && cr > min(kShortRowList, p.cand_cap)) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
             SEL_MARK(7);
             Tc = max(margin_key(T3, qi), skip);  // >= T2m: every row that can matter is in LR
+            if (S > 1) {  // a part: count its candidates, reserve their slice of the query's list, write them there
+                uint32_t mine = 0;
+                for (uint32_t e = tid; e < cr; e += kSelThreads) mine += ((uint32_t)(LR[e] >> 32) >= Tc) ? 1u : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+                if ((tid & 63u) == 0 && mine) atomicAdd(&s_w[3], mine);
+                __syncthreads();
+                if (tid == 0) {
+                    s_w[0] = atomicAdd(p.split_ctr + 4u * q + 1u, s_w[3]);
+                    s_w[3] = 0;
+                }
+                __syncthreads();
+                const uint32_t base = s_w[0];
+                for (uint32_t e = tid; e < cr; e += kSelThreads) {
+                    const unsigned long long ent = LR[e];
+                    const bool pr = (uint32_t)(ent >> 32) >= Tc;
+                    const uint32_t pos = wave_append(pr, &s_w[3]);
+                    if (pr && base + pos < p.cand_cap) out[base + pos] = (uint32_t)(ent & 0xFFFFFFFFull);
+                }
+                split_finish(false, T2m);
+                return;
+            }
             for (uint32_t e = tid; e < cr; e += kSelThreads) {
                 const unsigned long long ent = LR[e];
                 const bool pr = (uint32_t)(ent >> 32) >= Tc;
@@ -684,6 +836,10 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
         }
     }
     if (done) return;
+    if (S > 1) {  // (a row list that overflowed)
+        split_finish(true, Twm);
+        return;
+    }
 
     // ---- generic path (a compact list overflowed) ------------------------------------------------
     __syncthreads();
@@ -802,9 +958,15 @@ hipError_t launch_select(const SelectParams& p, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSelectLds);
     if (e != hipSuccess) return e;
     static const bool no_flat = getenv("NMN_NO_FLAT_SELECT") != nullptr;  // (A/B switch of the flat path)
+    static const bool no_split = getenv("NMN_NO_SPLIT_SELECT") != nullptr;  // (A/B switch of the split selection)
     SelectParams pf = p;
     pf.flat = no_flat ? 0 : 1;
-    hipLaunchKernelGGL(select_kernel, dim3(p.nq), dim3(kSelThreads), kSelectLds, s, pf);
+    // split: lone callers (<= 4 queries: the parts of ALL queries must be resident together, and a batch's selections already run
+    // side by side), k <= 256 (the group bound), 16 385 .. 16 x 16 384 tiles, 16-byte aligned rows of tmax, no extra rank
+    const uint32_t parts = (p.n_tiles + kFlatTiles - 1) / kFlatTiles;
+    pf.split = (!no_flat && !no_split && p.split_sg && p.split_ctr && p.nq <= 4 && p.k <= kFlatGroupK && !p.k_extra && parts >= 2 && parts <= 16 &&
+                (p.tmax_stride & 3ull) == 0ull) ? parts : 0u;
+    hipLaunchKernelGGL(select_kernel, dim3(p.nq * (pf.split ? pf.split : 1u)), dim3(kSelThreads), kSelectLds, s, pf);
     return hipGetLastError();
 }
 

@@ -72,3 +72,37 @@ def test_device_api_last_stats_reports_the_kind_too():
         # the read ceiling of that sweep's own data movement: the ring with nothing behind it
         gbps = idx.read_probe(2)
         assert gbps > 500.0
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_split_selection_on_a_large_shard_matches_oracle(mode):
+    """Lone calls on shards of more than 16 384 tiles select with SEVERAL workgroups per query (round 6, SelectParams::split): each
+    holds a part of the tile maxima, the parts meet once on the super-group maxima and pick the same bound, every part appends its
+    candidates.  1.7M rows x 128 = 26 563 tiles = two parts: one and two queries per call, three metrics, a bitmap, planted
+    near-copies of the query at both ends of the shard and across the parts' border, duplicates (ties by row id across parts)."""
+    from neumann_amd import GpuFlatIndex
+    n, d, k = 1_700_000, 128, 50
+    A = oc.synth(5150, 0, n, d, nthreads=8)
+    Q = oc.synth(5151, 0, 3, d)
+    rng = np.random.default_rng(11)
+    per = ((n // 64 + 1 + 1) // 2 + 3) // 4 * 4 * 64   # rows of the first part (tiles per part rounded up to a multiple of four)
+    with GpuFlatIndex(d, n) as idx:
+        idx.set_mirror(mode)
+        idx.fill_synthetic(5150, n)
+        for j, row in enumerate((0, 63, per - 1, per, per + 64, n - 1, n // 3, n // 3 + 1)):
+            v = (Q[0] * np.float32(1.0 + 0.05 * (j % 3))).astype(np.float32)
+            if j >= 6:
+                v = (Q[0] * np.float32(2.0)).astype(np.float32)      # two identical rows: the tie is broken by the row id
+            else:
+                v[rng.integers(0, d, size=2)] += np.float32(1e-3 * j)
+            idx.set_row(row, v)
+            A[row] = v
+        keep = rng.random(n) < 0.2
+        keep[[0, per - 1, per, n - 1]] = True
+        for metric in (0, 1, 2):
+            for qq, mask in ((Q[:1], None), (Q[:2], None), (Q[:1], oc.mask_from_bool(keep))):
+                rows, scores, counts, st = idx.search(qq, k, metric, mask=mask, with_stats=True)
+                assert st.fallback_queries == 0
+                for i in range(qq.shape[0]):
+                    er, es = oc.search(A, qq[i], k, metric, mask=mask, nthreads=8, partial=True, native=True)
+                    assert counts[i] == er.size and np.array_equal(rows[i, :er.size], er) and np.all(scores[i, :er.size] == es), (mode, metric, i)
