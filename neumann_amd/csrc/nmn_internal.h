@@ -270,7 +270,7 @@ struct SelectParams {
     // its candidates to the query's list; the last part to finish writes the query's state.  0 = one workgroup per query.
     uint32_t split;
     uint32_t* split_sg;        // [nq][1024] keys, zero between launches
-    uint32_t* split_ctr;       // [nq][4]: arrived at the bound | candidates so far | finished | trouble flag; zero between launches
+    uint32_t* split_ctr;       // [nq][4]: [0] parts arrived at the bound, [2..3] one 64-bit word (parts finished << 32 | candidates reserved); zero between launches
 };
 hipError_t launch_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_count_untrusted(const float* norms, uint64_t n_rows, uint32_t* out, hipStream_t s);

@@ -242,26 +242,28 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     // tiles, except that its candidates go behind the other parts' (a slice reserved by one global atomic) and the last part to finish
     // writes the query's state.  Anything unusual in a part — a list that overflows, a crowd to hand over — flags the query
     // `overflow` with the common tile-level threshold: the crowd kernels / the host's follow-up take it from there.
-    // (a part's end: candidates are in; the last part to arrive writes the state and leaves the meeting places zeroed)
-    auto split_finish = [&](bool trouble, uint32_t thr_common) {
-        __shared__ uint32_t s_last;
-        uint32_t* ctr = p.split_ctr + 4u * q;
+    // A part's end, ONE device-scope atomic: split_ctr[q] holds (parts finished << 32 | candidates reserved so far) as one 64-bit word
+    // behind the arrival counter; adding (1 << 32 | mine) reserves this part's slice of the query's candidate list (the old low half
+    // is its start) and tells whether it is the LAST part (the old high half) — which then knows the total, writes the query's state
+    // and zeroes the meeting places (every part has read the super-group maxima before it came here, and touches this word once).
+    // A part in trouble reserves cand_cap + 1 candidates: the total overflows the list, which is what its trouble amounts to.
+    // No fences: the hand-overs are atomics, the candidate rows are for the NEXT kernel (ordered by the kernel boundary).
+    // Returns the start of the part's slice.
+    auto split_reserve_and_finish = [&](uint32_t mine, bool trouble, uint32_t thr_common) -> uint32_t {
+        __shared__ uint32_t s_base, s_last;
         __syncthreads();
         if (tid == 0) {
-            // (the meeting is through device-scope atomics only; the candidate rows the parts wrote are for the NEXT kernel, which the
-            //  kernel boundary orders behind all of them: no fence)
-            uint32_t flagged = 0;
-            if (trouble) flagged = atomicOr(ctr + 3, 1u);
-            asm volatile("" ::"v"(flagged));  // (returned: performed before the arrival is counted)
-            const uint32_t t = atomicAdd(ctr + 2, 1u);
-            s_last = t == S - 1u ? 1u : 0u;
+            unsigned long long* word = reinterpret_cast<unsigned long long*>(p.split_ctr + 4u * q + 2u);
+            const uint32_t add = trouble ? p.cand_cap + 1u : mine;
+            const unsigned long long old = atomicAdd(word, (1ull << 32) | (unsigned long long)add);
+            s_base = (uint32_t)(old & 0xFFFFFFFFull);
+            s_last = (uint32_t)(old >> 32) == S - 1u ? 1u : 0u;
             if (s_last) {
-                const uint32_t total = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t trb = __hip_atomic_load(ctr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t total = s_base + add;
                 QState st;
                 st.n_valid = vw;
                 st.thr_key = thr_common;
-                st.overflow = (trb || total > p.cand_cap) ? 1u : 0u;
+                st.overflow = total > p.cand_cap ? 1u : 0u;
                 st.cand_count = st.overflow ? 0u : total;
                 p.qstate[q] = st;
                 if (p.count_overflows && p.half_stats && st.overflow) atomicAdd(p.half_stats + 1, 1u);
@@ -269,18 +271,20 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
                     const float tau = key_to_score(thr_common);
                     *p.l2_hint = (tau > 0.0f && tau <= 1.0f) ? 1.0f / tau - 1.0f : 0.0f;
                 }
-                ctr[0] = 0u; ctr[1] = 0u; ctr[2] = 0u; ctr[3] = 0u;
+                p.split_ctr[4u * q + 0u] = 0u;
+                *word = 0ull;
 #ifdef NMN_SELECT_TRACE
                 if (q == 0) {
                     const unsigned long long t_now = wall_clock64();
-                    printf("select (split, last of %u parts: part %u) cand=%u trouble=%u | ticks: load %llu meet %llu pick %llu compaction %llu rest %llu total %llu\n", S, part,
-                           total, trb, sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], t_now - sel_t[4], t_now - sel_t[0]);
+                    printf("select (split, last of %u parts: part %u) cand=%u | ticks: load %llu meet %llu pick %llu compaction %llu rest %llu total %llu\n", S, part,
+                           total, sel_t[1] - sel_t[0], sel_t[2] - sel_t[1], sel_t[3] - sel_t[2], sel_t[4] - sel_t[3], t_now - sel_t[4], t_now - sel_t[0]);
                 }
 #endif
             }
         }
         __syncthreads();
-        if (s_last) p.split_sg[(size_t)q * kSelThreads + tid] = kKeyMasked;  // (every part has long read them)
+        if (s_last) p.split_sg[(size_t)q * kSelThreads + tid] = kKeyMasked;
+        return s_base;
     };
     if (S > 1) {
         uint32_t* tk = reinterpret_cast<uint32_t*>(LR);
@@ -640,7 +644,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     // k-th best score) — and go.  crowd_alloc turns the query into a crowd (every row >= the bound is re-scored exactly), or,
     // if that is more than an eighth of the shard, leaves it to the f32 retry like any other overflow.
     if (S > 1 && ((p.crowd_follows && !p.retry && ct > kBailTiles) || ct > kCompCap)) {  // (block-uniform) a part in trouble: the query overflows
-        split_finish(true, Twm);
+        (void)split_reserve_and_finish(0u, true, Twm);
         return;
     }
     if (p.crowd_follows && !p.retry && ct > kBailTiles) {
@@ -781,26 +785,23 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
             if (cr > k && cr > min(kShortRowList, p.cand_cap)) T3 = radix2([&](uint32_t e) { return (uint32_t)(LR[e] >> 32); }, cr, k, hist, &pick);
             SEL_MARK(7);
             Tc = max(margin_key(T3, qi), skip);  // >= T2m: every row that can matter is in LR
-            if (S > 1) {  // a part: count its candidates, reserve their slice of the query's list, write them there
+            if (S > 1) {  // a part: count its candidates, reserve their slice of the query's list (and finish: one atomic), write them there
                 uint32_t mine = 0;
                 for (uint32_t e = tid; e < cr; e += kSelThreads) mine += ((uint32_t)(LR[e] >> 32) >= Tc) ? 1u : 0u;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
                 if ((tid & 63u) == 0 && mine) atomicAdd(&s_w[3], mine);
                 __syncthreads();
-                if (tid == 0) {
-                    s_w[0] = atomicAdd(p.split_ctr + 4u * q + 1u, s_w[3]);
-                    s_w[3] = 0;
-                }
+                const uint32_t c_local = s_w[3];
+                const uint32_t base = split_reserve_and_finish(c_local, false, T2m);  // (barriers inside: s_w[3] may be reused below)
+                if (tid == 0) s_w[3] = 0;
                 __syncthreads();
-                const uint32_t base = s_w[0];
                 for (uint32_t e = tid; e < cr; e += kSelThreads) {
                     const unsigned long long ent = LR[e];
                     const bool pr = (uint32_t)(ent >> 32) >= Tc;
                     const uint32_t pos = wave_append(pr, &s_w[3]);
                     if (pr && base + pos < p.cand_cap) out[base + pos] = (uint32_t)(ent & 0xFFFFFFFFull);
                 }
-                split_finish(false, T2m);
                 return;
             }
             for (uint32_t e = tid; e < cr; e += kSelThreads) {
@@ -837,7 +838,7 @@ __global__ void __launch_bounds__(kSelThreads) select_kernel(SelectParams p) {
     }
     if (done) return;
     if (S > 1) {  // (a row list that overflowed)
-        split_finish(true, Twm);
+        (void)split_reserve_and_finish(0u, true, Twm);
         return;
     }
 
