@@ -1119,7 +1119,12 @@ static nmn_status search_enqueue(nmn_index* idx, Workspace* w, const float* quer
         // Where it pays (profiles/r06p_*): cosine, k <= 128 — 10M x 768: 64 queries 1.53 -> 1.38-1.48 ms, 128 queries 2.29 -> 1.80; the
         // candidate lists grow (~900 -> ~4 000 rows for the worst query of a batch at 10M rows), which k = 1000 (1.75 -> 1.90 ms) and the
         // dot product's absolute margin (5M x 1536: 1.38 -> 1.51) do not repay.
-        const bool one_plane = use_i8 && use_mfma && !two_planes && metric == NMN_METRIC_COSINE && k <= 128u &&
+        // ... nor does a 64-query batch of a PIPELINED caller: with two batches in flight on two streams the longer candidate lists
+        // (~590 MB of exact re-scoring reads per batch instead of ~170) run under the next batch's sweep and cost it what the sweep
+        // gained (bench.py's c3_i8_*: 39.1 k -> 37.7 k q/s; 128-query passes still gain 11 %: profiles/r06t_*).  "Pipelined" = the shard's
+        // previous large sweep was enqueued on another stream (the sweep chain's own bookkeeping).
+        const bool pipelined = idx->sweep_seq != 0 && idx->sweep_stream != stream;
+        const bool one_plane = use_i8 && use_mfma && !two_planes && metric == NMN_METRIC_COSINE && k <= 128u && (nqc > 64u || !pipelined) &&
                                scan_mfma_i8_one_plane_supported((int)metric) && idx->q8_calls >= idx->one_plane_off_until;
         if (one_plane) idx->one_plane_recent = true;
         const bool f32_retry = (use_half || use_i8) && !use_mfma && n_rows >= (1u << 18) && !short_chain;
