@@ -1,6 +1,8 @@
 """Batched queries (config 3): the MFMA sweep (>= 3-5 queries, dim % 128 == 0; cosine / dot directly, Euclidean as
 |q|^2 + |v|^2 - 2 q.v) and the VALU multi-sweep path must both return exactly the oracle's rows and scores for
 every query."""
+import os
+
 import numpy as np
 import pytest
 
@@ -264,7 +266,8 @@ def test_one_launch_sweep_with_the_running_bound_matches_oracle(d, metric):
             idx.set_mirror(mode)
             rows, scores, counts, st = idx.search(Q, k, metric, with_stats=True)
             assert st.bytes_scanned == n * d * nbytes and st.sweep.startswith("mfma_"), (mode, st.sweep, st.bytes_scanned)
-            assert st.sweep_launches == 1, (mode, st.sweep_launches)
+            if not os.environ.get("NMN_NO_RUN_BOUND"):  # (the A/B switch brings the sampling pass and its launches back)
+                assert st.sweep_launches == 1, (mode, st.sweep_launches)
             assert st.fallback_queries == 0
             for i in range(nq):
                 er, es = want[i]
