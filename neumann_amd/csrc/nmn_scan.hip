@@ -439,12 +439,24 @@ static hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     const size_t lds = (size_t)NQ * p.ld * sizeof(float) + (MASKED ? 4 * NQ * 64 * sizeof(float) + 4 * 64 * sizeof(uint32_t) +  // + rank tables
                                                                        (NQ <= 2 ? 4 * kWalkRows * sizeof(uint16_t) + 4 * NQ * kWalkRows * sizeof(uint32_t) : 0) : 0);  // + the walk's list and parked scores
     auto kern = scan_kernel<METRIC, MASKED, NQ, CH, FULL, NT, HALF>;
-    if (lds > 48 * 1024) {
+    // Masked strided sweeps hold TWO workgroups per CU, not the four their registers allow (round 6): the LDS request is raised to 57 KiB (more than a third of a CU's),
+    // which is how a launch says so.  With four, all 1024 workgroups are resident from the start — 48 MB of row loads in flight, three
+    // times what the memory system needs — and nothing is left of the CUs for the OTHER stream's selection / rescore tail; with two, the
+    // second half of the workgroups goes wherever a CU frees up first.  10M x 1536 Euclidean TOP-1000 over the f32 rows, bench.py's
+    // pipelined loop, three rounds in one call: selectivity 0.5 206.1 -> 208.5 q/s, 0.1 957 -> 974, 0.02 3 592 -> 3 856 (+7 %: the tail
+    // no longer waits for the sweep to end), 0.25 +1.9 %, 0.004 -2.3 % (3 us); three per CU loses at 0.1, one per CU at 0.02
+    // (profiles/r06ap_*).  The f32 rows only: the bf16 mirror's shorter sweeps gain 4 % at 0.5 and lose 3-4 % at 0.1 / 0.02, the 8-bit
+    // mirror's +2 % / -3 % (nmn_scan_i8.hip keeps the knob, off).  NMN_SCAN_WGS_PER_CU=0: the A/B.
+    static const int wgs_per_cu = [] { const char* e = getenv("NMN_SCAN_WGS_PER_CU"); return e ? atoi(e) : 2; }();
+    size_t lds_total = lds;
+    if (MASKED && !HALF && p.strided && wgs_per_cu > 0 && grid.x > 256u * (unsigned)wgs_per_cu)
+        lds_total = std::max<size_t>(lds, ((size_t)160 * 1024 / (size_t)(wgs_per_cu + 1) + 4096) & ~(size_t)1023);  // more than a (n+1)-th of the CU's LDS: n fit
+    if (lds_total > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_total, s, p);
     return hipGetLastError();
 }
 
