@@ -750,7 +750,7 @@ hipError_t launch_one(const ScanParams& p, hipStream_t s) {
     // (workgroups resident per CU, by way of the LDS request — nmn_scan.hip's launch_one has the story; here a knob only)
     static const int wgs_per_cu = [] { const char* e = getenv("NMN_SCAN_I8_WGS_PER_CU"); return e ? atoi(e) : 0; }();
     size_t lds_total = lds;
-    if (MASKED && p.strided && wgs_per_cu > 0 && grid.x > 256u * (unsigned)wgs_per_cu)
+    if (wgs_per_cu > 0 && grid.x > 256u * (unsigned)wgs_per_cu)  // (masked or not)
         lds_total = std::max<size_t>(lds, ((size_t)160 * 1024 / (size_t)(wgs_per_cu + 1) + 4096) & ~(size_t)1023);
     if (lds_total > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
